@@ -1,0 +1,261 @@
+/*
+ * yolov6_hip.h — C ABI of libyolov6_hip.so, the MI355X (gfx950) hot path behind the
+ * YOLOv6 Python module API.
+ *
+ * The reference (meituan/YOLOv6) has no FFI of its own: its hot path is a composition of
+ * aten ops called from Python modules.  Every entry point below therefore names the
+ * reference Python interface it replaces (file:line relative to the reference tree), and
+ * `INTEGRATION.md` shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HBM) unless the parameter name ends in `_host`.
+ *   - Activations are NHWC fp16 ("channels-last"): element (b,y,x,c) of a tensor view lives
+ *     at  base[((b*H + y)*W + x) * cstride + coff + c].  `cstride`/`coff` let a producer
+ *     write straight into a channel slice of a consumer's buffer (concat-free necks,
+ *     reference: torch.cat at yolov6/models/reppan.py:228,232, yolov6/layers/common.py:718).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Nothing here
+ *     synchronises the device unless documented.
+ *   - Return value: 0 on success, negative Y6_E* code on failure; y6_last_error() returns a
+ *     thread-local human-readable message.  The Python host raises RuntimeError from it
+ *     (the reference's assigner fallback catches exactly RuntimeError, models/losses/loss.py:105).
+ */
+#ifndef YOLOV6_HIP_H
+#define YOLOV6_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y6_ABI_VERSION 1
+
+enum { Y6_OK = 0, Y6_EINVAL = -1, Y6_EHIP = -2, Y6_EUNSUPPORTED = -3, Y6_ENOMEM = -4 };
+
+/* activation_table of yolov6/layers/common.py:14-17 (+ None) */
+enum { Y6_ACT_NONE = 0, Y6_ACT_RELU = 1, Y6_ACT_SILU = 2, Y6_ACT_HARDSWISH = 3 };
+
+/* dtype tags for boundary tensors */
+enum { Y6_F16 = 0, Y6_F32 = 1 };
+
+int y6_abi_version(void);
+const char* y6_last_error(void);
+/* number of CUs / arch name of the current device ("gfx950"); fails if no HIP device */
+int y6_device_info(int* n_cu, char* arch, size_t arch_len);
+
+/* ------------------------------------------------------------------------------------ */
+/* A view of an NHWC fp16 activation tensor inside a (possibly wider) channel buffer.    */
+typedef struct y6_tensor {
+    void* data;      /* fp16 */
+    int32_t B, H, W, C;
+    int32_t cstride; /* channels of the underlying buffer (>= coff + C) */
+    int32_t coff;    /* first channel of this view */
+} y6_tensor;
+
+/* ------------------------------------------------------------------------------------ */
+/* Weight packing.
+ * Replaces nothing at run time: it is the derived cache SURVEY §8b allows next to the
+ * reference's OIHW parameters (`rbr_reparam.weight`, `block.conv.weight`, ...).
+ *
+ * src      : OIHW weights [Cout][Cin][K][K], fp16 or fp32 (src_dtype)
+ * dst      : packed fp16, y6_packed_weight_elems(Cout,Cin,K) elements, layout
+ *            [cout/32][cin/32][tap][kstep=2][lane=64][8]  (MFMA 32x32x16 A-fragment order),
+ *            zero padded to 32-multiples of Cout and Cin.
+ * For ConvTranspose2d(k=2,s=2) (common.py:181-194) use y6_pack_convt2x2_weight: src is
+ * IOHW [Cin][Cout][2][2]; dst holds 4 packed 1x1 weights (one per (dy,dx)), each of
+ * y6_packed_weight_elems(Cout,Cin,1) elements.                                            */
+size_t y6_packed_weight_elems(int Cout, int Cin, int K);
+int y6_pack_conv_weight(const void* src, int src_dtype, int Cout, int Cin, int K, void* dst, void* stream);
+int y6_pack_convt2x2_weight(const void* src, int src_dtype, int Cin, int Cout, void* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Fused conv + bias (+ post affine) + activation (+ residual), NHWC fp16, fp32 accumulate.
+ * Replaces: ConvModule.forward_fuse  yolov6/layers/common.py:51-54
+ *           RepVGGBlock.forward (deploy branch)  common.py:247-248
+ *           QARepVGGBlock.forward (deploy, post-BN kept)  common.py:338-339
+ *           BottleRep.forward residual  common.py:605-608  (res, res_alpha)
+ *           nn.Conv2d 1x1 prediction convs  yolov6/models/effidehead.py:169-179
+ * groups == 1, dilation == 1, padding == ksize/2 (the only forms the hot path uses).     */
+typedef struct y6_conv_desc {
+    y6_tensor in, out;
+    const void* w_packed;      /* from y6_pack_conv_weight                                */
+    const void* w_oihw;        /* optional: original OIHW fp16 weights (used by the naive  */
+                               /* cross-check variant only)                               */
+    const float* bias;         /* [Cout] or NULL                                          */
+    const float* post_scale;   /* [Cout] or NULL : y = y*scale + shift before activation  */
+    const float* post_shift;
+    y6_tensor res;             /* optional residual (data==NULL: none): out += alpha*res   */
+    const float* res_alpha;    /* device scalar or NULL (=> 1.0)                           */
+    int32_t ksize;             /* 1 or 3 */
+    int32_t stride;            /* 1 or 2 */
+    int32_t act;               /* Y6_ACT_*  */
+    int32_t variant;           /* -1 auto; >=0 force kernel variant (see y6_conv_variants) */
+} y6_conv_desc;
+
+int y6_conv2d(const y6_conv_desc* d, void* stream);
+/* number of kernel variants / name of variant i ("mfma_c2p2", "naive", ...) */
+int y6_conv_variants(void);
+const char* y6_conv_variant_name(int i);
+/* 1 if variant i can run desc d */
+int y6_conv_variant_supports(const y6_conv_desc* d, int i);
+
+/* ConvTranspose2d(k=2, s=2, bias) : out[b,2y+dy,2x+dx,:] = bias + in[b,y,x,:] @ W[:,:,dy,dx]
+ * Replaces: Transpose.forward  yolov6/layers/common.py:193-194                           */
+typedef struct y6_convt_desc {
+    y6_tensor in, out;         /* out.H == 2*in.H, out.W == 2*in.W                        */
+    const void* w_packed;      /* from y6_pack_convt2x2_weight                            */
+    const float* bias;
+} y6_convt_desc;
+int y6_convt2x2(const y6_convt_desc* d, void* stream);
+
+/* Stem: 3x3 stride-2 pad-1 conv reading the caller's NCHW image directly (Cin <= 4) and
+ * writing NHWC fp16, + bias + activation (+ optional post affine).
+ * Replaces: EfficientRep.stem (RepVGGBlock deploy form)  yolov6/models/efficientrep.py:28-33
+ * in_nchw: [B][Cin][H][W] fp16 or fp32 (in_dtype); w: OIHW fp32 [Cout][Cin][3][3].         */
+typedef struct y6_stem_desc {
+    const void* in_nchw;
+    int32_t in_dtype;
+    int32_t B, Cin, H, W;
+    y6_tensor out;
+    const float* w_oihw_f32;
+    const float* bias;
+    const float* post_scale;
+    const float* post_shift;
+    int32_t act;
+} y6_stem_desc;
+int y6_stem_conv(const y6_stem_desc* d, void* stream);
+
+/* Three chained MaxPool2d(5, stride 1, pad 2) (-inf padding) of `x`, written to y1,y2,y3.
+ * Replaces: SPPFModule.forward  common.py:106-112 ; CSPSPPFModule.forward  :150-158
+ * x,y1,y2,y3 are usually the four channel slices of one 4*C buffer (no torch.cat).        */
+int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3, void* stream);
+
+/* Layout adapters at the module boundary (reference tensors are NCHW). */
+int y6_nchw_to_nhwc(const void* src_nchw, int src_dtype, const y6_tensor* dst, void* stream);
+int y6_nhwc_to_nchw(const y6_tensor* src, void* dst_nchw, int dst_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Head epilogue: sigmoid(cls), optional DFL (softmax over reg_max+1 bins . proj),
+ * dist2bbox('xywh') * stride, concat -> out[B, A, 5+nc] fp32 (box4, 1.0, cls).
+ * Replaces: Detect.forward eval branch  yolov6/models/effidehead.py:93-139,
+ *           generate_anchors(is_eval=True)  yolov6/assigners/anchor_generator.py:13-33,
+ *           dist2bbox  yolov6/utils/general.py:32-43.
+ * Level l: cls[l] view [B,Hl,Wl,nc] logits, reg[l] view [B,Hl,Wl,4*(reg_max+1)] (ltrb bins
+ * in the reference's channel order: side-major, bin-minor).                               */
+#define Y6_MAX_LEVELS 4
+typedef struct y6_decode_desc {
+    int32_t n_levels;
+    y6_tensor cls[Y6_MAX_LEVELS];
+    y6_tensor reg[Y6_MAX_LEVELS];
+    float stride[Y6_MAX_LEVELS];
+    int32_t use_dfl;           /* 0/1 */
+    int32_t reg_max;           /* 0 or 16 */
+    const float* proj;         /* [reg_max+1] (Detect.proj) when use_dfl */
+    float grid_cell_offset;    /* 0.5 */
+    float* out;                /* [B, A, 5+nc] fp32 */
+    int32_t nc;
+} y6_decode_desc;
+int y6_head_decode(const y6_decode_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Batched NMS.  Replaces: non_max_suppression  yolov6/utils/nms.py:31-105 including the
+ * torchvision.ops.nms call at :96 (greedy, IoU > thr strict, fp32, boxes offset by
+ * cls*4096 unless agnostic, stable descending score order).
+ * pred        : [B, A, 5+nc] fp32 (xywh, obj, cls...)
+ * classes     : optional device int32 list of n_classes kept classes (NULL: all)
+ * out_dets    : [B, max_det, 6] fp32 (x1,y1,x2,y2,conf,cls)
+ * out_index   : [B, max_det] int32, flat candidate id = anchor*nc + cls (parity checks)
+ * out_count   : [B] int32 detections per image
+ * workspace   : y6_nms_workspace_bytes(B,A,nc,multi_label) bytes of scratch
+ * The reference's 10 s wall-clock break (nms.py:56,101-103) has no device analogue and is
+ * not reproduced (documented deviation).                                                  */
+typedef struct y6_nms_desc {
+    const float* pred;
+    int32_t B, A, nc;
+    float conf_thres, iou_thres;
+    const int32_t* classes;
+    int32_t n_classes;
+    int32_t agnostic, multi_label;
+    int32_t max_det;
+    int32_t max_nms;           /* 30000 in the reference */
+    float max_wh;              /* 4096 in the reference */
+    float* out_dets;
+    int32_t* out_index;
+    int32_t* out_count;
+    void* workspace;
+    size_t workspace_bytes;
+} y6_nms_desc;
+size_t y6_nms_workspace_bytes(int B, int A, int nc, int multi_label);
+int y6_nms(const y6_nms_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Task-aligned assigner.  Replaces: TaskAlignedAssigner.forward
+ * yolov6/assigners/tal_assigner.py:22-106 (+ get_pos_mask :108-123, get_box_metrics
+ * :125-141, select_topk_candidates :143-158, get_targets :160-181) and
+ * select_candidates_in_gts / select_highest_overlaps / iou_calculator
+ * yolov6/assigners/assigner_utils.py:25-89.  No [B,G,topk,A] one-hot temp is built.
+ * pd_scores [B,A,C] f32, pd_bboxes [B,A,4] f32 xyxy, anc_points [A,2] f32,
+ * gt_labels [B,G] f32 (class id as float, as the reference passes it), gt_bboxes [B,G,4],
+ * mask_gt [B,G] f32 (0/1).
+ * outputs: target_labels [B,A] int64, target_bboxes [B,A,4] f32, target_scores [B,A,C] f32,
+ * fg_mask [B,A] uint8 (bool).                                                             */
+typedef struct y6_tal_desc {
+    const float* pd_scores;
+    const float* pd_bboxes;
+    const float* anc_points;
+    const float* gt_labels;
+    const float* gt_bboxes;
+    const float* mask_gt;
+    int32_t B, A, C, G;
+    int32_t topk;
+    float alpha, beta, eps;
+    int64_t* target_labels;
+    float* target_bboxes;
+    float* target_scores;
+    uint8_t* fg_mask;
+    void* workspace;
+    size_t workspace_bytes;
+} y6_tal_desc;
+size_t y6_tal_workspace_bytes(int B, int A, int G);
+int y6_tal_assign(const y6_tal_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
+/* Execution plan: an ordered list of the ops above with fixed pointers, replayed with one
+ * call per forward (optionally from a captured hipGraph).  This is the native executor
+ * behind Model.forward  yolov6/models/yolo.py:33-41.                                      */
+typedef struct y6_plan y6_plan;
+enum { Y6_OP_CONV = 1, Y6_OP_CONVT = 2, Y6_OP_STEM = 3, Y6_OP_SPPF = 4, Y6_OP_DECODE = 5,
+       Y6_OP_NCHW2NHWC = 6, Y6_OP_NHWC2NCHW = 7 };
+
+y6_plan* y6_plan_create(void);
+void y6_plan_destroy(y6_plan* p);
+int y6_plan_add_conv(y6_plan* p, const y6_conv_desc* d);
+int y6_plan_add_convt(y6_plan* p, const y6_convt_desc* d);
+int y6_plan_add_stem(y6_plan* p, const y6_stem_desc* d);
+int y6_plan_add_sppf(y6_plan* p, const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3);
+int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);
+int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
+int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);
+int y6_plan_num_ops(const y6_plan* p);
+/* Time every supported conv variant of every conv op (hipEvents on `stream`, `iters` timed
+ * launches each) and pin the fastest.  Synchronises the stream. */
+int y6_plan_autotune(y6_plan* p, void* stream, int iters);
+/* Re-point every op that reads the caller's NCHW boundary tensor at `old_ptr` to `new_ptr`
+ * (same shape/dtype). Returns the number of fields changed (>=0) or a negative error.
+ * Invalidates a captured graph. */
+int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_ptr);
+/* Launch all ops in order on `stream` (no sync). */
+int y6_plan_run(y6_plan* p, void* stream);
+/* Capture the op list into a hipGraph once; later y6_plan_run replays the graph. */
+int y6_plan_capture(y6_plan* p, void* stream);
+/* Per-op profile: runs the plan op by op with hipEvents, `iters` times; fills ms[i] (average
+ * milliseconds of op i), kind[i], variant[i] and flops[i]/bytes[i] (algorithmic) for up to
+ * `cap` ops.  Returns the number of ops. Synchronises. */
+int y6_plan_profile(y6_plan* p, void* stream, int iters, float* ms, int32_t* kind, int32_t* variant,
+                    double* flops, double* bytes, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV6_HIP_H */

@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (read-only, from
+/root/reference) on CPU.  Run in the build container only - the GPU box has no reference:
+
+    python tests/golden/gen_golden.py
+
+What is pinned
+  model_<name>.npz  reference Model (yolov6/models/yolo.py) built from the reference's own
+                    configs/*.py, weights from oracle/synth.py, eval forward in train form and
+                    after fuse_model + switch_to_deploy (detections + neck feature maps)
+  keys_<name>.json  the reference state_dict keys/shapes (train form and deploy form)
+  nms_<case>.npz    reference yolov6/utils/nms.py::non_max_suppression.  torchvision is absent,
+                    so `torchvision.ops.nms` is served by oracle/nms_oracle.py::nms - the
+                    candidate / multi-label / class-offset / max_det logic around it is the
+                    reference's own code (PARITY UNPINNED for the torchvision call itself).
+  tal_<case>.npz    reference yolov6/assigners/tal_assigner.py::TaskAlignedAssigner on CPU
+Inputs are regenerated from seeds by oracle/synth.py, so only outputs are stored.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from oracle import nms_oracle, synth  # noqa: E402
+from yolov6_amd.configs import load_config  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def install_stubs():
+    """cv2 / torchvision are not installed; the reference imports them at module top (nms.py:9-11)."""
+    cv2 = types.ModuleType("cv2")
+    cv2.setNumThreads = lambda n: None
+    sys.modules.setdefault("cv2", cv2)
+    tv = types.ModuleType("torchvision")
+    ops = types.ModuleType("torchvision.ops")
+
+    def nms(boxes, scores, iou_threshold):
+        keep = nms_oracle.nms(boxes.detach().cpu().numpy(), scores.detach().cpu().numpy(), float(iou_threshold))
+        return torch.from_numpy(keep).to(boxes.device)
+
+    ops.nms = nms
+    tv.ops = ops
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.ops", ops)
+
+
+MODEL_CASES = {
+    # name: (reference config file, overrides, image size, batch, num_classes)
+    "tiny": ("configs/yolov6s.py", dict(width_multiple=0.125, depth_multiple=0.17), 64, 2, 80),
+    "n": ("configs/yolov6n.py", {}, 64, 1, 80),
+    "s": ("configs/yolov6s.py", {}, 64, 2, 80),
+    "s_qa_tiny": ("configs/qarepvgg/yolov6s_qa.py", dict(width_multiple=0.125, depth_multiple=0.17), 64, 2, 80),
+    "l6_tiny": ("configs/yolov6l6.py", dict(width_multiple=0.125, depth_multiple=0.34), 128, 1, 80),
+    "m_tiny": ("configs/yolov6m.py", dict(width_multiple=0.125, depth_multiple=0.34), 64, 1, 20),
+}
+
+
+def ref_config(path, overrides):
+    cfg = load_config(os.path.join(REF, path))
+    for k, v in overrides.items():
+        cfg.model[k] = v
+    return cfg
+
+
+def gen_models():
+    from yolov6.layers.common import RepVGGBlock
+    from yolov6.models.yolo import Model
+    from yolov6.utils.torch_utils import fuse_model
+
+    for name, (cfile, over, size, batch, nc) in MODEL_CASES.items():
+        cfg = ref_config(cfile, over)
+        torch.manual_seed(0)
+        model = Model(cfg, channels=3, num_classes=nc).eval()
+        sd = synth.synth_state_dict(model.state_dict(), seed=0)
+        model.load_state_dict(sd)
+        model.detect.proj_conv.weight.data = model.detect.proj.view(1, -1, 1, 1).clone()
+        x = synth.synth_images(batch, size, seed=1)
+        keys_train = {k: list(v.shape) for k, v in model.state_dict().items()}
+        with torch.no_grad():
+            det_train, feats_train = model(x)
+            fuse_model(model)
+            for m in model.modules():
+                if isinstance(m, RepVGGBlock):
+                    m.switch_to_deploy()
+            det_dep, feats_dep = model(x)
+        keys_dep = {k: list(v.shape) for k, v in model.state_dict().items()}
+        out = dict(det_train=det_train.numpy(), det_deploy=det_dep.numpy())
+        for i, f in enumerate(feats_dep):
+            out[f"feat{i}"] = f.numpy()
+        np.savez_compressed(os.path.join(HERE, f"model_{name}.npz"), **out)
+        with open(os.path.join(HERE, f"keys_{name}.json"), "w") as f:
+            json.dump(dict(config=cfile, overrides=over, size=size, batch=batch, num_classes=nc,
+                           training_mode=cfg.training_mode, train=keys_train, deploy=keys_dep), f)
+        d = float((det_train - det_dep).abs().max())
+        print(f"model_{name}: det {tuple(det_dep.shape)} train-vs-deploy max diff {d:.3e} "
+              f"params {sum(p.numel() for p in model.parameters()) / 1e6:.3f}M keys {len(keys_train)}/{len(keys_dep)}")
+
+
+NMS_CASES = {
+    # name: (B, A, nc, seed, frac, kwargs)
+    "eval_multilabel": (3, 600, 20, 0, 0.03, dict(conf_thres=0.03, iou_thres=0.65, multi_label=True, max_det=300)),
+    "infer_single": (2, 900, 80, 1, 0.01, dict(conf_thres=0.4, iou_thres=0.45, max_det=1000)),
+    "agnostic_classes": (2, 500, 20, 2, 0.05, dict(conf_thres=0.25, iou_thres=0.5, agnostic=True, classes=[1, 3, 7],
+                                                   multi_label=True, max_det=50)),
+    "max_det_cut": (1, 2000, 10, 3, 0.2, dict(conf_thres=0.03, iou_thres=0.9, multi_label=True, max_det=20)),
+    "over_max_nms": (1, 8400, 80, 4, 0.06, dict(conf_thres=0.03, iou_thres=0.65, multi_label=True, max_det=300)),
+    "empty": (2, 300, 20, 5, 0.0, dict(conf_thres=0.5, iou_thres=0.45)),
+}
+
+
+def gen_nms():
+    from yolov6.utils.nms import non_max_suppression
+    for name, (B, A, nc, seed, frac, kw) in NMS_CASES.items():
+        pred = synth.synth_predictions(B, A, nc, seed=seed, frac=frac)
+        with torch.no_grad():
+            res = non_max_suppression(pred.clone(), **kw)
+        counts = np.array([r.shape[0] for r in res], np.int32)
+        dets = np.concatenate([r.numpy().reshape(-1, 6) for r in res], 0).astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, f"nms_{name}.npz"), counts=counts, dets=dets,
+                            meta=json.dumps(dict(B=B, A=A, nc=nc, seed=seed, frac=frac, kwargs=kw)))
+        print(f"nms_{name}: counts {counts.tolist()}")
+
+
+TAL_CASES = {
+    # name: (B, feat sizes, strides, C, G, n_valid, seed, topk)
+    "basic": (2, [(20, 20), (10, 10), (5, 5)], [8, 16, 32], 20, 6, None, 0, 13),
+    "padded": (3, [(20, 20), (10, 10), (5, 5)], [8, 16, 32], 20, 8, [8, 3, 0], 1, 13),
+    "many_gt": (2, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 10, 101, None, 2, 13),   # per-image path (:55)
+    "topk26": (1, [(20, 20), (10, 10), (5, 5)], [8, 16, 32], 80, 5, None, 3, 26),
+    "empty": (2, [(8, 8), (4, 4), (2, 2)], [8, 16, 32], 20, 0, None, 4, 13),
+}
+
+
+def gen_tal():
+    from yolov6.assigners.tal_assigner import TaskAlignedAssigner
+    for name, (B, fs, st, C, G, nv, seed, topk) in TAL_CASES.items():
+        inp = synth.synth_tal_inputs(B, fs, st, C, G, seed=seed, n_valid=nv)
+        assigner = TaskAlignedAssigner(topk=topk, num_classes=C, alpha=1.0, beta=6.0)
+        with torch.no_grad():
+            tl, tb, ts, fg = assigner(inp["pd_scores"], inp["pd_bboxes"], inp["anc_points"], inp["gt_labels"],
+                                      inp["gt_bboxes"], inp["mask_gt"])
+        ts = ts.numpy().astype(np.float32)
+        nz = np.nonzero(ts)
+        np.savez_compressed(os.path.join(HERE, f"tal_{name}.npz"), labels=tl.numpy().astype(np.int64),
+                            bboxes=tb.numpy().astype(np.float32), fg=fg.numpy().astype(bool),
+                            score_idx=np.stack(nz, 1).astype(np.int32), score_val=ts[nz],
+                            meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, G=G, n_valid=nv, seed=seed,
+                                                 topk=topk)))
+        print(f"tal_{name}: fg {int(fg.sum())} nonzero scores {len(nz[0])}")
+
+
+if __name__ == "__main__":
+    install_stubs()
+    which = sys.argv[1:] or ["models", "nms", "tal"]
+    if "models" in which:
+        gen_models()
+    if "nms" in which:
+        gen_nms()
+    if "tal" in which:
+        gen_tal()

@@ -1,0 +1,162 @@
+"""CPU: host logic of the product package - module/state_dict ABI, re-parameterisation
+math, config loading, C-ABI symbol table, and the no-fallback contract."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle.model_oracle import deploy_state_dict
+from tests.helpers import case_config, case_meta
+from yolov6_amd import _lib
+from yolov6_amd.configs import Config, get_config, load_config
+from yolov6_amd.layers import common
+from yolov6_amd.models.yolo import Model, build_model
+from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+
+CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_state_dict_abi_matches_reference(case):
+    """Same keys and shapes as the reference Model, in train form and after the deploy transform."""
+    cfg, meta = case_config(case)
+    m = Model(cfg, 3, meta["num_classes"]).eval()
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["train"]
+    assert list(m.state_dict().keys()) == list(meta["train"].keys())      # registration order too
+    switch_to_deploy(fuse_model(m))
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta["deploy"]
+
+
+@pytest.mark.parametrize("case", ["tiny", "s_qa_tiny", "m_tiny"])
+def test_reparam_matches_oracle(case):
+    """fuse_model + switch_to_deploy of the product modules == the oracle's state_dict transform."""
+    cfg, meta = case_config(case)
+    m = Model(cfg, 3, meta["num_classes"]).eval()
+    sd = synth.synth_state_dict(m.state_dict(), 0)
+    m.load_state_dict(sd)
+    # plan-time (implicit) re-parameterisation of the un-fused block
+    exp = deploy_state_dict(cfg, sd, meta["num_classes"])
+    for name, mod in m.named_modules():
+        if isinstance(mod, common.RepVGGBlock):
+            w, b = mod._deploy_weight_bias()
+            torch.testing.assert_close(w, exp[name + ".rbr_reparam.weight"], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(b, exp[name + ".rbr_reparam.bias"], rtol=1e-5, atol=1e-6)
+    switch_to_deploy(fuse_model(m))
+    got = m.state_dict()
+    for k, v in exp.items():
+        torch.testing.assert_close(got[k].float(), v.float(), rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_builtin_configs_equal_reference_files():
+    """When the reference tree is present (build container), the built-in dicts equal configs/*.py."""
+    ref = "/root/reference/configs"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    pairs = {"yolov6n": "yolov6n.py", "yolov6s": "yolov6s.py", "yolov6m": "yolov6m.py", "yolov6l": "yolov6l.py",
+             "yolov6l6": "yolov6l6.py", "yolov6s_qa": "qarepvgg/yolov6s_qa.py"}
+    for name, f in pairs.items():
+        a, b = get_config(name), load_config(os.path.join(ref, f))
+        assert a.training_mode == b.training_mode, name
+        for part in ("backbone", "neck"):
+            for k, v in b.model[part].items():
+                assert a.model[part].get(k) == v or (not a.model[part].get(k) and not v), (name, part, k)
+        for k in ("num_layers", "use_dfl", "reg_max", "strides", "atss_warmup_epoch", "iou_type"):
+            assert a.model.head[k] == b.model.head[k], (name, k)
+        assert (a.model.depth_multiple, a.model.width_multiple) == (b.model.depth_multiple, b.model.width_multiple)
+
+
+def test_config_attr_dict():
+    c = Config(dict(model=dict(head=dict(num_layers=3)), x=1))
+    assert c.model.head.num_layers == 3 and c["model"]["head"]["num_layers"] == 3
+    assert c.model.get("missing") is None
+    with pytest.raises(AttributeError):
+        c.model.nope
+
+
+def test_get_block_contract():
+    assert common.get_block("repvgg") is common.RepVGGBlock
+    assert common.get_block("conv_silu") is common.ConvBNSiLU
+    with pytest.raises(NotImplementedError):
+        common.get_block("bogus")
+    with pytest.raises(AssertionError):
+        common.RepVGGBlock(8, 8, kernel_size=5)
+
+
+def test_header_and_library_symbols(hip_lib):
+    """Every function declared in include/yolov6_hip.h is bound in _lib.SIGNATURES and exported by the .so."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "yolov6_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(y6_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert hip_lib.y6_abi_version() == 1
+    assert hip_lib.y6_conv_variants() >= 2
+    assert hip_lib.y6_packed_weight_elems(80, 64, 1) == 4 * 2 * 1 * 1024
+
+
+def test_no_cpu_fallback(hip_lib):
+    """The product path must fail loudly on CPU tensors instead of computing with aten."""
+    cfg, meta = case_config("tiny")
+    m = build_model(cfg, 80, "cpu").eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 64, 64))
+    from yolov6_amd.utils.nms import non_max_suppression
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        non_max_suppression(torch.zeros(1, 10, 85))
+    from yolov6_amd.assigners import TaskAlignedAssigner
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TaskAlignedAssigner()(torch.zeros(1, 10, 80), torch.zeros(1, 10, 4), torch.zeros(10, 2), torch.zeros(1, 2, 1),
+                              torch.zeros(1, 2, 4), torch.zeros(1, 2, 1))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="is missing"):
+        _lib.load()
+
+
+def test_modules_pickle_without_plans():
+    cfg, _ = case_config("tiny")
+    m = Model(cfg, 3, 80).eval()
+    m.__dict__["_y6_plans"] = {"k": object()}
+    m2 = pickle.loads(pickle.dumps(m))
+    assert "_y6_plans" not in m2.__dict__
+    assert list(m2.state_dict()) == list(m.state_dict())
+
+
+def test_install_as_yolov6_aliases():
+    import sys
+    import yolov6_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "yolov6" or k.startswith("yolov6.")}
+    try:
+        for k in saved:
+            del sys.modules[k]
+        yolov6_amd.install_as_yolov6()
+        from yolov6.layers.common import RepVGGBlock
+        from yolov6.models.yolo import Model as M2
+        from yolov6.utils.nms import non_max_suppression  # noqa: F401
+        assert RepVGGBlock is common.RepVGGBlock and M2 is Model
+    finally:
+        for k in [k for k in sys.modules if k == "yolov6" or k.startswith("yolov6.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def test_anchor_generator_matches_oracle_grid():
+    from yolov6_amd.assigners import generate_anchors
+    feats = [torch.zeros(1, 8, 4, 6), torch.zeros(1, 8, 2, 3)]
+    pts, st = generate_anchors(feats, [8, 16], is_eval=True)
+    assert pts.shape == (30, 2) and st.shape == (30, 1)
+    assert pts[0].tolist() == [0.5, 0.5] and pts[7].tolist() == [1.5, 1.5] and st[-1].item() == 16
+    anchors, pts2, n, st2 = generate_anchors(feats, [8, 16], 5.0, 0.5, is_eval=False)
+    assert n == [24, 6] and anchors.shape == (30, 4)
+    assert pts2[0].tolist() == [4.0, 4.0] and anchors[0].tolist() == [-16.0, -16.0, 24.0, 24.0]

@@ -1,0 +1,105 @@
+"""CPU: the oracle restatements against the golden vectors produced by the reference itself
+(tests/golden/gen_golden.py).  These pin the oracle; the GPU tests then compare HIP vs oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms_oracle, synth, tal_oracle
+from oracle.model_oracle import Oracle, deploy_state_dict
+from tests.helpers import GOLDEN, case_config, case_golden, rel_err, synth_sd_from_keys
+
+MODEL_CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny"]
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_model_oracle_matches_reference(case):
+    cfg, meta = case_config(case)
+    g = case_golden(case)
+    sd = synth_sd_from_keys(meta["train"])
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    nc = meta["num_classes"]
+    with torch.no_grad():
+        det_t, _ = Oracle(cfg, sd, nc).forward(x, train_form=True)
+        det_d, feats = Oracle(cfg, sd, nc).forward(x, train_form=False)
+    # fp32 CPU conv summation order differs between fused and unfused graphs: 1e-4 relative
+    assert rel_err(det_t.numpy(), g["det_train"]) < 2e-4
+    assert rel_err(det_d.numpy(), g["det_deploy"]) < 2e-4
+    for i, f in enumerate(feats):
+        assert rel_err(f.numpy(), g[f"feat{i}"]) < 2e-4
+
+
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_deploy_state_dict_keys_match_reference(case):
+    cfg, meta = case_config(case)
+    sd = synth_sd_from_keys(meta["train"])
+    dep = deploy_state_dict(cfg, sd, meta["num_classes"])
+    assert {k: list(v.shape) for k, v in dep.items()} == meta["deploy"]
+    # and the deploy-form state dict evaluates to the same detections
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    with torch.no_grad():
+        det, _ = Oracle(cfg, dep, meta["num_classes"]).forward(x)
+    assert rel_err(det.numpy(), case_golden(case)["det_deploy"]) < 2e-4
+
+
+def test_fp16_emulation_stays_close():
+    cfg, meta = case_config("tiny")
+    sd = synth_sd_from_keys(meta["train"])
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    with torch.no_grad():
+        a, _ = Oracle(cfg, sd, 80).forward(x)
+        b, _ = Oracle(cfg, sd, 80, emulate_fp16=True).forward(x)
+    assert rel_err(b.numpy(), a.numpy()) < 2e-2
+
+
+NMS_CASES = ["eval_multilabel", "infer_single", "agnostic_classes", "max_det_cut", "over_max_nms", "empty"]
+
+
+@pytest.mark.parametrize("case", NMS_CASES)
+def test_nms_oracle_matches_reference(case):
+    g = np.load(os.path.join(GOLDEN, f"nms_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    pred = synth.synth_predictions(meta["B"], meta["A"], meta["nc"], seed=meta["seed"], frac=meta["frac"]).numpy()
+    res = nms_oracle.non_max_suppression(pred, **meta["kwargs"])
+    counts = np.array([r.shape[0] for r in res], np.int32)
+    assert counts.tolist() == g["counts"].tolist()
+    dets = np.concatenate([r.reshape(-1, 6) for r in res], 0)
+    assert np.array_equal(dets, g["dets"])          # bit-exact, including order
+
+
+def test_nms_known_answers():
+    # two identical boxes: the later one is suppressed; IoU == thr is NOT suppressed (strict >)
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [0, 0, 10, 5]], np.float32)
+    s = np.array([0.9, 0.8, 0.7], np.float32)
+    assert nms_oracle.nms(b, s, 0.5).tolist() == [0, 2]         # duplicate 1 dies; IoU(0,2) = 0.5 is not > 0.5
+    assert nms_oracle.nms(b[[0, 2]], s[[0, 2]], 0.5).tolist() == [0, 1]   # 0.5 > 0.5 is false
+    assert nms_oracle.nms(b[[0, 2]], s[[0, 2]], 0.49).tolist() == [0]
+    # stable order on equal scores
+    s2 = np.array([0.5, 0.5, 0.5], np.float32)
+    far = np.array([[0, 0, 1, 1], [5, 5, 6, 6], [9, 9, 10, 10]], np.float32)
+    assert nms_oracle.nms(far, s2, 0.5).tolist() == [0, 1, 2]
+    assert nms_oracle.nms(np.zeros((0, 4), np.float32), np.zeros((0,), np.float32), 0.5).shape == (0,)
+
+
+TAL_CASES = ["basic", "padded", "many_gt", "topk26", "empty"]
+
+
+@pytest.mark.parametrize("case", TAL_CASES)
+def test_tal_oracle_matches_reference(case):
+    g = np.load(os.path.join(GOLDEN, f"tal_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    inp = synth.synth_tal_inputs(meta["B"], [tuple(f) for f in meta["feat_sizes"]], meta["strides"], meta["C"],
+                                 meta["G"], seed=meta["seed"], n_valid=meta["n_valid"])
+    L, Bx, S, F = tal_oracle.assign(*(inp[k].numpy() for k in ("pd_scores", "pd_bboxes", "anc_points", "gt_labels",
+                                                                "gt_bboxes", "mask_gt")),
+                                    topk=meta["topk"], num_classes=meta["C"])
+    assert np.array_equal(F.astype(bool), g["fg"])
+    assert np.array_equal(L, g["labels"])                      # bit-exact assignment
+    assert np.array_equal(Bx, g["bboxes"])
+    ref_scores = np.zeros_like(S)
+    idx = g["score_idx"]
+    ref_scores[idx[:, 0], idx[:, 1], idx[:, 2]] = g["score_val"]
+    assert np.array_equal(S != 0, ref_scores != 0)
+    np.testing.assert_allclose(S, ref_scores, rtol=2e-6, atol=1e-12)

@@ -1,0 +1,141 @@
+"""ctypes binding of libyolov6_hip.so (the C ABI declared in include/yolov6_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the reference's assigner fallback catches exactly RuntimeError,
+yolov6/models/losses/loss.py:105).  torch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libyolov6_hip.so")
+
+Y6_F16, Y6_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_HARDSWISH = 0, 1, 2, 3
+ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU, "hardswish": ACT_HARDSWISH}
+MAX_LEVELS = 4
+
+
+class Tensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("cstride", C.c_int32), ("coff", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", Tensor), ("out", Tensor), ("w_packed", C.c_void_p), ("w_oihw", C.c_void_p),
+                ("bias", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("res", Tensor),
+                ("res_alpha", C.c_void_p), ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+                ("variant", C.c_int32)]
+
+
+class ConvTDesc(C.Structure):
+    _fields_ = [("inp", Tensor), ("out", Tensor), ("w_packed", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class StemDesc(C.Structure):
+    _fields_ = [("in_nchw", C.c_void_p), ("in_dtype", C.c_int32), ("B", C.c_int32), ("Cin", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32), ("out", Tensor), ("w_oihw_f32", C.c_void_p),
+                ("bias", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int32)]
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("cls", Tensor * MAX_LEVELS), ("reg", Tensor * MAX_LEVELS),
+                ("stride", C.c_float * MAX_LEVELS), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
+                ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32)]
+
+
+class NmsDesc(C.Structure):
+    _fields_ = [("pred", C.c_void_p), ("B", C.c_int32), ("A", C.c_int32), ("nc", C.c_int32),
+                ("conf_thres", C.c_float), ("iou_thres", C.c_float), ("classes", C.c_void_p),
+                ("n_classes", C.c_int32), ("agnostic", C.c_int32), ("multi_label", C.c_int32),
+                ("max_det", C.c_int32), ("max_nms", C.c_int32), ("max_wh", C.c_float), ("out_dets", C.c_void_p),
+                ("out_index", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+class TalDesc(C.Structure):
+    _fields_ = [("pd_scores", C.c_void_p), ("pd_bboxes", C.c_void_p), ("anc_points", C.c_void_p),
+                ("gt_labels", C.c_void_p), ("gt_bboxes", C.c_void_p), ("mask_gt", C.c_void_p), ("B", C.c_int32),
+                ("A", C.c_int32), ("C", C.c_int32), ("G", C.c_int32), ("topk", C.c_int32), ("alpha", C.c_float),
+                ("beta", C.c_float), ("eps", C.c_float), ("target_labels", C.c_void_p),
+                ("target_bboxes", C.c_void_p), ("target_scores", C.c_void_p), ("fg_mask", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+# symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
+SIGNATURES = {
+    "y6_abi_version": (C.c_int, []),
+    "y6_last_error": (C.c_char_p, []),
+    "y6_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "y6_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "y6_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y6_pack_convt2x2_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y6_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "y6_conv_variants": (C.c_int, []),
+    "y6_conv_variant_name": (C.c_char_p, [C.c_int]),
+    "y6_conv_variant_supports": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "y6_convt2x2": (C.c_int, [C.POINTER(ConvTDesc), C.c_void_p]),
+    "y6_stem_conv": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
+    "y6_sppf_pool": (C.c_int, [C.POINTER(Tensor)] * 4 + [C.c_void_p]),
+    "y6_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tensor), C.c_void_p]),
+    "y6_nhwc_to_nchw": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_int, C.c_void_p]),
+    "y6_head_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "y6_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y6_nms": (C.c_int, [C.POINTER(NmsDesc), C.c_void_p]),
+    "y6_tal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "y6_tal_assign": (C.c_int, [C.POINTER(TalDesc), C.c_void_p]),
+    "y6_plan_create": (C.c_void_p, []),
+    "y6_plan_destroy": (None, [C.c_void_p]),
+    "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "y6_plan_add_convt": (C.c_int, [C.c_void_p, C.POINTER(ConvTDesc)]),
+    "y6_plan_add_stem": (C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
+    "y6_plan_add_sppf": (C.c_int, [C.c_void_p] + [C.POINTER(Tensor)] * 4),
+    "y6_plan_add_decode": (C.c_int, [C.c_void_p, C.POINTER(DecodeDesc)]),
+    "y6_plan_add_nchw2nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Tensor)]),
+    "y6_plan_add_nhwc2nchw": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_void_p, C.c_int]),
+    "y6_plan_num_ops": (C.c_int, [C.c_void_p]),
+    "y6_plan_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "y6_plan_rebind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y6_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y6_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y6_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the shared library; RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"yolov6_amd: {LIB_PATH} is missing - build it with `python yolov6_amd/csrc/build.py` "
+            "(there is no CPU or PyTorch fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.y6_abi_version() != 1:
+        raise RuntimeError("yolov6_amd: libyolov6_hip.so ABI version mismatch - rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().y6_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"yolov6_hip {what} failed (code {rc}): {msg}")
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu_tensor(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"yolov6_amd: {name} must live on a ROCm device (got {t.device}); the hot path has no CPU fallback")

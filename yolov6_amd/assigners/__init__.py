@@ -1,0 +1,2 @@
+from .tal_assigner import TaskAlignedAssigner  # noqa: F401
+from .anchor_generator import generate_anchors  # noqa: F401

@@ -1,0 +1,117 @@
+"""Model configurations and an `addict`-free attribute dict.
+
+The reference describes models with mmcv-style `.py` files (configs/*.py) loaded by
+yolov6/utils/config.py:33-63 (which needs the `addict` package).  `load_config(path)`
+executes such a file unchanged; `get_config(name)` returns the built-in restatement of the
+BASELINE configurations' `model` dicts (so nothing under /root/reference is needed at run
+time): yolov6n / yolov6s (configs/yolov6n.py, yolov6s.py), yolov6m / yolov6l
+(configs/yolov6m.py, yolov6l.py), yolov6l6 (configs/yolov6l6.py) and yolov6s_qa
+(configs/qarepvgg/yolov6s_qa.py).
+"""
+import copy
+import os
+
+
+class ConfigDict(dict):
+    """dict with attribute access, recursively (what the reference gets from addict.Dict)."""
+
+    def __init__(self, *a, **kw):
+        super().__init__()
+        for k, v in dict(*a, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, ConfigDict(v) if isinstance(v, dict) and not isinstance(v, ConfigDict) else v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(f"'ConfigDict' object has no attribute '{k}'") from None
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def __deepcopy__(self, memo):
+        return ConfigDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
+
+
+class Config(ConfigDict):
+    @staticmethod
+    def fromfile(path):
+        return load_config(path)
+
+
+def load_config(path):
+    """Execute a reference-style config file and return its public names as a Config."""
+    path = os.path.abspath(os.path.expanduser(path))
+    if not path.endswith(".py"):
+        raise IOError("Only .py type are supported now!")
+    ns = {"__file__": path}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), ns)
+    cfg = Config({k: v for k, v in ns.items() if not k.startswith("__") and not callable(v) and
+                  not isinstance(v, type(os))})
+    cfg.setdefault("training_mode", "repvgg")   # tools/train.py:99-100
+    return cfg
+
+
+_ANCHORS = [[10, 13, 19, 19, 33, 23], [30, 61, 59, 59, 59, 119], [116, 90, 185, 185, 373, 326]]
+
+
+def _p5(depth, width, backbone, neck, csp, iou, use_dfl=False, reg_max=0, cspsppf=True, extra=None):
+    b = dict(type=backbone, num_repeats=[1, 6, 12, 18, 6], out_channels=[64, 128, 256, 512, 1024], fuse_P2=True,
+             cspsppf=cspsppf)
+    n = dict(type=neck, num_repeats=[12, 12, 12, 12], out_channels=[256, 128, 128, 256, 256, 512])
+    if csp is not None:
+        b["csp_e"] = csp
+        n["csp_e"] = csp
+    m = dict(pretrained=None, depth_multiple=depth, width_multiple=width, backbone=b, neck=n,
+             head=dict(type='EffiDeHead', in_channels=[128, 256, 512], num_layers=3, begin_indices=24, anchors=3,
+                       anchors_init=_ANCHORS, out_indices=[17, 20, 23], strides=[8, 16, 32], atss_warmup_epoch=0,
+                       iou_type=iou, use_dfl=use_dfl, reg_max=reg_max,
+                       distill_weight={'class': 1.0, 'dfl': 1.0}))
+    if extra:
+        m.update(extra)
+    return m
+
+
+_MODELS = {
+    "yolov6n": dict(model=dict(type='YOLOv6n', **_p5(0.33, 0.25, 'EfficientRep', 'RepBiFPANNeck', None, 'siou')),
+                    training_mode="repvgg"),
+    "yolov6s": dict(model=dict(type='YOLOv6s', **_p5(0.33, 0.50, 'EfficientRep', 'RepBiFPANNeck', None, 'giou')),
+                    training_mode="repvgg"),
+    "yolov6s_qa": dict(model=dict(type='YOLOv6s', **_p5(0.33, 0.50, 'EfficientRep', 'RepBiFPANNeck', None, 'giou')),
+                       training_mode="qarepvggv2"),
+    "yolov6m": dict(model=dict(type='YOLOv6m', **_p5(0.60, 0.75, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(2) / 3,
+                                                      'giou', use_dfl=True, reg_max=16, cspsppf=False)),
+                    training_mode="repvgg"),
+    "yolov6l": dict(model=dict(type='YOLOv6l', **_p5(1.0, 1.0, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(1) / 2,
+                                                      'giou', use_dfl=True, reg_max=16, cspsppf=False)),
+                    training_mode="conv_silu"),
+    "yolov6l6": dict(model=dict(
+        type='YOLOv6l6', pretrained=None, depth_multiple=1.0, width_multiple=1.0,
+        backbone=dict(type='CSPBepBackbone_P6', num_repeats=[1, 6, 12, 18, 6, 6],
+                      out_channels=[64, 128, 256, 512, 768, 1024], csp_e=float(1) / 2, fuse_P2=True),
+        neck=dict(type='CSPRepBiFPANNeck_P6', num_repeats=[12, 12, 12, 12, 12, 12],
+                  out_channels=[512, 256, 128, 256, 512, 1024], csp_e=float(1) / 2),
+        head=dict(type='EffiDeHead', in_channels=[128, 256, 512, 1024], num_layers=4, anchors=1,
+                  strides=[8, 16, 32, 64], atss_warmup_epoch=4, iou_type='giou', use_dfl=True, reg_max=16,
+                  distill_weight={'class': 1.0, 'dfl': 1.0})), training_mode="conv_silu"),
+}
+
+
+def get_config(name):
+    """Built-in model config by name ('yolov6s', ...)."""
+    if name not in _MODELS:
+        raise KeyError(f"unknown config {name!r}; known: {sorted(_MODELS)}")
+    return Config(copy.deepcopy(_MODELS[name]))
+
+
+def tiny_config(width=0.125, depth=0.17, training_mode="repvgg", p6=False):
+    """A narrow/shallow variant of the N/S (or L6) graph for fast parity tests."""
+    cfg = get_config("yolov6l6" if p6 else "yolov6s")
+    cfg.model.width_multiple = width
+    cfg.model.depth_multiple = depth
+    cfg.training_mode = training_mode
+    return cfg

@@ -1,0 +1,68 @@
+// Shared helpers for libyolov6_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/yolov6_hip.h"
+
+void y6_set_error(const char* fmt, ...);
+
+#define Y6_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            y6_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return Y6_EHIP;                                                                  \
+        }                                                                                    \
+    } while (0)
+
+#define Y6_REQUIRE(cond, ...)                                                                \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            y6_set_error(__VA_ARGS__);                                                       \
+            return Y6_EINVAL;                                                                \
+        }                                                                                    \
+    } while (0)
+
+#define Y6_LAUNCH_CHECK()                                                                    \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            y6_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return Y6_EHIP;                                                                  \
+        }                                                                                    \
+    } while (0)
+
+static inline int y6_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t y6_tensor_elems(const y6_tensor& t) { return (size_t)t.B * t.H * t.W * t.cstride; }
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float y6_act(float v, int act) {
+    switch (act) {
+        case Y6_ACT_RELU: return v > 0.f ? v : 0.f;
+        case Y6_ACT_SILU: return v / (1.f + __expf(-v));
+        case Y6_ACT_HARDSWISH: {
+            float r = v + 3.f;
+            r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r);
+            return v * r * (1.f / 6.f);
+        }
+        default: return v;
+    }
+}
+
+// internal launchers shared between translation units
+struct y6_conv_geom;  // conv_mfma.hip
+int y6_conv_naive_launch(const y6_conv_desc* d, hipStream_t s);                 // conv_misc.hip
+int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s,      // conv_mfma.hip
+                        int up, int updy, int updx);
+int y6_conv_mfma_supports(const y6_conv_desc* d, int variant);
+double y6_conv_flops(const y6_conv_desc* d);
+double y6_conv_bytes(const y6_conv_desc* d);

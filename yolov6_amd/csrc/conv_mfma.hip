@@ -1,0 +1,445 @@
+// conv_mfma.hip — NHWC fp16 direct convolution (k in {1,3}, stride in {1,2}) on the gfx950
+// matrix cores, im2col-free: a spatial tile's input halo is staged ONCE per 32-channel
+// chunk into LDS and re-used by all 9 taps; weights arrive by LDS-DMA (global_load_lds)
+// in pre-packed MFMA fragment order through a 3-slot ring, two taps ahead.
+//
+// Replaces the aten compositions behind ConvModule.forward_fuse (reference
+// yolov6/layers/common.py:51-54), RepVGGBlock deploy forward (:247-248), QARepVGGBlock
+// deploy forward (:338-339), BottleRep's residual (:605-608) and the head's 1x1 convs
+// (yolov6/models/effidehead.py:169-179).
+//
+// MFMA orientation (v_mfma_f32_32x32x16_f16, guide cdna_hip_programming.md §3):
+//   A operand  = weights : row = cout (lane&31), k = cin (8 consecutive at (lane>>5)*8)
+//   B operand  = pixels  : col = pixel (lane&31), same k
+//   C/D        : col = pixel = lane&31, row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// so every lane ends up with 4 consecutive couts of ONE pixel per 4 accumulator registers
+// -> 8-byte NHWC stores in the epilogue.
+#include "common.hpp"
+
+namespace {
+
+constexpr int PIXB = 80;  // LDS bytes per halo pixel: 32 ch * 2 B + 16 B pad (bank spread)
+
+struct ConvKArgs {
+    const __half* in;
+    __half* out;
+    const __half* wpk;
+    const float* bias;
+    const float* pscale;
+    const float* pshift;
+    const __half* res;
+    const float* res_alpha;
+    int B, H, W, Ho, Wo;
+    int Cin, Cout;
+    int in_cs, in_co, out_cs, out_co, res_cs, res_co;
+    int TH, TW, tiles_x, tiles_y, ntiles;
+    int HH, HWd;
+    int nchunk, ncb;
+    int ldsA_bytes;
+    int act;
+    int vec_ok;
+    int up, updy, updx, upH, upW;
+};
+
+template <int KS, int ST, int PF>
+struct HaloCap {
+    static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 192) : 576);
+};
+
+template <int CF, int PF, int KS, int ST>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = KS * KS;
+    constexpr int WIMG = CF * 2 * 1024;  // bytes of one tap's weight image [cf][ks][lane][16B]
+    constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
+    constexpr int NP = (MAXHP * 4 + 255) / 256;  // 16-byte halo pieces per thread
+    constexpr int NWJ = (CF * 2 + 3) / 4;        // DMA pieces per wave per tap
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- block -> (spatial tile, cout block); cout blocks of one tile share an XCD (id % 8)
+    int tile, cb;
+    {
+        const int id = blockIdx.x;
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    }
+    if (tile >= a.ntiles) return;
+    const int tx_i = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_i = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
+    const int iy0 = oy0 * ST - KS / 2, ix0 = ox0 * ST - KS / 2;
+
+    char* ldsA = smem;
+    char* ldsW = smem + a.ldsA_bytes;
+
+    // ---- per-thread halo piece table (element offsets into a.in; <0: zero fill / skip)
+    const int npieces = a.HH * a.HWd * 4;
+    int goff[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        int g = -2;
+        if (idx < npieces) {
+            const int hp = idx >> 2, q = idx & 3;
+            const int hy = hp / a.HWd, hx = hp - hy * a.HWd;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool v = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+            g = v ? (((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + q * 8) : -1;
+        }
+        goff[i] = g;
+    }
+
+    // ---- per-lane pixel operand addressing
+    int pixoff[PF];
+    int opix[PF];  // output pixel index (elements / out_cs), -1 when masked
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+        const int npx = a.TH * a.TW;
+        bool v = m < npx;
+        const int mm = v ? m : npx - 1;
+        const int ty = mm / a.TW, tx = mm - ty * a.TW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        v = v && (oy < a.Ho) && (ox < a.Wo);
+        pixoff[pf] = ((ty * ST) * a.HWd + tx * ST) * PIXB + (lane >> 5) * 16;
+        int op;
+        if (a.up) {  // ConvTranspose2d(k2,s2) scatter: ox is a flattened (b,y,x) index
+            const int x = ox % a.upW;
+            const int t = ox / a.upW;
+            const int y = t % a.upH;
+            const int bb = t / a.upH;
+            op = (bb * 2 * a.upH + 2 * y + a.updy) * (2 * a.upW) + 2 * x + a.updx;
+        } else {
+            op = (b * a.Ho + oy) * a.Wo + ox;
+        }
+        opix[pf] = v ? op : -1;
+    }
+
+    f32x16_t acc[CF][PF];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+
+    auto issue_w = [&](int step, int buf) {
+        const int chunk = step / NT, tap = step - chunk * NT;
+#pragma unroll
+        for (int j = 0; j < NWJ; ++j) {
+            const int p = wave + 4 * j;
+            if (p < CF * 2) {
+                const int cf = p >> 1, ks = p & 1;
+                const size_t cfg = (size_t)cb * CF + cf;
+                const __half* src = a.wpk + (((cfg * a.nchunk + chunk) * NT + tap) * 2 + ks) * 512 + lane * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsW + buf * WIMG + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    auto load_A = [&](int chunk, uint4 (&regs)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int idx = tid + i * 256;
+            const int q = idx & 3;
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
+                v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
+            regs[i] = v;
+        }
+    };
+    auto store_A = [&](const uint4 (&regs)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < npieces) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = regs[i];
+        }
+    };
+
+    // Weight ring: 3 tap images; the DMA for step s+2 is issued at the top of step s, so it
+    // has a whole tap-step of MFMA work to land.  One raw barrier per step:
+    //   vmcnt(NWJ)  -> this wave's DMA pieces for step s+1 have landed (only the NWJ pieces of
+    //                  step s+2 may still fly; a wave's per-step piece count is constant),
+    //   lgkmcnt(0)  -> this wave's LDS reads of step s are done, so the ring slot and (at a
+    //                  chunk boundary) the halo buffer may be overwritten after the barrier.
+    // The asm "memory" clobber keeps the compiler from moving LDS accesses across it.
+    const int nsteps = a.nchunk * NT;
+    uint4 areg[NP];
+    load_A(0, areg);
+    issue_w(0, 0);
+    if (nsteps > 1) issue_w(1, 1);
+    store_A(areg);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int step = 0;
+    int buf = 0;  // ring slot of `step`
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        const bool more = (chunk + 1) < a.nchunk;
+        if (more) load_A(chunk + 1, areg);  // register prefetch of the next halo chunk
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap, ++step) {
+            const int buf2 = (buf >= 1) ? buf - 1 : 2;  // (buf + 2) % 3
+            const bool ahead = (step + 2) < nsteps;
+            if (ahead) issue_w(step + 2, buf2);
+            const int dy = tap / KS, dx = tap - dy * KS;
+            const int tapoff = (dy * a.HWd + dx) * PIXB;
+            const char* wb = ldsW + buf * WIMG + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8_t af[CF], bf[PF];
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) af[cf] = *reinterpret_cast<const h8_t*>(wb + (cf * 2 + ks) * 1024);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf)
+                    bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf)
+                        acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
+            }
+            if (ahead) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NWJ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
+        if (more) {
+            store_A(areg);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- epilogue: bias (+affine) + activation (+residual) -> fp16 NHWC
+    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        if (opix[pf] < 0) continue;
+        __half* orow = a.out + (size_t)opix[pf] * a.out_cs + a.out_co;
+        const __half* rrow = a.res ? a.res + (size_t)opix[pf] * a.res_cs + a.res_co : nullptr;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c0 = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);
+                if (c0 >= a.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    float x = acc[cf][pf][r4 * 4 + j];
+                    if (c < a.Cout) {
+                        if (a.bias) x += a.bias[c];
+                        if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
+                        x = y6_act(x, a.act);
+                        if (rrow) x += ralpha * __half2float(rrow[c]);
+                    }
+                    v[j] = x;
+                }
+                if (a.vec_ok && (c0 + 3) < a.Cout) {
+                    h4_t o;
+                    o[0] = (_Float16)v[0];
+                    o[1] = (_Float16)v[1];
+                    o[2] = (_Float16)v[2];
+                    o[3] = (_Float16)v[3];
+                    *reinterpret_cast<h4_t*>(orow + c0) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < a.Cout) orow[c0 + j] = __float2half(v[j]);
+                }
+            }
+        }
+    }
+}
+
+struct VariantCfg {
+    int cf, pf;
+    const char* name;
+};
+// index 0 is the naive kernel (conv_misc.hip)
+const VariantCfg kVariants[] = {{0, 0, "naive"},     {1, 1, "mfma_c1p1"}, {2, 1, "mfma_c2p1"}, {4, 1, "mfma_c4p1"},
+                                {1, 2, "mfma_c1p2"}, {2, 2, "mfma_c2p2"}, {4, 2, "mfma_c4p2"}};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+int halo_cap(int ks, int st, int pf) {
+    if (ks == 1) return pf * 128;
+    if (st == 1) return pf == 2 ? 352 : 192;
+    return 576;
+}
+
+// choose the spatial tile (TH x TW outputs) for a block of `bp` pixel slots
+void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int* pTW) {
+    double best = -1.0;
+    int bTH = 1, bTW = 1;
+    const int maxTW = Wo < bp ? Wo : bp;
+    for (int TW = 1; TW <= maxTW; ++TW) {
+        int TH = bp / TW;
+        if (TH > Ho) TH = Ho;
+        for (; TH >= 1; --TH) {
+            const int HH = (TH - 1) * st + ks, HW = (TW - 1) * st + ks;
+            if (HH * HW <= cap) break;
+        }
+        if (TH < 1) continue;
+        const double tiles = (double)y6_cdiv(Ho, TH) * y6_cdiv(Wo, TW);
+        const int HH = (TH - 1) * st + ks, HW = (TW - 1) * st + ks;
+        // useful MFMA work / issued MFMA work, lightly penalised by halo staging volume
+        const double eff = ((double)Ho * Wo) / (tiles * bp);
+        const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
+        const double score = eff * (0.85 + 0.15 * halo);
+        if (score > best + 1e-9) {
+            best = score;
+            bTH = TH;
+            bTW = TW;
+        }
+    }
+    *pTH = bTH;
+    *pTW = bTW;
+}
+
+struct Launch {
+    ConvKArgs k;
+    int grid;
+    size_t lds;
+};
+
+int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx, Launch* L) {
+    const VariantCfg& vc = kVariants[variant];
+    const int ks = d->ksize, st = d->stride;
+    ConvKArgs& k = L->k;
+    memset(&k, 0, sizeof(k));
+    k.in = (const __half*)d->in.data;
+    k.out = (__half*)d->out.data;
+    k.wpk = (const __half*)d->w_packed;
+    k.bias = d->bias;
+    k.pscale = d->post_scale;
+    k.pshift = d->post_shift;
+    k.res = (const __half*)d->res.data;
+    k.res_alpha = d->res_alpha;
+    k.Cin = d->in.C;
+    k.Cout = d->out.C;
+    k.in_cs = d->in.cstride;
+    k.in_co = d->in.coff;
+    k.out_cs = d->out.cstride;
+    k.out_co = d->out.coff;
+    k.res_cs = d->res.cstride;
+    k.res_co = d->res.coff;
+    k.act = d->act;
+    k.vec_ok = (d->out.cstride % 4 == 0) && (d->out.coff % 4 == 0) && (((uintptr_t)d->out.data & 7) == 0);
+    k.up = up;
+    k.updy = updy;
+    k.updx = updx;
+    k.upH = d->in.H;
+    k.upW = d->in.W;
+    const int bp = 128 * vc.pf;
+    if (ks == 1) {
+        // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row
+        const long npix = (long)d->in.B * d->in.H * d->in.W;
+        k.B = 1;
+        k.H = 1;
+        k.W = (int)npix;
+        k.Ho = 1;
+        k.Wo = (int)npix;
+        k.TH = 1;
+        k.TW = bp;
+    } else {
+        k.B = d->in.B;
+        k.H = d->in.H;
+        k.W = d->in.W;
+        k.Ho = d->out.H;
+        k.Wo = d->out.W;
+        choose_tile(k.Ho, k.Wo, ks, st, bp, halo_cap(ks, st, vc.pf), &k.TH, &k.TW);
+    }
+    k.tiles_x = y6_cdiv(k.Wo, k.TW);
+    k.tiles_y = y6_cdiv(k.Ho, k.TH);
+    k.ntiles = k.B * k.tiles_x * k.tiles_y;
+    k.HH = (k.TH - 1) * st + ks;
+    k.HWd = (k.TW - 1) * st + ks;
+    k.nchunk = y6_cdiv(k.Cin, 32);
+    k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
+    k.ldsA_bytes = k.HH * k.HWd * PIXB;
+    L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;
+    L->grid = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
+    return Y6_OK;
+}
+
+template <int CF, int PF>
+int launch_cfg(const Launch& L, int ks, int st, hipStream_t s) {
+    dim3 grid(L.grid), block(256);
+    if (ks == 1 && st == 1) {
+        hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, 1, 1>), grid, block, L.lds, s, L.k);
+    } else if (ks == 3 && st == 1) {
+        hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, 3, 1>), grid, block, L.lds, s, L.k);
+    } else if (ks == 3 && st == 2) {
+        if constexpr (PF == 1) {
+            hipLaunchKernelGGL((conv_mfma_kernel<CF, 1, 3, 2>), grid, block, L.lds, s, L.k);
+        } else {
+            y6_set_error("conv_mfma: stride-2 needs a pf=1 variant");
+            return Y6_EUNSUPPORTED;
+        }
+    } else {
+        y6_set_error("conv_mfma: unsupported ksize/stride %d/%d", ks, st);
+        return Y6_EUNSUPPORTED;
+    }
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+}  // namespace
+
+extern "C" int y6_conv_variants(void) { return kNumVariants; }
+extern "C" const char* y6_conv_variant_name(int i) {
+    return (i >= 0 && i < kNumVariants) ? kVariants[i].name : "?";
+}
+
+int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
+    if (variant < 1 || variant >= kNumVariants) return 0;
+    const VariantCfg& vc = kVariants[variant];
+    const int ks = d->ksize, st = d->stride;
+    if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
+    if (st == 2 && vc.pf != 1) return 0;
+    if (d->w_packed == nullptr) return 0;
+    // 16-byte halo pieces need 8-channel alignment of the input view
+    if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
+    if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
+    // element offsets are 32-bit in the kernel
+    if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
+    // don't spend a 4-frag (128 cout) block on a narrow layer
+    const int cfr = y6_cdiv(d->out.C, 32);
+    if (vc.cf > cfr) return 0;
+    return 1;
+}
+
+int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int up, int updy, int updx) {
+    if (!y6_conv_mfma_supports(d, variant)) {
+        y6_set_error("conv_mfma: variant %d does not support this conv (k%d s%d Cin %d Cout %d)", variant, d->ksize,
+                     d->stride, d->in.C, d->out.C);
+        return Y6_EUNSUPPORTED;
+    }
+    Launch L;
+    int rc = build_launch(d, variant, up, updy, updx, &L);
+    if (rc) return rc;
+    switch (variant) {
+        case 1: return launch_cfg<1, 1>(L, d->ksize, d->stride, s);
+        case 2: return launch_cfg<2, 1>(L, d->ksize, d->stride, s);
+        case 3: return launch_cfg<4, 1>(L, d->ksize, d->stride, s);
+        case 4: return launch_cfg<1, 2>(L, d->ksize, d->stride, s);
+        case 5: return launch_cfg<2, 2>(L, d->ksize, d->stride, s);
+        case 6: return launch_cfg<4, 2>(L, d->ksize, d->stride, s);
+    }
+    return Y6_EINVAL;
+}

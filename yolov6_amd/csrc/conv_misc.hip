@@ -1,0 +1,452 @@
+// conv_misc.hip — the small kernels around the MFMA conv: weight packing, the naive
+// cross-check conv, the NCHW stem conv, ConvTranspose2d(k2,s2), SPPF pooling and the
+// NCHW<->NHWC boundary adapters.  File:line citations are into the reference tree.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+// dst[cfr][chunk][tap][ks][lane][j] = W[cout = cfr*32 + (lane&31)][cin = chunk*32 + ks*16 + (lane>>5)*8 + j][tap]
+template <typename T>
+__global__ void pack_conv_weight_kernel(const T* __restrict__ src, int Cout, int Cin, int K, int cfr_pad, int nchunk,
+                                        __half* __restrict__ dst) {
+    const int NT = K * K;
+    const size_t total = (size_t)cfr_pad * nchunk * NT * 1024;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        const int lane = (int)((i >> 3) & 63);
+        const int ks = (int)((i >> 9) & 1);
+        size_t r = i >> 10;
+        const int tap = (int)(r % NT);
+        r /= NT;
+        const int chunk = (int)(r % nchunk);
+        const int cfr = (int)(r / nchunk);
+        const int cout = cfr * 32 + (lane & 31);
+        const int cin = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
+        float v = 0.f;
+        if (cout < Cout && cin < Cin) v = (float)src[((size_t)cout * Cin + cin) * NT + tap];
+        dst[i] = __float2half(v);
+    }
+}
+
+// ConvTranspose2d weight is IOHW [Cin][Cout][2][2]; sub-kernel (dy,dx) is a 1x1 conv
+template <typename T>
+__global__ void pack_convt_weight_kernel(const T* __restrict__ src, int Cin, int Cout, int cfr_pad, int nchunk,
+                                         __half* __restrict__ dst) {
+    const size_t per = (size_t)cfr_pad * nchunk * 1024;
+    const size_t total = per * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int sub = (int)(i / per);  // dy*2+dx
+        const size_t ii = i - (size_t)sub * per;
+        const int j = (int)(ii & 7);
+        const int lane = (int)((ii >> 3) & 63);
+        const int ks = (int)((ii >> 9) & 1);
+        size_t r = ii >> 10;
+        const int chunk = (int)(r % nchunk);
+        const int cfr = (int)(r / nchunk);
+        const int cout = cfr * 32 + (lane & 31);
+        const int cin = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
+        float v = 0.f;
+        if (cout < Cout && cin < Cin) v = (float)src[((size_t)cin * Cout + cout) * 4 + sub];
+        dst[i] = __float2half(v);
+    }
+}
+
+// ------------------------------------------------------------------ naive conv (cross-check / any shape)
+__global__ void conv_naive_kernel(const __half* __restrict__ in, __half* __restrict__ out,
+                                  const __half* __restrict__ w /*OIHW*/, const float* __restrict__ bias,
+                                  const float* __restrict__ pscale, const float* __restrict__ pshift,
+                                  const __half* __restrict__ res, const float* __restrict__ res_alpha, int B, int H,
+                                  int W, int Ho, int Wo, int Cin, int Cout, int in_cs, int in_co, int out_cs,
+                                  int out_co, int res_cs, int res_co, int K, int S, int act) {
+    const size_t total = (size_t)B * Ho * Wo * Cout;
+    const int pad = K / 2;
+    const float ra = (res && res_alpha) ? *res_alpha : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        size_t p = i / Cout;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc = 0.f;
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * S - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * S - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                const __half* ip = in + ((size_t)(b * H + iy) * W + ix) * in_cs + in_co;
+                const __half* wp = w + (size_t)co * Cin * K * K + ky * K + kx;
+                for (int ci = 0; ci < Cin; ++ci) acc += __half2float(ip[ci]) * __half2float(wp[(size_t)ci * K * K]);
+            }
+        }
+        if (bias) acc += bias[co];
+        if (pscale) acc = acc * pscale[co] + pshift[co];
+        acc = y6_act(acc, act);
+        const size_t op = ((size_t)(b * Ho + oy) * Wo + ox);
+        if (res) acc += ra * __half2float(res[op * res_cs + res_co + co]);
+        out[op * out_cs + out_co + co] = __float2half(acc);
+    }
+}
+
+// ------------------------------------------------------------------ stem conv (NCHW in, NHWC out)
+// One thread = one output pixel x CO couts.  Weights are read with wave-uniform indices
+// (scalar loads); the 27 input taps are per-lane loads of neighbouring NCHW elements.
+template <typename TI, int CO>
+__global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ in, __half* __restrict__ out,
+                                                        const float* __restrict__ w /*[CO][Cin][3][3]*/,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ pscale,
+                                                        const float* __restrict__ pshift, int B, int Cin, int H, int W,
+                                                        int Ho, int Wo, int out_cs, int out_co, int act) {
+    const size_t total = (size_t)B * Ho * Wo;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ox = (int)(i % Wo);
+    const size_t p = i / Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.f;
+    for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                float v = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (float)in[(((size_t)b * Cin + ci) * H + iy) * W + ix];
+                const float* wp = w + (ci * 3 + ky) * 3 + kx;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) acc[c] = fmaf(v, wp[(size_t)c * Cin * 9], acc[c]);
+            }
+        }
+    }
+    __half* op = out + i * out_cs + out_co;
+#pragma unroll
+    for (int c0 = 0; c0 < CO; c0 += 8) {
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = acc[c0 + j];
+            if (pscale) x = x * pscale[c0 + j] + pshift[c0 + j];
+            o[j] = (_Float16)y6_act(x, act);
+        }
+        *reinterpret_cast<h8_t*>(op + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------ SPPF: 3 chained 5x5 s1 p2 max pools
+// One block = one image x 8 channels; the HxW plane lives in LDS; each pool is a
+// separable row-max / column-max pass with -inf padding (nn.MaxPool2d semantics).
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const __half* __restrict__ x, int x_cs, int x_co,
+                                                        __half* __restrict__ y1, int y1_cs, int y1_co,
+                                                        __half* __restrict__ y2, int y2_cs, int y2_co,
+                                                        __half* __restrict__ y3, int y3_cs, int y3_co, int H, int W,
+                                                        int C8) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    h8_t* cur = reinterpret_cast<h8_t*>(smem);
+    h8_t* tmp = cur + H * W;
+    const int b = blockIdx.x / C8, cg = blockIdx.x % C8;
+    const int HW = H * W;
+    const size_t pbase = (size_t)b * HW;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x)
+        cur[p] = *reinterpret_cast<const h8_t*>(x + (pbase + p) * x_cs + x_co + cg * 8);
+    __syncthreads();
+    __half* outs[3] = {y1, y2, y3};
+    const int ocs[3] = {y1_cs, y2_cs, y3_cs};
+    const int oco[3] = {y1_co, y2_co, y3_co};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {  // row max
+            const int yy = p / W, xx = p - yy * W;
+            h8_t m = cur[p];
+            for (int d = -2; d <= 2; ++d) {
+                const int x2 = xx + d;
+                if (d == 0 || x2 < 0 || x2 >= W) continue;
+                const h8_t v = cur[yy * W + x2];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+            tmp[p] = m;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < HW; p += blockDim.x) {  // column max
+            const int yy = p / W, xx = p - yy * W;
+            h8_t m = tmp[p];
+            for (int d = -2; d <= 2; ++d) {
+                const int y2i = yy + d;
+                if (d == 0 || y2i < 0 || y2i >= H) continue;
+                const h8_t v = tmp[y2i * W + xx];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+            }
+            *reinterpret_cast<h8_t*>(outs[pass] + (pbase + p) * ocs[pass] + oco[pass] + cg * 8) = m;
+            // safe to overwrite cur[p]: the column pass reads tmp only
+            cur[p] = m;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ layout adapters
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const T* __restrict__ src, __half* __restrict__ dst, int B, int C, int H, int W,
+                                    int cs, int co) {
+    const size_t total = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;  // (b*H + y)*W + x
+        const size_t hw = (size_t)H * W;
+        const size_t b = p / hw, yx = p % hw;
+        dst[p * cs + co + c] = __float2half((float)src[(b * C + c) * hw + yx]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const __half* __restrict__ src, T* __restrict__ dst, int B, int C, int H, int W,
+                                    int cs, int co) {
+    const size_t total = (size_t)B * H * W * C;
+    const size_t hw = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t yx = i % hw;
+        const size_t bc = i / hw;
+        const size_t c = bc % C, b = bc / C;
+        dst[i] = (T)__half2float(src[(b * hw + yx) * cs + co + c]);
+    }
+}
+
+inline int grid_for(size_t total, int block, int cap = 256 * 16) {
+    size_t g = (total + block - 1) / block;
+    if (g > (size_t)cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" size_t y6_packed_weight_elems(int Cout, int Cin, int K) {
+    const size_t cfr_pad = (size_t)y6_cdiv(y6_cdiv(Cout, 32), 4) * 4;
+    return cfr_pad * y6_cdiv(Cin, 32) * K * K * 1024;
+}
+
+extern "C" int y6_pack_conv_weight(const void* src, int src_dtype, int Cout, int Cin, int K, void* dst, void* stream) {
+    Y6_REQUIRE(src && dst && Cout > 0 && Cin > 0 && (K == 1 || K == 3), "pack_conv_weight: bad arguments");
+    const int cfr_pad = y6_cdiv(y6_cdiv(Cout, 32), 4) * 4, nchunk = y6_cdiv(Cin, 32);
+    const size_t total = (size_t)cfr_pad * nchunk * K * K * 1024;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == Y6_F16)
+        hipLaunchKernelGGL(pack_conv_weight_kernel<__half>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const __half*)src, Cout, Cin, K, cfr_pad, nchunk, (__half*)dst);
+    else if (src_dtype == Y6_F32)
+        hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const float*)src, Cout, Cin, K, cfr_pad, nchunk, (__half*)dst);
+    else
+        Y6_REQUIRE(false, "pack_conv_weight: bad dtype %d", src_dtype);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_pack_convt2x2_weight(const void* src, int src_dtype, int Cin, int Cout, void* dst, void* stream) {
+    Y6_REQUIRE(src && dst && Cout > 0 && Cin > 0, "pack_convt2x2_weight: bad arguments");
+    const int cfr_pad = y6_cdiv(y6_cdiv(Cout, 32), 4) * 4, nchunk = y6_cdiv(Cin, 32);
+    const size_t total = (size_t)cfr_pad * nchunk * 1024 * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == Y6_F16)
+        hipLaunchKernelGGL(pack_convt_weight_kernel<__half>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const __half*)src, Cin, Cout, cfr_pad, nchunk, (__half*)dst);
+    else if (src_dtype == Y6_F32)
+        hipLaunchKernelGGL(pack_convt_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const float*)src, Cin, Cout, cfr_pad, nchunk, (__half*)dst);
+    else
+        Y6_REQUIRE(false, "pack_convt2x2_weight: bad dtype %d", src_dtype);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+int y6_conv_naive_launch(const y6_conv_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d->w_oihw != nullptr, "conv naive: w_oihw not provided");
+    const size_t total = (size_t)d->out.B * d->out.H * d->out.W * d->out.C;
+    hipLaunchKernelGGL(conv_naive_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s,
+                       (const __half*)d->in.data, (__half*)d->out.data, (const __half*)d->w_oihw, d->bias,
+                       d->post_scale, d->post_shift, (const __half*)d->res.data, d->res_alpha, d->in.B, d->in.H,
+                       d->in.W, d->out.H, d->out.W, d->in.C, d->out.C, d->in.cstride, d->in.coff, d->out.cstride,
+                       d->out.coff, d->res.cstride, d->res.coff, d->ksize, d->stride, d->act);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+static int check_conv_desc(const y6_conv_desc* d) {
+    Y6_REQUIRE(d && d->in.data && d->out.data, "conv2d: null tensor");
+    Y6_REQUIRE(d->ksize == 1 || d->ksize == 3, "conv2d: ksize %d unsupported (1 or 3)", d->ksize);
+    Y6_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride %d unsupported", d->stride);
+    const int pad = d->ksize / 2;
+    const int Ho = (d->in.H + 2 * pad - d->ksize) / d->stride + 1, Wo = (d->in.W + 2 * pad - d->ksize) / d->stride + 1;
+    Y6_REQUIRE(d->out.B == d->in.B && d->out.H == Ho && d->out.W == Wo, "conv2d: output shape [%d,%d,%d] != expected [%d,%d,%d]",
+               d->out.B, d->out.H, d->out.W, d->in.B, Ho, Wo);
+    Y6_REQUIRE(d->in.coff + d->in.C <= d->in.cstride && d->out.coff + d->out.C <= d->out.cstride,
+               "conv2d: channel slice out of range");
+    if (d->res.data)
+        Y6_REQUIRE(d->res.B == d->out.B && d->res.H == d->out.H && d->res.W == d->out.W && d->res.C == d->out.C,
+                   "conv2d: residual shape mismatch");
+    Y6_REQUIRE((d->post_scale == nullptr) == (d->post_shift == nullptr), "conv2d: post_scale/post_shift must come together");
+    return Y6_OK;
+}
+
+// default variant: widest cout block that fits, 256-pixel tiles for stride 1
+static int default_variant(const y6_conv_desc* d) {
+    const int prefs_s1[] = {6, 5, 4, 3, 2, 1, 0};
+    const int prefs_s2[] = {3, 2, 1, 0};
+    const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
+    const int n = d->stride == 1 ? 7 : 4;
+    for (int i = 0; i < n; ++i)
+        if (y6_conv_variant_supports(d, prefs[i])) return prefs[i];
+    return -1;
+}
+
+extern "C" int y6_conv_variant_supports(const y6_conv_desc* d, int i) {
+    if (!d) return 0;
+    if (i == 0) return d->w_oihw != nullptr;
+    return y6_conv_mfma_supports(d, i);
+}
+
+extern "C" int y6_conv2d(const y6_conv_desc* d, void* stream) {
+    int rc = check_conv_desc(d);
+    if (rc) return rc;
+    int v = d->variant;
+    if (v < 0) v = default_variant(d);
+    Y6_REQUIRE(v >= 0, "conv2d: no kernel variant supports this conv (k%d s%d Cin %d Cout %d)", d->ksize, d->stride,
+               d->in.C, d->out.C);
+    if (v == 0) return y6_conv_naive_launch(d, (hipStream_t)stream);
+    return y6_conv_mfma_launch(d, v, (hipStream_t)stream, 0, 0, 0);
+}
+
+double y6_conv_flops(const y6_conv_desc* d) {
+    return 2.0 * d->out.B * d->out.H * d->out.W * (double)d->out.C * d->in.C * d->ksize * d->ksize;
+}
+double y6_conv_bytes(const y6_conv_desc* d) {
+    // algorithmic: read input once, write output once, weights once (fp16) + bias
+    return 2.0 * ((double)d->in.B * d->in.H * d->in.W * d->in.C + (double)d->out.B * d->out.H * d->out.W * d->out.C +
+                  (double)d->out.C * d->in.C * d->ksize * d->ksize) +
+           4.0 * d->out.C + (d->res.data ? 2.0 * d->out.B * d->out.H * d->out.W * d->out.C : 0.0);
+}
+
+extern "C" int y6_convt2x2(const y6_convt_desc* d, void* stream) {
+    Y6_REQUIRE(d && d->in.data && d->out.data && d->w_packed, "convt2x2: null argument");
+    Y6_REQUIRE(d->out.B == d->in.B && d->out.H == 2 * d->in.H && d->out.W == 2 * d->in.W, "convt2x2: output must be 2x input");
+    const size_t per = y6_packed_weight_elems(d->out.C, d->in.C, 1);
+    for (int sub = 0; sub < 4; ++sub) {
+        y6_conv_desc c;
+        memset(&c, 0, sizeof(c));
+        c.in = d->in;
+        c.out = d->out;
+        // the 1x1 sub-conv runs over the INPUT grid; the kernel scatters to (2y+dy, 2x+dx)
+        c.out.H = d->in.H;
+        c.out.W = d->in.W;
+        c.w_packed = (const __half*)d->w_packed + sub * per;
+        c.bias = d->bias;
+        c.ksize = 1;
+        c.stride = 1;
+        c.act = Y6_ACT_NONE;
+        int v = -1;
+        const int prefs[] = {6, 5, 4, 3, 2, 1};
+        for (int i = 0; i < 6; ++i)
+            if (y6_conv_mfma_supports(&c, prefs[i])) {
+                v = prefs[i];
+                break;
+            }
+        Y6_REQUIRE(v > 0, "convt2x2: unsupported shape Cin %d Cout %d", d->in.C, d->out.C);
+        int rc = y6_conv_mfma_launch(&c, v, (hipStream_t)stream, 1, sub >> 1, sub & 1);
+        if (rc) return rc;
+    }
+    return Y6_OK;
+}
+
+extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
+    Y6_REQUIRE(d && d->in_nchw && d->out.data && d->w_oihw_f32, "stem_conv: null argument");
+    const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
+    Y6_REQUIRE(d->out.B == d->B && d->out.H == Ho && d->out.W == Wo, "stem_conv: bad output shape");
+    Y6_REQUIRE(d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "stem_conv: output slice must be 8-channel aligned");
+    const int CO = d->out.C;
+    const size_t total = (size_t)d->B * Ho * Wo;
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define Y6_STEM_CASE(TI, CO_)                                                                                      \
+    hipLaunchKernelGGL((stem_conv_kernel<TI, CO_>), grid, block, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data, \
+                       d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo,      \
+                       d->out.cstride, d->out.coff, d->act)
+    if (d->in_dtype == Y6_F16) {
+        switch (CO) {
+            case 8: Y6_STEM_CASE(__half, 8); break;
+            case 16: Y6_STEM_CASE(__half, 16); break;
+            case 32: Y6_STEM_CASE(__half, 32); break;
+            case 48: Y6_STEM_CASE(__half, 48); break;
+            case 64: Y6_STEM_CASE(__half, 64); break;
+            default: Y6_REQUIRE(false, "stem_conv: Cout %d unsupported (8,16,32,48,64)", CO);
+        }
+    } else if (d->in_dtype == Y6_F32) {
+        switch (CO) {
+            case 8: Y6_STEM_CASE(float, 8); break;
+            case 16: Y6_STEM_CASE(float, 16); break;
+            case 32: Y6_STEM_CASE(float, 32); break;
+            case 48: Y6_STEM_CASE(float, 48); break;
+            case 64: Y6_STEM_CASE(float, 64); break;
+            default: Y6_REQUIRE(false, "stem_conv: Cout %d unsupported (8,16,32,48,64)", CO);
+        }
+    } else {
+        Y6_REQUIRE(false, "stem_conv: bad input dtype");
+    }
+#undef Y6_STEM_CASE
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3,
+                            void* stream) {
+    Y6_REQUIRE(x && y1 && y2 && y3 && x->data && y1->data && y2->data && y3->data, "sppf_pool: null tensor");
+    Y6_REQUIRE(x->C % 8 == 0 && x->coff % 8 == 0 && x->cstride % 8 == 0, "sppf_pool: channels must be 8-aligned");
+    const y6_tensor* ys[3] = {y1, y2, y3};
+    for (int i = 0; i < 3; ++i)
+        Y6_REQUIRE(ys[i]->B == x->B && ys[i]->H == x->H && ys[i]->W == x->W && ys[i]->C == x->C &&
+                       ys[i]->coff % 8 == 0 && ys[i]->cstride % 8 == 0,
+                   "sppf_pool: output %d shape/alignment mismatch", i);
+    const size_t lds = (size_t)x->H * x->W * 16 * 2;
+    Y6_REQUIRE(lds <= 160 * 1024, "sppf_pool: plane %dx%d too large for LDS", x->H, x->W);
+    if (lds > 64 * 1024)
+        Y6_HIP(hipFuncSetAttribute((const void*)sppf_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int C8 = x->C / 8;
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3(x->B * C8), dim3(256), lds, (hipStream_t)stream, (const __half*)x->data,
+                       x->cstride, x->coff, (__half*)y1->data, y1->cstride, y1->coff, (__half*)y2->data, y2->cstride,
+                       y2->coff, (__half*)y3->data, y3->cstride, y3->coff, x->H, x->W, C8);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_nchw_to_nhwc(const void* src, int src_dtype, const y6_tensor* dst, void* stream) {
+    Y6_REQUIRE(src && dst && dst->data, "nchw_to_nhwc: null argument");
+    const size_t total = (size_t)dst->B * dst->H * dst->W * dst->C;
+    dim3 grid(grid_for(total, 256)), block(256);
+    if (src_dtype == Y6_F16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<__half>, grid, block, 0, (hipStream_t)stream, (const __half*)src,
+                           (__half*)dst->data, dst->B, dst->C, dst->H, dst->W, dst->cstride, dst->coff);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)src,
+                           (__half*)dst->data, dst->B, dst->C, dst->H, dst->W, dst->cstride, dst->coff);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_nhwc_to_nchw(const y6_tensor* src, void* dst, int dst_dtype, void* stream) {
+    Y6_REQUIRE(src && dst && src->data, "nhwc_to_nchw: null argument");
+    const size_t total = (size_t)src->B * src->H * src->W * src->C;
+    dim3 grid(grid_for(total, 256)), block(256);
+    if (dst_dtype == Y6_F16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<__half>, grid, block, 0, (hipStream_t)stream, (const __half*)src->data,
+                           (__half*)dst, src->B, src->C, src->H, src->W, src->cstride, src->coff);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, (hipStream_t)stream, (const __half*)src->data,
+                           (float*)dst, src->B, src->C, src->H, src->W, src->cstride, src->coff);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

@@ -1,0 +1,123 @@
+// head_decode.hip — EffiDeHead eval epilogue.
+// Restates Detect.forward eval branch (reference yolov6/models/effidehead.py:93-139):
+//   cls = sigmoid(cls_logits); reg = (use_dfl ? proj . softmax(bins) : reg)
+//   anchor_points = (x+0.5, y+0.5), stride per level  (assigners/anchor_generator.py:13-33)
+//   box = dist2bbox(reg, anchor_points, 'xywh') * stride   (utils/general.py:32-43)
+//   out[b, a, :] = (cx, cy, w, h, 1.0, cls[0..nc))   fp32, levels concatenated along a.
+// One thread per output element -> fully coalesced fp32 stores; the fp16 NHWC logits of a
+// pixel are contiguous so the class reads coalesce too.
+#include "common.hpp"
+
+namespace {
+
+struct DecodeArgs {
+    int n_levels;
+    const __half* cls[Y6_MAX_LEVELS];
+    const __half* reg[Y6_MAX_LEVELS];
+    int cls_cs[Y6_MAX_LEVELS], cls_co[Y6_MAX_LEVELS];
+    int reg_cs[Y6_MAX_LEVELS], reg_co[Y6_MAX_LEVELS];
+    int H[Y6_MAX_LEVELS], W[Y6_MAX_LEVELS];
+    int astart[Y6_MAX_LEVELS + 1];  // first anchor of each level
+    float stride[Y6_MAX_LEVELS];
+    int use_dfl, reg_max;
+    const float* proj;
+    float cell_offset;
+    float* out;
+    int B, A, nc;
+};
+
+__device__ __forceinline__ float side_dist(const DecodeArgs& a, int l, size_t pix, int side) {
+    const __half* r = a.reg[l] + pix * a.reg_cs[l] + a.reg_co[l];
+    if (!a.use_dfl) return __half2float(r[side]);
+    const int nb = a.reg_max + 1;
+    const __half* bins = r + side * nb;
+    float m = -INFINITY;
+    for (int k = 0; k < nb; ++k) m = fmaxf(m, __half2float(bins[k]));
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < nb; ++k) {
+        const float e = __expf(__half2float(bins[k]) - m);
+        den += e;
+        num += e * a.proj[k];
+    }
+    return num / den;
+}
+
+__global__ void head_decode_kernel(const DecodeArgs a) {
+    const int no = a.nc + 5;
+    const size_t total = (size_t)a.B * a.A * no;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % no);
+        const size_t ba = i / no;
+        const int an = (int)(ba % a.A);
+        const int b = (int)(ba / a.A);
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < Y6_MAX_LEVELS; ++t)
+            if (t < a.n_levels && an >= a.astart[t]) l = t;
+        const int local = an - a.astart[l];
+        const int y = local / a.W[l], x = local - y * a.W[l];
+        const size_t pix = ((size_t)b * a.H[l] + y) * a.W[l] + x;
+        float v;
+        if (j >= 5) {
+            const float z = __half2float(a.cls[l][pix * a.cls_cs[l] + a.cls_co[l] + (j - 5)]);
+            v = 1.f / (1.f + __expf(-z));
+        } else if (j == 4) {
+            v = 1.f;
+        } else {
+            // (l,t,r,b) distances -> xywh
+            const int ax = j & 1;  // 0: x / w, 1: y / h
+            const float lo = side_dist(a, l, pix, ax);       // left or top
+            const float hi = side_dist(a, l, pix, 2 + ax);   // right or bottom
+            const float ap = (ax == 0 ? (float)x : (float)y) + a.cell_offset;
+            const float p1 = ap - lo, p2 = ap + hi;
+            v = (j < 2) ? (p1 + p2) / 2.f : (p2 - p1);
+            v *= a.stride[l];
+        }
+        a.out[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
+    Y6_REQUIRE(d && d->out && d->n_levels >= 1 && d->n_levels <= Y6_MAX_LEVELS, "head_decode: bad descriptor");
+    Y6_REQUIRE(!d->use_dfl || d->proj, "head_decode: use_dfl needs proj");
+    DecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_levels = d->n_levels;
+    int A = 0;
+    const int nreg = 4 * (d->use_dfl ? d->reg_max + 1 : 1);
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor &c = d->cls[l], &r = d->reg[l];
+        Y6_REQUIRE(c.data && r.data, "head_decode: level %d null tensor", l);
+        Y6_REQUIRE(c.C == d->nc && r.C == nreg, "head_decode: level %d channels cls %d (want %d) reg %d (want %d)", l, c.C,
+                   d->nc, r.C, nreg);
+        Y6_REQUIRE(c.B == r.B && c.H == r.H && c.W == r.W && c.B == d->cls[0].B, "head_decode: level %d shape mismatch", l);
+        a.cls[l] = (const __half*)c.data;
+        a.reg[l] = (const __half*)r.data;
+        a.cls_cs[l] = c.cstride;
+        a.cls_co[l] = c.coff;
+        a.reg_cs[l] = r.cstride;
+        a.reg_co[l] = r.coff;
+        a.H[l] = c.H;
+        a.W[l] = c.W;
+        a.astart[l] = A;
+        a.stride[l] = d->stride[l];
+        A += c.H * c.W;
+    }
+    a.astart[d->n_levels] = A;
+    a.use_dfl = d->use_dfl;
+    a.reg_max = d->reg_max;
+    a.proj = d->proj;
+    a.cell_offset = d->grid_cell_offset;
+    a.out = d->out;
+    a.B = d->cls[0].B;
+    a.A = A;
+    a.nc = d->nc;
+    const size_t total = (size_t)a.B * A * (d->nc + 5);
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

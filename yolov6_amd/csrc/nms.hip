@@ -1,0 +1,313 @@
+// nms.hip — batched, class-aware NMS on the device.
+// Restates non_max_suppression (reference yolov6/utils/nms.py:31-105) and the
+// torchvision.ops.nms it calls at :96 (torchvision is an un-vendored dependency; its
+// published algorithm: stable sort by score descending, greedy sweep, suppress j when
+// IoU(i,j) > thr with IoU = inter / (area_i + area_j - inter), fp32, no +1, no eps).
+//
+// Stage 1 (nms_candidates_kernel): one wave per anchor row; rows that pass
+//   obj > conf AND max(cls) > conf (nms.py:48) emit (conf = cls*obj (:69), class) candidates
+//   (multi-label: every class with conf > thr (:75-77); else best class (:79-80)), filtered
+//   by `classes` (:83-84), appended with one atomic per wave.  A candidate is a 64-bit key
+//   (conf bits << 32 | ~flat) with flat = anchor*nc + cls, so a descending key sort IS the
+//   reference's "score descending, earlier row first" order.
+// Stage 2 (nms_sort_sweep_kernel): one 1024-thread block per image: bitonic sort of the keys
+//   (LDS when they fit, workspace otherwise), cap to max_nms (:90-91), build the xyxy boxes
+//   (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95), then the greedy sweep: the next
+//   surviving box is found by a wave ballot over the removed-bitmask, every later box is
+//   tested against it in parallel, until max_det (:97-98) boxes are kept.
+// Compile with -ffp-contract=off: index parity needs the reference's unfused fp32 arithmetic.
+#include "common.hpp"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classes) {
+    if (!classes) return true;
+    for (int k = 0; k < n_classes; ++k)
+        if (classes[k] == j) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int B, int A, int nc,
+                                                             float conf_thres, const int* __restrict__ classes,
+                                                             int n_classes, int multi_label, u64* __restrict__ keys,
+                                                             size_t cap, int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const size_t gw = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int no = nc + 5;
+    const size_t rows = (size_t)B * A;
+    for (size_t idx = gw; idx < rows; idx += nw) {
+        const int b = (int)(idx / A), an = (int)(idx % A);
+        const float* row = pred + idx * no;
+        const float obj = row[4];
+        if (!(obj > conf_thres)) continue;
+        float mx = -INFINITY;
+        for (int j = lane; j < nc; j += 64) mx = fmaxf(mx, row[5 + j]);
+        mx = wave_max(mx);
+        if (!(mx > conf_thres)) continue;
+        u64* kb = keys + (size_t)b * cap;
+        if (multi_label) {
+            for (int j0 = 0; j0 < nc; j0 += 64) {
+                const int j = j0 + lane;
+                float c = 0.f;
+                bool pass = false;
+                if (j < nc) {
+                    c = row[5 + j] * obj;
+                    pass = (c > conf_thres) && class_ok(j, classes, n_classes);
+                }
+                const u64 bal = __ballot(pass);
+                if (bal == 0) continue;
+                const int n = __popcll(bal);
+                const int leader = __ffsll((long long)bal) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&counts[b], n);
+                base = __shfl(base, leader, 64);
+                if (pass) {
+                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)j;
+                    kb[pos] = ((u64)__float_as_uint(c) << 32) | (u64)(0xFFFFFFFFu - flat);
+                }
+            }
+        } else {
+            // best class: max conf, first (lowest) class index on ties (torch.max semantics)
+            float bc = -INFINITY;
+            int bj = 0x7fffffff;
+            for (int j = lane; j < nc; j += 64) {
+                const float c = row[5 + j] * obj;
+                if (c > bc) {
+                    bc = c;
+                    bj = j;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float oc = __shfl_xor(bc, o, 64);
+                const int oj = __shfl_xor(bj, o, 64);
+                if (oc > bc || (oc == bc && oj < bj)) {
+                    bc = oc;
+                    bj = oj;
+                }
+            }
+            if (lane == 0 && bc > conf_thres && class_ok(bj, classes, n_classes)) {
+                const int pos = atomicAdd(&counts[b], 1);
+                const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)bj;
+                kb[pos] = ((u64)__float_as_uint(bc) << 32) | (u64)(0xFFFFFFFFu - flat);
+            }
+        }
+    }
+}
+
+// descending bitonic sort of P (power of two) keys by the whole block
+__device__ void bitonic_desc(u64* keys, int P) {
+    const int T = blockDim.x;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += T) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const u64 x = keys[i], y = keys[ixj];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+constexpr int kLdsKeys = 16384;  // 128 KiB of 64-bit keys
+
+__global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __restrict__ pred, int A, int nc,
+                                                              float iou_thres, int agnostic, int max_det, int max_nms,
+                                                              float max_wh, u64* __restrict__ keys, size_t cap,
+                                                              const int* __restrict__ counts, float4* __restrict__ boxes,
+                                                              float* __restrict__ out_dets, int* __restrict__ out_index,
+                                                              int* __restrict__ out_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int T = blockDim.x;
+    int n = counts[b];
+    if (n <= 0) {
+        if (tid == 0) out_count[b] = 0;
+        return;
+    }
+    u64* gk = keys + (size_t)b * cap;
+    int P = 1;
+    while (P < n) P <<= 1;
+    u64* sk;
+    if (P <= kLdsKeys) {
+        sk = reinterpret_cast<u64*>(smem);
+        for (int i = tid; i < P; i += T) sk[i] = i < n ? gk[i] : 0ull;
+    } else {
+        sk = gk;  // cap is a power of two >= P
+        for (int i = n + tid; i < P; i += T) sk[i] = 0ull;
+    }
+    __syncthreads();
+    bitonic_desc(sk, P);
+    if (n > max_nms) n = max_nms;
+
+    // sorted boxes (class-offset xyxy) to the workspace; keep flat ids next to them
+    float4* bx = boxes + (size_t)b * max_nms;
+    const int no = nc + 5;
+    for (int i = tid; i < n; i += T) {
+        const u64 key = sk[i];
+        const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
+        const float* row = pred + ((size_t)b * A + an) * no;
+        const float x = row[0], y = row[1], w = row[2], h = row[3];
+        const float off = agnostic ? 0.f : (float)cls * max_wh;
+        float4 q;
+        q.x = (x - w / 2.f) + off;
+        q.y = (y - h / 2.f) + off;
+        q.z = (x + w / 2.f) + off;
+        q.w = (y + h / 2.f) + off;
+        bx[i] = q;
+        if (sk != gk) gk[i] = key;  // sorted keys back to global for the output stage
+    }
+    __syncthreads();
+
+    // removed bitmask in LDS (the key area is dead now when it lived in LDS; reuse its head)
+    u64* removed = reinterpret_cast<u64*>(smem);
+    const int nwords = (n + 63) >> 6;
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < nwords; i += T) removed[i] = 0ull;
+    __syncthreads();
+
+    const int lane = tid & 63;
+    int kept = 0;
+    int cur = 0;
+    while (kept < max_det) {
+        // every wave finds the first surviving index >= cur (identical result in all waves)
+        int found = -1;
+        for (int w0 = cur >> 6; w0 < nwords && found < 0; w0 += 64) {
+            const int wi = w0 + lane;
+            u64 alive = 0ull;
+            if (wi < nwords) {
+                alive = ~removed[wi];
+                if (wi == (cur >> 6)) alive &= ~((1ull << (cur & 63)) - 1ull);
+                const int base = wi << 6;
+                if (base + 64 > n) alive &= (n - base >= 64) ? ~0ull : ((1ull << (n - base)) - 1ull);
+            }
+            const u64 bal = __ballot(alive != 0ull);
+            if (bal) {
+                const int src = __ffsll((long long)bal) - 1;
+                const u64 wv = __shfl(alive, src, 64);
+                found = ((w0 + src) << 6) + (__ffsll((long long)wv) - 1);
+            }
+        }
+        if (found < 0) break;
+        const int i = found;
+        const float4 bi = bx[i];
+        if (tid == 0) {
+            const u64 key = gk[i];
+            const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
+            const float* row = pred + ((size_t)b * A + an) * no;
+            const float x = row[0], y = row[1], w = row[2], h = row[3];
+            float* o = out_dets + ((size_t)b * max_det + kept) * 6;
+            o[0] = x - w / 2.f;
+            o[1] = y - h / 2.f;
+            o[2] = x + w / 2.f;
+            o[3] = y + h / 2.f;
+            o[4] = __uint_as_float((unsigned)(key >> 32));
+            o[5] = (float)cls;
+            out_index[(size_t)b * max_det + kept] = (int)flat;
+        }
+        ++kept;
+        if (kept >= max_det) break;
+        const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+        for (int j = i + 1 + tid; j < n; j += T) {
+            if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
+            const float4 bj = bx[j];
+            const float left = fmaxf(bi.x, bj.x), right = fminf(bi.z, bj.z);
+            const float top = fmaxf(bi.y, bj.y), bottom = fminf(bi.w, bj.w);
+            const float iw = fmaxf(right - left, 0.f), ih = fmaxf(bottom - top, 0.f);
+            const float inter = iw * ih;
+            const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+            const float iou = inter / (area_i + area_j - inter);
+            if (iou > iou_thres) atomicOr(&removed[j >> 6], 1ull << (j & 63));
+        }
+        __syncthreads();
+        cur = i + 1;
+        if (cur >= n) break;
+    }
+    if (tid == 0) out_count[b] = kept;
+}
+
+inline size_t next_pow2(size_t v) {
+    size_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct NmsWs {
+    size_t cap;       // keys per image (power of two)
+    size_t off_keys, off_boxes, off_counts, total;
+};
+NmsWs nms_ws_layout(int B, int A, int nc, int multi_label, int max_nms) {
+    NmsWs w;
+    const bool ml = multi_label && nc > 1;
+    w.cap = next_pow2(ml ? (size_t)A * nc : (size_t)A);
+    w.off_keys = 0;
+    w.off_boxes = align256(w.off_keys + (size_t)B * w.cap * sizeof(u64));
+    w.off_counts = align256(w.off_boxes + (size_t)B * max_nms * sizeof(float4));
+    w.total = align256(w.off_counts + (size_t)B * sizeof(int));
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t y6_nms_workspace_bytes(int B, int A, int nc, int multi_label) {
+    return nms_ws_layout(B, A, nc, multi_label, 30000).total;
+}
+
+extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
+    Y6_REQUIRE(d && d->pred && d->out_dets && d->out_index && d->out_count && d->workspace, "nms: null argument");
+    Y6_REQUIRE(d->conf_thres >= 0.f && d->conf_thres <= 1.f, "conf_thresh must be in 0.0 to 1.0, however %g is provided.",
+               (double)d->conf_thres);
+    Y6_REQUIRE(d->iou_thres >= 0.f && d->iou_thres <= 1.f, "iou_thres must be in 0.0 to 1.0, however %g is provided.",
+               (double)d->iou_thres);
+    Y6_REQUIRE(d->B > 0 && d->A > 0 && d->nc > 0 && d->max_det > 0, "nms: bad sizes");
+    Y6_REQUIRE(d->max_nms > 0 && d->max_nms <= 30000, "nms: max_nms must be in (0, 30000]");
+    Y6_REQUIRE((size_t)d->A * d->nc < 0xFFFFFFFFull, "nms: A*nc overflows the 32-bit candidate id");
+    const int ml = d->multi_label && d->nc > 1;
+    const NmsWs w = nms_ws_layout(d->B, d->A, d->nc, ml, 30000);
+    Y6_REQUIRE(d->workspace_bytes >= w.total, "nms: workspace too small (%zu < %zu)", d->workspace_bytes, w.total);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)d->workspace;
+    u64* keys = (u64*)(ws + w.off_keys);
+    float4* boxes = (float4*)(ws + w.off_boxes);
+    int* counts = (int*)(ws + w.off_counts);
+    Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * sizeof(int), s));
+    const size_t rows = (size_t)d->B * d->A;
+    size_t blocks = (rows + 3) / 4;  // one wave per row
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d->pred, d->B, d->A, d->nc,
+                       d->conf_thres, d->classes, d->n_classes, ml, keys, w.cap, counts);
+    Y6_LAUNCH_CHECK();
+    const size_t lds = (size_t)kLdsKeys * sizeof(u64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        Y6_HIP(hipFuncSetAttribute((const void*)nms_sort_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_sort_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres,
+                       d->agnostic, d->max_det, d->max_nms, d->max_wh, keys, w.cap, counts, boxes, d->out_dets,
+                       d->out_index, d->out_count);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

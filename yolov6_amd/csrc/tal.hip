@@ -1,0 +1,274 @@
+// tal.hip — Task-aligned assigner without the [B,G,topk,A] one-hot temp.
+// Restates TaskAlignedAssigner.forward (reference yolov6/assigners/tal_assigner.py:22-106):
+//   T1 (per (b,g) block)  get_box_metrics :125-141 + select_candidates_in_gts
+//        (assigner_utils.py:25-44) + select_topk_candidates :143-158: the metric row lives in
+//        LDS, top-k is k rounds of a block arg-max (value desc, anchor index asc), winners
+//        that are inside the gt bump fg_cnt[b,a] and atomicMin first_g[b,a].
+//   T2 (per (b,a) thread) select_highest_overlaps (assigner_utils.py:46-67): anchors claimed
+//        by >1 gt go to argmax_g IoU over ALL gts (first max), others keep their gt; the
+//        chosen (b,g,a) metric / IoU feed atomicMax pos_align[b,g], pos_ov[b,g]  (:76-78).
+//   T3a/T3b  get_targets :160-181 + normalisation :76-81:
+//        norm = align * pos_ov / (pos_align + eps); target_scores = one_hot(label) * norm.
+// Ties: torch.topk's tie order is unspecified; this kernel (and the oracle) define
+// "lower anchor index wins" (SURVEY §7 hard parts).  Compile with -ffp-contract=off.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float iou_gt_pd(const float4 g, const float4 p, float eps) {
+    // iou_calculator(box1=gt, box2=pd)  assigner_utils.py:69-89
+    const float x1 = fmaxf(g.x, p.x), y1 = fmaxf(g.y, p.y);
+    const float x2 = fminf(g.z, p.z), y2 = fminf(g.w, p.w);
+    const float ow = fmaxf(x2 - x1, 0.f), oh = fmaxf(y2 - y1, 0.f);
+    const float overlap = ow * oh;
+    const float a1 = fmaxf(g.z - g.x, 0.f) * fmaxf(g.w - g.y, 0.f);
+    const float a2 = fmaxf(p.z - p.x, 0.f) * fmaxf(p.w - p.y, 0.f);
+    const float uni = a1 + a2 - overlap + eps;
+    return overlap / uni;
+}
+
+__device__ __forceinline__ float align_metric(float score, float iou, float alpha, float beta) {
+    const float s = (alpha == 1.f) ? score : powf(score, alpha);
+    const float o = powf(iou, beta);
+    return s * o;
+}
+
+__device__ __forceinline__ bool in_gt(const float2 c, const float4 g, float eps) {
+    const float m = fminf(fminf(c.x - g.x, c.y - g.y), fminf(g.z - c.x, g.w - c.y));
+    return m > eps;
+}
+
+__device__ __forceinline__ int gt_label(const float* gt_labels, size_t bg) {
+    return (int)(long long)gt_labels[bg];
+}
+
+struct TalArgs {
+    const float* pd_scores;
+    const float4* pd_bboxes;
+    const float2* anc;
+    const float* gt_labels;
+    const float4* gt_bboxes;
+    const float* mask_gt;
+    int B, A, C, G, topk;
+    float alpha, beta, eps;
+    int* fg_cnt;
+    int* first_g;
+    int* assign;
+    float* norm;
+    unsigned* pos_am;
+    unsigned* pos_ov;
+    long long* target_labels;
+    float4* target_bboxes;
+    float* target_scores;
+    unsigned char* fg_mask;
+};
+
+__global__ __launch_bounds__(256) void tal_topk_kernel(const TalArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* vals = reinterpret_cast<float*>(smem);  // [A]
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    const int bg = blockIdx.x;
+    const int b = bg / a.G;
+    if (!(a.mask_gt[bg] != 0.f)) return;  // padded gt: topk_idxs forced to 0, then de-duplicated to nothing (:152-156)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 g = a.gt_bboxes[bg];
+    const int label = gt_label(a.gt_labels, bg);
+    const float* sc = a.pd_scores + (size_t)b * a.A * a.C + label;
+    const float4* pb = a.pd_bboxes + (size_t)b * a.A;
+    for (int an = tid; an < a.A; an += 256) {
+        const float iou = iou_gt_pd(g, pb[an], 1e-9f);
+        const float m = align_metric(sc[(size_t)an * a.C], iou, a.alpha, a.beta);
+        vals[an] = in_gt(a.anc[an], g, 1e-9f) ? m : 0.f * m;  // metrics * mask_in_gts (:116)
+    }
+    __syncthreads();
+    const int k = a.topk < a.A ? a.topk : a.A;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int an = tid; an < a.A; an += 256) {
+            const float v = vals[an];
+            if (v > bv) {  // ascending scan: first (lowest index) max per thread
+                bv = v;
+                bi = an;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_i[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+                    bv = s_v[w];
+                    bi = s_i[w];
+                }
+            if (bi < a.A) {
+                vals[bi] = -INFINITY;  // taken
+                if (in_gt(a.anc[bi], g, 1e-9f)) {  // mask_pos = mask_topk * mask_in_gts * mask_gt (:121)
+                    atomicAdd(&a.fg_cnt[(size_t)b * a.A + bi], 1);
+                    atomicMin(&a.first_g[(size_t)b * a.A + bi], bg - b * a.G);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void tal_resolve_kernel(const TalArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.B * a.A) return;
+    const int b = (int)(i / a.A), an = (int)(i % a.A);
+    const int cnt = a.fg_cnt[i];
+    int gsel = -1;
+    const float4 p = a.pd_bboxes[i];
+    if (cnt == 1) {
+        gsel = a.first_g[i];
+    } else if (cnt > 1) {
+        // overlaps.argmax(axis=1) over ALL gts, first max (assigner_utils.py:60-63)
+        float best = -INFINITY;
+        for (int g = 0; g < a.G; ++g) {
+            const float o = iou_gt_pd(a.gt_bboxes[(size_t)b * a.G + g], p, 1e-9f);
+            if (o > best) {
+                best = o;
+                gsel = g;
+            }
+        }
+    }
+    a.assign[i] = gsel;
+    if (gsel >= 0) {
+        const size_t bg = (size_t)b * a.G + gsel;
+        const float iou = iou_gt_pd(a.gt_bboxes[bg], p, 1e-9f);
+        const int label = gt_label(a.gt_labels, bg);
+        const float m = align_metric(a.pd_scores[i * a.C + label], iou, a.alpha, a.beta);
+        atomicMax(&a.pos_am[bg], __float_as_uint(m));    // values are >= 0: uint order == float order
+        atomicMax(&a.pos_ov[bg], __float_as_uint(iou));
+        a.norm[i] = m;  // raw align metric; normalised in T3a
+    }
+}
+
+__global__ __launch_bounds__(256) void tal_targets_kernel(const TalArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.B * a.A) return;
+    const int b = (int)(i / a.A);
+    const int gsel = a.assign[i];
+    const int g0 = gsel >= 0 ? gsel : 0;  // mask_pos.argmax(-2) of an all-zero column is 0 (:66)
+    const size_t bg = (size_t)b * a.G + g0;
+    int label = gt_label(a.gt_labels, bg);
+    if (label < 0) label = 0;  // target_labels[target_labels<0] = 0 (:172)
+    a.target_labels[i] = label;
+    a.target_bboxes[i] = a.gt_bboxes[bg];
+    a.fg_mask[i] = gsel >= 0 ? 1 : 0;
+    float nrm = 0.f;
+    if (gsel >= 0) {
+        const float am = a.norm[i];
+        const float pov = __uint_as_float(a.pos_ov[bg]);
+        const float pam = __uint_as_float(a.pos_am[bg]);
+        nrm = am * pov / (pam + a.eps);
+    }
+    a.norm[i] = nrm;
+}
+
+__global__ __launch_bounds__(256) void tal_scores_kernel(const TalArgs a) {
+    const size_t total = (size_t)a.B * a.A * a.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ba = i / a.C;
+        const int c = (int)(i - ba * a.C);
+        float v = 0.f;
+        if (a.assign[ba] >= 0 && (long long)c == a.target_labels[ba]) v = a.norm[ba];
+        a.target_scores[i] = v;
+    }
+}
+
+__global__ void tal_empty_kernel(const TalArgs a) {
+    // n_max_boxes == 0 early-out (:48-53): labels = bg_idx, everything else zero
+    const size_t total = (size_t)a.B * a.A;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        a.target_labels[i] = a.C;
+        a.target_bboxes[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.fg_mask[i] = 0;
+    }
+}
+
+inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t y6_tal_workspace_bytes(int B, int A, int G) {
+    const size_t ba = (size_t)B * A * 4, bgn = (size_t)B * (G > 0 ? G : 1) * 4;
+    return 4 * al256(ba) + 2 * al256(bgn);
+}
+
+extern "C" int y6_tal_assign(const y6_tal_desc* d, void* stream) {
+    Y6_REQUIRE(d && d->pd_scores && d->pd_bboxes && d->anc_points && d->target_labels && d->target_bboxes &&
+                   d->target_scores && d->fg_mask,
+               "tal_assign: null argument");
+    Y6_REQUIRE(d->B > 0 && d->A > 0 && d->C > 0 && d->G >= 0 && d->topk > 0, "tal_assign: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    TalArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pd_scores = d->pd_scores;
+    a.pd_bboxes = (const float4*)d->pd_bboxes;
+    a.anc = (const float2*)d->anc_points;
+    a.gt_labels = d->gt_labels;
+    a.gt_bboxes = (const float4*)d->gt_bboxes;
+    a.mask_gt = d->mask_gt;
+    a.B = d->B;
+    a.A = d->A;
+    a.C = d->C;
+    a.G = d->G;
+    a.topk = d->topk;
+    a.alpha = d->alpha;
+    a.beta = d->beta;
+    a.eps = d->eps;
+    a.target_labels = (long long*)d->target_labels;
+    a.target_bboxes = (float4*)d->target_bboxes;
+    a.target_scores = d->target_scores;
+    a.fg_mask = d->fg_mask;
+    const size_t nba = (size_t)d->B * d->A;
+    if (d->G == 0) {
+        hipLaunchKernelGGL(tal_empty_kernel, dim3(1024), dim3(256), 0, s, a);
+        Y6_LAUNCH_CHECK();
+        Y6_HIP(hipMemsetAsync(d->target_scores, 0, nba * d->C * sizeof(float), s));
+        return Y6_OK;
+    }
+    Y6_REQUIRE(d->gt_labels && d->gt_bboxes && d->mask_gt && d->workspace, "tal_assign: null gt / workspace");
+    Y6_REQUIRE(d->workspace_bytes >= y6_tal_workspace_bytes(d->B, d->A, d->G), "tal_assign: workspace too small");
+    Y6_REQUIRE((size_t)d->A * 4 <= 160 * 1024 - 64, "tal_assign: A=%d does not fit the LDS metric row", d->A);
+    char* ws = (char*)d->workspace;
+    const size_t ba = al256(nba * 4), bgn = al256((size_t)d->B * d->G * 4);
+    a.fg_cnt = (int*)ws;
+    a.first_g = (int*)(ws + ba);
+    a.assign = (int*)(ws + 2 * ba);
+    a.norm = (float*)(ws + 3 * ba);
+    a.pos_am = (unsigned*)(ws + 4 * ba);
+    a.pos_ov = (unsigned*)(ws + 4 * ba + bgn);
+    Y6_HIP(hipMemsetAsync(a.fg_cnt, 0, nba * 4, s));
+    Y6_HIP(hipMemsetAsync(a.first_g, 0x7f, nba * 4, s));
+    Y6_HIP(hipMemsetAsync(a.pos_am, 0, 2 * bgn, s));
+    const size_t lds = (size_t)d->A * 4;
+    if (lds > 64 * 1024)
+        Y6_HIP(hipFuncSetAttribute((const void*)tal_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(tal_topk_kernel, dim3(d->B * d->G), dim3(256), lds, s, a);
+    Y6_LAUNCH_CHECK();
+    const unsigned nb = (unsigned)((nba + 255) / 256);
+    hipLaunchKernelGGL(tal_resolve_kernel, dim3(nb), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tal_targets_kernel, dim3(nb), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    size_t g = (nba * d->C + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(tal_scores_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

@@ -1,0 +1,304 @@
+"""Plan builder: lowers the module tree (yolov6_amd.layers / .models) into a native
+`y6_plan` (yolov6_amd/csrc/plan.hip) of HIP kernel launches over NHWC fp16 buffers.
+
+torch provides device memory (buffers, packed weights) and the stream; all compute goes
+through the C ABI in include/yolov6_hip.h.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT_BY_NAME, Y6_F16, Y6_F32
+
+
+@dataclass
+class TRef:
+    """View [B,H,W,C] of an NHWC fp16 buffer: channels [coff, coff+C) of `cstride`."""
+    buf: torch.Tensor
+    B: int
+    H: int
+    W: int
+    C: int
+    cstride: int
+    coff: int = 0
+
+    def slice(self, c0: int, n: int) -> "TRef":
+        assert 0 <= c0 and c0 + n <= self.C
+        return TRef(self.buf, self.B, self.H, self.W, n, self.cstride, self.coff + c0)
+
+    def ct(self) -> _lib.Tensor:
+        return _lib.Tensor(C.c_void_p(self.buf.data_ptr()), self.B, self.H, self.W, self.C, self.cstride, self.coff)
+
+    def to_nhwc_tensor(self) -> torch.Tensor:
+        """torch view [B,H,W,C] (for tests/debug)."""
+        return self.buf.view(self.B, self.H, self.W, self.cstride)[..., self.coff:self.coff + self.C]
+
+
+@dataclass
+class NCHWInput:
+    """The caller's NCHW image/feature tensor (fp16 or fp32), not yet in the NHWC domain."""
+    t: torch.Tensor
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+
+def _dtype_tag(t: torch.Tensor) -> int:
+    if t.dtype == torch.float16:
+        return Y6_F16
+    if t.dtype == torch.float32:
+        return Y6_F32
+    raise RuntimeError(f"yolov6_amd: unsupported dtype {t.dtype} (fp16 / fp32 only)")
+
+
+def _null_tensor() -> _lib.Tensor:
+    return _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+
+
+class Plan:
+    """A finalized native plan; run() enqueues every kernel on the current stream."""
+
+    def __init__(self, handle, keep, outputs, inputs=()):
+        self._lib = _lib.load()
+        self._h = handle
+        self._keep = keep
+        self.outputs = outputs
+        self.inputs = list(inputs)   # caller tensors the first ops read (rebindable)
+        self.captured = False
+
+    def bind_inputs(self, tensors):
+        """Zero-copy: point the plan at new input tensors of the same shape/dtype."""
+        for i, (old, new) in enumerate(zip(self.inputs, tensors)):
+            if new.data_ptr() == old.data_ptr():
+                continue
+            if new.shape != old.shape or new.dtype != old.dtype or not new.is_contiguous():
+                raise RuntimeError("yolov6_amd: rebinding needs a contiguous tensor of the compiled shape/dtype")
+            if self.captured:   # a captured graph baked the address: stage through the bound tensor
+                old.copy_(new)
+                continue
+            rc = self._lib.y6_plan_rebind(self._h, C.c_void_p(old.data_ptr()), C.c_void_p(new.data_ptr()))
+            if rc < 0:
+                _lib.check(rc, "plan_rebind")
+            self.inputs[i] = new
+
+    def run(self):
+        _lib.check(self._lib.y6_plan_run(self._h, _lib.current_stream_ptr()), "plan_run")
+        return self.outputs
+
+    def autotune(self, iters: int = 3):
+        _lib.check(self._lib.y6_plan_autotune(self._h, _lib.current_stream_ptr(), iters), "plan_autotune")
+
+    def capture(self):
+        """Capture into a hipGraph (needs a non-default stream current)."""
+        _lib.check(self._lib.y6_plan_capture(self._h, _lib.current_stream_ptr()), "plan_capture")
+        self.captured = True
+
+    @property
+    def num_ops(self) -> int:
+        return self._lib.y6_plan_num_ops(self._h)
+
+    def profile(self, iters: int = 5):
+        n = self.num_ops
+        ms = (C.c_float * n)()
+        kind = (C.c_int32 * n)()
+        var = (C.c_int32 * n)()
+        fl = (C.c_double * n)()
+        by = (C.c_double * n)()
+        rc = self._lib.y6_plan_profile(self._h, _lib.current_stream_ptr(), iters, ms, kind, var, fl, by, n)
+        if rc < 0:
+            _lib.check(rc, "plan_profile")
+        names = {1: "conv", 2: "convt", 3: "stem", 4: "sppf", 5: "decode", 6: "nchw2nhwc", 7: "nhwc2nchw"}
+        rows = []
+        for i in range(n):
+            vname = self._lib.y6_conv_variant_name(var[i]).decode() if var[i] >= 0 else ""
+            rows.append(dict(op=i, kind=names.get(kind[i], str(kind[i])), variant=vname, ms=float(ms[i]),
+                             flops=float(fl[i]), bytes=float(by[i])))
+        return rows
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.y6_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class PlanBuilder:
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("yolov6_amd: the HIP hot path needs a ROCm device; there is no CPU fallback")
+        self.h = C.c_void_p(self.lib.y6_plan_create())
+        self.keep: List[torch.Tensor] = []
+        self.force_variant = -1  # tests: force one conv kernel variant for every conv
+        self.inputs: List[torch.Tensor] = []
+        self.conv_log = []       # (Cin, Cout, k, s, H, W) per conv, for reporting
+
+    # ---------------------------------------------------------------- memory
+    def new_buffer(self, B, H, W, C_) -> TRef:
+        t = torch.empty((B, H, W, C_), dtype=torch.float16, device=self.device)
+        self.keep.append(t)
+        return TRef(t, B, H, W, C_, C_, 0)
+
+    def _f32(self, t: Optional[torch.Tensor], fp16_round=True):
+        if t is None:
+            return None
+        t = t.detach().to(self.device, torch.float32)
+        if fp16_round:  # the reference runs model.half(): biases / affine terms are fp16 values
+            t = t.half().float()
+        t = t.contiguous()
+        self.keep.append(t)
+        return t
+
+    @staticmethod
+    def _ptr(t: Optional[torch.Tensor]):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    # ---------------------------------------------------------------- inputs / outputs
+    def as_nhwc(self, x) -> TRef:
+        """NCHWInput -> TRef through the layout adapter kernel (TRef passes through)."""
+        if isinstance(x, TRef):
+            return x
+        t = x.t
+        _lib.require_gpu_tensor(t, "input")
+        if not t.is_contiguous():
+            raise RuntimeError("yolov6_amd: input must be a contiguous NCHW tensor")
+        B, C_, H, W = t.shape
+        out = self.new_buffer(B, H, W, C_)
+        self.inputs.append(t)
+        ct = out.ct()
+        _lib.check(self.lib.y6_plan_add_nchw2nhwc(self.h, C.c_void_p(t.data_ptr()), _dtype_tag(t), C.byref(ct)),
+                   "plan_add_nchw2nhwc")
+        return out
+
+    def to_nchw(self, x: TRef, dtype=torch.float16) -> torch.Tensor:
+        out = torch.empty((x.B, x.C, x.H, x.W), dtype=dtype, device=self.device)
+        self.keep.append(out)
+        ct = x.ct()
+        _lib.check(self.lib.y6_plan_add_nhwc2nchw(self.h, C.byref(ct), C.c_void_p(out.data_ptr()), _dtype_tag(out)),
+                   "plan_add_nhwc2nchw")
+        return out
+
+    # ---------------------------------------------------------------- ops
+    def conv(self, x, weight, bias, stride=1, act=None, out: Optional[TRef] = None, post=None,
+             res: Optional[TRef] = None, res_alpha: Optional[torch.Tensor] = None) -> TRef:
+        """conv(k in {1,3}, pad=k//2) + bias (+post affine) + act (+alpha*res). weight: OIHW."""
+        Cout, Cin, K, K2 = weight.shape
+        assert K == K2
+        if isinstance(x, NCHWInput):
+            if K == 3 and stride == 2 and x.shape[1] <= 4 and Cout in (8, 16, 32, 48, 64) and res is None:
+                return self._stem(x, weight, bias, act, out, post)
+            x = self.as_nhwc(x)
+        if x.C != Cin:
+            raise RuntimeError(f"yolov6_amd: conv expects {Cin} input channels, got {x.C}")
+        pad = K // 2
+        Ho = (x.H + 2 * pad - K) // stride + 1
+        Wo = (x.W + 2 * pad - K) // stride + 1
+        if out is None:
+            out = self.new_buffer(x.B, Ho, Wo, Cout)
+        assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), "conv output slice has the wrong shape"
+        w32 = weight.detach().to(self.device, torch.float32).contiguous()
+        w16 = w32.half().contiguous()
+        n = self.lib.y6_packed_weight_elems(Cout, Cin, K)
+        packed = torch.empty(n, dtype=torch.float16, device=self.device)
+        _lib.check(self.lib.y6_pack_conv_weight(self._ptr(w16), Y6_F16, Cout, Cin, K, self._ptr(packed),
+                                                _lib.current_stream_ptr()), "pack_conv_weight")
+        self.keep += [w16, packed]
+        b32 = self._f32(bias)
+        ps = self._f32(post[0]) if post is not None else None
+        pt = self._f32(post[1]) if post is not None else None
+        ra = self._f32(res_alpha.reshape(1), fp16_round=True) if res_alpha is not None else None
+        d = _lib.ConvDesc()
+        d.inp, d.out = x.ct(), out.ct()
+        d.w_packed, d.w_oihw = self._ptr(packed), self._ptr(w16)
+        d.bias, d.post_scale, d.post_shift = self._ptr(b32), self._ptr(ps), self._ptr(pt)
+        d.res = res.ct() if res is not None else _null_tensor()
+        d.res_alpha = self._ptr(ra)
+        d.ksize, d.stride, d.act, d.variant = K, stride, ACT_BY_NAME[act], self.force_variant
+        _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
+        self.conv_log.append((Cin, Cout, K, stride, x.H, x.W))
+        return out
+
+    def _stem(self, x: NCHWInput, weight, bias, act, out, post) -> TRef:
+        t = x.t
+        _lib.require_gpu_tensor(t, "input")
+        if not t.is_contiguous():
+            raise RuntimeError("yolov6_amd: input must be a contiguous NCHW tensor")
+        B, Cin, H, W = t.shape
+        Cout = weight.shape[0]
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        if out is None:
+            out = self.new_buffer(B, Ho, Wo, Cout)
+        # fp16-rounded weights, as model.half() would hold them
+        w32 = weight.detach().to(self.device, torch.float32).half().float().contiguous()
+        self.keep += [w32]
+        self.inputs.append(t)
+        d = _lib.StemDesc()
+        d.in_nchw, d.in_dtype = C.c_void_p(t.data_ptr()), _dtype_tag(t)
+        d.B, d.Cin, d.H, d.W = B, Cin, H, W
+        d.out = out.ct()
+        d.w_oihw_f32 = self._ptr(w32)
+        d.bias = self._ptr(self._f32(bias))
+        d.post_scale = self._ptr(self._f32(post[0])) if post is not None else None
+        d.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
+        d.act = ACT_BY_NAME[act]
+        _lib.check(self.lib.y6_plan_add_stem(self.h, C.byref(d)), "plan_add_stem")
+        return out
+
+    def convt2x2(self, x, weight, bias, out: Optional[TRef] = None) -> TRef:
+        """ConvTranspose2d(k=2, s=2): weight IOHW [Cin, Cout, 2, 2]."""
+        x = self.as_nhwc(x)
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        assert tuple(weight.shape[2:]) == (2, 2) and x.C == Cin
+        if out is None:
+            out = self.new_buffer(x.B, 2 * x.H, 2 * x.W, Cout)
+        w16 = weight.detach().to(self.device, torch.float16).contiguous()
+        n = self.lib.y6_packed_weight_elems(Cout, Cin, 1) * 4
+        packed = torch.empty(n, dtype=torch.float16, device=self.device)
+        _lib.check(self.lib.y6_pack_convt2x2_weight(self._ptr(w16), Y6_F16, Cin, Cout, self._ptr(packed),
+                                                    _lib.current_stream_ptr()), "pack_convt2x2_weight")
+        self.keep += [w16, packed]
+        d = _lib.ConvTDesc()
+        d.inp, d.out = x.ct(), out.ct()
+        d.w_packed = self._ptr(packed)
+        d.bias = self._ptr(self._f32(bias))
+        _lib.check(self.lib.y6_plan_add_convt(self.h, C.byref(d)), "plan_add_convt")
+        return out
+
+    def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
+        cts = [t.ct() for t in (x, y1, y2, y3)]
+        _lib.check(self.lib.y6_plan_add_sppf(self.h, *[C.byref(c) for c in cts]), "plan_add_sppf")
+
+    def head_decode(self, cls: List[TRef], reg: List[TRef], strides, use_dfl, reg_max, proj, nc,
+                    grid_cell_offset=0.5) -> torch.Tensor:
+        B = cls[0].B
+        A = sum(c.H * c.W for c in cls)
+        out = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=self.device)
+        self.keep.append(out)
+        d = _lib.DecodeDesc()
+        d.n_levels = len(cls)
+        for i, (c, r) in enumerate(zip(cls, reg)):
+            d.cls[i], d.reg[i] = c.ct(), r.ct()
+            d.stride[i] = float(strides[i])
+        d.use_dfl, d.reg_max = int(bool(use_dfl)), int(reg_max)
+        pj = self._f32(proj, fp16_round=False) if use_dfl else None
+        d.proj = self._ptr(pj)
+        d.grid_cell_offset = grid_cell_offset
+        d.out = C.c_void_p(out.data_ptr())
+        d.nc = nc
+        _lib.check(self.lib.y6_plan_add_decode(self.h, C.byref(d)), "plan_add_decode")
+        return out
+
+    # ---------------------------------------------------------------- finish
+    def finalize(self, outputs, autotune=True, iters=3) -> Plan:
+        plan = Plan(self.h, self.keep, outputs, self.inputs)
+        self.h = None
+        if autotune and self.force_variant < 0:
+            plan.autotune(iters)
+        return plan

@@ -1,0 +1,551 @@
+"""Building blocks with the reference's names, constructor signatures and state_dict keys
+(yolov6/layers/common.py), whose forward runs on the HIP hot path.
+
+Each block knows how to *lower* itself into a native plan (yolov6_amd.engine.PlanBuilder):
+  ConvModule / ConvBN{ReLU,SiLU,HS}   -> one fused conv+bias+act kernel        (common.py:26-94)
+  RepVGGBlock / QARepVGGBlock[V2]     -> re-parameterised 3x3 conv (+post-BN)   (:197-477)
+  RepBlock / BottleRep / BepC3        -> sequences, residual in the conv epilogue,(:569-650)
+                                         concat-free channel slices
+  SPPFModule / CSPSPPFModule          -> 1x1 convs + one pooling kernel         (:97-178)
+  Transpose / BiFusion                -> convT as 4 scatter GEMMs, slice writes (:181-194, :695-718)
+
+`forward(x)` keeps the reference convention (NCHW tensors in/out).  Modules hold ordinary
+torch parameters (checkpoints / state_dicts stay interchangeable); packed MFMA weights are
+derived caches inside the plan.  There is no aten fallback: CPU tensors, training-mode
+BatchNorm and grouped convs raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..engine import NCHWInput, PlanBuilder, TRef
+
+# the reference keeps one shared activation module per kind (common.py:14-17); state_dicts do
+# not depend on it but `model.modules()` walkers (initialize_weights) do.
+activation_table = {"relu": nn.ReLU(), "silu": nn.SiLU(), "hardswish": nn.Hardswish()}
+
+
+# ------------------------------------------------------------------------------------------
+# re-parameterisation math (fp32, on whatever device the parameters live)
+# ------------------------------------------------------------------------------------------
+def bn_scale_shift(bn: nn.BatchNorm2d):
+    """Eval-mode BatchNorm as y = x*scale + shift (uses bn.eps, set to 1e-3 by initialize_weights)."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale, shift
+
+
+def fold_conv_bn(weight, bias, bn):
+    """fuse_conv_and_bn (reference yolov6/utils/torch_utils.py:50-82) as tensors."""
+    scale, shift = bn_scale_shift(bn)
+    w = weight.detach().float() * scale.view(-1, 1, 1, 1)
+    b = shift if bias is None else shift + bias.detach().float() * scale
+    return w, b
+
+
+def identity_kernel3x3(channels, device):
+    k = torch.zeros(channels, channels, 3, 3, device=device)
+    idx = torch.arange(channels, device=device)
+    k[idx, idx, 1, 1] = 1.0
+    return k
+
+
+# ------------------------------------------------------------------------------------------
+# forward machinery shared by every block
+# ------------------------------------------------------------------------------------------
+def _flatten(x):
+    if isinstance(x, torch.Tensor):
+        return [x]
+    out = []
+    for e in x:
+        out += _flatten(e)
+    return out
+
+
+def _wrap(x, it):
+    """Same nesting as x with every tensor replaced by NCHWInput(next contiguous tensor)."""
+    if isinstance(x, torch.Tensor):
+        return NCHWInput(next(it))
+    return type(x)(_wrap(e, it) for e in x) if isinstance(x, tuple) else [_wrap(e, it) for e in x]
+
+
+def _params_version(module):
+    v = 0
+    for p in module.parameters():
+        v += p._version + (p.data_ptr() & 0xFFFF)
+    for b in module.buffers():
+        v += b._version
+    return v
+
+
+class HipModule(nn.Module):
+    """nn.Module whose forward is a cached native plan of HIP kernels."""
+
+    def lower(self, pb: PlanBuilder, x, out=None):
+        raise NotImplementedError
+
+    # plans hold ctypes handles: never pickle them with the module (checkpoints pickle modules)
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st.pop("_y6_plans", None)
+        return st
+
+    def _check_runnable(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and m.training:
+                raise NotImplementedError(
+                    "yolov6_amd: batch-statistics BatchNorm (training-form forward, SURVEY K15) is not on the HIP "
+                    "path yet; call .eval() (running statistics are folded into the conv kernels)")
+
+    def _finish_outputs(self, pb, outs, dtype):
+        if isinstance(outs, TRef):
+            return pb.to_nchw(outs, dtype)
+        if isinstance(outs, torch.Tensor):
+            return outs
+        return type(outs)(self._finish_outputs(pb, o, dtype) for o in outs) if isinstance(outs, tuple) else \
+            [self._finish_outputs(pb, o, dtype) for o in outs]
+
+    def compile(self, *inputs, autotune=True):
+        """Build (or fetch) the plan for these input shapes and bind it to these tensors."""
+        x = inputs[0] if len(inputs) == 1 else list(inputs)
+        flat = _flatten(x)
+        for t in flat:
+            if not t.is_cuda:
+                raise RuntimeError("yolov6_amd: the HIP hot path needs ROCm tensors; there is no CPU fallback "
+                                   f"(got a tensor on {t.device})")
+        contig = [t.contiguous() for t in flat]
+        key = (tuple((tuple(t.shape), t.dtype) for t in flat), _params_version(self), self.training, autotune)
+        cache = self.__dict__.setdefault("_y6_plans", {})
+        plan = cache.get(key)
+        if plan is None:
+            self._check_runnable()
+            cache.clear()  # one live plan per module: buffers are large
+            pb = PlanBuilder(flat[0].device)
+            outs = self.lower(pb, _wrap(x, iter(contig)))
+            odt = flat[0].dtype if flat[0].dtype in (torch.float16, torch.float32) else torch.float16
+            outs = self._finish_outputs(pb, outs, odt)
+            plan = pb.finalize(outs, autotune=autotune)
+            # builder order of the boundary tensors -> position in the caller's argument list
+            plan.input_order = [next(j for j, c in enumerate(contig) if c is t) for t in plan.inputs]
+            cache[key] = plan
+        else:
+            plan.bind_inputs([contig[j] for j in plan.input_order])
+        return plan
+
+    def forward(self, *inputs):
+        plan = self.compile(*inputs)
+        outs = plan.run()
+        return _clone_tree(outs)
+
+
+def _clone_tree(o):
+    if isinstance(o, torch.Tensor):
+        return o.clone()
+    return type(o)(_clone_tree(e) for e in o) if isinstance(o, tuple) else [_clone_tree(e) for e in o]
+
+
+# ------------------------------------------------------------------------------------------
+# Conv + BN + activation
+# ------------------------------------------------------------------------------------------
+class ConvModule(HipModule):
+    '''Conv2d(bias=False) -> BatchNorm2d -> activation.  Reference: common.py:26-54.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, activation_type, padding=None, groups=1,
+                 bias=False):
+        super().__init__()
+        if padding is None:
+            padding = kernel_size // 2
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              groups=groups, bias=bias)
+        self.bn = nn.BatchNorm2d(out_channels)
+        if activation_type is not None:
+            self.act = activation_table.get(activation_type)
+        self.activation_type = activation_type
+
+    def fused_weight_bias(self):
+        """(weight, bias) of the equivalent bias-conv: BN folded if it is still attached."""
+        if hasattr(self, "bn"):
+            return fold_conv_bn(self.conv.weight, self.conv.bias, self.bn)
+        b = self.conv.bias
+        return self.conv.weight.detach().float(), None if b is None else b.detach().float()
+
+    def lower(self, pb, x, out=None, res=None, res_alpha=None):
+        c = self.conv
+        if c.groups != 1 or c.dilation != (1, 1):
+            raise NotImplementedError("yolov6_amd: grouped / dilated convs are not on the YOLOv6 N/S/M/L hot path")
+        k = c.kernel_size[0]
+        if c.padding != (k // 2, k // 2):
+            raise NotImplementedError("yolov6_amd: only 'same' padding (k//2) is supported")
+        w, b = self.fused_weight_bias()
+        return pb.conv(x, w, b, stride=c.stride[0], act=self.activation_type, out=out, res=res, res_alpha=res_alpha)
+
+
+class _ConvBNAct(HipModule):
+    _act = None
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=None, groups=1, bias=False):
+        super().__init__()
+        self.block = ConvModule(in_channels, out_channels, kernel_size, stride, self._act, padding, groups, bias)
+
+    def lower(self, pb, x, out=None, res=None, res_alpha=None):
+        return self.block.lower(pb, x, out, res, res_alpha)
+
+
+class ConvBNReLU(_ConvBNAct):
+    '''Reference: common.py:57-64.'''
+    _act = "relu"
+
+
+class ConvBNSiLU(_ConvBNAct):
+    '''Reference: common.py:67-74.'''
+    _act = "silu"
+
+
+class ConvBN(_ConvBNAct):
+    '''Reference: common.py:77-84.'''
+    _act = None
+
+
+class ConvBNHS(_ConvBNAct):
+    '''Reference: common.py:87-94.'''
+    _act = "hardswish"
+
+
+# ------------------------------------------------------------------------------------------
+# SPPF family
+# ------------------------------------------------------------------------------------------
+class SPPFModule(HipModule):
+    '''1x1 -> three chained 5x5 max-pools -> concat(4) -> 1x1.  Reference: common.py:97-112.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, block=ConvBNReLU):
+        super().__init__()
+        hidden = in_channels // 2
+        self.cv1 = block(in_channels, hidden, 1, 1)
+        self.cv2 = block(hidden * 4, out_channels, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+
+    def lower(self, pb, x, out=None):
+        if self.m.kernel_size != 5:
+            raise NotImplementedError("yolov6_amd: SPPF pooling kernel is specialised for kernel_size=5")
+        x = pb.as_nhwc(x)
+        hidden = self.cv1.block.conv.out_channels
+        cat = pb.new_buffer(x.B, x.H, x.W, 4 * hidden)
+        s = [cat.slice(i * hidden, hidden) for i in range(4)]
+        self.cv1.lower(pb, x, out=s[0])
+        pb.sppf_pool(s[0], s[1], s[2], s[3])
+        return self.cv2.lower(pb, cat, out=out)
+
+
+class SimSPPF(HipModule):
+    '''Reference: common.py:115-122.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, block=ConvBNReLU):
+        super().__init__()
+        self.sppf = SPPFModule(in_channels, out_channels, kernel_size, block)
+
+    def lower(self, pb, x, out=None):
+        return self.sppf.lower(pb, x, out)
+
+
+class SPPF(HipModule):
+    '''Reference: common.py:125-132.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, block=ConvBNSiLU):
+        super().__init__()
+        self.sppf = SPPFModule(in_channels, out_channels, kernel_size, block)
+
+    def lower(self, pb, x, out=None):
+        return self.sppf.lower(pb, x, out)
+
+
+class CSPSPPFModule(HipModule):
+    '''CSP variant: bypass 1x1 || (1x1, 3x3, 1x1, pools, 1x1, 3x3) -> concat -> 1x1.
+    Reference: common.py:135-158.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, e=0.5, block=ConvBNReLU):
+        super().__init__()
+        hidden = int(out_channels * e)
+        self.cv1 = block(in_channels, hidden, 1, 1)
+        self.cv2 = block(in_channels, hidden, 1, 1)
+        self.cv3 = block(hidden, hidden, 3, 1)
+        self.cv4 = block(hidden, hidden, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=kernel_size // 2)
+        self.cv5 = block(4 * hidden, hidden, 1, 1)
+        self.cv6 = block(hidden, hidden, 3, 1)
+        self.cv7 = block(2 * hidden, out_channels, 1, 1)
+
+    def lower(self, pb, x, out=None):
+        if self.m.kernel_size != 5:
+            raise NotImplementedError("yolov6_amd: SPPF pooling kernel is specialised for kernel_size=5")
+        x = pb.as_nhwc(x)
+        hidden = self.cv1.block.conv.out_channels
+        pools = pb.new_buffer(x.B, x.H, x.W, 4 * hidden)
+        ps = [pools.slice(i * hidden, hidden) for i in range(4)]
+        tail = pb.new_buffer(x.B, x.H, x.W, 2 * hidden)     # cat((y0, y3))
+        t = self.cv1.lower(pb, x)
+        t = self.cv3.lower(pb, t)
+        self.cv4.lower(pb, t, out=ps[0])
+        self.cv2.lower(pb, x, out=tail.slice(0, hidden))
+        pb.sppf_pool(ps[0], ps[1], ps[2], ps[3])
+        t = self.cv5.lower(pb, pools)
+        self.cv6.lower(pb, t, out=tail.slice(hidden, hidden))
+        return self.cv7.lower(pb, tail, out=out)
+
+
+class SimCSPSPPF(HipModule):
+    '''Reference: common.py:161-168.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, e=0.5, block=ConvBNReLU):
+        super().__init__()
+        self.cspsppf = CSPSPPFModule(in_channels, out_channels, kernel_size, e, block)
+
+    def lower(self, pb, x, out=None):
+        return self.cspsppf.lower(pb, x, out)
+
+
+class CSPSPPF(HipModule):
+    '''Reference: common.py:171-178.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, e=0.5, block=ConvBNSiLU):
+        super().__init__()
+        self.cspsppf = CSPSPPFModule(in_channels, out_channels, kernel_size, e, block)
+
+    def lower(self, pb, x, out=None):
+        return self.cspsppf.lower(pb, x, out)
+
+
+class Transpose(HipModule):
+    '''ConvTranspose2d(k=2, s=2, bias) upsampling.  Reference: common.py:181-194.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2):
+        super().__init__()
+        self.upsample_transpose = torch.nn.ConvTranspose2d(in_channels=in_channels, out_channels=out_channels,
+                                                           kernel_size=kernel_size, stride=stride, bias=True)
+
+    def lower(self, pb, x, out=None):
+        ct = self.upsample_transpose
+        if ct.kernel_size != (2, 2) or ct.stride != (2, 2):
+            raise NotImplementedError("yolov6_amd: Transpose is specialised for kernel_size=2, stride=2")
+        return pb.convt2x2(x, ct.weight, ct.bias, out=out)
+
+
+# ------------------------------------------------------------------------------------------
+# RepVGG family
+# ------------------------------------------------------------------------------------------
+class RepVGGBlock(HipModule):
+    '''Training form: ReLU(conv3x3.BN + conv1x1.BN + BN_id(x)); deploy form: ReLU(conv3x3(x)+b).
+    Reference: common.py:197-319.  On the HIP path both forms run as ONE fused 3x3 kernel: the
+    eval-mode training form is re-parameterised while the plan is built.'''
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
+                 padding_mode='zeros', deploy=False, use_se=False):
+        super().__init__()
+        assert kernel_size == 3
+        assert padding == 1
+        if use_se:
+            raise NotImplementedError("se block not supported yet")
+        self.deploy = deploy
+        self.groups = groups
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.nonlinearity = nn.ReLU()
+        self.se = nn.Identity()
+        if deploy:
+            self.rbr_reparam = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                         dilation=dilation, groups=groups, bias=True, padding_mode=padding_mode)
+        else:
+            has_identity = out_channels == in_channels and stride == 1
+            self.rbr_identity = nn.BatchNorm2d(num_features=in_channels) if has_identity else None
+            self.rbr_dense = ConvModule(in_channels, out_channels, kernel_size, stride, None, padding=padding,
+                                        groups=groups)
+            self.rbr_1x1 = ConvModule(in_channels, out_channels, 1, stride, None, padding=padding - kernel_size // 2,
+                                      groups=groups)
+
+    # ---- re-parameterisation (reference get_equivalent_kernel_bias :257-261, _fuse_bn_tensor :278-300)
+    def _identity_branch(self):
+        bn = getattr(self, "rbr_identity", None)
+        if bn is None:
+            return 0, 0
+        scale, shift = bn_scale_shift(bn)
+        k = identity_kernel3x3(self.in_channels, scale.device) * scale.view(-1, 1, 1, 1)
+        return k, shift
+
+    def get_equivalent_kernel_bias(self):
+        k3, b3 = self.rbr_dense.fused_weight_bias()
+        k1, b1 = self.rbr_1x1.fused_weight_bias()
+        kid, bid = self._identity_branch()
+        bias = sum(b for b in (b3, b1, bid) if b is not None)
+        return k3 + F.pad(k1, [1, 1, 1, 1]) + kid, bias
+
+    def _install_reparam(self, kernel, bias):
+        d = self.rbr_dense.conv
+        self.rbr_reparam = nn.Conv2d(d.in_channels, d.out_channels, d.kernel_size, stride=d.stride, padding=d.padding,
+                                     dilation=d.dilation, groups=d.groups, bias=True).to(kernel.device)
+        self.rbr_reparam.weight.data = kernel
+        self.rbr_reparam.bias.data = bias
+        for p in self.parameters():
+            p.detach_()
+        for name in ("rbr_dense", "rbr_1x1", "rbr_identity", "rbr_avg", "id_tensor"):
+            if hasattr(self, name):
+                self.__delattr__(name)
+        self.deploy = True
+
+    def switch_to_deploy(self):
+        if hasattr(self, "rbr_reparam"):
+            return
+        if self.groups != 1:
+            raise NotImplementedError("yolov6_amd: grouped RepVGG blocks are not supported")
+        self._install_reparam(*self.get_equivalent_kernel_bias())
+
+    def _deploy_weight_bias(self):
+        if hasattr(self, "rbr_reparam"):
+            return self.rbr_reparam.weight.detach().float(), self.rbr_reparam.bias.detach().float()
+        return self.get_equivalent_kernel_bias()
+
+    def _post_affine(self):
+        return None
+
+    def _stride(self):
+        return (self.rbr_reparam if hasattr(self, "rbr_reparam") else self.rbr_dense.conv).stride[0]
+
+    def lower(self, pb, x, out=None, res=None, res_alpha=None):
+        if self.groups != 1:
+            raise NotImplementedError("yolov6_amd: grouped RepVGG blocks are not supported")
+        w, b = self._deploy_weight_bias()
+        return pb.conv(x, w, b, stride=self._stride(), act="relu", out=out, post=self._post_affine(), res=res,
+                       res_alpha=res_alpha)
+
+
+class QARepVGGBlock(RepVGGBlock):
+    '''Quantisation-aware RepVGG: BN-free 1x1 branch, raw identity, post-BN kept after deploy.
+    Reference: common.py:322-393.'''
+    _with_avg = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, dilation=1, groups=1,
+                 padding_mode='zeros', deploy=False, use_se=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, padding_mode,
+                         deploy, use_se)
+        if not deploy:
+            self.bn = nn.BatchNorm2d(out_channels)
+            self.rbr_1x1 = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, groups=groups,
+                                     bias=False)
+            same = out_channels == in_channels and stride == 1
+            self.rbr_identity = nn.Identity() if same else None
+            if self._with_avg:
+                self.rbr_avg = nn.AvgPool2d(kernel_size=kernel_size, stride=stride, padding=padding) if same else None
+        self._id_tensor = None
+
+    def get_equivalent_kernel_bias(self):
+        k3, b3 = self.rbr_dense.fused_weight_bias()
+        kernel = k3 + F.pad(self.rbr_1x1.weight.detach().float(), [1, 1, 1, 1])
+        if getattr(self, "rbr_avg", None) is not None:   # V2: 3x3 average pooling as a constant kernel (:430-432)
+            kernel = kernel + identity_kernel3x3(self.in_channels, kernel.device).amax((2, 3), keepdim=True) / 9.0
+        if self.rbr_identity is not None:
+            kernel = kernel + identity_kernel3x3(self.in_channels, kernel.device)
+        return kernel, b3
+
+    def _post_affine(self):
+        # the deploy form keeps self.bn after the conv (:338-339, :390-392)
+        return bn_scale_shift(self.bn) if hasattr(self, "bn") else None
+
+
+class QARepVGGBlockV2(QARepVGGBlock):
+    '''QARepVGG + 3x3 average-pool branch.  Reference: common.py:396-477.'''
+    _with_avg = True
+
+
+# ------------------------------------------------------------------------------------------
+# stage blocks
+# ------------------------------------------------------------------------------------------
+class BottleRep(HipModule):
+    '''Two basic blocks with an optional (learnably weighted) shortcut.  Reference: common.py:590-608.
+    The shortcut `out + alpha*x` is the residual term of the second conv's epilogue.'''
+
+    def __init__(self, in_channels, out_channels, basic_block=RepVGGBlock, weight=False):
+        super().__init__()
+        self.conv1 = basic_block(in_channels, out_channels)
+        self.conv2 = basic_block(out_channels, out_channels)
+        self.shortcut = in_channels == out_channels
+        self.alpha = nn.Parameter(torch.ones(1)) if weight else 1.0
+
+    def lower(self, pb, x, out=None):
+        x = pb.as_nhwc(x)
+        t = self.conv1.lower(pb, x)
+        if not self.shortcut:
+            return self.conv2.lower(pb, t, out=out)
+        alpha = self.alpha if isinstance(self.alpha, torch.Tensor) else None
+        return self.conv2.lower(pb, t, out=out, res=x, res_alpha=alpha)
+
+
+class RepBlock(HipModule):
+    '''Stage = conv1 + (n-1) more blocks (BottleRep stages halve n).  Reference: common.py:569-587.'''
+
+    def __init__(self, in_channels, out_channels, n=1, block=RepVGGBlock, basic_block=RepVGGBlock):
+        super().__init__()
+        if block == BottleRep:
+            make = lambda i, o: BottleRep(i, o, basic_block=basic_block, weight=True)
+            n = n // 2
+        else:
+            make = lambda i, o: block(i, o)
+        self.conv1 = make(in_channels, out_channels)
+        self.block = nn.Sequential(*(make(out_channels, out_channels) for _ in range(n - 1))) if n > 1 else None
+
+    def lower(self, pb, x, out=None):
+        rest = list(self.block) if self.block is not None else []
+        x = self.conv1.lower(pb, x, out=out if not rest else None)
+        for i, m in enumerate(rest):
+            x = m.lower(pb, x, out=out if i == len(rest) - 1 else None)
+        return x
+
+
+class BepC3(HipModule):
+    '''CSPStackRep block: cv3(cat(m(cv1(x)), cv2(x))).  Reference: common.py:634-650.'''
+
+    def __init__(self, in_channels, out_channels, n=1, e=0.5, block=RepVGGBlock):
+        super().__init__()
+        hidden = int(out_channels * e)
+        conv = ConvBNSiLU if block == ConvBNSiLU else ConvBNReLU
+        self.cv1 = conv(in_channels, hidden, 1, 1)
+        self.cv2 = conv(in_channels, hidden, 1, 1)
+        self.cv3 = conv(2 * hidden, out_channels, 1, 1)
+        self.m = RepBlock(in_channels=hidden, out_channels=hidden, n=n, block=BottleRep, basic_block=block)
+
+    def lower(self, pb, x, out=None):
+        x = pb.as_nhwc(x)
+        hidden = self.cv1.block.conv.out_channels
+        cat = pb.new_buffer(x.B, x.H, x.W, 2 * hidden)
+        t = self.cv1.lower(pb, x)
+        self.m.lower(pb, t, out=cat.slice(0, hidden))
+        self.cv2.lower(pb, x, out=cat.slice(hidden, hidden))
+        return self.cv3.lower(pb, cat, out=out)
+
+
+class BiFusion(HipModule):
+    '''cv3(cat(upsample(x0), cv1(x1), downsample(cv2(x2)))).  Reference: common.py:695-718.'''
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.cv1 = ConvBNReLU(in_channels[0], out_channels, 1, 1)
+        self.cv2 = ConvBNReLU(in_channels[1], out_channels, 1, 1)
+        self.cv3 = ConvBNReLU(out_channels * 3, out_channels, 1, 1)
+        self.upsample = Transpose(in_channels=out_channels, out_channels=out_channels)
+        self.downsample = ConvBNReLU(in_channels=out_channels, out_channels=out_channels, kernel_size=3, stride=2)
+
+    def lower(self, pb, x, out=None):
+        x0, x1, x2 = (pb.as_nhwc(t) for t in x)
+        oc = self.cv1.block.conv.out_channels
+        cat = pb.new_buffer(x1.B, x1.H, x1.W, 3 * oc)
+        self.upsample.lower(pb, x0, out=cat.slice(0, oc))
+        self.cv1.lower(pb, x1, out=cat.slice(oc, oc))
+        t = self.cv2.lower(pb, x2)
+        self.downsample.lower(pb, t, out=cat.slice(2 * oc, oc))
+        return self.cv3.lower(pb, cat, out=out)
+
+
+def get_block(mode):
+    '''Reference: common.py:721-737 (hyper_search / repopt blocks are outside the hot path).'''
+    table = {"repvgg": RepVGGBlock, "qarepvgg": QARepVGGBlock, "qarepvggv2": QARepVGGBlockV2,
+             "conv_relu": ConvBNReLU, "conv_silu": ConvBNSiLU}
+    if mode not in table:
+        raise NotImplementedError("Undefied Repblock choice for mode {}".format(mode))
+    return table[mode]

@@ -1,0 +1,84 @@
+"""EffiDeHead (anchor-free decoupled head) on the HIP path.
+Reference: yolov6/models/effidehead.py (Detect :10-139, build_effidehead_layer :142-293).
+
+Per level: stem 1x1 SiLU -> {cls 3x3 SiLU -> 1x1 (nc)} , {reg 3x3 SiLU -> 1x1 (4*(reg_max+1))}
+as five fused conv kernels, then ONE decode kernel for all levels (sigmoid, DFL, dist2bbox,
+x stride, concat) that writes the reference's [B, A, 5+nc] fp32 tensor directly.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..layers.common import ConvBNSiLU, HipModule
+
+
+class Detect(HipModule):
+    export = False
+
+    def __init__(self, num_classes=80, num_layers=3, inplace=True, head_layers=None, use_dfl=True, reg_max=16):
+        super().__init__()
+        assert head_layers is not None
+        self.nc = num_classes
+        self.no = num_classes + 5
+        self.nl = num_layers
+        self.grid = [torch.zeros(1)] * num_layers
+        self.prior_prob = 1e-2
+        self.inplace = inplace
+        self.stride = torch.tensor([8, 16, 32] if num_layers == 3 else [8, 16, 32, 64])
+        self.use_dfl = use_dfl
+        self.reg_max = reg_max
+        self.proj_conv = nn.Conv2d(self.reg_max + 1, 1, 1, bias=False)
+        self.grid_cell_offset = 0.5
+        self.grid_cell_size = 5.0
+        groups = {"stems": 0, "cls_convs": 1, "reg_convs": 2, "cls_preds": 3, "reg_preds": 4}
+        for name, k in groups.items():
+            setattr(self, name, nn.ModuleList(head_layers[i * 5 + k] for i in range(num_layers)))
+
+    def initialize_biases(self):
+        '''Reference: effidehead.py:49-69 (prior-probability bias, zero prediction weights, DFL proj).'''
+        cls_bias = -math.log((1 - self.prior_prob) / self.prior_prob)
+        for convs, value in ((self.cls_preds, cls_bias), (self.reg_preds, 1.0)):
+            for conv in convs:
+                conv.bias = nn.Parameter(torch.full_like(conv.bias.detach().view(-1), value), requires_grad=True)
+                conv.weight = nn.Parameter(torch.zeros_like(conv.weight.detach()), requires_grad=True)
+        self.proj = nn.Parameter(torch.linspace(0, self.reg_max, self.reg_max + 1), requires_grad=False)
+        self.proj_conv.weight = nn.Parameter(self.proj.view([1, self.reg_max + 1, 1, 1]).clone().detach(),
+                                             requires_grad=False)
+
+    def lower(self, pb, x, out=None):
+        if self.training:
+            raise NotImplementedError("yolov6_amd: Detect training branch (effidehead.py:72-92) is not on the HIP path "
+                                      "yet; call .eval()")
+        if self.export:
+            raise NotImplementedError("yolov6_amd: export mode (ONNX tracing) is out of scope of the HIP path")
+        cls_out, reg_out = [], []
+        for i in range(self.nl):
+            f = self.stems[i].lower(pb, x[i])
+            c = self.cls_convs[i].lower(pb, f)
+            cp = self.cls_preds[i]
+            cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
+            r = self.reg_convs[i].lower(pb, f)
+            rp = self.reg_preds[i]
+            reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
+        use_dfl = bool(self.use_dfl)
+        return pb.head_decode(cls_out, reg_out, [float(s) for s in self.stride.tolist()], use_dfl, self.reg_max,
+                              self.proj if use_dfl else None, self.nc, self.grid_cell_offset)
+
+
+def build_effidehead_layer(channels_list, num_anchors, num_classes, reg_max=16, num_layers=3):
+    '''Five layers per level in the reference's order (stem, cls_conv, reg_conv, cls_pred, reg_pred);
+    levels beyond the third are registered under the reference's names (effidehead.py:248-291).'''
+    chx = [6, 8, 10] if num_layers == 3 else [8, 9, 10, 11]
+    head_layers = nn.Sequential()
+    for lvl, ci in enumerate(chx):
+        c = channels_list[ci]
+        made = (("stem", ConvBNSiLU(in_channels=c, out_channels=c, kernel_size=1, stride=1)),
+                ("cls_conv", ConvBNSiLU(in_channels=c, out_channels=c, kernel_size=3, stride=1)),
+                ("reg_conv", ConvBNSiLU(in_channels=c, out_channels=c, kernel_size=3, stride=1)),
+                ("cls_pred", nn.Conv2d(in_channels=c, out_channels=num_classes * num_anchors, kernel_size=1)),
+                ("reg_pred", nn.Conv2d(in_channels=c, out_channels=4 * (reg_max + num_anchors), kernel_size=1)))
+        for k, (name, layer) in enumerate(made):
+            # nn.Sequential(*layers) names children "0".."14"; add_module uses explicit names for level 3
+            head_layers.add_module(str(lvl * 5 + k) if lvl < 3 else f"{name}{lvl}", layer)
+    return head_layers

@@ -1,0 +1,121 @@
+"""Necks with the reference's class names and state_dict keys (yolov6/models/reppan.py).
+
+The bi-directional FPN is lowered concat-free: every `torch.cat` of the reference
+(reppan.py:228,232 and common.py:718) becomes a pre-allocated NHWC buffer whose channel
+slices the producers write directly (conv epilogues take an output channel offset/stride).
+"""
+from ..layers.common import BepC3, BiFusion, BottleRep, ConvBNReLU, HipModule, RepBlock, RepVGGBlock
+
+
+class _BiFPAN(HipModule):
+    """Top-down (reduce -> BiFusion -> stage) then bottom-up (downsample -> cat -> stage).
+    Subclasses create the attributes under the reference's names and list them in
+    `_td` (top-down) and `_bu` (bottom-up) order."""
+    _td = ()   # (reduce, bifusion, stage)  from the deepest level up
+    _bu = ()   # (downsample, stage)        from the shallowest level down
+
+    def lower(self, pb, x, out=None):
+        feats = [pb.as_nhwc(t) for t in x]            # shallow ... deep (x_k ... x0)
+        n_td = len(self._td)
+        deep = feats[-1]
+        lateral = []                                   # fpn_out_i, each living in its bottom-up cat buffer
+        cur = deep
+        for i, (reduce_n, fuse_n, stage_n) in enumerate(self._td):
+            reduce, fuse, stage = getattr(self, reduce_n), getattr(self, fuse_n), getattr(self, stage_n)
+            # bottom-up partner of this lateral: cat([down_feat, fpn_out_i]) (reference forward order)
+            down = getattr(self, self._bu[n_td - 1 - i][0])
+            c_down = down.block.conv.out_channels
+            c_lat = reduce.block.conv.out_channels
+            cat = pb.new_buffer(cur.B, cur.H, cur.W, c_down + c_lat)
+            fpn_out = reduce.lower(pb, cur, out=cat.slice(c_down, c_lat))
+            lateral.append((cat, c_down))
+            mid, low = feats[-2 - i], feats[-3 - i]
+            cur = stage.lower(pb, fuse.lower(pb, [fpn_out, mid, low]))
+        outs = [cur]
+        for j, (down_n, stage_n) in enumerate(self._bu):
+            cat, c_down = lateral[n_td - 1 - j]
+            getattr(self, down_n).lower(pb, cur, out=cat.slice(0, c_down))
+            cur = getattr(self, stage_n).lower(pb, cat)
+            outs.append(cur)
+        return outs
+
+
+class RepBiFPANNeck(_BiFPAN):
+    '''RepBiFPAN neck (YOLOv6-N/S).  Reference: reppan.py:132-237.'''
+    _td = (("reduce_layer0", "Bifusion0", "Rep_p4"), ("reduce_layer1", "Bifusion1", "Rep_p3"))
+    _bu = (("downsample2", "Rep_n3"), ("downsample1", "Rep_n4"))
+
+    def __init__(self, channels_list=None, num_repeats=None, block=RepVGGBlock):
+        super().__init__()
+        assert channels_list is not None
+        assert num_repeats is not None
+        c, n = channels_list, num_repeats
+        stage = lambda i, o, r: RepBlock(in_channels=i, out_channels=o, n=r, block=block)
+        self.reduce_layer0 = ConvBNReLU(in_channels=c[4], out_channels=c[5], kernel_size=1, stride=1)
+        self.Bifusion0 = BiFusion(in_channels=[c[3], c[2]], out_channels=c[5])
+        self.Rep_p4 = stage(c[5], c[5], n[5])
+        self.reduce_layer1 = ConvBNReLU(in_channels=c[5], out_channels=c[6], kernel_size=1, stride=1)
+        self.Bifusion1 = BiFusion(in_channels=[c[2], c[1]], out_channels=c[6])
+        self.Rep_p3 = stage(c[6], c[6], n[6])
+        self.downsample2 = ConvBNReLU(in_channels=c[6], out_channels=c[7], kernel_size=3, stride=2)
+        self.Rep_n3 = stage(c[6] + c[7], c[8], n[7])
+        self.downsample1 = ConvBNReLU(in_channels=c[8], out_channels=c[9], kernel_size=3, stride=2)
+        self.Rep_n4 = stage(c[5] + c[9], c[10], n[8])
+
+
+class CSPRepBiFPANNeck(_BiFPAN):
+    '''CSP RepBiFPAN neck (YOLOv6-M/L).  Reference: reppan.py:666-785.'''
+    _td = RepBiFPANNeck._td
+    _bu = RepBiFPANNeck._bu
+
+    def __init__(self, channels_list=None, num_repeats=None, block=BottleRep, csp_e=float(1) / 2,
+                 stage_block_type="BepC3"):
+        super().__init__()
+        assert channels_list is not None
+        assert num_repeats is not None
+        if stage_block_type != "BepC3":
+            raise NotImplementedError
+        c, n = channels_list, num_repeats
+        stage = lambda i, o, r: BepC3(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
+        self.reduce_layer0 = ConvBNReLU(in_channels=c[4], out_channels=c[5], kernel_size=1, stride=1)
+        self.Bifusion0 = BiFusion(in_channels=[c[3], c[2]], out_channels=c[5])
+        self.Rep_p4 = stage(c[5], c[5], n[5])
+        self.reduce_layer1 = ConvBNReLU(in_channels=c[5], out_channels=c[6], kernel_size=1, stride=1)
+        self.Bifusion1 = BiFusion(in_channels=[c[2], c[1]], out_channels=c[6])
+        self.Rep_p3 = stage(c[6], c[6], n[6])
+        self.downsample2 = ConvBNReLU(in_channels=c[6], out_channels=c[7], kernel_size=3, stride=2)
+        self.Rep_n3 = stage(c[6] + c[7], c[8], n[7])
+        self.downsample1 = ConvBNReLU(in_channels=c[8], out_channels=c[9], kernel_size=3, stride=2)
+        self.Rep_n4 = stage(c[5] + c[9], c[10], n[8])
+
+
+class CSPRepBiFPANNeck_P6(_BiFPAN):
+    '''CSP RepBiFPAN neck with a P6 level (YOLOv6-M6/L6).  Reference: reppan.py:955-1116.'''
+    _td = (("reduce_layer0", "Bifusion0", "Rep_p5"), ("reduce_layer1", "Bifusion1", "Rep_p4"),
+           ("reduce_layer2", "Bifusion2", "Rep_p3"))
+    _bu = (("downsample2", "Rep_n4"), ("downsample1", "Rep_n5"), ("downsample0", "Rep_n6"))
+
+    def __init__(self, channels_list=None, num_repeats=None, block=BottleRep, csp_e=float(1) / 2,
+                 stage_block_type="BepC3"):
+        super().__init__()
+        assert channels_list is not None
+        assert num_repeats is not None
+        if stage_block_type != "BepC3":
+            raise NotImplementedError
+        c, n = channels_list, num_repeats
+        stage = lambda i, o, r: BepC3(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
+        self.reduce_layer0 = ConvBNReLU(in_channels=c[5], out_channels=c[6], kernel_size=1, stride=1)
+        self.Bifusion0 = BiFusion(in_channels=[c[4], c[6]], out_channels=c[6])
+        self.Rep_p5 = stage(c[6], c[6], n[6])
+        self.reduce_layer1 = ConvBNReLU(in_channels=c[6], out_channels=c[7], kernel_size=1, stride=1)
+        self.Bifusion1 = BiFusion(in_channels=[c[3], c[7]], out_channels=c[7])
+        self.Rep_p4 = stage(c[7], c[7], n[7])
+        self.reduce_layer2 = ConvBNReLU(in_channels=c[7], out_channels=c[8], kernel_size=1, stride=1)
+        self.Bifusion2 = BiFusion(in_channels=[c[2], c[8]], out_channels=c[8])
+        self.Rep_p3 = stage(c[8], c[8], n[8])
+        self.downsample2 = ConvBNReLU(in_channels=c[8], out_channels=c[8], kernel_size=3, stride=2)
+        self.Rep_n4 = stage(c[8] + c[8], c[9], n[9])
+        self.downsample1 = ConvBNReLU(in_channels=c[9], out_channels=c[9], kernel_size=3, stride=2)
+        self.Rep_n5 = stage(c[7] + c[9], c[10], n[10])
+        self.downsample0 = ConvBNReLU(in_channels=c[10], out_channels=c[10], kernel_size=3, stride=2)
+        self.Rep_n6 = stage(c[6] + c[10], c[11], n[11])

@@ -1,0 +1,108 @@
+"""Model assembly.  Reference: yolov6/models/yolo.py (Model :14-47, build_network :55-133,
+build_model :136-138).  `Model.forward(x)` keeps the reference contract
+`[detections[B,A,5+nc] fp32, featmaps]` but runs as one native plan of HIP kernels.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..layers.common import HipModule, get_block
+from ..utils.torch_utils import initialize_weights
+from . import efficientrep, reppan
+from .effidehead import Detect, build_effidehead_layer
+
+
+class _LazyFeatmaps(list):
+    """The neck outputs as NCHW tensors, converted from the plan's NHWC buffers on first use.
+    (Eval callers drop them: `outputs, _ = model(imgs)` evaler.py:128.)"""
+
+    def __init__(self, refs, dtype):
+        super().__init__()
+        self._refs, self._dtype = refs, dtype
+
+    def _fill(self):
+        if self._refs is not None:
+            refs, self._refs = self._refs, None
+            for r in refs:
+                super().append(r.to_nhwc_tensor().permute(0, 3, 1, 2).contiguous().to(self._dtype))
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+
+class Model(HipModule):
+    export = False
+
+    def __init__(self, config, channels=3, num_classes=None, fuse_ab=False, distill_ns=False):
+        super().__init__()
+        num_layers = config.model.head.num_layers
+        self.backbone, self.neck, self.detect = build_network(config, channels, num_classes, num_layers,
+                                                              fuse_ab=fuse_ab, distill_ns=distill_ns)
+        self.stride = self.detect.stride
+        self.detect.initialize_biases()
+        initialize_weights(self)
+
+    def lower(self, pb, x, out=None):
+        feats = self.neck.lower(pb, self.backbone.lower(pb, x))
+        self._featrefs = list(feats)
+        return self.detect.lower(pb, list(feats))
+
+    def forward(self, x):
+        if torch.onnx.is_in_onnx_export() or self.export:
+            raise NotImplementedError("yolov6_amd: ONNX export mode is out of scope of the HIP path")
+        plan = self.compile(x)
+        det = plan.run()
+        return [det.clone(), _LazyFeatmaps(self._featrefs, x.dtype)]
+
+    def _apply(self, fn):
+        self = super()._apply(fn)
+        self.detect.stride = fn(self.detect.stride)
+        self.detect.grid = list(map(fn, self.detect.grid))
+        return self
+
+
+def make_divisible(x, divisor):
+    return math.ceil(x / divisor) * divisor
+
+
+def build_network(config, channels, num_classes, num_layers, fuse_ab=False, distill_ns=False):
+    m = config.model
+    depth_mul, width_mul = m.depth_multiple, m.width_multiple
+    reps = m.backbone.num_repeats + m.neck.num_repeats
+    chans = m.backbone.out_channels + m.neck.out_channels
+    num_repeat = [(max(round(i * depth_mul), 1) if i > 1 else i) for i in reps]
+    channels_list = [make_divisible(i * width_mul, 8) for i in chans]
+    block = get_block(config.training_mode)
+    backbone_cls = getattr(efficientrep, m.backbone.type, None)
+    neck_cls = getattr(reppan, m.neck.type, None)
+    if backbone_cls is None or neck_cls is None:
+        raise NotImplementedError(f"yolov6_amd: backbone/neck {m.backbone.type}/{m.neck.type} is outside the HIP hot path")
+    if fuse_ab or distill_ns:
+        raise NotImplementedError("yolov6_amd: fuse_ab / distill heads are scheduled after the base hot path (SURVEY §8f)")
+    bkw = dict(in_channels=channels, channels_list=channels_list, num_repeats=num_repeat, block=block,
+               fuse_P2=m.backbone.get('fuse_P2'), cspsppf=m.backbone.get('cspsppf'))
+    nkw = dict(channels_list=channels_list, num_repeats=num_repeat, block=block)
+    if 'CSP' in m.backbone.type:
+        stage_block_type = m.backbone.get("stage_block_type") or "BepC3"
+        bkw.update(csp_e=m.backbone.csp_e, stage_block_type=stage_block_type)
+        nkw.update(csp_e=m.neck.csp_e, stage_block_type=stage_block_type)
+    backbone, neck = backbone_cls(**bkw), neck_cls(**nkw)
+    head_layers = build_effidehead_layer(channels_list, 1, num_classes, reg_max=m.head.reg_max, num_layers=num_layers)
+    # like the reference (yolo.py:128-130) Detect keeps its default reg_max=16 (proj has 17 bins even
+    # when use_dfl is False); only build_effidehead_layer sees the config's reg_max
+    head = Detect(num_classes, num_layers, head_layers=head_layers, use_dfl=m.head.use_dfl)
+    return backbone, neck, head
+
+
+def build_model(cfg, num_classes, device, fuse_ab=False, distill_ns=False):
+    return Model(cfg, channels=3, num_classes=num_classes, fuse_ab=fuse_ab, distill_ns=distill_ns).to(device)

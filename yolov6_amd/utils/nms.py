@@ -1,0 +1,82 @@
+"""non_max_suppression with the reference's signature and return convention
+(yolov6/utils/nms.py:31-105), running as two HIP kernels (yolov6_amd/csrc/nms.hip).
+
+Deviation (documented in DESIGN.md): the reference's 10 s wall-clock `time_limit` break
+(nms.py:56, :101-103) has no analogue - all images are processed in one launch.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index, )
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    """Device-side result without host synchronisation:
+    (dets [B,max_det,6] f32, index [B,max_det] i32 (anchor*nc+cls), count [B] i32)."""
+    lib = _lib.load()
+    _lib.require_gpu_tensor(prediction, "prediction")
+    # the reference asserts the thresholds (nms.py:50-51)
+    assert 0 <= conf_thres <= 1, f'conf_thresh must be in 0.0 to 1.0, however {conf_thres} is provided.'
+    assert 0 <= iou_thres <= 1, f'iou_thres must be in 0.0 to 1.0, however {iou_thres} is provided.'
+    pred = prediction
+    if pred.dtype != torch.float32:
+        pred = pred.float()          # the head emits fp32 even for .half() models
+    pred = pred.contiguous()
+    B, A, no = pred.shape
+    nc = no - 5
+    dev = pred.device
+    ml = bool(multi_label) and nc > 1
+    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=dev)
+    index = torch.full((B, max_det), -1, dtype=torch.int32, device=dev)
+    count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    nbytes = lib.y6_nms_workspace_bytes(B, A, nc, int(ml))
+    ws = _workspace(dev, nbytes)
+    cls_t = None
+    if classes is not None:
+        cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
+    d = _lib.NmsDesc()
+    d.pred = C.c_void_p(pred.data_ptr())
+    d.B, d.A, d.nc = B, A, nc
+    d.conf_thres, d.iou_thres = float(conf_thres), float(iou_thres)
+    d.classes = C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None
+    d.n_classes = int(cls_t.numel()) if cls_t is not None else 0
+    d.agnostic, d.multi_label = int(bool(agnostic)), int(ml)
+    d.max_det, d.max_nms, d.max_wh = int(max_det), 30000, 4096.0
+    d.out_dets, d.out_index, d.out_count = (C.c_void_p(t.data_ptr()) for t in (dets, index, count))
+    d.workspace, d.workspace_bytes = C.c_void_p(ws.data_ptr()), ws.numel()
+    _lib.check(lib.y6_nms(C.byref(d), _lib.current_stream_ptr()), "nms")
+    return dets, index, count
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        max_det=300):
+    """Runs Non-Maximum Suppression on inference results.
+
+    Args and return value as the reference: a list with one [n, 6] tensor (xyxy, conf, cls)
+    per image, boxes in descending confidence order, at most `max_det` rows.
+    """
+    dets, _, count = nms_raw(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, max_det)
+    counts = count.tolist()          # the one host sync; the reference syncs once per image
+    return [dets[i, :n] for i, n in enumerate(counts)]
+
+
+def xywh2xyxy(x):
+    '''[n,4] (cx, cy, w, h) -> (x1, y1, x2, y2).  Reference: nms.py:21-28 (host helper).'''
+    y = x.clone() if isinstance(x, torch.Tensor) else x.copy()
+    y[:, 0] = x[:, 0] - x[:, 2] / 2
+    y[:, 1] = x[:, 1] - x[:, 3] / 2
+    y[:, 2] = x[:, 0] + x[:, 2] / 2
+    y[:, 3] = x[:, 1] + x[:, 3] / 2
+    return y
