@@ -247,6 +247,14 @@ int y6_plan_autotune(y6_plan* p, void* stream, int iters);
 int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_ptr);
 /* Launch all ops in order on `stream` (no sync). */
 int y6_plan_run(y6_plan* p, void* stream);
+/* Live per-op timing: reserve `slots` runs worth of hipEvents, run eagerly with an event between
+ * consecutive ops (on `stream`), then - after the caller synchronised - read the per-op sums. */
+int y6_plan_timing_begin(y6_plan* p, int slots);
+int y6_plan_run_timed(y6_plan* p, void* stream);
+int y6_plan_timing_read(y6_plan* p, float* ms_sum, int cap);  /* returns the number of slots summed */
+/* kind / conv variant / ksize / stride and algorithmic FLOPs + bytes of op i */
+int y6_plan_op_info(const y6_plan* p, int i, int32_t* kind, int32_t* variant, int32_t* ksize, int32_t* stride,
+                    double* flops, double* bytes);
 /* Capture the op list into a hipGraph once; later y6_plan_run replays the graph. */
 int y6_plan_capture(y6_plan* p, void* stream);
 /* Per-op profile: runs the plan op by op with hipEvents, `iters` times; fills ms[i] (average

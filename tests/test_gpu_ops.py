@@ -1,0 +1,207 @@
+"""GPU: every HIP kernel against a plain fp32 CPU statement of the same op, through the C ABI.
+Tolerance (north_star): 1e-3 on values (relative to max(1,|ref|)); exact for pooling/layout."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import gpu_utils as G
+from yolov6_amd.engine import PlanBuilder, TRef
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+# (Cin, Cout, k, s, H, W, B) - the layer shapes of YOLOv6-S/N/L6 at reduced spatial size + ragged tiles
+CONV_SHAPES = [
+    (32, 64, 3, 2, 40, 40, 2),     # ERBlock_2.0 (stride 2, Cin 32: one chunk)
+    (64, 64, 3, 1, 40, 40, 2),     # ERBlock_2 stage
+    (128, 128, 3, 1, 20, 20, 3),   # 20x20: ragged 2-D tile
+    (256, 256, 3, 1, 10, 14, 2),   # non-square, smaller than one tile
+    (128, 256, 3, 2, 20, 20, 2),
+    (512, 256, 1, 1, 20, 20, 2),   # CSPSPPF cv1
+    (192, 64, 1, 1, 13, 17, 2),    # BiFusion cv3 (Cin = 3*64), odd sizes
+    (64, 80, 1, 1, 20, 20, 2),     # cls_pred: Cout not a multiple of 32
+    (64, 4, 1, 1, 20, 20, 2),      # reg_pred: Cout 4
+    (16, 16, 3, 1, 24, 24, 2),     # YOLOv6-N width: half-filled K chunk
+    (48, 96, 3, 1, 9, 33, 1),      # M width, Cin not a multiple of 32
+    (64, 68, 1, 1, 16, 16, 1),     # reg_pred with DFL (4*17)
+]
+
+
+def _mk_weights(Cout, Cin, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (1.0 / np.sqrt(Cin * k * k))
+    b = torch.randn((Cout,), generator=g) * 0.1
+    return w, b
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=lambda s: "c%d-%d_k%ds%d_%dx%d_b%d" % s)
+def test_conv_all_variants(shape):
+    Cin, Cout, k, s, H, W, B = shape
+    x = G.rand_nhwc(B, H, W, Cin, seed=1)
+    w, b = _mk_weights(Cout, Cin, k, 2)
+    ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, s, "relu")
+    ran = []
+    for v, name in enumerate(G.variant_names()):
+        if not G.supports(x, w, s, v):
+            continue
+        o, _ = G.run_conv(x, w, b, s, "relu", v)
+        err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+        assert err < TOL, f"variant {name}: max rel err {err:.3e} on {shape}"
+        ran.append(name)
+    assert "naive" in ran and len(ran) >= 2, ran
+
+
+def test_conv_mfma_layout_is_not_transposed():
+    """Asymmetric weights: output channel c copies input channel (c+1)%C of the centre tap only."""
+    C_, H, W = 64, 16, 16
+    x = G.rand_nhwc(1, H, W, C_, seed=3)
+    w = torch.zeros(C_, C_, 3, 3)
+    for c in range(C_):
+        w[c, (c + 1) % C_, 1, 1] = 1.0
+    exp = G.nhwc_to_nchw_f32(x).roll(-1, dims=1)
+    for v, name in enumerate(G.variant_names()):
+        if not G.supports(x, w, 1, v):
+            continue
+        o, _ = G.run_conv(x, w, None, 1, None, v)
+        assert torch.equal(G.nhwc_to_nchw_f32(o), exp), f"{name}: channel permutation conv is wrong"
+
+
+def test_conv_tap_geometry():
+    """One-hot taps: each of the 9 taps shifts the image; catches dy/dx swaps and halo offsets."""
+    C_, H, W = 32, 12, 20
+    x = G.rand_nhwc(2, H, W, C_, seed=4)
+    xn = G.nhwc_to_nchw_f32(x)
+    for dy in range(3):
+        for dx in range(3):
+            w = torch.zeros(C_, C_, 3, 3)
+            w[torch.arange(C_), torch.arange(C_), dy, dx] = 1.0
+            ref = F.conv2d(xn, w, padding=1)
+            for v, name in enumerate(G.variant_names()):
+                if v == 0 or not G.supports(x, w, 1, v):
+                    continue
+                o, _ = G.run_conv(x, w, None, 1, None, v)
+                assert torch.equal(G.nhwc_to_nchw_f32(o), ref), f"{name}: tap ({dy},{dx}) misplaced"
+            ref2 = F.conv2d(xn, w, padding=1, stride=2)
+            for v, name in enumerate(G.variant_names()):
+                if v == 0 or not G.supports(x, w, 2, v):
+                    continue
+                o, _ = G.run_conv(x, w, None, 2, None, v)
+                assert torch.equal(G.nhwc_to_nchw_f32(o), ref2), f"{name}: stride-2 tap ({dy},{dx}) misplaced"
+
+
+@pytest.mark.parametrize("act", [None, "relu", "silu", "hardswish"])
+def test_conv_epilogue_variants(act):
+    """Activation table, QA post-affine, residual with alpha, and channel-slice in/out views."""
+    B, H, W, Cin, Cout = 2, 20, 20, 64, 64
+    xin = G.rand_nhwc(B, H, W, Cin, cstride=160, coff=32, seed=5)          # input is a slice of a wider buffer
+    w, b = _mk_weights(Cout, Cin, 3, 6)
+    g = torch.Generator().manual_seed(7)
+    post = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1)
+    res = G.rand_nhwc(B, H, W, Cout, cstride=96, coff=16, seed=8)
+    alpha = torch.tensor([0.75])
+    outbuf = G.rand_nhwc(B, H, W, 192, seed=9)                              # poisoned output buffer
+    before = outbuf.buf.clone()
+    out = outbuf.slice(64, Cout)
+    ref = G.conv_reference(G.nhwc_to_nchw_f32(xin), w, b, 1, act, post, G.nhwc_to_nchw_f32(res), alpha)
+    for v, name in enumerate(G.variant_names()):
+        if not G.supports(xin, w, 1, v):
+            continue
+        outbuf.buf.copy_(before)
+        o, _ = G.run_conv(xin, w, b, 1, act, v, out=out, post=post, res=res, alpha=alpha)
+        err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+        assert err < TOL, f"{name}/{act}: {err:.3e}"
+        # channels outside the slice are untouched (concat-free writes must not spill)
+        assert torch.equal(outbuf.buf[..., :64], before[..., :64]) and torch.equal(outbuf.buf[..., 128:], before[..., 128:])
+
+
+def test_convt2x2():
+    B, H, W, Cin, Cout = 2, 10, 12, 64, 64
+    x = G.rand_nhwc(B, H, W, Cin, seed=11)
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn((Cin, Cout, 2, 2), generator=g) / 8
+    b = torch.randn((Cout,), generator=g) * 0.1
+    pb = PlanBuilder(G.DEV)
+    catbuf = pb.new_buffer(B, 2 * H, 2 * W, 3 * Cout)
+    o = pb.convt2x2(x, w, b, out=catbuf.slice(Cout, Cout))
+    pb.finalize(o, autotune=False).run()
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(G.nhwc_to_nchw_f32(x), w.half().float(), b.half().float(), stride=2)
+    assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("cout", [16, 32, 64])
+def test_stem_conv(dtype, cout):
+    g = torch.Generator().manual_seed(13)
+    x = torch.rand((2, 3, 64, 96), generator=g)
+    w, b = _mk_weights(cout, 3, 3, 14)
+    from yolov6_amd.engine import NCHWInput
+    pb = PlanBuilder(G.DEV)
+    o = pb.conv(NCHWInput(x.to(G.DEV, dtype).contiguous()), w, b, stride=2, act="relu")
+    pb.finalize(o, autotune=False).run()
+    torch.cuda.synchronize()
+    ref = G.conv_reference(x.to(dtype).float(), w, b, 2, "relu")
+    assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
+
+
+def test_sppf_pool_exact():
+    B, H, W, C_ = 2, 20, 20, 64
+    cat = G.rand_nhwc(B, H, W, 4 * C_, seed=15)
+    s = [cat.slice(i * C_, C_) for i in range(4)]
+    pb = PlanBuilder(G.DEV)
+    pb.sppf_pool(*s)
+    pb.finalize(None, autotune=False).run()
+    torch.cuda.synchronize()
+    x = G.nhwc_to_nchw_f32(s[0])
+    y = x
+    for i in range(1, 4):
+        y = F.max_pool2d(y, 5, 1, 2)
+        assert torch.equal(G.nhwc_to_nchw_f32(s[i]), y), f"pool {i}"
+
+
+def test_layout_adapters_exact():
+    from yolov6_amd.engine import NCHWInput
+    g = torch.Generator().manual_seed(16)
+    x = torch.rand((2, 24, 7, 9), generator=g).half().to(G.DEV)
+    pb = PlanBuilder(G.DEV)
+    r = pb.as_nhwc(NCHWInput(x))
+    y = pb.to_nchw(r, torch.float32)
+    pb.finalize(y, autotune=False).run()
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), x.float().cpu())
+    assert torch.equal(r.to_nhwc_tensor().cpu(), x.permute(0, 2, 3, 1).cpu())
+
+
+@pytest.mark.parametrize("use_dfl", [False, True])
+def test_head_decode(use_dfl):
+    B, nc, reg_max = 2, 80, 16
+    sizes, strides = [(8, 12), (4, 6), (2, 3)], [8.0, 16.0, 32.0]
+    nreg = 4 * (reg_max + 1) if use_dfl else 4
+    cls = [G.rand_nhwc(B, h, w, nc, seed=20 + i, scale=4.0) for i, (h, w) in enumerate(sizes)]
+    reg = [G.rand_nhwc(B, h, w, nreg, seed=30 + i, scale=3.0) for i, (h, w) in enumerate(sizes)]
+    proj = torch.linspace(0, reg_max, reg_max + 1)
+    pb = PlanBuilder(G.DEV)
+    out = pb.head_decode(cls, reg, strides, use_dfl, reg_max, proj, nc)
+    pb.finalize(out, autotune=False).run()
+    torch.cuda.synchronize()
+    # reference statement (effidehead.py:93-139) in fp32
+    cl, rl, pts, st = [], [], [], []
+    for c, r, (h, w), s in zip(cls, reg, sizes, strides):
+        cn, rn = G.nhwc_to_nchw_f32(c), G.nhwc_to_nchw_f32(r)
+        if use_dfl:
+            rn = rn.reshape(-1, 4, reg_max + 1, h * w).permute(0, 2, 1, 3)
+            rn = F.conv2d(F.softmax(rn, dim=1), proj.view(1, -1, 1, 1))
+        cl.append(torch.sigmoid(cn).reshape(B, nc, h * w))
+        rl.append(rn.reshape(B, 4, h * w))
+        gy, gx = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
+        pts.append(torch.stack([gx, gy], -1).reshape(-1, 2))
+        st.append(torch.full((h * w, 1), s))
+    c = torch.cat(cl, -1).permute(0, 2, 1)
+    r = torch.cat(rl, -1).permute(0, 2, 1)
+    pts, st = torch.cat(pts), torch.cat(st)
+    x1y1, x2y2 = pts - r[..., :2], pts + r[..., 2:]
+    box = torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], -1) * st
+    ref = torch.cat([box, torch.ones(B, box.shape[1], 1), c], -1)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert G.max_rel(out.cpu(), ref) < TOL

@@ -1,0 +1,48 @@
+#!/usr/bin/env bash
+# One GPU-box visit: smoke, -m gpu tests, bench (+ autotune log, per-op table), rocprofv3 kernel stats.
+# Everything of interest lands under gpurun_out/ (merged back by gpurun).
+#   usage: tools/gpu_round.sh [tag] [what...]    what in {smoke,tests,bench,prof,pmc} (default: all but pmc)
+set -u
+TAG=${1:-r01}
+shift || true
+WHAT=${*:-smoke tests bench prof}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+has() { [[ " $WHAT " == *" $1 "* ]]; }
+
+{
+  echo "== device"; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx9|Compute Unit" | head -6
+  python -c "import torch;print('torch',torch.__version__,torch.cuda.is_available(),torch.cuda.get_device_name(0) if torch.cuda.is_available() else '')"
+  nproc
+} > "$OUT/device.txt" 2>&1
+
+if has smoke; then
+  echo "== smoke"; timeout 600 python __graft_entry__.py smoke > "$OUT/smoke.log" 2>&1; echo "smoke rc=$?" | tee -a "$OUT/smoke.log"; tail -3 "$OUT/smoke.log"
+fi
+if has tests; then
+  echo "== tests"; timeout 2400 python -m pytest tests -m gpu -q --tb=short --timeout 600 -p no:cacheprovider > "$OUT/pytest_gpu.log" 2>&1
+  echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"; tail -40 "$OUT/pytest_gpu.log"
+fi
+if has bench; then
+  echo "== bench"; rm -f "$OUT/autotune.log"
+  Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 1200 python bench.py --steps 20 --warmup 3 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "bench rc=$?"; tail -2 "$OUT/bench.err"; cat "$OUT/bench.json"
+fi
+if has prof; then
+  echo "== rocprofv3 kernel stats"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  echo "prof rc=$?"; find "$OUT/prof" -name "*kernel_stats*" | head -3
+  f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
+  # keep the merge-back small: drop the raw trace, keep stats
+  find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+fi
+if has pmc; then
+  echo "== rocprofv3 pmc (separate passes)"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$OLDPWD/$OUT/pmc_sq" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err" )
+  ls "$OUT"/pmc_*
+fi
+du -sh "$OUT"

@@ -98,6 +98,10 @@ SIGNATURES = {
     "y6_plan_rebind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y6_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y6_plan_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "y6_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "y6_plan_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "y6_plan_op_info": (C.c_int, [C.c_void_p, C.c_int] + [C.POINTER(C.c_int32)] * 4 + [C.POINTER(C.c_double)] * 2),
     "y6_plan_profile": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
 }

@@ -2,6 +2,7 @@
 // replayed once per forward (eagerly or from a captured hipGraph), with per-conv kernel
 // autotuning and a per-op hipEvent profile.  This is what sits behind Model.forward
 // (reference yolov6/models/yolo.py:33-41) instead of ~200 aten dispatches.
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -50,6 +51,9 @@ struct y6_plan {
     std::vector<Op> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    std::vector<hipEvent_t> events;  // timing slots: (ops+1) events per slot
+    int slots = 0;
+    int slots_used = 0;
 };
 
 static int run_op(const Op& op, hipStream_t s) {
@@ -66,6 +70,33 @@ static int run_op(const Op& op, hipStream_t s) {
     return Y6_EINVAL;
 }
 
+// algorithmic FLOPs / HBM bytes of one op (input once + output once + weights once)
+static void op_cost(const Op& op, double* pf, double* pby) {
+    double f = 0.0, by = 0.0;
+        if (op.kind == Y6_OP_CONV) {
+        f = y6_conv_flops(&op.conv);
+        by = y6_conv_bytes(&op.conv);
+    } else if (op.kind == Y6_OP_CONVT) {
+        const y6_tensor &a = op.convt.in, &o = op.convt.out;
+        f = 2.0 * o.B * o.H * o.W * (double)o.C * a.C;
+        by = 2.0 * ((double)a.B * a.H * a.W * a.C + (double)o.B * o.H * o.W * o.C + 4.0 * a.C * o.C);
+    } else if (op.kind == Y6_OP_STEM) {
+        const y6_tensor& o = op.stem.out;
+        f = 2.0 * o.B * o.H * o.W * (double)o.C * op.stem.Cin * 9;
+        by = (op.stem.in_dtype == Y6_F16 ? 2.0 : 4.0) * op.stem.B * op.stem.Cin * (double)op.stem.H * op.stem.W +
+             2.0 * o.B * o.H * o.W * o.C;
+    } else if (op.kind == Y6_OP_SPPF) {
+        by = 2.0 * 4.0 * op.t[0].B * op.t[0].H * op.t[0].W * op.t[0].C;
+    } else if (op.kind == Y6_OP_DECODE) {
+        double A = 0;
+        for (int l = 0; l < op.dec.n_levels; ++l) A += (double)op.dec.cls[l].H * op.dec.cls[l].W;
+        const double B = op.dec.cls[0].B;
+        by = B * A * ((op.dec.nc + 5) * 4.0 + (op.dec.nc + op.dec.reg[0].C) * 2.0);
+    }
+    *pf = f;
+    *pby = by;
+}
+
 static void drop_graph(y6_plan* p) {
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
@@ -74,10 +105,74 @@ static void drop_graph(y6_plan* p) {
 }
 
 extern "C" y6_plan* y6_plan_create(void) { return new y6_plan(); }
+static void drop_events(y6_plan* p) {
+    for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+    p->events.clear();
+    p->slots = p->slots_used = 0;
+}
 extern "C" void y6_plan_destroy(y6_plan* p) {
     if (!p) return;
     drop_graph(p);
+    drop_events(p);
     delete p;
+}
+
+extern "C" int y6_plan_timing_begin(y6_plan* p, int slots) {
+    Y6_REQUIRE(p && slots > 0, "plan_timing_begin: bad arguments");
+    drop_events(p);
+    const size_t n = (size_t)slots * (p->ops.size() + 1);
+    p->events.resize(n);
+    for (size_t i = 0; i < n; ++i) Y6_HIP(hipEventCreate(&p->events[i]));
+    p->slots = slots;
+    return Y6_OK;
+}
+
+extern "C" int y6_plan_run_timed(y6_plan* p, void* stream) {
+    // Eager run with a hipEvent between consecutive ops (on `stream`, the stream the kernels are
+    // launched on).  No synchronisation here; y6_plan_timing_read sums the slots afterwards.
+    Y6_REQUIRE(p && p->slots_used < p->slots, "plan_run_timed: no timing slot left (call y6_plan_timing_begin)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = p->ops.size();
+    hipEvent_t* ev = &p->events[(size_t)p->slots_used * (n + 1)];
+    Y6_HIP(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < n; ++i) {
+        int rc = run_op(p->ops[i], s);
+        if (rc) return rc;
+        Y6_HIP(hipEventRecord(ev[i + 1], s));
+    }
+    ++p->slots_used;
+    return Y6_OK;
+}
+
+extern "C" int y6_plan_timing_read(y6_plan* p, float* ms_sum, int cap) {
+    // ms_sum[i] = total milliseconds op i took over all used slots. Call after synchronising.
+    Y6_REQUIRE(p && ms_sum, "plan_timing_read: null argument");
+    const size_t n = p->ops.size();
+    for (size_t i = 0; i < n && (int)i < cap; ++i) ms_sum[i] = 0.f;
+    for (int sl = 0; sl < p->slots_used; ++sl) {
+        hipEvent_t* ev = &p->events[(size_t)sl * (n + 1)];
+        for (size_t i = 0; i < n && (int)i < cap; ++i) {
+            float ms = 0.f;
+            Y6_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_sum[i] += ms;
+        }
+    }
+    return p->slots_used;
+}
+
+extern "C" int y6_plan_op_info(const y6_plan* p, int i, int32_t* kind, int32_t* variant, int32_t* ksize, int32_t* stride,
+                               double* flops, double* bytes) {
+    Y6_REQUIRE(p && i >= 0 && i < (int)p->ops.size(), "plan_op_info: bad index");
+    const Op& op = p->ops[i];
+    if (kind) *kind = op.kind;
+    if (variant) *variant = op.kind == Y6_OP_CONV ? op.conv.variant : -1;
+    if (ksize) *ksize = op.kind == Y6_OP_CONV ? op.conv.ksize : 0;
+    if (stride) *stride = op.kind == Y6_OP_CONV ? op.conv.stride : 0;
+    double f = 0.0, by = 0.0;
+    op_cost(op, &f, &by);
+    if (flops) *flops = f;
+    if (bytes) *bytes = by;
+    return Y6_OK;
 }
 extern "C" int y6_plan_num_ops(const y6_plan* p) { return p ? (int)p->ops.size() : 0; }
 
@@ -233,6 +328,8 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     drop_graph(p);
     if (iters < 1) iters = 3;
     const int nv = y6_conv_variants();
+    const char* logpath = getenv("Y6_AUTOTUNE_LOG");   // optional: append every (op, variant, ms) measurement
+    FILE* logf = logpath ? fopen(logpath, "a") : nullptr;
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
         if (op.kind != Y6_OP_CONV) continue;
@@ -244,7 +341,14 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             trial.conv.variant = v;
             float ms = 0.f;
             int rc = time_op(trial, s, iters, &ms);
-            if (rc) return rc;
+            if (rc) {
+                if (logf) fclose(logf);
+                return rc;
+            }
+            if (logf)
+                fprintf(logf, "op %zu k%d s%d cin %d cout %d in %dx%dx%d variant %s ms %.5f gflops %.1f\n", i,
+                        op.conv.ksize, op.conv.stride, op.conv.in.C, op.conv.out.C, op.conv.in.B, op.conv.in.H,
+                        op.conv.in.W, y6_conv_variant_name(v), ms, y6_conv_flops(&op.conv) / (ms * 1e6));
             if (ms < best_ms) {
                 best_ms = ms;
                 best = v;
@@ -254,6 +358,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
         Y6_REQUIRE(best >= 0, "plan_autotune: op %zu has no runnable conv variant", i);
         op.conv.variant = best;
     }
+    if (logf) fclose(logf);
     Y6_HIP(hipStreamSynchronize(s));
     return Y6_OK;
 }
@@ -272,26 +377,7 @@ extern "C" int y6_plan_profile(y6_plan* p, void* stream, int iters, float* ms, i
         if (kind) kind[i] = op.kind;
         if (variant) variant[i] = op.kind == Y6_OP_CONV ? op.conv.variant : -1;
         double f = 0.0, by = 0.0;
-        if (op.kind == Y6_OP_CONV) {
-            f = y6_conv_flops(&op.conv);
-            by = y6_conv_bytes(&op.conv);
-        } else if (op.kind == Y6_OP_CONVT) {
-            const y6_tensor &a = op.convt.in, &o = op.convt.out;
-            f = 2.0 * o.B * o.H * o.W * (double)o.C * a.C;
-            by = 2.0 * ((double)a.B * a.H * a.W * a.C + (double)o.B * o.H * o.W * o.C + 4.0 * a.C * o.C);
-        } else if (op.kind == Y6_OP_STEM) {
-            const y6_tensor& o = op.stem.out;
-            f = 2.0 * o.B * o.H * o.W * (double)o.C * op.stem.Cin * 9;
-            by = (op.stem.in_dtype == Y6_F16 ? 2.0 : 4.0) * op.stem.B * op.stem.Cin * (double)op.stem.H * op.stem.W +
-                 2.0 * o.B * o.H * o.W * o.C;
-        } else if (op.kind == Y6_OP_SPPF) {
-            by = 2.0 * 4.0 * op.t[0].B * op.t[0].H * op.t[0].W * op.t[0].C;
-        } else if (op.kind == Y6_OP_DECODE) {
-            double A = 0;
-            for (int l = 0; l < op.dec.n_levels; ++l) A += (double)op.dec.cls[l].H * op.dec.cls[l].W;
-            const double B = op.dec.cls[0].B;
-            by = B * A * ((op.dec.nc + 5) * 4.0 + (op.dec.nc + op.dec.reg[0].C) * 2.0);
-        }
+        op_cost(op, &f, &by);
         if (flops) flops[i] = f;
         if (bytes) bytes[i] = by;
     }

@@ -97,6 +97,33 @@ class Plan:
         _lib.check(self._lib.y6_plan_capture(self._h, _lib.current_stream_ptr()), "plan_capture")
         self.captured = True
 
+    def timing_begin(self, slots: int):
+        _lib.check(self._lib.y6_plan_timing_begin(self._h, slots), "plan_timing_begin")
+
+    def run_timed(self):
+        """run() with a hipEvent between consecutive ops (live per-kernel timing)."""
+        _lib.check(self._lib.y6_plan_run_timed(self._h, _lib.current_stream_ptr()), "plan_run_timed")
+        return self.outputs
+
+    def timing_read(self):
+        """After a device sync: list of dict(op, kind, variant, ksize, stride, ms, flops, bytes) with ms = mean per run."""
+        n = self.num_ops
+        ms = (C.c_float * n)()
+        used = self._lib.y6_plan_timing_read(self._h, ms, n)
+        if used < 0:
+            _lib.check(used, "plan_timing_read")
+        names = {1: "conv", 2: "convt", 3: "stem", 4: "sppf", 5: "decode", 6: "nchw2nhwc", 7: "nhwc2nchw"}
+        rows = []
+        for i in range(n):
+            kind, var, ks, st = (C.c_int32() for _ in range(4))
+            fl, by = C.c_double(), C.c_double()
+            _lib.check(self._lib.y6_plan_op_info(self._h, i, C.byref(kind), C.byref(var), C.byref(ks), C.byref(st),
+                                                 C.byref(fl), C.byref(by)), "plan_op_info")
+            vname = self._lib.y6_conv_variant_name(var.value).decode() if var.value >= 0 else ""
+            rows.append(dict(op=i, kind=names.get(kind.value, "?"), variant=vname, ksize=ks.value, stride=st.value,
+                             ms=float(ms[i]) / max(used, 1), flops=fl.value, bytes=by.value))
+        return rows
+
     @property
     def num_ops(self) -> int:
         return self._lib.y6_plan_num_ops(self._h)
