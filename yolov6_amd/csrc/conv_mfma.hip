@@ -377,26 +377,36 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     return Y6_OK;
 }
 
+template <int CF, int PF, int KS, int ST>
+int launch_one(const Launch& L, hipStream_t s) {
+    // dynamic LDS above 64 KiB (stride-2 halo + a 3-slot ring of 4-fragment weight images) must be
+    // opted into once per kernel; gfx950 has 160 KiB per CU
+    static bool big_lds_enabled = false;
+    if (L.lds > 64 * 1024 && !big_lds_enabled) {
+        Y6_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<CF, PF, KS, ST>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        big_lds_enabled = true;
+    }
+    Y6_REQUIRE(L.lds <= 128 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
+    hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, KS, ST>), dim3(L.grid), dim3(256), L.lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 template <int CF, int PF>
 int launch_cfg(const Launch& L, int ks, int st, hipStream_t s) {
-    dim3 grid(L.grid), block(256);
-    if (ks == 1 && st == 1) {
-        hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, 1, 1>), grid, block, L.lds, s, L.k);
-    } else if (ks == 3 && st == 1) {
-        hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, 3, 1>), grid, block, L.lds, s, L.k);
-    } else if (ks == 3 && st == 2) {
+    if (ks == 1 && st == 1) return launch_one<CF, PF, 1, 1>(L, s);
+    if (ks == 3 && st == 1) return launch_one<CF, PF, 3, 1>(L, s);
+    if (ks == 3 && st == 2) {
         if constexpr (PF == 1) {
-            hipLaunchKernelGGL((conv_mfma_kernel<CF, 1, 3, 2>), grid, block, L.lds, s, L.k);
+            return launch_one<CF, 1, 3, 2>(L, s);
         } else {
             y6_set_error("conv_mfma: stride-2 needs a pf=1 variant");
             return Y6_EUNSUPPORTED;
         }
-    } else {
-        y6_set_error("conv_mfma: unsupported ksize/stride %d/%d", ks, st);
-        return Y6_EUNSUPPORTED;
     }
-    Y6_LAUNCH_CHECK();
-    return Y6_OK;
+    y6_set_error("conv_mfma: unsupported ksize/stride %d/%d", ks, st);
+    return Y6_EUNSUPPORTED;
 }
 
 }  // namespace

@@ -88,6 +88,7 @@ class HipModule(nn.Module):
     def __getstate__(self):
         st = self.__dict__.copy()
         st.pop("_y6_plans", None)
+        st.pop("_featrefs", None)
         return st
 
     def _check_runnable(self):
