@@ -32,7 +32,7 @@ if has bench; then
 fi
 if has prof; then
   echo "== rocprofv3 kernel stats"
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
   echo "prof rc=$?"; find "$OUT/prof" -name "*kernel_stats*" | head -3
   f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep the merge-back small: drop the raw trace, keep stats
@@ -40,9 +40,9 @@ if has prof; then
 fi
 if has pmc; then
   echo "== rocprofv3 pmc (separate passes)"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" )
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err" )
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$OLDPWD/$OUT/pmc_sq" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$OLDPWD/$OUT/pmc_sq" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err" )
   ls "$OUT"/pmc_*
 fi
 du -sh "$OUT"

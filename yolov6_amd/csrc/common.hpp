@@ -28,6 +28,10 @@ void y6_set_error(const char* fmt, ...);
         }                                                                                    \
     } while (0)
 
+// hipGetLastError() is sticky per thread: an unrelated earlier failure (e.g. a device probe made by
+// another library) would otherwise be reported by the next launch check.  Entry points clear it.
+#define Y6_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
 #define Y6_LAUNCH_CHECK()                                                                    \
     do {                                                                                     \
         hipError_t _e = hipGetLastError();                                                   \

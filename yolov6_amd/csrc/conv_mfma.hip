@@ -38,7 +38,7 @@ struct ConvKArgs {
     int ldsA_bytes;
     int act;
     int vec_ok;
-    int up, updy, updx, upH, upW;
+    int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
 template <int KS, int ST, int PF>
@@ -100,6 +100,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         goff[i] = g;
     }
 
+    // ConvTranspose2d(k2,s2): which (dy,dx) this block scatters to, and its first real channel
+    int updy = a.updy, updx = a.updx, upc0 = 0;
+    if (a.up == 2) {
+        const int sub = (cb * CF * 32) / a.upC;
+        updy = sub >> 1;
+        updx = sub & 1;
+        upc0 = sub * a.upC;
+    }
+
     // ---- per-lane pixel operand addressing
     int pixoff[PF];
     int opix[PF];  // output pixel index (elements / out_cs), -1 when masked
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
             const int t = ox / a.upW;
             const int y = t % a.upH;
             const int bb = t / a.upH;
-            op = (bb * 2 * a.upH + 2 * y + a.updy) * (2 * a.upW) + 2 * x + a.updx;
+            op = (bb * 2 * a.upH + 2 * y + updy) * (2 * a.upW) + 2 * x + updx;
         } else {
             op = (b * a.Ho + oy) * a.Wo + ox;
         }
@@ -235,14 +244,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         for (int cf = 0; cf < CF; ++cf) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int c0 = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);
-                if (c0 >= a.Cout) continue;
+                const int cg = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);  // row of the weight matrix
+                if (cg >= a.Cout) continue;
+                const int c0 = cg - upc0;                                       // output channel
+                const int cend = a.up == 2 ? a.upC : a.Cout;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = c0 + j;
                     float x = acc[cf][pf][r4 * 4 + j];
-                    if (c < a.Cout) {
+                    if (c < cend) {
                         if (a.bias) x += a.bias[c];
                         if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
                         x = y6_act(x, a.act);
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
                     }
                     v[j] = x;
                 }
-                if (a.vec_ok && (c0 + 3) < a.Cout) {
+                if (a.vec_ok && (c0 + 3) < cend) {
                     h4_t o;
                     o[0] = (_Float16)v[0];
                     o[1] = (_Float16)v[1];
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c0 + j < a.Cout) orow[c0 + j] = __float2half(v[j]);
+                        if (c0 + j < cend) orow[c0 + j] = __float2half(v[j]);
                 }
             }
         }
@@ -345,6 +356,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.updx = updx;
     k.upH = d->in.H;
     k.upW = d->in.W;
+    k.upC = up == 2 ? d->out.C / 4 : d->out.C;
     const int bp = 128 * vc.pf;
     if (ks == 1) {
         // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row

@@ -29,25 +29,33 @@ __global__ void pack_conv_weight_kernel(const T* __restrict__ src, int Cout, int
     }
 }
 
-// ConvTranspose2d weight is IOHW [Cin][Cout][2][2]; sub-kernel (dy,dx) is a 1x1 conv
+// ConvTranspose2d weight is IOHW [Cin][Cout][2][2]; sub-kernel (dy,dx) is a 1x1 conv.
+// fused (Cout % 32 == 0): ONE packed matrix of 4*Cout rows, row = sub*Cout + c, sub = dy*2+dx;
+// otherwise four separately padded packed 1x1 weights.
 template <typename T>
 __global__ void pack_convt_weight_kernel(const T* __restrict__ src, int Cin, int Cout, int cfr_pad, int nchunk,
-                                         __half* __restrict__ dst) {
+                                         int fused, __half* __restrict__ dst) {
     const size_t per = (size_t)cfr_pad * nchunk * 1024;
-    const size_t total = per * 4;
+    const size_t total = fused ? per : per * 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int sub = (int)(i / per);  // dy*2+dx
-        const size_t ii = i - (size_t)sub * per;
+        int sub = fused ? 0 : (int)(i / per);
+        const size_t ii = fused ? i : i - (size_t)sub * per;
         const int j = (int)(ii & 7);
         const int lane = (int)((ii >> 3) & 63);
         const int ks = (int)((ii >> 9) & 1);
         size_t r = ii >> 10;
         const int chunk = (int)(r % nchunk);
         const int cfr = (int)(r / nchunk);
-        const int cout = cfr * 32 + (lane & 31);
+        int cout = cfr * 32 + (lane & 31);
+        bool ok = cout < Cout;
+        if (fused) {
+            sub = cout / Cout;
+            ok = cout < 4 * Cout;
+            cout -= sub * Cout;
+        }
         const int cin = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
         float v = 0.f;
-        if (cout < Cout && cin < Cin) v = (float)src[((size_t)cin * Cout + cout) * 4 + sub];
+        if (ok && cin < Cin) v = (float)src[((size_t)cin * Cout + cout) * 4 + sub];
         dst[i] = __float2half(v);
     }
 }
@@ -136,6 +144,122 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ i
             o[j] = (_Float16)y6_act(x, act);
         }
         *reinterpret_cast<h8_t*>(op + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------ stem conv on the matrix cores
+// The stem is a [pixels x 27] x [27 x Cout] GEMM (Cin = 3): K is padded to 32 = two
+// v_mfma_f32_32x32x16_f16 k-steps.  A operand = weights (row = cout), B operand = the 3x3x3 patch of
+// one output pixel, gathered straight from the caller's NCHW image (k = ci*9 + ky*3 + kx, exactly
+// the OIHW flattening).  One wave = 64 output pixels x CF*32 couts; no LDS, no layout pre-pass.
+template <typename TI, int CF>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ in, __half* __restrict__ out,
+                                                        const float* __restrict__ w /*[Cout][Cin*9]*/,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ pscale,
+                                                        const float* __restrict__ pshift, int B, int Cin, int H, int W,
+                                                        int Ho, int Wo, int Cout, int out_cs, int out_co, int act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int kh = lane >> 5;  // which 8-wide k group of a k-step this lane feeds
+    const int K = Cin * 9;
+    const size_t npix = (size_t)B * Ho * Wo;
+    const size_t HW = (size_t)H * W;
+
+    // weights: A fragments (cout = cf*32 + lane&31, k = ks*16 + kh*8 + j)
+    h8_t af[CF][2];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = cf * 32 + (lane & 31), k = ks * 16 + kh * 8 + j;
+                af[cf][ks][j] = (co < Cout && k < K) ? (_Float16)w[(size_t)co * K + k] : (_Float16)0.f;
+            }
+
+    // per-lane patch offsets (relative to the patch origin) - identical for every pixel
+    int koff[2][8];
+    int kyx[2][8];  // ky | kx<<8 | valid<<16
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + kh * 8 + j;
+            const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
+            koff[ks][j] = (int)(ci * HW) + ky * W + kx;
+            kyx[ks][j] = ky | (kx << 8) | ((k < K) << 16);
+        }
+
+    const size_t wave_pix0 = ((size_t)blockIdx.x * 4 + wave) * 64;
+    f32x16_t acc[CF][2];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+
+    size_t gp[2];
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        gp[pf] = wave_pix0 + pf * 32 + (lane & 31);
+        const size_t q = gp[pf] < npix ? gp[pf] : npix - 1;
+        const int ox = (int)(q % Wo);
+        const size_t t = q / Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const int iy0 = oy * 2 - 1, ix0 = ox * 2 - 1;
+        const long base = (long)((size_t)b * Cin * HW) + (long)iy0 * W + ix0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h8_t bf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ky = kyx[ks][j] & 0xff, kx = (kyx[ks][j] >> 8) & 0xff;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                const bool ok = (kyx[ks][j] >> 16) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const long off = ok ? base + koff[ks][j] : 0;  // clamp the address, select the value
+                const float v = (float)in[off];
+                bf[j] = ok ? (_Float16)v : (_Float16)0.f;
+            }
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+                acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf][ks], bf, acc[cf][pf], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        if (gp[pf] >= npix) continue;
+        __half* orow = out + gp[pf] * out_cs + out_co;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c0 = cf * 32 + 8 * r4 + 4 * kh;
+                if (c0 >= Cout) continue;
+                h4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    float x = acc[cf][pf][r4 * 4 + j];
+                    if (c < Cout) {
+                        if (bias) x += bias[c];
+                        if (pscale) x = x * pscale[c] + pshift[c];
+                        x = y6_act(x, act);
+                    }
+                    o[j] = (_Float16)x;
+                }
+                if (c0 + 3 < Cout) {
+                    *reinterpret_cast<h4_t*>(orow + c0) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < Cout) orow[c0 + j] = (__half)o[j];
+                }
+            }
     }
 }
 
@@ -232,6 +356,7 @@ extern "C" size_t y6_packed_weight_elems(int Cout, int Cin, int K) {
 }
 
 extern "C" int y6_pack_conv_weight(const void* src, int src_dtype, int Cout, int Cin, int K, void* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(src && dst && Cout > 0 && Cin > 0 && (K == 1 || K == 3), "pack_conv_weight: bad arguments");
     const int cfr_pad = y6_cdiv(y6_cdiv(Cout, 32), 4) * 4, nchunk = y6_cdiv(Cin, 32);
     const size_t total = (size_t)cfr_pad * nchunk * K * K * 1024;
@@ -249,16 +374,19 @@ extern "C" int y6_pack_conv_weight(const void* src, int src_dtype, int Cout, int
 }
 
 extern "C" int y6_pack_convt2x2_weight(const void* src, int src_dtype, int Cin, int Cout, void* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(src && dst && Cout > 0 && Cin > 0, "pack_convt2x2_weight: bad arguments");
-    const int cfr_pad = y6_cdiv(y6_cdiv(Cout, 32), 4) * 4, nchunk = y6_cdiv(Cin, 32);
-    const size_t total = (size_t)cfr_pad * nchunk * 1024 * 4;
+    const int fused = (Cout % 32) == 0;
+    const int rows = fused ? 4 * Cout : Cout;
+    const int cfr_pad = y6_cdiv(y6_cdiv(rows, 32), 4) * 4, nchunk = y6_cdiv(Cin, 32);
+    const size_t total = (size_t)cfr_pad * nchunk * 1024 * (fused ? 1 : 4);
     hipStream_t s = (hipStream_t)stream;
     if (src_dtype == Y6_F16)
         hipLaunchKernelGGL(pack_convt_weight_kernel<__half>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                           (const __half*)src, Cin, Cout, cfr_pad, nchunk, (__half*)dst);
+                           (const __half*)src, Cin, Cout, cfr_pad, nchunk, fused, (__half*)dst);
     else if (src_dtype == Y6_F32)
         hipLaunchKernelGGL(pack_convt_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s,
-                           (const float*)src, Cin, Cout, cfr_pad, nchunk, (__half*)dst);
+                           (const float*)src, Cin, Cout, cfr_pad, nchunk, fused, (__half*)dst);
     else
         Y6_REQUIRE(false, "pack_convt2x2_weight: bad dtype %d", src_dtype);
     Y6_LAUNCH_CHECK();
@@ -294,10 +422,10 @@ static int check_conv_desc(const y6_conv_desc* d) {
     return Y6_OK;
 }
 
-// default variant: widest cout block that fits, 256-pixel tiles for stride 1
+// default variant when a plan was not autotuned
 static int default_variant(const y6_conv_desc* d) {
-    const int prefs_s1[] = {6, 5, 4, 3, 2, 1, 0};
-    const int prefs_s2[] = {3, 2, 1, 0};
+    const int prefs_s1[] = {2, 1, 5, 4, 3, 6, 0};   // measured: high-occupancy small tiles win (profiles/r01)
+    const int prefs_s2[] = {2, 1, 3, 0};
     const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
     const int n = d->stride == 1 ? 7 : 4;
     for (int i = 0; i < n; ++i)
@@ -312,6 +440,7 @@ extern "C" int y6_conv_variant_supports(const y6_conv_desc* d, int i) {
 }
 
 extern "C" int y6_conv2d(const y6_conv_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     int rc = check_conv_desc(d);
     if (rc) return rc;
     int v = d->variant;
@@ -332,31 +461,47 @@ double y6_conv_bytes(const y6_conv_desc* d) {
            4.0 * d->out.C + (d->res.data ? 2.0 * d->out.B * d->out.H * d->out.W * d->out.C : 0.0);
 }
 
+// variant for a convT (sub-)GEMM: small pixel tiles win (autotune table, profiles/r01); the cout block
+// must not straddle two (dy,dx) sub-kernels in the fused form
+static int convt_variant(const y6_conv_desc* c, int upC, int fused) {
+    const int prefs[] = {2, 1, 5, 4, 3, 6};
+    const int cfs[] = {0, 1, 2, 4, 1, 2, 4};
+    for (int i = 0; i < 6; ++i) {
+        const int v = prefs[i];
+        if (fused && (upC % (cfs[v] * 32)) != 0) continue;
+        if (y6_conv_mfma_supports(c, v)) return v;
+    }
+    return -1;
+}
+
 extern "C" int y6_convt2x2(const y6_convt_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(d && d->in.data && d->out.data && d->w_packed, "convt2x2: null argument");
     Y6_REQUIRE(d->out.B == d->in.B && d->out.H == 2 * d->in.H && d->out.W == 2 * d->in.W, "convt2x2: output must be 2x input");
-    const size_t per = y6_packed_weight_elems(d->out.C, d->in.C, 1);
+    const int Cout = d->out.C;
+    y6_conv_desc c;
+    memset(&c, 0, sizeof(c));
+    c.in = d->in;
+    c.out = d->out;
+    // the 1x1 (sub-)conv runs over the INPUT grid; the kernel scatters to (2y+dy, 2x+dx)
+    c.out.H = d->in.H;
+    c.out.W = d->in.W;
+    c.bias = d->bias;
+    c.ksize = 1;
+    c.stride = 1;
+    c.act = Y6_ACT_NONE;
+    if (Cout % 32 == 0) {  // one launch: the four sub-kernels are cout blocks of one [4*Cout x Cin] GEMM
+        c.out.C = 4 * Cout;
+        c.w_packed = d->w_packed;
+        const int v = convt_variant(&c, Cout, 1);
+        Y6_REQUIRE(v > 0, "convt2x2: unsupported shape Cin %d Cout %d", d->in.C, Cout);
+        return y6_conv_mfma_launch(&c, v, (hipStream_t)stream, 2, 0, 0);
+    }
+    const size_t per = y6_packed_weight_elems(Cout, d->in.C, 1);
     for (int sub = 0; sub < 4; ++sub) {
-        y6_conv_desc c;
-        memset(&c, 0, sizeof(c));
-        c.in = d->in;
-        c.out = d->out;
-        // the 1x1 sub-conv runs over the INPUT grid; the kernel scatters to (2y+dy, 2x+dx)
-        c.out.H = d->in.H;
-        c.out.W = d->in.W;
         c.w_packed = (const __half*)d->w_packed + sub * per;
-        c.bias = d->bias;
-        c.ksize = 1;
-        c.stride = 1;
-        c.act = Y6_ACT_NONE;
-        int v = -1;
-        const int prefs[] = {6, 5, 4, 3, 2, 1};
-        for (int i = 0; i < 6; ++i)
-            if (y6_conv_mfma_supports(&c, prefs[i])) {
-                v = prefs[i];
-                break;
-            }
-        Y6_REQUIRE(v > 0, "convt2x2: unsupported shape Cin %d Cout %d", d->in.C, d->out.C);
+        const int v = convt_variant(&c, Cout, 0);
+        Y6_REQUIRE(v > 0, "convt2x2: unsupported shape Cin %d Cout %d", d->in.C, Cout);
         int rc = y6_conv_mfma_launch(&c, v, (hipStream_t)stream, 1, sub >> 1, sub & 1);
         if (rc) return rc;
     }
@@ -364,14 +509,32 @@ extern "C" int y6_convt2x2(const y6_convt_desc* d, void* stream) {
 }
 
 extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(d && d->in_nchw && d->out.data && d->w_oihw_f32, "stem_conv: null argument");
     const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
     Y6_REQUIRE(d->out.B == d->B && d->out.H == Ho && d->out.W == Wo, "stem_conv: bad output shape");
     Y6_REQUIRE(d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "stem_conv: output slice must be 8-channel aligned");
     const int CO = d->out.C;
     const size_t total = (size_t)d->B * Ho * Wo;
-    dim3 grid((unsigned)((total + 255) / 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (d->Cin * 9 <= 32 && CO <= 64 && d->out.cstride % 4 == 0 && d->out.coff % 4 == 0) {
+        dim3 g((unsigned)((total + 255) / 256)), blk(256);
+#define Y6_STEM_MFMA(TI, CF_)                                                                                     \
+    hipLaunchKernelGGL((stem_mfma_kernel<TI, CF_>), g, blk, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data,      \
+                       d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo, CO, \
+                       d->out.cstride, d->out.coff, d->act)
+        if (d->in_dtype == Y6_F16) {
+            if (CO <= 32) Y6_STEM_MFMA(__half, 1); else Y6_STEM_MFMA(__half, 2);
+        } else if (d->in_dtype == Y6_F32) {
+            if (CO <= 32) Y6_STEM_MFMA(float, 1); else Y6_STEM_MFMA(float, 2);
+        } else {
+            Y6_REQUIRE(false, "stem_conv: bad input dtype");
+        }
+#undef Y6_STEM_MFMA
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
 #define Y6_STEM_CASE(TI, CO_)                                                                                      \
     hipLaunchKernelGGL((stem_conv_kernel<TI, CO_>), grid, block, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data, \
                        d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo,      \
@@ -404,6 +567,7 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
 
 extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3,
                             void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(x && y1 && y2 && y3 && x->data && y1->data && y2->data && y3->data, "sppf_pool: null tensor");
     Y6_REQUIRE(x->C % 8 == 0 && x->coff % 8 == 0 && x->cstride % 8 == 0, "sppf_pool: channels must be 8-aligned");
     const y6_tensor* ys[3] = {y1, y2, y3};
@@ -424,6 +588,7 @@ extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_te
 }
 
 extern "C" int y6_nchw_to_nhwc(const void* src, int src_dtype, const y6_tensor* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(src && dst && dst->data, "nchw_to_nhwc: null argument");
     const size_t total = (size_t)dst->B * dst->H * dst->W * dst->C;
     dim3 grid(grid_for(total, 256)), block(256);
@@ -438,6 +603,7 @@ extern "C" int y6_nchw_to_nhwc(const void* src, int src_dtype, const y6_tensor* 
 }
 
 extern "C" int y6_nhwc_to_nchw(const y6_tensor* src, void* dst, int dst_dtype, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(src && dst && src->data, "nhwc_to_nchw: null argument");
     const size_t total = (size_t)src->B * src->H * src->W * src->C;
     dim3 grid(grid_for(total, 256)), block(256);

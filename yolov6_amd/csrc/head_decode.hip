@@ -4,7 +4,7 @@
 //   anchor_points = (x+0.5, y+0.5), stride per level  (assigners/anchor_generator.py:13-33)
 //   box = dist2bbox(reg, anchor_points, 'xywh') * stride   (utils/general.py:32-43)
 //   out[b, a, :] = (cx, cy, w, h, 1.0, cls[0..nc))   fp32, levels concatenated along a.
-// One thread per output element -> fully coalesced fp32 stores; the fp16 NHWC logits of a
+// Four output elements per thread -> 16-byte coalesced fp32 stores; the fp16 NHWC logits of a
 // pixel are contiguous so the class reads coalesce too.
 #include "common.hpp"
 
@@ -42,44 +42,59 @@ __device__ __forceinline__ float side_dist(const DecodeArgs& a, int l, size_t pi
     return num / den;
 }
 
-__global__ void head_decode_kernel(const DecodeArgs a) {
+__device__ __forceinline__ float decode_element(const DecodeArgs& a, size_t i, int no) {
+    const int j = (int)(i % no);
+    const size_t ba = i / no;
+    const int an = (int)(ba % a.A);
+    const int b = (int)(ba / a.A);
+    int l = 0;
+#pragma unroll
+    for (int t = 1; t < Y6_MAX_LEVELS; ++t)
+        if (t < a.n_levels && an >= a.astart[t]) l = t;
+    const int local = an - a.astart[l];
+    const int y = local / a.W[l], x = local - y * a.W[l];
+    const size_t pix = ((size_t)b * a.H[l] + y) * a.W[l] + x;
+    if (j >= 5) {
+        const float z = __half2float(a.cls[l][pix * a.cls_cs[l] + a.cls_co[l] + (j - 5)]);
+        return 1.f / (1.f + __expf(-z));
+    }
+    if (j == 4) return 1.f;
+    // (l,t,r,b) distances -> xywh
+    const int ax = j & 1;  // 0: x / w, 1: y / h
+    const float lo = side_dist(a, l, pix, ax);       // left or top
+    const float hi = side_dist(a, l, pix, 2 + ax);   // right or bottom
+    const float ap = (ax == 0 ? (float)x : (float)y) + a.cell_offset;
+    const float p1 = ap - lo, p2 = ap + hi;
+    const float v = (j < 2) ? (p1 + p2) / 2.f : (p2 - p1);
+    return v * a.stride[l];
+}
+
+// Four consecutive output floats per thread -> one 16-byte store per lane (the [B,A,5+nc] tensor is
+// written exactly once, fully coalesced); the fp16 logits of a pixel are contiguous, so the reads of
+// a wave are contiguous runs too.
+__global__ __launch_bounds__(256) void head_decode_kernel(const DecodeArgs a) {
     const int no = a.nc + 5;
     const size_t total = (size_t)a.B * a.A * no;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % no);
-        const size_t ba = i / no;
-        const int an = (int)(ba % a.A);
-        const int b = (int)(ba / a.A);
-        int l = 0;
-#pragma unroll
-        for (int t = 1; t < Y6_MAX_LEVELS; ++t)
-            if (t < a.n_levels && an >= a.astart[t]) l = t;
-        const int local = an - a.astart[l];
-        const int y = local / a.W[l], x = local - y * a.W[l];
-        const size_t pix = ((size_t)b * a.H[l] + y) * a.W[l] + x;
-        float v;
-        if (j >= 5) {
-            const float z = __half2float(a.cls[l][pix * a.cls_cs[l] + a.cls_co[l] + (j - 5)]);
-            v = 1.f / (1.f + __expf(-z));
-        } else if (j == 4) {
-            v = 1.f;
+    const size_t nvec = (total + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nvec; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t i0 = q * 4;
+        if (i0 + 3 < total) {
+            float4 v;
+            v.x = decode_element(a, i0, no);
+            v.y = decode_element(a, i0 + 1, no);
+            v.z = decode_element(a, i0 + 2, no);
+            v.w = decode_element(a, i0 + 3, no);
+            *reinterpret_cast<float4*>(a.out + i0) = v;
         } else {
-            // (l,t,r,b) distances -> xywh
-            const int ax = j & 1;  // 0: x / w, 1: y / h
-            const float lo = side_dist(a, l, pix, ax);       // left or top
-            const float hi = side_dist(a, l, pix, 2 + ax);   // right or bottom
-            const float ap = (ax == 0 ? (float)x : (float)y) + a.cell_offset;
-            const float p1 = ap - lo, p2 = ap + hi;
-            v = (j < 2) ? (p1 + p2) / 2.f : (p2 - p1);
-            v *= a.stride[l];
+            for (size_t i = i0; i < total; ++i) a.out[i] = decode_element(a, i, no);
         }
-        a.out[i] = v;
     }
 }
 
 }  // namespace
 
 extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(d && d->out && d->n_levels >= 1 && d->n_levels <= Y6_MAX_LEVELS, "head_decode: bad descriptor");
     Y6_REQUIRE(!d->use_dfl || d->proj, "head_decode: use_dfl needs proj");
     DecodeArgs a;
@@ -115,7 +130,8 @@ extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
     a.A = A;
     a.nc = d->nc;
     const size_t total = (size_t)a.B * A * (d->nc + 5);
-    size_t g = (total + 255) / 256;
+    Y6_REQUIRE(((uintptr_t)d->out & 15) == 0, "head_decode: output must be 16-byte aligned");
+    size_t g = ((total + 3) / 4 + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
     Y6_LAUNCH_CHECK();

@@ -35,25 +35,34 @@ __device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classe
     return false;
 }
 
+// One block = `rpb` consecutive anchor rows of ONE image (blockIdx interleaves images so that
+// concurrently running blocks append to different per-image counters).  Candidates are staged in
+// LDS (one LDS atomic per wave-row), then the block reserves its slice of the image's key list
+// with a single global atomic and copies the keys out coalesced.  (v1 did one global atomic per
+// row: all resident waves hit the same counter and serialised at ~12 ns each - 4.3 ms per call.)
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int B, int A, int nc,
                                                              float conf_thres, const int* __restrict__ classes,
-                                                             int n_classes, int multi_label, u64* __restrict__ keys,
-                                                             size_t cap, int* __restrict__ counts) {
-    const int lane = threadIdx.x & 63;
-    const size_t gw = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+                                                             int n_classes, int multi_label, int rpb,
+                                                             u64* __restrict__ keys, size_t cap,
+                                                             int* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* stage = reinterpret_cast<u64*>(smem);                         // [rpb * (multi_label ? nc : 1)]
+    __shared__ int s_cnt, s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x % B, chunk = blockIdx.x / B;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     const int no = nc + 5;
-    const size_t rows = (size_t)B * A;
-    for (size_t idx = gw; idx < rows; idx += nw) {
-        const int b = (int)(idx / A), an = (int)(idx % A);
-        const float* row = pred + idx * no;
+    for (int r = wave; r < rpb; r += 4) {
+        const int an = chunk * rpb + r;
+        if (an >= A) break;
+        const float* row = pred + ((size_t)b * A + an) * no;
         const float obj = row[4];
         if (!(obj > conf_thres)) continue;
         float mx = -INFINITY;
         for (int j = lane; j < nc; j += 64) mx = fmaxf(mx, row[5 + j]);
         mx = wave_max(mx);
         if (!(mx > conf_thres)) continue;
-        u64* kb = keys + (size_t)b * cap;
         if (multi_label) {
             for (int j0 = 0; j0 < nc; j0 += 64) {
                 const int j = j0 + lane;
@@ -68,12 +77,12 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                 const int n = __popcll(bal);
                 const int leader = __ffsll((long long)bal) - 1;
                 int base = 0;
-                if (lane == leader) base = atomicAdd(&counts[b], n);
+                if (lane == leader) base = atomicAdd(&s_cnt, n);
                 base = __shfl(base, leader, 64);
                 if (pass) {
                     const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
                     const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)j;
-                    kb[pos] = ((u64)__float_as_uint(c) << 32) | (u64)(0xFFFFFFFFu - flat);
+                    stage[pos] = ((u64)__float_as_uint(c) << 32) | (u64)(0xFFFFFFFFu - flat);
                 }
             }
         } else {
@@ -97,12 +106,19 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                 }
             }
             if (lane == 0 && bc > conf_thres && class_ok(bj, classes, n_classes)) {
-                const int pos = atomicAdd(&counts[b], 1);
+                const int pos = atomicAdd(&s_cnt, 1);
                 const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)bj;
-                kb[pos] = ((u64)__float_as_uint(bc) << 32) | (u64)(0xFFFFFFFFu - flat);
+                stage[pos] = ((u64)__float_as_uint(bc) << 32) | (u64)(0xFFFFFFFFu - flat);
             }
         }
     }
+    __syncthreads();
+    const int total = s_cnt;
+    if (total == 0) return;
+    if (tid == 0) s_base = atomicAdd(&counts[b], total);
+    __syncthreads();
+    u64* kb = keys + (size_t)b * cap + s_base;
+    for (int i = tid; i < total; i += 256) kb[i] = stage[i];
 }
 
 // descending bitonic sort of P (power of two) keys by the whole block
@@ -126,7 +142,10 @@ __device__ void bitonic_desc(u64* keys, int P) {
     }
 }
 
-constexpr int kLdsKeys = 16384;  // 128 KiB of 64-bit keys
+constexpr int kLdsKeys = 16384;                 // 128 KiB of 64-bit keys during the sort
+constexpr int kLdsBoxes = 7936;                 // afterwards: 124 KiB of sorted boxes ...
+constexpr int kLdsRemovedWords = 512;           // ... + 4 KiB removed-bitmask (max_nms 30000 -> 469 words)
+constexpr size_t kSweepLds = (size_t)kLdsBoxes * 16 + (size_t)kLdsRemovedWords * 8;
 
 __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __restrict__ pred, int A, int nc,
                                                               float iou_thres, int agnostic, int max_det, int max_nms,
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
     bitonic_desc(sk, P);
     if (n > max_nms) n = max_nms;
 
-    // sorted boxes (class-offset xyxy) to the workspace; keep flat ids next to them
+    // sorted class-offset xyxy boxes -> global workspace; sorted keys back to global
     float4* bx = boxes + (size_t)b * max_nms;
     const int no = nc + 5;
     for (int i = tid; i < n; i += T) {
@@ -174,23 +193,25 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
         q.z = (x + w / 2.f) + off;
         q.w = (y + h / 2.f) + off;
         bx[i] = q;
-        if (sk != gk) gk[i] = key;  // sorted keys back to global for the output stage
+        if (sk != gk) gk[i] = key;
     }
-    __syncthreads();
+    __syncthreads();  // keys in LDS are dead from here: the LDS is re-used for boxes + bitmask
 
-    // removed bitmask in LDS (the key area is dead now when it lived in LDS; reuse its head)
-    u64* removed = reinterpret_cast<u64*>(smem);
+    float4* lbox = reinterpret_cast<float4*>(smem);
+    u64* removed = reinterpret_cast<u64*>(smem + (size_t)kLdsBoxes * 16);
+    const int nl = n < kLdsBoxes ? n : kLdsBoxes;
+    for (int i = tid; i < nl; i += T) lbox[i] = bx[i];
     const int nwords = (n + 63) >> 6;
-    __threadfence_block();
-    __syncthreads();
     for (int i = tid; i < nwords; i += T) removed[i] = 0ull;
     __syncthreads();
 
     const int lane = tid & 63;
     int kept = 0;
     int cur = 0;
+    int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids below
     while (kept < max_det) {
-        // every wave finds the first surviving index >= cur (identical result in all waves)
+        // every wave finds the first surviving index >= cur (identical result in all waves: bits set
+        // concurrently by faster waves belong to later boxes and cannot change "first")
         int found = -1;
         for (int w0 = cur >> 6; w0 < nwords && found < 0; w0 += 64) {
             const int wi = w0 + lane;
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
                 alive = ~removed[wi];
                 if (wi == (cur >> 6)) alive &= ~((1ull << (cur & 63)) - 1ull);
                 const int base = wi << 6;
-                if (base + 64 > n) alive &= (n - base >= 64) ? ~0ull : ((1ull << (n - base)) - 1ull);
+                if (base + 64 > n) alive &= ((1ull << (n - base)) - 1ull);
             }
             const u64 bal = __ballot(alive != 0ull);
             if (bal) {
@@ -210,28 +231,14 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
         }
         if (found < 0) break;
         const int i = found;
-        const float4 bi = bx[i];
-        if (tid == 0) {
-            const u64 key = gk[i];
-            const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-            const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
-            const float* row = pred + ((size_t)b * A + an) * no;
-            const float x = row[0], y = row[1], w = row[2], h = row[3];
-            float* o = out_dets + ((size_t)b * max_det + kept) * 6;
-            o[0] = x - w / 2.f;
-            o[1] = y - h / 2.f;
-            o[2] = x + w / 2.f;
-            o[3] = y + h / 2.f;
-            o[4] = __uint_as_float((unsigned)(key >> 32));
-            o[5] = (float)cls;
-            out_index[(size_t)b * max_det + kept] = (int)flat;
-        }
+        if (tid == 0) kept_pos[kept] = i;
         ++kept;
         if (kept >= max_det) break;
+        const float4 bi = i < nl ? lbox[i] : bx[i];
         const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
         for (int j = i + 1 + tid; j < n; j += T) {
             if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
-            const float4 bj = bx[j];
+            const float4 bj = j < nl ? lbox[j] : bx[j];
             const float left = fmaxf(bi.x, bj.x), right = fminf(bi.z, bj.z);
             const float top = fmaxf(bi.y, bj.y), bottom = fminf(bi.w, bj.w);
             const float iw = fmaxf(right - left, 0.f), ih = fmaxf(bottom - top, 0.f);
@@ -243,6 +250,23 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
         __syncthreads();
         cur = i + 1;
         if (cur >= n) break;
+    }
+    __syncthreads();
+    // detections: (xyxy without the class offset, conf, cls)  nms.py:98 `x[keep_box_idx]`
+    for (int k = tid; k < kept; k += T) {
+        const u64 key = gk[kept_pos[k]];
+        const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
+        const float* row = pred + ((size_t)b * A + an) * no;
+        const float x = row[0], y = row[1], w = row[2], h = row[3];
+        float* o = out_dets + ((size_t)b * max_det + k) * 6;
+        o[0] = x - w / 2.f;
+        o[1] = y - h / 2.f;
+        o[2] = x + w / 2.f;
+        o[3] = y + h / 2.f;
+        o[4] = __uint_as_float((unsigned)(key >> 32));
+        o[5] = (float)cls;
+        kept_pos[k] = (int)flat;
     }
     if (tid == 0) out_count[b] = kept;
 }
@@ -276,6 +300,7 @@ extern "C" size_t y6_nms_workspace_bytes(int B, int A, int nc, int multi_label) 
 }
 
 extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(d && d->pred && d->out_dets && d->out_index && d->out_count && d->workspace, "nms: null argument");
     Y6_REQUIRE(d->conf_thres >= 0.f && d->conf_thres <= 1.f, "conf_thresh must be in 0.0 to 1.0, however %g is provided.",
                (double)d->conf_thres);
@@ -293,13 +318,23 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     float4* boxes = (float4*)(ws + w.off_boxes);
     int* counts = (int*)(ws + w.off_counts);
     Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * sizeof(int), s));
-    const size_t rows = (size_t)d->B * d->A;
-    size_t blocks = (rows + 3) / 4;  // one wave per row
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(nms_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d->pred, d->B, d->A, d->nc,
-                       d->conf_thres, d->classes, d->n_classes, ml, keys, w.cap, counts);
+    // rows per block: as many as fit a 48 KiB staging area (64 rows x 80 classes = 40 KiB)
+    const int per_row = ml ? d->nc : 1;
+    int rpb = 6144 / per_row;
+    rpb = rpb > 64 ? 64 : (rpb < 4 ? 4 : (rpb / 4) * 4);
+    const size_t stage_bytes = (size_t)rpb * per_row * sizeof(u64);
+    Y6_REQUIRE(stage_bytes <= 160 * 1024 - 1024, "nms: %d classes do not fit the LDS staging area", d->nc);
+    static bool cand_attr = false;
+    if (stage_bytes > 64 * 1024 && !cand_attr) {
+        Y6_HIP(hipFuncSetAttribute((const void*)nms_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024 - 1024));
+        cand_attr = true;
+    }
+    const unsigned blocks = (unsigned)d->B * (unsigned)((d->A + rpb - 1) / rpb);
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3(blocks), dim3(256), stage_bytes, s, d->pred, d->B, d->A, d->nc,
+                       d->conf_thres, d->classes, d->n_classes, ml, rpb, keys, w.cap, counts);
     Y6_LAUNCH_CHECK();
-    const size_t lds = (size_t)kLdsKeys * sizeof(u64);
+    const size_t lds = kSweepLds > (size_t)kLdsKeys * sizeof(u64) ? kSweepLds : (size_t)kLdsKeys * sizeof(u64);
     static bool attr_set = false;
     if (!attr_set) {
         Y6_HIP(hipFuncSetAttribute((const void*)nms_sort_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -210,6 +210,7 @@ extern "C" size_t y6_tal_workspace_bytes(int B, int A, int G) {
 }
 
 extern "C" int y6_tal_assign(const y6_tal_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
     Y6_REQUIRE(d && d->pd_scores && d->pd_bboxes && d->anc_points && d->target_labels && d->target_bboxes &&
                    d->target_scores && d->fg_mask,
                "tal_assign: null argument");
