@@ -23,7 +23,7 @@ DEV = "cuda:0"
 CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny"]
 
 
-def _build(case, deploy):
+def _build(case, deploy, half=True):
     cfg, meta = case_config(case)
     m = build_model(cfg, meta["num_classes"], "cpu").eval()
     sd = synth_sd_from_keys(meta["train"])
@@ -31,7 +31,8 @@ def _build(case, deploy):
     m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
     if deploy:
         switch_to_deploy(fuse_model(m))
-    return cfg, meta, sd, m.to(DEV).half()
+    m = m.to(DEV)
+    return cfg, meta, sd, (m.half() if half else m)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -63,11 +64,10 @@ def test_model_vs_oracle_and_golden(case):
 @pytest.mark.parametrize("case", ["tiny", "s_qa_tiny"])
 def test_train_form_eval_equals_deploy(case):
     """Un-fused multi-branch modules in eval mode are re-parameterised at plan-build time."""
-    cfg, meta, sd, m_dep = _build(case, deploy=True)
-    _, _, _, m_train = _build(case, deploy=False)
     # keep the parameters fp32 on both sides: the plan folds in fp32 and rounds the packed weights to
     # fp16 once, exactly like deploy-then-half() (a .half() train-form model rounds each branch first)
-    m_dep, m_train = m_dep.float(), m_train.float()
+    cfg, meta, sd, m_dep = _build(case, deploy=True, half=False)
+    _, _, _, m_train = _build(case, deploy=False, half=False)
     x = synth.synth_images(meta["batch"], meta["size"], seed=2).to(DEV).half()
     a, _ = m_dep(x)
     b, _ = m_train(x)

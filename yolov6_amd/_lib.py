@@ -114,6 +114,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own copy of the HIP runtime; it must be the first one in the process, so that
+    # libyolov6_hip.so's libamdhip64 dependency resolves to the SAME runtime (two runtimes in one
+    # process cannot both own the device: launches fail with "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"yolov6_amd: {LIB_PATH} is missing - build it with `python yolov6_amd/csrc/build.py` "

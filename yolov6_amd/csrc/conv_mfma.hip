@@ -38,6 +38,7 @@ struct ConvKArgs {
     int ldsA_bytes;
     int act;
     int vec_ok;
+    int nids;  // padded (tile, cout-block) id space of the 1-D grid
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -45,6 +46,55 @@ template <int KS, int ST, int PF>
 struct HaloCap {
     static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 192) : 576);
 };
+
+// bias (+affine) + activation (+residual) -> fp16 NHWC.  C/D layout: col = pixel (lane&31),
+// row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive couts of one pixel per 4 registers.
+template <int CF, int PF>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF], const int (&opix)[PF],
+                                              int cb, int upc0, int lane) {
+    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        if (opix[pf] < 0) continue;
+        __half* orow = a.out + (size_t)opix[pf] * a.out_cs + a.out_co;
+        const __half* rrow = a.res ? a.res + (size_t)opix[pf] * a.res_cs + a.res_co : nullptr;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int cg = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);  // row of the weight matrix
+                if (cg >= a.Cout) continue;
+                const int c0 = cg - upc0;                                       // output channel
+                const int cend = a.up == 2 ? a.upC : a.Cout;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = c0 + j;
+                    float x = acc[cf][pf][r4 * 4 + j];
+                    if (c < cend) {
+                        if (a.bias) x += a.bias[c];
+                        if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
+                        x = y6_act(x, a.act);
+                        if (rrow) x += ralpha * __half2float(rrow[c]);
+                    }
+                    v[j] = x;
+                }
+                if (a.vec_ok && (c0 + 3) < cend) {
+                    h4_t o;
+                    o[0] = (_Float16)v[0];
+                    o[1] = (_Float16)v[1];
+                    o[2] = (_Float16)v[2];
+                    o[3] = (_Float16)v[3];
+                    *reinterpret_cast<h4_t*>(orow + c0) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c0 + j < cend) orow[c0 + j] = __float2half(v[j]);
+                }
+            }
+        }
+    }
+}
 
 template <int CF, int PF, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
@@ -233,58 +283,228 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         }
     }
 
-    // ---- epilogue: bias (+affine) + activation (+residual) -> fp16 NHWC
-    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+    conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent variant (3x3 only): a block walks a strided list of (tile, cout-block) items.
+//   * the NEXT item's first halo chunk is prefetched into registers during the current item's last
+//     chunk, so the HBM/L2 latency of a tile's prologue hides behind the previous tile's MFMAs;
+//   * one raw barrier per ROW of taps (3 taps = 6 k-steps): 3x fewer barriers than conv_mfma_kernel,
+//     and the weight DMA for the next row (2-slot ring) has a whole row of MFMAs to land.
+// This is what lets the LDS-efficient larger tiles (fewer ds_read per MFMA) run at low occupancy.
+template <int CF, int PF, int ST>
+__global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 3, NT = 9, TPS = 3;
+    constexpr int NPIECE = TPS * CF * 2;         // 1 KiB DMA pieces per step image [tap][cf][ks]
+    constexpr int WIMG = NPIECE * 1024;
+    constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
+    constexpr int NP = (MAXHP * 4 + 255) / 256;
+    constexpr int NWJ = (NPIECE + 3) / 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* ldsA = smem;
+    char* ldsW = smem + a.ldsA_bytes;
+    const int nids = a.nids;
+    const int gstride = gridDim.x;
+
+    auto decode = [&](int id, int& tile, int& cb) {
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    };
+    auto next_valid = [&](int id) {
+        for (id += gstride; id < nids; id += gstride) {
+            int t, c;
+            decode(id, t, c);
+            if (t < a.ntiles) break;
+        }
+        return id;
+    };
+
+    int id = blockIdx.x;
+    {
+        int t, c;
+        decode(id, t, c);
+        if (t >= a.ntiles) id = next_valid(id);
+    }
+    if (id >= nids) return;
+
+    const int npieces = a.HH * a.HWd * 4;
+    int goff[NP];
+    auto setup_goff = [&](int item) {
+        int tile, cbx;
+        decode(item, tile, cbx);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int iy0 = ty_i * a.TH * ST - 1, ix0 = tx_i * a.TW * ST - 1;
 #pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        if (opix[pf] < 0) continue;
-        __half* orow = a.out + (size_t)opix[pf] * a.out_cs + a.out_co;
-        const __half* rrow = a.res ? a.res + (size_t)opix[pf] * a.res_cs + a.res_co : nullptr;
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            int g = -2;
+            if (idx < npieces) {
+                const int hp = idx >> 2, q = idx & 3;
+                const int hy = hp / a.HWd, hx = hp - hy * a.HWd;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const bool v = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+                g = v ? (((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + q * 8) : -1;
+            }
+            goff[i] = g;
+        }
+    };
+    int pixoff[PF], opix[PF], cb = 0;
+    auto setup_pix = [&](int item) {
+        int tile;
+        decode(item, tile, cb);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
 #pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
+        for (int pf = 0; pf < PF; ++pf) {
+            const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+            const int npx = a.TH * a.TW;
+            bool v = m < npx;
+            const int mm = v ? m : npx - 1;
+            const int ty = mm / a.TW, tx = mm - ty * a.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            v = v && (oy < a.Ho) && (ox < a.Wo);
+            pixoff[pf] = ((ty * ST) * a.HWd + tx * ST) * PIXB + (lane >> 5) * 16;
+            opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
+        }
+    };
+    auto load_A = [&](int chunk, uint4 (&regs)[NP]) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int cg = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);  // row of the weight matrix
-                if (cg >= a.Cout) continue;
-                const int c0 = cg - upc0;                                       // output channel
-                const int cend = a.up == 2 ? a.upC : a.Cout;
-                float v[4];
+        for (int i = 0; i < NP; ++i) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            const int q = (tid + i * 256) & 3;
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
+                v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
+            regs[i] = v;
+        }
+    };
+    auto store_A = [&](const uint4 (&regs)[NP]) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = c0 + j;
-                    float x = acc[cf][pf][r4 * 4 + j];
-                    if (c < cend) {
-                        if (a.bias) x += a.bias[c];
-                        if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
-                        x = y6_act(x, a.act);
-                        if (rrow) x += ralpha * __half2float(rrow[c]);
-                    }
-                    v[j] = x;
-                }
-                if (a.vec_ok && (c0 + 3) < cend) {
-                    h4_t o;
-                    o[0] = (_Float16)v[0];
-                    o[1] = (_Float16)v[1];
-                    o[2] = (_Float16)v[2];
-                    o[3] = (_Float16)v[3];
-                    *reinterpret_cast<h4_t*>(orow + c0) = o;
-                } else {
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < npieces) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = regs[i];
+        }
+    };
+
+    // weight stream state: the NEXT (item, chunk, tap-row) whose image has not been issued yet
+    int w_id = id, w_chunk = 0, w_row = 0, w_slot = 0;
+    auto issue_w = [&]() {
+        if (w_id >= nids) return;
+        int wt, wcb;
+        decode(w_id, wt, wcb);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c0 + j < cend) orow[c0 + j] = __float2half(v[j]);
-                }
+        for (int j = 0; j < NWJ; ++j) {
+            const int p = wave + 4 * j;
+            if (p < NPIECE) {
+                const int t = p / (CF * 2), q = p - t * (CF * 2);
+                const int cf = q >> 1, ks = q & 1;
+                const size_t cfg = (size_t)wcb * CF + cf;
+                const int tap = w_row * TPS + t;
+                const __half* src = a.wpk + (((cfg * a.nchunk + w_chunk) * NT + tap) * 2 + ks) * 512 + lane * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsW + w_slot * WIMG + p * 1024),
+                                                 16, 0, 0);
             }
         }
+        w_slot ^= 1;
+        if (++w_row == KS) {
+            w_row = 0;
+            if (++w_chunk == a.nchunk) {
+                w_chunk = 0;
+                w_id = next_valid(w_id);
+            }
+        }
+    };
+
+    setup_goff(id);
+    setup_pix(id);
+    uint4 areg[NP];
+    load_A(0, areg);
+    issue_w();  // row 0 of the first item -> slot 0
+    store_A(areg);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int slot = 0;
+    while (true) {
+        f32x16_t acc[CF][PF];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+        const int nid = next_valid(id);
+        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+            const bool last = (chunk + 1) == a.nchunk;
+            const bool have_next = !last || nid < nids;
+            if (have_next) {
+                if (last) setup_goff(nid);           // the current item's table is dead from here
+                load_A(last ? 0 : chunk + 1, areg);  // register prefetch: next chunk, or next ITEM's first
+            }
+#pragma unroll
+            for (int row = 0; row < KS; ++row) {
+                issue_w();  // next row's image into the other slot (read two barriers ago)
+                const char* wb = ldsW + slot * WIMG + lane * 16;
+#pragma unroll
+                for (int t = 0; t < TPS; ++t) {
+                    const int tapoff = (row * a.HWd + t) * PIXB;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        h8_t af[CF], bf[PF];
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf)
+                            af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf)
+                            bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                            for (int pf = 0; pf < PF; ++pf)
+                                acc[cf][pf] =
+                                    __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                slot ^= 1;
+            }
+            if (have_next) {
+                store_A(areg);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+        }
+        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane);
+        if (nid >= nids) break;
+        id = nid;
+        setup_pix(id);
     }
 }
 
 struct VariantCfg {
-    int cf, pf;
+    int cf, pf, persist;
     const char* name;
 };
-// index 0 is the naive kernel (conv_misc.hip)
-const VariantCfg kVariants[] = {{0, 0, "naive"},     {1, 1, "mfma_c1p1"}, {2, 1, "mfma_c2p1"}, {4, 1, "mfma_c4p1"},
-                                {1, 2, "mfma_c1p2"}, {2, 2, "mfma_c2p2"}, {4, 2, "mfma_c4p2"}};
+// index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block); 7-12 persistent
+const VariantCfg kVariants[] = {
+    {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"}, {1, 2, 0, "mfma_c1p2"},
+    {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"}, {2, 1, 1, "pers_c2p1"}, {4, 1, 1, "pers_c4p1"},
+    {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}, {4, 2, 1, "pers_c4p2"}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -384,8 +604,12 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.nchunk = y6_cdiv(k.Cin, 32);
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
     k.ldsA_bytes = k.HH * k.HWd * PIXB;
-    L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;
-    L->grid = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
+    k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
+    L->grid = k.nids;
+    if (vc.persist)
+        L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)3 * vc.cf * 2 * 1024;  // 2-slot ring of tap-row images
+    else
+        L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
     return Y6_OK;
 }
 
@@ -403,6 +627,46 @@ int launch_one(const Launch& L, hipStream_t s) {
     hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, KS, ST>), dim3(L.grid), dim3(256), L.lds, s, L.k);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
+}
+
+template <int CF, int PF, int ST>
+int launch_persist(const Launch& L, hipStream_t s) {
+    auto kern = conv_mfma_persist_kernel<CF, PF, ST>;
+    static bool big_lds_enabled = false;
+    if (L.lds > 64 * 1024 && !big_lds_enabled) {
+        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        big_lds_enabled = true;
+    }
+    Y6_REQUIRE(L.lds <= 128 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
+    // resident blocks per CU for this LDS footprint (cached per footprint)
+    static size_t cached_lds = 0;
+    static int cached_bpc = 0, n_cu = 0;
+    if (cached_lds != L.lds) {
+        int bpc = 0;
+        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 256, L.lds));
+        if (n_cu == 0) {
+            int dev = 0;
+            Y6_HIP(hipGetDevice(&dev));
+            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        cached_bpc = bpc < 1 ? 1 : bpc;
+        cached_lds = L.lds;
+    }
+    int grid = n_cu * cached_bpc;
+    grid -= grid % 8;                 // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple
+    if (grid < 8) grid = 8;
+    if (grid > L.grid) grid = L.grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+template <int CF, int PF>
+int launch_persist_cfg(const Launch& L, int st, hipStream_t s) {
+    if (st == 1) return launch_persist<CF, PF, 1>(L, s);
+    if constexpr (PF == 1) return launch_persist<CF, 1, 2>(L, s);
+    y6_set_error("conv_mfma: stride-2 needs a pf=1 variant");
+    return Y6_EUNSUPPORTED;
 }
 
 template <int CF, int PF>
@@ -434,6 +698,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     const int ks = d->ksize, st = d->stride;
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
     if (st == 2 && vc.pf != 1) return 0;
+    if (vc.persist && ks != 3) return 0;
     if (d->w_packed == nullptr) return 0;
     // 16-byte halo pieces need 8-channel alignment of the input view
     if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -452,6 +717,10 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
                      d->stride, d->in.C, d->out.C);
         return Y6_EUNSUPPORTED;
     }
+    if (kVariants[variant].persist && up) {
+        y6_set_error("conv_mfma: persistent variants do not implement the convT scatter");
+        return Y6_EUNSUPPORTED;
+    }
     Launch L;
     int rc = build_launch(d, variant, up, updy, updx, &L);
     if (rc) return rc;
@@ -462,6 +731,12 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 4: return launch_cfg<1, 2>(L, d->ksize, d->stride, s);
         case 5: return launch_cfg<2, 2>(L, d->ksize, d->stride, s);
         case 6: return launch_cfg<4, 2>(L, d->ksize, d->stride, s);
+        case 7: return launch_persist_cfg<1, 1>(L, d->stride, s);
+        case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
+        case 9: return launch_persist_cfg<4, 1>(L, d->stride, s);
+        case 10: return launch_persist_cfg<1, 2>(L, d->stride, s);
+        case 11: return launch_persist_cfg<2, 2>(L, d->stride, s);
+        case 12: return launch_persist_cfg<4, 2>(L, d->stride, s);
     }
     return Y6_EINVAL;
 }

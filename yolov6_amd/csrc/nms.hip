@@ -11,10 +11,10 @@
 //   (conf bits << 32 | ~flat) with flat = anchor*nc + cls, so a descending key sort IS the
 //   reference's "score descending, earlier row first" order.
 // Stage 2 (nms_sort_sweep_kernel): one 1024-thread block per image: bitonic sort of the keys
-//   (LDS when they fit, workspace otherwise), cap to max_nms (:90-91), build the xyxy boxes
-//   (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95), then the greedy sweep: the next
-//   surviving box is found by a wave ballot over the removed-bitmask, every later box is
-//   tested against it in parallel, until max_det (:97-98) boxes are kept.
+//   (LDS when they fit, workspace otherwise), cap to max_nms (:90-91), then a windowed greedy
+//   sweep over the sorted list: xyxy boxes (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95)
+//   are built 2048 at a time in LDS, tested against the boxes already kept, and swept with a wave
+//   ballot over the alive-bitmask, until max_det (:97-98) boxes are kept.
 // Compile with -ffp-contract=off: index parity needs the reference's unfused fp32 arithmetic.
 #include "common.hpp"
 
@@ -121,20 +121,22 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
     for (int i = tid; i < total; i += 256) kb[i] = stage[i];
 }
 
-// descending bitonic sort of P (power of two) keys by the whole block
-__device__ void bitonic_desc(u64* keys, int P) {
+// descending bitonic sort of P (power of two) keys by the whole block; one compare-exchange pair per
+// thread-iteration (no idle half).  Force-inlined so that a pointer derived from the LDS array keeps
+// its address space (ds_read/ds_write instead of flat accesses).
+__device__ __forceinline__ void bitonic_desc(u64* keys, int P) {
     const int T = blockDim.x;
+    const int half = P >> 1;
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < P; i += T) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const u64 x = keys[i], y = keys[ixj];
-                    const bool desc = (i & k) == 0;
-                    if (desc ? (x < y) : (x > y)) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
+            for (int t = threadIdx.x; t < half; t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const u64 x = keys[i], y = keys[l];
+                const bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) {
+                    keys[i] = y;
+                    keys[l] = x;
                 }
             }
             __syncthreads();
@@ -142,21 +144,39 @@ __device__ void bitonic_desc(u64* keys, int P) {
     }
 }
 
-constexpr int kLdsKeys = 16384;                 // 128 KiB of 64-bit keys during the sort
-constexpr int kLdsBoxes = 7936;                 // afterwards: 124 KiB of sorted boxes ...
-constexpr int kLdsRemovedWords = 512;           // ... + 4 KiB removed-bitmask (max_nms 30000 -> 469 words)
-constexpr size_t kSweepLds = (size_t)kLdsBoxes * 16 + (size_t)kLdsRemovedWords * 8;
+constexpr int kLdsKeys = 16384;   // 128 KiB of 64-bit keys during the sort
+constexpr int kWin = 2048;        // sweep window: sorted candidates resident in LDS at a time
+constexpr int kKeptCap = 2048;    // kept boxes resident in LDS (max_det limit)
+constexpr size_t kSweepLds = (size_t)(kWin + kKeptCap) * 16 + (kWin / 64) * 8;
 
+__device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
+    // torchvision devIoU / cpu kernel arithmetic, fp32, unfused
+    const float left = fmaxf(bi.x, bj.x), right = fminf(bi.z, bj.z);
+    const float top = fmaxf(bi.y, bj.y), bottom = fminf(bi.w, bj.w);
+    const float iw = fmaxf(right - left, 0.f), ih = fmaxf(bottom - top, 0.f);
+    const float inter = iw * ih;
+    const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+    const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+    return inter / (area_i + area_j - inter);
+}
+
+// One 1024-thread block per image.
+//  1. bitonic sort of the candidate keys (LDS when <= 16384, else in the global workspace);
+//  2. windowed greedy sweep: 2048 sorted candidates at a time become class-offset boxes in LDS, are
+//     first tested against the boxes kept so far, then swept greedily: a wave ballot over the alive
+//     bitmask finds the next survivor, every later box of the window is tested against it in parallel.
+//     Boxes are only ever built for the windows the sweep reaches before max_det boxes are kept.
 __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __restrict__ pred, int A, int nc,
                                                               float iou_thres, int agnostic, int max_det, int max_nms,
                                                               float max_wh, u64* __restrict__ keys, size_t cap,
-                                                              const int* __restrict__ counts, float4* __restrict__ boxes,
+                                                              const int* __restrict__ counts,
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
                                                               int* __restrict__ out_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
     int n = counts[b];
     if (n <= 0) {
         if (tid == 0) out_count[b] = 0;
@@ -165,91 +185,95 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
     u64* gk = keys + (size_t)b * cap;
     int P = 1;
     while (P < n) P <<= 1;
-    u64* sk;
     if (P <= kLdsKeys) {
-        sk = reinterpret_cast<u64*>(smem);
-        for (int i = tid; i < P; i += T) sk[i] = i < n ? gk[i] : 0ull;
+        u64* lk = reinterpret_cast<u64*>(smem);
+        for (int i = tid; i < P; i += T) lk[i] = i < n ? gk[i] : 0ull;
+        __syncthreads();
+        bitonic_desc(lk, P);
+        for (int i = tid; i < n; i += T) gk[i] = lk[i];   // sorted keys back to global: the LDS is re-used below
     } else {
-        sk = gk;  // cap is a power of two >= P
-        for (int i = n + tid; i < P; i += T) sk[i] = 0ull;
+        for (int i = n + tid; i < P; i += T) gk[i] = 0ull;  // cap is a power of two >= P
+        __syncthreads();
+        bitonic_desc(gk, P);
     }
-    __syncthreads();
-    bitonic_desc(sk, P);
     if (n > max_nms) n = max_nms;
-
-    // sorted class-offset xyxy boxes -> global workspace; sorted keys back to global
-    float4* bx = boxes + (size_t)b * max_nms;
-    const int no = nc + 5;
-    for (int i = tid; i < n; i += T) {
-        const u64 key = sk[i];
-        const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
-        const float* row = pred + ((size_t)b * A + an) * no;
-        const float x = row[0], y = row[1], w = row[2], h = row[3];
-        const float off = agnostic ? 0.f : (float)cls * max_wh;
-        float4 q;
-        q.x = (x - w / 2.f) + off;
-        q.y = (y - h / 2.f) + off;
-        q.z = (x + w / 2.f) + off;
-        q.w = (y + h / 2.f) + off;
-        bx[i] = q;
-        if (sk != gk) gk[i] = key;
-    }
-    __syncthreads();  // keys in LDS are dead from here: the LDS is re-used for boxes + bitmask
-
-    float4* lbox = reinterpret_cast<float4*>(smem);
-    u64* removed = reinterpret_cast<u64*>(smem + (size_t)kLdsBoxes * 16);
-    const int nl = n < kLdsBoxes ? n : kLdsBoxes;
-    for (int i = tid; i < nl; i += T) lbox[i] = bx[i];
-    const int nwords = (n + 63) >> 6;
-    for (int i = tid; i < nwords; i += T) removed[i] = 0ull;
     __syncthreads();
 
-    const int lane = tid & 63;
+    float4* wbox = reinterpret_cast<float4*>(smem);
+    float4* kbox = wbox + kWin;
+    u64* walive = reinterpret_cast<u64*>(kbox + kKeptCap);
+    int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids at the end
+    const int no = nc + 5;
     int kept = 0;
-    int cur = 0;
-    int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids below
-    while (kept < max_det) {
-        // every wave finds the first surviving index >= cur (identical result in all waves: bits set
-        // concurrently by faster waves belong to later boxes and cannot change "first")
-        int found = -1;
-        for (int w0 = cur >> 6; w0 < nwords && found < 0; w0 += 64) {
-            const int wi = w0 + lane;
-            u64 alive = 0ull;
-            if (wi < nwords) {
-                alive = ~removed[wi];
-                if (wi == (cur >> 6)) alive &= ~((1ull << (cur & 63)) - 1ull);
-                const int base = wi << 6;
-                if (base + 64 > n) alive &= ((1ull << (n - base)) - 1ull);
-            }
-            const u64 bal = __ballot(alive != 0ull);
-            if (bal) {
-                const int src = __ffsll((long long)bal) - 1;
-                const u64 wv = __shfl(alive, src, 64);
-                found = ((w0 + src) << 6) + (__ffsll((long long)wv) - 1);
-            }
-        }
-        if (found < 0) break;
-        const int i = found;
-        if (tid == 0) kept_pos[kept] = i;
-        ++kept;
-        if (kept >= max_det) break;
-        const float4 bi = i < nl ? lbox[i] : bx[i];
-        const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
-        for (int j = i + 1 + tid; j < n; j += T) {
-            if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
-            const float4 bj = j < nl ? lbox[j] : bx[j];
-            const float left = fmaxf(bi.x, bj.x), right = fminf(bi.z, bj.z);
-            const float top = fmaxf(bi.y, bj.y), bottom = fminf(bi.w, bj.w);
-            const float iw = fmaxf(right - left, 0.f), ih = fmaxf(bottom - top, 0.f);
-            const float inter = iw * ih;
-            const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
-            const float iou = inter / (area_i + area_j - inter);
-            if (iou > iou_thres) atomicOr(&removed[j >> 6], 1ull << (j & 63));
+    for (int pos = 0; pos < n && kept < max_det; pos += kWin) {
+        const int wn = (n - pos) < kWin ? (n - pos) : kWin;
+        // window boxes: xywh2xyxy (nms.py:72) + class offset (nms.py:94-95)
+        for (int t = tid; t < wn; t += T) {
+            const u64 key = gk[pos + t];
+            const unsigned flat = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+            const unsigned an = flat / (unsigned)nc, cls = flat - an * (unsigned)nc;
+            const float* row = pred + ((size_t)b * A + an) * no;
+            const float x = row[0], y = row[1], w = row[2], h = row[3];
+            const float off = agnostic ? 0.f : (float)cls * max_wh;
+            float4 q;
+            q.x = (x - w / 2.f) + off;
+            q.y = (y - h / 2.f) + off;
+            q.z = (x + w / 2.f) + off;
+            q.w = (y + h / 2.f) + off;
+            wbox[t] = q;
         }
         __syncthreads();
-        cur = i + 1;
-        if (cur >= n) break;
+        // survivors of the boxes kept in earlier windows
+#pragma unroll
+        for (int r = 0; r < kWin / 1024; ++r) {
+            const int t = tid + r * 1024;
+            bool alive = t < wn;
+            if (alive) {
+                const float4 bj = wbox[t];
+                for (int k = 0; k < kept; ++k)
+                    if (nms_iou(kbox[k], bj) > iou_thres) {
+                        alive = false;
+                        break;
+                    }
+            }
+            const u64 bal = __ballot(alive);
+            if (lane == 0) walive[r * 16 + wave] = bal;   // bit (t & 63) of word (t >> 6)
+        }
+        __syncthreads();
+        // greedy sweep inside the window
+        int cur = 0;
+        while (true) {
+            // every wave finds the first alive index >= cur (same answer in every wave)
+            u64 w = 0ull;
+            if (lane < kWin / 64) {
+                w = walive[lane];
+                if (lane < (cur >> 6)) w = 0ull;
+                if (lane == (cur >> 6)) w &= ~((1ull << (cur & 63)) - 1ull);
+            }
+            const u64 bal = __ballot(w != 0ull);
+            if (bal == 0ull) break;
+            const int src = __ffsll((long long)bal) - 1;
+            const u64 wv = __shfl(w, src, 64);
+            const int i = (src << 6) + (__ffsll((long long)wv) - 1);
+            const float4 bi = wbox[i];
+            if (tid == 0) {
+                kbox[kept] = bi;
+                kept_pos[kept] = pos + i;
+            }
+            ++kept;
+            if (kept >= max_det) break;
+#pragma unroll
+            for (int r = 0; r < kWin / 1024; ++r) {
+                const int t = tid + r * 1024;
+                if (t > i && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
+                    if (nms_iou(bi, wbox[t]) > iou_thres) atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                }
+            }
+            __syncthreads();
+            cur = i + 1;
+            if (cur >= wn) break;
+        }
+        __syncthreads();
     }
     __syncthreads();
     // detections: (xyxy without the class offset, conf, cls)  nms.py:98 `x[keep_box_idx]`
@@ -308,6 +332,7 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
                (double)d->iou_thres);
     Y6_REQUIRE(d->B > 0 && d->A > 0 && d->nc > 0 && d->max_det > 0, "nms: bad sizes");
     Y6_REQUIRE(d->max_nms > 0 && d->max_nms <= 30000, "nms: max_nms must be in (0, 30000]");
+    Y6_REQUIRE(d->max_det <= kKeptCap, "nms: max_det %d exceeds the %d kept boxes held in LDS", d->max_det, kKeptCap);
     Y6_REQUIRE((size_t)d->A * d->nc < 0xFFFFFFFFull, "nms: A*nc overflows the 32-bit candidate id");
     const int ml = d->multi_label && d->nc > 1;
     const NmsWs w = nms_ws_layout(d->B, d->A, d->nc, ml, 30000);
@@ -315,7 +340,6 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     char* ws = (char*)d->workspace;
     u64* keys = (u64*)(ws + w.off_keys);
-    float4* boxes = (float4*)(ws + w.off_boxes);
     int* counts = (int*)(ws + w.off_counts);
     Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * sizeof(int), s));
     // rows per block: as many as fit a 48 KiB staging area (64 rows x 80 classes = 40 KiB)
@@ -341,8 +365,8 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL(nms_sort_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres,
-                       d->agnostic, d->max_det, d->max_nms, d->max_wh, keys, w.cap, counts, boxes, d->out_dets,
-                       d->out_index, d->out_count);
+                       d->agnostic, d->max_det, d->max_nms, d->max_wh, keys, w.cap, counts, d->out_dets, d->out_index,
+                       d->out_count);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
