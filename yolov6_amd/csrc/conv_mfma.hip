@@ -42,9 +42,26 @@ struct ConvKArgs {
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
+// LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it
+// cannot (a) insert a conservative `s_waitcnt vmcnt(0)` before every later ds_read because the DMA
+// "might alias", nor (b) count it - completion is awaited by the kernel's own vmcnt(0) at the chunk
+// boundary.  M0 (the LDS destination base) is saved/restored inside the statement
+// (cdna_hip_programming.md §5.7).  `lds_dst` must be wave-uniform.
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc_lane), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 template <int KS, int ST, int PF>
 struct HaloCap {
-    static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 192) : 576);
+    static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 208) : 576);
 };
 
 // bias (+affine) + activation (+residual) -> fp16 NHWC.  C/D layout: col = pixel (lane&31),
@@ -287,17 +304,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent variant (3x3 only): a block walks a strided list of (tile, cout-block) items.
-//   * the NEXT item's first halo chunk is prefetched into registers during the current item's last
-//     chunk, so the HBM/L2 latency of a tile's prologue hides behind the previous tile's MFMAs;
-//   * one raw barrier per ROW of taps (3 taps = 6 k-steps): 3x fewer barriers than conv_mfma_kernel,
-//     and the weight DMA for the next row (2-slot ring) has a whole row of MFMAs to land.
-// This is what lets the LDS-efficient larger tiles (fewer ds_read per MFMA) run at low occupancy.
+// Persistent, chunk-granular variant (3x3 only).  Lessons from the r03 counters (profiles/):
+// per-tap barriers + in-order vmcnt waits parked the waves 50 % of the time and forced the halo
+// register prefetch to complete at the first tap.  Here
+//   * a block walks a strided list of (tile, cout-block) items;
+//   * the unit of staging is a 32-channel CHUNK: its halo (LDS, via registers) and ALL NINE tap
+//     weight images (LDS-DMA, double-buffered per chunk) are requested one whole chunk ahead -
+//     across item boundaries too - so loads get 9 taps x 2 k-steps of MFMA time to land;
+//   * inside a chunk there is NO barrier: 18 k-steps of ds_read + MFMA the compiler can pipeline;
+//   * one `vmcnt(0) + barrier` per chunk (everyone done reading, everything for the next chunk
+//     landed), then the halo registers go to LDS and a second barrier publishes them.
 template <int CF, int PF, int ST>
 __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = 3, NT = 9, TPS = 3;
-    constexpr int NPIECE = TPS * CF * 2;         // 1 KiB DMA pieces per step image [tap][cf][ks]
+    constexpr int KS = 3, NT = 9;
+    constexpr int NPIECE = NT * CF * 2;          // 1 KiB DMA pieces per chunk image [tap][cf][ks]
     constexpr int WIMG = NPIECE * 1024;
     constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
     constexpr int NP = (MAXHP * 4 + 255) / 256;
@@ -308,6 +329,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* ldsA = smem;
     char* ldsW = smem + a.ldsA_bytes;
+    const unsigned ldsW_addr = lds_addr(ldsW);
     const int nids = a.nids;
     const int gstride = gridDim.x;
 
@@ -401,33 +423,20 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             if (idx < npieces) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = regs[i];
         }
     };
-
-    // weight stream state: the NEXT (item, chunk, tap-row) whose image has not been issued yet
-    int w_id = id, w_chunk = 0, w_row = 0, w_slot = 0;
-    auto issue_w = [&]() {
-        if (w_id >= nids) return;
+    // all nine tap images of (item, chunk) -> ring slot; pieces are contiguous in the packed weights:
+    // [cfrag][chunk][tap][ks][512 halves], i.e. one cfrag's chunk is 9*2 consecutive KiB
+    auto issue_w = [&](int item, int chunk, int wslot) {
         int wt, wcb;
-        decode(w_id, wt, wcb);
+        decode(item, wt, wcb);
 #pragma unroll
         for (int j = 0; j < NWJ; ++j) {
-            const int p = wave + 4 * j;
+            const int p = wave + 4 * j;              // p = (tap*CF + cf)*2 + ks
             if (p < NPIECE) {
                 const int t = p / (CF * 2), q = p - t * (CF * 2);
                 const int cf = q >> 1, ks = q & 1;
                 const size_t cfg = (size_t)wcb * CF + cf;
-                const int tap = w_row * TPS + t;
-                const __half* src = a.wpk + (((cfg * a.nchunk + w_chunk) * NT + tap) * 2 + ks) * 512 + lane * 8;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(ldsW + w_slot * WIMG + p * 1024),
-                                                 16, 0, 0);
-            }
-        }
-        w_slot ^= 1;
-        if (++w_row == KS) {
-            w_row = 0;
-            if (++w_chunk == a.nchunk) {
-                w_chunk = 0;
-                w_id = next_valid(w_id);
+                const __half* src = a.wpk + (((cfg * a.nchunk + chunk) * NT + t) * 2 + ks) * 512 + lane * 8;
+                lds_dma16(src, __builtin_amdgcn_readfirstlane(ldsW_addr + wslot * WIMG + p * 1024));
             }
         }
     };
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     setup_pix(id);
     uint4 areg[NP];
     load_A(0, areg);
-    issue_w();  // row 0 of the first item -> slot 0
+    issue_w(id, 0, 0);
     store_A(areg);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
@@ -453,40 +462,39 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
             const bool last = (chunk + 1) == a.nchunk;
             const bool have_next = !last || nid < nids;
-            if (have_next) {
+            if (have_next) {  // request everything the NEXT chunk needs, a whole chunk of MFMAs ahead
+                // halo loads FIRST: hipcc guards the re-use of `areg` with a vmcnt(0) that must not
+                // find the (compiler-invisible) weight DMAs already in flight
                 if (last) setup_goff(nid);           // the current item's table is dead from here
-                load_A(last ? 0 : chunk + 1, areg);  // register prefetch: next chunk, or next ITEM's first
+                load_A(last ? 0 : chunk + 1, areg);
+                issue_w(last ? nid : id, last ? 0 : chunk + 1, slot ^ 1);
             }
+            const char* wb = ldsW + slot * WIMG + lane * 16;
 #pragma unroll
-            for (int row = 0; row < KS; ++row) {
-                issue_w();  // next row's image into the other slot (read two barriers ago)
-                const char* wb = ldsW + slot * WIMG + lane * 16;
+            for (int t = 0; t < NT; ++t) {
+                const int tapoff = ((t / KS) * a.HWd + (t % KS)) * PIXB;
 #pragma unroll
-                for (int t = 0; t < TPS; ++t) {
-                    const int tapoff = (row * a.HWd + t) * PIXB;
+                for (int ks = 0; ks < 2; ++ks) {
+                    h8_t af[CF], bf[PF];
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        h8_t af[CF], bf[PF];
+                    for (int cf = 0; cf < CF; ++cf)
+                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
 #pragma unroll
-                        for (int cf = 0; cf < CF; ++cf)
-                            af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
+                    for (int pf = 0; pf < PF; ++pf)
+                        bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                         for (int pf = 0; pf < PF; ++pf)
-                            bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-                            for (int pf = 0; pf < PF; ++pf)
-                                acc[cf][pf] =
-                                    __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
-                    }
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
                 }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                slot ^= 1;
             }
             if (have_next) {
+                // everyone is done reading this chunk's halo; the next chunk's loads have landed
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 store_A(areg);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                slot ^= 1;
             }
         }
         conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane);
@@ -500,16 +508,17 @@ struct VariantCfg {
     int cf, pf, persist;
     const char* name;
 };
-// index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block); 7-12 persistent
+// index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
+// 7-10 persistent chunk-granular (a 4-fragment cout block would need 144 KiB of weight images)
 const VariantCfg kVariants[] = {
-    {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"}, {1, 2, 0, "mfma_c1p2"},
-    {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"}, {2, 1, 1, "pers_c2p1"}, {4, 1, 1, "pers_c4p1"},
-    {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}, {4, 2, 1, "pers_c4p2"}};
+    {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
+    {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
+    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
     if (ks == 1) return pf * 128;
-    if (st == 1) return pf == 2 ? 352 : 192;
+    if (st == 1) return pf == 2 ? 352 : 208;
     return 576;
 }
 
@@ -531,7 +540,10 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         // useful MFMA work / issued MFMA work, lightly penalised by halo staging volume
         const double eff = ((double)Ho * Wo) / (tiles * bp);
         const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
-        const double score = eff * (0.85 + 0.15 * halo);
+        // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
+        // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is ~2-way
+        const double rowfit = (TW % 32 == 0) ? 1.0 : 0.94;
+        const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
             bTH = TH;
@@ -607,7 +619,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     L->grid = k.nids;
     if (vc.persist)
-        L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)3 * vc.cf * 2 * 1024;  // 2-slot ring of tap-row images
+        L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
     return Y6_OK;
@@ -733,10 +745,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 6: return launch_cfg<4, 2>(L, d->ksize, d->stride, s);
         case 7: return launch_persist_cfg<1, 1>(L, d->stride, s);
         case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
-        case 9: return launch_persist_cfg<4, 1>(L, d->stride, s);
-        case 10: return launch_persist_cfg<1, 2>(L, d->stride, s);
-        case 11: return launch_persist_cfg<2, 2>(L, d->stride, s);
-        case 12: return launch_persist_cfg<4, 2>(L, d->stride, s);
+        case 9: return launch_persist_cfg<1, 2>(L, d->stride, s);
+        case 10: return launch_persist_cfg<2, 2>(L, d->stride, s);
     }
     return Y6_EINVAL;
 }
