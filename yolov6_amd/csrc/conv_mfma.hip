@@ -14,6 +14,8 @@
 //   C/D        : col = pixel = lane&31, row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // so every lane ends up with 4 consecutive couts of ONE pixel per 4 accumulator registers
 // -> 8-byte NHWC stores in the epilogue.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -39,6 +41,7 @@ struct ConvKArgs {
     int act;
     int vec_ok;
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
+    int ablate;  // debug (env Y6_CONV_ABLATE): 1 no weight DMA, 2 no halo loads, 4 no MFMA, 8 no LDS reads, 16 no epilogue
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             const int idx = tid + i * 256;
             const int q = idx & 3;
-            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin && !(a.ablate & 2))
                 v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
             regs[i] = v;
         }
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
         for (int i = 0; i < NP; ++i) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             const int q = (tid + i * 256) & 3;
-            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin && !(a.ablate & 2))
                 v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
             regs[i] = v;
         }
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     // all nine tap images of (item, chunk) -> ring slot; pieces are contiguous in the packed weights:
     // [cfrag][chunk][tap][ks][512 halves], i.e. one cfrag's chunk is 9*2 consecutive KiB
     auto issue_w = [&](int item, int chunk, int wslot) {
+        if (a.ablate & 1) return;
         int wt, wcb;
         decode(item, wt, wcb);
 #pragma unroll
@@ -476,17 +480,32 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     h8_t af[CF], bf[PF];
+                    if (!(a.ablate & 8)) {
 #pragma unroll
-                    for (int cf = 0; cf < CF; ++cf)
-                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
-#pragma unroll
-                    for (int pf = 0; pf < PF; ++pf)
-                        bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf)
+                        for (int cf = 0; cf < CF; ++cf)
+                            af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
 #pragma unroll
                         for (int pf = 0; pf < PF; ++pf)
-                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
+                            bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+                    } else {
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf) af[cf] = (h8_t)(_Float16)1.f;
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) bf[pf] = (h8_t)(_Float16)1.f;
+                    }
+                    if (!(a.ablate & 4)) {
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                            for (int pf = 0; pf < PF; ++pf)
+                                acc[cf][pf] =
+                                    __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf) asm volatile("" ::"v"(af[cf]));
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf) asm volatile("" ::"v"(bf[pf]));
+                    }
                 }
             }
             if (have_next) {
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                 slot ^= 1;
             }
         }
-        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane);
+        if (!(a.ablate & 16)) conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane);
         if (nid >= nids) break;
         id = nid;
         setup_pix(id);
@@ -542,7 +561,8 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
         // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
         // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is ~2-way
-        const double rowfit = (TW % 32 == 0) ? 1.0 : 0.94;
+        static const bool prefer_rows = getenv("Y6_CONV_ROWFIT") != nullptr;   // measured slower on r04: off by default
+        const double rowfit = (!prefer_rows || TW % 32 == 0) ? 1.0 : 0.94;
         const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
@@ -617,6 +637,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
     k.ldsA_bytes = k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
+    static const int ablate_env = getenv("Y6_CONV_ABLATE") ? atoi(getenv("Y6_CONV_ABLATE")) : 0;
+    k.ablate = ablate_env;
     L->grid = k.nids;
     if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
