@@ -14,8 +14,6 @@
 //   C/D        : col = pixel = lane&31, row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // so every lane ends up with 4 consecutive couts of ONE pixel per 4 accumulator registers
 // -> 8-byte NHWC stores in the epilogue.
-#include <cstdlib>
-
 #include "common.hpp"
 
 namespace {
@@ -39,9 +37,9 @@ struct ConvKArgs {
     int nchunk, ncb;
     int ldsA_bytes;
     int act;
-    int vec_ok;
+    int vec_ok;    // 8-byte stores legal (cstride/coff % 4 == 0)
+    int vec16_ok;  // 16-byte stores legal (cstride/coff % 8 == 0, base 16-byte aligned)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
-    int ablate;  // debug (env Y6_CONV_ABLATE): 1 no weight DMA, 2 no halo loads, 4 no MFMA, 8 no LDS reads, 16 no epilogue
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -67,49 +65,105 @@ struct HaloCap {
     static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 208) : 576);
 };
 
-// bias (+affine) + activation (+residual) -> fp16 NHWC.  C/D layout: col = pixel (lane&31),
-// row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5): four consecutive couts of one pixel per 4 registers.
+// Epilogue: bias (+affine) + activation (+residual) -> fp16 NHWC.
+// C/D layout: col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds four
+// consecutive couts of ONE pixel per group of 4 accumulator registers (group g = r>>2), and lane^32
+// holds the next four couts of the same pixel.
+//   * bias values are fetched up front by load_bias() (4 x 16-byte loads per fragment, issued before
+//     the main loop) instead of 4 dependent loads in front of every store group;
+//   * v_permlane32_swap pairs groups (g, g+1): afterwards lanes 0-31 own couts 8g..8g+7 and lanes 32-63
+//     own 8(g+1)..8(g+1)+7 of their pixel -> ONE 16-byte store per lane per pair instead of two 8-byte
+//     ones (the scattered 8-byte stores were store-issue bound: profiles/ ablation r04).
+template <int CF>
+struct BiasRegs {
+    float v[CF][16];
+};
+
+template <int CF>
+__device__ __forceinline__ void load_bias(const ConvKArgs& a, int cb, int upc0, int lane, BiasRegs<CF>& bz) {
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = (cb * CF + cf) * 32 + 8 * g + 4 * (lane >> 5) - upc0;
+            const int cend = a.up == 2 ? a.upC : a.Cout;
+            if (a.bias != nullptr && c0 + 3 < cend && c0 >= 0) {
+                const float4 t = *reinterpret_cast<const float4*>(a.bias + c0);
+                bz.v[cf][g * 4 + 0] = t.x;
+                bz.v[cf][g * 4 + 1] = t.y;
+                bz.v[cf][g * 4 + 2] = t.z;
+                bz.v[cf][g * 4 + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bz.v[cf][g * 4 + j] = (a.bias != nullptr && c0 + j < cend && c0 + j >= 0) ? a.bias[c0 + j] : 0.f;
+            }
+        }
+}
+
 template <int CF, int PF>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF], const int (&opix)[PF],
-                                              int cb, int upc0, int lane) {
+                                              int cb, int upc0, int lane, const BiasRegs<CF>& bz) {
     const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+    const int cend = a.up == 2 ? a.upC : a.Cout;
+    const int kh = lane >> 5;
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf) {
-        if (opix[pf] < 0) continue;
-        __half* orow = a.out + (size_t)opix[pf] * a.out_cs + a.out_co;
-        const __half* rrow = a.res ? a.res + (size_t)opix[pf] * a.res_cs + a.res_co : nullptr;
+        const bool pvalid = opix[pf] >= 0;
+        const size_t prow = pvalid ? (size_t)opix[pf] : 0;
+        __half* orow = a.out + prow * a.out_cs + a.out_co;
+        const __half* rrow = a.res ? a.res + prow * a.res_cs + a.res_co : nullptr;
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf) {
+            const int cfrag = (cb * CF + cf) * 32 - upc0;   // first output channel of this fragment
+            // 1) finish the 16 values of this lane
+            float v[16];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int cg = (cb * CF + cf) * 32 + 8 * r4 + 4 * (lane >> 5);  // row of the weight matrix
-                if (cg >= a.Cout) continue;
-                const int c0 = cg - upc0;                                       // output channel
-                const int cend = a.up == 2 ? a.upC : a.Cout;
-                float v[4];
+            for (int r = 0; r < 16; ++r) {
+                const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
+                float x = acc[cf][pf][r] + bz.v[cf][r];
+                if (a.pscale && c < cend) x = x * a.pscale[c] + a.pshift[c];
+                x = y6_act(x, a.act);
+                if (rrow && pvalid && c < cend) x += ralpha * __half2float(rrow[c]);
+                v[r] = x;
+            }
+            // 2) pack to fp16 pairs: group g -> dwords pk[g][0..1]
+            unsigned pk[4][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int c = c0 + j;
-                    float x = acc[cf][pf][r4 * 4 + j];
-                    if (c < cend) {
-                        if (a.bias) x += a.bias[c];
-                        if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
-                        x = y6_act(x, a.act);
-                        if (rrow) x += ralpha * __half2float(rrow[c]);
-                    }
-                    v[j] = x;
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    h2_t t;
+                    t[0] = (_Float16)v[g * 4 + h * 2];
+                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                    pk[g][h] = __builtin_bit_cast(unsigned, t);
                 }
-                if (a.vec_ok && (c0 + 3) < cend) {
-                    h4_t o;
-                    o[0] = (_Float16)v[0];
-                    o[1] = (_Float16)v[1];
-                    o[2] = (_Float16)v[2];
-                    o[3] = (_Float16)v[3];
-                    *reinterpret_cast<h4_t*>(orow + c0) = o;
-                } else {
+            if (a.vec16_ok && (cfrag + 32) <= cend && cfrag >= 0) {
+                // 3) pair groups across the two half-waves, 16-byte stores
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c0 + j < cend) orow[c0 + j] = __float2half(v[j]);
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned lo0 = pk[2 * gp][0], lo1 = pk[2 * gp][1], hi0 = pk[2 * gp + 1][0], hi1 = pk[2 * gp + 1][1];
+                    auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
+                    // lanes 0-31: {own g, partner's g} = couts 8g..8g+7 ; lanes 32-63: couts 8(g+1)..8(g+1)+7
+                    if (pvalid) {
+                        uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        *reinterpret_cast<uint4*>(orow + cfrag + 16 * gp + 8 * kh) = o;
+                    }
+                }
+            } else if (pvalid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cfrag + 8 * g + 4 * kh;
+                    if (c0 >= cend || c0 < 0) continue;
+                    if (a.vec_ok && (c0 + 3) < cend) {
+                        *reinterpret_cast<uint2*>(orow + c0) = make_uint2(pk[g][0], pk[g][1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c0 + j < cend) orow[c0 + j] = __float2half(v[g * 4 + j]);
+                    }
                 }
             }
         }
@@ -205,6 +259,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         opix[pf] = v ? op : -1;
     }
 
+    BiasRegs<CF> bz;
+    load_bias<CF>(a, cb, upc0, lane, bz);
+
     f32x16_t acc[CF][PF];
 #pragma unroll
     for (int cf = 0; cf < CF; ++cf)
@@ -235,7 +292,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             const int idx = tid + i * 256;
             const int q = idx & 3;
-            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin && !(a.ablate & 2))
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
                 v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
             regs[i] = v;
         }
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         }
     }
 
-    conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane);
+    conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane, bz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -414,7 +471,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
         for (int i = 0; i < NP; ++i) {
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             const int q = (tid + i * 256) & 3;
-            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin && !(a.ablate & 2))
+            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
                 v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
             regs[i] = v;
         }
@@ -429,7 +486,6 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     // all nine tap images of (item, chunk) -> ring slot; pieces are contiguous in the packed weights:
     // [cfrag][chunk][tap][ks][512 halves], i.e. one cfrag's chunk is 9*2 consecutive KiB
     auto issue_w = [&](int item, int chunk, int wslot) {
-        if (a.ablate & 1) return;
         int wt, wcb;
         decode(item, wt, wcb);
 #pragma unroll
@@ -462,6 +518,8 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+        BiasRegs<CF> bz;
+        load_bias<CF>(a, cb, 0, lane, bz);   // in flight during the whole chunk loop
         const int nid = next_valid(id);
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
             const bool last = (chunk + 1) == a.nchunk;
@@ -480,32 +538,17 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     h8_t af[CF], bf[PF];
-                    if (!(a.ablate & 8)) {
 #pragma unroll
-                        for (int cf = 0; cf < CF; ++cf)
-                            af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
+                    for (int cf = 0; cf < CF; ++cf)
+                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf)
+                        bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+#pragma unroll
+                    for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                         for (int pf = 0; pf < PF; ++pf)
-                            bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
-                    } else {
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf) af[cf] = (h8_t)(_Float16)1.f;
-#pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) bf[pf] = (h8_t)(_Float16)1.f;
-                    }
-                    if (!(a.ablate & 4)) {
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-                            for (int pf = 0; pf < PF; ++pf)
-                                acc[cf][pf] =
-                                    __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int cf = 0; cf < CF; ++cf) asm volatile("" ::"v"(af[cf]));
-#pragma unroll
-                        for (int pf = 0; pf < PF; ++pf) asm volatile("" ::"v"(bf[pf]));
-                    }
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
                 }
             }
             if (have_next) {
@@ -516,7 +559,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                 slot ^= 1;
             }
         }
-        if (!(a.ablate & 16)) conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane);
+        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
         if (nid >= nids) break;
         id = nid;
         setup_pix(id);
@@ -561,8 +604,7 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
         // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
         // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is ~2-way
-        static const bool prefer_rows = getenv("Y6_CONV_ROWFIT") != nullptr;   // measured slower on r04: off by default
-        const double rowfit = (!prefer_rows || TW % 32 == 0) ? 1.0 : 0.94;
+        const double rowfit = 1.0;  // (TW % 32 == 0 ? 1.0 : 0.94) measured slower on r04: halo overhead outweighs the conflicts
         const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
@@ -603,6 +645,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.res_co = d->res.coff;
     k.act = d->act;
     k.vec_ok = (d->out.cstride % 4 == 0) && (d->out.coff % 4 == 0) && (((uintptr_t)d->out.data & 7) == 0);
+    k.vec16_ok = (d->out.cstride % 8 == 0) && (d->out.coff % 8 == 0) && (((uintptr_t)d->out.data & 15) == 0);
     k.up = up;
     k.updy = updy;
     k.updx = updx;
@@ -637,8 +680,6 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
     k.ldsA_bytes = k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
-    static const int ablate_env = getenv("Y6_CONV_ABLATE") ? atoi(getenv("Y6_CONV_ABLATE")) : 0;
-    k.ablate = ablate_env;
     L->grid = k.nids;
     if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
