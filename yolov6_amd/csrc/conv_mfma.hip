@@ -14,6 +14,8 @@
 //   C/D        : col = pixel = lane&31, row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // so every lane ends up with 4 consecutive couts of ONE pixel per 4 accumulator registers
 // -> 8-byte NHWC stores in the epilogue.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -39,6 +41,7 @@ struct ConvKArgs {
     int act;
     int vec_ok;    // 8-byte stores legal (cstride/coff % 4 == 0)
     int vec16_ok;  // 16-byte stores legal (cstride/coff % 8 == 0, base 16-byte aligned)
+    int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
@@ -168,6 +171,75 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t
             }
         }
     }
+}
+
+// LDS-staged epilogue: the direct path above makes every store instruction touch 32 different cache
+// lines with 16-32 bytes each (store-issue / request-rate bound: the 210 MB stem output ran at
+// ~550 GB/s).  Here each wave writes its [PF*32 pixels][CF*32 couts] fp16 tile into its own LDS
+// region, then reads it back so that consecutive lanes hold consecutive 16-byte pieces of one pixel's
+// channel row: a store instruction now covers 64*16 B of (at most 64/(CF*4)) complete NHWC rows.
+// Wave-private region -> no block barrier (LDS ops of one wave complete in order; lgkmcnt(0) between
+// the phases).  Callers must have passed a block barrier after the last main-loop LDS read.
+template <int CF, int PF>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF],
+                                                  const int (&opix)[PF], int cb, int upc0, int lane, int wave,
+                                                  const BiasRegs<CF>& bz, char* lds) {
+    constexpr int RS = CF * 64 + 16;                 // row pitch: CF*32 couts * 2 B + 16 B (bank spread)
+    constexpr int ROWS = PF * 32;
+    constexpr int REGION = ROWS * RS + ROWS * 4;      // tile + one int (output pixel index) per row
+    char* tile = lds + wave * REGION;
+    int* rowpix = reinterpret_cast<int*>(tile + ROWS * RS);
+    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+    const int cend = a.up == 2 ? a.upC : a.Cout;
+    const int kh = lane >> 5;
+    const int cblock = cb * CF * 32 - upc0;           // first output channel of this block's tile
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const bool pvalid = opix[pf] >= 0;
+        const size_t prow = pvalid ? (size_t)opix[pf] : 0;
+        const __half* rrow = a.res ? a.res + prow * a.res_cs + a.res_co : nullptr;
+        const int row = pf * 32 + (lane & 31);
+        if (kh == 0) rowpix[row] = opix[pf];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+            const int cfrag = cblock + cf * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                h4v o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = g * 4 + j;
+                    const int c = cfrag + 8 * g + 4 * kh + j;
+                    float x = acc[cf][pf][r] + bz.v[cf][r];
+                    if (a.pscale && c < cend) x = x * a.pscale[c] + a.pshift[c];
+                    x = y6_act(x, a.act);
+                    if (rrow && pvalid && c < cend) x += ralpha * __half2float(rrow[c]);
+                    o[j] = (_Float16)x;
+                }
+                *reinterpret_cast<h4v*>(tile + row * RS + cf * 64 + g * 16 + kh * 8) = o;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int PPR = CF * 4;                        // 16-byte pieces per row
+    constexpr int NPC = ROWS * PPR;                    // pieces per wave tile
+#pragma unroll
+    for (int i = 0; i < NPC / 64; ++i) {
+        const int q = lane + 64 * i;
+        const int row = q / PPR, pc = q - row * PPR;
+        const int op = rowpix[row];
+        const int c0 = cblock + pc * 8;
+        if (op >= 0 && c0 + 8 <= cend) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + row * RS + pc * 16);
+            *reinterpret_cast<uint4*>(a.out + (size_t)op * a.out_cs + a.out_co + c0) = v;
+        }
+    }
+}
+
+template <int CF, int PF>
+constexpr int epi_lds_bytes() {
+    return 4 * (PF * 32 * (CF * 64 + 16) + PF * 32 * 4);
 }
 
 template <int CF, int PF, int KS, int ST>
@@ -360,7 +432,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         }
     }
 
-    conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane, bz);
+    // the last step's barrier has been passed by every wave: halo / weight LDS is dead, re-use it
+    if (a.epi_lds)
+        conv_epilogue_lds<CF, PF>(a, acc, opix, cb, upc0, lane, wave, bz, smem);
+    else
+        conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane, bz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -646,6 +722,11 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.act = d->act;
     k.vec_ok = (d->out.cstride % 4 == 0) && (d->out.coff % 4 == 0) && (((uintptr_t)d->out.data & 7) == 0);
     k.vec16_ok = (d->out.cstride % 8 == 0) && (d->out.coff % 8 == 0) && (((uintptr_t)d->out.data & 15) == 0);
+    {
+        static const bool no_epi_lds = getenv("Y6_CONV_NO_EPI_LDS") != nullptr;   // A/B switch for profiling
+        const int cend = up == 2 ? d->out.C / 4 : d->out.C;
+        k.epi_lds = k.vec16_ok && (cend % 8 == 0) && !vc.persist && !no_epi_lds;
+    }
     k.up = up;
     k.updy = updy;
     k.updx = updx;
@@ -685,6 +766,10 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
+    if (k.epi_lds) {
+        const size_t e = 4 * ((size_t)vc.pf * 32 * (vc.cf * 64 + 16) + (size_t)vc.pf * 32 * 4);
+        if (e > L->lds) L->lds = e;
+    }
     return Y6_OK;
 }
 

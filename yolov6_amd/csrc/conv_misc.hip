@@ -229,17 +229,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
         }
     }
 
-    // epilogue: C/D col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The 64 pixels of a wave are consecutive NHWC rows: stage the [64][CF*32] fp16 tile in the wave's
+    // LDS region and write it out as whole rows, 16 bytes per lane (see conv_epilogue_lds).
+    constexpr int RS = CF * 64 + 16;
+    __shared__ __attribute__((aligned(16))) char s_tile[4 * 64 * RS];
+    char* tile = s_tile + wave * 64 * RS;
+    const bool rows_ok = (Cout % 8 == 0) && (out_cs % 8 == 0) && (out_co % 8 == 0);
 #pragma unroll
     for (int pf = 0; pf < 2; ++pf) {
-        if (gp[pf] >= npix) continue;
         __half* orow = out + gp[pf] * out_cs + out_co;
+        const int row = pf * 32 + (lane & 31);
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int c0 = cf * 32 + 8 * r4 + 4 * kh;
-                if (c0 >= Cout) continue;
                 h4_t o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -252,14 +257,27 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
                     }
                     o[j] = (_Float16)x;
                 }
-                if (c0 + 3 < Cout) {
-                    *reinterpret_cast<h4_t*>(orow + c0) = o;
-                } else {
+                if (rows_ok) {
+                    *reinterpret_cast<h4_t*>(tile + row * RS + c0 * 2) = o;
+                } else if (gp[pf] < npix && c0 < Cout) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c0 + j < Cout) orow[c0 + j] = (__half)o[j];
                 }
             }
+    }
+    if (rows_ok) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int PPR = CF * 4;   // 16-byte pieces per pixel row
+#pragma unroll
+        for (int i = 0; i < PPR; ++i) {
+            const int q = lane + 64 * i;
+            const int row = q / PPR, pc = q - row * PPR;
+            const size_t pix = wave_pix0 + row;
+            if (pix < npix && pc * 8 + 8 <= Cout)
+                *reinterpret_cast<uint4*>(out + pix * out_cs + out_co + pc * 8) =
+                    *reinterpret_cast<const uint4*>(tile + row * RS + pc * 16);
+        }
     }
 }
 

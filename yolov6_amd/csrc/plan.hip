@@ -339,8 +339,13 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             if (!y6_conv_variant_supports(&op.conv, v)) continue;
             Op trial = op;
             trial.conv.variant = v;
-            float ms = 0.f;
-            int rc = time_op(trial, s, iters, &ms);
+            float ms = 1e30f;
+            int rc = Y6_OK;
+            for (int rep = 0; rep < 3 && rc == Y6_OK; ++rep) {   // min of three short bursts: robust to clock ramps
+                float t = 0.f;
+                rc = time_op(trial, s, iters, &t);
+                if (t < ms) ms = t;
+            }
             if (rc) {
                 if (logf) fclose(logf);
                 return rc;
