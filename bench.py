@@ -113,16 +113,11 @@ def cpu_baseline(args, cfg, sd_train, shift):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the hot path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://")   # RCCL; used for barriers + max-reduce only
+    from yolov6_amd.parallel import Replicas
+    rep = Replicas()                     # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
+    rank, world = rep.rank, rep.world
+    device = rep.device()                # "nccl" (= RCCL) process group for N > 1: barriers + one MAX reduce only
 
     from yolov6_amd.utils.nms import nms_raw
     cfg, sd_train, model, x = build_model_and_input(args, device)
@@ -139,8 +134,7 @@ def main():
     plan.timing_begin(args.steps)
     nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    if dist is not None:
-        dist.barrier()
+    rep.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -149,13 +143,8 @@ def main():
         out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
         nms_ev[i][1].record()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rep.barrier()
+    elapsed = rep.max_over_ranks(time.perf_counter() - t0)
 
     rows = plan.timing_read()
     nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / args.steps
@@ -177,7 +166,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         res = {
             "metric": "images/sec (b32, 640x640) YOLOv6-S fp16 inference (forward + NMS)",
-            "value": round(world * args.batch * args.steps / elapsed, 2),
+            "value": round(rep.throughput(args.batch, args.steps, elapsed), 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -207,9 +196,7 @@ def main():
             with open(args.profile_out, "w") as f:
                 json.dump(dict(rows=rows, result=res), f, indent=1)
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rep.close()
 
 
 if __name__ == "__main__":
