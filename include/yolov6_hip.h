@@ -220,6 +220,33 @@ typedef struct y6_tal_desc {
 size_t y6_tal_workspace_bytes(int B, int A, int G);
 int y6_tal_assign(const y6_tal_desc* d, void* stream);
 
+/* ATSS assigner (warm-up epochs).  Replaces: ATSSAssigner.forward
+ * yolov6/assigners/atss_assigner.py:18-86 (+ select_topk_candidates :88-115, thres_calculator
+ * :117-136, get_targets :138-161), bbox_overlaps yolov6/assigners/iou2d_calculator.py:63-241 and
+ * dist_calculator yolov6/assigners/assigner_utils.py:4-23.
+ * anc_bboxes [A,4] f32, n_level_bboxes[n_levels] anchors per level (host array, sums to A),
+ * gt_labels [B,G] f32, gt_bboxes [B,G,4], mask_gt [B,G] f32, pd_bboxes [B,A,4] f32 or NULL
+ * (soft labels). Outputs as y6_tal_assign; background label = C.                           */
+typedef struct y6_atss_desc {
+    const float* anc_bboxes;
+    int32_t n_level_bboxes[Y6_MAX_LEVELS];
+    int32_t n_levels;
+    const float* gt_labels;
+    const float* gt_bboxes;
+    const float* mask_gt;
+    const float* pd_bboxes;
+    int32_t B, A, C, G;
+    int32_t topk;
+    int64_t* target_labels;
+    float* target_bboxes;
+    float* target_scores;
+    uint8_t* fg_mask;
+    void* workspace;
+    size_t workspace_bytes;
+} y6_atss_desc;
+size_t y6_atss_workspace_bytes(int B, int A, int G);
+int y6_atss_assign(const y6_atss_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Execution plan: an ordered list of the ops above with fixed pointers, replayed with one
  * call per forward (optionally from a captured hipGraph).  This is the native executor

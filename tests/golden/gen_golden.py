@@ -14,6 +14,8 @@ What is pinned
                     candidate / multi-label / class-offset / max_det logic around it is the
                     reference's own code (PARITY UNPINNED for the torchvision call itself).
   tal_<case>.npz    reference yolov6/assigners/tal_assigner.py::TaskAlignedAssigner on CPU
+  atss_<case>.npz   reference yolov6/assigners/atss_assigner.py::ATSSAssigner on CPU (anchors from the
+                    reference's generate_anchors)
 Inputs are regenerated from seeds by oracle/synth.py, so only outputs are stored.
 """
 import json
@@ -159,12 +161,51 @@ def gen_tal():
         print(f"tal_{name}: fg {int(fg.sum())} nonzero scores {len(nz[0])}")
 
 
+ATSS_CASES = {
+    # name: (B, feat sizes, strides, C, G, n_valid, seed, with_pd)
+    "basic": (2, [(20, 20), (10, 10), (5, 5)], [8, 16, 32], 20, 6, None, 10, True),
+    "padded_nopd": (3, [(20, 20), (10, 10), (5, 5)], [8, 16, 32], 20, 8, [8, 3, 0], 11, False),
+    "p6": (1, [(32, 32), (16, 16), (8, 8), (4, 4)], [8, 16, 32, 64], 80, 12, None, 12, True),   # every level >= topk anchors (the reference itself breaks below that, atss_assigner.py:104)
+    "empty": (2, [(8, 8), (4, 4), (2, 2)], [8, 16, 32], 20, 0, None, 13, True),
+}
+
+
+def atss_anchors(fs, st):
+    """Train-form anchors exactly as the reference builds them (anchor_generator.py:35-63)."""
+    from yolov6.assigners.anchor_generator import generate_anchors
+    feats = [torch.zeros(1, 1, h, w) for h, w in fs]
+    anchors, _, n_list, _ = generate_anchors(feats, st, 5.0, 0.5, device="cpu", is_eval=False)
+    return anchors, n_list
+
+
+def gen_atss():
+    from yolov6.assigners.atss_assigner import ATSSAssigner
+    for name, (B, fs, st, C, G, nv, seed, with_pd) in ATSS_CASES.items():
+        inp = synth.synth_tal_inputs(B, fs, st, C, G, seed=seed, n_valid=nv)
+        anchors, n_list = atss_anchors(fs, st)
+        assigner = ATSSAssigner(9, num_classes=C)
+        with torch.no_grad():
+            tl, tb, ts, fg = assigner(anchors, n_list, inp["gt_labels"], inp["gt_bboxes"], inp["mask_gt"],
+                                      inp["pd_bboxes"] if with_pd else None)
+        ts = ts.numpy().astype(np.float32)
+        nz = np.nonzero(ts)
+        np.savez_compressed(os.path.join(HERE, f"atss_{name}.npz"), labels=tl.numpy().astype(np.int64),
+                            bboxes=tb.numpy().astype(np.float32), fg=fg.numpy().astype(bool),
+                            score_idx=np.stack(nz, 1).astype(np.int32), score_val=ts[nz],
+                            anchors=anchors.numpy().astype(np.float32), n_list=np.array(n_list, np.int32),
+                            meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, G=G, n_valid=nv, seed=seed,
+                                                 with_pd=with_pd)))
+        print(f"atss_{name}: fg {int(fg.sum())} nonzero scores {len(nz[0])}")
+
+
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss"]
     if "models" in which:
         gen_models()
     if "nms" in which:
         gen_nms()
     if "tal" in which:
         gen_tal()
+    if "atss" in which:
+        gen_atss()

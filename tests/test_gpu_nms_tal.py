@@ -129,3 +129,46 @@ def test_tal_training_size_vs_oracle():
     # properties: every fg anchor has exactly one non-zero class score; background rows are all zero
     nz = (S != 0).sum(-1)
     assert np.all(nz[F.astype(bool)] <= 1) and np.all(nz[~F.astype(bool)] == 0)
+
+
+ATSS_CASES = ["basic", "padded_nopd", "p6", "empty"]
+
+
+@pytest.mark.parametrize("case", ATSS_CASES)
+def test_atss_matches_reference_golden(case):
+    from yolov6_amd.assigners import ATSSAssigner
+    g = np.load(os.path.join(GOLDEN, f"atss_{case}.npz"))
+    meta = json.loads(str(g["meta"]))
+    inp = synth.synth_tal_inputs(meta["B"], [tuple(f) for f in meta["feat_sizes"]], meta["strides"], meta["C"],
+                                 meta["G"], seed=meta["seed"], n_valid=meta["n_valid"])
+    a = ATSSAssigner(9, num_classes=meta["C"])
+    out = a(torch.from_numpy(g["anchors"]).to(DEV), g["n_list"].tolist(), inp["gt_labels"].to(DEV),
+            inp["gt_bboxes"].to(DEV), inp["mask_gt"].to(DEV), inp["pd_bboxes"].to(DEV) if meta["with_pd"] else None)
+    torch.cuda.synchronize()
+    L, Bx, S, F = [o.cpu().numpy() for o in out]
+    assert np.array_equal(F.astype(bool), g["fg"])                 # bit-exact assignment
+    assert np.array_equal(L.astype(np.int64), g["labels"])
+    assert np.array_equal(Bx, g["bboxes"])
+    ref = np.zeros_like(S)
+    idx = g["score_idx"]
+    ref[idx[:, 0], idx[:, 1], idx[:, 2]] = g["score_val"]
+    assert np.array_equal(S != 0, ref != 0)
+    np.testing.assert_allclose(S, ref, rtol=2e-5, atol=1e-10)
+
+
+def test_atss_training_size_vs_oracle():
+    from oracle import atss_oracle
+    from yolov6_amd.assigners import ATSSAssigner, generate_anchors
+    fs, st = [(80, 80), (40, 40), (20, 20)], [8, 16, 32]
+    nv = [40, 0, 17, 40]
+    inp = synth.synth_tal_inputs(4, fs, st, 80, 40, seed=19, n_valid=nv, img=640)
+    feats = [torch.zeros(1, 1, h, w) for h, w in fs]
+    anchors, _, n_list, _ = generate_anchors(feats, st, 5.0, 0.5, device="cpu", is_eval=False)
+    out = ATSSAssigner(9, 80)(anchors.to(DEV), n_list, inp["gt_labels"].to(DEV), inp["gt_bboxes"].to(DEV),
+                              inp["mask_gt"].to(DEV), inp["pd_bboxes"].to(DEV))
+    torch.cuda.synchronize()
+    L, Bx, S, F = [o.cpu().numpy() for o in out]
+    eL, eB, eS, eF = atss_oracle.assign(anchors.numpy(), n_list, inp["gt_labels"].numpy(), inp["gt_bboxes"].numpy(),
+                                        inp["mask_gt"].numpy(), inp["pd_bboxes"].numpy(), 9, 80)
+    assert np.array_equal(F.astype(bool), eF) and np.array_equal(L.astype(np.int64), eL) and np.array_equal(Bx, eB)
+    np.testing.assert_allclose(S, eS, rtol=2e-5, atol=1e-10)

@@ -103,3 +103,37 @@ def test_tal_oracle_matches_reference(case):
     ref_scores[idx[:, 0], idx[:, 1], idx[:, 2]] = g["score_val"]
     assert np.array_equal(S != 0, ref_scores != 0)
     np.testing.assert_allclose(S, ref_scores, rtol=2e-6, atol=1e-12)
+
+
+ATSS_CASES = ["basic", "padded_nopd", "p6", "empty"]
+
+
+def _atss_inputs(g):
+    meta = json.loads(str(g["meta"]))
+    inp = synth.synth_tal_inputs(meta["B"], [tuple(f) for f in meta["feat_sizes"]], meta["strides"], meta["C"],
+                                 meta["G"], seed=meta["seed"], n_valid=meta["n_valid"])
+    return meta, inp
+
+
+@pytest.mark.parametrize("case", ATSS_CASES)
+def test_atss_oracle_matches_reference(case):
+    from oracle import atss_oracle
+    from yolov6_amd.assigners import generate_anchors
+    g = np.load(os.path.join(GOLDEN, f"atss_{case}.npz"))
+    meta, inp = _atss_inputs(g)
+    # the product's host-side generate_anchors equals the reference's (anchors stored in the golden)
+    feats = [torch.zeros(1, 1, h, w) for h, w in meta["feat_sizes"]]
+    anchors, _, n_list, _ = generate_anchors(feats, meta["strides"], 5.0, 0.5, device="cpu", is_eval=False)
+    assert np.array_equal(anchors.numpy(), g["anchors"]) and list(n_list) == g["n_list"].tolist()
+    L, Bx, S, F = atss_oracle.assign(g["anchors"], g["n_list"].tolist(), inp["gt_labels"].numpy(),
+                                     inp["gt_bboxes"].numpy(), inp["mask_gt"].numpy(),
+                                     inp["pd_bboxes"].numpy() if meta["with_pd"] else None, topk=9,
+                                     num_classes=meta["C"])
+    assert np.array_equal(F.astype(bool), g["fg"])
+    assert np.array_equal(L, g["labels"])
+    assert np.array_equal(Bx, g["bboxes"])
+    ref = np.zeros_like(S)
+    idx = g["score_idx"]
+    ref[idx[:, 0], idx[:, 1], idx[:, 2]] = g["score_val"]
+    assert np.array_equal(S != 0, ref != 0)
+    np.testing.assert_allclose(S, ref, rtol=2e-6, atol=1e-12)

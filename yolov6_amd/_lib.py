@@ -62,6 +62,15 @@ class TalDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class AtssDesc(C.Structure):
+    _fields_ = [("anc_bboxes", C.c_void_p), ("n_level_bboxes", C.c_int32 * MAX_LEVELS), ("n_levels", C.c_int32),
+                ("gt_labels", C.c_void_p), ("gt_bboxes", C.c_void_p), ("mask_gt", C.c_void_p),
+                ("pd_bboxes", C.c_void_p), ("B", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("G", C.c_int32),
+                ("topk", C.c_int32), ("target_labels", C.c_void_p), ("target_bboxes", C.c_void_p),
+                ("target_scores", C.c_void_p), ("fg_mask", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
 # symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
 SIGNATURES = {
     "y6_abi_version": (C.c_int, []),
@@ -84,6 +93,8 @@ SIGNATURES = {
     "y6_nms": (C.c_int, [C.POINTER(NmsDesc), C.c_void_p]),
     "y6_tal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "y6_tal_assign": (C.c_int, [C.POINTER(TalDesc), C.c_void_p]),
+    "y6_atss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "y6_atss_assign": (C.c_int, [C.POINTER(AtssDesc), C.c_void_p]),
     "y6_plan_create": (C.c_void_p, []),
     "y6_plan_destroy": (None, [C.c_void_p]),
     "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),

@@ -150,21 +150,51 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ i
 // ------------------------------------------------------------------ stem conv on the matrix cores
 // The stem is a [pixels x 27] x [27 x Cout] GEMM (Cin = 3): K is padded to 32 = two
 // v_mfma_f32_32x32x16_f16 k-steps.  A operand = weights (row = cout), B operand = the 3x3x3 patch of
-// one output pixel, gathered straight from the caller's NCHW image (k = ci*9 + ky*3 + kx, exactly
-// the OIHW flattening).  One wave = 64 output pixels x CF*32 couts; no LDS, no layout pre-pass.
+// one output pixel (k = ci*9 + ky*3 + kx, exactly the OIHW flattening).
+// One block = a 4 x 64 output tile (one wave per output row, 64 pixels each).  The 9 x 129 input
+// window of each channel is read from the caller's NCHW image with coalesced loads (consecutive
+// lanes = consecutive pixels of a row), converted to fp16 and staged in LDS; patches are then
+// gathered from LDS (bank-conflict free: stride-2 halves across lanes).  v1 gathered the patches
+// straight from HBM with 2-byte loads and was latency bound at 0.36 ms (roofline 0.07 ms).
+constexpr int STEM_TOH = 4, STEM_TOW = 64;
+constexpr int STEM_IH = 2 * STEM_TOH + 1, STEM_IW = 2 * STEM_TOW + 1, STEM_PITCH = STEM_IW + 1;  // 9 x 129 (+1 pad)
+
 template <typename TI, int CF>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ in, __half* __restrict__ out,
                                                         const float* __restrict__ w /*[Cout][Cin*9]*/,
                                                         const float* __restrict__ bias,
                                                         const float* __restrict__ pscale,
                                                         const float* __restrict__ pshift, int B, int Cin, int H, int W,
-                                                        int Ho, int Wo, int Cout, int out_cs, int out_co, int act) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int kh = lane >> 5;  // which 8-wide k group of a k-step this lane feeds
+                                                        int Ho, int Wo, int Cout, int out_cs, int out_co, int act,
+                                                        int tiles_x, int tiles_y) {
+    constexpr int RS = CF * 64 + 16;  // epilogue row pitch (bytes)
+    __shared__ __attribute__((aligned(16))) char s_mem[(3 * STEM_IH * STEM_PITCH * 2 > 4 * 64 * RS)
+                                                           ? 3 * STEM_IH * STEM_PITCH * 2
+                                                           : 4 * 64 * RS];
+    _Float16* s_in = reinterpret_cast<_Float16*>(s_mem);   // [ci][STEM_IH][STEM_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5;
     const int K = Cin * 9;
-    const size_t npix = (size_t)B * Ho * Wo;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
+    const int oy0 = ty * STEM_TOH, ox0 = tx * STEM_TOW;
+    const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
     const size_t HW = (size_t)H * W;
+
+    // stage the input window (zero outside the image = conv padding)
+    const int nwin = Cin * STEM_IH * STEM_IW;
+    for (int i = tid; i < nwin; i += 256) {
+        const int ci = i / (STEM_IH * STEM_IW);
+        const int r = i - ci * (STEM_IH * STEM_IW);
+        const int yy = r / STEM_IW, xx = r - yy * STEM_IW;
+        const int iy = iy0 + yy, ix = ix0 + xx;
+        float v = 0.f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (float)in[((size_t)b * Cin + ci) * HW + (size_t)iy * W + ix];
+        s_in[(ci * STEM_IH + yy) * STEM_PITCH + xx] = (_Float16)v;
+    }
 
     // weights: A fragments (cout = cf*32 + lane&31, k = ks*16 + kh*8 + j)
     h8_t af[CF][2];
@@ -177,21 +207,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
                 const int co = cf * 32 + (lane & 31), k = ks * 16 + kh * 8 + j;
                 af[cf][ks][j] = (co < Cout && k < K) ? (_Float16)w[(size_t)co * K + k] : (_Float16)0.f;
             }
+    __syncthreads();
 
-    // per-lane patch offsets (relative to the patch origin) - identical for every pixel
-    int koff[2][8];
-    int kyx[2][8];  // ky | kx<<8 | valid<<16
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ks * 16 + kh * 8 + j;
-            const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
-            koff[ks][j] = (int)(ci * HW) + ky * W + kx;
-            kyx[ks][j] = ky | (kx << 8) | ((k < K) << 16);
-        }
-
-    const size_t wave_pix0 = ((size_t)blockIdx.x * 4 + wave) * 64;
     f32x16_t acc[CF][2];
 #pragma unroll
     for (int cf = 0; cf < CF; ++cf)
@@ -200,46 +217,38 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
 
-    size_t gp[2];
 #pragma unroll
     for (int pf = 0; pf < 2; ++pf) {
-        gp[pf] = wave_pix0 + pf * 32 + (lane & 31);
-        const size_t q = gp[pf] < npix ? gp[pf] : npix - 1;
-        const int ox = (int)(q % Wo);
-        const size_t t = q / Wo;
-        const int oy = (int)(t % Ho);
-        const int b = (int)(t / Ho);
-        const int iy0 = oy * 2 - 1, ix0 = ox * 2 - 1;
-        const long base = (long)((size_t)b * Cin * HW) + (long)iy0 * W + ix0;
+        const int px = pf * 32 + (lane & 31);             // output column inside the tile; row = wave
+        const _Float16* base = s_in + (2 * wave) * STEM_PITCH + 2 * px;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             h8_t bf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int ky = kyx[ks][j] & 0xff, kx = (kyx[ks][j] >> 8) & 0xff;
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                const bool ok = (kyx[ks][j] >> 16) && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const long off = ok ? base + koff[ks][j] : 0;  // clamp the address, select the value
-                const float v = (float)in[off];
-                bf[j] = ok ? (_Float16)v : (_Float16)0.f;
+                const int k = ks * 16 + kh * 8 + j;
+                const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
+                bf[j] = (k < K) ? base[(ci * STEM_IH + ky) * STEM_PITCH + kx] : (_Float16)0.f;
             }
 #pragma unroll
             for (int cf = 0; cf < CF; ++cf)
                 acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf][ks], bf, acc[cf][pf], 0, 0, 0);
         }
     }
+    __syncthreads();   // every wave is done with the input window: the LDS becomes the output staging area
 
     // epilogue: C/D col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // The 64 pixels of a wave are consecutive NHWC rows: stage the [64][CF*32] fp16 tile in the wave's
-    // LDS region and write it out as whole rows, 16 bytes per lane (see conv_epilogue_lds).
-    constexpr int RS = CF * 64 + 16;
-    __shared__ __attribute__((aligned(16))) char s_tile[4 * 64 * RS];
-    char* tile = s_tile + wave * 64 * RS;
+    // The 64 pixels of a wave are consecutive NHWC rows of one image row: stage the [64][CF*32] fp16
+    // tile in the wave's LDS region and write it out as whole rows, 16 bytes per lane.
+    char* tile = s_mem + wave * 64 * RS;
+    const int oy = oy0 + wave;
     const bool rows_ok = (Cout % 8 == 0) && (out_cs % 8 == 0) && (out_co % 8 == 0);
+    const size_t rowbase = ((size_t)b * Ho + oy) * Wo;     // first pixel of this image row
 #pragma unroll
     for (int pf = 0; pf < 2; ++pf) {
-        __half* orow = out + gp[pf] * out_cs + out_co;
-        const int row = pf * 32 + (lane & 31);
+        const int px = pf * 32 + (lane & 31);
+        const bool pvalid = oy < Ho && (ox0 + px) < Wo;
+        __half* orow = out + (rowbase + ox0 + px) * out_cs + out_co;
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
                     o[j] = (_Float16)x;
                 }
                 if (rows_ok) {
-                    *reinterpret_cast<h4_t*>(tile + row * RS + c0 * 2) = o;
-                } else if (gp[pf] < npix && c0 < Cout) {
+                    *reinterpret_cast<h4_t*>(tile + px * RS + c0 * 2) = o;
+                } else if (pvalid && c0 < Cout) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c0 + j < Cout) orow[c0 + j] = (__half)o[j];
@@ -272,11 +281,10 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
 #pragma unroll
         for (int i = 0; i < PPR; ++i) {
             const int q = lane + 64 * i;
-            const int row = q / PPR, pc = q - row * PPR;
-            const size_t pix = wave_pix0 + row;
-            if (pix < npix && pc * 8 + 8 <= Cout)
-                *reinterpret_cast<uint4*>(out + pix * out_cs + out_co + pc * 8) =
-                    *reinterpret_cast<const uint4*>(tile + row * RS + pc * 16);
+            const int px = q / PPR, pc = q - px * PPR;
+            if (oy < Ho && (ox0 + px) < Wo && pc * 8 + 8 <= Cout)
+                *reinterpret_cast<uint4*>(out + (rowbase + ox0 + px) * out_cs + out_co + pc * 8) =
+                    *reinterpret_cast<const uint4*>(tile + px * RS + pc * 16);
         }
     }
 }
@@ -536,11 +544,12 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     const size_t total = (size_t)d->B * Ho * Wo;
     hipStream_t s = (hipStream_t)stream;
     if (d->Cin * 9 <= 32 && CO <= 64 && d->out.cstride % 4 == 0 && d->out.coff % 4 == 0) {
-        dim3 g((unsigned)((total + 255) / 256)), blk(256);
+        const int tiles_x = y6_cdiv(Wo, STEM_TOW), tiles_y = y6_cdiv(Ho, STEM_TOH);
+        dim3 g((unsigned)(tiles_x * tiles_y * d->B)), blk(256);
 #define Y6_STEM_MFMA(TI, CF_)                                                                                     \
     hipLaunchKernelGGL((stem_mfma_kernel<TI, CF_>), g, blk, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data,      \
                        d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo, CO, \
-                       d->out.cstride, d->out.coff, d->act)
+                       d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
         if (d->in_dtype == Y6_F16) {
             if (CO <= 32) Y6_STEM_MFMA(__half, 1); else Y6_STEM_MFMA(__half, 2);
         } else if (d->in_dtype == Y6_F32) {

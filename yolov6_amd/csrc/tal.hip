@@ -200,6 +200,187 @@ __global__ void tal_empty_kernel(const TalArgs a) {
     }
 }
 
+// ============================================================================================
+// ATSS assigner.  Restates ATSSAssigner.forward (reference yolov6/assigners/atss_assigner.py:18-86):
+//   A1 (per (b,g) block)  bbox_overlaps(gt, anchor) iou2d_calculator.py:63-241 (union = max(.,1e-6)),
+//        dist_calculator assigner_utils.py:4-23, per-level top-k NEAREST anchors
+//        (select_topk_candidates :88-115), threshold = mean + unbiased std of the candidates' IoUs
+//        (thres_calculator :117-136), positives = candidates with IoU > thr whose centre is inside
+//        the gt (:64-71).  The distance row lives in LDS; top-k is k rounds of a block arg-min.
+//   A2 (per (b,a))  select_highest_overlaps (assigner_utils.py:46-67) on the ANCHOR-box IoUs,
+//        soft label IoU(gt, predicted box) (:80-84).
+//   A3  get_targets :138-161: background label = num_classes, one-hot without the bg column.
+// Tie rule (torch.topk leaves it open): smaller distance first, then lower anchor index.
+struct AtssArgs {
+    const float4* anc;         // [A] anchor boxes
+    const float* gt_labels;
+    const float4* gt_bboxes;
+    const float* mask_gt;
+    const float4* pd_bboxes;   // [B,A] or null
+    int B, A, C, G, topk, n_levels;
+    int lvl_start[Y6_MAX_LEVELS + 1];
+    int* fg_cnt;
+    int* first_g;
+    int* assign;
+    float* norm;               // soft-label IoU per anchor
+    long long* target_labels;
+    float4* target_bboxes;
+    float* target_scores;
+    unsigned char* fg_mask;
+};
+
+__device__ __forceinline__ float iou_mmdet(const float4 g, const float4 q) {
+    // bbox_overlaps(mode='iou', is_aligned=False, eps=1e-6)  iou2d_calculator.py:186-241
+    const float area1 = (g.z - g.x) * (g.w - g.y);
+    const float area2 = (q.z - q.x) * (q.w - q.y);
+    const float w = fmaxf(fminf(g.z, q.z) - fmaxf(g.x, q.x), 0.f);
+    const float h = fmaxf(fminf(g.w, q.w) - fmaxf(g.y, q.y), 0.f);
+    const float overlap = w * h;
+    const float uni = fmaxf(area1 + area2 - overlap, 1e-6f);
+    return overlap / uni;
+}
+
+constexpr int ATSS_MAX_CAND = 4 * 16;   // levels x topk held in LDS
+
+__global__ __launch_bounds__(256) void atss_candidates_kernel(const AtssArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dist = reinterpret_cast<float*>(smem);  // [A]
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ int s_cand[ATSS_MAX_CAND];
+    __shared__ int s_ncand;
+    const int bg = blockIdx.x;
+    const int b = bg / a.G;
+    if (!(a.mask_gt[bg] != 0.f)) return;   // masked gt: candidate indices forced to 0 and de-duplicated away (:104-108)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 g = a.gt_bboxes[bg];
+    const float gcx = (g.x + g.z) / 2.0f, gcy = (g.y + g.w) / 2.0f;
+    for (int an = tid; an < a.A; an += 256) {
+        const float4 q = a.anc[an];
+        const float dx = gcx - (q.x + q.z) / 2.0f, dy = gcy - (q.y + q.w) / 2.0f;
+        dist[an] = sqrtf(dx * dx + dy * dy);
+    }
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+    for (int l = 0; l < a.n_levels; ++l) {
+        const int lo = a.lvl_start[l], hi = a.lvl_start[l + 1];
+        const int k = a.topk < (hi - lo) ? a.topk : (hi - lo);
+        for (int r = 0; r < k; ++r) {
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+            for (int an = lo + tid; an < hi; an += 256) {
+                const float v = dist[an];
+                if (v < bv) {
+                    bv = v;
+                    bi = an;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov < bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                }
+            }
+            if (lane == 0) {
+                s_v[wave] = bv;
+                s_i[wave] = bi;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < 4; ++w)
+                    if (s_v[w] < bv || (s_v[w] == bv && s_i[w] < bi)) {
+                        bv = s_v[w];
+                        bi = s_i[w];
+                    }
+                if (bi < a.A) {
+                    dist[bi] = INFINITY;  // taken
+                    s_cand[s_ncand++] = bi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const int n = s_ncand;
+        float iou[ATSS_MAX_CAND];
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) {
+            iou[i] = iou_mmdet(g, a.anc[s_cand[i]]);
+            sum += iou[i];
+        }
+        const float mean = sum / (float)n;
+        double m2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double dv = (double)iou[i] - (double)mean;
+            m2 += dv * dv;
+        }
+        const float sd = n > 1 ? (float)sqrt(m2 / (double)(n - 1)) : NAN;   // torch.std: unbiased; NaN for one sample
+        const float thr = mean + sd;
+        for (int i = 0; i < n; ++i) {
+            if (!(iou[i] > thr)) continue;
+            const int an = s_cand[i];
+            const float4 q = a.anc[an];
+            const float2 c = make_float2((q.x + q.z) / 2.0f, (q.y + q.w) / 2.0f);
+            if (in_gt(c, g, 1e-9f)) {
+                atomicAdd(&a.fg_cnt[(size_t)b * a.A + an], 1);
+                atomicMin(&a.first_g[(size_t)b * a.A + an], bg - b * a.G);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void atss_targets_kernel(const AtssArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)a.B * a.A) return;
+    const int b = (int)(i / a.A), an = (int)(i % a.A);
+    const int cnt = a.fg_cnt[i];
+    int gsel = -1;
+    if (cnt == 1) {
+        gsel = a.first_g[i];
+    } else if (cnt > 1) {
+        const float4 q = a.anc[an];
+        float best = -INFINITY;
+        for (int g = 0; g < a.G; ++g) {
+            const float o = iou_mmdet(a.gt_bboxes[(size_t)b * a.G + g], q);
+            if (o > best) {
+                best = o;
+                gsel = g;
+            }
+        }
+    }
+    a.assign[i] = gsel;
+    const size_t bg = (size_t)b * a.G + (gsel >= 0 ? gsel : 0);
+    a.target_bboxes[i] = a.gt_bboxes[bg];
+    a.target_labels[i] = gsel >= 0 ? (long long)a.gt_labels[bg] : (long long)a.C;
+    a.fg_mask[i] = gsel >= 0 ? 1 : 0;
+    float soft = gsel >= 0 ? 1.f : 0.f;
+    if (gsel >= 0 && a.pd_bboxes) soft = iou_gt_pd(a.gt_bboxes[bg], a.pd_bboxes[i], 1e-9f);
+    a.norm[i] = soft;
+}
+
+__global__ __launch_bounds__(256) void atss_scores_kernel(const AtssArgs a) {
+    const size_t total = (size_t)a.B * a.A * a.C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ba = i / a.C;
+        const int c = (int)(i - ba * a.C);
+        float v = 0.f;
+        if (a.assign[ba] >= 0 && (long long)c == a.target_labels[ba]) v = a.norm[ba];
+        a.target_scores[i] = v;
+    }
+}
+
+__global__ void atss_empty_kernel(const AtssArgs a) {
+    const size_t total = (size_t)a.B * a.A;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        a.target_labels[i] = a.C;
+        a.target_bboxes[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.fg_mask[i] = 0;
+    }
+}
+
 inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -270,6 +451,73 @@ extern "C" int y6_tal_assign(const y6_tal_desc* d, void* stream) {
     size_t g = (nba * d->C + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(tal_scores_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" size_t y6_atss_workspace_bytes(int B, int A, int G) { return y6_tal_workspace_bytes(B, A, G); }
+
+extern "C" int y6_atss_assign(const y6_atss_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(d && d->anc_bboxes && d->target_labels && d->target_bboxes && d->target_scores && d->fg_mask,
+               "atss_assign: null argument");
+    Y6_REQUIRE(d->B > 0 && d->A > 0 && d->C > 0 && d->G >= 0 && d->topk > 0, "atss_assign: bad sizes");
+    Y6_REQUIRE(d->n_levels >= 1 && d->n_levels <= Y6_MAX_LEVELS, "atss_assign: 1..%d levels", Y6_MAX_LEVELS);
+    Y6_REQUIRE(d->n_levels * d->topk <= ATSS_MAX_CAND, "atss_assign: levels x topk must be <= %d", ATSS_MAX_CAND);
+    hipStream_t s = (hipStream_t)stream;
+    AtssArgs a;
+    memset(&a, 0, sizeof(a));
+    a.anc = (const float4*)d->anc_bboxes;
+    a.gt_labels = d->gt_labels;
+    a.gt_bboxes = (const float4*)d->gt_bboxes;
+    a.mask_gt = d->mask_gt;
+    a.pd_bboxes = (const float4*)d->pd_bboxes;
+    a.B = d->B;
+    a.A = d->A;
+    a.C = d->C;
+    a.G = d->G;
+    a.topk = d->topk;
+    a.n_levels = d->n_levels;
+    int acc = 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+        a.lvl_start[l] = acc;
+        acc += d->n_level_bboxes[l];
+    }
+    a.lvl_start[d->n_levels] = acc;
+    Y6_REQUIRE(acc == d->A, "atss_assign: n_level_bboxes sum %d != A %d", acc, d->A);
+    a.target_labels = (long long*)d->target_labels;
+    a.target_bboxes = (float4*)d->target_bboxes;
+    a.target_scores = d->target_scores;
+    a.fg_mask = d->fg_mask;
+    const size_t nba = (size_t)d->B * d->A;
+    if (d->G == 0) {   // early-out :48-53
+        hipLaunchKernelGGL(atss_empty_kernel, dim3(1024), dim3(256), 0, s, a);
+        Y6_LAUNCH_CHECK();
+        Y6_HIP(hipMemsetAsync(d->target_scores, 0, nba * d->C * sizeof(float), s));
+        return Y6_OK;
+    }
+    Y6_REQUIRE(d->gt_labels && d->gt_bboxes && d->mask_gt && d->workspace, "atss_assign: null gt / workspace");
+    Y6_REQUIRE(d->workspace_bytes >= y6_atss_workspace_bytes(d->B, d->A, d->G), "atss_assign: workspace too small");
+    Y6_REQUIRE((size_t)d->A * 4 <= 160 * 1024 - 2048, "atss_assign: A=%d does not fit the LDS distance row", d->A);
+    char* ws = (char*)d->workspace;
+    const size_t ba = al256(nba * 4);
+    a.fg_cnt = (int*)ws;
+    a.first_g = (int*)(ws + ba);
+    a.assign = (int*)(ws + 2 * ba);
+    a.norm = (float*)(ws + 3 * ba);
+    Y6_HIP(hipMemsetAsync(a.fg_cnt, 0, nba * 4, s));
+    Y6_HIP(hipMemsetAsync(a.first_g, 0x7f, nba * 4, s));
+    const size_t lds = (size_t)d->A * 4;
+    if (lds > 60 * 1024)
+        Y6_HIP(hipFuncSetAttribute((const void*)atss_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(atss_candidates_kernel, dim3(d->B * d->G), dim3(256), lds, s, a);
+    Y6_LAUNCH_CHECK();
+    const unsigned nb = (unsigned)((nba + 255) / 256);
+    hipLaunchKernelGGL(atss_targets_kernel, dim3(nb), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    size_t g = (nba * d->C + 255) / 256;
+    if (g > 256 * 32) g = 256 * 32;
+    hipLaunchKernelGGL(atss_scores_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
