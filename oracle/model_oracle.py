@@ -319,16 +319,24 @@ class Oracle:
         cls = torch.cat(cls_l, -1).permute(0, 2, 1)
         reg = torch.cat(reg_l, -1).permute(0, 2, 1)
         pts, strd = [], []
+        dev = feats[0].device
         for x, s in zip(feats, a.strides):
             h, w = x.shape[-2:]
-            gy, gx = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
+            gy, gx = torch.meshgrid(torch.arange(h, device=dev) + 0.5, torch.arange(w, device=dev) + 0.5, indexing="ij")
             pts.append(torch.stack([gx, gy], -1).float().reshape(-1, 2))
-            strd.append(torch.full((h * w, 1), float(s)))
+            strd.append(torch.full((h * w, 1), float(s), device=dev))
         pts, strd = torch.cat(pts), torch.cat(strd)
         lt, rb = reg[..., :2], reg[..., 2:]
         x1y1, x2y2 = pts - lt, pts + rb
         box = torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], -1) * strd
-        return torch.cat([box, torch.ones(box.shape[0], box.shape[1], 1), cls], -1)
+        return torch.cat([box, torch.ones(box.shape[0], box.shape[1], 1, device=dev), cls], -1)
+
+    def forward_device(self, x):
+        """Calibration helper (tools/torch_baseline.py): the same graph on whatever device/dtype the
+        state_dict and x live on (no fp32 upcast) - the reference's eager path on a GPU."""
+        self.train_form = False
+        feats = self.neck(self.backbone(x))
+        return self.head(list(feats)), feats
 
     def forward(self, x, train_form=False):
         """Returns (det [B,A,5+nc] fp32, featmaps list).  train_form=True evaluates the un-fused
