@@ -43,6 +43,7 @@ struct ConvKArgs {
     int vec16_ok;  // 16-byte stores legal (cstride/coff % 8 == 0, base 16-byte aligned)
     int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
+    unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -577,6 +578,17 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
         }
     };
 
+    int dbg_n = 0;
+    const bool tracing = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+#define Y6_TRACE(tag)                                                        \
+    do {                                                                     \
+        if (tracing && dbg_n < 256) {                                        \
+            a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                 \
+            a.dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                \
+            ++dbg_n;                                                         \
+        }                                                                    \
+    } while (0)
+    Y6_TRACE(1);
     setup_goff(id);
     setup_pix(id);
     uint4 areg[NP];
@@ -584,6 +596,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     issue_w(id, 0, 0);
     store_A(areg);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    Y6_TRACE(2);
 
     int slot = 0;
     while (true) {
@@ -607,6 +620,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                 load_A(last ? 0 : chunk + 1, areg);
                 issue_w(last ? nid : id, last ? 0 : chunk + 1, slot ^ 1);
             }
+            Y6_TRACE(10);   // prefetch issued
             const char* wb = ldsW + slot * WIMG + lane * 16;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -627,15 +641,23 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                             acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
                 }
             }
+            Y6_TRACE(11);   // 18 k-steps of ds_read + MFMA issued
             if (have_next) {
                 // everyone is done reading this chunk's halo; the next chunk's loads have landed
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Y6_TRACE(12);   // own LDS reads done
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                Y6_TRACE(13);   // own prefetch landed
+                asm volatile("s_barrier" ::: "memory");
+                Y6_TRACE(14);   // block barrier
                 store_A(areg);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                Y6_TRACE(15);   // halo published
                 slot ^= 1;
             }
         }
         conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
+        Y6_TRACE(20);       // epilogue issued
         if (nid >= nids) break;
         id = nid;
         setup_pix(id);
@@ -761,6 +783,10 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
     k.ldsA_bytes = k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
+    k.dbg = nullptr;
+    if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
+        k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
+    }
     L->grid = k.nids;
     if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
