@@ -78,6 +78,54 @@ struct HaloCap {
 //   * v_permlane32_swap pairs groups (g, g+1): afterwards lanes 0-31 own couts 8g..8g+7 and lanes 32-63
 //     own 8(g+1)..8(g+1)+7 of their pixel -> ONE 16-byte store per lane per pair instead of two 8-byte
 //     ones (the scattered 8-byte stores were store-issue bound: profiles/ ablation r04).
+// finish(): acc + bias -> (affine) -> activation -> (+alpha*residual), for the 16 values a lane holds of one
+// fragment.  All mode decisions are wave-uniform and hoisted out of the element loop (the r07 trace
+// showed ~4000 cycles per fragment when `switch(act)` / affine / residual were tested per element).
+template <int ACT>
+__device__ __forceinline__ float act_const(float v) {
+    if constexpr (ACT == Y6_ACT_RELU) return v > 0.f ? v : 0.f;
+    if constexpr (ACT == Y6_ACT_SILU) return v / (1.f + __expf(-v));
+    if constexpr (ACT == Y6_ACT_HARDSWISH) {
+        float r = v + 3.f;
+        r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r);
+        return v * r * (1.f / 6.f);
+    }
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc, const float (&bias)[16], int cfrag,
+                                         int kh, int cend, const __half* rrow, float ralpha, float (&v)[16]) {
+    if (a.pscale == nullptr && rrow == nullptr) {   // the common case: conv + bias + act
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = act_const<ACT>(acc[r] + bias[r]);
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
+        float x = acc[r] + bias[r];
+        if (c < cend) {
+            if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
+            x = act_const<ACT>(x);
+            if (rrow) x += ralpha * __half2float(rrow[c]);
+        } else {
+            x = act_const<ACT>(x);
+        }
+        v[r] = x;
+    }
+}
+
+__device__ __forceinline__ void finish16_any(const ConvKArgs& a, const f32x16_t& acc, const float (&bias)[16], int cfrag,
+                                             int kh, int cend, const __half* rrow, float ralpha, float (&v)[16]) {
+    switch (a.act) {   // one wave-uniform branch per fragment
+        case Y6_ACT_RELU: finish16<Y6_ACT_RELU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
+        case Y6_ACT_SILU: finish16<Y6_ACT_SILU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
+        case Y6_ACT_HARDSWISH: finish16<Y6_ACT_HARDSWISH>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
+        default: finish16<Y6_ACT_NONE>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
+    }
+}
+
 template <int CF>
 struct BiasRegs {
     float v[CF][16];
@@ -122,15 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t
             const int cfrag = (cb * CF + cf) * 32 - upc0;   // first output channel of this fragment
             // 1) finish the 16 values of this lane
             float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
-                float x = acc[cf][pf][r] + bz.v[cf][r];
-                if (a.pscale && c < cend) x = x * a.pscale[c] + a.pshift[c];
-                x = y6_act(x, a.act);
-                if (rrow && pvalid && c < cend) x += ralpha * __half2float(rrow[c]);
-                v[r] = x;
-            }
+            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
             // 2) pack to fp16 pairs: group g -> dwords pk[g][0..1]
             unsigned pk[4][2];
 #pragma unroll
@@ -204,20 +244,14 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvKArgs& a, const f32x
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf) {
             const int cfrag = cblock + cf * 32;
+            float v[16];
+            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
                 h4v o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = g * 4 + j;
-                    const int c = cfrag + 8 * g + 4 * kh + j;
-                    float x = acc[cf][pf][r] + bz.v[cf][r];
-                    if (a.pscale && c < cend) x = x * a.pscale[c] + a.pshift[c];
-                    x = y6_act(x, a.act);
-                    if (rrow && pvalid && c < cend) x += ralpha * __half2float(rrow[c]);
-                    o[j] = (_Float16)x;
-                }
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[g * 4 + j];
                 *reinterpret_cast<h4v*>(tile + row * RS + cf * 64 + g * 16 + kh * 8) = o;
             }
         }
@@ -441,32 +475,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent, chunk-granular variant (3x3 only).  Lessons from the r03 counters (profiles/):
-// per-tap barriers + in-order vmcnt waits parked the waves 50 % of the time and forced the halo
-// register prefetch to complete at the first tap.  Here
+// Persistent, chunk-granular variant (3x3 only).  What the r03-r08 counters and the s_memtime trace
+// (profiles/r01/conv_trace_r08.txt) showed for the per-tap kernel above and the first persistent cuts:
+//   * per-tap barriers + in-order vmcnt waits parked the waves ~50 % of the time;
+//   * every 1 KiB LDS-DMA piece costs 100-185 cycles of ISSUE time in the wave that issues it
+//     (nine pieces + the halo loads = ~2500 cycles per chunk against 2304 cycles of MFMA);
+//   * a per-element `switch(act)` epilogue cost ~4000 cycles per fragment.
+// Here
 //   * a block walks a strided list of (tile, cout-block) items;
-//   * the unit of staging is a 32-channel CHUNK: its halo (LDS, via registers) and ALL NINE tap
-//     weight images (LDS-DMA, double-buffered per chunk) are requested one whole chunk ahead -
-//     across item boundaries too - so loads get 9 taps x 2 k-steps of MFMA time to land;
-//   * inside a chunk there is NO barrier: 18 k-steps of ds_read + MFMA the compiler can pipeline;
-//   * one `vmcnt(0) + barrier` per chunk (everyone done reading, everything for the next chunk
-//     landed), then the halo registers go to LDS and a second barrier publishes them.
+//   * the unit of staging is a 32-channel CHUNK: its halo AND all nine tap weight images are fetched
+//     with plain 16-byte global loads into registers one whole chunk ahead (across item boundaries
+//     too) - hipcc tracks them, no manual vmcnt - and written to LDS at the chunk boundary;
+//     the weight image of (cout fragment, chunk) is 18 KiB CONTIGUOUS in the packed weights, so the
+//     staging is a straight copy into the LDS layout [cf][tap][ks][lane][16 B];
+//   * inside a chunk there is NO barrier: 18 k-steps of ds_read + MFMA the compiler pipelines;
+//   * two barriers per chunk: "everyone done reading" -> LDS writes -> "published".
 template <int CF, int PF, int ST>
 __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 3, NT = 9;
-    constexpr int NPIECE = NT * CF * 2;          // 1 KiB DMA pieces per chunk image [tap][cf][ks]
-    constexpr int WIMG = NPIECE * 1024;
+    constexpr int WQ = CF * NT * 2 * 64;         // 16-byte units of one chunk's weight image (CF x 18 KiB)
+    constexpr int NWR = (WQ + 255) / 256;        // ... per thread
     constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
     constexpr int NP = (MAXHP * 4 + 255) / 256;
-    constexpr int NWJ = (NPIECE + 3) / 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* ldsA = smem;
     char* ldsW = smem + a.ldsA_bytes;
-    const unsigned ldsW_addr = lds_addr(ldsW);
     const int nids = a.nids;
     const int gstride = gridDim.x;
 
@@ -560,24 +597,31 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             if (idx < npieces) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = regs[i];
         }
     };
-    // all nine tap images of (item, chunk) -> ring slot; pieces are contiguous in the packed weights:
-    // [cfrag][chunk][tap][ks][512 halves], i.e. one cfrag's chunk is 9*2 consecutive KiB
-    auto issue_w = [&](int item, int chunk, int wslot) {
+    // weights of (item, chunk): CF contiguous 18 KiB blocks -> registers (16 B per thread per step)
+    auto load_W = [&](int item, int chunk, uint4 (&regs)[NWR]) {
         int wt, wcb;
         decode(item, wt, wcb);
 #pragma unroll
-        for (int j = 0; j < NWJ; ++j) {
-            const int p = wave + 4 * j;              // p = (tap*CF + cf)*2 + ks
-            if (p < NPIECE) {
-                const int t = p / (CF * 2), q = p - t * (CF * 2);
-                const int cf = q >> 1, ks = q & 1;
+        for (int j = 0; j < NWR; ++j) {
+            const int q = tid + j * 256;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (q < WQ) {
+                const int cf = q / (NT * 2 * 64), r = q - cf * (NT * 2 * 64);
                 const size_t cfg = (size_t)wcb * CF + cf;
-                const __half* src = a.wpk + (((cfg * a.nchunk + chunk) * NT + t) * 2 + ks) * 512 + lane * 8;
-                lds_dma16(src, __builtin_amdgcn_readfirstlane(ldsW_addr + wslot * WIMG + p * 1024));
+                v = *reinterpret_cast<const uint4*>(a.wpk + ((cfg * a.nchunk + chunk) * (NT * 2 * 64) + r) * 8);
             }
+            regs[j] = v;
+        }
+    };
+    auto store_W = [&](const uint4 (&regs)[NWR]) {
+#pragma unroll
+        for (int j = 0; j < NWR; ++j) {
+            const int q = tid + j * 256;
+            if (q < WQ) *reinterpret_cast<uint4*>(ldsW + q * 16) = regs[j];
         }
     };
 
+    // optional s_memtime trace of block 0 / thread 0 (tools/conv_trace.py, env Y6_CONV_TRACE)
     int dbg_n = 0;
     const bool tracing = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
 #define Y6_TRACE(tag)                                                        \
@@ -592,13 +636,14 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     setup_goff(id);
     setup_pix(id);
     uint4 areg[NP];
+    uint4 wreg[NWR];
     load_A(0, areg);
-    issue_w(id, 0, 0);
+    load_W(id, 0, wreg);
     store_A(areg);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    store_W(wreg);
+    __syncthreads();
     Y6_TRACE(2);
 
-    int slot = 0;
     while (true) {
         f32x16_t acc[CF][PF];
 #pragma unroll
@@ -614,14 +659,12 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             const bool last = (chunk + 1) == a.nchunk;
             const bool have_next = !last || nid < nids;
             if (have_next) {  // request everything the NEXT chunk needs, a whole chunk of MFMAs ahead
-                // halo loads FIRST: hipcc guards the re-use of `areg` with a vmcnt(0) that must not
-                // find the (compiler-invisible) weight DMAs already in flight
                 if (last) setup_goff(nid);           // the current item's table is dead from here
                 load_A(last ? 0 : chunk + 1, areg);
-                issue_w(last ? nid : id, last ? 0 : chunk + 1, slot ^ 1);
+                load_W(last ? nid : id, last ? 0 : chunk + 1, wreg);
             }
             Y6_TRACE(10);   // prefetch issued
-            const char* wb = ldsW + slot * WIMG + lane * 16;
+            const char* wb = ldsW + lane * 16;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tapoff = ((t / KS) * a.HWd + (t % KS)) * PIXB;
@@ -630,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                     h8_t af[CF], bf[PF];
 #pragma unroll
                     for (int cf = 0; cf < CF; ++cf)
-                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((t * CF + cf) * 2 + ks) * 1024);
+                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((cf * NT + t) * 2 + ks) * 1024);
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf)
                         bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
@@ -643,17 +686,12 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             }
             Y6_TRACE(11);   // 18 k-steps of ds_read + MFMA issued
             if (have_next) {
-                // everyone is done reading this chunk's halo; the next chunk's loads have landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                Y6_TRACE(12);   // own LDS reads done
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                Y6_TRACE(13);   // own prefetch landed
-                asm volatile("s_barrier" ::: "memory");
-                Y6_TRACE(14);   // block barrier
+                __syncthreads();   // everyone is done reading this chunk's halo and weights
+                Y6_TRACE(14);
                 store_A(areg);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                Y6_TRACE(15);   // halo published
-                slot ^= 1;
+                store_W(wreg);
+                __syncthreads();   // next chunk published
+                Y6_TRACE(15);
             }
         }
         conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
@@ -673,7 +711,7 @@ struct VariantCfg {
 const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
-    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}};
+    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}, {4, 1, 1, "pers_c4p1"}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -789,7 +827,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     }
     L->grid = k.nids;
     if (vc.persist)
-        L->lds = (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 2 * 1024;  // two chunks of nine tap images
+        L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024;      // one chunk of nine tap images (regs hold the next)
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
     if (k.epi_lds) {
@@ -921,6 +959,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
         case 9: return launch_persist_cfg<1, 2>(L, d->stride, s);
         case 10: return launch_persist_cfg<2, 2>(L, d->stride, s);
+        case 11: return launch_persist_cfg<4, 1>(L, d->stride, s);
     }
     return Y6_EINVAL;
 }
