@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 //   * inside a chunk there is NO barrier: 18 k-steps of ds_read + MFMA the compiler pipelines;
 //   * two barriers per chunk: "everyone done reading" -> LDS writes -> "published".
 template <int CF, int PF, int ST>
-__global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvKArgs a) {   // 2 waves/SIMD: <= 256 VGPR+AGPR
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 3, NT = 9;
     constexpr int WQ = CF * NT * 2 * 64;         // 16-byte units of one chunk's weight image (CF x 18 KiB)
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
     __syncthreads();
     Y6_TRACE(2);
 
+    int item_parity = 0;
     while (true) {
         f32x16_t acc[CF][PF];
 #pragma unroll
@@ -652,8 +653,13 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
             for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
-        BiasRegs<CF> bz;
-        load_bias<CF>(a, cb, 0, lane, bz);   // in flight during the whole chunk loop
+        // bias of this item's couts -> LDS (double-buffered by item parity); holding 16*CF floats in
+        // registers across the chunk loop tipped the kernel into spilling
+        float* lbias = reinterpret_cast<float*>(ldsW + WQ * 16) + (item_parity ? CF * 32 : 0);
+        if (tid < CF * 32) {
+            const int c = cb * CF * 32 + tid;
+            lbias[tid] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
+        }
         const int nid = next_valid(id);
         for (int chunk = 0; chunk < a.nchunk; ++chunk) {
             const bool last = (chunk + 1) == a.nchunk;
@@ -664,25 +670,38 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                 load_W(last ? nid : id, last ? 0 : chunk + 1, wreg);
             }
             Y6_TRACE(10);   // prefetch issued
+            // Two-stage software pipeline over the nine taps: the fragments of tap t+1 are requested from
+            // LDS BEFORE tap t's MFMAs are issued, so the reads complete in the shadow of the matrix pipe.
+            // sched_barrier(0) keeps hipcc from hoisting further ahead (it otherwise pre-loads the whole
+            // chunk and spills: 377 registers without).
             const char* wb = ldsW + lane * 16;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            h8_t fa[2][2][CF], fb[2][2][PF];
+            auto ldfrag = [&](int t, int buf) {
                 const int tapoff = ((t / KS) * a.HWd + (t % KS)) * PIXB;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    h8_t af[CF], bf[PF];
 #pragma unroll
                     for (int cf = 0; cf < CF; ++cf)
-                        af[cf] = *reinterpret_cast<const h8_t*>(wb + ((cf * NT + t) * 2 + ks) * 1024);
+                        fa[buf][ks][cf] = *reinterpret_cast<const h8_t*>(wb + ((cf * NT + t) * 2 + ks) * 1024);
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf)
-                        bf[pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+                        fb[buf][ks][pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+                }
+            };
+            ldfrag(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                         for (int pf = 0; pf < PF; ++pf)
-                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
-                }
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t & 1][ks][cf], fb[t & 1][ks][pf],
+                                                                                 acc[cf][pf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             Y6_TRACE(11);   // 18 k-steps of ds_read + MFMA issued
             if (have_next) {
@@ -694,10 +713,23 @@ __global__ __launch_bounds__(256) void conv_mfma_persist_kernel(const ConvKArgs 
                 Y6_TRACE(15);
             }
         }
+        if (a.nchunk == 1 && nid >= nids) __syncthreads();   // no chunk barrier has published lbias yet
+        BiasRegs<CF> bz;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
+                bz.v[cf][g * 4 + 0] = t.x;
+                bz.v[cf][g * 4 + 1] = t.y;
+                bz.v[cf][g * 4 + 2] = t.z;
+                bz.v[cf][g * 4 + 3] = t.w;
+            }
         conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
         Y6_TRACE(20);       // epilogue issued
         if (nid >= nids) break;
         id = nid;
+        item_parity ^= 1;
         setup_pix(id);
     }
 }
@@ -707,11 +739,11 @@ struct VariantCfg {
     const char* name;
 };
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
-// 7-10 persistent chunk-granular (a 4-fragment cout block would need 144 KiB of weight images)
+// 7-9 persistent chunk-granular
 const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
-    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}, {2, 2, 1, "pers_c2p2"}, {4, 1, 1, "pers_c4p1"}};
+    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}};   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -827,7 +859,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     }
     L->grid = k.nids;
     if (vc.persist)
-        L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024;      // one chunk of nine tap images (regs hold the next)
+        L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
     if (k.epi_lds) {
@@ -923,6 +955,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
     if (st == 2 && vc.pf != 1) return 0;
     if (vc.persist && ks != 3) return 0;
+    if (vc.persist && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
     if (d->w_packed == nullptr) return 0;
     // 16-byte halo pieces need 8-channel alignment of the input view
     if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -958,8 +991,6 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 7: return launch_persist_cfg<1, 1>(L, d->stride, s);
         case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
         case 9: return launch_persist_cfg<1, 2>(L, d->stride, s);
-        case 10: return launch_persist_cfg<2, 2>(L, d->stride, s);
-        case 11: return launch_persist_cfg<4, 1>(L, d->stride, s);
     }
     return Y6_EINVAL;
 }
