@@ -772,7 +772,10 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
         // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
         // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is ~2-way
-        const double rowfit = 1.0;  // (TW % 32 == 0 ? 1.0 : 0.94) measured slower on r04: halo overhead outweighs the conflicts
+        // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
+        // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is 2-way.
+        static const int tw32 = getenv("Y6_CONV_TW32") ? atoi(getenv("Y6_CONV_TW32")) : 0;
+        const double rowfit = (tw32 == 0 || TW % 32 == 0) ? 1.0 : 0.90;
         const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
