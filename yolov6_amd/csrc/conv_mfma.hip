@@ -734,16 +734,267 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvKAr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3: pipelined persistent kernel (3x3 stride 1).  tools/mfma_ceiling.hip shows what LDS-fed MFMA loops
+// sustain on this box (1.4-1.9 PFLOP/s); the s_memtime traces of the kernels above show where they lose
+// it: the fill of the next chunk (global loads issued back-to-back saturate the 64 B/clk TA path and
+// block the wave at issue; the publish sits between two barriers).  Here
+//   * a chunk is 16 input channels (one MFMA k-step per tap) so that two LDS buffers of halo + weights
+//     fit twice per CU (two blocks -> two waves per SIMD);
+//   * the next chunk's global loads are issued one or two per tap during taps 0-3, its LDS publishes
+//     during taps 5-8 into the OTHER buffer, and a single barrier per chunk closes it;
+//   * work items (tile, cout block) are walked persistently, so the fill of the next item's first chunk
+//     overlaps the last chunk of the current one, and the epilogue overlaps the co-resident block.
+// Pixel pitch is 48 bytes (32 data + 16 pad): an odd number of 16-byte slots keeps a 32-pixel fragment
+// read conflict-free, as with the 80-byte pitch above.
+// ---------------------------------------------------------------------------------------------
+constexpr int PIXP = 48;
+
+template <int CF, int PF, int WPS>
+__global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 9;
+    constexpr int WQ = CF * NT * 64;             // 16-byte units of one 16-channel weight image (CF x 9 KiB)
+    constexpr int NWR = (WQ + 255) / 256;
+    constexpr int MAXHP = HaloCap<3, 1, PF>::value;
+    constexpr int NP = (MAXHP * 2 + 255) / 256;  // two 16-byte pieces per halo pixel
+    constexpr int NL = NP + NWR;                 // staged 16-byte pieces per thread per chunk
+    constexpr int LPT = (NL + 3) / 4;            // issued per tap in taps 0-3, published per tap in taps 5-8
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* ldsA = smem;                            // 2 x ldsA_bytes
+    char* ldsW = smem + 2 * a.ldsA_bytes;         // 2 x WQ*16
+    float* ldsBias = reinterpret_cast<float*>(ldsW + 2 * WQ * 16);
+    const int nids = a.nids;
+    const int gstride = gridDim.x;
+    const int nch = (a.Cin + 15) >> 4;
+
+    auto decode = [&](int id, int& tile, int& cb) {
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    };
+    auto next_valid = [&](int id) {
+        for (id += gstride; id < nids; id += gstride) {
+            int t, c;
+            decode(id, t, c);
+            if (t < a.ntiles) break;
+        }
+        return id;
+    };
+    int id = blockIdx.x;
+    {
+        int t, c;
+        decode(id, t, c);
+        if (t >= a.ntiles) id = next_valid(id);
+    }
+    if (id >= nids) return;
+
+    const int npieces = a.HH * a.HWd * 2;
+    int goff[NP];
+    auto setup_goff = [&](int item) {
+        int tile, cbx;
+        decode(item, tile, cbx);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int iy0 = ty_i * a.TH - 1, ix0 = tx_i * a.TW - 1;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            int g = -1;
+            if (idx < npieces) {
+                const int hp = idx >> 1, q = idx & 1;
+                const int hy = hp / a.HWd, hx = hp - hy * a.HWd;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const bool v = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+                g = v ? (((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + q * 8) : -1;
+            }
+            goff[i] = g;
+        }
+    };
+    // per-thread constant part of the packed-weight address of staged piece j:
+    // [cout/32][cin/32][tap][kstep=2][lane][8]  ->  cf, tap, lane of this thread's piece
+    int woff[NWR];
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+        const int q = tid + j * 256;
+        const int cf = q / (NT * 64), r = q - cf * (NT * 64);
+        woff[j] = (q < WQ) ? (cf * a.nchunk * NT * 2 * 64 + (r >> 6) * 2 * 64 + (r & 63)) * 8 : -1;
+    }
+    int pixoff[PF], opix[PF], cb = 0;
+    auto setup_pix = [&](int item) {
+        int tile;
+        decode(item, tile, cb);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+            const int npx = a.TH * a.TW;
+            bool v = m < npx;
+            const int mm = v ? m : npx - 1;
+            const int ty = mm / a.TW, tx = mm - ty * a.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            v = v && (oy < a.Ho) && (ox < a.Wo);
+            pixoff[pf] = (ty * a.HWd + tx) * PIXP + (lane >> 5) * 16;
+            opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
+        }
+    };
+
+    uint4 stg[NL];
+    // uniform parts of the next chunk's addresses
+    int nx_cin0 = 0;        // first input channel of the chunk being staged
+    size_t nx_wbase = 0;    // element offset of its weight image for cf = 0
+    auto set_next = [&](int item, int chunk) {
+        int t, wcb;
+        decode(item, t, wcb);
+        nx_cin0 = chunk * 16;
+        nx_wbase = (((size_t)wcb * CF * a.nchunk + (chunk >> 1)) * NT * 2 + (chunk & 1)) * 64 * 8;
+    };
+    auto load_piece = [&](int k) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k < NP) {
+            const int q = (tid + k * 256) & 1;
+            if (goff[k] >= 0 && (nx_cin0 + q * 8) < a.Cin)
+                v = *reinterpret_cast<const uint4*>(a.in + goff[k] + nx_cin0);
+        } else {
+            const int j = k - NP;
+            if (woff[j] >= 0) v = *reinterpret_cast<const uint4*>(a.wpk + nx_wbase + woff[j]);
+        }
+        stg[k] = v;
+    };
+    auto store_piece = [&](int k, int buf) {
+        if (k < NP) {
+            const int idx = tid + k * 256;
+            if (idx < npieces)
+                *reinterpret_cast<uint4*>(ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16) = stg[k];
+        } else {
+            const int q = tid + (k - NP) * 256;
+            if (q < WQ) *reinterpret_cast<uint4*>(ldsW + (buf * WQ + q) * 16) = stg[k];
+        }
+    };
+
+    int dbg_n = 0;
+    const bool tracing = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+    Y6_TRACE(1);
+    setup_goff(id);
+    setup_pix(id);
+    set_next(id, 0);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load_piece(k);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) store_piece(k, 0);
+    __syncthreads();
+    Y6_TRACE(2);
+
+    int pb = 0, item_parity = 0;
+    while (true) {
+        f32x16_t acc[CF][PF];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+        float* lbias = ldsBias + (item_parity ? CF * 32 : 0);
+        if (tid < CF * 32) {
+            const int c = cb * CF * 32 + tid;
+            lbias[tid] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
+        }
+        const int nid = next_valid(id);
+        bool synced = false;
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            const bool last = (chunk + 1) == nch;
+            const bool have_next = !last || nid < nids;
+            if (have_next) {
+                if (last) setup_goff(nid);   // the current item's table is dead: its last chunk is already in LDS
+                set_next(last ? nid : id, last ? 0 : chunk + 1);
+            }
+            Y6_TRACE(10);
+            const char* Ab = ldsA + pb * a.ldsA_bytes;
+            const char* Wb = ldsW + pb * (WQ * 16) + lane * 16;
+            h8_t fa[2][CF], fb[2][PF];
+            auto ldfrag = [&](int t, int buf) {
+                const int tapoff = ((t / 3) * a.HWd + (t % 3)) * PIXP;
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const h8_t*>(Wb + (cf * NT + t) * 1024);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const h8_t*>(Ab + pixoff[pf] + tapoff);
+            };
+            ldfrag(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (have_next && t < 4) {
+#pragma unroll
+                    for (int u = 0; u < LPT; ++u)
+                        if (t * LPT + u < NL) load_piece(t * LPT + u);
+                }
+                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf)
+                        acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t & 1][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
+                if (have_next && t >= 5) {
+#pragma unroll
+                    for (int u = 0; u < LPT; ++u)
+                        if ((t - 5) * LPT + u < NL) store_piece((t - 5) * LPT + u, pb ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            Y6_TRACE(11);
+            if (have_next) {
+                __syncthreads();   // next chunk published; everyone is done with this one
+                synced = true;
+                pb ^= 1;
+            }
+            Y6_TRACE(15);
+        }
+        if (!synced) __syncthreads();   // no chunk barrier has published lbias yet
+        BiasRegs<CF> bz;
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
+                bz.v[cf][g * 4 + 0] = t.x;
+                bz.v[cf][g * 4 + 1] = t.y;
+                bz.v[cf][g * 4 + 2] = t.z;
+                bz.v[cf][g * 4 + 3] = t.w;
+            }
+        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
+        Y6_TRACE(20);
+        if (nid >= nids) break;
+        id = nid;
+        item_parity ^= 1;
+        setup_pix(id);
+    }
+}
+
 struct VariantCfg {
     int cf, pf, persist;
     const char* name;
 };
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
-// 7-9 persistent chunk-granular
+// 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
 const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
-    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"}};   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
+    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
+    {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -854,14 +1105,16 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.HWd = (k.TW - 1) * st + ks;
     k.nchunk = y6_cdiv(k.Cin, 32);
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
-    k.ldsA_bytes = k.HH * k.HWd * PIXB;
+    k.ldsA_bytes = vc.persist == 2 ? ((k.HH * k.HWd * PIXP + 127) & ~127) : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
     L->grid = k.nids;
-    if (vc.persist)
+    if (vc.persist == 2)
+        L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4;   // two buffers of halo + nine 16-channel tap images, bias x2
+    else if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
@@ -920,6 +1173,37 @@ int launch_persist(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
+template <int CF, int PF, int WPS>
+int launch_pipe(const Launch& L, hipStream_t s) {
+    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS>;
+    static bool big_lds_enabled = false;
+    if (L.lds > 64 * 1024 && !big_lds_enabled) {
+        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big_lds_enabled = true;
+    }
+    Y6_REQUIRE(L.lds <= 160 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
+    static size_t cached_lds = 0;
+    static int cached_bpc = 0, n_cu = 0;
+    if (cached_lds != L.lds) {
+        int bpc = 0;
+        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 256, L.lds));
+        if (n_cu == 0) {
+            int dev = 0;
+            Y6_HIP(hipGetDevice(&dev));
+            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        cached_bpc = bpc < 1 ? 1 : bpc;
+        cached_lds = L.lds;
+    }
+    int grid = n_cu * cached_bpc;
+    grid -= grid % 8;
+    if (grid < 8) grid = 8;
+    if (grid > L.grid) grid = L.grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 template <int CF, int PF>
 int launch_persist_cfg(const Launch& L, int st, hipStream_t s) {
     if (st == 1) return launch_persist<CF, PF, 1>(L, s);
@@ -958,7 +1242,8 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
     if (st == 2 && vc.pf != 1) return 0;
     if (vc.persist && ks != 3) return 0;
-    if (vc.persist && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
+    if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
+    if (vc.persist == 2 && st != 1) return 0;
     if (d->w_packed == nullptr) return 0;
     // 16-byte halo pieces need 8-channel alignment of the input view
     if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -994,6 +1279,11 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 7: return launch_persist_cfg<1, 1>(L, d->stride, s);
         case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
         case 9: return launch_persist_cfg<1, 2>(L, d->stride, s);
+        case 10: return launch_pipe<2, 2, 2>(L, s);
+        case 11: return launch_pipe<2, 1, 2>(L, s);
+        case 12: return launch_pipe<1, 2, 2>(L, s);
+        case 13: return launch_pipe<4, 2, 1>(L, s);
+        case 14: return launch_pipe<4, 1, 1>(L, s);
     }
     return Y6_EINVAL;
 }
