@@ -759,14 +759,15 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     constexpr int MAXHP = HaloCap<3, 1, PF>::value;
     constexpr int NP = (MAXHP * 2 + 255) / 256;  // two 16-byte pieces per halo pixel
     constexpr int NL = NP + NWR;                 // staged 16-byte pieces per thread per chunk
-    constexpr int LPT = (NL + 3) / 4;            // issued per tap in taps 0-3, published per tap in taps 5-8
+    constexpr int LPT = (NL + 3) / 4;            // pieces published + re-requested per tap in taps 0-3
+    constexpr int WQP = NWR * 256;               // weight buffer padded so that the publish needs no predicate
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* ldsA = smem;                            // 2 x ldsA_bytes
-    char* ldsW = smem + 2 * a.ldsA_bytes;         // 2 x WQ*16
-    float* ldsBias = reinterpret_cast<float*>(ldsW + 2 * WQ * 16);
+    char* ldsW = smem + 2 * a.ldsA_bytes;         // 2 x WQP*16
+    float* ldsBias = reinterpret_cast<float*>(ldsW + 2 * WQP * 16);
     const int nids = a.nids;
     const int gstride = gridDim.x;
     const int nch = (a.Cin + 15) >> 4;
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     for (int j = 0; j < NWR; ++j) {
         const int q = tid + j * 256;
         const int cf = q / (NT * 64), r = q - cf * (NT * 64);
-        woff[j] = (q < WQ) ? (cf * a.nchunk * NT * 2 * 64 + (r >> 6) * 2 * 64 + (r & 63)) * 8 : -1;
+        woff[j] = (q < WQ) ? (cf * a.nchunk * NT * 2 * 64 + (r >> 6) * 2 * 64 + (r & 63)) * 8 : 0;   // pad threads re-read piece 0
     }
     int pixoff[PF], opix[PF], cb = 0;
     auto setup_pix = [&](int item) {
@@ -854,48 +855,79 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     };
 
     uint4 stg[NL];
-    // uniform parts of the next chunk's addresses
-    int nx_cin0 = 0;        // first input channel of the chunk being staged
+    // Staging cursor: the (item, chunk) whose data is being requested from global memory.  It runs TWO
+    // chunks ahead of the chunk being multiplied: a piece is requested during chunk c, published to the
+    // free LDS buffer during chunk c+1 (a whole chunk of MFMAs later, so the publish never waits on the
+    // load), and consumed in chunk c+2.
+    int s_item = id, s_chunk = 0, s_wcb = 0;
+    int nx_cin0 = 0;        // first input channel of the staged chunk
     size_t nx_wbase = 0;    // element offset of its weight image for cf = 0
-    auto set_next = [&](int item, int chunk) {
-        int t, wcb;
-        decode(item, t, wcb);
-        nx_cin0 = chunk * 16;
-        nx_wbase = (((size_t)wcb * CF * a.nchunk + (chunk >> 1)) * NT * 2 + (chunk & 1)) * 64 * 8;
+    auto stage_addr = [&]() {
+        nx_cin0 = s_chunk * 16;
+        nx_wbase = (((size_t)s_wcb * CF * a.nchunk + (s_chunk >> 1)) * NT * 2 + (s_chunk & 1)) * 64 * 8;
     };
+    auto stage_advance = [&]() {
+        if (s_item >= nids) return;   // end of this block's stream: keep re-requesting the last (valid) chunk
+        if (s_chunk + 1 < nch) {
+            ++s_chunk;
+        } else {
+            const int n = next_valid(s_item);
+            if (n >= nids) {
+                s_item = n;
+                return;
+            }
+            s_item = n;
+            s_chunk = 0;
+            int t;
+            decode(s_item, t, s_wcb);
+            setup_goff(s_item);   // the previous item's table is dead: all its chunks have been requested
+        }
+        stage_addr();
+    };
+    // Every staged load and publish is UNPREDICATED: out-of-image / out-of-channel halo pieces read the tensor
+    // base and are zeroed at publish time through a per-thread flag word, pad threads re-read weight piece 0
+    // into the buffers' pad area.  With exec-masked branches around them hipcc's waitcnt insertion falls
+    // back to vmcnt(0) before every ds_write, i.e. the full load latency four times per chunk.
+    unsigned stg_ok = 0;
     auto load_piece = [&](int k) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (k < NP) {
             const int q = (tid + k * 256) & 1;
-            if (goff[k] >= 0 && (nx_cin0 + q * 8) < a.Cin)
-                v = *reinterpret_cast<const uint4*>(a.in + goff[k] + nx_cin0);
+            const bool ok = goff[k] >= 0 && (nx_cin0 + q * 8) < a.Cin;
+            stg[k] = *reinterpret_cast<const uint4*>(a.in + (ok ? goff[k] + nx_cin0 : 0));
+            stg_ok = ok ? (stg_ok | (1u << k)) : (stg_ok & ~(1u << k));
         } else {
-            const int j = k - NP;
-            if (woff[j] >= 0) v = *reinterpret_cast<const uint4*>(a.wpk + nx_wbase + woff[j]);
+            stg[k] = *reinterpret_cast<const uint4*>(a.wpk + nx_wbase + woff[k - NP]);
         }
-        stg[k] = v;
     };
     auto store_piece = [&](int k, int buf) {
         if (k < NP) {
             const int idx = tid + k * 256;
-            if (idx < npieces)
-                *reinterpret_cast<uint4*>(ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16) = stg[k];
+            uint4 v = stg[k];
+            if (!((stg_ok >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16) = v;
         } else {
             const int q = tid + (k - NP) * 256;
-            if (q < WQ) *reinterpret_cast<uint4*>(ldsW + (buf * WQ + q) * 16) = stg[k];
+            *reinterpret_cast<uint4*>(ldsW + (buf * WQP + q) * 16) = stg[k];
         }
     };
 
     int dbg_n = 0;
     const bool tracing = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
     Y6_TRACE(1);
+    {
+        int t;
+        decode(id, t, s_wcb);
+    }
     setup_goff(id);
     setup_pix(id);
-    set_next(id, 0);
+    stage_addr();
 #pragma unroll
     for (int k = 0; k < NL; ++k) load_piece(k);
 #pragma unroll
     for (int k = 0; k < NL; ++k) store_piece(k, 0);
+    stage_advance();          // second chunk of the stream stays in registers until the first chunk's taps
+#pragma unroll
+    for (int k = 0; k < NL; ++k) load_piece(k);
     __syncthreads();
     Y6_TRACE(2);
 
@@ -917,14 +949,11 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
         bool synced = false;
         for (int chunk = 0; chunk < nch; ++chunk) {
             const bool last = (chunk + 1) == nch;
-            const bool have_next = !last || nid < nids;
-            if (have_next) {
-                if (last) setup_goff(nid);   // the current item's table is dead: its last chunk is already in LDS
-                set_next(last ? nid : id, last ? 0 : chunk + 1);
-            }
+            const bool have_next = !last || nid < nids;   // registers hold the chunk after this one
+            if (have_next) stage_advance();               // ... and the one after that gets requested now
             Y6_TRACE(10);
             const char* Ab = ldsA + pb * a.ldsA_bytes;
-            const char* Wb = ldsW + pb * (WQ * 16) + lane * 16;
+            const char* Wb = ldsW + pb * (WQP * 16) + lane * 16;
             h8_t fa[2][CF], fb[2][PF];
             auto ldfrag = [&](int t, int buf) {
                 const int tapoff = ((t / 3) * a.HWd + (t % 3)) * PIXP;
@@ -937,22 +966,22 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (have_next && t < 4) {
+                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
+                if (t < 4) {   // publish what was requested a chunk ago, then reuse the registers (no branches:
+                               // past the end of the stream this republishes / re-requests the last chunk)
+#pragma unroll
+                    for (int u = 0; u < LPT; ++u)
+                        if (t * LPT + u < NL) store_piece(t * LPT + u, pb ^ 1);
 #pragma unroll
                     for (int u = 0; u < LPT; ++u)
                         if (t * LPT + u < NL) load_piece(t * LPT + u);
                 }
-                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf)
                         acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t & 1][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
-                if (have_next && t >= 5) {
-#pragma unroll
-                    for (int u = 0; u < LPT; ++u)
-                        if ((t - 5) * LPT + u < NL) store_piece((t - 5) * LPT + u, pb ^ 1);
-                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             Y6_TRACE(11);
@@ -1105,7 +1134,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.HWd = (k.TW - 1) * st + ks;
     k.nchunk = y6_cdiv(k.Cin, 32);
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
-    k.ldsA_bytes = vc.persist == 2 ? ((k.HH * k.HWd * PIXP + 127) & ~127) : k.HH * k.HWd * PIXB;
+    // pipe kernels publish unpredicated: the halo buffer covers every staging thread's slot
+    k.ldsA_bytes = vc.persist == 2 ? ((halo_cap(3, 1, vc.pf) * 2 + 255) / 256) * 128 * PIXP : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
@@ -1113,7 +1143,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     }
     L->grid = k.nids;
     if (vc.persist == 2)
-        L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4;   // two buffers of halo + nine 16-channel tap images, bias x2
+        L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)((9 * vc.cf * 64 + 255) / 256) * 4096 + 2 * vc.cf * 32 * 4;   // two buffers of halo + nine 16-channel tap images (padded), bias x2
     else if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
     else
