@@ -81,6 +81,11 @@ def calibrate_head_bias(model, x, target_frac=0.02):
     return shift
 
 
+def variant_name(v):
+    from yolov6_amd import _lib
+    return _lib.load().y6_conv_variant_name(int(v)).decode() if v is not None and int(v) >= 0 else "-"
+
+
 def classify(row):
     if row["kind"] == "conv":
         return f"conv{row['ksize']}x{row['ksize']}s{row['stride']}"
@@ -161,6 +166,11 @@ def main():
         by_class["nms"] = dict(ms=nms_ms, flops=0.0, bytes=float(args.batch * 8400 * 85 * 4), launches=2)
         dom = by_class.get("conv3x3s1", dict(ms=0.0, flops=0.0, launches=0))
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        dom_variants = {}
+        for r in rows:
+            if classify(r) == "conv3x3s1":
+                n = variant_name(r["variant"])
+                dom_variants[n] = dom_variants.get(n, 0) + 1
         total_flops = sum(r["flops"] for r in rows)
         fwd_ms = sum(r["ms"] for r in rows)
         ms_per_step = elapsed / args.steps * 1e3
@@ -176,7 +186,8 @@ def main():
                                    "forward (deploy form) + NMS conf 0.03 / IoU 0.65 / multi-label / max_det 300",
                        "global_batch": world * args.batch, "parallelism": f"replicas x{world} (no collective)",
                        "weights": "random (oracle/synth.py), cls bias calibrated to ~2% candidates"},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<*,*,3,1> (3x3 stride-1 conv+bias+act)",
+            "roofline": {"bound": "mfma", "kernel": "3x3 stride-1 conv+bias+act (conv_mfma.hip); variants chosen per layer: "
+                                                    + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items())),
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "launches_per_step": dom["launches"], "gflop_per_step": round(dom["flops"] / 1e9, 2),

@@ -26,13 +26,14 @@ if has tests; then
   echo "pytest rc=$?" | tee -a "$OUT/pytest_gpu.log"; tail -40 "$OUT/pytest_gpu.log"
 fi
 if has bench; then
-  echo "== bench"; rm -f "$OUT/autotune.log"
-  Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 1200 python bench.py --steps 20 --warmup 3 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+  echo "== bench"; rm -f "$OUT/autotune.log" "$OUT/autotune.cache"
+  Y6_AUTOTUNE_CACHE="$PWD/$OUT/autotune.cache" Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 1200 python bench.py --steps 20 --warmup 3 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
   echo "bench rc=$?"; tail -2 "$OUT/bench.err"; cat "$OUT/bench.json"
 fi
 if has prof; then
   echo "== rocprofv3 kernel stats"
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  # the bench leg's tuning choices are reused, so the stats hold the chosen kernels only
+  ( cd /tmp && Y6_AUTOTUNE_CACHE="$OLDPWD/$OUT/autotune.cache" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
   echo "prof rc=$?"; find "$OUT/prof" -name "*kernel_stats*" | head -3
   f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep the merge-back small: drop the raw trace, keep stats

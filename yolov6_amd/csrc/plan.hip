@@ -330,11 +330,42 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     const int nv = y6_conv_variants();
     const char* logpath = getenv("Y6_AUTOTUNE_LOG");   // optional: append every (op, variant, ms) measurement
     FILE* logf = logpath ? fopen(logpath, "a") : nullptr;
+    // optional persistent choices (env Y6_AUTOTUNE_CACHE=<file>): "signature variant-name" per line, looked up
+    // before measuring and appended after - a deployment tunes once per machine, and a profiler run of the
+    // same command sees only the chosen kernels.
+    const char* cachepath = getenv("Y6_AUTOTUNE_CACHE");
+    std::vector<std::pair<std::string, std::string>> cache;
+    if (cachepath) {
+        if (FILE* cf = fopen(cachepath, "r")) {
+            char key[256], name[64];
+            while (fscanf(cf, "%255s %63s", key, name) == 2) cache.emplace_back(key, name);
+            fclose(cf);
+        }
+    }
+    auto signature = [](const y6_conv_desc& c) {
+        char b[256];
+        snprintf(b, sizeof(b), "k%ds%d_ci%d_co%d_b%d_h%d_w%d_ics%d_ocs%d_act%d_res%d_ps%d", c.ksize, c.stride, c.in.C,
+                 c.out.C, c.in.B, c.in.H, c.in.W, c.in.cstride, c.out.cstride, c.act, c.res.data != nullptr,
+                 c.post_scale != nullptr);
+        return std::string(b);
+    };
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
         if (op.kind != Y6_OP_CONV) continue;
         int best = -1;
         float best_ms = 1e30f;
+        const std::string sig = signature(op.conv);
+        if (cachepath) {
+            for (const auto& kv : cache) {
+                if (kv.first != sig) continue;
+                for (int v = 1; v < nv; ++v)
+                    if (kv.second == y6_conv_variant_name(v) && y6_conv_variant_supports(&op.conv, v)) best = v;
+            }
+            if (best >= 0) {
+                op.conv.variant = best;
+                continue;
+            }
+        }
         for (int v = 1; v < nv; ++v) {  // variant 0 (naive) is a cross-check, never a candidate
             if (!y6_conv_variant_supports(&op.conv, v)) continue;
             Op trial = op;
@@ -362,6 +393,13 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
         if (best < 0) best = y6_conv_variant_supports(&op.conv, 0) ? 0 : -1;
         Y6_REQUIRE(best >= 0, "plan_autotune: op %zu has no runnable conv variant", i);
         op.conv.variant = best;
+        if (cachepath && best > 0) {
+            cache.emplace_back(sig, y6_conv_variant_name(best));
+            if (FILE* cf = fopen(cachepath, "a")) {
+                fprintf(cf, "%s %s\n", sig.c_str(), y6_conv_variant_name(best));
+                fclose(cf);
+            }
+        }
     }
     if (logf) fclose(logf);
     Y6_HIP(hipStreamSynchronize(s));
