@@ -132,9 +132,10 @@ def test_convt2x2():
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("cout", [16, 32, 64])
-def test_stem_conv(dtype, cout):
+@pytest.mark.parametrize("hw", [(64, 96), (40, 264), (38, 92), (18, 8)])   # vector-load path (W % 8 == 0, several tiles per block) and the scalar fallback
+def test_stem_conv(dtype, cout, hw):
     g = torch.Generator().manual_seed(13)
-    x = torch.rand((2, 3, 64, 96), generator=g)
+    x = torch.rand((2, 3) + hw, generator=g)
     w, b = _mk_weights(cout, 3, 3, 14)
     from yolov6_amd.engine import NCHWInput
     pb = PlanBuilder(G.DEV)
@@ -142,6 +143,20 @@ def test_stem_conv(dtype, cout):
     pb.finalize(o, autotune=False).run()
     torch.cuda.synchronize()
     ref = G.conv_reference(x.to(dtype).float(), w, b, 2, "relu")
+    assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
+
+
+def test_stem_conv_persistent_many_tiles():
+    """More tiles than resident blocks: exercises the prefetch-next-tile loop of the persistent stem."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand((6, 3, 320, 512), generator=g) - 0.5
+    w, b = _mk_weights(32, 3, 3, 24)
+    from yolov6_amd.engine import NCHWInput
+    pb = PlanBuilder(G.DEV)
+    o = pb.conv(NCHWInput(x.to(G.DEV, torch.float16).contiguous()), w, b, stride=2, act="silu")
+    pb.finalize(o, autotune=False).run()
+    torch.cuda.synchronize()
+    ref = G.conv_reference(x.half().float(), w, b, 2, "silu")
     assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
 
 

@@ -289,6 +289,218 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
     }
 }
 
+// ---- stem v4: same tile (4 x 64 outputs) and MFMA mapping, but
+//   * the input window is fetched as aligned 16-byte pieces (8 pixels of one NCHW row): 9 rows x 3 channels x
+//     17 pieces per tile instead of 3483 two-byte loads;
+//   * blocks are persistent: weights / bias live in registers for the whole kernel, and the NEXT tile's window
+//     is requested before the current tile is multiplied and written, so the HBM latency is off the path.
+// Needs W % 8 == 0 and a 16-byte aligned image (anything else takes the kernel above).
+constexpr int STEM4_WPC = 17;                       // 16-byte pieces per window row: cols [2*ox0-8, 2*ox0+128)
+constexpr int STEM4_PITCH = STEM4_WPC * 8 + 8;      // halves
+constexpr int STEM4_NPIECE = 3 * STEM_IH * STEM4_WPC;
+
+template <typename TI>
+struct StemPiece;
+template <>
+struct StemPiece<__half> {
+    uint4 v;
+    __device__ __forceinline__ void load(const __half* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ uint4 as_half8() const { return v; }
+};
+template <>
+struct StemPiece<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = b = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ uint4 as_half8() const {
+        h8_t h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
+                  (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        return *reinterpret_cast<const uint4*>(&h);
+    }
+};
+
+template <int ACT>
+__device__ __forceinline__ float stem_act(float v) {
+    return y6_act(v, ACT);
+}
+
+template <typename TI, int CF>
+__global__ __launch_bounds__(256) void stem_mfma_v4_kernel(const TI* __restrict__ in, __half* __restrict__ out,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ pscale,
+                                                           const float* __restrict__ pshift, int B, int H, int W, int Ho,
+                                                           int Wo, int Cout, int out_cs, int out_co, int act, int tiles_x,
+                                                           int tiles_y) {
+    constexpr int RS = CF * 64 + 16;   // epilogue row pitch (bytes)
+    __shared__ __attribute__((aligned(16))) _Float16 s_in[3 * STEM_IH * STEM4_PITCH];
+    __shared__ __attribute__((aligned(16))) char s_out[4 * 64 * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = lane >> 5;
+    constexpr int K = 27;
+    const int ntiles = tiles_x * tiles_y * B;
+    const size_t HW = (size_t)H * W;
+
+    // this thread's two window pieces: (channel, window row, piece column) - tile independent
+    int pc_ci[2], pc_yy[2], pc_px[2];
+    bool pc_on[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = tid + i * 256;
+        pc_on[i] = p < STEM4_NPIECE;
+        const int pp = pc_on[i] ? p : 0;
+        pc_ci[i] = pp / (STEM_IH * STEM4_WPC);
+        const int r = pp - pc_ci[i] * (STEM_IH * STEM4_WPC);
+        pc_yy[i] = r / STEM4_WPC;
+        pc_px[i] = r - pc_yy[i] * STEM4_WPC;
+    }
+    StemPiece<TI> pre[2];
+    auto request = [&](int tile) {
+        const int tx = tile % tiles_x;
+        const int t2 = tile / tiles_x;
+        const int ty = t2 % tiles_y;
+        const int b = t2 / tiles_y;
+        const int iy0 = 2 * ty * STEM_TOH - 1, cx0 = 2 * tx * STEM_TOW - 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = iy0 + pc_yy[i], ix = cx0 + pc_px[i] * 8;
+            if (pc_on[i] && iy >= 0 && iy < H && ix >= 0 && ix < W)   // W % 8 == 0: a piece is wholly in or out
+                pre[i].load(in + ((size_t)b * 3 + pc_ci[i]) * HW + (size_t)iy * W + ix);
+            else
+                pre[i].zero();
+        }
+    };
+
+    // weights: A fragments (cout = cf*32 + lane&31, k = ks*16 + kh*8 + j), bias / post-affine of this lane's couts
+    h8_t af[CF][2];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = cf * 32 + (lane & 31), k = ks * 16 + kh * 8 + j;
+                af[cf][ks][j] = (co < Cout && k < K) ? (_Float16)w[(size_t)co * K + k] : (_Float16)0.f;
+            }
+    float bz[CF][16], psc[CF][16], psh[CF][16];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = cf * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const bool ok = c < Cout;
+            bz[cf][r] = (ok && bias) ? bias[c] : 0.f;
+            psc[cf][r] = (ok && pscale) ? pscale[c] : 1.f;
+            psh[cf][r] = (ok && pscale) ? pshift[c] : 0.f;
+        }
+    const bool affine = pscale != nullptr;
+    const bool rows_ok = (Cout % 8 == 0) && (out_cs % 8 == 0) && (out_co % 8 == 0);
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) request(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (pc_on[i])
+                *reinterpret_cast<uint4*>(s_in + (pc_ci[i] * STEM_IH + pc_yy[i]) * STEM4_PITCH + pc_px[i] * 8) =
+                    pre[i].as_half8();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);   // in flight during the MFMAs and the stores below
+
+        const int tx = tile % tiles_x;
+        const int t2 = tile / tiles_x;
+        const int ty = t2 % tiles_y;
+        const int b = t2 / tiles_y;
+        const int oy0 = ty * STEM_TOH, ox0 = tx * STEM_TOW;
+
+        f32x16_t acc[CF][2];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int px = pf * 32 + (lane & 31);   // output column inside the tile; output row = wave
+            const _Float16* base = s_in + (2 * wave) * STEM4_PITCH + 2 * px + 7;   // window col of (kx = 0)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8_t bf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = ks * 16 + kh * 8 + j;   // kh is per-lane: both alternatives are compile-time offsets
+                    const int k0 = ks * 16 + j, k1 = ks * 16 + 8 + j;
+                    const int o0 = ((k0 / 9) * STEM_IH + (k0 % 9) / 3) * STEM4_PITCH + (k0 % 3);
+                    const int o1 = ((k1 / 9) * STEM_IH + (k1 % 9) / 3) * STEM4_PITCH + (k1 % 3);
+                    const _Float16 v0 = (k0 < K) ? base[o0] : (_Float16)0.f;
+                    const _Float16 v1 = (k1 < K) ? base[o1] : (_Float16)0.f;
+                    bf[j] = kh ? v1 : v0;
+                    (void)k;
+                }
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+                    acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cf][ks], bf, acc[cf][pf], 0, 0, 0);
+            }
+        }
+
+        // epilogue: C/D col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*kh -> wave-private LDS tile -> rows
+        char* tl = s_out + wave * 64 * RS;
+        const int oy = oy0 + wave;
+        const size_t rowbase = ((size_t)b * Ho + oy) * Wo;
+        auto finish = [&](auto actfn) {
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                const int px = pf * 32 + (lane & 31);
+                const bool pvalid = oy < Ho && (ox0 + px) < Wo;
+                __half* orow = out + (rowbase + ox0 + px) * out_cs + out_co;
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int c0 = cf * 32 + 8 * r4 + 4 * kh;
+                        h4_t o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = acc[cf][pf][r4 * 4 + j] + bz[cf][r4 * 4 + j];
+                            if (affine) x = x * psc[cf][r4 * 4 + j] + psh[cf][r4 * 4 + j];
+                            o[j] = (_Float16)actfn(x);
+                        }
+                        if (rows_ok) {
+                            *reinterpret_cast<h4_t*>(tl + px * RS + c0 * 2) = o;
+                        } else if (pvalid) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (c0 + j < Cout) orow[c0 + j] = (__half)o[j];
+                        }
+                    }
+            }
+        };
+        switch (act) {   // one uniform branch per tile instead of one per element
+            case Y6_ACT_RELU: finish([](float v) { return stem_act<Y6_ACT_RELU>(v); }); break;
+            case Y6_ACT_SILU: finish([](float v) { return stem_act<Y6_ACT_SILU>(v); }); break;
+            case Y6_ACT_HARDSWISH: finish([](float v) { return stem_act<Y6_ACT_HARDSWISH>(v); }); break;
+            default: finish([](float v) { return v; }); break;
+        }
+        if (rows_ok) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int PPR = CF * 4;   // 16-byte pieces per pixel row
+#pragma unroll
+            for (int i = 0; i < PPR; ++i) {
+                const int q = lane + 64 * i;
+                const int px = q / PPR, pcq = q - px * PPR;
+                if (oy < Ho && (ox0 + px) < Wo && pcq * 8 + 8 <= Cout)
+                    *reinterpret_cast<uint4*>(out + (rowbase + ox0 + px) * out_cs + out_co + pcq * 8) =
+                        *reinterpret_cast<const uint4*>(tl + px * RS + pcq * 16);
+            }
+        }
+        __syncthreads();   // window reads and tile reads are over: the next iteration overwrites both
+    }
+}
+
 // ------------------------------------------------------------------ SPPF: 3 chained 5x5 s1 p2 max pools
 // One block = one image x 8 channels; the HxW plane lives in LDS; each pool is a
 // separable row-max / column-max pass with -inf padding (nn.MaxPool2d semantics).
@@ -550,6 +762,32 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     hipLaunchKernelGGL((stem_mfma_kernel<TI, CF_>), g, blk, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data,      \
                        d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo, CO, \
                        d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
+        const size_t esz = d->in_dtype == Y6_F16 ? 2 : 4;
+        static const bool no_v4 = getenv("Y6_STEM_NO_V4") != nullptr;   // A/B switch for profiling
+        if (!no_v4 && d->Cin == 3 && d->W % 8 == 0 && ((uintptr_t)d->in_nchw & 15) == 0 && ((size_t)d->H * d->W * esz) % 16 == 0 &&
+            (d->in_dtype == Y6_F16 || d->in_dtype == Y6_F32)) {
+            static int n_cu = 0;
+            if (n_cu == 0) {
+                int dev = 0;
+                Y6_HIP(hipGetDevice(&dev));
+                Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            }
+            const int ntiles = tiles_x * tiles_y * d->B;
+            int gridp = n_cu * 4;
+            if (gridp > ntiles) gridp = ntiles;
+#define Y6_STEM_V4(TI, CF_)                                                                                        \
+    hipLaunchKernelGGL((stem_mfma_v4_kernel<TI, CF_>), dim3(gridp), blk, 0, s, (const TI*)d->in_nchw,                \
+                       (__half*)d->out.data, d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->H, d->W, \
+                       Ho, Wo, CO, d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
+            if (d->in_dtype == Y6_F16) {
+                if (CO <= 32) Y6_STEM_V4(__half, 1); else Y6_STEM_V4(__half, 2);
+            } else {
+                if (CO <= 32) Y6_STEM_V4(float, 1); else Y6_STEM_V4(float, 2);
+            }
+#undef Y6_STEM_V4
+            Y6_LAUNCH_CHECK();
+            return Y6_OK;
+        }
         if (d->in_dtype == Y6_F16) {
             if (CO <= 32) Y6_STEM_MFMA(__half, 1); else Y6_STEM_MFMA(__half, 2);
         } else if (d->in_dtype == Y6_F32) {
