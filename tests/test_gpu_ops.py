@@ -189,9 +189,11 @@ def test_layout_adapters_exact():
 
 
 @pytest.mark.parametrize("use_dfl", [False, True])
-def test_head_decode(use_dfl):
-    B, nc, reg_max = 2, 80, 16
-    sizes, strides = [(8, 12), (4, 6), (2, 3)], [8.0, 16.0, 32.0]
+@pytest.mark.parametrize("nc,sizes", [(80, [(8, 12), (4, 6), (2, 3)]), (20, [(8, 12), (4, 6), (2, 3)]),
+                                      (80, [(16, 16), (8, 8), (4, 4)])])   # tiled (ragged / aligned rows) and flat (nc % 8 != 0) kernels
+def test_head_decode(use_dfl, nc, sizes):
+    B, reg_max = 2, 16
+    strides = [8.0, 16.0, 32.0]
     nreg = 4 * (reg_max + 1) if use_dfl else 4
     cls = [G.rand_nhwc(B, h, w, nc, seed=20 + i, scale=4.0) for i, (h, w) in enumerate(sizes)]
     reg = [G.rand_nhwc(B, h, w, nreg, seed=30 + i, scale=3.0) for i, (h, w) in enumerate(sizes)]

@@ -69,9 +69,8 @@ __device__ __forceinline__ float decode_element(const DecodeArgs& a, size_t i, i
     return v * a.stride[l];
 }
 
-// Four consecutive output floats per thread -> one 16-byte store per lane (the [B,A,5+nc] tensor is
-// written exactly once, fully coalesced); the fp16 logits of a pixel are contiguous, so the reads of
-// a wave are contiguous runs too.
+// Flat variant: four consecutive output floats per thread -> one 16-byte store per lane.  Used when the
+// class logits cannot be fetched as 16-byte pieces (nc % 8 != 0 or unaligned views).
 __global__ __launch_bounds__(256) void head_decode_kernel(const DecodeArgs a) {
     const int no = a.nc + 5;
     const size_t total = (size_t)a.B * a.A * no;
@@ -88,6 +87,69 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const DecodeArgs a) {
         } else {
             for (size_t i = i0; i < total; ++i) a.out[i] = decode_element(a, i, no);
         }
+    }
+}
+
+// Tiled variant: one block = DEC_TA consecutive anchors of one image.  The fp16 class logits of an anchor
+// are read as 16-byte pieces (8 classes), sigmoid'ed into an LDS image of the block's [DEC_TA][5+nc] fp32
+// output rows, the four box values are added by one thread per anchor, and the rows - contiguous in the
+// output tensor - leave as 16-byte stores.  Reads and writes are both fully coalesced; the integer
+// div/mod chain of the flat variant runs once per anchor instead of once per element.
+constexpr int DEC_TA = 64;
+
+__global__ __launch_bounds__(256) void head_decode_tiled_kernel(const DecodeArgs a, int blocks_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [DEC_TA][no] then int pix[DEC_TA], lvl[DEC_TA]
+    const int no = a.nc + 5, nc8 = a.nc >> 3;
+    int* s_pix = reinterpret_cast<int*>(s_rows + DEC_TA * no);
+    int* s_lvl = s_pix + DEC_TA;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / blocks_per_image;
+    const int a0 = (blockIdx.x - b * blocks_per_image) * DEC_TA;
+    const int na = min(DEC_TA, a.A - a0);
+
+    if (tid < DEC_TA && tid < na) {
+        const int an = a0 + tid;
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < Y6_MAX_LEVELS; ++t)
+            if (t < a.n_levels && an >= a.astart[t]) l = t;
+        const int local = an - a.astart[l];
+        const int y = local / a.W[l], x = local - y * a.W[l];
+        const int pix = (b * a.H[l] + y) * a.W[l] + x;
+        s_pix[tid] = pix;
+        s_lvl[tid] = l;
+        // (l,t,r,b) distances -> xywh (utils/general.py:32-43), scaled by the level stride
+        const float d0 = side_dist(a, l, (size_t)pix, 0), d1 = side_dist(a, l, (size_t)pix, 1);
+        const float d2 = side_dist(a, l, (size_t)pix, 2), d3 = side_dist(a, l, (size_t)pix, 3);
+        const float ax = (float)x + a.cell_offset, ay = (float)y + a.cell_offset;
+        const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
+        float* r = s_rows + tid * no;
+        r[0] = (x1 + x2) / 2.f * a.stride[l];
+        r[1] = (y1 + y2) / 2.f * a.stride[l];
+        r[2] = (x2 - x1) * a.stride[l];
+        r[3] = (y2 - y1) * a.stride[l];
+        r[4] = 1.f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < na * nc8; idx += 256) {
+        const int t = idx / nc8, piece = idx - t * nc8;
+        const int l = s_lvl[t];
+        const uint4 raw = *reinterpret_cast<const uint4*>(a.cls[l] + (size_t)s_pix[t] * a.cls_cs[l] + a.cls_co[l] + piece * 8);
+        const __half* h = reinterpret_cast<const __half*>(&raw);
+        float* r = s_rows + t * no + 5 + piece * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = 1.f / (1.f + __expf(-__half2float(h[j])));
+    }
+    __syncthreads();
+    const size_t obase = ((size_t)b * a.A + a0) * no;
+    const int nfl = na * no;
+    if ((obase & 3) == 0) {
+        const int nv = nfl >> 2;
+        for (int i = tid; i < nv; i += 256)
+            reinterpret_cast<float4*>(a.out + obase)[i] = reinterpret_cast<const float4*>(s_rows)[i];
+        for (int i = (nv << 2) + tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
+    } else {
+        for (int i = tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
     }
 }
 
@@ -131,6 +193,19 @@ extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
     a.nc = d->nc;
     const size_t total = (size_t)a.B * A * (d->nc + 5);
     Y6_REQUIRE(((uintptr_t)d->out & 15) == 0, "head_decode: output must be 16-byte aligned");
+    // tiled path: class logits fetchable as 16-byte pieces on every level
+    bool tiled = (d->nc % 8 == 0);
+    for (int l = 0; l < d->n_levels; ++l)
+        tiled = tiled && (a.cls_cs[l] % 8 == 0) && (a.cls_co[l] % 8 == 0) && (((uintptr_t)a.cls[l] & 15) == 0);
+    static const bool no_tiled = getenv("Y6_DECODE_FLAT") != nullptr;   // A/B switch for profiling
+    if (tiled && !no_tiled) {
+        const int bpi = (A + DEC_TA - 1) / DEC_TA;
+        const size_t lds = (size_t)DEC_TA * (d->nc + 5) * sizeof(float) + 2 * DEC_TA * sizeof(int);
+        Y6_REQUIRE(lds <= 64 * 1024, "head_decode: %d classes need %zu bytes of LDS", d->nc, lds);
+        hipLaunchKernelGGL(head_decode_tiled_kernel, dim3((unsigned)(a.B * bpi)), dim3(256), lds, (hipStream_t)stream, a, bpi);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
     size_t g = ((total + 3) / 4 + 255) / 256;
     if (g > 256 * 32) g = 256 * 32;
     hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
