@@ -81,11 +81,6 @@ def calibrate_head_bias(model, x, target_frac=0.02):
     return shift
 
 
-def variant_name(v):
-    from yolov6_amd import _lib
-    return _lib.load().y6_conv_variant_name(int(v)).decode() if v is not None and int(v) >= 0 else "-"
-
-
 def classify(row):
     if row["kind"] == "conv":
         return f"conv{row['ksize']}x{row['ksize']}s{row['stride']}"
@@ -169,7 +164,7 @@ def main():
         dom_variants = {}
         for r in rows:
             if classify(r) == "conv3x3s1":
-                n = variant_name(r["variant"])
+                n = str(r["variant"])
                 dom_variants[n] = dom_variants.get(n, 0) + 1
         total_flops = sum(r["flops"] for r in rows)
         fwd_ms = sum(r["ms"] for r in rows)

@@ -50,13 +50,29 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
     __shared__ int s_cnt, s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x % B, chunk = blockIdx.x / B;
+    const int no = nc + 5;
+    // the block's rows are one contiguous run of the prediction tensor: fetch it with 16-byte loads, all in
+    // flight at once, and work from LDS (v2 walked the rows with dependent 4-byte loads: latency bound)
+    float* rows = reinterpret_cast<float*>(smem + (size_t)rpb * (multi_label ? nc : 1) * sizeof(u64));
+    const int a0 = chunk * rpb;
+    const int nrows = min(rpb, A - a0);
+    {
+        const size_t gbase = ((size_t)b * A + a0) * no;
+        const int nfl = nrows * no;
+        const float* src = pred + gbase;
+        if (((gbase & 3) == 0) && ((reinterpret_cast<uintptr_t>(pred) & 15) == 0)) {
+            const int nv = nfl >> 2;
+            for (int i = tid; i < nv; i += 256) reinterpret_cast<float4*>(rows)[i] = reinterpret_cast<const float4*>(src)[i];
+            for (int i = (nv << 2) + tid; i < nfl; i += 256) rows[i] = src[i];
+        } else {
+            for (int i = tid; i < nfl; i += 256) rows[i] = src[i];
+        }
+    }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
-    const int no = nc + 5;
-    for (int r = wave; r < rpb; r += 4) {
-        const int an = chunk * rpb + r;
-        if (an >= A) break;
-        const float* row = pred + ((size_t)b * A + an) * no;
+    for (int r = wave; r < nrows; r += 4) {
+        const int an = a0 + r;
+        const float* row = rows + r * no;
         const float obj = row[4];
         if (!(obj > conf_thres)) continue;
         float mx = -INFINITY;
@@ -144,6 +160,57 @@ __device__ __forceinline__ void bitonic_desc(u64* keys, int P) {
     }
 }
 
+// LDS variant for a 1024-thread block.  Wave w owns the chunk [w*C, (w+1)*C) (C = P/16, at least 128):
+// every compare-exchange stage with distance j < C stays inside one chunk, so those stages - 95 of the
+// 105 for 16384 keys - run with wave-level ordering only; block barriers remain for j >= C.
+__device__ __forceinline__ void bitonic_desc_lds(u64* keys, int P) {
+    const int T = blockDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int C = P >> 4;
+    if (C < 128) C = 128;
+    if (C > P) C = P;
+    const int nchunk = P / C;
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < C) {
+                if (wave < nchunk) {
+                    u64* base = keys + wave * C;
+                    for (int jj = j; jj > 0; jj >>= 1) {
+                        for (int u = lane; u < (C >> 1); u += 64) {
+                            const int i = ((u & ~(jj - 1)) << 1) | (u & (jj - 1));
+                            const int l = i | jj;
+                            const u64 x = base[i], y = base[l];
+                            const bool desc = ((wave * C + i) & k) == 0;
+                            if (desc ? (x < y) : (x > y)) {
+                                base[i] = y;
+                                base[l] = x;
+                            }
+                        }
+                        // same-wave LDS accesses complete in issue order; keep the compiler from reordering them
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                break;   // all remaining distances of this k were handled above
+            }
+            for (int t = threadIdx.x; t < half; t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const u64 x = keys[i], y = keys[l];
+                const bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) {
+                    keys[i] = y;
+                    keys[l] = x;
+                }
+            }
+            __syncthreads();
+        }
+        if (k >= C) __syncthreads();   // the next k starts with a cross-chunk distance (or the sort is over)
+    }
+    __syncthreads();
+}
+
 constexpr int kLdsKeys = 16384;   // 128 KiB of 64-bit keys during the sort
 constexpr int kWin = 2048;        // sweep window: sorted candidates resident in LDS at a time
 constexpr int kKeptCap = 2048;    // kept boxes resident in LDS (max_det limit)
@@ -173,6 +240,8 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
                                                               int* __restrict__ out_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_batch[64];
+    __shared__ int s_nb, s_k0, s_kept, s_last;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
@@ -189,7 +258,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
         u64* lk = reinterpret_cast<u64*>(smem);
         for (int i = tid; i < P; i += T) lk[i] = i < n ? gk[i] : 0ull;
         __syncthreads();
-        bitonic_desc(lk, P);
+        bitonic_desc_lds(lk, P);
         for (int i = tid; i < n; i += T) gk[i] = lk[i];   // sorted keys back to global: the LDS is re-used below
     } else {
         for (int i = n + tid; i < P; i += T) gk[i] = 0ull;  // cap is a power of two >= P
@@ -240,37 +309,88 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
             if (lane == 0) walive[r * 16 + wave] = bal;   // bit (t & 63) of word (t >> 6)
         }
         __syncthreads();
-        // greedy sweep inside the window
+        // Greedy sweep inside the window, 64 undecided candidates at a time.  Wave 0 takes the first (up to)
+        // 64 alive candidates, settles their mutual suppression with lane broadcasts - no block barrier per
+        // kept box - and publishes the boxes it kept; then every thread tests the window's later alive
+        // candidates against just those new boxes.  Exactly the sequential greedy order: a candidate left
+        // outside a batch is alive only if it lies behind every member of that batch.
         int cur = 0;
-        while (true) {
-            // every wave finds the first alive index >= cur (same answer in every wave)
-            u64 w = 0ull;
-            if (lane < kWin / 64) {
-                w = walive[lane];
-                if (lane < (cur >> 6)) w = 0ull;
-                if (lane == (cur >> 6)) w &= ~((1ull << (cur & 63)) - 1ull);
+        while (kept < max_det) {
+            if (wave == 0) {
+                u64 w = 0ull;
+                if (lane < kWin / 64) {
+                    w = walive[lane];
+                    if (lane < (cur >> 6)) w = 0ull;
+                    if (lane == (cur >> 6)) w &= ~((1ull << (cur & 63)) - 1ull);
+                }
+                const int pc = __popcll(w);
+                int incl = pc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int total = __shfl(incl, 63, 64);
+                int p = incl - pc;
+                u64 ww = w;
+                while (ww != 0ull && p < 64) {
+                    s_batch[p++] = (lane << 6) + (__ffsll((long long)ww) - 1);
+                    ww &= ww - 1ull;
+                }
+                if (lane == 0) s_nb = total < 64 ? total : 64;
             }
-            const u64 bal = __ballot(w != 0ull);
-            if (bal == 0ull) break;
-            const int src = __ffsll((long long)bal) - 1;
-            const u64 wv = __shfl(w, src, 64);
-            const int i = (src << 6) + (__ffsll((long long)wv) - 1);
-            const float4 bi = wbox[i];
-            if (tid == 0) {
-                kbox[kept] = bi;
-                kept_pos[kept] = pos + i;
+            __syncthreads();
+            const int nb = s_nb;
+            if (nb == 0) break;
+            if (wave == 0) {
+                const int idx = lane < nb ? s_batch[lane] : 0;
+                const float4 bx = wbox[idx];
+                bool alive = lane < nb;
+                u64 keepmask = 0ull;
+                int nk = 0;
+                for (int i = 0; i < nb; ++i) {
+                    const u64 am = __ballot(alive);
+                    if (!((am >> i) & 1ull)) continue;
+                    if (kept + nk >= max_det) break;
+                    keepmask |= 1ull << i;
+                    ++nk;
+                    float4 bi;
+                    bi.x = __shfl(bx.x, i, 64);
+                    bi.y = __shfl(bx.y, i, 64);
+                    bi.z = __shfl(bx.z, i, 64);
+                    bi.w = __shfl(bx.w, i, 64);
+                    if (lane > i && alive && nms_iou(bi, bx) > iou_thres) alive = false;
+                }
+                if ((keepmask >> lane) & 1ull) {
+                    const int kp = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
+                    kbox[kp] = bx;
+                    kept_pos[kp] = pos + idx;
+                }
+                if (lane < nb) atomicAnd(&walive[idx >> 6], ~(1ull << (idx & 63)));   // decided either way
+                if (lane == 0) {
+                    s_k0 = kept;
+                    s_kept = kept + nk;
+                    s_last = s_batch[nb - 1];
+                }
             }
-            ++kept;
+            __syncthreads();
+            const int k0 = s_k0, last = s_last;
+            kept = s_kept;
             if (kept >= max_det) break;
 #pragma unroll
             for (int r = 0; r < kWin / 1024; ++r) {
                 const int t = tid + r * 1024;
-                if (t > i && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
-                    if (nms_iou(bi, wbox[t]) > iou_thres) atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                if (t > last && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
+                    const float4 bj = wbox[t];
+                    for (int k = k0; k < kept; ++k)
+                        if (nms_iou(kbox[k], bj) > iou_thres) {
+                            atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                            break;
+                        }
                 }
             }
             __syncthreads();
-            cur = i + 1;
+            cur = last + 1;
             if (cur >= wn) break;
         }
         __syncthreads();
@@ -346,10 +466,10 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     const int per_row = ml ? d->nc : 1;
     int rpb = 6144 / per_row;
     rpb = rpb > 64 ? 64 : (rpb < 4 ? 4 : (rpb / 4) * 4);
-    const size_t stage_bytes = (size_t)rpb * per_row * sizeof(u64);
+    const size_t stage_bytes = (size_t)rpb * per_row * sizeof(u64) + (size_t)rpb * (d->nc + 5) * sizeof(float);   // keys + row image
     Y6_REQUIRE(stage_bytes <= 160 * 1024 - 1024, "nms: %d classes do not fit the LDS staging area", d->nc);
     static bool cand_attr = false;
-    if (stage_bytes > 64 * 1024 && !cand_attr) {
+    if (stage_bytes > 48 * 1024 && !cand_attr) {
         Y6_HIP(hipFuncSetAttribute((const void*)nms_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024 - 1024));
         cand_attr = true;
