@@ -164,9 +164,9 @@ int y6_head_decode(const y6_decode_desc* d, void* stream);
  * cls*4096 unless agnostic, stable descending score order).
  * pred        : [B, A, 5+nc] fp32 (xywh, obj, cls...)
  * classes     : optional device int32 list of n_classes kept classes (NULL: all)
- * out_dets    : [B, max_det, 6] fp32 (x1,y1,x2,y2,conf,cls)
- * out_index   : [B, max_det] int32, flat candidate id = anchor*nc + cls (parity checks)
- * out_count   : [B] int32 detections per image
+ * out_dets    : [B, max_det, 6] fp32 (x1,y1,x2,y2,conf,cls); rows >= out_count[b] are written as 0
+ * out_index   : [B, max_det] int32, flat candidate id = anchor*nc + cls (parity checks); -1 past the count
+ * out_count   : [B] int32 detections per image  (all three outputs are fully written: no pre-fill needed)
  * workspace   : y6_nms_workspace_bytes(B,A,nc,multi_label) bytes of scratch
  * The reference's 10 s wall-clock break (nms.py:56,101-103) has no device analogue and is
  * not reproduced (documented deviation).                                                  */

@@ -4,29 +4,25 @@
 // published algorithm: stable sort by score descending, greedy sweep, suppress j when
 // IoU(i,j) > thr with IoU = inter / (area_i + area_j - inter), fp32, no +1, no eps).
 //
-// Stage 1 (nms_candidates_kernel): one wave per anchor row; rows that pass
+// Stage 1 (nms_candidates_kernel): a block fetches 64 consecutive anchor rows into LDS; rows that pass
 //   obj > conf AND max(cls) > conf (nms.py:48) emit (conf = cls*obj (:69), class) candidates
 //   (multi-label: every class with conf > thr (:75-77); else best class (:79-80)), filtered
-//   by `classes` (:83-84), appended with one atomic per wave.  A candidate is a 64-bit key
+//   by `classes` (:83-84), appended with one global atomic per block.  A candidate is a 64-bit key
 //   (conf bits << 32 | ~flat) with flat = anchor*nc + cls, so a descending key sort IS the
 //   reference's "score descending, earlier row first" order.
-// Stage 2 (nms_sort_sweep_kernel): one 1024-thread block per image: bitonic sort of the keys
-//   (LDS when they fit, workspace otherwise), cap to max_nms (:90-91), then a windowed greedy
-//   sweep over the sorted list: xyxy boxes (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95)
-//   are built 2048 at a time in LDS, tested against the boxes already kept, and swept with a wave
-//   ballot over the alive-bitmask, until max_det (:97-98) boxes are kept.
+// Stage 2 (nms_chunk_sort_kernel + nms_merge_rank_kernel): the keys of every image are sorted by the whole
+//   chip: 2048-key chunks by bitonic networks in LDS, then a rank merge that also applies the
+//   max_nms cap (:90-91).
+// Stage 3 (nms_sweep_kernel): one 1024-thread block per image, windowed greedy sweep over the sorted
+//   list: xyxy boxes (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95) are built 2048 at a time
+//   in LDS, tested against the boxes already kept, and settled 64 candidates at a time, until
+//   max_det (:97-98) boxes are kept.
 // Compile with -ffp-contract=off: index parity needs the reference's unfused fp32 arithmetic.
 #include "common.hpp"
 
 namespace {
 
 typedef unsigned long long u64;
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
 
 __device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classes) {
     if (!classes) return true;
@@ -36,24 +32,29 @@ __device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classe
 }
 
 // One block = `rpb` consecutive anchor rows of ONE image (blockIdx interleaves images so that
-// concurrently running blocks append to different per-image counters).  Candidates are staged in
-// LDS (one LDS atomic per wave-row), then the block reserves its slice of the image's key list
-// with a single global atomic and copies the keys out coalesced.  (v1 did one global atomic per
-// row: all resident waves hit the same counter and serialised at ~12 ns each - 4.3 ms per call.)
+// concurrently running blocks append to different per-image counters).  The rows are one contiguous run
+// of the prediction tensor: they are fetched with 16-byte loads, all in flight at once, and examined in
+// LDS with a thread per (row, 8 classes) - no cross-lane traffic.  Pass 1 raises the row flag of
+// nms.py:48 (obj > conf AND max cls > conf); pass 2 finds the candidates of flagged rows and reserves
+// block-local slots with LDS atomics; one global atomic per block reserves the block's slice of the
+// image's key list and the keys go straight to it.  LDS holds only the rows (22 KiB for 80 classes), so
+// seven blocks per CU keep ~150 KiB of loads in flight.
+// History: v1 one global atomic per row (same-address atomics serialise at ~12 ns: 4.3 ms per call);
+// v2 wave per row with shuffles and a 40 KiB LDS key stage (0.17 ms); this version 0.08 -> see DESIGN.md.
+constexpr int kCandTasks = 4;   // (row, 8-class) tasks per thread
+
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int B, int A, int nc,
                                                              float conf_thres, const int* __restrict__ classes,
                                                              int n_classes, int multi_label, int rpb,
                                                              u64* __restrict__ keys, size_t cap,
                                                              int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* stage = reinterpret_cast<u64*>(smem);                         // [rpb * (multi_label ? nc : 1)]
     __shared__ int s_cnt, s_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int b = blockIdx.x % B, chunk = blockIdx.x / B;
     const int no = nc + 5;
-    // the block's rows are one contiguous run of the prediction tensor: fetch it with 16-byte loads, all in
-    // flight at once, and work from LDS (v2 walked the rows with dependent 4-byte loads: latency bound)
-    float* rows = reinterpret_cast<float*>(smem + (size_t)rpb * (multi_label ? nc : 1) * sizeof(u64));
+    float* rows = reinterpret_cast<float*>(smem);
+    int* rowflag = reinterpret_cast<int*>(rows + (size_t)rpb * no);
     const int a0 = chunk * rpb;
     const int nrows = min(rpb, A - a0);
     {
@@ -69,62 +70,64 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
         }
     }
     if (tid == 0) s_cnt = 0;
+    for (int r = tid; r < nrows; r += 256) rowflag[r] = 0;
     __syncthreads();
-    for (int r = wave; r < nrows; r += 4) {
-        const int an = a0 + r;
+    const int npc = (nc + 7) >> 3;
+    const int ntask = nrows * npc;   // <= 256 * kCandTasks by the launcher's choice of rpb
+#pragma unroll
+    for (int m = 0; m < kCandTasks; ++m) {
+        const int idx = tid + m * 256;
+        if (idx >= ntask) break;
+        const int r = idx / npc, j0 = (idx - r * npc) << 3;
         const float* row = rows + r * no;
-        const float obj = row[4];
-        if (!(obj > conf_thres)) continue;
-        float mx = -INFINITY;
-        for (int j = lane; j < nc; j += 64) mx = fmaxf(mx, row[5 + j]);
-        mx = wave_max(mx);
-        if (!(mx > conf_thres)) continue;
-        if (multi_label) {
-            for (int j0 = 0; j0 < nc; j0 += 64) {
-                const int j = j0 + lane;
-                float c = 0.f;
-                bool pass = false;
-                if (j < nc) {
-                    c = row[5 + j] * obj;
-                    pass = (c > conf_thres) && class_ok(j, classes, n_classes);
-                }
-                const u64 bal = __ballot(pass);
-                if (bal == 0) continue;
-                const int n = __popcll(bal);
-                const int leader = __ffsll((long long)bal) - 1;
-                int base = 0;
-                if (lane == leader) base = atomicAdd(&s_cnt, n);
-                base = __shfl(base, leader, 64);
-                if (pass) {
-                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                    const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)j;
-                    stage[pos] = ((u64)__float_as_uint(c) << 32) | (u64)(0xFFFFFFFFu - flat);
-                }
-            }
-        } else {
-            // best class: max conf, first (lowest) class index on ties (torch.max semantics)
+        if (!(row[4] > conf_thres)) continue;
+        bool any = false;
+        for (int j = j0; j < j0 + 8 && j < nc; ++j) any = any || (row[5 + j] > conf_thres);
+        if (any) rowflag[r] = 1;   // benign race: every writer stores 1
+    }
+    __syncthreads();
+    unsigned passm[kCandTasks];
+    int off[kCandTasks];
+    if (multi_label) {
+#pragma unroll
+        for (int m = 0; m < kCandTasks; ++m) {
+            passm[m] = 0u;
+            off[m] = 0;
+            const int idx = tid + m * 256;
+            if (idx >= ntask) continue;
+            const int r = idx / npc, j0 = (idx - r * npc) << 3;
+            if (!rowflag[r]) continue;
+            const float* row = rows + r * no;
+            const float obj = row[4];
+            unsigned pm = 0u;
+            for (int j = j0; j < j0 + 8 && j < nc; ++j)
+                if ((row[5 + j] * obj > conf_thres) && class_ok(j, classes, n_classes)) pm |= 1u << (j - j0);
+            passm[m] = pm;
+            if (pm) off[m] = atomicAdd(&s_cnt, __popc(pm));
+        }
+    } else {
+        // best class per row: max conf, first (lowest) class index on ties (torch.max semantics, nms.py:79);
+        // task slot 0 of thread r carries row r (rpb <= 256); passm holds class+1
+#pragma unroll
+        for (int m = 0; m < kCandTasks; ++m) {
+            passm[m] = 0u;
+            off[m] = 0;
+        }
+        if (tid < nrows && rowflag[tid]) {
+            const float* row = rows + tid * no;
+            const float obj = row[4];
             float bc = -INFINITY;
-            int bj = 0x7fffffff;
-            for (int j = lane; j < nc; j += 64) {
+            int bj = 0;
+            for (int j = 0; j < nc; ++j) {
                 const float c = row[5 + j] * obj;
                 if (c > bc) {
                     bc = c;
                     bj = j;
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float oc = __shfl_xor(bc, o, 64);
-                const int oj = __shfl_xor(bj, o, 64);
-                if (oc > bc || (oc == bc && oj < bj)) {
-                    bc = oc;
-                    bj = oj;
-                }
-            }
-            if (lane == 0 && bc > conf_thres && class_ok(bj, classes, n_classes)) {
-                const int pos = atomicAdd(&s_cnt, 1);
-                const unsigned flat = (unsigned)an * (unsigned)nc + (unsigned)bj;
-                stage[pos] = ((u64)__float_as_uint(bc) << 32) | (u64)(0xFFFFFFFFu - flat);
+            if (bc > conf_thres && class_ok(bj, classes, n_classes)) {
+                passm[0] = (unsigned)bj + 1u;
+                off[0] = atomicAdd(&s_cnt, 1);
             }
         }
     }
@@ -134,39 +137,39 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
     if (tid == 0) s_base = atomicAdd(&counts[b], total);
     __syncthreads();
     u64* kb = keys + (size_t)b * cap + s_base;
-    for (int i = tid; i < total; i += 256) kb[i] = stage[i];
-}
-
-// descending bitonic sort of P (power of two) keys by the whole block; one compare-exchange pair per
-// thread-iteration (no idle half).  Force-inlined so that a pointer derived from the LDS array keeps
-// its address space (ds_read/ds_write instead of flat accesses).
-__device__ __forceinline__ void bitonic_desc(u64* keys, int P) {
-    const int T = blockDim.x;
-    const int half = P >> 1;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += T) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const u64 x = keys[i], y = keys[l];
-                const bool desc = (i & k) == 0;
-                if (desc ? (x < y) : (x > y)) {
-                    keys[i] = y;
-                    keys[l] = x;
-                }
+    if (multi_label) {
+#pragma unroll
+        for (int m = 0; m < kCandTasks; ++m) {
+            unsigned pm = passm[m];
+            if (!pm) continue;
+            const int idx = tid + m * 256;
+            const int r = idx / npc, j0 = (idx - r * npc) << 3;
+            const float* row = rows + r * no;
+            const float obj = row[4];
+            int pos = off[m];
+            while (pm) {
+                const int j = j0 + __ffs((int)pm) - 1;
+                pm &= pm - 1u;
+                const unsigned flat = (unsigned)(a0 + r) * (unsigned)nc + (unsigned)j;
+                kb[pos++] = ((u64)__float_as_uint(row[5 + j] * obj) << 32) | (u64)(0xFFFFFFFFu - flat);
             }
-            __syncthreads();
         }
+    } else if (passm[0]) {
+        const int bj = (int)passm[0] - 1;
+        const float* row = rows + tid * no;
+        const unsigned flat = (unsigned)(a0 + tid) * (unsigned)nc + (unsigned)bj;
+        kb[off[0]] = ((u64)__float_as_uint(row[5 + bj] * row[4]) << 32) | (u64)(0xFFFFFFFFu - flat);
     }
 }
 
-// LDS variant for a 1024-thread block.  Wave w owns the chunk [w*C, (w+1)*C) (C = P/16, at least 128):
-// every compare-exchange stage with distance j < C stays inside one chunk, so those stages - 95 of the
-// 105 for 16384 keys - run with wave-level ordering only; block barriers remain for j >= C.
+// descending bitonic sort of P (power of two) keys held in LDS by the whole block.
+// LDS variant.  Wave w owns the chunk [w*C, (w+1)*C) (C = P / waves, at least 128): every compare-exchange
+// stage with distance j < C stays inside one chunk, so those stages run with wave-level ordering only;
+// block barriers remain for j >= C.
 __device__ __forceinline__ void bitonic_desc_lds(u64* keys, int P) {
     const int T = blockDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int C = P >> 4;
+    int C = P / (T >> 6);
     if (C < 128) C = 128;
     if (C > P) C = P;
     const int nchunk = P / C;
@@ -211,8 +214,7 @@ __device__ __forceinline__ void bitonic_desc_lds(u64* keys, int P) {
     __syncthreads();
 }
 
-constexpr int kLdsKeys = 16384;   // 128 KiB of 64-bit keys during the sort
-constexpr int kWin = 2048;        // sweep window: sorted candidates resident in LDS at a time
+constexpr int kWin = 1024;        // sweep window: sorted candidates resident in LDS at a time (one per thread)
 constexpr int kKeptCap = 2048;    // kept boxes resident in LDS (max_det limit)
 constexpr size_t kSweepLds = (size_t)(kWin + kKeptCap) * 16 + (kWin / 64) * 8;
 
@@ -227,46 +229,160 @@ __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
     return inter / (area_i + area_j - inter);
 }
 
-// One 1024-thread block per image.
-//  1. bitonic sort of the candidate keys (LDS when <= 16384, else in the global workspace);
-//  2. windowed greedy sweep: 2048 sorted candidates at a time become class-offset boxes in LDS, are
-//     first tested against the boxes kept so far, then swept greedily: a wave ballot over the alive
-//     bitmask finds the next survivor, every later box of the window is tested against it in parallel.
-//     Boxes are only ever built for the windows the sweep reaches before max_det boxes are kept.
-__global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __restrict__ pred, int A, int nc,
-                                                              float iou_thres, int agnostic, int max_det, int max_nms,
-                                                              float max_wh, u64* __restrict__ keys, size_t cap,
-                                                              const int* __restrict__ counts,
+// IoU(bi, bj) > thr with the arithmetic above, but the division only runs for boxes that overlap.
+// Exact: when right-left (or bottom-top) is <= 0 or NaN the reference's clamped extent is 0, the
+// intersection is 0 (or NaN against an infinite extent) and `0/union > thr`, `NaN > thr` are both false.
+// With class offsets (nms.py:94-95) almost every pair ends here - the sweep's inner loop is 5x shorter.
+__device__ __forceinline__ bool nms_suppresses(const float4 bi, const float4 bj, float thr) {
+    const float dw = fminf(bi.z, bj.z) - fmaxf(bi.x, bj.x);
+    if (!(dw > 0.f)) return false;
+    const float dh = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);
+    if (!(dh > 0.f)) return false;
+    return nms_iou(bi, bj) > thr;
+}
+
+// ---- sort, spread over the whole chip -------------------------------------------------------------
+// One image's candidate list used to be sorted by its single sweep block (one CU, LDS-throughput bound:
+// ~140 us for 13k keys while 224 CUs idled).  Now:
+//   nms_chunk_sort_kernel   every 2048-key chunk of every image is sorted (descending) in LDS by its own
+//                           256-thread block, in place;
+//   nms_merge_rank_kernel   every key finds its final rank = its position in its own chunk + the number of
+//                           larger keys in each other chunk of the image (binary search; keys are unique, so
+//                           ranks are a permutation) and is scattered to sorted[b][rank] if rank < max_nms
+//                           (the cap of nms.py:90-91).
+constexpr int kChunk = 2048;
+
+__global__ __launch_bounds__(256) void nms_chunk_sort_kernel(u64* __restrict__ keys, size_t cap,
+                                                             const int* __restrict__ counts, int chunks_per_image) {
+    __shared__ __attribute__((aligned(16))) u64 lk[kChunk];
+    // the grid holds `chunks_per_image` blocks per image (a few); a block walks the image's chunks with that stride
+    const int b = blockIdx.x / chunks_per_image;
+    const int n = counts[b];
+    for (int c = blockIdx.x - b * chunks_per_image; c * kChunk < n; c += chunks_per_image) {
+        const int c0 = c * kChunk;
+        u64* gk = keys + (size_t)b * cap + c0;
+        const int m = min(kChunk, n - c0);
+        int P = 128;
+        while (P < m) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += 256) lk[i] = i < m ? gk[i] : 0ull;   // real keys are never 0
+        __syncthreads();
+        bitonic_desc_lds(lk, P);
+        for (int i = threadIdx.x; i < m; i += 256) gk[i] = lk[i];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_merge_rank_kernel(const u64* __restrict__ keys, size_t cap,
+                                                             const int* __restrict__ counts, int chunks_per_image,
+                                                             u64* __restrict__ sorted, int max_nms) {
+    // The other chunks of the image pass through a double-buffered LDS stage (coalesced 8-byte loads, the next
+    // one in flight while the current one is searched): the 11-12 probes of a binary search cost LDS latency,
+    // not a dependent chain of L2 round trips (first version: 0.16 ms, all of it load latency).
+    __shared__ __attribute__((aligned(16))) u64 run[2][kChunk];
+    constexpr int KPT = kChunk / 256;   // keys per thread
+    const int b = blockIdx.x / chunks_per_image;
+    const int n = counts[b];
+    const int tid = threadIdx.x;
+    const u64* gk = keys + (size_t)b * cap;
+    const int nchunks = (n + kChunk - 1) / kChunk;
+    for (int c = blockIdx.x - b * chunks_per_image; c < nchunks; c += chunks_per_image) {
+    const int c0 = c * kChunk;
+    u64 mykey[KPT];
+    int rank[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        const int p = tid + q * 256;
+        mykey[q] = (c0 + p < n) ? gk[c0 + p] : 0ull;
+        rank[q] = p;
+    }
+    u64 stg[KPT];
+    auto fetch = [&](int oc) {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const int i = oc * kChunk + tid + q * 256;
+            stg[q] = i < n ? gk[i] : 0ull;
+        }
+    };
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) run[buf][tid + q * 256] = stg[q];
+    };
+    auto other = [&](int t) { return t < c ? t : t + 1; };   // t-th chunk that is not c
+    const int nother = nchunks - 1;
+    if (nother > 0) {
+        fetch(other(0));
+        publish(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < nother; ++t) {
+        const int oc = other(t);
+        if (t + 1 < nother) fetch(other(t + 1));
+        const u64* r = run[t & 1];
+        const int len = min(kChunk, n - oc * kChunk);
+        int lo[KPT], hi[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            lo[q] = 0;
+            hi[q] = len;
+        }
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {   // 2^11 = kChunk: 12 halvings settle any length <= kChunk
+#pragma unroll
+            for (int q = 0; q < KPT; ++q) {
+                // branch-free so that the KPT probes of one halving are in flight together
+                const bool act = lo[q] < hi[q];
+                const int mid = (lo[q] + hi[q]) >> 1;
+                const bool gt = r[act ? mid : 0] > mykey[q];   // r is descending: lo converges to #entries > key
+                lo[q] = (act && gt) ? mid + 1 : lo[q];
+                hi[q] = (act && !gt) ? mid : hi[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) rank[q] += lo[q];
+        if (t + 1 < nother) publish((t + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        const int p = tid + q * 256;
+        if (c0 + p < n && rank[q] < max_nms) sorted[(size_t)b * max_nms + rank[q]] = mykey[q];
+    }
+    __syncthreads();   // the LDS stage is re-used by the block's next chunk
+    }
+}
+
+// One 1024-thread block per image: windowed greedy sweep over the sorted candidate list.  2048 sorted
+// candidates at a time become class-offset boxes in LDS, are first tested against the boxes kept so far,
+// then settled in batches of 64 (see below).  Boxes are only ever built for the windows the sweep reaches
+// before max_det boxes are kept.
+__global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict__ pred, int A, int nc,
+                                                         float iou_thres, int agnostic, int max_det, int max_nms,
+                                                         float max_wh, const u64* __restrict__ sorted,
+                                                         const int* __restrict__ counts,
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
                                                               int* __restrict__ out_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_batch[64];
+    __shared__ u64 s_mask[64];
     __shared__ int s_nb, s_k0, s_kept, s_last;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     int n = counts[b];
+    // the outputs need no pre-fill by the caller: rows past the kept count are written here (zeros / -1)
+    auto pad_outputs = [&](int from) {
+        for (int i = from * 6 + tid; i < max_det * 6; i += T) out_dets[(size_t)b * max_det * 6 + i] = 0.f;
+        for (int i = from + tid; i < max_det; i += T) out_index[(size_t)b * max_det + i] = -1;
+    };
     if (n <= 0) {
+        pad_outputs(0);
         if (tid == 0) out_count[b] = 0;
         return;
     }
-    u64* gk = keys + (size_t)b * cap;
-    int P = 1;
-    while (P < n) P <<= 1;
-    if (P <= kLdsKeys) {
-        u64* lk = reinterpret_cast<u64*>(smem);
-        for (int i = tid; i < P; i += T) lk[i] = i < n ? gk[i] : 0ull;
-        __syncthreads();
-        bitonic_desc_lds(lk, P);
-        for (int i = tid; i < n; i += T) gk[i] = lk[i];   // sorted keys back to global: the LDS is re-used below
-    } else {
-        for (int i = n + tid; i < P; i += T) gk[i] = 0ull;  // cap is a power of two >= P
-        __syncthreads();
-        bitonic_desc(gk, P);
-    }
+    const u64* gk = sorted + (size_t)b * max_nms;   // descending, already cut to max_nms (nms.py:90-91)
     if (n > max_nms) n = max_nms;
-    __syncthreads();
+    if (tid < 64) s_mask[tid] = 0ull;
 
     float4* wbox = reinterpret_cast<float4*>(smem);
     float4* kbox = wbox + kWin;
@@ -300,7 +416,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
             if (alive) {
                 const float4 bj = wbox[t];
                 for (int k = 0; k < kept; ++k)
-                    if (nms_iou(kbox[k], bj) > iou_thres) {
+                    if (nms_suppresses(kbox[k], bj, iou_thres)) {
                         alive = false;
                         break;
                     }
@@ -342,24 +458,35 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
             __syncthreads();
             const int nb = s_nb;
             if (nb == 0) break;
+            {   // all-pairs suppression bits of the batch, 4 pairs per thread: bit j of s_mask[i] <=> j > i and IoU(i, j) > thr
+                const int i = tid >> 4, jb = (tid & 15) << 2;
+                if (i < nb) {
+                    const float4 bi = wbox[s_batch[i]];
+                    u64 bits = 0ull;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = jb + q;
+                        if (j > i && j < nb && nms_suppresses(bi, wbox[s_batch[j]], iou_thres)) bits |= 1ull << j;
+                    }
+                    if (bits) atomicOr(&s_mask[i], bits);
+                }
+            }
+            __syncthreads();
             if (wave == 0) {
                 const int idx = lane < nb ? s_batch[lane] : 0;
                 const float4 bx = wbox[idx];
-                bool alive = lane < nb;
-                u64 keepmask = 0ull;
+                const u64 mymask = lane < nb ? s_mask[lane] : 0ull;
+                s_mask[lane] = 0ull;   // clean for the next batch
+                u64 removed = 0ull, keepmask = 0ull;
                 int nk = 0;
-                for (int i = 0; i < nb; ++i) {
-                    const u64 am = __ballot(alive);
-                    if (!((am >> i) & 1ull)) continue;
+                for (int i = 0; i < nb; ++i) {   // the sequential part of greedy NMS: ~10 scalar-ish instructions per candidate
+                    if ((removed >> i) & 1ull) continue;
                     if (kept + nk >= max_det) break;
                     keepmask |= 1ull << i;
                     ++nk;
-                    float4 bi;
-                    bi.x = __shfl(bx.x, i, 64);
-                    bi.y = __shfl(bx.y, i, 64);
-                    bi.z = __shfl(bx.z, i, 64);
-                    bi.w = __shfl(bx.w, i, 64);
-                    if (lane > i && alive && nms_iou(bi, bx) > iou_thres) alive = false;
+                    const unsigned mlo = __builtin_amdgcn_readlane((unsigned)(mymask & 0xFFFFFFFFull), i);
+                    const unsigned mhi = __builtin_amdgcn_readlane((unsigned)(mymask >> 32), i);
+                    removed |= ((u64)mhi << 32) | (u64)mlo;
                 }
                 if ((keepmask >> lane) & 1ull) {
                     const int kp = kept + __popcll(keepmask & ((1ull << lane) - 1ull));
@@ -383,7 +510,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
                 if (t > last && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
                     const float4 bj = wbox[t];
                     for (int k = k0; k < kept; ++k)
-                        if (nms_iou(kbox[k], bj) > iou_thres) {
+                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
                             atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
                             break;
                         }
@@ -412,6 +539,7 @@ __global__ __launch_bounds__(1024) void nms_sort_sweep_kernel(const float* __res
         o[5] = (float)cls;
         kept_pos[k] = (int)flat;
     }
+    pad_outputs(kept);
     if (tid == 0) out_count[b] = kept;
 }
 
@@ -461,32 +589,41 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     char* ws = (char*)d->workspace;
     u64* keys = (u64*)(ws + w.off_keys);
     int* counts = (int*)(ws + w.off_counts);
+    static const int stop0 = getenv("Y6_NMS_STOP_AFTER") ? atoi(getenv("Y6_NMS_STOP_AFTER")) : 99;
+    if (stop0 < 1) return Y6_OK;   // host-side cost of a call only
     Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * sizeof(int), s));
-    // rows per block: as many as fit a 48 KiB staging area (64 rows x 80 classes = 40 KiB)
-    const int per_row = ml ? d->nc : 1;
-    int rpb = 6144 / per_row;
-    rpb = rpb > 64 ? 64 : (rpb < 4 ? 4 : (rpb / 4) * 4);
-    const size_t stage_bytes = (size_t)rpb * per_row * sizeof(u64) + (size_t)rpb * (d->nc + 5) * sizeof(float);   // keys + row image
-    Y6_REQUIRE(stage_bytes <= 160 * 1024 - 1024, "nms: %d classes do not fit the LDS staging area", d->nc);
-    static bool cand_attr = false;
-    if (stage_bytes > 48 * 1024 && !cand_attr) {
-        Y6_HIP(hipFuncSetAttribute((const void*)nms_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   160 * 1024 - 1024));
-        cand_attr = true;
-    }
+    // rows per block: up to 64, bounded by kCandTasks (row, 8-class) tasks per thread
+    const int npc = (d->nc + 7) / 8;
+    int rpb = (256 * kCandTasks) / npc;
+    rpb = rpb > 64 ? 64 : (rpb < 1 ? 1 : rpb);
+    Y6_REQUIRE(npc <= 256 * kCandTasks, "nms: %d classes exceed the candidate kernel's task budget", d->nc);
+    const size_t stage_bytes = (size_t)rpb * (d->nc + 5) * sizeof(float) + (size_t)rpb * sizeof(int);   // row image + row flags
+    Y6_REQUIRE(stage_bytes <= 64 * 1024, "nms: %d classes do not fit the LDS row image", d->nc);
     const unsigned blocks = (unsigned)d->B * (unsigned)((d->A + rpb - 1) / rpb);
     hipLaunchKernelGGL(nms_candidates_kernel, dim3(blocks), dim3(256), stage_bytes, s, d->pred, d->B, d->A, d->nc,
                        d->conf_thres, d->classes, d->n_classes, ml, rpb, keys, w.cap, counts);
     Y6_LAUNCH_CHECK();
-    const size_t lds = kSweepLds > (size_t)kLdsKeys * sizeof(u64) ? kSweepLds : (size_t)kLdsKeys * sizeof(u64);
+    static const int stop_after = getenv("Y6_NMS_STOP_AFTER") ? atoi(getenv("Y6_NMS_STOP_AFTER")) : 99;   // stage timing (tools/nms_bench.py)
+    if (stop_after < 2) return Y6_OK;
+    // sort: chunks, then rank-merge into the (otherwise unused) box area of the workspace
+    u64* sorted = (u64*)(ws + w.off_boxes);
+    int cpi = (int)(w.cap / kChunk) > 0 ? (int)(w.cap / kChunk) : 1;
+    if (cpi > 16) cpi = 16;   // blocks per image in the sort grids (each walks the image's chunks with this stride)
+    hipLaunchKernelGGL(nms_chunk_sort_kernel, dim3((unsigned)(d->B * cpi)), dim3(256), 0, s, keys, w.cap, counts, cpi);
+    Y6_LAUNCH_CHECK();
+    if (stop_after < 3) return Y6_OK;
+    hipLaunchKernelGGL(nms_merge_rank_kernel, dim3((unsigned)(d->B * cpi)), dim3(256), 0, s, keys, w.cap, counts, cpi,
+                       sorted, d->max_nms);
+    Y6_LAUNCH_CHECK();
+    if (stop_after < 4) return Y6_OK;
+    const size_t lds = kSweepLds;
     static bool attr_set = false;
     if (!attr_set) {
-        Y6_HIP(hipFuncSetAttribute((const void*)nms_sort_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Y6_HIP(hipFuncSetAttribute((const void*)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nms_sort_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres,
-                       d->agnostic, d->max_det, d->max_nms, d->max_wh, keys, w.cap, counts, d->out_dets, d->out_index,
-                       d->out_count);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
+                       d->max_det, d->max_nms, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

@@ -38,9 +38,10 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     nc = no - 5
     dev = pred.device
     ml = bool(multi_label) and nc > 1
-    dets = torch.zeros((B, max_det, 6), dtype=torch.float32, device=dev)
-    index = torch.full((B, max_det), -1, dtype=torch.int32, device=dev)
-    count = torch.zeros((B,), dtype=torch.int32, device=dev)
+    # no fills: y6_nms writes every element (rows past the kept count become 0 / -1)
+    dets = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+    index = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
     nbytes = lib.y6_nms_workspace_bytes(B, A, nc, int(ml))
     ws = _workspace(dev, nbytes)
     cls_t = None
