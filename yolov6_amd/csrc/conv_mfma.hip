@@ -750,24 +750,31 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvKAr
 // ---------------------------------------------------------------------------------------------
 constexpr int PIXP = 48;
 
-template <int CF, int PF, int WPS>
-__global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArgs a) {
+template <int BP>
+struct PipeHaloCap {   // halo pixels (3x3 stride 1) of the largest tile shape offered for BP output pixels
+    static constexpr int value = BP <= 128 ? 208 : (BP <= 256 ? 352 : (BP <= 512 ? 660 : 1190));
+};
+
+// NW waves per block: 4 (two blocks per CU) or 8 (one block per CU, twice the pixels sharing one weight image)
+template <int CF, int PF, int WPS, int NW>
+__global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const ConvKArgs a) {
+    constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 9;
     constexpr int WQ = CF * NT * 64;             // 16-byte units of one 16-channel weight image (CF x 9 KiB)
-    constexpr int NWR = (WQ + 255) / 256;
-    constexpr int MAXHP = HaloCap<3, 1, PF>::value;
-    constexpr int NP = (MAXHP * 2 + 255) / 256;  // two 16-byte pieces per halo pixel
+    constexpr int NWR = (WQ + NTHR - 1) / NTHR;
+    constexpr int MAXHP = PipeHaloCap<NW * PF * 32>::value;
+    constexpr int NP = (MAXHP * 2 + NTHR - 1) / NTHR;  // two 16-byte pieces per halo pixel
     constexpr int NL = NP + NWR;                 // staged 16-byte pieces per thread per chunk
     constexpr int LPT = (NL + 3) / 4;            // pieces published + re-requested per tap in taps 0-3
-    constexpr int WQP = NWR * 256;               // weight buffer padded so that the publish needs no predicate
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     char* ldsA = smem;                            // 2 x ldsA_bytes
-    char* ldsW = smem + 2 * a.ldsA_bytes;         // 2 x WQP*16
-    float* ldsBias = reinterpret_cast<float*>(ldsW + 2 * WQP * 16);
+    char* ldsW = smem + 2 * a.ldsA_bytes;         // 2 x WQ*16
+    float* ldsBias = reinterpret_cast<float*>(ldsW + 2 * WQ * 16);
+    char* ldsDump = reinterpret_cast<char*>(ldsBias + 2 * CF * 32);   // 16 bytes: where the staging threads without a piece publish
     const int nids = a.nids;
     const int gstride = gridDim.x;
     const int nch = (a.Cin + 15) >> 4;
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
         const int iy0 = ty_i * a.TH - 1, ix0 = tx_i * a.TW - 1;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NTHR;
             int g = -1;
             if (idx < npieces) {
                 const int hp = idx >> 1, q = idx & 1;
@@ -827,14 +834,28 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     int woff[NWR];
 #pragma unroll
     for (int j = 0; j < NWR; ++j) {
-        const int q = tid + j * 256;
+        const int q = tid + j * NTHR;
         const int cf = q / (NT * 64), r = q - cf * (NT * 64);
         woff[j] = (q < WQ) ? (cf * a.nchunk * NT * 2 * 64 + (r >> 6) * 2 * 64 + (r & 63)) * 8 : 0;   // pad threads re-read piece 0
     }
-    int pixoff[PF], opix[PF], cb = 0;
+    // LDS offsets of this lane's pixels (needed all through the chunk loop) and, separately, their output
+    // pixel indices (needed by the epilogue only: computed there so they are not live across the loop)
+    int pixoff[PF], cb = 0;
     auto setup_pix = [&](int item) {
         int tile;
         decode(item, tile, cb);
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+            const int npx = a.TH * a.TW;
+            const int mm = m < npx ? m : npx - 1;
+            const int ty = mm / a.TW, tx = mm - ty * a.TW;
+            pixoff[pf] = (ty * a.HWd + tx) * PIXP + (lane >> 5) * 16;
+        }
+    };
+    auto out_pix = [&](int item, int (&opix)[PF]) {
+        int tile, cbx;
+        decode(item, tile, cbx);
         const int tx_i = tile % a.tiles_x;
         const int t2 = tile / a.tiles_x;
         const int ty_i = t2 % a.tiles_y;
@@ -849,7 +870,6 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
             const int ty = mm / a.TW, tx = mm - ty * a.TW;
             const int oy = oy0 + ty, ox = ox0 + tx;
             v = v && (oy < a.Ho) && (ox < a.Wo);
-            pixoff[pf] = (ty * a.HWd + tx) * PIXP + (lane >> 5) * 16;
             opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
         }
     };
@@ -891,7 +911,7 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     unsigned stg_ok = 0;
     auto load_piece = [&](int k) {
         if (k < NP) {
-            const int q = (tid + k * 256) & 1;
+            const int q = (tid + k * NTHR) & 1;
             const bool ok = goff[k] >= 0 && (nx_cin0 + q * 8) < a.Cin;
             stg[k] = *reinterpret_cast<const uint4*>(a.in + (ok ? goff[k] + nx_cin0 : 0));
             stg_ok = ok ? (stg_ok | (1u << k)) : (stg_ok & ~(1u << k));
@@ -901,13 +921,15 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
     };
     auto store_piece = [&](int k, int buf) {
         if (k < NP) {
-            const int idx = tid + k * 256;
+            const int idx = tid + k * NTHR;
             uint4 v = stg[k];
             if (!((stg_ok >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16) = v;
+            char* dst = ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16;
+            *reinterpret_cast<uint4*>(idx < npieces ? dst : ldsDump) = v;   // address select, not a branch
         } else {
-            const int q = tid + (k - NP) * 256;
-            *reinterpret_cast<uint4*>(ldsW + (buf * WQP + q) * 16) = stg[k];
+            const int q = tid + (k - NP) * NTHR;
+            char* dst = ldsW + (buf * WQ + q) * 16;
+            *reinterpret_cast<uint4*>(q < WQ ? dst : ldsDump) = stg[k];
         }
     };
 
@@ -953,20 +975,31 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
             if (have_next) stage_advance();               // ... and the one after that gets requested now
             Y6_TRACE(10);
             const char* Ab = ldsA + pb * a.ldsA_bytes;
-            const char* Wb = ldsW + pb * (WQP * 16) + lane * 16;
-            h8_t fa[2][CF], fb[2][PF];
-            auto ldfrag = [&](int t, int buf) {
-                const int tapoff = ((t / 3) * a.HWd + (t % 3)) * PIXP;
+            const char* Wb = ldsW + pb * (WQ * 16) + lane * 16;
+            // A fragments (pixels) are requested one tap ahead.  The weight fragments too, unless the
+            // accumulators already take 128 registers (CF*PF = 8): then they are requested at the top of
+            // their own tap and the co-resident wave covers the LDS latency.
+            constexpr int WST = (CF * PF >= 8) ? 1 : 2;
+            h8_t fa[WST][CF], fb[2][PF];
+            auto ldfragW = [&](int t, int buf) {
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const h8_t*>(Wb + (cf * NT + t) * 1024);
+            };
+            auto ldfragA = [&](int t, int buf) {
+                const int tapoff = ((t / 3) * a.HWd + (t % 3)) * PIXP;
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const h8_t*>(Ab + pixoff[pf] + tapoff);
             };
-            ldfrag(0, 0);
+            ldfragA(0, 0);
+            if (WST == 2) ldfragW(0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
+                if (WST == 1) ldfragW(t, 0);
+                if (t + 1 < NT) {
+                    ldfragA(t + 1, (t + 1) & 1);
+                    if (WST == 2) ldfragW(t + 1, (t + 1) & 1);
+                }
                 if (t < 4) {   // publish what was requested a chunk ago, then reuse the registers (no branches:
                                // past the end of the stream this republishes / re-requests the last chunk)
 #pragma unroll
@@ -981,7 +1014,7 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
                 for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf)
-                        acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t & 1][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
+                        acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WST == 2 ? (t & 1) : 0][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             Y6_TRACE(11);
@@ -993,18 +1026,22 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
             Y6_TRACE(15);
         }
         if (!synced) __syncthreads();   // no chunk barrier has published lbias yet
-        BiasRegs<CF> bz;
+        int opix[PF];
+        out_pix(id, opix);
+        // one cout fragment at a time: 16 bias registers live instead of 16*CF next to 16*CF*PF accumulators
 #pragma unroll
-        for (int cf = 0; cf < CF; ++cf)
+        for (int cf = 0; cf < CF; ++cf) {
+            BiasRegs<1> bz;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
-                bz.v[cf][g * 4 + 0] = t.x;
-                bz.v[cf][g * 4 + 1] = t.y;
-                bz.v[cf][g * 4 + 2] = t.z;
-                bz.v[cf][g * 4 + 3] = t.w;
+                bz.v[0][g * 4 + 0] = t.x;
+                bz.v[0][g * 4 + 1] = t.y;
+                bz.v[0][g * 4 + 2] = t.z;
+                bz.v[0][g * 4 + 3] = t.w;
             }
-        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
+            conv_epilogue<1, PF>(a, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
+        }
         Y6_TRACE(20);
         if (nid >= nids) break;
         id = nid;
@@ -1016,6 +1053,7 @@ __global__ __launch_bounds__(256, WPS) void conv_mfma_pipe_kernel(const ConvKArg
 struct VariantCfg {
     int cf, pf, persist;
     const char* name;
+    int nw = 4;   // waves per block (pipe kernels: 4 or 8)
 };
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
 // 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
@@ -1023,7 +1061,8 @@ const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
     {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
-    {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"}};
+    {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
+    {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1108,7 +1147,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.upH = d->in.H;
     k.upW = d->in.W;
     k.upC = up == 2 ? d->out.C / 4 : d->out.C;
-    const int bp = 128 * vc.pf;
+    const int bp = 32 * vc.nw * vc.pf;
     if (ks == 1) {
         // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row
         const long npix = (long)d->in.B * d->in.H * d->in.W;
@@ -1125,7 +1164,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.W = d->in.W;
         k.Ho = d->out.H;
         k.Wo = d->out.W;
-        choose_tile(k.Ho, k.Wo, ks, st, bp, halo_cap(ks, st, vc.pf), &k.TH, &k.TW);
+        const int cap = vc.persist == 2 ? (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190))) : halo_cap(ks, st, vc.pf);
+        choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW);
     }
     k.tiles_x = y6_cdiv(k.Wo, k.TW);
     k.tiles_y = y6_cdiv(k.Ho, k.TH);
@@ -1134,8 +1174,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.HWd = (k.TW - 1) * st + ks;
     k.nchunk = y6_cdiv(k.Cin, 32);
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
-    // pipe kernels publish unpredicated: the halo buffer covers every staging thread's slot
-    k.ldsA_bytes = vc.persist == 2 ? ((halo_cap(3, 1, vc.pf) * 2 + 255) / 256) * 128 * PIXP : k.HH * k.HWd * PIXB;
+    k.ldsA_bytes = vc.persist == 2 ? ((k.HH * k.HWd * PIXP + 15) & ~15) : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
@@ -1143,7 +1182,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     }
     L->grid = k.nids;
     if (vc.persist == 2)
-        L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)((9 * vc.cf * 64 + 255) / 256) * 4096 + 2 * vc.cf * 32 * 4;   // two buffers of halo + nine 16-channel tap images (padded), bias x2
+        L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
     else if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
     else
@@ -1203,9 +1242,9 @@ int launch_persist(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
-template <int CF, int PF, int WPS>
+template <int CF, int PF, int WPS, int NW = 4>
 int launch_pipe(const Launch& L, hipStream_t s) {
-    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS>;
+    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1216,7 +1255,7 @@ int launch_pipe(const Launch& L, hipStream_t s) {
     static int cached_bpc = 0, n_cu = 0;
     if (cached_lds != L.lds) {
         int bpc = 0;
-        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 256, L.lds));
+        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, L.lds));
         if (n_cu == 0) {
             int dev = 0;
             Y6_HIP(hipGetDevice(&dev));
@@ -1229,7 +1268,7 @@ int launch_pipe(const Launch& L, hipStream_t s) {
     grid -= grid % 8;
     if (grid < 8) grid = 8;
     if (grid > L.grid) grid = L.grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.lds, s, L.k);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), L.lds, s, L.k);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -1314,6 +1353,9 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 12: return launch_pipe<1, 2, 2>(L, s);
         case 13: return launch_pipe<4, 2, 1>(L, s);
         case 14: return launch_pipe<4, 1, 1>(L, s);
+        case 15: return launch_pipe<4, 2, 2, 8>(L, s);
+        case 16: return launch_pipe<2, 4, 2, 8>(L, s);
+        case 17: return launch_pipe<2, 2, 2, 8>(L, s);
     }
     return Y6_EINVAL;
 }
