@@ -349,6 +349,8 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                  c.post_scale != nullptr);
         return std::string(b);
     };
+    std::vector<std::vector<float>> times(p->ops.size());
+    std::vector<char> measured(p->ops.size(), 0);
     for (size_t i = 0; i < p->ops.size(); ++i) {
         Op& op = p->ops[i];
         if (op.kind != Y6_OP_CONV) continue;
@@ -366,7 +368,20 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                 continue;
             }
         }
-        for (int v = 1; v < nv; ++v) {  // variant 0 (naive) is a cross-check, never a candidate
+        std::vector<float>& row = times[i];
+        row.assign(nv, 1e30f);
+        bool reused = false;
+        for (size_t j = 0; j < i && !reused; ++j) {   // an identical layer measured earlier in this call: same numbers
+            if (!measured[j] || signature(p->ops[j].conv) != sig) continue;
+            row = times[j];
+            for (int v = 1; v < nv; ++v)
+                if (row[v] < best_ms && y6_conv_variant_supports(&op.conv, v)) {
+                    best_ms = row[v];
+                    best = v;
+                }
+            reused = best > 0;
+        }
+        for (int v = 1; v < nv && !reused; ++v) {  // variant 0 (naive) is a cross-check, never a candidate
             if (!y6_conv_variant_supports(&op.conv, v)) continue;
             Op trial = op;
             trial.conv.variant = v;
@@ -385,6 +400,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                 fprintf(logf, "op %zu k%d s%d cin %d cout %d in %dx%dx%d variant %s ms %.5f gflops %.1f\n", i,
                         op.conv.ksize, op.conv.stride, op.conv.in.C, op.conv.out.C, op.conv.in.B, op.conv.in.H,
                         op.conv.in.W, y6_conv_variant_name(v), ms, y6_conv_flops(&op.conv) / (ms * 1e6));
+            row[v] = ms;
             if (ms < best_ms) {
                 best_ms = ms;
                 best = v;
@@ -393,11 +409,38 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
         if (best < 0) best = y6_conv_variant_supports(&op.conv, 0) ? 0 : -1;
         Y6_REQUIRE(best >= 0, "plan_autotune: op %zu has no runnable conv variant", i);
         op.conv.variant = best;
-        if (cachepath && best > 0) {
-            cache.emplace_back(sig, y6_conv_variant_name(best));
-            if (FILE* cf = fopen(cachepath, "a")) {
-                fprintf(cf, "%s %s\n", sig.c_str(), y6_conv_variant_name(best));
-                fclose(cf);
+        measured[i] = best > 0;
+    }
+    // Consolidate: burst timings of the top variants are often within 1-3 % of each other, and a plan that
+    // hops between many different kernels pays for it at every switch (cold instruction cache, LDS / scratch
+    // reconfiguration: +15-35 us on the first launch after a switch, r12).  Variants are ranked by how many
+    // layers of this (ksize, stride) class they win, and a layer takes the highest ranked variant that is
+    // within 3 % of its own best time.
+    {
+        std::vector<std::vector<int>> wins(4, std::vector<int>(nv, 0));
+        auto klass = [](const y6_conv_desc& c) { return (c.ksize == 3 ? 0 : 2) + (c.stride == 2 ? 1 : 0); };
+        for (size_t i = 0; i < p->ops.size(); ++i)
+            if (measured[i]) wins[klass(p->ops[i].conv)][p->ops[i].conv.variant]++;
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            if (!measured[i]) continue;
+            Op& op = p->ops[i];
+            const std::vector<float>& row = times[i];
+            const std::vector<int>& w = wins[klass(op.conv)];
+            const float best_ms = row[op.conv.variant];
+            int pick = op.conv.variant;
+            for (int v = 1; v < nv; ++v)
+                if (row[v] <= best_ms * 1.03f && (w[v] > w[pick] || (w[v] == w[pick] && row[v] < row[pick]))) pick = v;
+            if (logf && pick != op.conv.variant)
+                fprintf(logf, "op %zu consolidated %s (%.5f ms) -> %s (%.5f ms)\n", i, y6_conv_variant_name(op.conv.variant),
+                        best_ms, y6_conv_variant_name(pick), row[pick]);
+            op.conv.variant = pick;
+            if (cachepath) {
+                const std::string sig = signature(op.conv);
+                cache.emplace_back(sig, y6_conv_variant_name(pick));
+                if (FILE* cf = fopen(cachepath, "a")) {
+                    fprintf(cf, "%s %s\n", sig.c_str(), y6_conv_variant_name(pick));
+                    fclose(cf);
+                }
             }
         }
     }
