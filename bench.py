@@ -81,6 +81,23 @@ def calibrate_head_bias(model, x, target_frac=0.02):
     return shift
 
 
+def pmc_traffic(klass):
+    """HBM bytes per launch of a kernel class from the newest committed PMC summary (profiles/*/pmc_traffic_*.json,
+    written by tools/gpu_pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so
+    this is the one roofline field that is not measured live; (None, reason) when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic_*.json")))
+    if not files:
+        return None, "no profiles/*/pmc_traffic_*.json committed"
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return int(d["classes"][klass]["hbm_bytes_per_launch"]), os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable {files[-1]}: {e}"
+
+
 def classify(row):
     if row["kind"] == "conv":
         return f"conv{row['ksize']}x{row['ksize']}s{row['stride']}"
@@ -161,6 +178,7 @@ def main():
         by_class["nms"] = dict(ms=nms_ms, flops=0.0, bytes=float(args.batch * 8400 * 85 * 4), launches=2)
         dom = by_class.get("conv3x3s1", dict(ms=0.0, flops=0.0, launches=0))
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("conv3x3s1")
         dom_variants = {}
         for r in rows:
             if classify(r) == "conv3x3s1":
@@ -184,7 +202,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "3x3 stride-1 conv+bias+act (conv_mfma.hip); variants chosen per layer: "
                                                     + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items())),
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "launches_per_step": dom["launches"], "gflop_per_step": round(dom["flops"] / 1e9, 2),
                          "ms_per_step": round(dom["ms"], 4)},
             "forward": {"ms": round(fwd_ms, 4), "tflops": round(total_flops / (fwd_ms * 1e-3) / 1e12, 2) if fwd_ms else 0,
