@@ -77,7 +77,7 @@ struct HaloCap {
 //     the main loop) instead of 4 dependent loads in front of every store group;
 //   * v_permlane32_swap pairs groups (g, g+1): afterwards lanes 0-31 own couts 8g..8g+7 and lanes 32-63
 //     own 8(g+1)..8(g+1)+7 of their pixel -> ONE 16-byte store per lane per pair instead of two 8-byte
-//     ones (the scattered 8-byte stores were store-issue bound: profiles/ ablation r04).
+//     ones (the scattered 8-byte stores were store-issue bound: profiles/r01/conv_ablation_abl01.log).
 // finish(): acc + bias -> (affine) -> activation -> (+alpha*residual), for the 16 values a lane holds of one
 // fragment.  All mode decisions are wave-uniform and hoisted out of the element loop (the r07 trace
 // showed ~4000 cycles per fragment when `switch(act)` / affine / residual were tested per element).
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // Persistent, chunk-granular variant (3x3 only).  What the r03-r08 counters and the s_memtime trace
-// (profiles/r01/conv_trace_r08.txt) showed for the per-tap kernel above and the first persistent cuts:
+// (tools/conv_trace.py; numbers in DESIGN.md §6) showed for the per-tap kernel above and the first persistent cuts:
 //   * per-tap barriers + in-order vmcnt waits parked the waves ~50 % of the time;
 //   * every 1 KiB LDS-DMA piece costs 100-185 cycles of ISSUE time in the wave that issues it
 //     (nine pieces + the halo loads = ~2500 cycles per chunk against 2304 cycles of MFMA);

@@ -662,10 +662,12 @@ static int check_conv_desc(const y6_conv_desc* d) {
 
 // default variant when a plan was not autotuned
 static int default_variant(const y6_conv_desc* d) {
-    const int prefs_s1[] = {2, 1, 5, 4, 3, 6, 0};   // measured: high-occupancy small tiles win (profiles/r01)
+    // measured (profiles/r01 autotune logs): the pipelined persistent kernel wins 3x3 stride 1 (variants 10-12 are
+    // skipped by `supports` for 1x1); elsewhere high-occupancy small tiles win
+    const int prefs_s1[] = {10, 11, 12, 2, 1, 5, 4, 3, 6, 0};
     const int prefs_s2[] = {2, 1, 3, 0};
     const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
-    const int n = d->stride == 1 ? 7 : 4;
+    const int n = d->stride == 1 ? 10 : 4;
     for (int i = 0; i < n; ++i)
         if (y6_conv_variant_supports(d, prefs[i])) return prefs[i];
     return -1;

