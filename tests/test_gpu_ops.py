@@ -18,6 +18,7 @@ CONV_SHAPES = [
     (128, 128, 3, 1, 20, 20, 3),   # 20x20: ragged 2-D tile
     (256, 256, 3, 1, 10, 14, 2),   # non-square, smaller than one tile
     (128, 256, 3, 2, 20, 20, 2),
+    (64, 96, 3, 2, 33, 47, 2),     # stride 2, odd sizes, Cout 96 (three fragments): ragged tiles of the de-interleaved halo
     (512, 256, 1, 1, 20, 20, 2),   # CSPSPPF cv1
     (192, 64, 1, 1, 13, 17, 2),    # BiFusion cv3 (Cin = 3*64), odd sizes
     (64, 80, 1, 1, 20, 20, 2),     # cls_pred: Cout not a multiple of 32

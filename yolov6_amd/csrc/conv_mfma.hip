@@ -756,14 +756,18 @@ struct PipeHaloCap {   // halo pixels (3x3 stride 1) of the largest tile shape o
 };
 
 // NW waves per block: 4 (two blocks per CU) or 8 (one block per CU, twice the pixels sharing one weight image)
-template <int CF, int PF, int WPS, int NW>
+// ST = 2 (stride-2 3x3): the halo is stored with its even and odd columns de-interleaved -
+//   slot(hy, hx) = (2*hy + (hx & 1)) * HWp + (hx >> 1),  HWp = (HWd + 1) / 2
+// so that the 32 output pixels of a fragment (input columns 2*tx + kx) read 32 CONSECUTIVE slots for every tap,
+// conflict-free like stride 1 (read in place they would stride by 96 bytes = 6 slots: 2-way conflicts and more).
+template <int CF, int PF, int WPS, int NW, int ST = 1>
 __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const ConvKArgs a) {
     constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 9;
     constexpr int WQ = CF * NT * 64;             // 16-byte units of one 16-channel weight image (CF x 9 KiB)
     constexpr int NWR = (WQ + NTHR - 1) / NTHR;
-    constexpr int MAXHP = PipeHaloCap<NW * PF * 32>::value;
+    constexpr int MAXHP = ST == 1 ? PipeHaloCap<NW * PF * 32>::value : 1280;   // stride 2: 256-pixel tiles only (9x130 slots at most)
     constexpr int NP = (MAXHP * 2 + NTHR - 1) / NTHR;  // two 16-byte pieces per halo pixel
     constexpr int NL = NP + NWR;                 // staged 16-byte pieces per thread per chunk
     constexpr int LPT = (NL + 3) / 4;            // pieces published + re-requested per tap in taps 0-3
@@ -814,7 +818,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
         const int t2 = tile / a.tiles_x;
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
-        const int iy0 = ty_i * a.TH - 1, ix0 = tx_i * a.TW - 1;
+        const int iy0 = ty_i * a.TH * ST - 1, ix0 = tx_i * a.TW * ST - 1;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int idx = tid + i * NTHR;
@@ -850,7 +854,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
             const int npx = a.TH * a.TW;
             const int mm = m < npx ? m : npx - 1;
             const int ty = mm / a.TW, tx = mm - ty * a.TW;
-            pixoff[pf] = (ty * a.HWd + tx) * PIXP + (lane >> 5) * 16;
+            const int HWp = (a.HWd + 1) >> 1;
+            pixoff[pf] = (ST == 1 ? (ty * a.HWd + tx) : (4 * ty * HWp + tx)) * PIXP + (lane >> 5) * 16;
         }
     };
     auto out_pix = [&](int item, int (&opix)[PF]) {
@@ -924,7 +929,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
             const int idx = tid + k * NTHR;
             uint4 v = stg[k];
             if (!((stg_ok >> k) & 1u)) v = make_uint4(0u, 0u, 0u, 0u);
-            char* dst = ldsA + buf * a.ldsA_bytes + (idx >> 1) * PIXP + (idx & 1) * 16;
+            int slot = idx >> 1;
+            if (ST == 2) {
+                const int hy = slot / a.HWd, hx = slot - hy * a.HWd;
+                slot = (2 * hy + (hx & 1)) * ((a.HWd + 1) >> 1) + (hx >> 1);
+            }
+            char* dst = ldsA + buf * a.ldsA_bytes + slot * PIXP + (idx & 1) * 16;
             *reinterpret_cast<uint4*>(idx < npieces ? dst : ldsDump) = v;   // address select, not a branch
         } else {
             const int q = tid + (k - NP) * NTHR;
@@ -986,7 +996,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
                 for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const h8_t*>(Wb + (cf * NT + t) * 1024);
             };
             auto ldfragA = [&](int t, int buf) {
-                const int tapoff = ((t / 3) * a.HWd + (t % 3)) * PIXP;
+                const int tapoff = (ST == 1 ? ((t / 3) * a.HWd + (t % 3))
+                                            : ((2 * (t / 3) + ((t % 3) & 1)) * ((a.HWd + 1) >> 1) + ((t % 3) >> 1))) * PIXP;
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const h8_t*>(Ab + pixoff[pf] + tapoff);
             };
@@ -1054,6 +1065,7 @@ struct VariantCfg {
     int cf, pf, persist;
     const char* name;
     int nw = 4;   // waves per block (pipe kernels: 4 or 8)
+    int st = 1;   // pipe kernels: the stride they are built for
 };
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
 // 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
@@ -1062,7 +1074,8 @@ const VariantCfg kVariants[] = {
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
     {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
     {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
-    {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8}};
+    {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8},
+    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1164,7 +1177,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.W = d->in.W;
         k.Ho = d->out.H;
         k.Wo = d->out.W;
-        const int cap = vc.persist == 2 ? (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190))) : halo_cap(ks, st, vc.pf);
+        const int cap = vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
         choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW);
     }
     k.tiles_x = y6_cdiv(k.Wo, k.TW);
@@ -1174,7 +1187,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.HWd = (k.TW - 1) * st + ks;
     k.nchunk = y6_cdiv(k.Cin, 32);
     k.ncb = y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf);
-    k.ldsA_bytes = vc.persist == 2 ? ((k.HH * k.HWd * PIXP + 15) & ~15) : k.HH * k.HWd * PIXB;
+    k.ldsA_bytes = vc.persist == 2 ? (st == 2 ? k.HH * 2 * ((k.HWd + 1) / 2) * PIXP : ((k.HH * k.HWd * PIXP + 15) & ~15))
+                                   : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
@@ -1242,9 +1256,9 @@ int launch_persist(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
-template <int CF, int PF, int WPS, int NW = 4>
+template <int CF, int PF, int WPS, int NW = 4, int ST = 1>
 int launch_pipe(const Launch& L, hipStream_t s) {
-    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW>;
+    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW, ST>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1312,7 +1326,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (st == 2 && vc.pf != 1) return 0;
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
-    if (vc.persist == 2 && st != 1) return 0;
+    if (vc.persist == 2 && st != vc.st) return 0;
     if (d->w_packed == nullptr) return 0;
     // 16-byte halo pieces need 8-channel alignment of the input view
     if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -1356,6 +1370,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 15: return launch_pipe<4, 2, 2, 8>(L, s);
         case 16: return launch_pipe<2, 4, 2, 8>(L, s);
         case 17: return launch_pipe<2, 2, 2, 8>(L, s);
+        case 18: return launch_pipe<2, 1, 2, 8, 2>(L, s);
+        case 19: return launch_pipe<1, 1, 2, 8, 2>(L, s);
     }
     return Y6_EINVAL;
 }
