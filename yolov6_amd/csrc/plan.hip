@@ -349,6 +349,22 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                  c.post_scale != nullptr);
         return std::string(b);
     };
+    // Candidate set.  Timing a layer alone in a burst flatters kernels that lose in sequence: with every
+    // variant allowed the plan hops between seven kernels and the whole step is 2.4 % slower than with the
+    // per-tap kernels + pipe_c2p2/pipe_c2p1 only (same box, tools/gpu_ab_variants.sh, r13).  The others stay
+    // built, tested and selectable: Y6_AUTOTUNE_EXCLUDE="" allows all, "15,16" excludes just those.
+    std::vector<char> excluded(nv, 0);
+    const char* ex = getenv("Y6_AUTOTUNE_EXCLUDE");
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19";
+    {
+        for (const char* c = ex; *c;) {
+            char* end = nullptr;
+            const long v = strtol(c, &end, 10);
+            if (end == c) break;
+            if (v >= 0 && v < nv) excluded[v] = 1;
+            c = (*end == ',') ? end + 1 : end;
+        }
+    }
     std::vector<std::vector<float>> times(p->ops.size());
     std::vector<char> measured(p->ops.size(), 0);
     for (size_t i = 0; i < p->ops.size(); ++i) {
@@ -382,7 +398,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             reused = best > 0;
         }
         for (int v = 1; v < nv && !reused; ++v) {  // variant 0 (naive) is a cross-check, never a candidate
-            if (!y6_conv_variant_supports(&op.conv, v)) continue;
+            if (!y6_conv_variant_supports(&op.conv, v) || excluded[v]) continue;
             Op trial = op;
             trial.conv.variant = v;
             float ms = 1e30f;
