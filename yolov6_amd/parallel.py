@@ -24,6 +24,10 @@ class Replicas:
             if backend is None:
                 backend = "nccl" if torch.cuda.is_available() else "gloo"
             self.backend = backend
+            if backend == "nccl":
+                # bind this process to its GPU BEFORE the communicator exists: RCCL's lazy init and every
+                # device-less barrier use the current device
+                torch.cuda.set_device(self.local_rank)
             if not dist.is_initialized():
                 dist.init_process_group(backend, init_method="env://", rank=self.rank, world_size=self.world)
             self.dist = dist
@@ -40,7 +44,10 @@ class Replicas:
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
         """MAX all-reduce of a host scalar (the bench reports the slowest rank's time)."""
@@ -63,6 +70,6 @@ class Replicas:
 
     def close(self):
         if self.dist is not None and self.dist.is_initialized():
-            self.dist.barrier()
+            self.barrier()
             self.dist.destroy_process_group()
             self.dist = None
