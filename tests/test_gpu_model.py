@@ -98,6 +98,24 @@ def test_graph_capture_matches_eager():
     assert torch.equal(out, eager)
 
 
+@pytest.mark.parametrize("case", ["tiny"])
+def test_multistream_graph_matches_eager(case, monkeypatch):
+    """Y6_GRAPH_STREAMS=2 (experimental path): independent branches (head levels, cls/reg, neck laterals) are captured on two streams;
+    the dependence analysis must keep every RAW/WAR/WAW edge - replays are bit-identical to the eager run."""
+    cfg, meta, sd, m = _build(case, deploy=True)
+    x = synth.synth_images(meta["batch"], meta["size"], seed=8).to(DEV).half()
+    plan = m.compile(x)
+    eager = plan.run().clone()
+    monkeypatch.setenv("Y6_GRAPH_STREAMS", "2")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        plan.capture()
+        outs = [plan.run().clone() for _ in range(5)]
+    s.synchronize()
+    for o in outs:
+        assert torch.equal(o, eager)
+
+
 def test_training_mode_is_refused_not_faked():
     cfg, meta, sd, m = _build("tiny", deploy=False)
     m.train()

@@ -19,5 +19,7 @@ plan.timing_begin(40)
 print("eager run_timed  %.4f ms (%s events)" % (timeit(plan.run_timed), os.environ.get("Y6_TIMED_EVENTS", "op")))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
-    plan.capture()
-    print("graph replay     %.4f ms" % timeit(plan.run))
+    for ns in ("1", "2"):
+        os.environ["Y6_GRAPH_STREAMS"] = ns
+        plan.capture()
+        print("graph replay, %s capture stream(s)  %.4f ms" % (ns, timeit(plan.run)))

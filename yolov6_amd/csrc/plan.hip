@@ -309,25 +309,177 @@ extern "C" int y6_plan_run(y6_plan* p, void* stream) {
     return Y6_OK;
 }
 
+// ---- data dependences between ops (for the multi-stream capture) -------------------------------------
+namespace {
+struct Span {            // channel slice [c0, c1) of the buffer at `base` (whole buffer: [0, INT_MAX))
+    const void* base;
+    int c0, c1;
+};
+inline bool overlaps(const Span& a, const Span& b) { return a.base && a.base == b.base && a.c0 < b.c1 && b.c0 < a.c1; }
+inline Span span_of(const y6_tensor& t) { return Span{t.data, t.coff, t.coff + t.C}; }
+inline Span whole(const void* p) { return Span{p, 0, 0x7fffffff}; }
+
+void op_access(const Op& op, std::vector<Span>* rd, std::vector<Span>* wr) {
+    switch (op.kind) {
+        case Y6_OP_CONV:
+            rd->push_back(span_of(op.conv.in));
+            if (op.conv.res.data) rd->push_back(span_of(op.conv.res));
+            wr->push_back(span_of(op.conv.out));
+            break;
+        case Y6_OP_CONVT:
+            rd->push_back(span_of(op.convt.in));
+            wr->push_back(span_of(op.convt.out));
+            break;
+        case Y6_OP_STEM:
+            rd->push_back(whole(op.stem.in_nchw));
+            wr->push_back(span_of(op.stem.out));
+            break;
+        case Y6_OP_SPPF:
+            rd->push_back(span_of(op.t[0]));
+            for (int i = 1; i < 4; ++i) wr->push_back(span_of(op.t[i]));
+            break;
+        case Y6_OP_DECODE:
+            for (int l = 0; l < op.dec.n_levels; ++l) {
+                rd->push_back(span_of(op.dec.cls[l]));
+                rd->push_back(span_of(op.dec.reg[l]));
+            }
+            wr->push_back(whole(op.dec.out));
+            break;
+        case Y6_OP_NCHW2NHWC:
+            rd->push_back(whole(op.src));
+            wr->push_back(span_of(op.t[0]));
+            break;
+        case Y6_OP_NHWC2NCHW:
+            rd->push_back(span_of(op.t[0]));
+            wr->push_back(whole(op.dst));
+            break;
+    }
+}
+}  // namespace
+
+// Capture the plan into a hipGraph.  EXPERIMENTAL, off by default: with Y6_GRAPH_STREAMS=2 independent ops - the three head levels
+// and their cls / reg branches, the neck's lateral convs - are captured on two streams joined by events, so the
+// graph has parallel branches and a replay can overlap their latency-bound small kernels.  Dependences are
+// derived from the tensor views (RAW, WAR, WAW on overlapping channel slices of the same buffer).  Measured on
+// YOLOv6-S b32 (tools/graph_ab.py, r14): 2.831 ms with one stream, 2.768 ms with two - the persistent conv
+// kernels already fill the chip, so overlapping them buys 2 %; not used by bench.py.
 extern "C" int y6_plan_capture(y6_plan* p, void* stream) {
     Y6_REQUIRE(p, "plan_capture: null plan");
     hipStream_t s = (hipStream_t)stream;
     drop_graph(p);
+    int nstreams = 1;
+    if (const char* e = getenv("Y6_GRAPH_STREAMS")) nstreams = atoi(e);
+    const bool dbg = getenv("Y6_PLAN_DEBUG") != nullptr;
+#define Y6_DBG(...) do { if (dbg) { fprintf(stderr, "[plan_capture] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
+    Y6_DBG("begin: %zu ops, %d streams", p->ops.size(), nstreams);
+    if (nstreams < 1) nstreams = 1;
+    if (nstreams > 2) nstreams = 2;   // hipStreamEndCapture of a 4-stream capture of the P6 models crashes inside the runtime (ROCm 7.2): capped
+    const size_t n = p->ops.size();
+
+    std::vector<hipStream_t> st(nstreams, s);
+    std::vector<hipEvent_t> ev(n + 1, nullptr);   // ev[i]: recorded after op i when another stream needs it; ev[n]: start
+    std::vector<std::vector<int>> deps(n);
+    if (nstreams > 1) {
+        std::vector<std::vector<Span>> rd(n), wr(n);
+        for (size_t i = 0; i < n; ++i) op_access(p->ops[i], &rd[i], &wr[i]);
+        for (size_t j = 0; j < n; ++j)
+            for (size_t i = 0; i < j; ++i) {
+                bool d = false;
+                for (const Span& w : wr[i]) {
+                    for (const Span& r : rd[j]) d = d || overlaps(w, r);
+                    for (const Span& w2 : wr[j]) d = d || overlaps(w, w2);
+                }
+                for (const Span& r : rd[i])
+                    for (const Span& w2 : wr[j]) d = d || overlaps(r, w2);
+                if (d) deps[j].push_back((int)i);
+            }
+        for (int k = 1; k < nstreams; ++k) Y6_HIP(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+    }
+    auto cleanup = [&]() {
+        for (int k = 1; k < nstreams; ++k)
+            if (st[k] != s) (void)hipStreamDestroy(st[k]);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    };
+
+    Y6_DBG("deps computed");
     Y6_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = Y6_OK;
-    for (size_t i = 0; i < p->ops.size() && rc == Y6_OK; ++i) rc = run_op(p->ops[i], s);
+    hipError_t herr = hipSuccess;
+#define Y6_CAP(call)                                    \
+    do {                                                \
+        if (rc == Y6_OK && herr == hipSuccess) herr = (call); \
+    } while (0)
+    std::vector<int> on(n, 0);                 // stream of op i
+    std::vector<int> tail(nstreams, -1);       // last op queued on stream k
+    std::vector<char> joined(nstreams, 0);     // stream k is part of the capture
+    joined[0] = 1;
+    if (nstreams > 1) {
+        Y6_CAP(hipEventCreateWithFlags(&ev[n], hipEventDisableTiming));
+        Y6_CAP(hipEventRecord(ev[n], s));
+    }
+    for (size_t j = 0; j < n && rc == Y6_OK && herr == hipSuccess; ++j) {
+        int k = 0;
+        if (nstreams > 1) {
+            // stay on the stream of the latest producer if nothing was queued behind it; else take the stream
+            // that has been idle longest
+            k = -1;
+            int latest = -1;
+            for (int d : deps[j])
+                if (d > latest) latest = d;
+            if (latest >= 0 && tail[on[latest]] == latest) k = on[latest];
+            if (k < 0) {
+                k = 0;
+                for (int q = 1; q < nstreams; ++q)
+                    if (tail[q] < tail[k]) k = q;
+            }
+            if (!joined[k]) {
+                Y6_CAP(hipStreamWaitEvent(st[k], ev[n], 0));
+                joined[k] = 1;
+            }
+            for (int d : deps[j]) {
+                if (on[d] == k) continue;   // same stream: in order
+                Y6_CAP(hipStreamWaitEvent(st[k], ev[d], 0));
+            }
+        }
+        Y6_DBG("op %zu kind %d -> stream %d (%zu deps) herr %d", j, p->ops[j].kind, k, deps[j].size(), (int)herr);
+        if (rc == Y6_OK && herr == hipSuccess) rc = run_op(p->ops[j], st[k]);
+        if (nstreams > 1) {   // every op gets its event right behind it (a late record hangs off unrelated later ops)
+            Y6_CAP(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
+            Y6_CAP(hipEventRecord(ev[j], st[k]));
+        }
+        on[j] = k;
+        tail[k] = (int)j;
+    }
+    // join every side stream back into the origin stream
+    for (int k = 1; k < nstreams && rc == Y6_OK && herr == hipSuccess; ++k) {
+        if (!joined[k]) continue;
+        hipEvent_t je = nullptr;
+        Y6_CAP(hipEventCreateWithFlags(&je, hipEventDisableTiming));
+        ev.push_back(je);
+        Y6_CAP(hipEventRecord(je, st[k]));
+        Y6_CAP(hipStreamWaitEvent(s, je, 0));
+    }
+#undef Y6_CAP
+    Y6_DBG("joined; rc %d herr %d", rc, (int)herr);
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(s, &g);
+    Y6_DBG("end capture: %d graph %p", (int)e, (void*)g);
+    cleanup();
+    Y6_DBG("cleanup done");
     if (rc) {
         if (g) (void)hipGraphDestroy(g);
         return rc;
     }
-    if (e != hipSuccess) {
-        y6_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    if (herr != hipSuccess || e != hipSuccess) {
+        if (g) (void)hipGraphDestroy(g);
+        y6_set_error("plan_capture failed: %s", hipGetErrorString(herr != hipSuccess ? herr : e));
         return Y6_EHIP;
     }
     p->graph = g;
     Y6_HIP(hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0));
+    Y6_DBG("instantiated");
+#undef Y6_DBG
     return Y6_OK;
 }
 
