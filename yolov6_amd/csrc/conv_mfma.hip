@@ -44,6 +44,7 @@ struct ConvKArgs {
     int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
     unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
+    int ceiling_probe;        // WRONG RESULTS, timing only (env Y6_CONV_PROBE): 1 = skip the pixel-fragment reads of taps kx=1,2; 2 = skip the weight-fragment reads of taps > 0; 3 = no fill (global loads + LDS publishes); 4 = no chunk barrier; 5 = no MFMAs; 6 = no epilogue stores
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -760,7 +761,7 @@ struct PipeHaloCap {   // halo pixels (3x3 stride 1) of the largest tile shape o
 //   slot(hy, hx) = (2*hy + (hx & 1)) * HWp + (hx >> 1),  HWp = (HWd + 1) / 2
 // so that the 32 output pixels of a fragment (input columns 2*tx + kx) read 32 CONSECUTIVE slots for every tap,
 // conflict-free like stride 1 (read in place they would stride by 96 bytes = 6 slots: 2-way conflicts and more).
-template <int CF, int PF, int WPS, int NW, int ST = 1>
+template <int CF, int PF, int WPS, int NW, int ST = 1, int DEPTH = 2>
 __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const ConvKArgs a) {
     constexpr int NTHR = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -879,11 +880,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
         }
     };
 
-    uint4 stg[NL];
-    // Staging cursor: the (item, chunk) whose data is being requested from global memory.  It runs TWO
-    // chunks ahead of the chunk being multiplied: a piece is requested during chunk c, published to the
-    // free LDS buffer during chunk c+1 (a whole chunk of MFMAs later, so the publish never waits on the
-    // load), and consumed in chunk c+2.
+    // Staging cursor: the (item, chunk) whose data is being requested from global memory.  It runs DEPTH
+    // chunks ahead of the chunk being multiplied.  DEPTH = 2: a piece is requested during chunk c, published
+    // to the free LDS buffer during chunk c+1 (a whole chunk of MFMAs later) and consumed in chunk c+2.
+    // DEPTH = 3: the HALO pieces (HBM / MALL latency) are requested during chunk c, held in registers through
+    // chunk c+1, published during chunk c+2 and consumed in chunk c+3 - two register sets alternate and the
+    // load has TWO chunk periods to arrive; the weight pieces (always L2 hits) stay at depth 2.
+    // (ceiling probes, DESIGN.md §6: with one period the fill side alone runs at the full kernel's speed).
+    uint4 stg0[NL];                        // halo pieces [0, NP) + weight pieces [NP, NL)
+    uint4 stg1[DEPTH == 3 ? NP : 1];       // second halo set
+    unsigned ok0 = 0, ok1 = 0;
+    size_t w_wbase = 0;                    // DEPTH 3: weight image of the chunk ONE behind the cursor
     int s_item = id, s_chunk = 0, s_wcb = 0;
     int nx_cin0 = 0;        // first input channel of the staged chunk
     size_t nx_wbase = 0;    // element offset of its weight image for cf = 0
@@ -892,6 +899,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
         nx_wbase = (((size_t)s_wcb * CF * a.nchunk + (s_chunk >> 1)) * NT * 2 + (s_chunk & 1)) * 64 * 8;
     };
     auto stage_advance = [&]() {
+        w_wbase = nx_wbase;
         if (s_item >= nids) return;   // end of this block's stream: keep re-requesting the last (valid) chunk
         if (s_chunk + 1 < nch) {
             ++s_chunk;
@@ -913,18 +921,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
     // base and are zeroed at publish time through a per-thread flag word, pad threads re-read weight piece 0
     // into the buffers' pad area.  With exec-masked branches around them hipcc's waitcnt insertion falls
     // back to vmcnt(0) before every ds_write, i.e. the full load latency four times per chunk.
-    unsigned stg_ok = 0;
-    auto load_piece = [&](int k) {
+    auto load_piece = [&](int k, uint4* stg, unsigned& stg_ok, size_t wbase) {
         if (k < NP) {
             const int q = (tid + k * NTHR) & 1;
             const bool ok = goff[k] >= 0 && (nx_cin0 + q * 8) < a.Cin;
             stg[k] = *reinterpret_cast<const uint4*>(a.in + (ok ? goff[k] + nx_cin0 : 0));
             stg_ok = ok ? (stg_ok | (1u << k)) : (stg_ok & ~(1u << k));
         } else {
-            stg[k] = *reinterpret_cast<const uint4*>(a.wpk + nx_wbase + woff[k - NP]);
+            stg[k] = *reinterpret_cast<const uint4*>(a.wpk + wbase + woff[k - NP]);
         }
     };
-    auto store_piece = [&](int k, int buf) {
+    auto store_piece = [&](int k, int buf, const uint4* stg, unsigned stg_ok) {
         if (k < NP) {
             const int idx = tid + k * NTHR;
             uint4 v = stg[k];
@@ -954,12 +961,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
     setup_pix(id);
     stage_addr();
 #pragma unroll
-    for (int k = 0; k < NL; ++k) load_piece(k);
+    for (int k = 0; k < NL; ++k) load_piece(k, stg0, ok0, nx_wbase);
 #pragma unroll
-    for (int k = 0; k < NL; ++k) store_piece(k, 0);
+    for (int k = 0; k < NL; ++k) store_piece(k, 0, stg0, ok0);
     stage_advance();          // second chunk of the stream stays in registers until the first chunk's taps
+    if (DEPTH == 3) {
 #pragma unroll
-    for (int k = 0; k < NL; ++k) load_piece(k);
+        for (int k = 0; k < NP; ++k) load_piece(k, stg1, ok1, 0);
+#pragma unroll
+        for (int k = NP; k < NL; ++k) load_piece(k, stg0, ok0, nx_wbase);
+        stage_advance();      // ... and the halo of the third one too
+#pragma unroll
+        for (int k = 0; k < NP; ++k) load_piece(k, stg0, ok0, 0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) load_piece(k, stg0, ok0, nx_wbase);
+    }
     __syncthreads();
     Y6_TRACE(2);
 
@@ -979,7 +996,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
         }
         const int nid = next_valid(id);
         bool synced = false;
-        for (int chunk = 0; chunk < nch; ++chunk) {
+        auto do_chunk = [&](int chunk, uint4* astg, unsigned& astg_ok) __attribute__((always_inline)) {
             const bool last = (chunk + 1) == nch;
             const bool have_next = !last || nid < nids;   // registers hold the chunk after this one
             if (have_next) stage_advance();               // ... and the one after that gets requested now
@@ -1001,40 +1018,61 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const h8_t*>(Ab + pixoff[pf] + tapoff);
             };
-            ldfragA(0, 0);
-            if (WST == 2) ldfragW(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (WST == 1) ldfragW(t, 0);
-                if (t + 1 < NT) {
-                    ldfragA(t + 1, (t + 1) & 1);
-                    if (WST == 2) ldfragW(t + 1, (t + 1) & 1);
-                }
-                if (t < 4) {   // publish what was requested a chunk ago, then reuse the registers (no branches:
-                               // past the end of the stream this republishes / re-requests the last chunk)
-#pragma unroll
-                    for (int u = 0; u < LPT; ++u)
-                        if (t * LPT + u < NL) store_piece(t * LPT + u, pb ^ 1);
-#pragma unroll
-                    for (int u = 0; u < LPT; ++u)
-                        if (t * LPT + u < NL) load_piece(t * LPT + u);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
-#pragma unroll
-                for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-                    for (int pf = 0; pf < PF; ++pf)
-                        acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WST == 2 ? (t & 1) : 0][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
+            auto taps = [&](uint4* astg, unsigned& astg_ok) __attribute__((always_inline)) {   // astg: the halo set holding the chunk after this one
+                ldfragA(0, 0);
+                if (WST == 2) ldfragW(0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (WST == 1) ldfragW(t, 0);
+                    if (t + 1 < NT) {
+                        if (!(a.ceiling_probe == 1 && ((t + 1) % 3) != 0)) ldfragA(t + 1, (t + 1) & 1);
+                        if (WST == 2 && a.ceiling_probe != 2) ldfragW(t + 1, (t + 1) & 1);
+                    }
+                    if (t < 4 && a.ceiling_probe != 3) {   // publish the oldest staged chunk, then reuse its registers (no
+                                                           // branches: past the end of the stream this republishes /
+                                                           // re-requests the last chunk)
+#pragma unroll
+                        for (int u = 0; u < LPT; ++u) {
+                            const int kk = t * LPT + u;
+                            if (kk < NL) store_piece(kk, pb ^ 1, kk < NP ? astg : stg0, kk < NP ? astg_ok : ok0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < LPT; ++u) {
+                            const int kk = t * LPT + u;
+                            if (kk < NP) load_piece(kk, astg, astg_ok, 0);
+                            else if (kk < NL) load_piece(kk, stg0, ok0, DEPTH == 3 ? w_wbase : nx_wbase);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
+                    if (a.ceiling_probe != 5) {
+#pragma unroll
+                        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                            for (int pf = 0; pf < PF; ++pf)
+                                acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[WST == 2 ? (t & 1) : 0][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            taps(astg, astg_ok);
             Y6_TRACE(11);
             if (have_next) {
-                __syncthreads();   // next chunk published; everyone is done with this one
+                if (a.ceiling_probe != 4) __syncthreads();   // next chunk published; everyone is done with this one
                 synced = true;
                 pb ^= 1;
             }
             Y6_TRACE(15);
+        };
+        if (DEPTH == 3) {
+            // two chunks per trip so that the halo register sets alternate statically (nch is even for these
+            // variants - y6_conv_mfma_supports): the chunk after an even chunk waits in set 1, after an odd one in set 0
+            for (int chunk = 0; chunk < nch; chunk += 2) {
+                do_chunk(chunk, stg1, ok1);
+                do_chunk(chunk + 1, stg0, ok0);
+            }
+        } else {
+            for (int chunk = 0; chunk < nch; ++chunk) do_chunk(chunk, stg0, ok0);
         }
         if (!synced) __syncthreads();   // no chunk barrier has published lbias yet
         int opix[PF];
@@ -1051,7 +1089,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
                 bz.v[0][g * 4 + 2] = t.z;
                 bz.v[0][g * 4 + 3] = t.w;
             }
-            conv_epilogue<1, PF>(a, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
+            if (a.ceiling_probe != 6)
+                conv_epilogue<1, PF>(a, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
         }
         Y6_TRACE(20);
         if (nid >= nids) break;
@@ -1064,8 +1103,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
 struct VariantCfg {
     int cf, pf, persist;
     const char* name;
-    int nw = 4;   // waves per block (pipe kernels: 4 or 8)
-    int st = 1;   // pipe kernels: the stride they are built for
+    int nw = 4;      // waves per block (pipe kernels: 4 or 8)
+    int st = 1;      // pipe kernels: the stride they are built for
+    int depth = 2;   // pipe kernels: chunks the halo fill runs ahead
 };
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
 // 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
@@ -1075,7 +1115,7 @@ const VariantCfg kVariants[] = {
     {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
     {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
     {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8},
-    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}};
+    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}, {2, 2, 2, "pipe3_c2p2", 4, 1, 3}, {2, 1, 2, "pipe3_c2p1", 4, 1, 3}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1191,6 +1231,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
                                    : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
+    k.ceiling_probe = getenv("Y6_CONV_PROBE") ? atoi(getenv("Y6_CONV_PROBE")) : 0;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
@@ -1256,9 +1297,9 @@ int launch_persist(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
-template <int CF, int PF, int WPS, int NW = 4, int ST = 1>
+template <int CF, int PF, int WPS, int NW = 4, int ST = 1, int DEPTH = 2>
 int launch_pipe(const Launch& L, hipStream_t s) {
-    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW, ST>;
+    auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW, ST, DEPTH>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1327,6 +1368,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
     if (vc.persist == 2 && st != vc.st) return 0;
+    if (vc.persist == 2 && vc.depth == 3 && (y6_cdiv(d->in.C, 16) & 1)) return 0;   // two chunks per loop trip
     if (d->w_packed == nullptr) return 0;
     // 16-byte halo pieces need 8-channel alignment of the input view
     if (d->in.C % 8 || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -1372,6 +1414,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 17: return launch_pipe<2, 2, 2, 8>(L, s);
         case 18: return launch_pipe<2, 1, 2, 8, 2>(L, s);
         case 19: return launch_pipe<1, 1, 2, 8, 2>(L, s);
+        case 20: return launch_pipe<2, 2, 2, 4, 1, 3>(L, s);
+        case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
     }
     return Y6_EINVAL;
 }
