@@ -26,6 +26,8 @@ CONV_SHAPES = [
     (16, 16, 3, 1, 24, 24, 2),     # YOLOv6-N width: half-filled K chunk
     (48, 96, 3, 1, 9, 33, 1),      # M width, Cin not a multiple of 32
     (64, 68, 1, 1, 16, 16, 1),     # reg_pred with DFL (4*17)
+    (128, 96, 1, 1, 20, 23, 2),    # streaming 1x1 kernel: 8 k-steps, ragged last pixel fragment, three cout fragments
+    (256, 64, 1, 1, 10, 14, 3),    # streaming 1x1 kernel: 16 k-steps
 ]
 
 

@@ -1100,6 +1100,75 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 1x1 conv, streaming form.  A 1x1 conv is a GEMM [pixels x Cin] x [Cin x Cout] with no reuse of a pixel
+// between waves, so nothing needs LDS: the lane layout of the MFMA pixel operand (pixel = lane & 31,
+// channels (lane >> 5) * 8 .. +8 of a 16-channel k-step) IS a 16-byte piece of the NHWC row, loaded straight
+// from global memory; the weights of the block's cout fragments (CF x Cin/16 fragments) are loaded ONCE
+// into registers.  A wave then streams 32-pixel fragments: the loads of the next fragment are in flight
+// while the current one is multiplied and stored.  No LDS, no barrier - the kernel moves bytes at the speed
+// the memory system delivers them, which is what these layers (64-256 FLOP/B) need.
+// Blocks are persistent over pixel fragments; blocks that share pixels (different cout blocks) sit on the
+// same XCD.  Requires Cin = 16 * KS exactly, KS in {4, 8, 16}.
+// ---------------------------------------------------------------------------------------------
+template <int CF, int KS>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs a) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int cb = (b >> 3) % a.ncb;                       // consecutive groups of 8 blocks: one per XCD, same cout block
+    const int j = (b / (8 * a.ncb)) * 8 + (b & 7);         // pixel-stream index of this block among its cout block's
+    const int nstream = (gridDim.x / a.ncb) * 4;           // waves sharing the pixel fragments of one cout block
+    const int npix = a.W;                                  // flattened B*H*W (build_launch)
+    const int nfrag = (npix + 31) >> 5;
+
+    h8_t w[CF][KS];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            w[cf][ks] = *reinterpret_cast<const h8_t*>(
+                a.wpk + ((((size_t)(cb * CF + cf) * a.nchunk + (ks >> 1)) * 2 + (ks & 1)) * 64 + lane) * 8);
+    BiasRegs<CF> bz;
+    load_bias<CF>(a, cb, 0, lane, bz);
+
+    auto load_px = [&](int f, h8_t (&r)[KS]) {
+        int px = f * 32 + (lane & 31);
+        px = px < npix ? px : npix - 1;                    // clamped rows are computed and dropped by the epilogue
+        const __half* p = a.in + (size_t)px * a.in_cs + a.in_co + (lane >> 5) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) r[ks] = *reinterpret_cast<const h8_t*>(p + ks * 16);
+    };
+    auto compute_store = [&](int f, const h8_t (&r)[KS]) {
+        f32x16_t acc[CF][1];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[cf][0][q] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int cf = 0; cf < CF; ++cf)
+                acc[cf][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cf][ks], r[ks], acc[cf][0], 0, 0, 0);
+        const int px = f * 32 + (lane & 31);
+        int opix[1] = {px < npix ? px : -1};
+        conv_epilogue<CF, 1>(a, acc, opix, cb, 0, lane, bz);
+    };
+
+    h8_t r0[KS], r1[KS];
+    int f = j * 4 + wave;
+    if (f < nfrag) load_px(f, r0);
+    while (f < nfrag) {
+        const int f1 = f + nstream;
+        if (f1 < nfrag) load_px(f1, r1);                   // in flight during this fragment's MFMAs and stores
+        compute_store(f, r0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) r0[ks] = r1[ks];   // waits for the prefetch exactly where the next MFMAs would
+        f = f1;
+    }
+}
+
 struct VariantCfg {
     int cf, pf, persist;
     const char* name;
@@ -1115,7 +1184,8 @@ const VariantCfg kVariants[] = {
     {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
     {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
     {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8},
-    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}, {2, 2, 2, "pipe3_c2p2", 4, 1, 3}, {2, 1, 2, "pipe3_c2p1", 4, 1, 3}};
+    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}, {2, 2, 2, "pipe3_c2p2", 4, 1, 3}, {2, 1, 2, "pipe3_c2p1", 4, 1, 3},
+    {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"}};   // persist == 3: the streaming 1x1 kernel
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1328,6 +1398,42 @@ int launch_pipe(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
+template <int CF, int KS>
+int launch_stream1x1(const Launch& L, hipStream_t s) {
+    auto kern = conv1x1_stream_kernel<CF, KS>;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        Y6_HIP(hipGetDevice(&dev));
+        Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int ncb = L.k.ncb;
+    const int nfrag = (L.k.W + 31) / 32;
+    const int unit = 8 * ncb;                                   // blocks come in groups of 8 (one per XCD) per cout block
+    int groups = (n_cu * 4) / unit;                             // ~4 resident blocks per CU
+    const int need = y6_cdiv(y6_cdiv(nfrag, 4), 8);             // groups that still get at least one fragment per wave
+    if (groups > need) groups = need;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(kern, dim3(groups * unit), dim3(256), 0, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+template <int CF>
+int launch_stream1x1_cfg(const Launch& L, hipStream_t s) {
+    switch (L.k.Cin / 16) {
+        case 4: return launch_stream1x1<CF, 4>(L, s);
+        case 8:
+            if constexpr (CF == 1) return launch_stream1x1<1, 8>(L, s);
+            break;
+        case 16:
+            if constexpr (CF == 1) return launch_stream1x1<1, 16>(L, s);
+            break;
+    }
+    y6_set_error("conv1x1_stream: unsupported Cin %d", L.k.Cin);
+    return Y6_EUNSUPPORTED;
+}
+
 template <int CF, int PF>
 int launch_persist_cfg(const Launch& L, int st, hipStream_t s) {
     if (st == 1) return launch_persist<CF, PF, 1>(L, s);
@@ -1365,6 +1471,15 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     const int ks = d->ksize, st = d->stride;
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
     if (st == 2 && vc.pf != 1) return 0;
+    if (vc.persist == 3) {   // streaming 1x1: Cin = 16 * {4, 8, 16} exactly, weights in registers
+        if (ks != 1 || st != 1 || d->w_packed == nullptr) return 0;
+        const int ksn = d->in.C / 16;
+        if (d->in.C % 16 || !(ksn == 4 || ksn == 8 || ksn == 16)) return 0;
+        if (vc.cf == 2 && ksn != 4) return 0;                // two cout fragments: weights + two pixel sets + epilogue fit for Cin 64 only
+        if (d->in.cstride % 8 || d->in.coff % 8 || ((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
+        if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
+        return vc.cf <= y6_cdiv(d->out.C, 32);
+    }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
     if (vc.persist == 2 && st != vc.st) return 0;
@@ -1416,6 +1531,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 19: return launch_pipe<1, 1, 2, 8, 2>(L, s);
         case 20: return launch_pipe<2, 2, 2, 4, 1, 3>(L, s);
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
+        case 22: return launch_stream1x1_cfg<1>(L, s);
+        case 23: return launch_stream1x1_cfg<2>(L, s);
     }
     return Y6_EINVAL;
 }
