@@ -44,7 +44,6 @@ struct ConvKArgs {
     int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
     unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
-    int ceiling_probe;        // WRONG RESULTS, timing only (env Y6_CONV_PROBE): 1 = skip the pixel-fragment reads of taps kx=1,2; 2 = skip the weight-fragment reads of taps > 0; 3 = no fill (global loads + LDS publishes); 4 = no chunk barrier; 5 = no MFMAs; 6 = no epilogue stores
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
 };
 
@@ -750,6 +749,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvKAr
 // read conflict-free, as with the 80-byte pitch above.
 // ---------------------------------------------------------------------------------------------
 constexpr int PIXP = 48;
+// Ceiling probes of the pipe kernel (WRONG RESULTS, timing only): rebuild with -DY6_PIPE_PROBE=n.
+//   1 = skip the pixel-fragment reads of taps kx=1,2; 2 = skip the weight-fragment reads of taps > 0;
+//   3 = no fill (global loads + LDS publishes); 4 = no chunk barrier; 5 = no MFMAs; 6 = no epilogue stores.
+// Compile-time on purpose: as RUNTIME flags the uniform branches around the staged loads made hipcc fall back
+// to conservative waitcnts and cost the production kernel 35 % (r15).
+#ifndef Y6_PIPE_PROBE
+#define Y6_PIPE_PROBE 0
+#endif
+constexpr int kPipeProbe = Y6_PIPE_PROBE;
 
 template <int BP>
 struct PipeHaloCap {   // halo pixels (3x3 stride 1) of the largest tile shape offered for BP output pixels
@@ -1026,10 +1034,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
                 for (int t = 0; t < NT; ++t) {
                     if (WST == 1) ldfragW(t, 0);
                     if (t + 1 < NT) {
-                        if (!(a.ceiling_probe == 1 && ((t + 1) % 3) != 0)) ldfragA(t + 1, (t + 1) & 1);
-                        if (WST == 2 && a.ceiling_probe != 2) ldfragW(t + 1, (t + 1) & 1);
+                        if (!(kPipeProbe == 1 && ((t + 1) % 3) != 0)) ldfragA(t + 1, (t + 1) & 1);
+                        if (WST == 2 && kPipeProbe != 2) ldfragW(t + 1, (t + 1) & 1);
                     }
-                    if (t < 4 && a.ceiling_probe != 3) {   // publish the oldest staged chunk, then reuse its registers (no
+                    if (t < 4 && kPipeProbe != 3) {   // publish the oldest staged chunk, then reuse its registers (no
                                                            // branches: past the end of the stream this republishes /
                                                            // re-requests the last chunk)
 #pragma unroll
@@ -1045,7 +1053,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
-                    if (a.ceiling_probe != 5) {
+                    if (kPipeProbe != 5) {
 #pragma unroll
                         for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
             taps(astg, astg_ok);
             Y6_TRACE(11);
             if (have_next) {
-                if (a.ceiling_probe != 4) __syncthreads();   // next chunk published; everyone is done with this one
+                if (kPipeProbe != 4) __syncthreads();   // next chunk published; everyone is done with this one
                 synced = true;
                 pb ^= 1;
             }
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv_mfma_pipe_kernel(const Conv
                 bz.v[0][g * 4 + 2] = t.z;
                 bz.v[0][g * 4 + 3] = t.w;
             }
-            if (a.ceiling_probe != 6)
+            if (kPipeProbe != 6)
                 conv_epilogue<1, PF>(a, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
         }
         Y6_TRACE(20);
@@ -1301,7 +1309,6 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
                                    : k.HH * k.HWd * PIXB;
     k.nids = (k.ncb == 1) ? k.ntiles : y6_cdiv(k.ntiles, 8) * 8 * k.ncb;
     k.dbg = nullptr;
-    k.ceiling_probe = getenv("Y6_CONV_PROBE") ? atoi(getenv("Y6_CONV_PROBE")) : 0;
     if (const char* tr = getenv("Y6_CONV_TRACE")) {   // debug: device address of a 4 KiB trace buffer (decimal)
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
