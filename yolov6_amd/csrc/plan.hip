@@ -506,6 +506,37 @@ static int time_op(const Op& op, hipStream_t s, int iters, float* ms_out) {
     return rc;
 }
 
+// In-context timing for the autotuner: `op` is timed right behind the op that precedes it in the plan (with that
+// op's current kernel choice).  A burst of the same kernel over the same tensors flatters it twice: its input
+// stays resident from the previous repetition, and it never pays the first-launch-after-a-kernel-switch cost
+// (+3...35 us depending on the box) that it pays in the real sequence.  Minimum over `iters` pairs.
+static int time_op_after(const Op& prev, const Op& op, hipStream_t s, int iters, float* ms_out) {
+    hipEvent_t e0, e1;
+    Y6_HIP(hipEventCreate(&e0));
+    Y6_HIP(hipEventCreate(&e1));
+    int rc = run_op(op, s);  // warm
+    float best = 1e30f;
+    for (int i = 0; i < iters && rc == Y6_OK; ++i) {
+        rc = run_op(prev, s);
+        if (rc) break;
+        (void)hipEventRecord(e0, s);
+        rc = run_op(op, s);
+        (void)hipEventRecord(e1, s);
+        hipError_t e = hipEventSynchronize(e1);
+        if (rc == Y6_OK && e != hipSuccess) {
+            y6_set_error("op failed during timing: %s", hipGetErrorString(e));
+            rc = Y6_EHIP;
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    *ms_out = best;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     Y6_REQUIRE(p, "plan_autotune: null plan");
     hipStream_t s = (hipStream_t)stream;
@@ -549,6 +580,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             c = (*end == ',') ? end + 1 : end;
         }
     }
+    static const bool in_context = !(getenv("Y6_AUTOTUNE_BURST") != nullptr);   // A/B switch: old burst timing
     std::vector<std::vector<float>> times(p->ops.size());
     std::vector<char> measured(p->ops.size(), 0);
     for (size_t i = 0; i < p->ops.size(); ++i) {
@@ -587,10 +619,14 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             trial.conv.variant = v;
             float ms = 1e30f;
             int rc = Y6_OK;
-            for (int rep = 0; rep < 3 && rc == Y6_OK; ++rep) {   // min of three short bursts: robust to clock ramps
-                float t = 0.f;
-                rc = time_op(trial, s, iters, &t);
-                if (t < ms) ms = t;
+            if (i > 0 && in_context) {
+                rc = time_op_after(p->ops[i - 1], trial, s, 3 * iters, &ms);
+            } else {
+                for (int rep = 0; rep < 3 && rc == Y6_OK; ++rep) {   // min of three short bursts: robust to clock ramps
+                    float t = 0.f;
+                    rc = time_op(trial, s, iters, &t);
+                    if (t < ms) ms = t;
+                }
             }
             if (rc) {
                 if (logf) fclose(logf);
