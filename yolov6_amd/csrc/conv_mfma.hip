@@ -1138,8 +1138,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
         for (int ks = 0; ks < KS; ++ks)
             w[cf][ks] = *reinterpret_cast<const h8_t*>(
                 a.wpk + ((((size_t)(cb * CF + cf) * a.nchunk + (ks >> 1)) * 2 + (ks & 1)) * 64 + lane) * 8);
-    BiasRegs<CF> bz;
-    load_bias<CF>(a, cb, 0, lane, bz);
+
+    BiasRegs<CF> bzall;   // resident: a bias LOAD inside the loop would wait (in-order vmcnt) for the pixel prefetch too
+    load_bias<CF>(a, cb, 0, lane, bzall);
 
     auto load_px = [&](int f, h8_t (&r)[KS]) {
         int px = f * 32 + (lane & 31);
@@ -1161,7 +1162,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
                 acc[cf][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[cf][ks], r[ks], acc[cf][0], 0, 0, 0);
         const int px = f * 32 + (lane & 31);
         int opix[1] = {px < npix ? px : -1};
-        conv_epilogue<CF, 1>(a, acc, opix, cb, 0, lane, bz);
+        // one cout fragment at a time: keeps the epilogue's live set small
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+            BiasRegs<1> bz;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bz.v[0][q] = bzall.v[cf][q];
+            conv_epilogue<1, 1>(a, *reinterpret_cast<const f32x16_t(*)[1][1]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
+        }
     };
 
     h8_t r0[KS], r1[KS];
@@ -1482,7 +1490,8 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         if (ks != 1 || st != 1 || d->w_packed == nullptr) return 0;
         const int ksn = d->in.C / 16;
         if (d->in.C % 16 || !(ksn == 4 || ksn == 8 || ksn == 16)) return 0;
-        if (vc.cf == 2 && ksn != 4) return 0;                // two cout fragments: weights + two pixel sets + epilogue fit for Cin 64 only
+        if (vc.cf == 2 && ksn != 4) return 0;                // two cout fragments fit without spills for Cin 64 only (a spill is a
+                                                             // scratch access, i.e. a vmcnt wait that also waits for the pixel prefetch)
         if (d->in.cstride % 8 || d->in.coff % 8 || ((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
         if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
         return vc.cf <= y6_cdiv(d->out.C, 32);
