@@ -8,6 +8,11 @@ out = sys.argv[1]
 
 
 def classify(name):
+    if "conv1x1_stream_kernel" in name:
+        return "conv1x1s1"
+    m = re.search(r"conv_mfma_pipe_kernel<\d+, \d+, \d+, \d+, (\d)", name)
+    if m:
+        return "conv3x3s%s" % m.group(1)
     if "conv_mfma_pipe_kernel" in name:
         return "conv3x3s1"
     m = re.search(r"conv_mfma_persist_kernel<\d+, \d+, (\d)>", name)
