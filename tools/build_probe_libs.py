@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Build ceiling-probe copies of the library: conv_mfma.hip recompiled with -DY6_PIPE_PROBE=n (WRONG RESULTS,
+timing only - see the comment at kPipeProbe), linked with the regular objects of the other sources into
+tools/_build/libyolov6_hip_probe<n>.so.  Use with  Y6_LIB_PATH=tools/_build/libyolov6_hip_probe5.so python tools/conv_bench.py ..."""
+import concurrent.futures as cf, glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "yolov6_amd", "csrc"))
+import build as B  # noqa: E402
+
+B.build(verbose=False)
+others = [o for o in glob.glob(os.path.join(B.OBJ_DIR, "*.o")) if not os.path.basename(o).startswith("conv_mfma.")]
+out = os.path.join(ROOT, "tools", "_build")
+os.makedirs(out, exist_ok=True)
+cc = B.hipcc()
+
+
+def one(n):
+    obj = os.path.join(out, f"conv_mfma_probe{n}.o")
+    lib = os.path.join(out, f"libyolov6_hip_probe{n}.so")
+    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_mfma.hip"] + [f"-DY6_PIPE_PROBE={n}", "-c",
+                    os.path.join(B.HERE, "conv_mfma.hip"), "-o", obj], check=True, capture_output=True)
+    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + sorted(others), check=True)
+    os.remove(obj)
+    return lib
+
+
+probes = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 6]
+with cf.ThreadPoolExecutor(max_workers=len(probes)) as ex:
+    for lib in ex.map(one, probes):
+        print("built", lib)

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libyolov6_hip.so")
+# Y6_LIB_PATH: developer override (e.g. a ceiling-probe build from tools/build_probe_libs.py); never a fallback
+LIB_PATH = os.environ.get("Y6_LIB_PATH") or os.path.join(_HERE, "lib", "libyolov6_hip.so")
 
 Y6_F16, Y6_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_HARDSWISH = 0, 1, 2, 3
