@@ -16,6 +16,7 @@ What is pinned
   tal_<case>.npz    reference yolov6/assigners/tal_assigner.py::TaskAlignedAssigner on CPU
   atss_<case>.npz   reference yolov6/assigners/atss_assigner.py::ATSSAssigner on CPU (anchors from the
                     reference's generate_anchors)
+  loss_<case>.npz   reference yolov6/models/losses/loss.py::ComputeLoss forward value (loss, loss_items) on CPU
 Inputs are regenerated from seeds by oracle/synth.py, so only outputs are stored.
 """
 import json
@@ -198,9 +199,42 @@ def gen_atss():
         print(f"atss_{name}: fg {int(fg.sum())} nonzero scores {len(nz[0])}")
 
 
+LOSS_CASES = {
+    # name: (B, feat sizes, strides, C, reg_max, use_dfl, iou_type, epoch (vs warmup 4), seed)
+    "tal_giou_dfl": (3, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 20, 16, True, "giou", 10, 0),
+    "tal_siou_nodfl": (2, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 80, 16, False, "siou", 10, 1),   # yolov6n/s setting
+    "atss_warmup": (3, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 20, 16, True, "giou", 0, 2),
+    "ciou": (2, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 10, 16, True, "ciou", 10, 3),
+    "no_targets": (2, [(8, 8), (4, 4), (2, 2)], [8, 16, 32], 20, 16, True, "giou", 10, 4),
+}
+
+
+def gen_loss():
+    """reference ComputeLoss (models/losses/loss.py) on CPU; `.cuda()` of its two param-less modules is patched
+    to a no-op (no GPU here) - nothing else is touched."""
+    import torch.nn as nn
+    nn.Module.cuda = lambda self, device=None: self
+    from yolov6.models.losses.loss import ComputeLoss
+    for name, (B, fs, st, C, reg_max, use_dfl, iou_type, epoch, seed) in LOSS_CASES.items():
+        inp = synth.synth_loss_inputs(B, fs, st, C, reg_max, use_dfl, seed=seed)
+        if name == "no_targets":
+            inp["targets"] = inp["targets"][:0]
+        crit = ComputeLoss(fpn_strides=st, num_classes=C, ori_img_size=inp["img"], warmup_epoch=4, use_dfl=use_dfl,
+                           reg_max=reg_max, iou_type=iou_type)
+        feats = [torch.zeros(B, 1, h, w) for h, w in fs]
+        with torch.no_grad():
+            loss, items = crit((feats, inp["pred_scores"].clone(), inp["pred_distri"].clone()), inp["targets"].clone(),
+                               epoch, 1, inp["img"], inp["img"])
+        np.savez_compressed(os.path.join(HERE, f"loss_{name}.npz"), loss=np.float64(float(loss)),
+                            items=items.numpy().astype(np.float64),
+                            meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, reg_max=reg_max, use_dfl=use_dfl,
+                                                 iou_type=iou_type, epoch=epoch, seed=seed)))
+        print(f"loss_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
+
+
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal", "atss"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss"]
     if "models" in which:
         gen_models()
     if "nms" in which:
@@ -209,3 +243,5 @@ if __name__ == "__main__":
         gen_tal()
     if "atss" in which:
         gen_atss()
+    if "loss" in which:
+        gen_loss()

@@ -137,3 +137,25 @@ def test_atss_oracle_matches_reference(case):
     ref[idx[:, 0], idx[:, 1], idx[:, 2]] = g["score_val"]
     assert np.array_equal(S != 0, ref != 0)
     np.testing.assert_allclose(S, ref, rtol=2e-6, atol=1e-12)
+
+
+# ------------------------------------------------------------------ ComputeLoss forward value (a16)
+LOSS_GOLDEN = sorted(f[len("loss_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("loss_"))
+
+
+@pytest.mark.parametrize("case", LOSS_GOLDEN)
+def test_loss_oracle_matches_reference_golden(case):
+    """oracle/loss_oracle.py vs the unmodified reference's ComputeLoss (tests/golden/gen_golden.py::gen_loss)."""
+    from oracle import loss_oracle
+    g = np.load(os.path.join(GOLDEN, f"loss_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp = synth.synth_loss_inputs(m["B"], m["feat_sizes"], m["strides"], m["C"], m["reg_max"], m["use_dfl"], seed=m["seed"])
+    targets = inp["targets"].numpy()
+    if case == "no_targets":
+        targets = targets[:0]
+    out = loss_oracle.compute_loss(m["feat_sizes"], inp["pred_scores"].numpy(), inp["pred_distri"].numpy(), targets,
+                                   m["epoch"], inp["img"], inp["img"], fpn_strides=m["strides"], num_classes=m["C"],
+                                   warmup_epoch=4, use_dfl=m["use_dfl"], reg_max=m["reg_max"], iou_type=m["iou_type"])
+    # the reference carries the targets in float64 (loss.py:189 builds them from python floats); fp32 here: 2e-5
+    np.testing.assert_allclose(out["loss"], float(g["loss"]), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(out["loss_items"], g["items"], rtol=2e-5, atol=1e-6)

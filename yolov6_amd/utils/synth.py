@@ -133,3 +133,32 @@ def synth_tal_inputs(B, feat_sizes, strides, C, G, seed=0, n_valid=None, img=Non
     t = torch.from_numpy
     return dict(pd_scores=t(pd_scores), pd_bboxes=t(pd_bboxes), anc_points=t(pts), gt_labels=t(gt_labels),
                 gt_bboxes=t(gt_bboxes), mask_gt=t(mask_gt))
+
+
+def synth_loss_inputs(B, feat_sizes, strides, C, reg_max, use_dfl, seed=0, boxes_per_image=(1, 6), img=None):
+    """Inputs of ComputeLoss.__call__ (reference models/losses/loss.py:52-60): the train-branch head outputs
+    pred_scores [B,A,C] (post-sigmoid) and pred_distri [B,A,4*(reg_max+1)] (raw DFL logits; [B,A,4] distances in
+    stride units without DFL), and targets [N,6] = (image, class, cx, cy, w, h in 0..1).  The distances are drawn so
+    that a decoded box is a plausible box around its anchor; a few images get no target."""
+    r = np.random.RandomState(seed + 211)
+    A = sum(h * w for h, w in feat_sizes)
+    if img is None:
+        img = feat_sizes[0][0] * strides[0]
+    pred_scores = r.uniform(0.005, 0.95, size=(B, A, C)).astype(np.float32)
+    if use_dfl:
+        pred_distri = r.normal(0.0, 1.5, size=(B, A, 4 * (reg_max + 1))).astype(np.float32)
+        peak = r.randint(1, reg_max, size=(B, A, 4))
+        bi, ai, si = np.meshgrid(np.arange(B), np.arange(A), np.arange(4), indexing="ij")
+        pred_distri[bi, ai, si * (reg_max + 1) + peak] += 4.0
+    else:
+        pred_distri = r.uniform(0.5, 6.0, size=(B, A, 4)).astype(np.float32)
+    rows = []
+    for b in range(B):
+        n = 0 if (B > 2 and b == B - 1) else r.randint(boxes_per_image[0], boxes_per_image[1] + 1)
+        for _ in range(n):
+            wh = r.uniform(0.2, 0.6, size=2)
+            c = r.uniform(0.3, 0.7, size=2)
+            rows.append([b, r.randint(0, C), c[0], c[1], wh[0], wh[1]])
+    targets = np.asarray(rows, np.float32).reshape(-1, 6)
+    t = torch.from_numpy
+    return dict(pred_scores=t(pred_scores), pred_distri=t(pred_distri), targets=t(targets), img=int(img))
