@@ -248,6 +248,40 @@ size_t y6_atss_workspace_bytes(int B, int A, int G);
 int y6_atss_assign(const y6_atss_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* Training-loss forward VALUE.  Replaces, around the assigner call, the arithmetic of
+ * ComputeLoss.__call__  yolov6/models/losses/loss.py:52-182:
+ *   y6_bbox_decode   bbox_decode :194-198 (softmax over reg_max+1 bins . linspace(0,reg_max), dist2bbox xyxy
+ *                    utils/general.py:32-43); anchor_points_s = anchor_points / stride  -> pred_bboxes [B,A,4]
+ *   y6_loss_forward  VarifocalLoss :201-211, BboxLoss :214-278 (IOUloss utils/figure_iou.py:7-100 xyxy eps 1e-10,
+ *                    DFL :267-278), normalisation by target_scores.sum() when > 1 (:168-169), weights (:171-181)
+ * target_* / fg_mask are the outputs of y6_tal_assign / y6_atss_assign (target_bboxes still in pixels: the
+ * division by the stride of loss.py:154 happens inside).  out[6] (device, double):
+ *   loss, w_iou*loss_iou, w_dfl*loss_dfl, w_class*loss_cls, target_scores_sum, num_pos.
+ * Values only - the backward pass is not part of the library yet.                          */
+enum { Y6_IOU_GIOU = 0, Y6_IOU_DIOU = 1, Y6_IOU_CIOU = 2, Y6_IOU_SIOU = 3 };
+typedef struct y6_loss_desc {
+    const float* pred_scores;      /* [B,A,C]  post-sigmoid */
+    const float* pred_distri;      /* [B,A,4*(reg_max+1)] DFL logits, or [B,A,4] without DFL */
+    const float* pred_bboxes;      /* [B,A,4]  y6_bbox_decode output (stride units) */
+    const float* anchor_points_s;  /* [A,2]    anchor points / stride */
+    const float* stride;           /* [A] */
+    const int64_t* target_labels;  /* [B,A] */
+    const float* target_bboxes;    /* [B,A,4]  pixels */
+    const float* target_scores;    /* [B,A,C] */
+    const uint8_t* fg_mask;        /* [B,A] */
+    int32_t B, A, C;
+    int32_t use_dfl, reg_max, iou_type;
+    float w_class, w_iou, w_dfl;
+    double* out;                   /* [6] */
+    void* workspace;
+    size_t workspace_bytes;
+} y6_loss_desc;
+int y6_bbox_decode(const float* pred_distri, const float* anchor_points_s, int B, int A, int use_dfl, int reg_max,
+                   float* pred_bboxes, void* stream);
+size_t y6_loss_workspace_bytes(void);
+int y6_loss_forward(const y6_loss_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* Execution plan: an ordered list of the ops above with fixed pointers, replayed with one
  * call per forward (optionally from a captured hipGraph).  This is the native executor
  * behind Model.forward  yolov6/models/yolo.py:33-41.                                      */

@@ -72,6 +72,17 @@ class AtssDesc(C.Structure):
                 ("workspace_bytes", C.c_size_t)]
 
 
+class LossDesc(C.Structure):
+    _fields_ = [("pred_scores", C.c_void_p), ("pred_distri", C.c_void_p), ("pred_bboxes", C.c_void_p),
+                ("anchor_points_s", C.c_void_p), ("stride", C.c_void_p), ("target_labels", C.c_void_p),
+                ("target_bboxes", C.c_void_p), ("target_scores", C.c_void_p), ("fg_mask", C.c_void_p),
+                ("B", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
+                ("iou_type", C.c_int32), ("w_class", C.c_float), ("w_iou", C.c_float), ("w_dfl", C.c_float),
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
+
 # symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
 SIGNATURES = {
     "y6_abi_version": (C.c_int, []),
@@ -96,6 +107,9 @@ SIGNATURES = {
     "y6_tal_assign": (C.c_int, [C.POINTER(TalDesc), C.c_void_p]),
     "y6_atss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "y6_atss_assign": (C.c_int, [C.POINTER(AtssDesc), C.c_void_p]),
+    "y6_bbox_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y6_loss_workspace_bytes": (C.c_size_t, []),
+    "y6_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
     "y6_plan_create": (C.c_void_p, []),
     "y6_plan_destroy": (None, [C.c_void_p]),
     "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),

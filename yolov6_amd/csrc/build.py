@@ -29,6 +29,7 @@ SOURCES = {
     "head_decode.hip": [],
     "nms.hip": ["-ffp-contract=off"],
     "tal.hip": ["-ffp-contract=off"],
+    "loss.hip": ["-ffp-contract=off"],
     "plan.hip": [],
 }
 HEADERS = ["common.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]

@@ -1,0 +1,251 @@
+// loss.hip — forward value of the training loss.
+// Restates (reference yolov6/models/losses/loss.py)
+//   bbox_decode      :194-198  softmax over the reg_max+1 DFL bins . linspace(0, reg_max), dist2bbox xyxy (general.py:32-43)
+//   VarifocalLoss    :201-211  BCE(p, q) * (0.75 p^2 (1-y) + q y), fp32, logs clamped at -100 (torch BCE)
+//   BboxLoss         :214-278  IOUloss (utils/figure_iou.py:7-100, xyxy, eps 1e-10) * sum_c target_scores, DFL two-bin
+//                              cross entropy (:267-278); both / target_scores_sum when that is > 1 (:168-169, :238-261)
+//   weights          :171-181  loss = w_class*cls + w_iou*iou + w_dfl*dfl; items = (w_iou*iou, w_dfl*dfl, w_class*cls)
+// The label assignment in between is y6_tal_assign / y6_atss_assign (tal.hip).  VALUES ONLY: the backward pass of
+// the training step is not part of this library yet.
+// Compile with -ffp-contract=off: every elementwise term follows the reference's unfused fp32 arithmetic; only the
+// final sums differ (block partials in double, one double atomic per block - order independent to ~1e-12).
+#include "common.hpp"
+
+namespace {
+
+constexpr float kPi = 3.14159265358979323846f;
+
+__global__ __launch_bounds__(256) void bbox_decode_kernel(const float* __restrict__ dist, const float* __restrict__ pts,
+                                                          int B, int A, int use_dfl, int reg_max, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * A) return;
+    const int a = (int)(i % A);
+    float d[4];
+    if (use_dfl) {
+        const int nb = reg_max + 1;
+        const float* p = dist + i * 4 * nb;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float* q = p + s * nb;
+            float m = -INFINITY;
+            for (int k = 0; k < nb; ++k) m = fmaxf(m, q[k]);
+            float den = 0.f;
+            for (int k = 0; k < nb; ++k) den += expf(q[k] - m);
+            float v = 0.f;
+            for (int k = 0; k < nb; ++k) v += (expf(q[k] - m) / den) * (float)k;   // softmax, then . proj
+            d[s] = v;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) d[s] = dist[i * 4 + s];
+    }
+    const float ax = pts[a * 2], ay = pts[a * 2 + 1];
+    float4 o;
+    o.x = ax - d[0];
+    o.y = ay - d[1];
+    o.z = ax + d[2];
+    o.w = ay + d[3];
+    reinterpret_cast<float4*>(out)[i] = o;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    __syncthreads();
+    return t;   // valid in thread 0
+}
+
+// acc[0] = sum VFL terms, acc[1] = sum target_scores
+__global__ __launch_bounds__(256) void loss_cls_kernel(const float* __restrict__ pred, const float* __restrict__ tscore,
+                                                       const int64_t* __restrict__ tlabel, const uint8_t* __restrict__ fg,
+                                                       size_t n_ba, int C, double* __restrict__ acc) {
+    __shared__ double sh[4];
+    double s_cls = 0.0, s_ts = 0.0;
+    const size_t total = n_ba * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ba = i / C;
+        const int c = (int)(i - ba * C);
+        const float p = pred[i], q = tscore[i];
+        const float y = (fg[ba] && tlabel[ba] == (int64_t)c) ? 1.f : 0.f;
+        const float weight = 0.75f * (p * p) * (1.f - y) + q * y;
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+        const float bce = -(q * lp + (1.f - q) * l1p);
+        s_cls += (double)(bce * weight);
+        s_ts += (double)q;
+    }
+    const double a = block_sum(s_cls, sh);
+    const double b = block_sum(s_ts, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], a);
+        atomicAdd(&acc[1], b);
+    }
+}
+
+__device__ __forceinline__ float iou_loss_xyxy(const float4 b1, const float4 b2, int type) {
+    const float e = 1e-10f;
+    const float iw = fmaxf(fminf(b1.z, b2.z) - fmaxf(b1.x, b2.x), 0.f);
+    const float ih = fmaxf(fminf(b1.w, b2.w) - fmaxf(b1.y, b2.y), 0.f);
+    const float inter = iw * ih;
+    const float w1 = b1.z - b1.x, h1 = b1.w - b1.y + e;
+    const float w2 = b2.z - b2.x, h2 = b2.w - b2.y + e;
+    const float uni = w1 * h1 + w2 * h2 - inter + e;
+    float iou = inter / uni;
+    const float cw = fmaxf(b1.z, b2.z) - fminf(b1.x, b2.x);
+    const float ch = fmaxf(b1.w, b2.w) - fminf(b1.y, b2.y);
+    if (type == Y6_IOU_GIOU) {
+        const float c_area = cw * ch + e;
+        iou = iou - (c_area - uni) / c_area;
+    } else if (type == Y6_IOU_DIOU || type == Y6_IOU_CIOU) {
+        const float c2 = cw * cw + ch * ch + e;
+        const float dx = b2.x + b2.z - b1.x - b1.z, dy = b2.y + b2.w - b1.y - b1.w;
+        const float rho2 = (dx * dx + dy * dy) / 4.f;
+        if (type == Y6_IOU_DIOU) {
+            iou = iou - rho2 / c2;
+        } else {
+            const float t = atanf(w2 / h2) - atanf(w1 / h1);
+            const float v = (4.f / (kPi * kPi)) * (t * t);
+            const float alpha = v / (v - iou + (1.f + e));
+            iou = iou - (rho2 / c2 + v * alpha);
+        }
+    } else if (type == Y6_IOU_SIOU) {
+        const float s_cw = (b2.x + b2.z - b1.x - b1.z) * 0.5f + e;
+        const float s_ch = (b2.y + b2.w - b1.y - b1.w) * 0.5f + e;
+        const float sigma = sqrtf(s_cw * s_cw + s_ch * s_ch);
+        const float sa1 = fabsf(s_cw) / sigma, sa2 = fabsf(s_ch) / sigma;
+        const float thr = 0.70710678118654752f;
+        const float sa = sa1 > thr ? sa2 : sa1;
+        const float angle_cost = cosf(asinf(sa) * 2.f - kPi / 2.f);
+        const float rx = (s_cw / cw) * (s_cw / cw), ry = (s_ch / ch) * (s_ch / ch);
+        const float gamma = angle_cost - 2.f;
+        const float distance_cost = 2.f - expf(gamma * rx) - expf(gamma * ry);
+        const float ow = fabsf(w1 - w2) / fmaxf(w1, w2), oh = fabsf(h1 - h2) / fmaxf(h1, h2);
+        const float tw = 1.f - expf(-ow), th = 1.f - expf(-oh);
+        const float shape_cost = (tw * tw) * (tw * tw) + (th * th) * (th * th);
+        iou = iou - 0.5f * (distance_cost + shape_cost);
+    }
+    return 1.f - iou;
+}
+
+// one thread per (b, a); foreground anchors contribute.  acc[2] = sum iou_loss * w, acc[3] = sum dfl * w, acc[4] = num_pos
+__global__ __launch_bounds__(256) void loss_box_kernel(const float* __restrict__ pred_distri,
+                                                       const float* __restrict__ pred_bboxes,
+                                                       const float* __restrict__ pts, const float* __restrict__ stride,
+                                                       const float* __restrict__ tboxes, const float* __restrict__ tscore,
+                                                       const uint8_t* __restrict__ fg, int B, int A, int C, int use_dfl,
+                                                       int reg_max, int iou_type, double* __restrict__ acc) {
+    __shared__ double sh[4];
+    double s_iou = 0.0, s_dfl = 0.0, s_n = 0.0;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)B * A && fg[i]) {
+        const int a = (int)(i % A);
+        float w = 0.f;
+        for (int c = 0; c < C; ++c) w += tscore[i * C + c];     // target_scores.sum(-1)  (:232-233)
+        const float st = stride[a];
+        const float4 tb4 = reinterpret_cast<const float4*>(tboxes)[i];
+        const float4 tb = make_float4(tb4.x / st, tb4.y / st, tb4.z / st, tb4.w / st);   // target_bboxes /= stride (:154)
+        const float4 pb = reinterpret_cast<const float4*>(pred_bboxes)[i];
+        s_iou = (double)(iou_loss_xyxy(pb, tb, iou_type) * w);
+        s_n = 1.0;
+        if (use_dfl) {
+            const int nb = reg_max + 1;
+            const float ax = pts[a * 2], ay = pts[a * 2 + 1];
+            const float hi = (float)reg_max - 0.01f;
+            float t[4] = {ax - tb.x, ay - tb.y, tb.z - ax, tb.w - ay};   // bbox2dist (general.py:45-49)
+            float l4 = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float tv = fminf(fmaxf(t[s], 0.f), hi);
+                const int tl = (int)tv, tr = tl + 1;
+                const float wl = (float)tr - tv, wr = 1.f - wl;
+                const float* q = pred_distri + (i * 4 + s) * nb;
+                float m = -INFINITY;
+                for (int k = 0; k < nb; ++k) m = fmaxf(m, q[k]);
+                float den = 0.f;
+                for (int k = 0; k < nb; ++k) den += expf(q[k] - m);
+                const float lse = logf(den) + m;
+                l4 += (lse - q[tl]) * wl + (lse - q[tr]) * wr;
+            }
+            s_dfl = (double)((l4 / 4.f) * w);    // .mean(-1) over the four sides (:278)
+        }
+    }
+    const double a0 = block_sum(s_iou, sh);
+    const double a1 = block_sum(s_dfl, sh);
+    const double a2 = block_sum(s_n, sh);
+    if (threadIdx.x == 0 && a2 > 0.0) {
+        atomicAdd(&acc[2], a0);
+        atomicAdd(&acc[3], a1);
+        atomicAdd(&acc[4], a2);
+    }
+}
+
+__global__ void loss_finalize_kernel(const double* __restrict__ acc, float w_class, float w_iou, float w_dfl, int use_dfl,
+                                     double* __restrict__ out) {
+    double cls = acc[0], iou = 0.0, dfl = 0.0;
+    const double ts = acc[1], npos = acc[4];
+    if (ts > 1.0) cls /= ts;                      // :168-169
+    if (npos > 0.0) {                             // :227
+        iou = acc[2];
+        dfl = use_dfl ? acc[3] : 0.0;
+        if (ts > 1.0) {                           // :238-241, :258-261
+            iou /= ts;
+            dfl /= ts;
+        }
+    }
+    out[0] = (double)w_class * cls + (double)w_iou * iou + (double)w_dfl * dfl;
+    out[1] = (double)w_iou * iou;
+    out[2] = (double)w_dfl * dfl;
+    out[3] = (double)w_class * cls;
+    out[4] = ts;
+    out[5] = npos;
+}
+
+}  // namespace
+
+extern "C" int y6_bbox_decode(const float* pred_distri, const float* anchor_points_s, int B, int A, int use_dfl, int reg_max,
+                              float* pred_bboxes, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(pred_distri && anchor_points_s && pred_bboxes && B > 0 && A > 0, "bbox_decode: bad arguments");
+    Y6_REQUIRE(!use_dfl || (reg_max >= 1 && reg_max <= 63), "bbox_decode: reg_max %d out of range", reg_max);
+    Y6_REQUIRE(((uintptr_t)pred_bboxes & 15) == 0, "bbox_decode: output must be 16-byte aligned");
+    const size_t n = (size_t)B * A;
+    hipLaunchKernelGGL(bbox_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred_distri,
+                       anchor_points_s, B, A, use_dfl, reg_max, pred_bboxes);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" size_t y6_loss_workspace_bytes(void) { return 8 * sizeof(double); }
+
+extern "C" int y6_loss_forward(const y6_loss_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(d && d->pred_scores && d->pred_distri && d->pred_bboxes && d->anchor_points_s && d->stride &&
+                   d->target_labels && d->target_bboxes && d->target_scores && d->fg_mask && d->out && d->workspace,
+               "loss_forward: null argument");
+    Y6_REQUIRE(d->B > 0 && d->A > 0 && d->C > 0, "loss_forward: bad sizes");
+    Y6_REQUIRE(d->iou_type >= Y6_IOU_GIOU && d->iou_type <= Y6_IOU_SIOU, "loss_forward: unknown iou_type %d", d->iou_type);
+    Y6_REQUIRE(!d->use_dfl || (d->reg_max >= 1 && d->reg_max <= 63), "loss_forward: reg_max %d out of range", d->reg_max);
+    Y6_REQUIRE(d->workspace_bytes >= y6_loss_workspace_bytes(), "loss_forward: workspace too small");
+    Y6_REQUIRE((((uintptr_t)d->pred_bboxes | (uintptr_t)d->target_bboxes) & 15) == 0, "loss_forward: boxes must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    double* acc = (double*)d->workspace;
+    Y6_HIP(hipMemsetAsync(acc, 0, 8 * sizeof(double), s));
+    const size_t n_ba = (size_t)d->B * d->A;
+    size_t g = (n_ba * d->C + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(loss_cls_kernel, dim3((unsigned)g), dim3(256), 0, s, d->pred_scores, d->target_scores, d->target_labels,
+                       d->fg_mask, n_ba, d->C, acc);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_box_kernel, dim3((unsigned)((n_ba + 255) / 256)), dim3(256), 0, s, d->pred_distri, d->pred_bboxes,
+                       d->anchor_points_s, d->stride, d->target_bboxes, d->target_scores, d->fg_mask, d->B, d->A, d->C,
+                       d->use_dfl, d->reg_max, d->iou_type, acc);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, acc, d->w_class, d->w_iou, d->w_dfl, d->use_dfl, d->out);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

@@ -1,0 +1,136 @@
+"""ComputeLoss - mirror of reference yolov6/models/losses/loss.py:14-198 (constructor arguments, call signature,
+return value), computing the FORWARD VALUE of the training loss on the GPU:
+
+    anchors            generate_anchors (host, cached per feature-map size like loss.py:63-69)
+    targets            preprocess (host, as the reference: loss.py:184-192)
+    pred_bboxes        y6_bbox_decode                       (loss.py:194-198)
+    label assignment   ATSSAssigner for epoch < warmup_epoch, TaskAlignedAssigner after (loss.py:83-103) - HIP
+    loss terms         y6_loss_forward: VarifocalLoss, IoU loss, DFL loss, normalisation, weights (loss.py:154-182)
+
+The result is a pair (loss, loss_items[iou, dfl, cls]) of fp32 tensors WITHOUT an autograd graph: the backward pass
+of the training step is not implemented yet, so this serves validation-loss monitoring and parity
+checks, not optimisation.  There is no CPU path and no OOM fallback to one (the reference's `except RuntimeError`
+branch, loss.py:105-152, exists because its assigner needs O(B*G*A) temporaries; the HIP assigners do not).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ...assigners.anchor_generator import generate_anchors
+from ...assigners.atss_assigner import ATSSAssigner
+from ...assigners.tal_assigner import TaskAlignedAssigner
+
+
+class ComputeLoss:
+    """Loss computation func (forward value)."""
+
+    def __init__(self, fpn_strides=[8, 16, 32], grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80,
+                 ori_img_size=640, warmup_epoch=4, use_dfl=True, reg_max=16, iou_type='giou',
+                 loss_weight={'class': 1.0, 'iou': 2.5, 'dfl': 0.5}):
+        self.fpn_strides = fpn_strides
+        self.cached_feat_sizes = [torch.Size([0, 0]) for _ in fpn_strides]
+        self.cached_anchors = None
+        self.grid_cell_size = grid_cell_size
+        self.grid_cell_offset = grid_cell_offset
+        self.num_classes = num_classes
+        self.ori_img_size = ori_img_size
+        self.warmup_epoch = warmup_epoch
+        self.warmup_assigner = ATSSAssigner(9, num_classes=self.num_classes)
+        self.formal_assigner = TaskAlignedAssigner(topk=13, num_classes=self.num_classes, alpha=1.0, beta=6.0)
+        self.use_dfl = use_dfl
+        self.reg_max = reg_max
+        self.iou_type = iou_type.lower()
+        if self.iou_type not in _lib.IOU_TYPES:
+            raise ValueError(f"iou_type must be one of {sorted(_lib.IOU_TYPES)}, got {iou_type!r}")
+        self.loss_weight = loss_weight
+        self._ws = {}
+
+    # ------------------------------------------------------------------ host pieces, as in the reference
+    def preprocess(self, targets, batch_size, scale_tensor):
+        """loss.py:184-192 (the packing runs on the host there too).  -> [B,G,5] fp32 (label, x1,y1,x2,y2 px)."""
+        rows = targets.detach().cpu().numpy().astype(np.float64)
+        lists = [[] for _ in range(batch_size)]
+        for item in rows.tolist():
+            lists[int(item[0])].append(item[1:])
+        max_len = max([len(l) for l in lists] + [0])
+        out = np.zeros((batch_size, max_len, 5), np.float32)
+        out[:, :, 0] = -1
+        for b, l in enumerate(lists):
+            if l:
+                out[b, :len(l)] = np.asarray(l, np.float32)
+        t = torch.from_numpy(out).to(scale_tensor.device)
+        box = t[:, :, 1:5] * scale_tensor
+        x1 = box[..., 0] - box[..., 2] * 0.5          # xywh2xyxy exactly as general.py:52-58 (x2 = x1 + w)
+        y1 = box[..., 1] - box[..., 3] * 0.5
+        t[:, :, 1:5] = torch.stack([x1, y1, x1 + box[..., 2], y1 + box[..., 3]], -1)
+        return t
+
+    def bbox_decode(self, anchor_points, pred_dist):
+        lib = _lib.load()
+        pred_dist = pred_dist.detach().float().contiguous()
+        _lib.require_gpu_tensor(pred_dist, "pred_dist")
+        B, A = pred_dist.shape[:2]
+        pts = anchor_points.float().contiguous()
+        out = torch.empty((B, A, 4), dtype=torch.float32, device=pred_dist.device)
+        _lib.check(lib.y6_bbox_decode(C.c_void_p(pred_dist.data_ptr()), C.c_void_p(pts.data_ptr()), B, A,
+                                      int(self.use_dfl), int(self.reg_max), C.c_void_p(out.data_ptr()),
+                                      _lib.current_stream_ptr()), "bbox_decode")
+        return out
+
+    # ------------------------------------------------------------------ the call
+    def __call__(self, outputs, targets, epoch_num, step_num, batch_height, batch_width):
+        lib = _lib.load()
+        feats, pred_scores, pred_distri = outputs
+        _lib.require_gpu_tensor(pred_scores, "pred_scores")
+        dev = pred_scores.device
+        if all(feat.shape[2:] == cfsize for feat, cfsize in zip(feats, self.cached_feat_sizes)):
+            anchors, anchor_points, n_anchors_list, stride_tensor = self.cached_anchors
+        else:
+            self.cached_feat_sizes = [feat.shape[2:] for feat in feats]
+            anchors, anchor_points, n_anchors_list, stride_tensor = generate_anchors(
+                feats, self.fpn_strides, self.grid_cell_size, self.grid_cell_offset, device=dev)
+            anchors, anchor_points, stride_tensor = (t.float().to(dev) for t in (anchors, anchor_points, stride_tensor))
+            self.cached_anchors = anchors, anchor_points, n_anchors_list, stride_tensor
+        assert pred_scores.type() == pred_distri.type()
+        pred_scores = pred_scores.detach().float().contiguous()
+        pred_distri = pred_distri.detach().float().contiguous()
+        B, A, Cn = pred_scores.shape
+        gt_bboxes_scale = torch.tensor([batch_width, batch_height, batch_width, batch_height], dtype=torch.float32, device=dev)
+        targets = self.preprocess(targets, B, gt_bboxes_scale)
+        gt_labels = targets[:, :, :1]
+        gt_bboxes = targets[:, :, 1:].contiguous()
+        mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
+
+        anchor_points_s = (anchor_points / stride_tensor).contiguous()
+        pred_bboxes = self.bbox_decode(anchor_points_s, pred_distri)
+        if epoch_num < self.warmup_epoch:
+            target_labels, target_bboxes, target_scores, fg_mask = self.warmup_assigner(
+                anchors, n_anchors_list, gt_labels, gt_bboxes, mask_gt, pred_bboxes * stride_tensor)
+        else:
+            target_labels, target_bboxes, target_scores, fg_mask = self.formal_assigner(
+                pred_scores, pred_bboxes * stride_tensor, anchor_points, gt_labels, gt_bboxes, mask_gt)
+
+        target_labels = target_labels.to(torch.int64).contiguous()
+        target_bboxes = target_bboxes.float().contiguous()
+        target_scores = target_scores.float().contiguous()
+        fg_u8 = fg_mask.to(torch.uint8).contiguous()
+        stride_flat = stride_tensor.reshape(-1).float().contiguous()
+        out = torch.empty((6,), dtype=torch.float64, device=dev)
+        ws = self._ws.get(dev)
+        if ws is None:
+            ws = self._ws[dev] = torch.empty(int(lib.y6_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+        d = _lib.LossDesc()
+        for name, t in (("pred_scores", pred_scores), ("pred_distri", pred_distri), ("pred_bboxes", pred_bboxes),
+                        ("anchor_points_s", anchor_points_s), ("stride", stride_flat), ("target_labels", target_labels),
+                        ("target_bboxes", target_bboxes), ("target_scores", target_scores), ("fg_mask", fg_u8),
+                        ("out", out), ("workspace", ws)):
+            setattr(d, name, C.c_void_p(t.data_ptr()))
+        d.B, d.A, d.C = B, A, Cn
+        d.use_dfl, d.reg_max, d.iou_type = int(self.use_dfl), int(self.reg_max), _lib.IOU_TYPES[self.iou_type]
+        d.w_class, d.w_iou, d.w_dfl = (float(self.loss_weight[k]) for k in ("class", "iou", "dfl"))
+        d.workspace_bytes = ws.numel()
+        _lib.check(lib.y6_loss_forward(C.byref(d), _lib.current_stream_ptr()), "loss_forward")
+        res = out.float()
+        return res[0], res[1:4].detach()
