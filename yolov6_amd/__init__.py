@@ -31,7 +31,7 @@ def __getattr__(name):
 
 _ALIASES = ("layers", "layers.common", "models", "models.yolo", "models.efficientrep", "models.reppan",
             "models.effidehead", "assigners", "assigners.tal_assigner", "assigners.atss_assigner", "assigners.anchor_generator", "utils",
-            "utils.nms", "utils.torch_utils", "utils.general")
+            "utils.nms", "utils.torch_utils", "utils.general", "models.losses", "models.losses.loss")
 
 
 def install_as_yolov6():
