@@ -382,3 +382,61 @@ def deploy_state_dict(cfg, sd, num_classes=80):
             continue
         out[k] = v
     return out
+
+
+class TrainOracle(Oracle):
+    """ORACLE for the TRAINING-mode forward: the un-fused graph with batch-statistics
+    BatchNorm (eps 1e-3, momentum 0.03: torch_utils.py:38-47) and the Detect training branch
+    (effidehead.py:72-92).  fp32.  `new_stats[prefix]` holds the running_mean / running_var a BatchNorm would have after
+    the step (unbiased variance in the running estimate, biased in the normalisation - torch semantics)."""
+    BN_MOMENTUM = 0.03
+
+    def __init__(self, cfg, sd, num_classes=80):
+        super().__init__(cfg, sd, num_classes, emulate_fp16=False)
+        self.train_form = True
+        self.new_stats = {}
+
+    def bn(self, x, p):
+        sd = self.sd
+        mean = x.mean((0, 2, 3))
+        var = x.var((0, 2, 3), unbiased=False)
+        n = x.numel() / x.shape[1]
+        m = self.BN_MOMENTUM
+        self.new_stats[p] = ((1 - m) * sd[p + ".running_mean"] + m * mean,
+                             (1 - m) * sd[p + ".running_var"] + m * var * (n / max(n - 1, 1)))
+        y = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + BN_EPS)
+        return y * sd[p + ".weight"].view(1, -1, 1, 1) + sd[p + ".bias"].view(1, -1, 1, 1)
+
+    def convbn(self, x, p, act, stride=1):
+        sd = self.sd
+        w = sd[p + ".block.conv.weight"]
+        y = F.conv2d(x, w, sd.get(p + ".block.conv.bias"), stride=stride, padding=w.shape[-1] // 2)
+        if p + ".block.bn.weight" in sd:
+            y = self.bn(y, p + ".block.bn")
+        return self.act(y, act)
+
+    def block(self, x, p, stride=1):
+        mode = self.a.mode
+        if mode in ("conv_relu", "conv_silu"):
+            return self.convbn(x, p, "relu" if mode == "conv_relu" else "silu", stride)
+        return self.repvgg_train_form(x, p, stride)
+
+    def head_train(self, feats):
+        sd = self.sd
+        xs, cls_l, reg_l = [], [], []
+        for i, x in enumerate(feats):
+            f = self.convbn(x, f"detect.stems.{i}", "silu")
+            c = self.convbn(f, f"detect.cls_convs.{i}", "silu")
+            r = self.convbn(f, f"detect.reg_convs.{i}", "silu")
+            co = F.conv2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])
+            ro = F.conv2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"])
+            xs.append(f)
+            cls_l.append(torch.sigmoid(co).flatten(2).permute(0, 2, 1))
+            reg_l.append(ro.flatten(2).permute(0, 2, 1))
+        return xs, torch.cat(cls_l, 1), torch.cat(reg_l, 1)
+
+    def forward_train(self, x):
+        """-> (head stem outputs per level, cls_scores [B,A,nc], reg_distri [B,A,4*(reg_max+1)]), neck featmaps."""
+        self.new_stats = {}
+        feats = self.neck(self.backbone(x.float()))
+        return self.head_train(list(feats)), feats

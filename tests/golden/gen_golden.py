@@ -16,6 +16,7 @@ What is pinned
   tal_<case>.npz    reference yolov6/assigners/tal_assigner.py::TaskAlignedAssigner on CPU
   atss_<case>.npz   reference yolov6/assigners/atss_assigner.py::ATSSAssigner on CPU (anchors from the
                     reference's generate_anchors)
+  train_<case>.npz  reference Model in TRAINING mode (batch-stat BN, Detect train branch): head outputs, BN running stats
   loss_<case>.npz   reference yolov6/models/losses/loss.py::ComputeLoss forward value (loss, loss_items) on CPU
 Inputs are regenerated from seeds by oracle/synth.py, so only outputs are stored.
 """
@@ -199,6 +200,36 @@ def gen_atss():
         print(f"atss_{name}: fg {int(fg.sum())} nonzero scores {len(nz[0])}")
 
 
+TRAIN_CASES = ["tiny", "s_qa_tiny", "m_tiny"]
+TRAIN_BN_PROBES = ["backbone.stem.rbr_dense.bn", "backbone.ERBlock_3.0.rbr_dense.bn", "detect.stems.0.block.bn", "neck.reduce_layer0.block.bn"]
+
+
+def gen_train_forward():
+    """reference Model in TRAINING mode on CPU (batch-statistics BN, Detect training branch effidehead.py:72-92):
+    head outputs, one neck feature map and the running statistics a few BatchNorms hold after the forward."""
+    from yolov6.models.yolo import Model
+    for name in TRAIN_CASES:
+        cfile, over, size, batch, nc = MODEL_CASES[name]
+        cfg = ref_config(cfile, over)
+        torch.manual_seed(0)
+        model = Model(cfg, channels=3, num_classes=nc)
+        sd = synth.synth_state_dict(model.state_dict(), seed=0)
+        model.load_state_dict(sd)
+        model.train()
+        x = synth.synth_images(max(batch, 2), size, seed=21)
+        with torch.no_grad():
+            (xs, cls_scores, reg_distri), featmaps = model(x)
+        after = model.state_dict()
+        out = dict(cls_scores=cls_scores.numpy(), reg_distri=reg_distri.numpy(), stem0=xs[0].numpy(), feat0=featmaps[0].numpy())
+        for q in TRAIN_BN_PROBES:
+            if q + ".running_mean" in after:
+                out[q + ".running_mean"] = after[q + ".running_mean"].numpy()
+                out[q + ".running_var"] = after[q + ".running_var"].numpy()
+        np.savez_compressed(os.path.join(HERE, f"train_{name}.npz"), **out)
+        print(f"train_{name}: cls {tuple(cls_scores.shape)} reg {tuple(reg_distri.shape)} "
+              f"probes {[q for q in TRAIN_BN_PROBES if q + '.running_mean' in after]}")
+
+
 LOSS_CASES = {
     # name: (B, feat sizes, strides, C, reg_max, use_dfl, iou_type, epoch (vs warmup 4), seed)
     "tal_giou_dfl": (3, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 20, 16, True, "giou", 10, 0),
@@ -234,7 +265,7 @@ def gen_loss():
 
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train"]
     if "models" in which:
         gen_models()
     if "nms" in which:
@@ -245,3 +276,5 @@ if __name__ == "__main__":
         gen_atss()
     if "loss" in which:
         gen_loss()
+    if "train" in which:
+        gen_train_forward()

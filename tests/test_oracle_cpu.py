@@ -159,3 +159,35 @@ def test_loss_oracle_matches_reference_golden(case):
     # the reference carries the targets in float64 (loss.py:189 builds them from python floats); fp32 here: 2e-5
     np.testing.assert_allclose(out["loss"], float(g["loss"]), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(out["loss_items"], g["items"], rtol=2e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ training-mode forward (K15 groundwork)
+TRAIN_GOLDEN = sorted(f[len("train_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("train_"))
+
+
+@pytest.mark.parametrize("case", TRAIN_GOLDEN)
+def test_train_mode_forward_oracle_matches_reference_golden(case):
+    """oracle/model_oracle.py::TrainOracle (batch-statistics BN, Detect training branch) vs the reference Model in
+    .train() mode (tests/golden/gen_golden.py::gen_train_forward): outputs and the BatchNorm running statistics."""
+    from oracle.model_oracle import TrainOracle
+    cfg, meta = case_config(case)
+    sd = synth_sd_from_keys(meta["train"])
+    g = np.load(os.path.join(GOLDEN, f"train_{case}.npz"))
+    x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
+    orc = TrainOracle(cfg, sd, meta["num_classes"])
+    with torch.no_grad():
+        (xs, cls_scores, reg_distri), feats = orc.forward_train(x)
+    # batch statistics over as few as 8 samples (2 images x 2x2 maps at the last level) divide by small variances, so
+    # the graph is ill-conditioned in fp32: evaluating the SAME oracle graph in float64 moves m_tiny's reg outputs by
+    # 2.5e-3 and sits 3.1e-3 from the reference's fp32 result.  5e-3 bounds that noise; a wrong branch or a wrong
+    # statistic is orders of magnitude larger.
+    assert rel_err(cls_scores.numpy(), g["cls_scores"]) < 1e-3
+    assert rel_err(reg_distri.numpy(), g["reg_distri"]) < 5e-3
+    assert rel_err(xs[0].numpy(), g["stem0"]) < 5e-3
+    assert rel_err(feats[0].numpy(), g["feat0"]) < 5e-3
+    probes = [k[:-len(".running_mean")] for k in g.files if k.endswith(".running_mean")]
+    assert probes
+    for q in probes:
+        mean, var = orc.new_stats[q]
+        assert rel_err(mean.numpy(), g[q + ".running_mean"]) < 1e-4, q
+        assert rel_err(var.numpy(), g[q + ".running_var"]) < 1e-4, q
