@@ -201,6 +201,8 @@ def gen_atss():
 
 
 TRAIN_CASES = ["tiny", "s_qa_tiny", "m_tiny"]
+TRAIN_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "backbone.ERBlock_3.0.rbr_dense.bn.weight",
+                     "detect.cls_preds.1.bias", "neck.reduce_layer0.block.conv.weight"]
 TRAIN_BN_PROBES = ["backbone.stem.rbr_dense.bn", "backbone.ERBlock_3.0.rbr_dense.bn", "detect.stems.0.block.bn", "neck.reduce_layer0.block.bn"]
 
 
@@ -217,10 +219,19 @@ def gen_train_forward():
         model.load_state_dict(sd)
         model.train()
         x = synth.synth_images(max(batch, 2), size, seed=21)
-        with torch.no_grad():
-            (xs, cls_scores, reg_distri), featmaps = model(x)
+        (xs, cls_scores, reg_distri), featmaps = model(x)
+        # a scalar of the head outputs, back-propagated by the reference's autograd: gradient goldens for three
+        # parameters at different depths (first conv, a mid-backbone BN weight, a head pred bias)
+        scalar = (cls_scores * cls_scores).sum() + reg_distri.square().mean()
+        model.zero_grad()
+        scalar.backward()
+        params = dict(model.named_parameters())
+        grads = {q: params[q].grad.detach().numpy().copy() for q in TRAIN_GRAD_PROBES if q in params and params[q].grad is not None}
         after = model.state_dict()
-        out = dict(cls_scores=cls_scores.numpy(), reg_distri=reg_distri.numpy(), stem0=xs[0].numpy(), feat0=featmaps[0].numpy())
+        out = dict(cls_scores=cls_scores.detach().numpy(), reg_distri=reg_distri.detach().numpy(), stem0=xs[0].detach().numpy(),
+                   feat0=featmaps[0].detach().numpy(), scalar=np.float64(float(scalar)))
+        for q, gq in grads.items():
+            out["grad:" + q] = gq
         for q in TRAIN_BN_PROBES:
             if q + ".running_mean" in after:
                 out[q + ".running_mean"] = after[q + ".running_mean"].numpy()

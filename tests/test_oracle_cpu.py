@@ -175,8 +175,21 @@ def test_train_mode_forward_oracle_matches_reference_golden(case):
     g = np.load(os.path.join(GOLDEN, f"train_{case}.npz"))
     x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
     orc = TrainOracle(cfg, sd, meta["num_classes"])
-    with torch.no_grad():
-        (xs, cls_scores, reg_distri), feats = orc.forward_train(x)
+    gprobes = [k[len("grad:"):] for k in g.files if k.startswith("grad:")]
+    assert gprobes
+    for q in gprobes:
+        orc.sd[q].requires_grad_(True)
+    (xs, cls_scores, reg_distri), feats = orc.forward_train(x)
+    # backward through the oracle graph: the same scalar the golden script back-propagated through the reference
+    scalar = (cls_scores * cls_scores).sum() + reg_distri.square().mean()
+    scalar.backward()
+    np.testing.assert_allclose(float(scalar), float(g["scalar"]), rtol=1e-4)
+    for q in gprobes:
+        ga, gb = orc.sd[q].grad.numpy(), g["grad:" + q]
+        scale = max(1e-6, float(np.abs(gb).max()))
+        assert float(np.abs(ga - gb).max()) / scale < 2e-2, f"gradient of {q}"   # same fp32 conditioning as the forward
+    cls_scores, reg_distri = cls_scores.detach(), reg_distri.detach()
+    xs, feats = [t.detach() for t in xs], [t.detach() for t in feats]
     # batch statistics over as few as 8 samples (2 images x 2x2 maps at the last level) divide by small variances, so
     # the graph is ill-conditioned in fp32: evaluating the SAME oracle graph in float64 moves m_tiny's reg outputs by
     # 2.5e-3 and sits 3.1e-3 from the reference's fp32 result.  5e-3 bounds that noise; a wrong branch or a wrong
@@ -189,5 +202,5 @@ def test_train_mode_forward_oracle_matches_reference_golden(case):
     assert probes
     for q in probes:
         mean, var = orc.new_stats[q]
-        assert rel_err(mean.numpy(), g[q + ".running_mean"]) < 1e-4, q
-        assert rel_err(var.numpy(), g[q + ".running_var"]) < 1e-4, q
+        assert rel_err(mean.detach().numpy(), g[q + ".running_mean"]) < 1e-4, q
+        assert rel_err(var.detach().numpy(), g[q + ".running_var"]) < 1e-4, q
