@@ -282,6 +282,26 @@ size_t y6_loss_workspace_bytes(void);
 int y6_loss_forward(const y6_loss_desc* d, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
+/* BatchNorm2d in TRAINING mode (batch statistics), forward only - the primitives the training-form forward needs
+ * around the conv kernels:
+ *   y6_bn_stats  per-channel mean / biased variance over B*H*W of an NHWC fp16 view: the statistics
+ *                F.batch_norm(training=True) uses in every ConvModule (yolov6/layers/common.py:26-54) and every
+ *                RepVGG branch (:250-255, :341-347).  workspace: y6_bn_stats_workspace_bytes(C).
+ *   y6_bn_apply  out = act( sum_b x_b * scale_b[c] + shift_b[c] ), 1..3 branches: the RepVGG train-form sum
+ *                ReLU(bn(conv3x3) + bn(conv1x1) + bn_id(x)) (:250-255) in one pass.  scale/shift: [C] fp32.     */
+typedef struct y6_bn_apply_desc {
+    int32_t n;
+    y6_tensor x[3];
+    const float* scale[3];
+    const float* shift[3];
+    y6_tensor out;
+    int32_t act;               /* Y6_ACT_* */
+} y6_bn_apply_desc;
+size_t y6_bn_stats_workspace_bytes(int C);
+int y6_bn_stats(const y6_tensor* x, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
+int y6_bn_apply(const y6_bn_apply_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------ */
 /* Execution plan: an ordered list of the ops above with fixed pointers, replayed with one
  * call per forward (optionally from a captured hipGraph).  This is the native executor
  * behind Model.forward  yolov6/models/yolo.py:33-41.                                      */

@@ -81,6 +81,11 @@ class LossDesc(C.Structure):
                 ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class BnApplyDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", Tensor * 3), ("scale", C.c_void_p * 3), ("shift", C.c_void_p * 3),
+                ("out", Tensor), ("act", C.c_int32)]
+
+
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
 # symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
@@ -110,6 +115,9 @@ SIGNATURES = {
     "y6_bbox_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_loss_workspace_bytes": (C.c_size_t, []),
     "y6_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
+    "y6_bn_stats_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "y6_bn_stats": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y6_bn_apply": (C.c_int, [C.POINTER(BnApplyDesc), C.c_void_p]),
     "y6_plan_create": (C.c_void_p, []),
     "y6_plan_destroy": (None, [C.c_void_p]),
     "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),

@@ -30,6 +30,7 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "tal.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=off"],
+    "bn_train.hip": [],
     "plan.hip": [],
 }
 HEADERS = ["common.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
