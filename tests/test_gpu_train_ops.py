@@ -49,12 +49,13 @@ def test_repvgg_train_forward(cin, cout, stride, hw):
     ref = copy.deepcopy(m)
     x = (torch.randn(4, cin, *hw, generator=torch.Generator().manual_seed(4))).half().float()
     # the reference arithmetic (common.py:250-255) with torch's training-mode batch_norm, fp32 on the CPU
-    d = _bn_train(F.conv2d(x, ref.rbr_dense.conv.weight, None, stride, 1), ref.rbr_dense.bn)
-    e = _bn_train(F.conv2d(x, ref.rbr_1x1.conv.weight, None, stride, 0), ref.rbr_1x1.bn)
-    y_ref = d + e
-    if ref.rbr_identity is not None:
-        y_ref = y_ref + _bn_train(x, ref.rbr_identity)
-    y_ref = F.relu(y_ref)
+    with torch.no_grad():
+        d = _bn_train(F.conv2d(x, ref.rbr_dense.conv.weight, None, stride, 1), ref.rbr_dense.bn)
+        e = _bn_train(F.conv2d(x, ref.rbr_1x1.conv.weight, None, stride, 0), ref.rbr_1x1.bn)
+        y_ref = d + e
+        if ref.rbr_identity is not None:
+            y_ref = y_ref + _bn_train(x, ref.rbr_identity)
+        y_ref = F.relu(y_ref)
     m = m.to(DEV)
     with torch.no_grad():
         y = repvgg_train_forward(m, x.to(DEV).half())
@@ -73,8 +74,9 @@ def test_conv_module_train_forward(k, stride, act):
     _randomise(m, 5)
     ref = copy.deepcopy(m)
     x = torch.randn(3, 48, 18, 22, generator=torch.Generator().manual_seed(6)).half().float()
-    y_ref = _bn_train(F.conv2d(x, ref.conv.weight, None, stride, k // 2), ref.bn)
-    y_ref = F.silu(y_ref) if act == "silu" else F.relu(y_ref)
+    with torch.no_grad():
+        y_ref = _bn_train(F.conv2d(x, ref.conv.weight, None, stride, k // 2), ref.bn)
+        y_ref = F.silu(y_ref) if act == "silu" else F.relu(y_ref)
     m = m.to(DEV)
     with torch.no_grad():
         y = conv_module_train_forward(m, x.to(DEV).half())
