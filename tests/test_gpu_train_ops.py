@@ -39,7 +39,7 @@ def _bn_train(x, bn):
 def _check_stats(hip_bn, ref_bn):
     assert rel_err(hip_bn.running_mean.cpu().numpy(), ref_bn.running_mean.numpy()) < 2e-3
     assert rel_err(hip_bn.running_var.cpu().numpy(), ref_bn.running_var.numpy()) < 2e-3
-    assert int(hip_bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+    assert int(hip_bn.num_batches_tracked) == 1     # nn.BatchNorm2d.forward counts the step (the functional reference does not)
 
 
 @pytest.mark.parametrize("cin,cout,stride,hw", [(64, 64, 1, (20, 24)), (32, 64, 2, (24, 24)), (128, 128, 1, (10, 14))])
