@@ -160,3 +160,25 @@ def test_anchor_generator_matches_oracle_grid():
     anchors, pts2, n, st2 = generate_anchors(feats, [8, 16], 5.0, 0.5, is_eval=False)
     assert n == [24, 6] and anchors.shape == (30, 4)
     assert pts2[0].tolist() == [4.0, 4.0] and anchors[0].tolist() == [-16.0, -16.0, 24.0, 24.0]
+
+
+def test_compute_loss_target_packing_matches_oracle():
+    """ComputeLoss.preprocess is host-side in the reference (loss.py:184-192) and here: same packing, same padding
+    rows, same xywh2xyxy arithmetic (x2 = x1 + w) as the oracle restatement."""
+    import numpy as np
+    from oracle import loss_oracle
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.utils import synth
+    inp = synth.synth_loss_inputs(4, [(8, 8), (4, 4), (2, 2)], [8, 16, 32], 20, 16, True, seed=5)
+    crit = ComputeLoss(num_classes=20)
+    scale = torch.tensor([64.0, 48.0, 64.0, 48.0])
+    got = crit.preprocess(inp["targets"], 4, scale).numpy()
+    ref = loss_oracle.preprocess(inp["targets"].numpy(), 4, scale.numpy())
+    assert got.shape == ref.shape and got.shape[0] == 4
+    assert np.array_equal(got, ref)
+    # an image without targets keeps only padding rows (label -1, zero box) -> mask_gt 0
+    assert (got[3, :, 0] == -1).all() and (got[3, :, 1:] == 0).all()
+    # no targets at all: G = 0
+    assert crit.preprocess(inp["targets"][:0], 4, scale).shape == (4, 0, 5)
+    with pytest.raises(ValueError):
+        ComputeLoss(iou_type="eiou")
