@@ -50,16 +50,19 @@ class ComputeLoss:
     # ------------------------------------------------------------------ host pieces, as in the reference
     def preprocess(self, targets, batch_size, scale_tensor):
         """loss.py:184-192 (the packing runs on the host there too).  -> [B,G,5] fp32 (label, x1,y1,x2,y2 px)."""
-        rows = targets.detach().cpu().numpy().astype(np.float64)
-        lists = [[] for _ in range(batch_size)]
-        for item in rows.tolist():
-            lists[int(item[0])].append(item[1:])
-        max_len = max([len(l) for l in lists] + [0])
+        rows = targets.detach().cpu().numpy().astype(np.float32).reshape(-1, 6)
+        img = rows[:, 0].astype(np.int64)
+        if rows.shape[0] and (img.min() < 0 or img.max() >= batch_size):
+            raise IndexError(f"targets name image {int(img.max())} but the batch holds {batch_size} images")
+        counts = np.bincount(img, minlength=batch_size)[:batch_size] if rows.shape[0] else np.zeros(batch_size, np.int64)
+        max_len = int(counts.max()) if rows.shape[0] else 0
         out = np.zeros((batch_size, max_len, 5), np.float32)
         out[:, :, 0] = -1
-        for b, l in enumerate(lists):
-            if l:
-                out[b, :len(l)] = np.asarray(l, np.float32)
+        if rows.shape[0]:
+            order = np.argsort(img, kind="stable")          # per image, rows keep their order (the reference appends in order)
+            starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+            pos = np.arange(rows.shape[0]) - starts[img[order]]
+            out[img[order], pos] = rows[order, 1:]
         t = torch.from_numpy(out).to(scale_tensor.device)
         box = t[:, :, 1:5] * scale_tensor
         x1 = box[..., 0] - box[..., 2] * 0.5          # xywh2xyxy exactly as general.py:52-58 (x2 = x1 + w)
