@@ -326,8 +326,13 @@ int y6_plan_autotune(y6_plan* p, void* stream, int iters);
  * (same shape/dtype). Returns the number of fields changed (>=0) or a negative error.
  * Invalidates a captured graph. */
 int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_ptr);
+/* Re-point the `index`-th boundary-reading op (stem / NCHW->NHWC adapter ops, in plan order) at `new_ptr`.
+ * Rebinding by position is safe when the caller permutes its input tensors. Returns 1 if changed, 0 if equal. */
+int y6_plan_rebind_input(y6_plan* p, int index, const void* new_ptr);
 /* Launch all ops in order on `stream` (no sync). */
 int y6_plan_run(y6_plan* p, void* stream);
+/* Eager launch of ops [first, last) only (teacher-forced per-layer parity tests, partial re-runs). */
+int y6_plan_run_range(y6_plan* p, void* stream, int first, int last);
 /* Live per-op timing: reserve `slots` runs worth of hipEvents, run eagerly with an event between
  * consecutive ops (on `stream`), then - after the caller synchronised - read the per-op sums. */
 int y6_plan_timing_begin(y6_plan* p, int slots);

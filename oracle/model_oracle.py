@@ -301,16 +301,26 @@ class Oracle:
         return outs
 
     def head(self, feats):
-        a, sd = self.a, self.sd
+        sd = self.sd
         cls_l, reg_l = [], []
         for i, x in enumerate(feats):
-            b, _, h, w = x.shape
             f = self.convbn(x, f"detect.stems.{i}", "silu")
             c = self.convbn(f, f"detect.cls_convs.{i}", "silu")
             r = self.convbn(f, f"detect.reg_convs.{i}", "silu")
             co = self.q(F.conv2d(c, self.q(sd[f"detect.cls_preds.{i}.weight"]), self.q(sd[f"detect.cls_preds.{i}.bias"])))
             ro = self.q(F.conv2d(r, self.q(sd[f"detect.reg_preds.{i}.weight"]), self.q(sd[f"detect.reg_preds.{i}.bias"])))
             self.trace[f"cls_logits{i}"], self.trace[f"reg_raw{i}"] = co, ro
+            cls_l.append(co)
+            reg_l.append(ro)
+        return self.decode(cls_l, reg_l)
+
+    def decode(self, cls_logits, reg_raw):
+        """Detect eval tail (effidehead.py:104-139) from the per-level prediction maps (NCHW): DFL softmax.proj,
+        sigmoid, anchors (anchor_generator.py:13-33), dist2bbox 'xywh' (general.py:32-43), x stride, concat."""
+        a, sd = self.a, self.sd
+        cls_l, reg_l = [], []
+        for co, ro in zip(cls_logits, reg_raw):
+            b, _, h, w = co.shape
             if a.use_dfl:
                 ro = ro.reshape(-1, 4, a.reg_max + 1, h * w).permute(0, 2, 1, 3)
                 ro = self.q(F.conv2d(self.q(F.softmax(ro, dim=1)), sd["detect.proj_conv.weight"]))
@@ -319,8 +329,8 @@ class Oracle:
         cls = torch.cat(cls_l, -1).permute(0, 2, 1)
         reg = torch.cat(reg_l, -1).permute(0, 2, 1)
         pts, strd = [], []
-        dev = feats[0].device
-        for x, s in zip(feats, a.strides):
+        dev = cls_logits[0].device
+        for x, s in zip(cls_logits, a.strides):
             h, w = x.shape[-2:]
             gy, gx = torch.meshgrid(torch.arange(h, device=dev) + 0.5, torch.arange(w, device=dev) + 0.5, indexing="ij")
             pts.append(torch.stack([gx, gy], -1).float().reshape(-1, 2))

@@ -85,7 +85,11 @@ def test_full_resolution_b1_vs_oracle_with_nms(case, size):
     # boxes are pixels (up to 1280) through a DFL softmax on fp16 logits x stride 64: two correct fp16 pipelines differ by
     # a few 1e-2 in this metric (the reference's own half path is 7e-3 ... 4e-2 from its fp32 result on the golden
     # cases); measured here 3.3e-2 (P6 @1280) and below 1e-2 (N @640)
-    assert e_all < 6e-2, f"{case}@{size}: boxes (pixels) HIP vs fp16-emulating oracle {e_all:.3e}"
+    px = float(np.abs(d[..., :4] - r[..., :4]).max())
+    print(f"{case}@{size}: boxes deviate by at most {px:.3f} px")
+    # bound = measured on MI355X (round 1: 3.3e-2 for the P6 graph, < 1e-2 for N) + 20 %
+    bound = {"n": 1.2e-2, "l6_tiny": 4.0e-2}[case]
+    assert e_all < bound, f"{case}@{size}: boxes (pixels) HIP vs fp16-emulating oracle {e_all:.3e}"
     # NMS on the HIP detections: device result == oracle NMS of the SAME tensor, bit for bit
     thr = float(np.quantile(d[0, :, 5:].max(-1), 0.97))     # random weights: take the top 3 % of anchors as candidates
     out = non_max_suppression(det, conf_thres=thr, iou_thres=0.45, max_det=1000)

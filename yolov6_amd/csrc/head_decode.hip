@@ -198,10 +198,11 @@ extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
     for (int l = 0; l < d->n_levels; ++l)
         tiled = tiled && (a.cls_cs[l] % 8 == 0) && (a.cls_co[l] % 8 == 0) && (((uintptr_t)a.cls[l] & 15) == 0);
     static const bool no_tiled = getenv("Y6_DECODE_FLAT") != nullptr;   // A/B switch for profiling
+    // the tiled kernel keeps DEC_TA fp32 output rows in LDS: class counts whose rows do not fit take the flat kernel
+    const size_t lds = (size_t)DEC_TA * (d->nc + 5) * sizeof(float) + 2 * DEC_TA * sizeof(int);
+    tiled = tiled && lds <= 64 * 1024;
     if (tiled && !no_tiled) {
         const int bpi = (A + DEC_TA - 1) / DEC_TA;
-        const size_t lds = (size_t)DEC_TA * (d->nc + 5) * sizeof(float) + 2 * DEC_TA * sizeof(int);
-        Y6_REQUIRE(lds <= 64 * 1024, "head_decode: %d classes need %zu bytes of LDS", d->nc, lds);
         hipLaunchKernelGGL(head_decode_tiled_kernel, dim3((unsigned)(a.B * bpi)), dim3(256), lds, (hipStream_t)stream, a, bpi);
         Y6_LAUNCH_CHECK();
         return Y6_OK;

@@ -295,6 +295,22 @@ extern "C" int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_p
     return n;
 }
 
+extern "C" int y6_plan_rebind_input(y6_plan* p, int index, const void* new_ptr) {
+    Y6_REQUIRE(p && index >= 0 && new_ptr, "plan_rebind_input: bad argument");
+    int k = 0;
+    for (Op& op : p->ops) {
+        const void** slot = op.kind == Y6_OP_STEM ? &op.stem.in_nchw : op.kind == Y6_OP_NCHW2NHWC ? &op.src : nullptr;
+        if (!slot) continue;
+        if (k++ != index) continue;
+        if (*slot == new_ptr) return 0;
+        *slot = new_ptr;
+        drop_graph(p);
+        return 1;
+    }
+    y6_set_error("plan_rebind_input: the plan has only %d boundary inputs (index %d)", k, index);
+    return Y6_EINVAL;
+}
+
 extern "C" int y6_plan_run(y6_plan* p, void* stream) {
     Y6_REQUIRE(p, "plan_run: null plan");
     hipStream_t s = (hipStream_t)stream;
@@ -303,6 +319,16 @@ extern "C" int y6_plan_run(y6_plan* p, void* stream) {
         return Y6_OK;
     }
     for (size_t i = 0; i < p->ops.size(); ++i) {
+        int rc = run_op(p->ops[i], s);
+        if (rc) return rc;
+    }
+    return Y6_OK;
+}
+
+extern "C" int y6_plan_run_range(y6_plan* p, void* stream, int first, int last) {
+    Y6_REQUIRE(p && first >= 0 && first <= last && last <= (int)p->ops.size(), "plan_run_range: bad range");
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = first; i < last; ++i) {
         int rc = run_op(p->ops[i], s);
         if (rc) return rc;
     }

@@ -80,14 +80,20 @@ class Plan:
             if self.captured:   # a captured graph baked the address: stage through the bound tensor
                 old.copy_(new)
                 continue
-            rc = self._lib.y6_plan_rebind(self._h, C.c_void_p(old.data_ptr()), C.c_void_p(new.data_ptr()))
+            # by position (the i-th boundary-reading op), never by matching the old address: a caller that swaps
+            # two inputs would otherwise end with both ops on the same tensor
+            rc = self._lib.y6_plan_rebind_input(self._h, i, C.c_void_p(new.data_ptr()))
             if rc < 0:
-                _lib.check(rc, "plan_rebind")
+                _lib.check(rc, "plan_rebind_input")
             self.inputs[i] = new
 
     def run(self):
         _lib.check(self._lib.y6_plan_run(self._h, _lib.current_stream_ptr()), "plan_run")
         return self.outputs
+
+    def run_range(self, first: int, last: int):
+        """Eager launch of ops [first, last) only (per-layer parity tests)."""
+        _lib.check(self._lib.y6_plan_run_range(self._h, _lib.current_stream_ptr(), first, last), "plan_run_range")
 
     def autotune(self, iters: int = 3):
         _lib.check(self._lib.y6_plan_autotune(self._h, _lib.current_stream_ptr(), iters), "plan_autotune")
@@ -166,6 +172,8 @@ class PlanBuilder:
         self.force_variant = -1  # tests: force one conv kernel variant for every conv
         self.inputs: List[torch.Tensor] = []
         self.conv_log = []       # (Cin, Cout, k, s, H, W) per conv, for reporting
+        self.op_log = []         # one dict per plan op, in plan order: what it reads / writes and its parameters
+                                 # (tests replay single ops against the oracle with these)
 
     # ---------------------------------------------------------------- memory
     def new_buffer(self, B, H, W, C_) -> TRef:
@@ -202,6 +210,7 @@ class PlanBuilder:
         ct = out.ct()
         _lib.check(self.lib.y6_plan_add_nchw2nhwc(self.h, C.c_void_p(t.data_ptr()), _dtype_tag(t), C.byref(ct)),
                    "plan_add_nchw2nhwc")
+        self.op_log.append(dict(kind="nchw2nhwc", x=t, out=out))
         return out
 
     def to_nchw(self, x: TRef, dtype=torch.float16) -> torch.Tensor:
@@ -210,6 +219,7 @@ class PlanBuilder:
         ct = x.ct()
         _lib.check(self.lib.y6_plan_add_nhwc2nchw(self.h, C.byref(ct), C.c_void_p(out.data_ptr()), _dtype_tag(out)),
                    "plan_add_nhwc2nchw")
+        self.op_log.append(dict(kind="nhwc2nchw", x=x, out=out))
         return out
 
     # ---------------------------------------------------------------- ops
@@ -250,6 +260,8 @@ class PlanBuilder:
         d.ksize, d.stride, d.act, d.variant = K, stride, ACT_BY_NAME[act], self.force_variant
         _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
         self.conv_log.append((Cin, Cout, K, stride, x.H, x.W))
+        self.op_log.append(dict(kind="conv", x=x, out=out, w=w32, b=bias, stride=stride, act=act, post=post, res=res,
+                                alpha=res_alpha))
         return out
 
     def _stem(self, x: NCHWInput, weight, bias, act, out, post) -> TRef:
@@ -276,6 +288,7 @@ class PlanBuilder:
         d.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
         d.act = ACT_BY_NAME[act]
         _lib.check(self.lib.y6_plan_add_stem(self.h, C.byref(d)), "plan_add_stem")
+        self.op_log.append(dict(kind="stem", x=t, out=out, w=w32, b=bias, stride=2, act=act, post=post, res=None, alpha=None))
         return out
 
     def convt2x2(self, x, weight, bias, out: Optional[TRef] = None) -> TRef:
@@ -296,11 +309,13 @@ class PlanBuilder:
         d.w_packed = self._ptr(packed)
         d.bias = self._ptr(self._f32(bias))
         _lib.check(self.lib.y6_plan_add_convt(self.h, C.byref(d)), "plan_add_convt")
+        self.op_log.append(dict(kind="convt", x=x, out=out, w=weight, b=bias))
         return out
 
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
         cts = [t.ct() for t in (x, y1, y2, y3)]
         _lib.check(self.lib.y6_plan_add_sppf(self.h, *[C.byref(c) for c in cts]), "plan_add_sppf")
+        self.op_log.append(dict(kind="sppf", x=x, outs=[y1, y2, y3]))
 
     def head_decode(self, cls: List[TRef], reg: List[TRef], strides, use_dfl, reg_max, proj, nc,
                     grid_cell_offset=0.5) -> torch.Tensor:
@@ -320,11 +335,14 @@ class PlanBuilder:
         d.out = C.c_void_p(out.data_ptr())
         d.nc = nc
         _lib.check(self.lib.y6_plan_add_decode(self.h, C.byref(d)), "plan_add_decode")
+        self.op_log.append(dict(kind="decode", cls=list(cls), reg=list(reg), out=out, strides=list(strides), use_dfl=bool(use_dfl),
+                                reg_max=int(reg_max), proj=proj, nc=nc))
         return out
 
     # ---------------------------------------------------------------- finish
     def finalize(self, outputs, autotune=True, iters=3) -> Plan:
         plan = Plan(self.h, self.keep, outputs, self.inputs)
+        plan.op_log = self.op_log
         self.h = None
         if autotune and self.force_variant < 0:
             plan.autotune(iters)

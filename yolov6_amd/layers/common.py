@@ -70,12 +70,26 @@ def _wrap(x, it):
 
 
 def _params_version(module):
-    v = 0
-    for p in module.parameters():
-        v += p._version + (p.data_ptr() & 0xFFFF)
-    for b in module.buffers():
-        v += b._version
-    return v
+    """Plan-cache key part: identity, version and dtype of every parameter / buffer plus the scalar attributes that
+    lowering bakes into the plan.  In-place edits through `.data` do not bump `_version`: after such an edit call
+    `module.invalidate_plans()` (switch_to_deploy, fuse_model and `_apply` do)."""
+    items = []
+    for t in list(module.parameters()) + list(module.buffers()):
+        items.append((t.data_ptr(), t._version, t.dtype))
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            items.append(("eps", m.eps))
+        for name in ("use_dfl", "reg_max", "grid_cell_offset", "shortcut", "deploy", "nc"):
+            v = m.__dict__.get(name)
+            if isinstance(v, (bool, int, float)):
+                items.append((name, v))
+        st = m.__dict__.get("stride")
+        if isinstance(st, torch.Tensor):
+            items.append(("stride", tuple(st.tolist())))
+        a = m.__dict__.get("alpha")
+        if isinstance(a, float):
+            items.append(("alpha", a))
+    return hash(tuple(items))
 
 
 class HipModule(nn.Module):
@@ -89,7 +103,19 @@ class HipModule(nn.Module):
         st = self.__dict__.copy()
         st.pop("_y6_plans", None)
         st.pop("_featrefs", None)
+        st.pop("_last_featmaps", None)
         return st
+
+    def invalidate_plans(self):
+        """Drop every cached native plan below this module (packed weights are derived caches: call this after
+        editing parameters through `.data`, which autograd's version counter does not see)."""
+        for m in self.modules():
+            m.__dict__.pop("_y6_plans", None)
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_plans()
+        return out
 
     def _check_runnable(self):
         for m in self.modules():

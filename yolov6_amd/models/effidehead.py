@@ -62,8 +62,12 @@ class Detect(HipModule):
             rp = self.reg_preds[i]
             reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
         use_dfl = bool(self.use_dfl)
-        return pb.head_decode(cls_out, reg_out, [float(s) for s in self.stride.tolist()], use_dfl, self.reg_max,
-                              self.proj if use_dfl else None, self.nc, self.grid_cell_offset)
+        # the reference's eval branch projects with proj_conv.weight (effidehead.py:107-109), not with self.proj;
+        # the bin count comes from the loaded weight, not from the constructor default
+        proj = self.proj_conv.weight.detach().reshape(-1) if use_dfl else None
+        reg_max = proj.numel() - 1 if use_dfl else self.reg_max
+        return pb.head_decode(cls_out, reg_out, [float(s) for s in self.stride.tolist()], use_dfl, reg_max,
+                              proj, self.nc, self.grid_cell_offset)
 
 
 def build_effidehead_layer(channels_list, num_anchors, num_classes, reg_max=16, num_layers=3):

@@ -121,9 +121,10 @@ class ComputeLoss:
         fg_u8 = fg_mask.to(torch.uint8).contiguous()
         stride_flat = stride_tensor.reshape(-1).float().contiguous()
         out = torch.empty((6,), dtype=torch.float64, device=dev)
-        ws = self._ws.get(dev)
+        ws_key = (dev, torch.cuda.current_stream(dev).cuda_stream)   # per stream: concurrent calls must not share it
+        ws = self._ws.get(ws_key)
         if ws is None:
-            ws = self._ws[dev] = torch.empty(int(lib.y6_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
+            ws = self._ws[ws_key] = torch.empty(int(lib.y6_loss_workspace_bytes()), dtype=torch.uint8, device=dev)
         d = _lib.LossDesc()
         for name, t in (("pred_scores", pred_scores), ("pred_distri", pred_distri), ("pred_bboxes", pred_bboxes),
                         ("anchor_points_s", anchor_points_s), ("stride", stride_flat), ("target_labels", target_labels),

@@ -3,6 +3,7 @@ build_model :136-138).  `Model.forward(x)` keeps the reference contract
 `[detections[B,A,5+nc] fp32, featmaps]` but runs as one native plan of HIP kernels.
 """
 import math
+import weakref
 
 import torch
 import torch.nn as nn
@@ -15,7 +16,9 @@ from .effidehead import Detect, build_effidehead_layer
 
 class _LazyFeatmaps(list):
     """The neck outputs as NCHW tensors, converted from the plan's NHWC buffers on first use.
-    (Eval callers drop them: `outputs, _ = model(imgs)` evaler.py:128.)"""
+    (Eval callers drop them: `outputs, _ = model(imgs)` evaler.py:128.)  The reference returns independent
+    tensors, so a result that is still unread when the plan is about to run again is materialised first
+    (`Model.forward` calls `_fill()` on the previous result through a weak reference)."""
 
     def __init__(self, refs, dtype):
         super().__init__()
@@ -61,8 +64,14 @@ class Model(HipModule):
         if torch.onnx.is_in_onnx_export() or self.export:
             raise NotImplementedError("yolov6_amd: ONNX export mode is out of scope of the HIP path")
         plan = self.compile(x)
+        prev = self.__dict__.get("_last_featmaps")
+        prev = prev() if prev is not None else None
+        if prev is not None:
+            prev._fill()            # a caller still holds the previous result unread: copy it out before overwriting
         det = plan.run()
-        return [det.clone(), _LazyFeatmaps(self._featrefs, x.dtype)]
+        feats = _LazyFeatmaps(self._featrefs, x.dtype)
+        self.__dict__["_last_featmaps"] = weakref.ref(feats)
+        return [det.clone(), feats]
 
     def _apply(self, fn):
         self = super()._apply(fn)

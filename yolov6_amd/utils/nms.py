@@ -14,7 +14,8 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.index, )
+    # one workspace per (device, stream): calls issued on different streams must not share keys/counts buffers
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)

@@ -31,6 +31,7 @@ def fuse_model(model):
         if type(m) is ConvModule and hasattr(m, "bn"):
             m.conv = fuse_conv_and_bn(m.conv, m.bn)
             delattr(m, "bn")
+    _invalidate(model)
     return model
 
 
@@ -41,4 +42,10 @@ def switch_to_deploy(model):
     for m in model.modules():
         if isinstance(m, RepVGGBlock):
             m.switch_to_deploy()
+    _invalidate(model)
     return model
+
+
+def _invalidate(model):
+    for m in model.modules():
+        m.__dict__.pop("_y6_plans", None)
