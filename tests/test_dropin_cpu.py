@@ -1,0 +1,43 @@
+"""CPU (build container): the overlay drop-in.  With the reference checkout present, `install_as_yolov6()` must let the
+reference's OWN callers import and run against this package: `import tools.eval`, `Evaler.init_model` (load_checkpoint ->
+fuse_model -> switch_to_deploy), `DetectBackend`, a checkpoint pickled by the unmodified reference.  Runs in
+subprocesses so that `sys.modules` of the test session stays clean.  Skipped where /root/reference does not exist
+(the GPU box); tests/test_gpu_dropin.py covers the GPU side with a committed checkpoint fixture."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "yolov6")), reason="reference checkout not present")
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(HERE, "dropin_probe.py"), *args], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_reference_callers_run_on_the_overlay(tmp_path):
+    ckpt = str(tmp_path / "ref_tiny.pt")
+    w = _run("write", REF, ckpt)
+    assert w["keys"] > 100
+    rep = _run("load", REF, ckpt)
+    assert rep["ref_dir"] == os.path.join(REF, "yolov6")
+    assert rep["tools_eval"].startswith(REF) and rep["evaler"].startswith(REF)          # the reference's own files
+    assert rep["common_is_ours"] and rep["yolo_is_ours"]
+    assert rep["fuse_model_is_ours"].startswith("yolov6_amd") and rep["time_sync_is_reference"] == "yolov6.utils.torch_utils"
+    assert rep["checkpoint_is_ours"] == "yolov6_amd.utils.checkpoint"
+    assert rep["check_img_size"] == 672 and rep["increment_name"].endswith("exp")
+    assert "RealVGGBlock" in rep["backfilled"] and "Lite_EffiBlockS1" in rep["backfilled"]   # star-imports stay complete
+    assert rep["model_type"] == "yolov6_amd.models.yolo.Model" and rep["stride"] == 32
+    assert rep["foreign_module_classes"] == []                 # every module of the un-pickled model is this package's
+    assert rep["n_repvgg"] > 10 and rep["deployed"] and rep["fused"]
+    assert rep["act_names"] == ["relu", "silu"]                # recovered from the pickled `act` modules
+    assert rep["backend_model_type"] == "Model" and rep["backend_stride"] == 32
+    assert rep["deploy_keys_equal"] and rep["deploy_max_diff"] < 1e-5
+    assert rep["config_type"] == "YOLOv6s"

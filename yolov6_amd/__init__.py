@@ -29,15 +29,9 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
-_ALIASES = ("layers", "layers.common", "models", "models.yolo", "models.efficientrep", "models.reppan",
-            "models.effidehead", "assigners", "assigners.tal_assigner", "assigners.atss_assigner", "assigners.anchor_generator", "utils",
-            "utils.nms", "utils.torch_utils", "utils.general", "models.losses", "models.losses.loss")
-
-
-def install_as_yolov6():
-    """Alias yolov6_amd.* as yolov6.* in sys.modules (drop-in for the reference's importers)."""
-    import importlib
-    sys.modules.setdefault("yolov6", sys.modules[__name__])
-    for sub in _ALIASES:
-        mod = importlib.import_module(f"{__name__}.{sub}")
-        sys.modules.setdefault(f"yolov6.{sub}", mod)
+def install_as_yolov6(reference_root=None, strict=False):
+    """Make `import yolov6...` resolve to the reference checkout with the hot-path modules replaced by this package
+    (overlay; see yolov6_amd/dropin.py).  Without a checkout, `yolov6` aliases this package alone.  Returns the
+    reference package directory in use, or None."""
+    from . import dropin
+    return dropin.install(reference_root, strict=strict)

@@ -196,6 +196,18 @@ class ConvModule(HipModule):
         b = self.conv.bias
         return self.conv.weight.detach().float(), None if b is None else b.detach().float()
 
+    def _activation_name(self):
+        # modules un-pickled from a reference-written checkpoint carry `act` but not `activation_type`
+        if "activation_type" in self.__dict__:
+            return self.activation_type
+        act = getattr(self, "act", None)
+        for name, kind in (("relu", nn.ReLU), ("silu", nn.SiLU), ("hardswish", nn.Hardswish)):
+            if isinstance(act, kind):
+                return name
+        if act is None:
+            return None
+        raise NotImplementedError(f"yolov6_amd: activation {type(act).__name__} is not on the HIP path")
+
     def lower(self, pb, x, out=None, res=None, res_alpha=None):
         c = self.conv
         if c.groups != 1 or c.dilation != (1, 1):
@@ -204,7 +216,7 @@ class ConvModule(HipModule):
         if c.padding != (k // 2, k // 2):
             raise NotImplementedError("yolov6_amd: only 'same' padding (k//2) is supported")
         w, b = self.fused_weight_bias()
-        return pb.conv(x, w, b, stride=c.stride[0], act=self.activation_type, out=out, res=res, res_alpha=res_alpha)
+        return pb.conv(x, w, b, stride=c.stride[0], act=self._activation_name(), out=out, res=res, res_alpha=res_alpha)
 
 
 class _ConvBNAct(HipModule):
@@ -567,6 +579,26 @@ class BiFusion(HipModule):
         t = self.cv2.lower(pb, x2)
         self.downsample.lower(pb, t, out=cat.slice(2 * oc, oc))
         return self.cv3.lower(pb, cat, out=out)
+
+
+class DetectBackend(nn.Module):
+    '''Checkpoint-backed inference wrapper used by core/inferer.py.  Reference: common.py:551-567.'''
+
+    def __init__(self, weights='yolov6s.pt', device=None, dnn=True):
+        super().__init__()
+        import os
+        from pathlib import Path
+        assert isinstance(weights, str) and Path(weights).suffix == '.pt', f'{Path(weights).suffix} format is not supported.'
+        if not os.path.exists(weights):
+            raise FileNotFoundError(f"yolov6_amd: checkpoint {weights} not found (no network: download it beforehand)")
+        from ..utils.checkpoint import load_checkpoint
+        model = load_checkpoint(weights, map_location=device)
+        stride = int(model.stride.max())
+        self.__dict__.update(locals())  # assign all variables to self (the reference does the same)
+
+    def forward(self, im, val=False):
+        y, _ = self.model(im)
+        return y
 
 
 def get_block(mode):
