@@ -301,13 +301,218 @@ size_t y6_bn_stats_workspace_bytes(int C);
 int y6_bn_stats(const y6_tensor* x, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
 int y6_bn_apply(const y6_bn_apply_desc* d, void* stream);
 
+typedef struct y6_plan y6_plan;
+
+/* ==================================================================================== */
+/* TRAINING STEP (config 3): forward in train form with batch-statistics BatchNorm, backward (data + weight
+ * gradients), loss gradient, fused SGD.  Replaces what torch autograd does for the reference's
+ *   RepVGGBlock.forward train form   yolov6/layers/common.py:250-255
+ *   ConvModule.forward               common.py:45-49
+ *   Detect.forward training branch   yolov6/models/effidehead.py:72-92
+ *   scaler.scale(total_loss).backward() / scaler.step(optimizer)   yolov6/core/engine.py:169-176, :258-266
+ * All entry points take plain device pointers; parameters, gradients and BatchNorm buffers are fp32 (master copies),
+ * activations and activation gradients NHWC fp16, parameter gradients ACCUMULATE (+=) into fp32 arrays the caller
+ * zeroes once per step.  Every op also exists as y6_plan_add_* so a step replays as two native plans.           */
+
+/* tags of training ops inside a plan (y6_plan_op_info reports them in `ksize` for Y6_OP_GENERIC) */
+enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_WGRAD_T = 4, Y6_TOP_WGRAD = 5,
+       Y6_TOP_PACK = 6, Y6_TOP_POOL_BWD = 7, Y6_TOP_HEAD_PACK = 8, Y6_TOP_HEAD_UNPACK = 9, Y6_TOP_S2D = 10,
+       Y6_TOP_BIAS_GRAD = 11, Y6_TOP_FILL = 12, Y6_TOP_ADD = 13 };
+
+/* Batch statistics of a conv output + everything derived from them, on device:
+ *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
+ *   running_mean/var updated in place with `momentum` (unbiased variance), num_batches_tracked += 1
+ * (torch.nn.BatchNorm2d training semantics; eps 1e-3 / momentum 0.03 come from initialize_weights torch_utils.py:38-47). */
+typedef struct y6_bn_train_desc {
+    y6_tensor x;
+    const float* gamma;            /* [C] or NULL (=1) */
+    const float* beta;             /* [C] or NULL (=0) */
+    float* running_mean;           /* [C] or NULL */
+    float* running_var;
+    int64_t* num_batches_tracked;  /* scalar or NULL */
+    float momentum, eps;
+    float* scale;                  /* outputs, [C] each */
+    float* shift;
+    float* mean;
+    float* invstd;
+    void* workspace;               /* y6_bn_stats_workspace_bytes(C) */
+    size_t workspace_bytes;
+} y6_bn_train_desc;
+int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream);
+
+/* out = act( sum_b ( x_b * scale_b[c] + shift_b[c] ) ) [+ alpha * res]   (1..3 branches; NULL scale = 1, NULL shift = 0)
+ * - the RepVGG train-form sum (common.py:250-255), ConvModule's BN + act (:45-49), QARepVGG's raw branches (:341-347),
+ * BottleRep's shortcut (:605-608). */
+typedef struct y6_bnact_desc {
+    int32_t n;
+    y6_tensor x[3];
+    const float* scale[3];
+    const float* shift[3];
+    y6_tensor res;                 /* data == NULL: none */
+    const float* res_alpha;        /* device scalar or NULL (= 1) */
+    y6_tensor out;
+    int32_t act;
+} y6_bnact_desc;
+int y6_bnact_forward(const y6_bnact_desc* d, void* stream);
+
+/* Backward of y6_bnact_forward + the BatchNorms that fed it.  With dz = dout * act'(z):
+ *   branch with BN:   dx_b = gamma_b*invstd_b * ( dz - mean(dz) - xhat_b * mean(dz*xhat_b) ),  dgamma_b += sum dz*xhat_b,
+ *                     dbeta_b += sum dz      (xhat_b = (x_b - mean_b)*invstd_b, batch statistics: torch's batch_norm_backward)
+ *   branch without:   dx_b = dz * scale_b (scale NULL = 1)
+ *   shortcut:         dres (+)= alpha*dout,  dalpha += sum dout*res
+ * z is recomputed from the saved branch inputs.  dx_b views may be `dilated` (dx_dil = 2: element (y,x) is written at
+ * (2y,2x) of a pre-zeroed buffer - the zero-inserted gradient a stride-2 conv's data gradient convolves) and may
+ * accumulate (+=). */
+typedef struct y6_bnact_bwd_desc {
+    y6_bnact_desc fwd;             /* the forward op's operands (out unused) */
+    const float* mean[3];          /* NULL: branch b has no BatchNorm */
+    const float* invstd[3];
+    const float* gamma[3];         /* NULL = 1 */
+    y6_tensor dout;
+    y6_tensor dx[3];               /* data == NULL: not needed */
+    int32_t dx_dil[3];             /* 1 or 2 */
+    int32_t dx_acc[3];             /* 1: += */
+    float* dgamma[3];              /* += ; NULL: skip */
+    float* dbeta[3];
+    y6_tensor dres;                /* data == NULL: none */
+    int32_t dres_acc;
+    float* dalpha;                 /* += ; NULL: skip */
+    void* workspace;               /* y6_bnact_bwd_workspace_bytes(C) */
+    size_t workspace_bytes;
+} y6_bnact_bwd_desc;
+size_t y6_bnact_bwd_workspace_bytes(int C);
+int y6_bnact_backward(const y6_bnact_bwd_desc* d, void* stream);
+
+/* Channel-major ("transposed") sampling of an activation for the weight-gradient GEMM:
+ *   dst[c][b][r][q] = src(b, r*sy + oy, q*sx + ox, c)   (0 outside the image),  r < R, q < Q (Q % 16 == 0)
+ * src: an NHWC fp16 view, or (nchw != 0) the caller's NCHW image tensor (fp16 / fp32) - the stem's input. */
+typedef struct y6_wgrad_t_desc {
+    y6_tensor src;                 /* NHWC view; for nchw: data = NCHW base, C/H/W/B filled, cstride/coff ignored */
+    int32_t nchw, src_dtype;       /* src_dtype: Y6_F16 / Y6_F32 (nchw only) */
+    int32_t sy, sx, oy, ox, R, Q;
+    void* dst;                     /* fp16 [C][B][R][Q] */
+} y6_wgrad_t_desc;
+int y6_wgrad_transpose(const y6_wgrad_t_desc* d, void* stream);
+
+/* Weight gradient as a tap-table GEMM over pixels on the matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate):
+ *   out[m*sm + n*sn + t*st] += sum_{b, y<rows, q<Q} A[m][b][y][q] * P_t[n][b][y + drow_t][q + shift_t]
+ * A and the planes P are y6_wgrad_transpose outputs (q contiguous: both operands are read straight from memory as MFMA
+ * fragments, the +-1 column shifts are built in registers).  Replaces the weight half of autograd's conv backward for
+ *   3x3 s1 (mode 0: one plane with a zero row above/below, 9 taps), 1x1 (mode 1), 3x3 s2 (mode 2: four row/column parity
+ *   planes), ConvTranspose2d k2 s2 (mode 3: A = input, planes = the four parities of dout).                          */
+enum { Y6_WG_3X3S1 = 0, Y6_WG_1X1 = 1, Y6_WG_3X3S2 = 2, Y6_WG_CONVT = 3 };
+typedef struct y6_wgrad_desc {
+    int32_t mode;
+    const void* a;                 /* [M][B][a_rows][Q] */
+    int32_t M, N, B, Q, rows, a_rows;
+    const void* plane[6];          /* per stream (mode table in wgrad.hip): [N][B][plane_rows[s]][Q] */
+    int32_t plane_rows[6];
+    int32_t drow[6];
+    float* out;
+    int32_t sm, sn, st;            /* element strides of the output (OIHW: sm = N*T, sn = T, st = 1) */
+    double flops;                  /* algorithmic FLOPs (2*M*N*T*B*Ho*Wo), for the timing table */
+} y6_wgrad_desc;
+int y6_wgrad(const y6_wgrad_desc* d, void* stream);
+
+/* Per-step weight preparation: every packed fp16 MFMA weight image the step's convs read is rebuilt from the fp32
+ * master parameters by ONE launch over a device job table.
+ *   kind 0: forward conv    dst = pack(W[Cout][Cin][K][K])
+ *   kind 1: data gradient   dst = pack(W'[Cin][Cout][K][K]),  W'[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]
+ *   kind 2: ConvTranspose2d forward (IOHW [Cin][Cout][2][2], the fused four-sub-kernel image of y6_pack_convt2x2_weight)
+ *   kind 3: ConvTranspose2d data gradient as a 1x1 conv over space-to-depth(dout): W'[ci][sub*Cout+co] = W[ci][co][sub] */
+typedef struct y6_pack_job {
+    const float* src;
+    void* dst;
+    int32_t kind, Cout, Cin, K;
+    uint64_t first;                /* index of this job's first packed element in the concatenated work list */
+} y6_pack_job;
+typedef struct y6_pack_batch_desc {
+    const y6_pack_job* jobs;       /* DEVICE array */
+    int32_t njobs;
+    uint64_t total;                /* packed elements over all jobs */
+} y6_pack_batch_desc;
+size_t y6_pack_job_elems(int kind, int Cout, int Cin, int K);
+int y6_pack_weights_batched(const y6_pack_batch_desc* d, void* stream);
+
+/* Backward of the three chained 5x5 max-pools of SPPFModule / CSPSPPFModule (common.py:106-112, :150-158):
+ * gradients flow to the FIRST maximum of each window in row-major order (torch max_pool2d_with_indices).
+ *   dx (+)= dcat0 + bwd(x->y1, dy1 + bwd(y1->y2, dy2 + bwd(y2->y3, dy3))) */
+typedef struct y6_sppf_bwd_desc {
+    y6_tensor x, y1, y2;           /* forward tensors (y3 is not needed) */
+    y6_tensor dy1, dy2, dy3;       /* gradients wrt the three pooled slices */
+    y6_tensor dx;                  /* gradient wrt x (the cv1 / cv4 output slice): receives the sum */
+    int32_t dx_acc;                /* 1: dx already holds the gradient that reached x directly (concat slice 0) */
+} y6_sppf_bwd_desc;
+int y6_sppf_pool_backward(const y6_sppf_bwd_desc* d, void* stream);
+
+/* Detect training branch (effidehead.py:72-92): per-level NHWC prediction maps -> cls_scores [B,A,nc] = sigmoid(logits),
+ * reg_distri [B,A,nreg], both fp32 (the loss computes in fp32, loss.py:208); and its backward
+ * dlogit = dscore * p * (1-p), dreg passes through, written as NHWC fp16 per level. */
+typedef struct y6_head_pack_desc {
+    int32_t n_levels;
+    y6_tensor cls[4], reg[4];      /* forward: inputs; backward: gradient outputs */
+    float* scores;                 /* [B,A,nc]   forward: out;  backward: in (the saved probabilities) */
+    float* distri;                 /* [B,A,nreg] forward: out;  backward: unused */
+    const float* dscores;          /* backward only */
+    const float* ddistri;
+    int32_t nc, nreg;
+} y6_head_pack_desc;
+int y6_head_pack(const y6_head_pack_desc* d, void* stream);
+int y6_head_unpack_backward(const y6_head_pack_desc* d, void* stream);
+
+/* space-to-depth for ConvTranspose2d's data gradient: dst[b,y,x,sub*C + c] = src[b,2y+dy,2x+dx,c], sub = dy*2+dx */
+int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, void* stream);
+/* per-channel sum of an NHWC fp16 view, accumulated into fp32: bias gradients of ConvTranspose2d / prediction convs */
+int y6_channel_sum(const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes, void* stream);
+/* dst (=|+=) a  for NHWC fp16 views of one shape (gradient fan-in of tensors with several consumers) */
+int y6_tensor_add(const y6_tensor* a, const y6_tensor* dst, int accumulate, void* stream);
+
+/* Training loss WITH gradient: y6_loss_forward's value plus d loss / d pred_scores and d loss / d pred_distri
+ * (through bbox_decode's DFL projection, dist2bbox, the IoU loss, the DFL cross entropies and VarifocalLoss including
+ * its prediction-dependent weight), multiplied by *grad_scale (device scalar, NULL = 1: the GradScaler's loss scale). */
+typedef struct y6_loss_grad_desc {
+    y6_loss_desc fwd;
+    const float* grad_scale;
+    float* dpred_scores;           /* [B,A,C] */
+    float* dpred_distri;           /* [B,A,4*(reg_max+1)] or [B,A,4] */
+} y6_loss_grad_desc;
+int y6_loss_forward_backward(const y6_loss_grad_desc* d, void* stream);
+/* gradient only: d->fwd.out must hold the result of y6_loss_forward on the same operands */
+int y6_loss_backward(const y6_loss_grad_desc* d, void* stream);
+
+/* SGD with (Nesterov) momentum over a flat fp32 arena, unscaling and overflow handling fused
+ * (torch.optim.SGD as configured by yolov6/solver/build.py:10-30 + GradScaler.step/update, engine.py:258-266):
+ *   y6_grad_finite_check  *found_inf = 1 if any gradient is inf/nan
+ *   y6_sgd_step           if !*found_inf:  g = grad * (1/ *scale) + wd*p;  buf = first ? g : mom*buf + g;
+ *                                          p -= lr * (nesterov ? g + mom*buf : buf)
+ *   y6_scaler_update      scale <- scale*backoff on overflow, *growth after `interval` clean steps; found_inf <- 0 */
+int y6_grad_finite_check(const float* grad, size_t n, int32_t* found_inf, void* stream);
+int y6_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, float weight_decay,
+                int nesterov, int first_step, const float* scale, const int32_t* found_inf, void* stream);
+int y6_scaler_update(float* scale, int32_t* found_inf, int32_t* growth_tracker, float growth, float backoff, int interval,
+                     void* stream);
+
+/* plan builders for the ops above */
+int y6_plan_add_bn_train_stats(y6_plan* p, const y6_bn_train_desc* d);
+int y6_plan_add_bnact_forward(y6_plan* p, const y6_bnact_desc* d);
+int y6_plan_add_bnact_backward(y6_plan* p, const y6_bnact_bwd_desc* d);
+int y6_plan_add_wgrad_transpose(y6_plan* p, const y6_wgrad_t_desc* d);
+int y6_plan_add_wgrad(y6_plan* p, const y6_wgrad_desc* d);
+int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d);
+int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
+int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);
+int y6_plan_add_head_unpack_backward(y6_plan* p, const y6_head_pack_desc* d);
+int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
+int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes);
+int y6_plan_add_tensor_add(y6_plan* p, const y6_tensor* a, const y6_tensor* dst, int accumulate);
+int y6_plan_add_fill_zero(y6_plan* p, void* ptr, size_t bytes);
+
 /* ------------------------------------------------------------------------------------ */
 /* Execution plan: an ordered list of the ops above with fixed pointers, replayed with one
  * call per forward (optionally from a captured hipGraph).  This is the native executor
  * behind Model.forward  yolov6/models/yolo.py:33-41.                                      */
-typedef struct y6_plan y6_plan;
 enum { Y6_OP_CONV = 1, Y6_OP_CONVT = 2, Y6_OP_STEM = 3, Y6_OP_SPPF = 4, Y6_OP_DECODE = 5,
-       Y6_OP_NCHW2NHWC = 6, Y6_OP_NHWC2NCHW = 7 };
+       Y6_OP_NCHW2NHWC = 6, Y6_OP_NHWC2NCHW = 7, Y6_OP_GENERIC = 8 /* training ops: tag = Y6_TOP_* */ };
 
 y6_plan* y6_plan_create(void);
 void y6_plan_destroy(y6_plan* p);

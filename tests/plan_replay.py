@@ -26,7 +26,7 @@ class OracleChain:
 
     # ---------------------------------------------------------------- buffer bookkeeping
     def _get(self, ref):
-        return self.cpu[ref.buf.data_ptr()][:, ref.coff:ref.coff + ref.C]
+        return self.cpu[ref.buf.data_ptr()][:, ref.coff:ref.coff + ref.C].contiguous()
 
     def _put(self, ref, val):
         key = ref.buf.data_ptr()

@@ -52,7 +52,10 @@ def test_per_layer_teacher_forced_and_end_to_end(name, size, batch):
         chain = OracleChain(plan, orc)
         # free-running comparison first (HIP buffers still hold the HIP pipeline's own activations)
         chain.run(teacher_force=False)
-        assert torch.equal(chain.final, ref), "per-layer oracle chain != Oracle.forward (test harness out of sync)"
+        # the chain multiplies with the plan's folded weights, Oracle.forward with its own fold of the same parameters
+        # (same formulas, fp32 association differs in the bias sum): equal up to isolated fp16 flips
+        sync = float(((chain.final - ref).abs() / ref.abs().clamp(min=1.0)).max())
+        assert sync < 2e-3, f"per-layer oracle chain deviates from Oracle.forward by {sync:.3e} (test harness out of sync)"
         free = []
         for i, e in enumerate(plan.op_log):
             outs = e.get("outs") or ([e["out"]] if e["kind"] in ("conv", "stem", "convt") else [])
@@ -71,7 +74,7 @@ def test_per_layer_teacher_forced_and_end_to_end(name, size, batch):
             jump = dict(op=f["op"], gain=f["err"] - prev, err=f["err"])
         prev = max(prev, f["err"])
     desc = {r["op"]: r["desc"] for r in rows}
-    summary = dict(model=name, size=size, batch=batch, ops=len(rows), per_layer_max=worst["err"], per_layer_worst=worst["desc"],
+    summary = dict(model=name, size=size, batch=batch, ops=len(rows), chain_vs_oracle_forward=sync, per_layer_max=worst["err"], per_layer_worst=worst["desc"],
                    end_to_end=rep, free_running_largest_jump=dict(jump, desc=desc.get(jump["op"], "?")),
                    free_running_final_layer_err=free[-1]["err"] if free else None)
     out_dir = os.path.join(ROOT, "gpurun_out")

@@ -86,6 +86,64 @@ class BnApplyDesc(C.Structure):
                 ("out", Tensor), ("act", C.c_int32)]
 
 
+class BnTrainDesc(C.Structure):
+    _fields_ = [("x", Tensor), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class BnActDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("x", Tensor * 3), ("scale", C.c_void_p * 3), ("shift", C.c_void_p * 3), ("res", Tensor),
+                ("res_alpha", C.c_void_p), ("out", Tensor), ("act", C.c_int32)]
+
+
+class BnActBwdDesc(C.Structure):
+    _fields_ = [("fwd", BnActDesc), ("mean", C.c_void_p * 3), ("invstd", C.c_void_p * 3), ("gamma", C.c_void_p * 3),
+                ("dout", Tensor), ("dx", Tensor * 3), ("dx_dil", C.c_int32 * 3), ("dx_acc", C.c_int32 * 3),
+                ("dgamma", C.c_void_p * 3), ("dbeta", C.c_void_p * 3), ("dres", Tensor), ("dres_acc", C.c_int32),
+                ("dalpha", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class WgradTDesc(C.Structure):
+    _fields_ = [("src", Tensor), ("nchw", C.c_int32), ("src_dtype", C.c_int32), ("sy", C.c_int32), ("sx", C.c_int32),
+                ("oy", C.c_int32), ("ox", C.c_int32), ("R", C.c_int32), ("Q", C.c_int32), ("dst", C.c_void_p)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("a", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("B", C.c_int32), ("Q", C.c_int32),
+                ("rows", C.c_int32), ("a_rows", C.c_int32), ("plane", C.c_void_p * 6), ("plane_rows", C.c_int32 * 6),
+                ("drow", C.c_int32 * 6), ("out", C.c_void_p), ("sm", C.c_int32), ("sn", C.c_int32), ("st", C.c_int32),
+                ("flops", C.c_double)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("K", C.c_int32), ("first", C.c_uint64)]
+
+
+class PackBatchDesc(C.Structure):
+    _fields_ = [("jobs", C.c_void_p), ("njobs", C.c_int32), ("total", C.c_uint64)]
+
+
+class SppfBwdDesc(C.Structure):
+    _fields_ = [("x", Tensor), ("y1", Tensor), ("y2", Tensor), ("dy1", Tensor), ("dy2", Tensor), ("dy3", Tensor),
+                ("dx", Tensor), ("dx_acc", C.c_int32)]
+
+
+class HeadPackDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("cls", Tensor * 4), ("reg", Tensor * 4), ("scores", C.c_void_p),
+                ("distri", C.c_void_p), ("dscores", C.c_void_p), ("ddistri", C.c_void_p), ("nc", C.c_int32), ("nreg", C.c_int32)]
+
+
+class LossGradDesc(C.Structure):
+    _fields_ = [("fwd", LossDesc), ("grad_scale", C.c_void_p), ("dpred_scores", C.c_void_p), ("dpred_distri", C.c_void_p)]
+
+
+WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
+TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
+             8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add"}
+
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
 # symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
@@ -118,6 +176,39 @@ SIGNATURES = {
     "y6_bn_stats_workspace_bytes": (C.c_size_t, [C.c_int]),
     "y6_bn_stats": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y6_bn_apply": (C.c_int, [C.POINTER(BnApplyDesc), C.c_void_p]),
+    "y6_bn_train_stats": (C.c_int, [C.POINTER(BnTrainDesc), C.c_void_p]),
+    "y6_bnact_forward": (C.c_int, [C.POINTER(BnActDesc), C.c_void_p]),
+    "y6_bnact_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "y6_bnact_backward": (C.c_int, [C.POINTER(BnActBwdDesc), C.c_void_p]),
+    "y6_wgrad_transpose": (C.c_int, [C.POINTER(WgradTDesc), C.c_void_p]),
+    "y6_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "y6_pack_job_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "y6_pack_weights_batched": (C.c_int, [C.POINTER(PackBatchDesc), C.c_void_p]),
+    "y6_sppf_pool_backward": (C.c_int, [C.POINTER(SppfBwdDesc), C.c_void_p]),
+    "y6_head_pack": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
+    "y6_head_unpack_backward": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
+    "y6_space_to_depth2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
+    "y6_channel_sum": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "y6_tensor_add": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_void_p]),
+    "y6_loss_forward_backward": (C.c_int, [C.POINTER(LossGradDesc), C.c_void_p]),
+    "y6_loss_backward": (C.c_int, [C.POINTER(LossGradDesc), C.c_void_p]),
+    "y6_grad_finite_check": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "y6_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y6_scaler_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "y6_plan_add_bn_train_stats": (C.c_int, [C.c_void_p, C.POINTER(BnTrainDesc)]),
+    "y6_plan_add_bnact_forward": (C.c_int, [C.c_void_p, C.POINTER(BnActDesc)]),
+    "y6_plan_add_bnact_backward": (C.c_int, [C.c_void_p, C.POINTER(BnActBwdDesc)]),
+    "y6_plan_add_wgrad_transpose": (C.c_int, [C.c_void_p, C.POINTER(WgradTDesc)]),
+    "y6_plan_add_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradDesc)]),
+    "y6_plan_add_pack_batch": (C.c_int, [C.c_void_p, C.POINTER(PackBatchDesc)]),
+    "y6_plan_add_sppf_backward": (C.c_int, [C.c_void_p, C.POINTER(SppfBwdDesc)]),
+    "y6_plan_add_head_pack": (C.c_int, [C.c_void_p, C.POINTER(HeadPackDesc)]),
+    "y6_plan_add_head_unpack_backward": (C.c_int, [C.c_void_p, C.POINTER(HeadPackDesc)]),
+    "y6_plan_add_space_to_depth2": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor)]),
+    "y6_plan_add_channel_sum": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_size_t]),
+    "y6_plan_add_tensor_add": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor), C.c_int]),
+    "y6_plan_add_fill_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "y6_plan_create": (C.c_void_p, []),
     "y6_plan_destroy": (None, [C.c_void_p]),
     "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),

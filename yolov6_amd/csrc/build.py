@@ -31,9 +31,11 @@ SOURCES = {
     "tal.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=off"],
     "bn_train.hip": [],
+    "train.hip": [],
+    "wgrad.hip": [],
     "plan.hip": [],
 }
-HEADERS = ["common.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
+HEADERS = ["common.hpp", "plan_internal.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
 
 
 def hipcc():

@@ -49,11 +49,18 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// The reference's half-precision model rounds to fp16 at every op boundary (conv -> activation -> residual add are
+// separate fp16 aten ops).  The fused epilogues compute in fp32 but round at the SAME places, so a fused kernel
+// reproduces the reference's fp16 pipeline instead of being "more accurate" by up to 2 ulp per layer (measured:
+// tests/test_gpu_parity_bench.py).  ReLU commutes with the rounding and needs none.
+__device__ __forceinline__ float y6_round_f16(float v) { return (float)(_Float16)v; }
+
 __device__ __forceinline__ float y6_act(float v, int act) {
     switch (act) {
         case Y6_ACT_RELU: return v > 0.f ? v : 0.f;
-        case Y6_ACT_SILU: return v / (1.f + __expf(-v));
+        case Y6_ACT_SILU: v = y6_round_f16(v); return v / (1.f + __expf(-v));
         case Y6_ACT_HARDSWISH: {
+            v = y6_round_f16(v);
             float r = v + 3.f;
             r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r);
             return v * r * (1.f / 6.f);

@@ -84,8 +84,12 @@ struct HaloCap {
 template <int ACT>
 __device__ __forceinline__ float act_const(float v) {
     if constexpr (ACT == Y6_ACT_RELU) return v > 0.f ? v : 0.f;
-    if constexpr (ACT == Y6_ACT_SILU) return v / (1.f + __expf(-v));
+    if constexpr (ACT == Y6_ACT_SILU) {
+        v = y6_round_f16(v);            // the conv output is an fp16 tensor in the reference (common.hpp)
+        return v / (1.f + __expf(-v));
+    }
     if constexpr (ACT == Y6_ACT_HARDSWISH) {
+        v = y6_round_f16(v);
         float r = v + 3.f;
         r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r);
         return v * r * (1.f / 6.f);
@@ -106,9 +110,9 @@ __device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc
         const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
         float x = acc[r] + bias[r];
         if (c < cend) {
-            if (a.pscale) x = x * a.pscale[c] + a.pshift[c];
+            if (a.pscale) x = y6_round_f16(x) * a.pscale[c] + a.pshift[c];      // QARepVGG: conv -> BN are two fp16 ops
             x = act_const<ACT>(x);
-            if (rrow) x += ralpha * __half2float(rrow[c]);
+            if (rrow) x = y6_round_f16(x) + y6_round_f16(ralpha * __half2float(rrow[c]));   // BottleRep: out + alpha*x
         } else {
             x = act_const<ACT>(x);
         }

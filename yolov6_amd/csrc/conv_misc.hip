@@ -90,10 +90,10 @@ __global__ void conv_naive_kernel(const __half* __restrict__ in, __half* __restr
             }
         }
         if (bias) acc += bias[co];
-        if (pscale) acc = acc * pscale[co] + pshift[co];
+        if (pscale) acc = y6_round_f16(acc) * pscale[co] + pshift[co];
         acc = y6_act(acc, act);
         const size_t op = ((size_t)(b * Ho + oy) * Wo + ox);
-        if (res) acc += ra * __half2float(res[op * res_cs + res_co + co]);
+        if (res) acc = y6_round_f16(acc) + y6_round_f16(ra * __half2float(res[op * res_cs + res_co + co]));
         out[op * out_cs + out_co + co] = __float2half(acc);
     }
 }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ i
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float x = acc[c0 + j];
-            if (pscale) x = x * pscale[c0 + j] + pshift[c0 + j];
+            if (pscale) x = y6_round_f16(x) * pscale[c0 + j] + pshift[c0 + j];
             o[j] = (_Float16)y6_act(x, act);
         }
         *reinterpret_cast<h8_t*>(op + c0) = o;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
                     float x = acc[cf][pf][r4 * 4 + j];
                     if (c < Cout) {
                         if (bias) x += bias[c];
-                        if (pscale) x = x * pscale[c] + pshift[c];
+                        if (pscale) x = y6_round_f16(x) * pscale[c] + pshift[c];
                         x = y6_act(x, act);
                     }
                     o[j] = (_Float16)x;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void stem_mfma_v4_kernel(const TI* __restrict_
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float x = acc[cf][pf][r4 * 4 + j] + bz[cf][r4 * 4 + j];
-                            if (affine) x = x * psc[cf][r4 * 4 + j] + psh[cf][r4 * 4 + j];
+                            if (affine) x = y6_round_f16(x) * psc[cf][r4 * 4 + j] + psh[cf][r4 * 4 + j];
                             o[j] = (_Float16)actfn(x);
                         }
                         if (rows_ok) {

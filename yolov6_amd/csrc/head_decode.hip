@@ -33,13 +33,13 @@ __device__ __forceinline__ float side_dist(const DecodeArgs& a, int l, size_t pi
     const __half* bins = r + side * nb;
     float m = -INFINITY;
     for (int k = 0; k < nb; ++k) m = fmaxf(m, __half2float(bins[k]));
-    float den = 0.f, num = 0.f;
-    for (int k = 0; k < nb; ++k) {
-        const float e = __expf(__half2float(bins[k]) - m);
-        den += e;
-        num += e * a.proj[k];
-    }
-    return num / den;
+    // op boundaries of the reference's half-precision model (effidehead.py:107-109): F.softmax returns fp16
+    // probabilities, proj_conv (fp32 accumulation) returns an fp16 distance - rounded at the same two places here
+    float den = 0.f;
+    for (int k = 0; k < nb; ++k) den += __expf(__half2float(bins[k]) - m);
+    float num = 0.f;
+    for (int k = 0; k < nb; ++k) num += y6_round_f16(__expf(__half2float(bins[k]) - m) / den) * a.proj[k];
+    return y6_round_f16(num);
 }
 
 __device__ __forceinline__ float decode_element(const DecodeArgs& a, size_t i, int no) {
@@ -56,7 +56,7 @@ __device__ __forceinline__ float decode_element(const DecodeArgs& a, size_t i, i
     const size_t pix = ((size_t)b * a.H[l] + y) * a.W[l] + x;
     if (j >= 5) {
         const float z = __half2float(a.cls[l][pix * a.cls_cs[l] + a.cls_co[l] + (j - 5)]);
-        return 1.f / (1.f + __expf(-z));
+        return y6_round_f16(1.f / (1.f + __expf(-z)));   // torch.sigmoid of an fp16 tensor is fp16
     }
     if (j == 4) return 1.f;
     // (l,t,r,b) distances -> xywh
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void head_decode_tiled_kernel(const DecodeArgs
         const __half* h = reinterpret_cast<const __half*>(&raw);
         float* r = s_rows + t * no + 5 + piece * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = 1.f / (1.f + __expf(-__half2float(h[j])));
+        for (int j = 0; j < 8; ++j) r[j] = y6_round_f16(1.f / (1.f + __expf(-__half2float(h[j]))));
     }
     __syncthreads();
     const size_t obase = ((size_t)b * a.A + a0) * no;

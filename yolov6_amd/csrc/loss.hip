@@ -5,8 +5,8 @@
 //   BboxLoss         :214-278  IOUloss (utils/figure_iou.py:7-100, xyxy, eps 1e-10) * sum_c target_scores, DFL two-bin
 //                              cross entropy (:267-278); both / target_scores_sum when that is > 1 (:168-169, :238-261)
 //   weights          :171-181  loss = w_class*cls + w_iou*iou + w_dfl*dfl; items = (w_iou*iou, w_dfl*dfl, w_class*cls)
-// The label assignment in between is y6_tal_assign / y6_atss_assign (tal.hip).  VALUES ONLY: the backward pass of
-// the training step is not part of this library yet.
+// The label assignment in between is y6_tal_assign / y6_atss_assign (tal.hip).  y6_loss_forward_backward adds the gradients
+// wrt pred_scores / pred_distri (dual-number IoU, closed forms for the rest).
 // Compile with -ffp-contract=off: every elementwise term follows the reference's unfused fp32 arithmetic; only the
 // final sums differ (block partials in double, one double atomic per block - order independent to ~1e-12).
 #include "common.hpp"
@@ -205,6 +205,182 @@ __global__ void loss_finalize_kernel(const double* __restrict__ acc, float w_cla
     out[5] = npos;
 }
 
+// ------------------------------------------------------------------ gradient (training step)
+// Forward-mode dual numbers over the four coordinates of the predicted box: ONE statement of the IoU family gives the
+// exact derivative autograd would produce for every iou_type.  Conventions at non-smooth points follow torch:
+// maximum/minimum split the gradient at ties, clamp passes it at the bound, abs'(0) = 0.
+struct D4 {
+    float v;
+    float d[4];
+};
+__device__ __forceinline__ D4 dconst(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 dvar(float c, int i) {
+    D4 r = dconst(c);
+    r.d[i] = 1.f;
+    return r;
+}
+#define D4_EACH(expr)              \
+    D4 r;                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) r.d[i] = (expr);
+__device__ __forceinline__ D4 operator+(const D4& a, const D4& b) { D4_EACH(a.d[i] + b.d[i]) r.v = a.v + b.v; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, const D4& b) { D4_EACH(a.d[i] - b.d[i]) r.v = a.v - b.v; return r; }
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) { D4_EACH(a.d[i] * b.v + a.v * b.d[i]) r.v = a.v * b.v; return r; }
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) {
+    const float q = a.v / b.v;
+    D4_EACH((a.d[i] - q * b.d[i]) / b.v) r.v = q; return r;
+}
+__device__ __forceinline__ D4 operator+(const D4& a, float c) { D4 r = a; r.v += c; return r; }
+__device__ __forceinline__ D4 operator-(const D4& a, float c) { D4 r = a; r.v -= c; return r; }
+__device__ __forceinline__ D4 operator-(float c, const D4& a) { D4_EACH(-a.d[i]) r.v = c - a.v; return r; }
+__device__ __forceinline__ D4 operator*(const D4& a, float c) { D4_EACH(a.d[i] * c) r.v = a.v * c; return r; }
+__device__ __forceinline__ D4 dmax(const D4& a, const D4& b) {
+    if (a.v > b.v) return a;
+    if (b.v > a.v) return b;
+    D4_EACH(0.5f * (a.d[i] + b.d[i])) r.v = a.v; return r;
+}
+__device__ __forceinline__ D4 dmin(const D4& a, const D4& b) {
+    if (a.v < b.v) return a;
+    if (b.v < a.v) return b;
+    D4_EACH(0.5f * (a.d[i] + b.d[i])) r.v = a.v; return r;
+}
+__device__ __forceinline__ D4 dclamp0(const D4& a) { return a.v >= 0.f ? a : dconst(0.f); }
+__device__ __forceinline__ D4 dabs(const D4& a) {
+    const float s = a.v > 0.f ? 1.f : (a.v < 0.f ? -1.f : 0.f);
+    D4_EACH(s * a.d[i]) r.v = fabsf(a.v); return r;
+}
+__device__ __forceinline__ D4 dfun(const D4& a, float value, float slope) { D4_EACH(slope * a.d[i]) r.v = value; return r; }
+__device__ __forceinline__ D4 dsqrt(const D4& a) { const float s = sqrtf(a.v); return dfun(a, s, 0.5f / s); }
+__device__ __forceinline__ D4 dexp(const D4& a) { const float e = expf(a.v); return dfun(a, e, e); }
+__device__ __forceinline__ D4 datan(const D4& a) { return dfun(a, atanf(a.v), 1.f / (1.f + a.v * a.v)); }
+__device__ __forceinline__ D4 dasin(const D4& a) { return dfun(a, asinf(a.v), 1.f / sqrtf(1.f - a.v * a.v)); }
+__device__ __forceinline__ D4 dcos(const D4& a) { return dfun(a, cosf(a.v), -sinf(a.v)); }
+#undef D4_EACH
+
+// utils/figure_iou.py:53-95 on dual numbers; b1 = prediction (variables), b2 = target (constants).  Returns 1 - iou.
+__device__ D4 iou_loss_dual(const float4 p, const float4 t, int type) {
+    const float e = 1e-10f;
+    const D4 x1 = dvar(p.x, 0), y1 = dvar(p.y, 1), x2 = dvar(p.z, 2), y2 = dvar(p.w, 3);
+    const D4 tx1 = dconst(t.x), ty1 = dconst(t.y), tx2 = dconst(t.z), ty2 = dconst(t.w);
+    const D4 inter = dclamp0(dmin(x2, tx2) - dmax(x1, tx1)) * dclamp0(dmin(y2, ty2) - dmax(y1, ty1));
+    const D4 w1 = x2 - x1, h1 = y2 - y1 + e;
+    const float w2 = t.z - t.x, h2 = t.w - t.y + e;
+    const D4 uni = w1 * h1 + (w2 * h2) - inter + e;
+    D4 iou = inter / uni;
+    const D4 cw = dmax(x2, tx2) - dmin(x1, tx1), ch = dmax(y2, ty2) - dmin(y1, ty1);
+    if (type == Y6_IOU_GIOU) {
+        const D4 c_area = cw * ch + e;
+        iou = iou - (c_area - uni) / c_area;
+    } else if (type == Y6_IOU_DIOU || type == Y6_IOU_CIOU) {
+        const D4 c2 = cw * cw + ch * ch + e;
+        const D4 dx = (t.x + t.z) - x1 - x2, dy = (t.y + t.w) - y1 - y2;
+        const D4 rho2 = (dx * dx + dy * dy) * 0.25f;
+        if (type == Y6_IOU_DIOU) {
+            iou = iou - rho2 / c2;
+        } else {
+            const D4 dt = atanf(w2 / h2) - datan(w1 / h1);
+            const D4 v = (dt * dt) * (4.f / (kPi * kPi));
+            const float alpha = v.v / (v.v - iou.v + (1.f + e));      // torch.no_grad() in the reference (:76-77)
+            iou = iou - (rho2 / c2 + v * alpha);
+        }
+    } else if (type == Y6_IOU_SIOU) {
+        const D4 s_cw = ((t.x + t.z) - x1 - x2) * 0.5f + e;
+        const D4 s_ch = ((t.y + t.w) - y1 - y2) * 0.5f + e;
+        const D4 sigma = dsqrt(s_cw * s_cw + s_ch * s_ch);
+        const D4 sa1 = dabs(s_cw) / sigma, sa2 = dabs(s_ch) / sigma;
+        const D4 sa = sa1.v > 0.70710678118654752f ? sa2 : sa1;
+        const D4 angle_cost = dcos(dasin(sa) * 2.f - (kPi / 2.f));
+        const D4 rx = (s_cw / cw) * (s_cw / cw), ry = (s_ch / ch) * (s_ch / ch);
+        const D4 gamma = angle_cost - 2.f;
+        const D4 distance_cost = 2.f - dexp(gamma * rx) - dexp(gamma * ry);
+        const D4 ow = dabs(w1 - w2) / dmax(w1, dconst(w2)), oh = dabs(h1 - h2) / dmax(h1, dconst(h2));
+        const D4 tw = 1.f - dexp(dconst(0.f) - ow), th = 1.f - dexp(dconst(0.f) - oh);
+        const D4 shape_cost = (tw * tw) * (tw * tw) + (th * th) * (th * th);
+        iou = iou - (distance_cost + shape_cost) * 0.5f;
+    }
+    return 1.f - iou;
+}
+
+// d loss / d pred_scores: VarifocalLoss with its prediction-dependent weight (loss.py:203-209); BCE's gradient as torch
+// writes it, (p - q) / max((1-p) p, 1e-12).  fin = y6_loss_forward's out[] (fin[4] = target_scores_sum).
+__global__ __launch_bounds__(256) void loss_cls_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tscore,
+                                                           const int64_t* __restrict__ tlabel, const uint8_t* __restrict__ fg,
+                                                           size_t n_ba, int C, const double* __restrict__ fin, float w_class,
+                                                           const float* __restrict__ grad_scale, float* __restrict__ dpred) {
+    const double ts = fin[4];
+    const float coef = w_class * (grad_scale ? *grad_scale : 1.f) * (ts > 1.0 ? (float)(1.0 / ts) : 1.f);
+    const size_t total = n_ba * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t ba = i / C;
+        const int c = (int)(i - ba * C);
+        const float p = pred[i], q = tscore[i];
+        const float y = (fg[ba] && tlabel[ba] == (int64_t)c) ? 1.f : 0.f;
+        const float weight = 0.75f * (p * p) * (1.f - y) + q * y;
+        const float dweight = 0.75f * 2.f * p * (1.f - y);
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+        const float bce = -(q * lp + (1.f - q) * l1p);
+        const float dbce = (p - q) / fmaxf((1.f - p) * p, 1e-12f);
+        dpred[i] = coef * (bce * dweight + weight * dbce);
+    }
+}
+
+// d loss / d pred_distri through IoU loss (dual numbers) -> dist2bbox -> DFL projection, plus the DFL cross entropies
+__global__ __launch_bounds__(256) void loss_box_bwd_kernel(const float* __restrict__ pred_distri, const float* __restrict__ pred_bboxes,
+                                                           const float* __restrict__ pts, const float* __restrict__ stride,
+                                                           const float* __restrict__ tboxes, const float* __restrict__ tscore,
+                                                           const uint8_t* __restrict__ fg, int B, int A, int C, int use_dfl, int reg_max,
+                                                           int iou_type, const double* __restrict__ fin, float w_iou, float w_dfl,
+                                                           const float* __restrict__ grad_scale, float* __restrict__ ddistri) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * A) return;
+    const int nb = use_dfl ? reg_max + 1 : 1;
+    float* out = ddistri + i * 4 * nb;
+    if (!fg[i]) {
+        for (int k = 0; k < 4 * nb; ++k) out[k] = 0.f;
+        return;
+    }
+    const double ts = fin[4];
+    const float norm = (grad_scale ? *grad_scale : 1.f) * (ts > 1.0 ? (float)(1.0 / ts) : 1.f);
+    const int a = (int)(i % A);
+    float w = 0.f;
+    for (int c = 0; c < C; ++c) w += tscore[i * C + c];
+    const float st = stride[a];
+    const float4 tb4 = reinterpret_cast<const float4*>(tboxes)[i];
+    const float4 tb = make_float4(tb4.x / st, tb4.y / st, tb4.z / st, tb4.w / st);
+    const float4 pb = reinterpret_cast<const float4*>(pred_bboxes)[i];
+    const D4 l = iou_loss_dual(pb, tb, iou_type);
+    const float ci = w * w_iou * norm;
+    // dist2bbox (general.py:32-43): x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3
+    const float dd[4] = {-ci * l.d[0], -ci * l.d[1], ci * l.d[2], ci * l.d[3]};
+    if (!use_dfl) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[s] = dd[s];
+        return;
+    }
+    const float ax = pts[a * 2], ay = pts[a * 2 + 1];
+    const float hi = (float)reg_max - 0.01f;
+    const float t[4] = {ax - tb.x, ay - tb.y, tb.z - ax, tb.w - ay};
+    const float cd = w * w_dfl * norm * 0.25f;          // .mean(-1) over the four sides (:278)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float* q = pred_distri + (i * 4 + s) * nb;
+        float m = -INFINITY;
+        for (int k = 0; k < nb; ++k) m = fmaxf(m, q[k]);
+        float den = 0.f;
+        for (int k = 0; k < nb; ++k) den += expf(q[k] - m);
+        float ex = 0.f;
+        for (int k = 0; k < nb; ++k) ex += (expf(q[k] - m) / den) * (float)k;
+        const float tv = fminf(fmaxf(t[s], 0.f), hi);
+        const int tl = (int)tv, tr = tl + 1;
+        const float wl = (float)tr - tv, wr = 1.f - wl;
+        for (int k = 0; k < nb; ++k) {
+            const float pk = expf(q[k] - m) / den;
+            float g = dd[s] * pk * ((float)k - ex);                               // softmax . proj
+            g += cd * (pk - (k == tl ? wl : 0.f) - (k == tr ? wr : 0.f));         // two-bin cross entropy
+            out[s * nb + k] = g;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int y6_bbox_decode(const float* pred_distri, const float* anchor_points_s, int B, int A, int use_dfl, int reg_max,
@@ -246,6 +422,31 @@ extern "C" int y6_loss_forward(const y6_loss_desc* d, void* stream) {
                        d->use_dfl, d->reg_max, d->iou_type, acc);
     Y6_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, s, acc, d->w_class, d->w_iou, d->w_dfl, d->use_dfl, d->out);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_loss_forward_backward(const y6_loss_grad_desc* g, void* stream) {
+    Y6_REQUIRE(g, "loss_forward_backward: null argument");
+    int rc = y6_loss_forward(&g->fwd, stream);
+    if (rc) return rc;
+    return y6_loss_backward(g, stream);
+}
+
+extern "C" int y6_loss_backward(const y6_loss_grad_desc* g, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(g && g->dpred_scores && g->dpred_distri && g->fwd.out, "loss_backward: null argument");
+    const y6_loss_desc* d = &g->fwd;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_ba = (size_t)d->B * d->A;
+    size_t gr = (n_ba * d->C + 255) / 256;
+    if (gr > 8192) gr = 8192;
+    hipLaunchKernelGGL(loss_cls_bwd_kernel, dim3((unsigned)gr), dim3(256), 0, s, d->pred_scores, d->target_scores, d->target_labels,
+                       d->fg_mask, n_ba, d->C, d->out, d->w_class, g->grad_scale, g->dpred_scores);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_box_bwd_kernel, dim3((unsigned)((n_ba + 255) / 256)), dim3(256), 0, s, d->pred_distri, d->pred_bboxes,
+                       d->anchor_points_s, d->stride, d->target_bboxes, d->target_scores, d->fg_mask, d->B, d->A, d->C, d->use_dfl,
+                       d->reg_max, d->iou_type, d->out, d->w_iou, d->w_dfl, g->grad_scale, g->dpred_distri);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "plan_internal.hpp"
 
 static thread_local char g_err[512] = "";
 
@@ -44,6 +45,11 @@ struct Op {
     const void* src;
     void* dst;
     int dtype;
+    // generic op (training path, train.hip / wgrad.hip / loss.hip): launcher + descriptor blob
+    y6_generic_fn gfn;
+    int gtag;
+    double gflops, gbytes;
+    alignas(16) unsigned char blob[Y6_GENERIC_BLOB];
 };
 }  // namespace
 
@@ -65,6 +71,7 @@ static int run_op(const Op& op, hipStream_t s) {
         case Y6_OP_DECODE: return y6_head_decode(&op.dec, s);
         case Y6_OP_NCHW2NHWC: return y6_nchw_to_nhwc(op.src, op.dtype, &op.t[0], s);
         case Y6_OP_NHWC2NCHW: return y6_nhwc_to_nchw(&op.t[0], op.dst, op.dtype, s);
+        case Y6_OP_GENERIC: return op.gfn(op.blob, s);
     }
     y6_set_error("plan: unknown op kind %d", op.kind);
     return Y6_EINVAL;
@@ -87,6 +94,9 @@ static void op_cost(const Op& op, double* pf, double* pby) {
              2.0 * o.B * o.H * o.W * o.C;
     } else if (op.kind == Y6_OP_SPPF) {
         by = 2.0 * 4.0 * op.t[0].B * op.t[0].H * op.t[0].W * op.t[0].C;
+    } else if (op.kind == Y6_OP_GENERIC) {
+        f = op.gflops;
+        by = op.gbytes;
     } else if (op.kind == Y6_OP_DECODE) {
         double A = 0;
         for (int l = 0; l < op.dec.n_levels; ++l) A += (double)op.dec.cls[l].H * op.dec.cls[l].W;
@@ -198,7 +208,7 @@ extern "C" int y6_plan_op_info(const y6_plan* p, int i, int32_t* kind, int32_t* 
     const Op& op = p->ops[i];
     if (kind) *kind = op.kind;
     if (variant) *variant = op.kind == Y6_OP_CONV ? op.conv.variant : -1;
-    if (ksize) *ksize = op.kind == Y6_OP_CONV ? op.conv.ksize : 0;
+    if (ksize) *ksize = op.kind == Y6_OP_CONV ? op.conv.ksize : (op.kind == Y6_OP_GENERIC ? op.gtag : 0);
     if (stride) *stride = op.kind == Y6_OP_CONV ? op.conv.stride : 0;
     double f = 0.0, by = 0.0;
     op_cost(op, &f, &by);
@@ -273,6 +283,21 @@ extern "C" int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* d, void* dst, 
     op.dtype = dst_dtype;
     op.t[0] = *d;
     p->ops.push_back(op);
+    return Y6_OK;
+}
+
+int y6_plan_push_generic(y6_plan* p, y6_generic_fn fn, const void* desc, size_t size, int tag, double flops, double bytes) {
+    Y6_REQUIRE(p && fn && desc && size <= Y6_GENERIC_BLOB, "plan_push_generic: bad arguments");
+    drop_graph(p);
+    p->ops.emplace_back();
+    Op& op = p->ops.back();
+    memset((void*)&op, 0, sizeof(op));
+    op.kind = Y6_OP_GENERIC;
+    op.gfn = fn;
+    op.gtag = tag;
+    op.gflops = flops;
+    op.gbytes = bytes;
+    memcpy(op.blob, desc, size);
     return Y6_OK;
 }
 
@@ -399,7 +424,9 @@ extern "C" int y6_plan_capture(y6_plan* p, void* stream) {
 #define Y6_DBG(...) do { if (dbg) { fprintf(stderr, "[plan_capture] " __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
     Y6_DBG("begin: %zu ops, %d streams", p->ops.size(), nstreams);
     if (nstreams < 1) nstreams = 1;
-    if (nstreams > 2) nstreams = 2;   // hipStreamEndCapture of a 4-stream capture of the P6 models crashes inside the runtime (ROCm 7.2): capped
+    if (nstreams > 2) nstreams = 2;
+    for (const Op& op : p->ops)
+        if (op.kind == Y6_OP_GENERIC) nstreams = 1;   // no tensor-view dependence info for generic ops   // hipStreamEndCapture of a 4-stream capture of the P6 models crashes inside the runtime (ROCm 7.2): capped
     const size_t n = p->ops.size();
 
     std::vector<hipStream_t> st(nstreams, s);

@@ -1,0 +1,1123 @@
+// train.hip — the elementwise / reduction half of the TRAINING step on NHWC fp16 activations (gfx950):
+//   y6_bn_train_stats         batch statistics -> scale/shift/mean/invstd + running-stat update, all on device
+//   y6_bnact_forward          act( sum_b x_b*scale_b + shift_b ) [+ alpha*res]      (RepVGG train-form sum, ConvModule BN+act)
+//   y6_bnact_backward         its backward incl. BatchNorm's (two passes: per-channel sums, then the gradients)
+//   y6_wgrad_transpose        channel-major sampling of an activation for the weight-gradient GEMM (wgrad.hip)
+//   y6_pack_weights_batched   per-step fp32 master weights -> packed fp16 MFMA images (forward, data-gradient, convT)
+//   y6_sppf_pool_backward     backward of the three chained 5x5 max-pools
+//   y6_head_pack / _unpack    Detect training branch: sigmoid + [B,A,C] packing, and its backward
+//   y6_space_to_depth2, y6_channel_sum, y6_tensor_add, fused SGD / overflow check / loss-scale update
+// Reference: yolov6/layers/common.py:45-49, :250-255 (forward the autograd graph is built from), torch's
+// batch_norm_backward / max_pool2d_with_indices_backward semantics, yolov6/models/effidehead.py:72-92,
+// yolov6/solver/build.py:10-30, yolov6/core/engine.py:169-176, :258-266.
+// All of these are HBM-bound: 16-byte accesses, one pass per tensor, per-channel sums in double.
+#include "common.hpp"
+#include "plan_internal.hpp"
+
+namespace {
+
+bool view_ok(const y6_tensor& t) {
+    return t.data && t.C % 8 == 0 && t.cstride % 8 == 0 && t.coff % 8 == 0 && (((uintptr_t)t.data) & 15) == 0;
+}
+bool same_shape(const y6_tensor& a, const y6_tensor& b) { return a.B == b.B && a.H == b.H && a.W == b.W && a.C == b.C; }
+
+inline unsigned grid_for(size_t total, int block, size_t cap = 256 * 32) {
+    size_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+__device__ __forceinline__ void load8(const __half* p, float (&v)[8]) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __half2float(h[j]);
+}
+__device__ __forceinline__ void store8(__half* p, const float (&v)[8]) {
+    h8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
+    *reinterpret_cast<h8_t*>(p) = o;
+}
+__device__ __forceinline__ void loadf8(const float* p, float (&v)[8], float dflt) {
+    if (!p) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dflt;
+        return;
+    }
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+}
+
+// ------------------------------------------------------------------ batch statistics (forward)
+__global__ __launch_bounds__(256) void bn_sum_kernel(const __half* __restrict__ x, int cs, int co, long npix, int G,
+                                                     long pix_per_block, double* __restrict__ ws, int C) {
+    extern __shared__ double s_acc[];   // [2*C]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+    const int R = 256 / G;
+    if (tid < R * G) {
+        const int g = tid % G, prow = tid / G;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+        double s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
+        for (long p = p0 + prow; p < p1; p += R) {
+            float v[8];
+            load8(x + p * cs + co + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)v[j];
+                q[j] += (double)v[j] * (double)v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&s_acc[g * 8 + j], s[j]);
+            atomicAdd(&s_acc[C + g * 8 + j], q[j]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) atomicAdd(&ws[i], s_acc[i]);
+}
+
+__global__ void bn_train_finalize_kernel(const double* __restrict__ ws, int C, double n, const y6_bn_train_desc d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && d.num_batches_tracked) *d.num_batches_tracked += 1;
+    if (c >= C) return;
+    const double m = ws[c] / n;
+    double v = ws[C + c] / n - m * m;
+    v = v > 0.0 ? v : 0.0;
+    const float mean = (float)m, var = (float)v;
+    const float invstd = 1.f / sqrtf(var + d.eps);
+    const float g = d.gamma ? d.gamma[c] : 1.f, b = d.beta ? d.beta[c] : 0.f;
+    const float scale = g * invstd;
+    d.scale[c] = scale;
+    d.shift[c] = b - mean * scale;
+    d.mean[c] = mean;
+    d.invstd[c] = invstd;
+    if (d.running_mean) {
+        const float mo = d.momentum;
+        const float unb = (float)(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        d.running_mean[c] = (1.f - mo) * d.running_mean[c] + mo * mean;
+        d.running_var[c] = (1.f - mo) * d.running_var[c] + mo * unb;
+    }
+}
+
+int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d && d->scale && d->shift && d->mean && d->invstd && d->workspace, "bn_train_stats: null argument");
+    Y6_REQUIRE(view_ok(d->x), "bn_train_stats: the view must be fp16 NHWC with 8-channel alignment");
+    const int C = d->x.C, G = C / 8;
+    Y6_REQUIRE(C <= 2048, "bn_train_stats: at most 2048 channels");
+    Y6_REQUIRE(d->workspace_bytes >= (size_t)2 * C * sizeof(double), "bn_train_stats: workspace too small");
+    const long npix = (long)d->x.B * d->x.H * d->x.W;
+    Y6_REQUIRE(npix > 0, "bn_train_stats: empty tensor");
+    double* ws = (double*)d->workspace;
+    Y6_HIP(hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), s));
+    const int R = 256 / G;
+    long ppb = (long)R * 64;
+    long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > 2048) {
+        blocks = 2048;
+        ppb = (npix + blocks - 1) / blocks;
+    }
+    hipLaunchKernelGGL(bn_sum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)2 * C * sizeof(double), s,
+                       (const __half*)d->x.data, d->x.cstride, d->x.coff, npix, G, ppb, ws, C);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, ws, C, (double)npix, *d);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ bn + branch sum + activation (+ shortcut)
+struct BnActArgs {
+    int n;
+    const __half* x[3];
+    int cs[3], co[3];
+    const float* scale[3];
+    const float* shift[3];
+    const __half* res;
+    int rcs, rco;
+    const float* alpha;
+    __half* out;
+    int ocs, oco, act, C;
+    long npix;
+};
+
+__device__ __forceinline__ void preact8(const BnActArgs& a, long p, int g, float (&z)[8], float (&xb)[3][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b >= a.n) break;
+        float sc[8], sh[8];
+        load8(a.x[b] + p * a.cs[b] + a.co[b] + g * 8, xb[b]);
+        loadf8(a.scale[b] ? a.scale[b] + g * 8 : nullptr, sc, 1.f);
+        loadf8(a.shift[b] ? a.shift[b] + g * 8 : nullptr, sh, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] += xb[b][j] * sc[j] + sh[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void bnact_fwd_kernel(const BnActArgs a) {
+    const int G = a.C >> 3;
+    const long total = a.npix * G;
+    const float alpha = a.res ? (a.alpha ? *a.alpha : 1.f) : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / G;
+        const int g = (int)(i - p * G);
+        float z[8], xb[3][8];
+        preact8(a, p, g, z, xb);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = y6_act(z[j], a.act);
+        if (a.res) {
+            float r[8];
+            load8(a.res + p * a.rcs + a.rco + g * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += alpha * r[j];
+        }
+        store8(a.out + p * a.ocs + a.oco + g * 8, o);
+    }
+}
+
+int fill_bnact_args(const y6_bnact_desc* d, BnActArgs* a, bool need_out) {
+    Y6_REQUIRE(d && d->n >= 1 && d->n <= 3, "bnact: 1..3 branches");
+    memset(a, 0, sizeof(*a));
+    a->n = d->n;
+    const y6_tensor& ref = d->x[0];
+    for (int b = 0; b < d->n; ++b) {
+        const y6_tensor& t = d->x[b];
+        Y6_REQUIRE(view_ok(t), "bnact: branch %d is not a valid fp16 NHWC view", b);
+        Y6_REQUIRE(same_shape(t, ref), "bnact: branch %d shape mismatch", b);
+        Y6_REQUIRE((((uintptr_t)d->scale[b] | (uintptr_t)d->shift[b]) & 15) == 0, "bnact: scale/shift must be 16-byte aligned");
+        a->x[b] = (const __half*)t.data;
+        a->cs[b] = t.cstride;
+        a->co[b] = t.coff;
+        a->scale[b] = d->scale[b];
+        a->shift[b] = d->shift[b];
+    }
+    if (d->res.data) {
+        Y6_REQUIRE(view_ok(d->res) && same_shape(d->res, ref), "bnact: bad shortcut view");
+        a->res = (const __half*)d->res.data;
+        a->rcs = d->res.cstride;
+        a->rco = d->res.coff;
+        a->alpha = d->res_alpha;
+    }
+    if (need_out) {
+        Y6_REQUIRE(view_ok(d->out) && same_shape(d->out, ref), "bnact: bad output view");
+        a->out = (__half*)d->out.data;
+        a->ocs = d->out.cstride;
+        a->oco = d->out.coff;
+    }
+    Y6_REQUIRE(d->act == Y6_ACT_NONE || d->act == Y6_ACT_RELU || d->act == Y6_ACT_SILU || d->act == Y6_ACT_HARDSWISH, "bnact: bad activation");
+    a->act = d->act;
+    a->C = ref.C;
+    a->npix = (long)ref.B * ref.H * ref.W;
+    return Y6_OK;
+}
+
+int bnact_forward_launch(const y6_bnact_desc* d, hipStream_t s) {
+    BnActArgs a;
+    int rc = fill_bnact_args(d, &a, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bnact_fwd_kernel, dim3(grid_for((size_t)a.npix * (a.C / 8), 256, 256 * 16)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ backward of the above
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case Y6_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case Y6_ACT_SILU: {
+            const float s = 1.f / (1.f + __expf(-z));
+            return s * (1.f + z * (1.f - s));
+        }
+        case Y6_ACT_HARDSWISH: return z < -3.f ? 0.f : (z > 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
+        default: return 1.f;
+    }
+}
+
+struct BnActBwdArgs {
+    BnActArgs f;
+    const float* mean[3];
+    const float* invstd[3];
+    const float* gamma[3];
+    const __half* dout;
+    int dcs, dco;
+    __half* dx[3];
+    int xcs[3], xco[3], xdil[3], xacc[3], xH[3], xW[3];
+    float* dgamma[3];
+    float* dbeta[3];
+    __half* dres;
+    int rcs, rco, racc;
+    float* dalpha;
+    double* ws;       // [ (1 + n) * C + 1 ] : sum dz | sum dz*xhat_b ... | sum dout*res
+    int H, W;
+};
+
+// pass 1: per-channel sums of dz and dz*xhat_b (double), optional sum dout*res
+__global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BnActBwdArgs a, long pix_per_block) {
+    extern __shared__ double s_acc[];   // [(1+n)*C]
+    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const int tid = threadIdx.x;
+    const int nacc = (1 + n) * C;
+    for (int i = tid; i < nacc; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+    const int R = 256 / G;
+    double s_alpha = 0.0;
+    if (tid < R * G) {
+        const int g = tid % G, prow = tid / G;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = p0 + pix_per_block < a.f.npix ? p0 + pix_per_block : a.f.npix;
+        double sdz[8], sxy[3][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sdz[j] = sxy[0][j] = sxy[1][j] = sxy[2][j] = 0.0;
+        float mu[3][8], is[3][8];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            loadf8(a.mean[b] ? a.mean[b] + g * 8 : nullptr, mu[b], 0.f);
+            loadf8(a.invstd[b] ? a.invstd[b] + g * 8 : nullptr, is[b], 0.f);
+        }
+        for (long p = p0 + prow; p < p1; p += R) {
+            float z[8], xb[3][8], go[8];
+            preact8(a.f, p, g, z, xb);
+            load8(a.dout + p * a.dcs + a.dco + g * 8, go);
+            if (a.dalpha) {
+                float r[8];
+                load8(a.f.res + p * a.f.rcs + a.f.rco + g * 8, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s_alpha += (double)(go[j] * r[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dz = go[j] * act_grad(z[j], a.f.act);
+                sdz[j] += (double)dz;
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    if (b < n) sxy[b][j] += (double)(dz * ((xb[b][j] - mu[b][j]) * is[b][j]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&s_acc[g * 8 + j], sdz[j]);
+            for (int b = 0; b < n; ++b)
+                if (a.mean[b]) atomicAdd(&s_acc[(1 + b) * C + g * 8 + j], sxy[b][j]);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nacc; i += 256) atomicAdd(&a.ws[i], s_acc[i]);
+    if (a.dalpha) {
+        // wave reduce then one atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s_alpha += __shfl_xor(s_alpha, o, 64);
+        if ((tid & 63) == 0) atomicAdd(&a.ws[nacc], s_alpha);
+    }
+}
+
+// pass 2: gradients wrt every branch input (and the shortcut)
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs a) {
+    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const long total = a.f.npix * G;
+    const double invN = 1.0 / (double)a.f.npix;
+    const float alpha = a.f.res ? (a.f.alpha ? *a.f.alpha : 1.f) : 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / G;
+        const int g = (int)(i - p * G);
+        float z[8], xb[3][8], go[8], dz[8];
+        preact8(a.f, p, g, z, xb);
+        load8(a.dout + p * a.dcs + a.dco + g * 8, go);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
+        if (a.dres) {
+            __half* q = a.dres + p * a.rcs + a.rco + g * 8;
+            float r[8];
+            if (a.racc) load8(q, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
+            store8(q, r);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            if (!a.dx[b]) continue;
+            float d[8];
+            if (a.mean[b]) {
+                float mu[8], is[8], ga[8];
+                loadf8(a.mean[b] + g * 8, mu, 0.f);
+                loadf8(a.invstd[b] + g * 8, is, 0.f);
+                loadf8(a.gamma[b] ? a.gamma[b] + g * 8 : nullptr, ga, 1.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float mdz = (float)(a.ws[g * 8 + j] * invN);
+                    const float mxy = (float)(a.ws[(1 + b) * C + g * 8 + j] * invN);
+                    const float xh = (xb[b][j] - mu[j]) * is[j];
+                    d[j] = ga[j] * is[j] * (dz[j] - mdz - xh * mxy);
+                }
+            } else {
+                float sc[8];
+                loadf8(a.f.scale[b] ? a.f.scale[b] + g * 8 : nullptr, sc, 1.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = dz[j] * sc[j];
+            }
+            long q = p;
+            if (a.xdil[b] == 2) {       // (b, y, x) of the logical grid -> (b, 2y, 2x) of the dilated buffer
+                const long hw = (long)a.H * a.W;
+                const long bi = p / hw, rem = p - bi * hw;
+                const long y = rem / a.W, x = rem - y * a.W;
+                q = (bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
+            }
+            __half* dst = a.dx[b] + q * a.xcs[b] + a.xco[b] + g * 8;
+            if (a.xacc[b]) {
+                float old[8];
+                load8(dst, old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] += old[j];
+            }
+            store8(dst, d);
+        }
+    }
+}
+
+__global__ void bnact_bwd_params_kernel(const BnActBwdArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = a.f.C;
+    if (c == 0 && a.dalpha) *a.dalpha += (float)a.ws[(1 + a.f.n) * C];
+    if (c >= C) return;
+    for (int b = 0; b < a.f.n; ++b) {
+        if (!a.mean[b]) continue;
+        if (a.dgamma[b]) a.dgamma[b][c] += (float)a.ws[(1 + b) * C + c];
+        if (a.dbeta[b]) a.dbeta[b][c] += (float)a.ws[c];
+    }
+}
+
+int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d && d->workspace, "bnact_backward: null argument");
+    BnActBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    int rc = fill_bnact_args(&d->fwd, &a.f, false);
+    if (rc) return rc;
+    const y6_tensor& ref = d->fwd.x[0];
+    const int C = ref.C, n = d->fwd.n;
+    Y6_REQUIRE(C <= 2048, "bnact_backward: at most 2048 channels");
+    Y6_REQUIRE(d->workspace_bytes >= y6_bnact_bwd_workspace_bytes(C), "bnact_backward: workspace too small");
+    Y6_REQUIRE(view_ok(d->dout) && same_shape(d->dout, ref), "bnact_backward: bad dout view");
+    a.dout = (const __half*)d->dout.data;
+    a.dcs = d->dout.cstride;
+    a.dco = d->dout.coff;
+    a.H = ref.H;
+    a.W = ref.W;
+    for (int b = 0; b < n; ++b) {
+        a.mean[b] = d->mean[b];
+        a.invstd[b] = d->invstd[b];
+        a.gamma[b] = d->gamma[b];
+        Y6_REQUIRE((d->mean[b] == nullptr) == (d->invstd[b] == nullptr), "bnact_backward: branch %d needs mean AND invstd", b);
+        Y6_REQUIRE((((uintptr_t)d->mean[b] | (uintptr_t)d->invstd[b] | (uintptr_t)d->gamma[b]) & 15) == 0,
+                   "bnact_backward: statistics must be 16-byte aligned");
+        a.dgamma[b] = d->dgamma[b];
+        a.dbeta[b] = d->dbeta[b];
+        const y6_tensor& t = d->dx[b];
+        if (!t.data) continue;
+        const int dil = d->dx_dil[b] == 2 ? 2 : 1;
+        Y6_REQUIRE(view_ok(t) && t.C == C && t.B == ref.B, "bnact_backward: bad dx view of branch %d", b);
+        if (dil == 1)
+            Y6_REQUIRE(t.H == ref.H && t.W == ref.W, "bnact_backward: dx shape mismatch of branch %d", b);
+        else
+            Y6_REQUIRE(t.H >= 2 * ref.H - 1 && t.W >= 2 * ref.W - 1, "bnact_backward: dilated dx of branch %d is too small", b);
+        a.dx[b] = (__half*)t.data;
+        a.xcs[b] = t.cstride;
+        a.xco[b] = t.coff;
+        a.xdil[b] = dil;
+        a.xacc[b] = d->dx_acc[b];
+        a.xH[b] = t.H;
+        a.xW[b] = t.W;
+    }
+    if (d->dres.data) {
+        Y6_REQUIRE(a.f.res && view_ok(d->dres) && same_shape(d->dres, ref), "bnact_backward: bad dres view");
+        a.dres = (__half*)d->dres.data;
+        a.rcs = d->dres.cstride;
+        a.rco = d->dres.coff;
+        a.racc = d->dres_acc;
+    }
+    a.dalpha = (a.f.res && d->dalpha) ? d->dalpha : nullptr;
+    a.ws = (double*)d->workspace;
+    const size_t nacc = (size_t)(1 + n) * C + 1;
+    Y6_HIP(hipMemsetAsync(a.ws, 0, nacc * sizeof(double), s));
+    const int G = C / 8, R = 256 / G;
+    long ppb = (long)R * 32;
+    long blocks = (a.f.npix + ppb - 1) / ppb;
+    if (blocks > 2048) {
+        blocks = 2048;
+        ppb = (a.f.npix + blocks - 1) / blocks;
+    }
+    hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double), s, a, ppb);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid_for((size_t)a.f.npix * G, 256, 256 * 16)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bnact_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ channel-major sampling for the weight gradient
+// block = (b, r, 64-column tile, 64-channel tile): NHWC rows -> LDS -> 16-byte runs along q per channel
+__global__ __launch_bounds__(256) void wt_nhwc_kernel(const __half* __restrict__ src, int cs, int co, int B, int H, int W, int C,
+                                                      int sy, int sx, int oy, int ox, int R, int Q, __half* __restrict__ dst,
+                                                      int qtiles, int ctiles) {
+    __shared__ __half tile[64][72];
+    int bid = blockIdx.x;
+    const int qt = bid % qtiles;
+    bid /= qtiles;
+    const int ct = bid % ctiles;
+    bid /= ctiles;
+    const int r = bid % R;
+    const int b = bid / R;
+    const int tid = threadIdx.x;
+    const int y = r * sy + oy;
+    const int q0 = qt * 64, c0 = ct * 64;
+    const bool row_ok = y >= 0 && y < H;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int ql = (tid >> 3) + it * 32, cg = tid & 7;
+        const int x = (q0 + ql) * sx + ox;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row_ok && x >= 0 && x < W && q0 + ql < Q && c0 + cg * 8 < C)
+            v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + y) * W + x) * cs + co + c0 + cg * 8);
+        *reinterpret_cast<uint4*>(&tile[ql][cg * 8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * 256;          // 64 channels x 8 runs
+        const int run = item & 7, cl = item >> 3;
+        if (c0 + cl >= C || q0 + run * 8 >= Q) continue;
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const _Float16*>(&tile[run * 8 + j][cl]);
+        *reinterpret_cast<h8_t*>(dst + (((size_t)(c0 + cl) * B + b) * R + r) * Q + q0 + run * 8) = o;
+    }
+}
+
+template <typename T>
+__global__ void wt_nchw_kernel(const T* __restrict__ src, int B, int H, int W, int C, int sy, int sx, int oy, int ox, int R, int Q,
+                               __half* __restrict__ dst) {
+    const size_t total = (size_t)C * B * R * (Q / 8);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int run = (int)(i % (Q / 8));
+        size_t t = i / (Q / 8);
+        const int r = (int)(t % R);
+        t /= R;
+        const int b = (int)(t % B);
+        const int c = (int)(t / B);
+        const int y = r * sy + oy;
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = (run * 8 + j) * sx + ox;
+            float v = 0.f;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = (float)src[(((size_t)b * C + c) * H + y) * W + x];
+            o[j] = (_Float16)v;
+        }
+        *reinterpret_cast<h8_t*>(dst + i * 8) = o;
+    }
+}
+
+int wgrad_transpose_launch(const y6_wgrad_t_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d && d->src.data && d->dst, "wgrad_transpose: null argument");
+    Y6_REQUIRE(d->R > 0 && d->Q > 0 && d->Q % 16 == 0 && d->sy >= 1 && d->sx >= 1, "wgrad_transpose: bad geometry");
+    Y6_REQUIRE(((uintptr_t)d->dst & 15) == 0, "wgrad_transpose: dst must be 16-byte aligned");
+    const y6_tensor& t = d->src;
+    if (d->nchw) {
+        const size_t total = (size_t)t.C * t.B * d->R * (d->Q / 8);
+        if (d->src_dtype == Y6_F16)
+            hipLaunchKernelGGL(wt_nchw_kernel<__half>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const __half*)t.data, t.B, t.H,
+                               t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst);
+        else if (d->src_dtype == Y6_F32)
+            hipLaunchKernelGGL(wt_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)t.data, t.B, t.H,
+                               t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst);
+        else
+            Y6_REQUIRE(false, "wgrad_transpose: bad dtype %d", d->src_dtype);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
+    Y6_REQUIRE(view_ok(t), "wgrad_transpose: the source must be an fp16 NHWC view with 8-channel alignment");
+    const int qtiles = (d->Q + 63) / 64, ctiles = (t.C + 63) / 64;
+    const size_t blocks = (size_t)t.B * d->R * qtiles * ctiles;
+    Y6_REQUIRE(blocks < (1ull << 31), "wgrad_transpose: grid too large");
+    hipLaunchKernelGGL(wt_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const __half*)t.data, t.cstride, t.coff, t.B, t.H,
+                       t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst, qtiles, ctiles);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ batched weight packing
+// packed layout as y6_pack_conv_weight: dst[cfr][chunk][tap][ks][lane][j] = W'[o = cfr*32 + (lane&31)][i = chunk*32 + ks*16 + (lane>>5)*8 + j][tap]
+__global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t total) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = njobs - 1;                 // last job with first <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first <= i) lo = mid; else hi = mid - 1;
+        }
+        const y6_pack_job jb = jobs[lo];
+        const uint64_t e = i - jb.first;
+        const int K = jb.K, NT = K * K;
+        // logical output-channel / input-channel counts of the packed matrix
+        int O = jb.Cout, I = jb.Cin;
+        if (jb.kind == 1) { O = jb.Cin; I = jb.Cout; }
+        if (jb.kind == 2) { O = 4 * jb.Cout; I = jb.Cin; }          // rows = sub*Cout + co
+        if (jb.kind == 3) { O = jb.Cin; I = 4 * jb.Cout; }          // cols = sub*Cout + co
+        const int nchunk = (I + 31) / 32;
+        const int nt = (jb.kind >= 2) ? 1 : NT;
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+        uint64_t r = e >> 10;
+        const int tap = (int)(r % nt);
+        r /= nt;
+        const int chunk = (int)(r % nchunk);
+        const int cfr = (int)(r / nchunk);
+        const int o = cfr * 32 + (lane & 31);
+        const int ic = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
+        float v = 0.f;
+        if (o < O && ic < I) {
+            if (jb.kind == 0) {
+                v = jb.src[((size_t)o * jb.Cin + ic) * NT + tap];
+            } else if (jb.kind == 1) {                 // W'[ci=o][co=ic][tap] = W[co][ci][NT-1-tap]
+                v = jb.src[((size_t)ic * jb.Cin + o) * NT + (NT - 1 - tap)];
+            } else if (jb.kind == 2) {                 // IOHW [Cin][Cout][2][2]: row = sub*Cout + co
+                const int sub = o / jb.Cout, co = o - sub * jb.Cout;
+                v = jb.src[((size_t)ic * jb.Cout + co) * 4 + sub];
+            } else {                                   // W'[ci=o][sub*Cout+co = ic]
+                const int sub = ic / jb.Cout, co = ic - sub * jb.Cout;
+                v = jb.src[((size_t)o * jb.Cout + co) * 4 + sub];
+            }
+        }
+        reinterpret_cast<__half*>(jb.dst)[e] = __float2half(v);
+    }
+}
+
+int pack_batch_launch(const y6_pack_batch_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d && d->jobs && d->njobs > 0 && d->total > 0, "pack_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(grid_for((size_t)d->total, 256, 256 * 64)), dim3(256), 0, s, d->jobs, d->njobs, d->total);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ SPPF pools backward
+// block = (image, 8-channel group); planes in LDS; three scatter passes with LDS float atomics.
+__device__ __forceinline__ void pool_scatter(const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gin,
+                                             int H, int W, int tid, int nthr) {
+    // in/gout/gin: [H*W][8] in LDS; gin += scatter(gout) to the first maximum of each 5x5 window of `in`
+    const int HW = H * W;
+    for (int i = tid; i < HW * 8; i += nthr) {
+        const int p = i >> 3, c = i & 7;
+        const int y = p / W, x = p - y * W;
+        float best = -INFINITY;
+        int arg = p;
+        bool found = false;
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= W) continue;
+                const float v = in[(yy * W + xx) * 8 + c];
+                if (!found || v > best) {
+                    best = v;
+                    arg = yy * W + xx;
+                    found = true;
+                }
+            }
+        }
+        const float g = gout[i];
+        if (g != 0.f) atomicAdd(&gin[arg * 8 + c], g);
+    }
+}
+
+struct SppfBwdArgs {
+    const __half *x, *y1, *y2, *dy1, *dy2, *dy3;
+    __half* dx;
+    int cs[7], co[7];    // x, y1, y2, dy1, dy2, dy3, dx
+    int H, W, C, acc;
+};
+
+__global__ __launch_bounds__(256) void sppf_bwd_kernel(const SppfBwdArgs a) {
+    extern __shared__ float sm[];
+    const int HW = a.H * a.W, G = a.C >> 3;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    float* vin = sm;               // [HW][8] forward plane of the current stage
+    float* gA = sm + HW * 8;       // gradient arriving at the stage's output
+    float* gB = sm + 2 * HW * 8;   // gradient wrt the stage's input (accumulated)
+    const int tid = threadIdx.x;
+    auto load_plane = [&](const __half* base, int cs, int co, float* dst, bool add) {
+        for (int p = tid; p < HW; p += 256) {
+            float v[8];
+            load8(base + ((size_t)b * HW + p) * cs + co + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[p * 8 + j] = add ? dst[p * 8 + j] + v[j] : v[j];
+        }
+    };
+    // stage 3: y2 -> y3
+    load_plane(a.y2, a.cs[2], a.co[2], vin, false);
+    load_plane(a.dy3, a.cs[5], a.co[5], gA, false);
+    load_plane(a.dy2, a.cs[4], a.co[4], gB, false);       // gradient that reached y2 directly
+    __syncthreads();
+    pool_scatter(vin, gA, gB, a.H, a.W, tid, 256);
+    __syncthreads();
+    // stage 2: y1 -> y2 ; gout = gB
+    load_plane(a.y1, a.cs[1], a.co[1], vin, false);
+    load_plane(a.dy1, a.cs[3], a.co[3], gA, false);
+    __syncthreads();
+    pool_scatter(vin, gB, gA, a.H, a.W, tid, 256);        // gA now holds d y1 total
+    __syncthreads();
+    // stage 1: x -> y1 ; gout = gA, result into gB
+    load_plane(a.x, a.cs[0], a.co[0], vin, false);
+    for (int i = tid; i < HW * 8; i += 256) gB[i] = 0.f;
+    __syncthreads();
+    if (a.acc) load_plane(a.dx, a.cs[6], a.co[6], gB, true);
+    __syncthreads();
+    pool_scatter(vin, gA, gB, a.H, a.W, tid, 256);
+    __syncthreads();
+    for (int p = tid; p < HW; p += 256) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gB[p * 8 + j];
+        store8(a.dx + ((size_t)b * HW + p) * a.cs[6] + a.co[6] + g * 8, v);
+    }
+}
+
+int sppf_backward_launch(const y6_sppf_bwd_desc* d, hipStream_t s) {
+    Y6_REQUIRE(d, "sppf_pool_backward: null argument");
+    const y6_tensor* t[7] = {&d->x, &d->y1, &d->y2, &d->dy1, &d->dy2, &d->dy3, &d->dx};
+    SppfBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 7; ++i) {
+        Y6_REQUIRE(view_ok(*t[i]) && same_shape(*t[i], d->x), "sppf_pool_backward: tensor %d is not a matching fp16 NHWC view", i);
+        a.cs[i] = t[i]->cstride;
+        a.co[i] = t[i]->coff;
+    }
+    a.x = (const __half*)d->x.data;
+    a.y1 = (const __half*)d->y1.data;
+    a.y2 = (const __half*)d->y2.data;
+    a.dy1 = (const __half*)d->dy1.data;
+    a.dy2 = (const __half*)d->dy2.data;
+    a.dy3 = (const __half*)d->dy3.data;
+    a.dx = (__half*)d->dx.data;
+    a.H = d->x.H;
+    a.W = d->x.W;
+    a.C = d->x.C;
+    a.acc = d->dx_acc;
+    const size_t lds = (size_t)3 * a.H * a.W * 8 * sizeof(float);
+    Y6_REQUIRE(lds <= 160 * 1024 - 1024, "sppf_pool_backward: %dx%d plane does not fit the LDS", a.H, a.W);
+    if (lds > 64 * 1024)
+        Y6_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(sppf_bwd_kernel, dim3((unsigned)(d->x.B * (a.C / 8))), dim3(256), lds, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ Detect training branch: pack / unpack
+struct HeadArgs {
+    int n_levels, nc, nreg, B, A;
+    const __half* cls[4];
+    const __half* reg[4];
+    __half* dcls[4];
+    __half* dreg[4];
+    int ccs[4], cco[4], rcs[4], rco[4], hw[4], a0[5];
+    float* scores;
+    float* distri;
+    const float* dscores;
+    const float* ddistri;
+};
+
+__global__ __launch_bounds__(256) void head_pack_kernel(const HeadArgs a) {
+    const int per = a.nc + a.nreg;
+    const size_t total = (size_t)a.B * a.A * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % per);
+        const size_t ba = i / per;
+        const int an = (int)(ba % a.A), b = (int)(ba / a.A);
+        int l = 0;
+        while (l + 1 < a.n_levels && an >= a.a0[l + 1]) ++l;
+        const size_t pix = (size_t)b * a.hw[l] + (an - a.a0[l]);
+        if (c < a.nc) {
+            const float z = __half2float(a.cls[l][pix * a.ccs[l] + a.cco[l] + c]);
+            a.scores[ba * a.nc + c] = 1.f / (1.f + expf(-z));
+        } else {
+            const int r = c - a.nc;
+            a.distri[ba * a.nreg + r] = __half2float(a.reg[l][pix * a.rcs[l] + a.rco[l] + r]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_unpack_kernel(const HeadArgs a) {
+    const int per = a.nc + a.nreg;
+    const size_t total = (size_t)a.B * a.A * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % per);
+        const size_t ba = i / per;
+        const int an = (int)(ba % a.A), b = (int)(ba / a.A);
+        int l = 0;
+        while (l + 1 < a.n_levels && an >= a.a0[l + 1]) ++l;
+        const size_t pix = (size_t)b * a.hw[l] + (an - a.a0[l]);
+        if (c < a.nc) {
+            const float p = a.scores[ba * a.nc + c];
+            a.dcls[l][pix * a.ccs[l] + a.cco[l] + c] = __float2half(a.dscores[ba * a.nc + c] * p * (1.f - p));
+        } else {
+            const int r = c - a.nc;
+            a.dreg[l][pix * a.rcs[l] + a.rco[l] + r] = __float2half(a.ddistri[ba * a.nreg + r]);
+        }
+    }
+}
+
+int fill_head_args(const y6_head_pack_desc* d, HeadArgs* a, bool backward) {
+    Y6_REQUIRE(d && d->n_levels >= 1 && d->n_levels <= 4 && d->scores, "head_pack: bad descriptor");
+    Y6_REQUIRE(backward ? (d->dscores && d->ddistri) : (d->distri != nullptr), "head_pack: null buffer");
+    memset(a, 0, sizeof(*a));
+    a->n_levels = d->n_levels;
+    a->nc = d->nc;
+    a->nreg = d->nreg;
+    int A = 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor &c = d->cls[l], &r = d->reg[l];
+        Y6_REQUIRE(c.data && r.data && c.C == d->nc && r.C == d->nreg, "head_pack: level %d channels", l);
+        Y6_REQUIRE(c.B == r.B && c.H == r.H && c.W == r.W && c.B == d->cls[0].B, "head_pack: level %d shape mismatch", l);
+        a->cls[l] = (const __half*)c.data;
+        a->reg[l] = (const __half*)r.data;
+        a->dcls[l] = (__half*)c.data;
+        a->dreg[l] = (__half*)r.data;
+        a->ccs[l] = c.cstride;
+        a->cco[l] = c.coff;
+        a->rcs[l] = r.cstride;
+        a->rco[l] = r.coff;
+        a->hw[l] = c.H * c.W;
+        a->a0[l] = A;
+        A += c.H * c.W;
+    }
+    a->a0[d->n_levels] = A;
+    a->B = d->cls[0].B;
+    a->A = A;
+    a->scores = d->scores;
+    a->distri = d->distri;
+    a->dscores = d->dscores;
+    a->ddistri = d->ddistri;
+    return Y6_OK;
+}
+
+int head_pack_launch(const y6_head_pack_desc* d, hipStream_t s) {
+    HeadArgs a;
+    int rc = fill_head_args(d, &a, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+int head_unpack_launch(const y6_head_pack_desc* d, hipStream_t s) {
+    HeadArgs a;
+    int rc = fill_head_args(d, &a, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_unpack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ small data movers
+struct TwoT {
+    y6_tensor a, b;
+    int flag;
+};
+
+__global__ __launch_bounds__(256) void s2d_kernel(const __half* __restrict__ src, int scs, int sco, int H, int W, int C,
+                                                  __half* __restrict__ dst, int dcs, int dco, int B) {
+    const int G = C >> 3, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * 4 * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int sub = (int)(t & 3);
+        t >>= 2;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        const uint4 v = *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + 2 * y + (sub >> 1)) * W + 2 * x + (sub & 1)) * scs + sco + g * 8);
+        *reinterpret_cast<uint4*>(dst + ((size_t)(b * Ho + y) * Wo + x) * dcs + dco + sub * C + g * 8) = v;
+    }
+}
+int s2d_launch(const TwoT* d, hipStream_t s) {
+    const y6_tensor &a = d->a, &o = d->b;
+    Y6_REQUIRE(view_ok(a) && view_ok(o), "space_to_depth2: bad views");
+    Y6_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0 && o.H == a.H / 2 && o.W == a.W / 2 && o.C == 4 * a.C && o.B == a.B, "space_to_depth2: shape mismatch");
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * (a.C / 8), 256)), dim3(256), 0, s, (const __half*)a.data,
+                       a.cstride, a.coff, a.H, a.W, a.C, (__half*)o.data, o.cstride, o.coff, a.B);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+__global__ __launch_bounds__(256) void tensor_add_kernel(const __half* __restrict__ a, int acs, int aco, __half* __restrict__ dst, int dcs,
+                                                         int dco, long npix, int C, int acc) {
+    const int G = C >> 3;
+    const long total = npix * G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i / G;
+        const int g = (int)(i - p * G);
+        float v[8];
+        load8(a + p * acs + aco + g * 8, v);
+        __half* q = dst + p * dcs + dco + g * 8;
+        if (acc) {
+            float o[8];
+            load8(q, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        store8(q, v);
+    }
+}
+int tensor_add_launch(const TwoT* d, hipStream_t s) {
+    Y6_REQUIRE(view_ok(d->a) && view_ok(d->b) && same_shape(d->a, d->b), "tensor_add: bad views");
+    const long npix = (long)d->a.B * d->a.H * d->a.W;
+    hipLaunchKernelGGL(tensor_add_kernel, dim3(grid_for((size_t)npix * (d->a.C / 8), 256)), dim3(256), 0, s, (const __half*)d->a.data,
+                       d->a.cstride, d->a.coff, (__half*)d->b.data, d->b.cstride, d->b.coff, npix, d->a.C, d->flag);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+struct ChanSum {
+    y6_tensor x;
+    float* out;
+    void* ws;
+    size_t ws_bytes;
+};
+__global__ void chan_sum_finalize_kernel(const double* __restrict__ ws, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] += (float)ws[c];
+}
+// generic (any C): one thread per (pixel-row-slice, channel); used for the prediction convs (C = 80, 68, 4)
+__global__ __launch_bounds__(256) void chan_sum_kernel(const __half* __restrict__ x, int cs, int co, long npix, int C, double* __restrict__ ws) {
+    const int c = threadIdx.x % C;                    // C <= 256 handled by rows of C threads
+    const int rows = 256 / C;
+    const int row = threadIdx.x / C;
+    if (row >= rows) return;
+    double s = 0.0;
+    for (long p = (long)blockIdx.x * rows + row; p < npix; p += (long)gridDim.x * rows) s += (double)__half2float(x[p * cs + co + c]);
+    atomicAdd(&ws[c], s);
+}
+int chan_sum_launch(const ChanSum* d, hipStream_t s) {
+    const y6_tensor& t = d->x;
+    Y6_REQUIRE(t.data && d->out && d->ws && t.C >= 1 && t.C <= 256, "channel_sum: bad arguments (1..256 channels)");
+    Y6_REQUIRE(d->ws_bytes >= (size_t)t.C * sizeof(double), "channel_sum: workspace too small");
+    const long npix = (long)t.B * t.H * t.W;
+    Y6_HIP(hipMemsetAsync(d->ws, 0, (size_t)t.C * sizeof(double), s));
+    long g = (npix + 63) / 64;
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(chan_sum_kernel, dim3((unsigned)g), dim3(256), 0, s, (const __half*)t.data, t.cstride, t.coff, npix, t.C, (double*)d->ws);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)d->ws, t.C, d->out);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+struct FillZero {
+    void* p;
+    size_t n;
+};
+int fill_zero_launch(const FillZero* d, hipStream_t s) {
+    Y6_HIP(hipMemsetAsync(d->p, 0, d->n, s));
+    return Y6_OK;
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ __launch_bounds__(256) void finite_check_kernel(const float* __restrict__ g, size_t n, int32_t* __restrict__ flag) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = g[i];
+        bad = bad || !(fabsf(v) <= 3.402823466e38f);    // inf or nan
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, size_t n, float lr,
+                                                  float mom, float wd, int nesterov, int first, const float* __restrict__ scale,
+                                                  const int32_t* __restrict__ found_inf) {
+    if (found_inf && *found_inf) return;
+    const float inv = scale ? 1.f / *scale : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float w = p[i];
+        float d = g[i] * inv;
+        if (wd != 0.f) d += wd * w;
+        float b = d;
+        if (mom != 0.f) {
+            b = first ? d : mom * m[i] + d;
+            m[i] = b;
+            if (nesterov) b = d + mom * b;
+        }
+        p[i] = w - lr * b;
+    }
+}
+
+__global__ void scaler_update_kernel(float* scale, int32_t* found_inf, int32_t* tracker, float growth, float backoff, int interval) {
+    if (*found_inf) {
+        *scale *= backoff;
+        *tracker = 0;
+    } else if (++(*tracker) >= interval) {
+        *scale *= growth;
+        *tracker = 0;
+    }
+    *found_inf = 0;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" size_t y6_bnact_bwd_workspace_bytes(int C) { return ((size_t)4 * C + 1) * sizeof(double); }
+
+extern "C" int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return bn_train_stats_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_bnact_forward(const y6_bnact_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return bnact_forward_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_bnact_backward(const y6_bnact_bwd_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return bnact_backward_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_wgrad_transpose(const y6_wgrad_t_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return wgrad_transpose_launch(d, (hipStream_t)stream);
+}
+extern "C" size_t y6_pack_job_elems(int kind, int Cout, int Cin, int K) {
+    int O = Cout, I = Cin, nt = K * K;
+    if (kind == 1) { O = Cin; I = Cout; }
+    if (kind == 2) { O = 4 * Cout; I = Cin; nt = 1; }
+    if (kind == 3) { O = Cin; I = 4 * Cout; nt = 1; }
+    const size_t cfr_pad = (size_t)y6_cdiv(y6_cdiv(O, 32), 4) * 4;
+    return cfr_pad * y6_cdiv(I, 32) * nt * 1024;
+}
+extern "C" int y6_pack_weights_batched(const y6_pack_batch_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return pack_batch_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_sppf_pool_backward(const y6_sppf_bwd_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return sppf_backward_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_head_pack(const y6_head_pack_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return head_pack_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_head_unpack_backward(const y6_head_pack_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return head_unpack_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(src && dst, "space_to_depth2: null argument");
+    TwoT t{*src, *dst, 0};
+    return s2d_launch(&t, (hipStream_t)stream);
+}
+extern "C" int y6_channel_sum(const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(x, "channel_sum: null argument");
+    ChanSum c{*x, out_accum, workspace, workspace_bytes};
+    return chan_sum_launch(&c, (hipStream_t)stream);
+}
+extern "C" int y6_tensor_add(const y6_tensor* a, const y6_tensor* dst, int accumulate, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(a && dst, "tensor_add: null argument");
+    TwoT t{*a, *dst, accumulate};
+    return tensor_add_launch(&t, (hipStream_t)stream);
+}
+extern "C" int y6_grad_finite_check(const float* grad, size_t n, int32_t* found_inf, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(grad && found_inf, "grad_finite_check: null argument");
+    if (n == 0) return Y6_OK;
+    hipLaunchKernelGGL(finite_check_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, grad, n, found_inf);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+extern "C" int y6_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, float weight_decay,
+                           int nesterov, int first_step, const float* scale, const int32_t* found_inf, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(param && grad && (momentum == 0.f || momentum_buf), "sgd_step: null argument");
+    if (n == 0) return Y6_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
+                       weight_decay, nesterov, first_step, scale, found_inf);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+extern "C" int y6_scaler_update(float* scale, int32_t* found_inf, int32_t* growth_tracker, float growth, float backoff, int interval, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(scale && found_inf && growth_tracker, "scaler_update: null argument");
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scale, found_inf, growth_tracker, growth, backoff, interval);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// ---------------------------------------------------------------------- plan builders
+static double nhwc_bytes(const y6_tensor& t) { return 2.0 * t.B * t.H * t.W * t.C; }
+
+extern "C" int y6_plan_add_bn_train_stats(y6_plan* p, const y6_bn_train_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, bn_train_stats_launch, d, Y6_TOP_BN_STATS, 0.0, nhwc_bytes(d->x));
+}
+extern "C" int y6_plan_add_bnact_forward(y6_plan* p, const y6_bnact_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, bnact_forward_launch, d, Y6_TOP_BNACT_FWD, 0.0, nhwc_bytes(d->x[0]) * (d->n + 1 + (d->res.data ? 1 : 0)));
+}
+extern "C" int y6_plan_add_bnact_backward(y6_plan* p, const y6_bnact_bwd_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    int nout = 0;
+    for (int b = 0; b < d->fwd.n; ++b) nout += d->dx[b].data ? 1 : 0;
+    return y6_plan_push(p, bnact_backward_launch, d, Y6_TOP_BNACT_BWD, 0.0, nhwc_bytes(d->dout) * (2.0 * (d->fwd.n + 1) + nout));
+}
+extern "C" int y6_plan_add_wgrad_transpose(y6_plan* p, const y6_wgrad_t_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, wgrad_transpose_launch, d, Y6_TOP_WGRAD_T, 0.0, 2.0 * 2.0 * d->src.C * d->src.B * d->R * d->Q);
+}
+extern "C" int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, pack_batch_launch, d, Y6_TOP_PACK, 0.0, 6.0 * (double)d->total);
+}
+extern "C" int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, sppf_backward_launch, d, Y6_TOP_POOL_BWD, 0.0, nhwc_bytes(d->x) * 7);
+}
+extern "C" int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    double n = 0;
+    for (int l = 0; l < d->n_levels; ++l) n += (double)d->cls[l].B * d->cls[l].H * d->cls[l].W;
+    return y6_plan_push(p, head_pack_launch, d, Y6_TOP_HEAD_PACK, 0.0, n * (d->nc + d->nreg) * 6.0);
+}
+extern "C" int y6_plan_add_head_unpack_backward(y6_plan* p, const y6_head_pack_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    double n = 0;
+    for (int l = 0; l < d->n_levels; ++l) n += (double)d->cls[l].B * d->cls[l].H * d->cls[l].W;
+    return y6_plan_push(p, head_unpack_launch, d, Y6_TOP_HEAD_UNPACK, 0.0, n * (d->nc + d->nreg) * 10.0);
+}
+extern "C" int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst) {
+    Y6_REQUIRE(p && src && dst, "plan_add: null argument");
+    TwoT t{*src, *dst, 0};
+    return y6_plan_push(p, s2d_launch, &t, Y6_TOP_S2D, 0.0, 2.0 * nhwc_bytes(*src));
+}
+extern "C" int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes) {
+    Y6_REQUIRE(p && x, "plan_add: null argument");
+    ChanSum c{*x, out_accum, workspace, workspace_bytes};
+    return y6_plan_push(p, chan_sum_launch, &c, Y6_TOP_BIAS_GRAD, 0.0, nhwc_bytes(*x));
+}
+extern "C" int y6_plan_add_tensor_add(y6_plan* p, const y6_tensor* a, const y6_tensor* dst, int accumulate) {
+    Y6_REQUIRE(p && a && dst, "plan_add: null argument");
+    TwoT t{*a, *dst, accumulate};
+    return y6_plan_push(p, tensor_add_launch, &t, Y6_TOP_ADD, 0.0, nhwc_bytes(*a) * (accumulate ? 3 : 2));
+}
+extern "C" int y6_plan_add_fill_zero(y6_plan* p, void* ptr, size_t bytes) {
+    Y6_REQUIRE(p && ptr, "plan_add: null argument");
+    FillZero f{ptr, bytes};
+    return y6_plan_push(p, fill_zero_launch, &f, Y6_TOP_FILL, 0.0, (double)bytes);
+}
