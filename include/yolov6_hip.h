@@ -462,6 +462,9 @@ int y6_head_unpack_backward(const y6_head_pack_desc* d, void* stream);
 
 /* space-to-depth for ConvTranspose2d's data gradient: dst[b,y,x,sub*C + c] = src[b,2y+dy,2x+dx,c], sub = dy*2+dx */
 int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, void* stream);
+/* dst[b,y,x,:] = src[b,2y,2x,:] - the input sampling of a 1x1 stride-2 conv (RepVGG's rbr_1x1 in the stride-2 blocks,
+ * common.py:243), which then runs as a stride-1 GEMM */
+int y6_subsample2(const y6_tensor* src, const y6_tensor* dst, void* stream);
 /* per-channel sum of an NHWC fp16 view, accumulated into fp32: bias gradients of ConvTranspose2d / prediction convs */
 int y6_channel_sum(const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes, void* stream);
 /* dst (=|+=) a  for NHWC fp16 views of one shape (gradient fan-in of tensors with several consumers) */
@@ -503,6 +506,7 @@ int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
 int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);
 int y6_plan_add_head_unpack_backward(y6_plan* p, const y6_head_pack_desc* d);
 int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
+int y6_plan_add_subsample2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
 int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes);
 int y6_plan_add_tensor_add(y6_plan* p, const y6_tensor* a, const y6_tensor* dst, int accumulate);
 int y6_plan_add_fill_zero(y6_plan* p, void* ptr, size_t bytes);

@@ -272,6 +272,13 @@ def gen_loss():
                             meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, reg_max=reg_max, use_dfl=use_dfl,
                                                  iou_type=iou_type, epoch=epoch, seed=seed)))
         print(f"loss_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
+        # the same call with autograd: d loss / d pred_scores, d loss / d pred_distri as the reference back-propagates them
+        ps = inp["pred_scores"].clone().requires_grad_(True)
+        pd = inp["pred_distri"].clone().requires_grad_(True)
+        loss2, _ = crit((feats, ps, pd), inp["targets"].clone(), epoch, 1, inp["img"], inp["img"])
+        loss2.backward()
+        np.savez_compressed(os.path.join(HERE, f"lossgrad_{name}.npz"), loss=np.float64(float(loss2)),
+                            dscores=ps.grad.numpy(), ddistri=pd.grad.numpy())
 
 
 if __name__ == "__main__":

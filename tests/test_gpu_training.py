@@ -1,0 +1,476 @@
+"""GPU: the training step (BASELINE configs[2]) - kernels one by one against torch-CPU fp32 autograd of the same op, then the
+whole training graph (train-form forward with batch statistics, backward, parameter gradients, running statistics) against
+oracle/model_oracle.py::TrainOracle, which is pinned to the unmodified reference's train-mode goldens
+(tests/golden/train_*.npz, incl. reference parameter gradients), and the loss gradient against
+oracle/loss_grad_oracle.py, pinned to the reference's autograd (tests/golden/lossgrad_*.npz).
+
+Tolerances: weight-gradient / BatchNorm / pooling kernels see exact fp16 inputs and accumulate in fp32 / double ->
+1e-3 of the tensor's max.  Whole-model gradients pass ~40 fp16-stored layers forward and backward: stated per tensor as
+max|g - g_ref| / max|g_ref| against the fp32 oracle, bound measured on MI355X + 20 % (see the test)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from yolov6_amd import _lib
+from yolov6_amd.engine import TRef
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _stream():
+    return _lib.current_stream_ptr()
+
+
+def _nhwc(t_nchw):
+    """CPU NCHW fp32 -> GPU NHWC fp16 buffer + TRef."""
+    B, Cn, H, W = t_nchw.shape
+    buf = t_nchw.permute(0, 2, 3, 1).contiguous().half().to(DEV)
+    return TRef(buf, B, H, W, Cn, Cn, 0)
+
+
+def _back(ref):
+    return ref.to_nhwc_tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+def _transpose(src: TRef, sy, sx, oy, ox, R, Q, nchw=None):
+    lib = _lib.load()
+    Cn, B = (nchw.shape[1], nchw.shape[0]) if nchw is not None else (src.C, src.B)
+    dst = torch.empty(Cn * B * R * Q, dtype=torch.float16, device=DEV)
+    d = _lib.WgradTDesc()
+    if nchw is not None:
+        Bn, Cc, Hn, Wn = nchw.shape
+        d.src = _lib.Tensor(C.c_void_p(nchw.data_ptr()), Bn, Hn, Wn, Cc, Cc, 0)
+        d.nchw, d.src_dtype = 1, (_lib.Y6_F16 if nchw.dtype == torch.float16 else _lib.Y6_F32)
+    else:
+        d.src = src.ct()
+    d.sy, d.sx, d.oy, d.ox, d.R, d.Q = sy, sx, oy, ox, R, Q
+    d.dst = dst.data_ptr()
+    _lib.check(lib.y6_wgrad_transpose(C.byref(d), _stream()), "wgrad_transpose")
+    return dst
+
+
+def _wgrad(mode, a, planes, M, N, B, Q, rows, T):
+    lib = _lib.load()
+    out = torch.zeros(M * N * T, dtype=torch.float32, device=DEV)
+    w = _lib.WgradDesc()
+    w.mode = mode
+    w.a = a.data_ptr()
+    w.M, w.N, w.B, w.Q, w.rows, w.a_rows = M, N, B, Q, rows, rows
+    for i, (t, prow, drow) in enumerate(planes):
+        w.plane[i], w.plane_rows[i], w.drow[i] = t.data_ptr(), prow, drow
+    w.out = out.data_ptr()
+    w.sm, w.sn, w.st = N * T, T, 1
+    _lib.check(lib.y6_wgrad(C.byref(w), _stream()), "wgrad")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def test_transpose_sampling_exact():
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand((2, 24, 7, 11), generator=g).half().float()
+    xr = _nhwc(x)
+    for (sy, sx, oy, ox, R, Q) in [(1, 1, -1, 0, 9, 16), (1, 1, 0, 0, 7, 16), (2, 2, 0, 1, 4, 16), (2, 2, -1, 0, 5, 16)]:
+        t = _transpose(xr, sy, sx, oy, ox, R, Q).float().cpu().view(24, 2, R, Q)
+        ref = torch.zeros(24, 2, R, Q)
+        for r in range(R):
+            for q in range(Q):
+                y, xx = r * sy + oy, q * sx + ox
+                if 0 <= y < 7 and 0 <= xx < 11:
+                    ref[:, :, r, q] = x[:, :, y, xx].t()
+        assert torch.equal(t, ref), (sy, sx, oy, ox)
+    img = torch.rand((2, 3, 8, 12), generator=g)
+    t = _transpose(None, 2, 2, -1, 1, 5, 16, nchw=img.to(DEV)).float().cpu().view(3, 2, 5, 16)
+    ref = torch.zeros(3, 2, 5, 16)
+    for r in range(5):
+        for q in range(16):
+            y, xx = 2 * r - 1, 2 * q + 1
+            if 0 <= y < 8 and 0 <= xx < 12:
+                ref[:, :, r, q] = img[:, :, y, xx].half().float().t()
+    assert torch.equal(t, ref)
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(16, 24, 3, 13, 17), (64, 64, 2, 20, 20), (40, 80, 2, 9, 33), (128, 32, 1, 40, 40)])
+def test_wgrad_3x3_s1_and_1x1(cin, cout, B, H, W):
+    g = torch.Generator().manual_seed(cin + cout)
+    x = (torch.rand((B, cin, H, W), generator=g) - 0.5).half().float()
+    dy = (torch.rand((B, cout, H, W), generator=g) - 0.5).half().float()
+    Q = _rup(W, 16)
+    a = _transpose(_nhwc(dy), 1, 1, 0, 0, H, Q)
+    xr = _nhwc(x)
+    p = _transpose(xr, 1, 1, -1, 0, H + 2, Q)
+    got3 = _wgrad(_lib.WG_3X3S1, a, [(p, H + 2, 0), (p, H + 2, 1), (p, H + 2, 2)], cout, cin, B, Q, H, 9).view(cout, cin, 3, 3)
+    ref3 = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=1, padding=1)
+    assert float((got3 - ref3).abs().max()) <= 1e-3 * float(ref3.abs().max())
+    # transpose-detecting: the centre tap differs from every other tap
+    got1 = _wgrad(_lib.WG_1X1, a, [(p, H + 2, 1)], cout, cin, B, Q, H, 1).view(cout, cin, 1, 1)
+    ref1 = torch.nn.grad.conv2d_weight(x, (cout, cin, 1, 1), dy, stride=1, padding=0)
+    assert float((got1 - ref1).abs().max()) <= 1e-3 * float(ref1.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(16, 32, 2, 12, 20), (32, 64, 3, 16, 16), (3, 16, 2, 24, 40)])
+def test_wgrad_stride2(cin, cout, B, H, W):
+    g = torch.Generator().manual_seed(7 + cin)
+    x = (torch.rand((B, cin, H, W), generator=g) - 0.5).half().float()
+    Ho, Wo = H // 2, W // 2
+    dy = (torch.rand((B, cout, Ho, Wo), generator=g) - 0.5).half().float()
+    Q = _rup(Wo, 16)
+    # the backward sees dy zero-inserted at (2y, 2x): sample it back with stride 2
+    dil = torch.zeros((B, cout, H, W))
+    dil[:, :, ::2, ::2] = dy
+    a = _transpose(_nhwc(dil), 2, 2, 0, 0, Ho, Q)
+    nchw = x.to(DEV) if cin == 3 else None            # the stem reads the caller's NCHW image
+    xr = None if cin == 3 else _nhwc(x)
+    pe = [_transpose(xr, 2, 2, 0, cp, Ho, Q, nchw) for cp in (0, 1)]
+    po = [_transpose(xr, 2, 2, -1, cp, Ho + 1, Q, nchw) for cp in (0, 1)]
+    planes = []
+    for ky in range(3):
+        for cp in range(2):
+            planes.append((pe[cp], Ho, 0) if ky == 1 else (po[cp], Ho + 1, 0 if ky == 0 else 1))
+    got = _wgrad(_lib.WG_3X3S2, a, planes, cout, cin, B, Q, Ho, 9).view(cout, cin, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=2, padding=1)
+    assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max())
+    got1 = _wgrad(_lib.WG_1X1, a, [(pe[0], Ho, 0)], cout, cin, B, Q, Ho, 1).view(cout, cin, 1, 1)
+    ref1 = torch.nn.grad.conv2d_weight(x, (cout, cin, 1, 1), dy, stride=2, padding=0)
+    assert float((got1 - ref1).abs().max()) <= 1e-3 * float(ref1.abs().max())
+
+
+def test_wgrad_convt():
+    g = torch.Generator().manual_seed(3)
+    B, cin, cout, H, W = 2, 32, 64, 10, 14
+    x = (torch.rand((B, cin, H, W), generator=g) - 0.5).half().float()
+    dout = (torch.rand((B, cout, 2 * H, 2 * W), generator=g) - 0.5).half().float()
+    Q = _rup(W, 16)
+    a = _transpose(_nhwc(x), 1, 1, 0, 0, H, Q)
+    dr = _nhwc(dout)
+    planes = [(_transpose(dr, 2, 2, sub >> 1, sub & 1, H, Q), H, 0) for sub in range(4)]
+    got = _wgrad(_lib.WG_CONVT, a, planes, cin, cout, B, Q, H, 4).view(cin, cout, 2, 2)
+    w = torch.zeros((cin, cout, 2, 2), requires_grad=True)
+    F.conv_transpose2d(x, w, stride=2).backward(dout)
+    assert float((got - w.grad).abs().max()) <= 1e-3 * float(w.grad.abs().max())
+
+
+def _bn_stats(ref: TRef, gamma, beta, rm, rv, eps=1e-3, mom=0.03):
+    lib = _lib.load()
+    Cn = ref.C
+    outs = [torch.empty(Cn, dtype=torch.float32, device=DEV) for _ in range(4)]
+    ws = torch.zeros(int(lib.y6_bn_stats_workspace_bytes(Cn)), dtype=torch.uint8, device=DEV)
+    nb = torch.zeros((), dtype=torch.int64, device=DEV)
+    d = _lib.BnTrainDesc()
+    d.x = ref.ct()
+    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+    d.running_mean, d.running_var, d.num_batches_tracked = rm.data_ptr(), rv.data_ptr(), nb.data_ptr()
+    d.momentum, d.eps = mom, eps
+    d.scale, d.shift, d.mean, d.invstd = (t.data_ptr() for t in outs)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.y6_bn_train_stats(C.byref(d), _stream()), "bn_train_stats")
+    return outs, nb
+
+
+@pytest.mark.parametrize("act,with_res,dil", [("relu", False, 1), ("silu", False, 1), ("relu", True, 1), ("relu", False, 2), (None, False, 1)])
+def test_bnact_forward_backward_vs_autograd(act, with_res, dil):
+    """ReLU(bn(y3) + bn(y1) + bn_id(x)) [+ alpha*res] with batch statistics, and every gradient of it."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    B, Cn, H, W = 3, 24, 6, 10
+    ys = [(torch.randn((B, Cn, H, W), generator=g) * s).half().float() for s in (1.0, 0.5, 2.0)]
+    res = torch.randn((B, Cn, H, W), generator=g).half().float()
+    gam = [torch.rand(Cn, generator=g) + 0.5 for _ in range(3)]
+    bet = [torch.randn(Cn, generator=g) * 0.1 for _ in range(3)]
+    alpha = torch.tensor([0.7])
+    dout = torch.randn((B, Cn, H, W), generator=g).half().float()
+    # ---- torch reference (fp32 autograd)
+    yv = [y.clone().requires_grad_(True) for y in ys]
+    gv = [t.clone().requires_grad_(True) for t in gam]
+    bv = [t.clone().requires_grad_(True) for t in bet]
+    rv_ = res.clone().requires_grad_(True)
+    av = alpha.clone().requires_grad_(True)
+    rms = [torch.zeros(Cn) for _ in range(3)]
+    rvs = [torch.ones(Cn) for _ in range(3)]
+    z = sum(F.batch_norm(y, rm, rvv, w, b, True, 0.03, 1e-3) for y, rm, rvv, w, b in zip(yv, rms, rvs, gv, bv))
+    o = {"relu": F.relu, "silu": F.silu, None: lambda t: t}[act](z)
+    if with_res:
+        o = o + av * rv_
+    o.backward(dout)
+    # ---- HIP
+    refs = [_nhwc(y) for y in ys]
+    dgam = [t.to(DEV) for t in gam]
+    dbet = [t.to(DEV) for t in bet]
+    stats, rmd, rvd = [], [], []
+    for i in range(3):
+        rm, rvv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+        st, nb = _bn_stats(refs[i], dgam[i], dbet[i], rm, rvv)
+        stats.append(st)
+        rmd.append(rm)
+        rvd.append(rvv)
+    out = TRef(torch.empty((B, H, W, Cn), dtype=torch.float16, device=DEV), B, H, W, Cn, Cn, 0)
+    rref = _nhwc(res)
+    adev = alpha.to(DEV)
+    d = _lib.BnActDesc()
+    d.n = 3
+    for i in range(3):
+        d.x[i] = refs[i].ct()
+        d.scale[i], d.shift[i] = stats[i][0].data_ptr(), stats[i][1].data_ptr()
+    if with_res:
+        d.res = rref.ct()
+        d.res_alpha = adev.data_ptr()
+    d.out = out.ct()
+    d.act = _lib.ACT_BY_NAME[act]
+    _lib.check(lib.y6_bnact_forward(C.byref(d), _stream()), "bnact_forward")
+    torch.cuda.synchronize()
+    assert float((_back(out) - o.detach()).abs().max()) < 4e-3 * max(1.0, float(o.abs().max()))     # fp16 output
+    for i in range(3):
+        assert torch.allclose(rmd[i].cpu(), rms[i], atol=1e-5) and torch.allclose(rvd[i].cpu(), rvs[i], atol=1e-5, rtol=1e-4)
+    assert int(nb) == 1
+    b = _lib.BnActBwdDesc()
+    b.fwd = d
+    dref = _nhwc(dout)
+    b.dout = dref.ct()
+    dxs = []
+    dgd = [torch.zeros(Cn, device=DEV) for _ in range(3)]
+    dbd = [torch.zeros(Cn, device=DEV) for _ in range(3)]
+    for i in range(3):
+        b.mean[i], b.invstd[i] = stats[i][2].data_ptr(), stats[i][3].data_ptr()
+        b.gamma[i] = dgam[i].data_ptr()
+        dil_i = dil if i == 0 else 1
+        t = torch.zeros((B, H * dil_i, W * dil_i, Cn), dtype=torch.float16, device=DEV)
+        if i == 2:
+            t += 1.0                          # accumulate mode: the buffer already holds a gradient of ones
+        dxs.append(TRef(t, B, H * dil_i, W * dil_i, Cn, Cn, 0))
+        b.dx[i] = dxs[i].ct()
+        b.dx_dil[i] = dil_i
+        b.dx_acc[i] = 1 if i == 2 else 0
+        b.dgamma[i], b.dbeta[i] = dgd[i].data_ptr(), dbd[i].data_ptr()
+    dres = TRef(torch.zeros((B, H, W, Cn), dtype=torch.float16, device=DEV), B, H, W, Cn, Cn, 0)
+    dal = torch.zeros(1, device=DEV)
+    if with_res:
+        b.dres = dres.ct()
+        b.dalpha = dal.data_ptr()
+    ws = torch.zeros(int(lib.y6_bnact_bwd_workspace_bytes(Cn)), dtype=torch.uint8, device=DEV)
+    b.workspace, b.workspace_bytes = ws.data_ptr(), ws.numel()
+    _lib.check(lib.y6_bnact_backward(C.byref(b), _stream()), "bnact_backward")
+    torch.cuda.synchronize()
+    for i in range(3):
+        got = _back(dxs[i])
+        if i == 0 and dil == 2:
+            full = got
+            got = full[:, :, ::2, ::2]
+            full[:, :, ::2, ::2] = 0
+            assert float(full.abs().max()) == 0.0           # nothing but the (2y, 2x) positions is written
+        if i == 2:
+            got = got - 1.0
+        ref = yv[i].grad
+        assert float((got - ref).abs().max()) < 3e-3 * max(1.0, float(ref.abs().max())), f"dx[{i}]"
+        assert float((dgd[i].cpu() - gv[i].grad).abs().max()) < 2e-3 * float(gv[i].grad.abs().max()), f"dgamma[{i}]"
+        assert float((dbd[i].cpu() - bv[i].grad).abs().max()) < 2e-3 * float(bv[i].grad.abs().max()), f"dbeta[{i}]"
+    if with_res:
+        assert float((_back(dres) - rv_.grad).abs().max()) < 3e-3 * float(rv_.grad.abs().max())
+        assert abs(float(dal) - float(av.grad)) < 2e-3 * abs(float(av.grad))
+
+
+def test_sppf_pool_backward_first_max_semantics():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    B, Cn, H, W = 2, 16, 20, 20
+    # ReLU-like input: many exact ties (zeros) - the gradient must go to the FIRST maximum in window order
+    x = F.relu(torch.randn((B, Cn, H, W), generator=g)).half().float().requires_grad_(True)
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    d0, d1, d2, d3 = [torch.randn((B, Cn, H, W), generator=g).half().float() for _ in range(4)]
+    ((x * d0).sum() + (y1 * d1).sum() + (y2 * d2).sum() + (y3 * d3).sum()).backward()
+    ref = x.grad
+    xr, y1r, y2r = _nhwc(x.detach()), _nhwc(y1.detach()), _nhwc(y2.detach())
+    dx, g1, g2, g3 = _nhwc(d0), _nhwc(d1), _nhwc(d2), _nhwc(d3)
+    d = _lib.SppfBwdDesc()
+    d.x, d.y1, d.y2 = xr.ct(), y1r.ct(), y2r.ct()
+    d.dy1, d.dy2, d.dy3, d.dx = g1.ct(), g2.ct(), g3.ct(), dx.ct()
+    d.dx_acc = 1
+    _lib.check(lib.y6_sppf_pool_backward(C.byref(d), _stream()), "sppf_pool_backward")
+    torch.cuda.synchronize()
+    assert float((_back(dx) - ref).abs().max()) < 2e-2      # sums of up to ~75 fp16 values, stored in fp16
+
+
+def test_head_pack_and_unpack():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(2)
+    B, nc, nreg = 2, 80, 68
+    sizes = [(8, 8), (4, 4), (2, 2)]
+    cls = [torch.randn((B, nc, h, w), generator=g).half().float() for h, w in sizes]
+    reg = [torch.randn((B, nreg, h, w), generator=g).half().float() for h, w in sizes]
+    A = sum(h * w for h, w in sizes)
+    d = _lib.HeadPackDesc()
+    d.n_levels = 3
+    crefs, rrefs = [_nhwc(t) for t in cls], [_nhwc(t) for t in reg]
+    for i in range(3):
+        d.cls[i], d.reg[i] = crefs[i].ct(), rrefs[i].ct()
+    scores = torch.empty((B, A, nc), device=DEV)
+    distri = torch.empty((B, A, nreg), device=DEV)
+    d.scores, d.distri, d.nc, d.nreg = scores.data_ptr(), distri.data_ptr(), nc, nreg
+    _lib.check(lib.y6_head_pack(C.byref(d), _stream()), "head_pack")
+    ref_s = torch.cat([torch.sigmoid(t).flatten(2).permute(0, 2, 1) for t in cls], 1)
+    ref_d = torch.cat([t.flatten(2).permute(0, 2, 1) for t in reg], 1)
+    assert torch.allclose(scores.cpu(), ref_s, atol=1e-6) and torch.equal(distri.cpu(), ref_d)
+    ds, dd = torch.randn((B, A, nc), generator=g), torch.randn((B, A, nreg), generator=g)
+    dsd, ddd = ds.to(DEV), dd.to(DEV)
+    gcls = [TRef(torch.zeros((B, h, w, nc), dtype=torch.float16, device=DEV), B, h, w, nc, nc, 0) for h, w in sizes]
+    greg = [TRef(torch.zeros((B, h, w, 72), dtype=torch.float16, device=DEV), B, h, w, nreg, 72, 0) for h, w in sizes]
+    u = _lib.HeadPackDesc()
+    u.n_levels = 3
+    for i in range(3):
+        u.cls[i], u.reg[i] = gcls[i].ct(), greg[i].ct()
+    u.scores, u.dscores, u.ddistri, u.nc, u.nreg = scores.data_ptr(), dsd.data_ptr(), ddd.data_ptr(), nc, nreg
+    _lib.check(lib.y6_head_unpack_backward(C.byref(u), _stream()), "head_unpack_backward")
+    torch.cuda.synchronize()
+    a0 = 0
+    for i, (h, w) in enumerate(sizes):
+        n = h * w
+        p = ref_s[:, a0:a0 + n]
+        want_c = (ds[:, a0:a0 + n] * p * (1 - p)).permute(0, 2, 1).reshape(B, nc, h, w)
+        want_r = dd[:, a0:a0 + n].permute(0, 2, 1).reshape(B, nreg, h, w)
+        assert float((_back(gcls[i]) - want_c).abs().max()) < 2e-3
+        assert float((_back(greg[i]) - want_r).abs().max()) < 3e-3
+        assert float(greg[i].buf[..., nreg:].abs().max()) == 0.0       # pad channels stay zero
+        a0 += n
+
+
+def test_sgd_step_matches_torch_and_skips_on_overflow():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    n = 10007
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=0.02, momentum=0.937, nesterov=True, weight_decay=5e-4)
+    p, m = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+    scale = torch.tensor([1024.0], device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in range(3):
+        ref.grad = gr.clone() * (step + 1)
+        opt.step()
+        gd = (gr * (step + 1) * 1024.0).to(DEV)
+        _lib.check(lib.y6_grad_finite_check(gd.data_ptr(), n, flag.data_ptr(), _stream()), "finite")
+        _lib.check(lib.y6_sgd_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), n, 0.02, 0.937, 5e-4, 1, int(step == 0), scale.data_ptr(),
+                                   flag.data_ptr(), _stream()), "sgd")
+    assert torch.allclose(p.cpu(), ref.detach(), atol=1e-5, rtol=1e-5)
+    before = p.clone()
+    gd[5] = float("inf")
+    tracker = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(lib.y6_grad_finite_check(gd.data_ptr(), n, flag.data_ptr(), _stream()), "finite")
+    _lib.check(lib.y6_sgd_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), n, 0.02, 0.937, 5e-4, 1, 0, scale.data_ptr(), flag.data_ptr(),
+                               _stream()), "sgd")
+    _lib.check(lib.y6_scaler_update(scale.data_ptr(), flag.data_ptr(), tracker.data_ptr(), 2.0, 0.5, 2000, _stream()), "scaler")
+    assert torch.equal(p, before) and float(scale) == 512.0 and int(flag) == 0
+
+
+LOSS_CASES = sorted(f[len("lossgrad_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("lossgrad_"))
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_compute_loss_gradient_vs_reference_autograd(case):
+    """ComputeLoss(...)[0].backward() on the HIP path == the gradients the unmodified reference back-propagates."""
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.utils import synth
+    gl = np.load(os.path.join(GOLDEN, f"loss_{case}.npz"))
+    gg = np.load(os.path.join(GOLDEN, f"lossgrad_{case}.npz"))
+    m = json.loads(str(gl["meta"]))
+    inp = synth.synth_loss_inputs(m["B"], m["feat_sizes"], m["strides"], m["C"], m["reg_max"], m["use_dfl"], seed=m["seed"])
+    targets = inp["targets"] if case != "no_targets" else inp["targets"][:0]
+    crit = ComputeLoss(fpn_strides=m["strides"], num_classes=m["C"], ori_img_size=inp["img"], warmup_epoch=4, use_dfl=m["use_dfl"],
+                       reg_max=m["reg_max"], iou_type=m["iou_type"])
+    feats = [torch.zeros(m["B"], 1, h, w, device=DEV) for h, w in m["feat_sizes"]]
+    ps = inp["pred_scores"].to(DEV).requires_grad_(True)
+    pd = inp["pred_distri"].to(DEV).requires_grad_(True)
+    loss, items = crit((feats, ps, pd), targets.to(DEV), m["epoch"], 1, inp["img"], inp["img"])
+    (loss * 8.0).backward()                       # the incoming gradient (a loss scale) is applied inside the kernels
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(gg["loss"]), rtol=1e-4)
+    for got, name in ((ps.grad, "dscores"), (pd.grad, "ddistri")):
+        ref = gg[name].astype(np.float64) * 8.0
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref).max()) / scale
+        assert err < 1e-4, f"{case}: {name} deviates by {err:.3e} of its max"
+
+
+def _tiny_train_model(case):
+    from tests.helpers import case_config, synth_sd_from_keys
+    from yolov6_amd.models.yolo import build_model
+    cfg, meta = case_config(case)
+    model = build_model(cfg, meta["num_classes"], "cpu")
+    sd = synth_sd_from_keys(meta["train"])
+    model.load_state_dict(sd)
+    return cfg, meta, sd, model
+
+
+@pytest.mark.parametrize("case", ["tiny"])
+def test_training_graph_forward_backward_vs_oracle(case):
+    """Whole model, train form: head outputs, BatchNorm running statistics and EVERY parameter gradient vs TrainOracle
+    (fp32 CPU autograd, pinned to the reference's goldens), for the scalar the reference goldens back-propagate."""
+    from oracle import synth
+    from oracle.model_oracle import TrainOracle
+    cfg, meta, sd, model = _tiny_train_model(case)
+    gold = np.load(os.path.join(GOLDEN, f"train_{case}.npz"))
+    x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
+    # ---- oracle
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    osd = dict(sd)
+    osd.update(params)
+    orc = TrainOracle(cfg, osd, meta["num_classes"])
+    orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+    (xs, cls_o, reg_o), feats_o = orc.forward_train(x)
+    scalar_o = (cls_o * cls_o).sum() + reg_o.square().mean()
+    scalar_o.backward()
+    np.testing.assert_allclose(float(scalar_o), float(gold["scalar"]), rtol=1e-4)     # the oracle run IS the golden run
+    # ---- HIP
+    model = model.to(DEV).train()
+    out, featmaps = model(x.to(DEV).half())
+    stems, scores, distri = out
+    S = 256.0                                    # loss scale: activation gradients are fp16
+    scalar = (scores * scores).sum() + distri.square().mean()
+    (scalar * S).backward()
+    torch.cuda.synchronize()
+    assert float((scores.detach().cpu() - cls_o.detach()).abs().max()) < 5e-3
+    assert float((distri.detach().cpu() - reg_o.detach()).abs().max()) < 2e-2 * max(1.0, float(reg_o.abs().max()))
+    np.testing.assert_allclose(float(scalar), float(scalar_o), rtol=5e-3)
+    for f, r in zip(list(stems), xs):
+        assert f.shape == r.shape
+    # running statistics after one step (momentum 0.03, unbiased variance)
+    msd = model.state_dict()
+    for k in gold.files:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float(np.abs(msd[k].cpu().numpy() - gold[k]).max()) < 3e-3 * max(1.0, float(np.abs(gold[k]).max())), k
+    assert int(msd["backbone.stem.rbr_dense.bn.num_batches_tracked"]) == int(sd["backbone.stem.rbr_dense.bn.num_batches_tracked"]) + 1
+    # every parameter gradient
+    named = dict(model.named_parameters())
+    report, worst = {}, ("", 0.0)
+    for k, p in params.items():
+        if p.grad is None or k == "detect.proj" or k.startswith("detect.proj_conv"):
+            continue
+        got = named[k].grad.detach().float().cpu() / S
+        ref = p.grad
+        scale = max(float(ref.abs().max()), 1e-8)
+        err = float((got - ref).abs().max()) / scale
+        report[k] = err
+        if err > worst[1]:
+            worst = (k, err)
+    os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", f"train_grad_report_{case}.json"), "w") as f:
+        json.dump(dict(worst=worst, errs=report), f, indent=1)
+    print(f"{case}: {len(report)} parameter gradients, worst {worst[0]} {worst[1]:.3e}, median {float(np.median(list(report.values()))):.3e}")
+    # the reference's own gradient goldens (three probes at different depths)
+    for k in gold.files:
+        if k.startswith("grad:"):
+            name = k[5:]
+            got = named[name].grad.detach().float().cpu().numpy() / S
+            scale = max(float(np.abs(gold[k]).max()), 1e-8)
+            assert float(np.abs(got - gold[k]).max()) / scale < 3e-2, name
+    assert worst[1] < 3e-2, f"worst parameter gradient {worst}"

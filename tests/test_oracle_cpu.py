@@ -161,6 +161,31 @@ def test_loss_oracle_matches_reference_golden(case):
     np.testing.assert_allclose(out["loss_items"], g["items"], rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("case", LOSS_GOLDEN if "LOSS_GOLDEN" in globals() else
+                         sorted(f[len("loss_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("loss_")))
+def test_loss_gradient_oracle_matches_reference_autograd(case):
+    """oracle/loss_grad_oracle.py (autograd restatement, float64) vs the gradients the unmodified reference
+    back-propagates through ComputeLoss (tests/golden/lossgrad_*.npz)."""
+    from oracle import loss_grad_oracle
+    g = np.load(os.path.join(GOLDEN, f"loss_{case}.npz"))
+    gg = np.load(os.path.join(GOLDEN, f"lossgrad_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp = synth.synth_loss_inputs(m["B"], m["feat_sizes"], m["strides"], m["C"], m["reg_max"], m["use_dfl"], seed=m["seed"])
+    targets = inp["targets"].numpy()
+    if case == "no_targets":
+        targets = targets[:0]
+    out = loss_grad_oracle.compute_loss_with_grads(
+        m["feat_sizes"], inp["pred_scores"].numpy(), inp["pred_distri"].numpy(), targets, m["epoch"], inp["img"], inp["img"],
+        fpn_strides=m["strides"], num_classes=m["C"], warmup_epoch=4, use_dfl=m["use_dfl"], reg_max=m["reg_max"],
+        iou_type=m["iou_type"])
+    np.testing.assert_allclose(out["loss"], float(gg["loss"]), rtol=2e-5, atol=1e-6)
+    for name in ("dscores", "ddistri"):
+        ref = gg[name].astype(np.float64)
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        err = float(np.abs(out[name] - ref).max()) / scale
+        assert err < 2e-4, f"{case}: {name} deviates from the reference's autograd by {err:.3e} of its max"
+
+
 # ------------------------------------------------------------------ training-mode forward (K15 groundwork)
 TRAIN_GOLDEN = sorted(f[len("train_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("train_"))
 

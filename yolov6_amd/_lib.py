@@ -188,6 +188,8 @@ SIGNATURES = {
     "y6_head_pack": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
     "y6_head_unpack_backward": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
     "y6_space_to_depth2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
+    "y6_subsample2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
+    "y6_plan_add_subsample2": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor)]),
     "y6_channel_sum": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y6_tensor_add": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_void_p]),
     "y6_loss_forward_backward": (C.c_int, [C.POINTER(LossGradDesc), C.c_void_p]),

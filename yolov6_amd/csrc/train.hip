@@ -566,6 +566,11 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
         }
         const y6_pack_job jb = jobs[lo];
         const uint64_t e = i - jb.first;
+        if (jb.kind == 4) {       // fp32 [Cout][Cin][3][3] with the 1x1 kernel at the centre tap (the stem's 1x1 stride-2 branch)
+            const uint64_t oi = e / 9;
+            reinterpret_cast<float*>(jb.dst)[e] = (e - oi * 9 == 4) ? jb.src[oi] : 0.f;
+            continue;
+        }
         const int K = jb.K, NT = K * K;
         // logical output-channel / input-channel counts of the packed matrix
         int O = jb.Cout, I = jb.Cin;
@@ -858,6 +863,32 @@ int s2d_launch(const TwoT* d, hipStream_t s) {
     return Y6_OK;
 }
 
+// dst[b,y,x,:] = src[b,2y,2x,:]  (the input sampling of a 1x1 stride-2 conv: the MFMA 1x1 kernels are stride-1 GEMMs)
+__global__ __launch_bounds__(256) void subsample2_kernel(const __half* __restrict__ src, int scs, int sco, int H, int W, int C,
+                                                         __half* __restrict__ dst, int dcs, int dco, int B, int Ho, int Wo) {
+    const int G = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int x = (int)(t % Wo);
+        t /= Wo;
+        const int y = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        *reinterpret_cast<uint4*>(dst + ((size_t)(b * Ho + y) * Wo + x) * dcs + dco + g * 8) =
+            *reinterpret_cast<const uint4*>(src + ((size_t)(b * H + 2 * y) * W + 2 * x) * scs + sco + g * 8);
+    }
+}
+int subsample2_launch(const TwoT* d, hipStream_t s) {
+    const y6_tensor &a = d->a, &o = d->b;
+    Y6_REQUIRE(view_ok(a) && view_ok(o), "subsample2: bad views");
+    Y6_REQUIRE(o.H == (a.H + 1) / 2 && o.W == (a.W + 1) / 2 && o.C == a.C && o.B == a.B, "subsample2: shape mismatch");
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((size_t)o.B * o.H * o.W * (o.C / 8), 256)), dim3(256), 0, s, (const __half*)a.data,
+                       a.cstride, a.coff, a.H, a.W, a.C, (__half*)o.data, o.cstride, o.coff, a.B, o.H, o.W);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 __global__ __launch_bounds__(256) void tensor_add_kernel(const __half* __restrict__ a, int acs, int aco, __half* __restrict__ dst, int dcs,
                                                          int dco, long npix, int C, int acc) {
     const int G = C >> 3;
@@ -898,17 +929,18 @@ __global__ void chan_sum_finalize_kernel(const double* __restrict__ ws, int C, f
 }
 // generic (any C): one thread per (pixel-row-slice, channel); used for the prediction convs (C = 80, 68, 4)
 __global__ __launch_bounds__(256) void chan_sum_kernel(const __half* __restrict__ x, int cs, int co, long npix, int C, double* __restrict__ ws) {
-    const int c = threadIdx.x % C;                    // C <= 256 handled by rows of C threads
-    const int rows = 256 / C;
-    const int row = threadIdx.x / C;
+    const int rows = C <= 256 ? 256 / C : 1;          // rows of C threads; wider tensors: one row, channels strided by 256
+    const int row = threadIdx.x / (C <= 256 ? C : 256);
     if (row >= rows) return;
-    double s = 0.0;
-    for (long p = (long)blockIdx.x * rows + row; p < npix; p += (long)gridDim.x * rows) s += (double)__half2float(x[p * cs + co + c]);
-    atomicAdd(&ws[c], s);
+    for (int c = threadIdx.x - row * (C <= 256 ? C : 256); c < C; c += 256) {
+        double s = 0.0;
+        for (long p = (long)blockIdx.x * rows + row; p < npix; p += (long)gridDim.x * rows) s += (double)__half2float(x[p * cs + co + c]);
+        atomicAdd(&ws[c], s);
+    }
 }
 int chan_sum_launch(const ChanSum* d, hipStream_t s) {
     const y6_tensor& t = d->x;
-    Y6_REQUIRE(t.data && d->out && d->ws && t.C >= 1 && t.C <= 256, "channel_sum: bad arguments (1..256 channels)");
+    Y6_REQUIRE(t.data && d->out && d->ws && t.C >= 1 && t.C <= 4096, "channel_sum: bad arguments (1..4096 channels)");
     Y6_REQUIRE(d->ws_bytes >= (size_t)t.C * sizeof(double), "channel_sum: workspace too small");
     const long npix = (long)t.B * t.H * t.W;
     Y6_HIP(hipMemsetAsync(d->ws, 0, (size_t)t.C * sizeof(double), s));
@@ -917,7 +949,7 @@ int chan_sum_launch(const ChanSum* d, hipStream_t s) {
     if (g < 1) g = 1;
     hipLaunchKernelGGL(chan_sum_kernel, dim3((unsigned)g), dim3(256), 0, s, (const __half*)t.data, t.cstride, t.coff, npix, t.C, (double*)d->ws);
     Y6_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(1), dim3(256), 0, s, (const double*)d->ws, t.C, d->out);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((unsigned)((t.C + 255) / 256)), dim3(256), 0, s, (const double*)d->ws, t.C, d->out);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -993,6 +1025,7 @@ extern "C" int y6_wgrad_transpose(const y6_wgrad_t_desc* d, void* stream) {
     return wgrad_transpose_launch(d, (hipStream_t)stream);
 }
 extern "C" size_t y6_pack_job_elems(int kind, int Cout, int Cin, int K) {
+    if (kind == 4) return (size_t)Cout * Cin * 9;
     int O = Cout, I = Cin, nt = K * K;
     if (kind == 1) { O = Cin; I = Cout; }
     if (kind == 2) { O = 4 * Cout; I = Cin; nt = 1; }
@@ -1021,6 +1054,12 @@ extern "C" int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, vo
     Y6_REQUIRE(src && dst, "space_to_depth2: null argument");
     TwoT t{*src, *dst, 0};
     return s2d_launch(&t, (hipStream_t)stream);
+}
+extern "C" int y6_subsample2(const y6_tensor* src, const y6_tensor* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(src && dst, "subsample2: null argument");
+    TwoT t{*src, *dst, 0};
+    return subsample2_launch(&t, (hipStream_t)stream);
 }
 extern "C" int y6_channel_sum(const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes, void* stream) {
     Y6_CLEAR_STALE_ERROR();
@@ -1105,6 +1144,11 @@ extern "C" int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, con
     Y6_REQUIRE(p && src && dst, "plan_add: null argument");
     TwoT t{*src, *dst, 0};
     return y6_plan_push(p, s2d_launch, &t, Y6_TOP_S2D, 0.0, 2.0 * nhwc_bytes(*src));
+}
+extern "C" int y6_plan_add_subsample2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst) {
+    Y6_REQUIRE(p && src && dst, "plan_add: null argument");
+    TwoT t{*src, *dst, 0};
+    return y6_plan_push(p, subsample2_launch, &t, Y6_TOP_S2D, 0.0, 2.0 * nhwc_bytes(*dst));
 }
 extern "C" int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes) {
     Y6_REQUIRE(p && x, "plan_add: null argument");

@@ -126,7 +126,8 @@ class Plan:
             _lib.check(self._lib.y6_plan_op_info(self._h, i, C.byref(kind), C.byref(var), C.byref(ks), C.byref(st),
                                                  C.byref(fl), C.byref(by)), "plan_op_info")
             vname = self._lib.y6_conv_variant_name(var.value).decode() if var.value >= 0 else ""
-            rows.append(dict(op=i, kind=names.get(kind.value, "?"), variant=vname, ksize=ks.value, stride=st.value,
+            kname = _lib.TOP_NAMES.get(ks.value, "generic") if kind.value == 8 else names.get(kind.value, "?")
+            rows.append(dict(op=i, kind=kname, variant=vname, ksize=ks.value if kind.value != 8 else 0, stride=st.value,
                              ms=float(ms[i]) / max(used, 1), flops=fl.value, bytes=by.value))
         return rows
 

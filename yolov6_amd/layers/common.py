@@ -121,8 +121,9 @@ class HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d) and m.training:
                 raise NotImplementedError(
-                    "yolov6_amd: batch-statistics BatchNorm (training-form forward, SURVEY K15) is not on the HIP "
-                    "path yet; call .eval() (running statistics are folded into the conv kernels)")
+                    "yolov6_amd: a single block in .train() mode has no standalone HIP forward; batch-statistics "
+                    "BatchNorm runs through the whole-model training graph (Model.forward in train mode, "
+                    "yolov6_amd/train_engine.py) - call .eval() for block-level inference")
 
     def _finish_outputs(self, pb, outs, dtype):
         if isinstance(outs, TRef):
@@ -215,6 +216,12 @@ class ConvModule(HipModule):
         k = c.kernel_size[0]
         if c.padding != (k // 2, k // 2):
             raise NotImplementedError("yolov6_amd: only 'same' padding (k//2) is supported")
+        if getattr(pb, "is_train", False):
+            # training form (common.py:45-49): conv -> BatchNorm on batch statistics -> activation, with a backward tape
+            if not hasattr(self, "bn") or c.bias is not None:
+                raise NotImplementedError("yolov6_amd: training needs the un-fused ConvModule (conv without bias + BatchNorm)")
+            y = pb.conv(x, c.weight, c.stride[0])
+            return pb.bnact([(y, pb.bn(y, self.bn))], self._activation_name(), out=out, res=res, alpha=res_alpha)
         w, b = self.fused_weight_bias()
         return pb.conv(x, w, b, stride=c.stride[0], act=self._activation_name(), out=out, res=res, res_alpha=res_alpha)
 
@@ -365,7 +372,7 @@ class Transpose(HipModule):
         ct = self.upsample_transpose
         if ct.kernel_size != (2, 2) or ct.stride != (2, 2):
             raise NotImplementedError("yolov6_amd: Transpose is specialised for kernel_size=2, stride=2")
-        return pb.convt2x2(x, ct.weight, ct.bias, out=out)
+        return pb.convt2x2(x, ct.weight, ct.bias, out=out)     # the training builder takes the Parameters themselves
 
 
 # ------------------------------------------------------------------------------------------
@@ -447,9 +454,24 @@ class RepVGGBlock(HipModule):
     def _stride(self):
         return (self.rbr_reparam if hasattr(self, "rbr_reparam") else self.rbr_dense.conv).stride[0]
 
+    def _lower_train(self, pb, x, out, res, res_alpha):
+        """Training form (common.py:250-255): ReLU(bn(conv3x3(x)) + bn(conv1x1(x)) + bn_id(x)), batch statistics."""
+        if hasattr(self, "rbr_reparam"):
+            raise NotImplementedError("yolov6_amd: a deployed RepVGG block cannot be trained (no branches left)")
+        s = self.rbr_dense.conv.stride[0]
+        y3 = pb.conv(x, self.rbr_dense.conv.weight, s)
+        y1 = pb.conv(x, self.rbr_1x1.conv.weight, s)
+        branches = [(y3, pb.bn(y3, self.rbr_dense.bn)), (y1, pb.bn(y1, self.rbr_1x1.bn))]
+        if self.rbr_identity is not None:
+            xr = pb.as_nhwc(x)
+            branches.append((xr, pb.bn(xr, self.rbr_identity)))
+        return pb.bnact(branches, "relu", out=out, res=res, alpha=res_alpha)
+
     def lower(self, pb, x, out=None, res=None, res_alpha=None):
         if self.groups != 1:
             raise NotImplementedError("yolov6_amd: grouped RepVGG blocks are not supported")
+        if getattr(pb, "is_train", False):
+            return self._lower_train(pb, x, out, res, res_alpha)
         w, b = self._deploy_weight_bias()
         return pb.conv(x, w, b, stride=self._stride(), act="relu", out=out, post=self._post_affine(), res=res,
                        res_alpha=res_alpha)
@@ -482,6 +504,9 @@ class QARepVGGBlock(RepVGGBlock):
         if self.rbr_identity is not None:
             kernel = kernel + identity_kernel3x3(self.in_channels, kernel.device)
         return kernel, b3
+
+    def _lower_train(self, pb, x, out, res, res_alpha):
+        raise NotImplementedError("yolov6_amd: QARepVGG training form (avg-pool / raw branches) is not on the HIP path yet")
 
     def _post_affine(self):
         # the deploy form keeps self.bn after the conv (:338-339, :390-392)

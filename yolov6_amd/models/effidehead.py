@@ -46,10 +46,25 @@ class Detect(HipModule):
         self.proj_conv.weight = nn.Parameter(self.proj.view([1, self.reg_max + 1, 1, 1]).clone().detach(),
                                              requires_grad=False)
 
+    def lower_train(self, tb, x):
+        """Training branch (effidehead.py:72-92): per level stem -> {cls conv, 1x1 pred}, {reg conv, 1x1 pred}; sigmoid on the
+        class logits; levels flattened and concatenated to cls_scores [B,A,nc], reg_distri [B,A,4*(reg_max+1)] (fp32)."""
+        stems, cls_out, reg_out = [], [], []
+        for i in range(self.nl):
+            f = self.stems[i].lower(tb, x[i])
+            stems.append(f)
+            c = self.cls_convs[i].lower(tb, f)
+            r = self.reg_convs[i].lower(tb, f)
+            cp, rp = self.cls_preds[i], self.reg_preds[i]
+            cls_out.append(tb.conv(c, cp.weight, 1, bias=cp.bias))
+            reg_out.append(tb.conv(r, rp.weight, 1, bias=rp.bias))
+        scores, distri = tb.head_pack(cls_out, reg_out, self.nc, self.reg_preds[0].out_channels)
+        return stems, scores, distri
+
     def lower(self, pb, x, out=None):
         if self.training:
-            raise NotImplementedError("yolov6_amd: Detect training branch (effidehead.py:72-92) is not on the HIP path "
-                                      "yet; call .eval()")
+            raise NotImplementedError("yolov6_amd: Detect's training branch runs through Model.forward in train mode "
+                                      "(whole-model training graph)")
         if self.export:
             raise NotImplementedError("yolov6_amd: export mode (ONNX tracing) is out of scope of the HIP path")
         cls_out, reg_out = [], []

@@ -7,10 +7,13 @@ return value), computing the FORWARD VALUE of the training loss on the GPU:
     label assignment   ATSSAssigner for epoch < warmup_epoch, TaskAlignedAssigner after (loss.py:83-103) - HIP
     loss terms         y6_loss_forward: VarifocalLoss, IoU loss, DFL loss, normalisation, weights (loss.py:154-182)
 
-The result is a pair (loss, loss_items[iou, dfl, cls]) of fp32 tensors WITHOUT an autograd graph: the backward pass
-of the training step is not implemented yet, so this serves validation-loss monitoring and parity
-checks, not optimisation.  There is no CPU path and no OOM fallback to one (the reference's `except RuntimeError`
-branch, loss.py:105-152, exists because its assigner needs O(B*G*A) temporaries; the HIP assigners do not).
+The result is the reference's pair (loss, loss_items[iou, dfl, cls]).  When the predictions require grad, `loss` carries an
+autograd node whose backward runs y6_loss_backward (dual-number IoU gradient, DFL / VarifocalLoss closed forms) with the
+incoming gradient - the GradScaler's loss scale - applied inside the kernels, and writes d loss / d pred_scores,
+d loss / d pred_distri straight into the training graph's head-gradient buffers (yolov6_amd/train_engine.py), so
+`scaler.scale(loss).backward()` (core/engine.py:173) drives the native backward plan.  There is no CPU path and no OOM
+fallback to one (the reference's `except RuntimeError` branch, loss.py:105-152, exists because its assigner needs
+O(B*G*A) temporaries; the HIP assigners do not).
 """
 import ctypes as C
 
@@ -23,8 +26,26 @@ from ...assigners.atss_assigner import ATSSAssigner
 from ...assigners.tal_assigner import TaskAlignedAssigner
 
 
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred_scores, pred_distri, holder):
+        ctx.holder = holder
+        ctx.dtypes = (pred_scores.dtype, pred_distri.dtype)
+        return holder["loss"].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        h = ctx.holder
+        gs = gout.detach().to(torch.float32).contiguous()
+        d = h["desc"]
+        d.grad_scale = C.c_void_p(gs.data_ptr())
+        _lib.check(_lib.load().y6_loss_backward(C.byref(d), _lib.current_stream_ptr()), "loss_backward")
+        ds, dd = h["dscores"], h["ddistri"]
+        return ds.to(ctx.dtypes[0]), dd.to(ctx.dtypes[1]), None
+
+
 class ComputeLoss:
-    """Loss computation func (forward value)."""
+    """Loss computation func."""
 
     def __init__(self, fpn_strides=[8, 16, 32], grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80,
                  ori_img_size=640, warmup_epoch=4, use_dfl=True, reg_max=16, iou_type='giou',
@@ -88,12 +109,16 @@ class ComputeLoss:
         feats, pred_scores, pred_distri = outputs
         _lib.require_gpu_tensor(pred_scores, "pred_scores")
         dev = pred_scores.device
-        if all(feat.shape[2:] == cfsize for feat, cfsize in zip(feats, self.cached_feat_sizes)):
+        # only the spatial sizes of `feats` matter (loss.py:63-69); lazily converted training-graph features are not touched
+        sizes = feats.feat_sizes() if hasattr(feats, "feat_sizes") else [feat.shape[2:] for feat in feats]
+        if len(sizes) == len(self.cached_feat_sizes) and all(tuple(a) == tuple(b) for a, b in zip(sizes, self.cached_feat_sizes)) \
+                and self.cached_anchors is not None:
             anchors, anchor_points, n_anchors_list, stride_tensor = self.cached_anchors
         else:
-            self.cached_feat_sizes = [feat.shape[2:] for feat in feats]
+            self.cached_feat_sizes = [torch.Size(sz) for sz in sizes]
+            shape_feats = [torch.zeros(1, device=dev).expand(1, 1, int(sz[0]), int(sz[1])) for sz in sizes]
             anchors, anchor_points, n_anchors_list, stride_tensor = generate_anchors(
-                feats, self.fpn_strides, self.grid_cell_size, self.grid_cell_offset, device=dev)
+                shape_feats, self.fpn_strides, self.grid_cell_size, self.grid_cell_offset, device=dev)
             anchors, anchor_points, stride_tensor = (t.float().to(dev) for t in (anchors, anchor_points, stride_tensor))
             self.cached_anchors = anchors, anchor_points, n_anchors_list, stride_tensor
         assert pred_scores.type() == pred_distri.type()
@@ -137,4 +162,18 @@ class ComputeLoss:
         d.workspace_bytes = ws.numel()
         _lib.check(lib.y6_loss_forward(C.byref(d), _lib.current_stream_ptr()), "loss_forward")
         res = out.float()
+        ps_in, pd_in = outputs[1], outputs[2]
+        if torch.is_grad_enabled() and (ps_in.requires_grad or pd_in.requires_grad):
+            graph = getattr(ps_in, "_y6_graph", None)
+            if graph is not None and graph.dscores.shape == pred_scores.shape:
+                dscores, ddistri = graph.dscores, graph.ddistri       # the native backward plan reads these directly
+            else:
+                dscores, ddistri = torch.empty_like(pred_scores), torch.empty_like(pred_distri)
+            g = _lib.LossGradDesc()
+            g.fwd = d
+            g.dpred_scores, g.dpred_distri = C.c_void_p(dscores.data_ptr()), C.c_void_p(ddistri.data_ptr())
+            keep = (pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_flat, target_labels, target_bboxes,
+                    target_scores, fg_u8, out, ws)
+            holder = dict(desc=g, dscores=dscores, ddistri=ddistri, loss=res[0], keep=keep)
+            return _LossFn.apply(ps_in, pd_in, holder), res[1:4].detach()
         return res[0], res[1:4].detach()

@@ -60,9 +60,18 @@ class Model(HipModule):
         self._featrefs = list(feats)
         return self.detect.lower(pb, list(feats))
 
+    def lower_train(self, tb, x):
+        feats = list(self.neck.lower(tb, self.backbone.lower(tb, x)))
+        stems, scores, distri = self.detect.lower_train(tb, feats)
+        return stems, feats, scores, distri
+
     def forward(self, x):
         if torch.onnx.is_in_onnx_export() or self.export:
             raise NotImplementedError("yolov6_amd: ONNX export mode is out of scope of the HIP path")
+        if self.training:
+            from ..train_engine import train_forward
+            _require_gpu(x)
+            return train_forward(self, x)
         plan = self.compile(x)
         prev = self.__dict__.get("_last_featmaps")
         prev = prev() if prev is not None else None
@@ -78,6 +87,12 @@ class Model(HipModule):
         self.detect.stride = fn(self.detect.stride)
         self.detect.grid = list(map(fn, self.detect.grid))
         return self
+
+
+def _require_gpu(x):
+    if not x.is_cuda:
+        raise RuntimeError("yolov6_amd: the HIP hot path needs ROCm tensors; there is no CPU fallback "
+                           f"(got a tensor on {x.device})")
 
 
 def make_divisible(x, divisor):

@@ -1,0 +1,691 @@
+"""Training-step builder: lowers the module tree in TRAIN form (batch-statistics BatchNorm, un-fused RepVGG branches,
+Detect training branch) into TWO native plans of HIP kernels - forward and backward - over NHWC fp16 activations, fp32
+master parameters and an fp32 gradient arena.
+
+Replaces, for the reference's training step (yolov6/core/engine.py:142-176):
+    preds = model(images)                      -> TrainGraph.forward      (one native plan)
+    scaler.scale(total_loss).backward()        -> TrainGraph.backward     (one native plan; parameter gradients are
+                                                                           accumulated straight into `p.grad`, which are
+                                                                           views of ONE flat arena - the DDP all-reduce
+                                                                           and the fused SGD run over that arena)
+Leaf modules (ConvModule, RepVGGBlock, Transpose, SPPF pools, Detect) call the builder below from their ordinary
+`lower()`; the composite modules (RepBlock, BepC3, BiFusion, backbones, necks) are shared with the inference lowering.
+
+Per conv the backward emits (see yolov6_amd/csrc/wgrad.hip, train.hip):
+    data gradient     the forward MFMA conv kernel on the flipped / transposed weights (stride 2: over the zero-inserted
+                      output gradient, which the BatchNorm backward writes directly in dilated form)
+    weight gradient   channel-major transposes of x and dy + the tap-table MFMA GEMM, fp32 atomics into the arena
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ACT_BY_NAME, Y6_F16, Y6_F32
+from .engine import NCHWInput, Plan, TRef, _dtype_tag, _null_tensor
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _rup(v, m):
+    return (v + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------------- parameter arena
+class ParamArena:
+    """All trainable parameters of a model as views of ONE flat fp32 tensor, their gradients as views of another.
+
+    `p.data` / `p.grad` are re-pointed (values preserved), so state_dict / optimizers / GradScaler keep working on the
+    ordinary Parameter objects while the DDP all-reduce and the fused SGD see two contiguous arrays.  Parameters are laid
+    out in REVERSE registration order: the backward pass finishes gradients roughly in that order, so leading chunks of
+    the arena can be all-reduced while the rest of the backward still runs."""
+
+    def __init__(self, model: nn.Module, device=None):
+        params = [p for p in model.parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for p in reversed(params):
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        self.params = uniq
+        device = device or uniq[0].device
+        offs, n = [], 0
+        for p in uniq:
+            offs.append(n)
+            n += _rup(p.numel(), 4)              # 16-byte aligned views (float4 loads of BN vectors)
+        self.offsets = offs
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        for p, o in zip(uniq, offs):
+            v = self.data[o:o + p.numel()].view(p.shape)
+            v.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = v
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.index = {id(p): i for i, p in enumerate(uniq)}
+
+    def offset_of(self, p):
+        return self.offsets[self.index[id(p)]]
+
+    def grad_ptr(self, p):
+        return C.c_void_p(self.grad.data_ptr() + 4 * self.offset_of(p))
+
+    def data_ptr(self, p):
+        return C.c_void_p(self.data.data_ptr() + 4 * self.offset_of(p))
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def reattach(self):
+        """`optimizer.zero_grad(set_to_none=True)` drops the views: point `.grad` back at the arena."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+# ---------------------------------------------------------------------------------------------------- records
+@dataclass
+class BnStats:
+    module: Optional[nn.BatchNorm2d]
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor
+    invstd: torch.Tensor
+
+
+@dataclass
+class ConvRec:
+    x: object                 # TRef or NCHWInput (stem)
+    y: TRef
+    weight: nn.Parameter
+    bias: Optional[nn.Parameter]
+    k: int
+    stride: int
+    dy: Optional[TRef] = None     # gradient wrt y as the backward sees it (dilated for stride 2)
+    dy_dil: int = 1
+    cpad: int = 0                 # channels of the (8-padded) dy view
+
+
+class TrainBuilder:
+    """PlanBuilder-compatible facade (as_nhwc / new_buffer / sppf_pool / convt2x2 / head ops) that records a tape."""
+    is_train = True
+
+    def __init__(self, device, arena: ParamArena):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.arena = arena
+        self.fwd = C.c_void_p(self.lib.y6_plan_create())
+        self.bwd = C.c_void_p(self.lib.y6_plan_create())
+        self.keep: List[torch.Tensor] = []
+        self.tape = []
+        self.pack_jobs = []          # (src_ptr, dst tensor, kind, Cout, Cin, K)
+        self.gbuf = {}               # forward buffer data_ptr -> gradient buffer
+        self.gspans = {}             # gradient buffer data_ptr -> list[(c0, c1)] already written
+        self.inputs: List[torch.Tensor] = []
+        self.bwd_marks = []          # (bwd op index after a closure, params finalised by it)
+        self.fwd_flops = 0.0
+        self.bwd_flops = 0.0
+        self.n_fwd_ops = 0
+        self.n_bwd_ops = 0
+
+    # ------------------------------------------------------------------ memory
+    def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
+        t = (torch.zeros if zero else torch.empty)((B, H, W, C_), dtype=torch.float16, device=self.device)
+        self.keep.append(t)
+        return TRef(t, B, H, W, C_, C_, 0)
+
+    def f32(self, n, zero=False):
+        t = (torch.zeros if zero else torch.empty)(_rup(n, 4), dtype=torch.float32, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def bytes_(self, n):
+        t = torch.zeros(_rup(n, 16), dtype=torch.uint8, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def as_nhwc(self, x):
+        if isinstance(x, TRef):
+            return x
+        raise RuntimeError("yolov6_amd: in training form only the stem reads the caller's NCHW tensor")
+
+    # ------------------------------------------------------------------ gradient bookkeeping
+    def grad(self, t: TRef) -> TRef:
+        key = t.buf.data_ptr()
+        g = self.gbuf.get(key)
+        if g is None:
+            g = torch.empty_like(t.buf)
+            self.keep.append(g)
+            self.gbuf[key] = g
+        return TRef(g, t.B, t.H, t.W, t.C, t.cstride, t.coff)
+
+    def grad_mode(self, g: TRef) -> int:
+        """0 if this is the first write to the span (overwrite), 1 if the op must accumulate.  Marks it written."""
+        spans = self.gspans.setdefault(g.buf.data_ptr(), [])
+        lo, hi = g.coff, g.coff + g.C
+        for (a, b) in spans:
+            if a <= lo and hi <= b:           # inside a span that was already written (e.g. by the conv over a concat)
+                return 1
+            if a < hi and lo < b:
+                raise RuntimeError("yolov6_amd: gradient spans overlap partially (unsupported concat pattern)")
+        spans.append((lo, hi))
+        return 0
+
+    def grad_ready(self, g: TRef):
+        spans = sorted(self.gspans.get(g.buf.data_ptr(), []))
+        pos = g.coff
+        for a, b in spans:
+            if a <= pos < b:
+                pos = b
+        if pos < g.coff + g.C:
+            raise RuntimeError("yolov6_amd: a gradient is read before every consumer wrote it (backward order bug)")
+
+    # ------------------------------------------------------------------ plan plumbing
+    def _f(self, rc, what):
+        _lib.check(rc, what)
+        self.n_fwd_ops += 1
+
+    def _b(self, rc, what):
+        _lib.check(rc, what)
+        self.n_bwd_ops += 1
+
+    def _add_pack(self, src_ptr, kind, Cout, Cin, K):
+        n = int(self.lib.y6_pack_job_elems(kind, Cout, Cin, K))
+        if kind == 4:
+            dst = torch.zeros(n, dtype=torch.float32, device=self.device)
+        else:
+            dst = torch.empty(n, dtype=torch.float16, device=self.device)
+        self.keep.append(dst)
+        self.pack_jobs.append((src_ptr, dst, kind, Cout, Cin, K, n))
+        return dst
+
+    def _conv_op(self, plan, x: TRef, out: TRef, packed, k, stride, bias_ptr=None, res: Optional[TRef] = None):
+        d = _lib.ConvDesc()
+        d.inp, d.out = x.ct(), out.ct()
+        d.w_packed = _ptr(packed)
+        d.w_oihw = None
+        d.bias = bias_ptr
+        d.post_scale = d.post_shift = None
+        d.res = res.ct() if res is not None else _null_tensor()
+        d.res_alpha = None
+        d.ksize, d.stride, d.act, d.variant = k, stride, 0, -1
+        rc = self.lib.y6_plan_add_conv(plan, C.byref(d))
+        flops = 2.0 * out.B * out.H * out.W * out.C * x.C * k * k
+        if plan is self.fwd:
+            self._f(rc, "plan_add_conv")
+            self.fwd_flops += flops
+        else:
+            self._b(rc, "plan_add_conv")
+            self.bwd_flops += flops
+
+    # ------------------------------------------------------------------ forward ops
+    def conv(self, x, weight: nn.Parameter, stride: int, bias: Optional[nn.Parameter] = None) -> TRef:
+        """Raw convolution y = conv(x, W) (+ bias for the prediction convs); W is the fp32 master parameter."""
+        Cout, Cin, K, _ = weight.shape
+        if K not in (1, 3) or stride not in (1, 2):
+            raise NotImplementedError("yolov6_amd: training convs are 1x1 / 3x3, stride 1 / 2")
+        wptr = self.arena.data_ptr(weight)
+        if isinstance(x, NCHWInput):
+            return self._stem_conv(x, weight, stride)
+        pad = K // 2
+        Ho, Wo = (x.H + 2 * pad - K) // stride + 1, (x.W + 2 * pad - K) // stride + 1
+        y = self.new_buffer(x.B, Ho, Wo, Cout)
+        packed = self._add_pack(wptr, 0, Cout, Cin, K)
+        bptr = self.arena.data_ptr(bias) if bias is not None else None
+        if K == 1 and stride == 2:      # the MFMA 1x1 kernels are stride-1 GEMMs: sample x[2y, 2x] first
+            xs = self.new_buffer(x.B, Ho, Wo, Cin)
+            ca, cb = x.ct(), xs.ct()
+            self._f(self.lib.y6_plan_add_subsample2(self.fwd, C.byref(ca), C.byref(cb)), "plan_add_subsample2")
+            self._conv_op(self.fwd, xs, y, packed, 1, 1, bias_ptr=bptr)
+        else:
+            self._conv_op(self.fwd, x, y, packed, K, stride, bias_ptr=bptr)
+        rec = ConvRec(x, y, weight, bias, K, stride)
+        y._conv = rec
+        self.tape.append(lambda: self._conv_backward(rec))
+        return y
+
+    def _stem_conv(self, x: NCHWInput, weight, stride):
+        t = x.t
+        _lib.require_gpu_tensor(t, "input") if self.device.type == "cuda" else None
+        if not t.is_contiguous():
+            raise RuntimeError("yolov6_amd: input must be a contiguous NCHW tensor")
+        B, Cin, H, W = t.shape
+        Cout, _, K, _ = weight.shape
+        if stride != 2 or Cin > 4:
+            raise NotImplementedError("yolov6_amd: the NCHW boundary is read by the stride-2 stem only")
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = self.new_buffer(B, Ho, Wo, Cout)
+        if t not in self.inputs:
+            self.inputs.append(t)
+        wptr = self.arena.data_ptr(weight)
+        if K == 1:     # the 1x1 stride-2 branch of the stem block: a 3x3 kernel with only the centre tap set
+            w33 = self._add_pack(wptr, 4, Cout, Cin, 1)
+            wsrc = C.c_void_p(w33.data_ptr())
+        else:
+            wsrc = wptr
+        d = _lib.StemDesc()
+        d.in_nchw, d.in_dtype = C.c_void_p(t.data_ptr()), _dtype_tag(t)
+        d.B, d.Cin, d.H, d.W = B, Cin, H, W
+        d.out = y.ct()
+        d.w_oihw_f32 = wsrc
+        d.bias = d.post_scale = d.post_shift = None
+        d.act = 0
+        self._f(self.lib.y6_plan_add_stem(self.fwd, C.byref(d)), "plan_add_stem")
+        self.fwd_flops += 2.0 * B * Ho * Wo * Cout * Cin * K * K
+        rec = ConvRec(x, y, weight, None, K, 2)
+        y._conv = rec
+        self.tape.append(lambda: self._conv_backward(rec))
+        return y
+
+    def bn(self, y: TRef, bn: nn.BatchNorm2d) -> BnStats:
+        Cn = y.C
+        st = BnStats(bn, self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn))
+        ws = self.bytes_(int(self.lib.y6_bn_stats_workspace_bytes(Cn)))
+        d = _lib.BnTrainDesc()
+        d.x = y.ct()
+        d.gamma = self.arena.data_ptr(bn.weight) if bn.weight is not None else None
+        d.beta = self.arena.data_ptr(bn.bias) if bn.bias is not None else None
+        track = bn.track_running_stats and bn.running_mean is not None
+        d.running_mean = _ptr(bn.running_mean) if track else None
+        d.running_var = _ptr(bn.running_var) if track else None
+        d.num_batches_tracked = _ptr(bn.num_batches_tracked) if track else None
+        d.momentum = float(bn.momentum if bn.momentum is not None else 0.1)
+        d.eps = float(bn.eps)
+        d.scale, d.shift, d.mean, d.invstd = (_ptr(t) for t in (st.scale, st.shift, st.mean, st.invstd))
+        d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
+        self._f(self.lib.y6_plan_add_bn_train_stats(self.fwd, C.byref(d)), "plan_add_bn_train_stats")
+        return st
+
+    def bnact(self, branches, act, out: Optional[TRef] = None, res: Optional[TRef] = None,
+              alpha: Optional[nn.Parameter] = None) -> TRef:
+        """out = act(sum_b x_b*scale_b + shift_b) [+ alpha*res];  branches: [(TRef, BnStats | None)]."""
+        ref = branches[0][0]
+        if out is None:
+            out = self.new_buffer(ref.B, ref.H, ref.W, ref.C)
+        d = _lib.BnActDesc()
+        d.n = len(branches)
+        for i, (t, st) in enumerate(branches):
+            d.x[i] = t.ct()
+            d.scale[i] = st.scale.data_ptr() if st is not None else None
+            d.shift[i] = st.shift.data_ptr() if st is not None else None
+        d.res = res.ct() if res is not None else _null_tensor()
+        d.res_alpha = self.arena.data_ptr(alpha) if alpha is not None else None
+        d.out = out.ct()
+        d.act = ACT_BY_NAME[act]
+        self._f(self.lib.y6_plan_add_bnact_forward(self.fwd, C.byref(d)), "plan_add_bnact_forward")
+        self.tape.append(lambda: self._bnact_backward(d, branches, out, res, alpha))
+        return out
+
+    def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
+        cts = [t.ct() for t in (x, y1, y2, y3)]
+        self._f(self.lib.y6_plan_add_sppf(self.fwd, *[C.byref(c) for c in cts]), "plan_add_sppf")
+        self.tape.append(lambda: self._sppf_backward(x, y1, y2, y3))
+
+    def convt2x2(self, x: TRef, weight: nn.Parameter, bias: nn.Parameter, out: Optional[TRef] = None) -> TRef:
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        if out is None:
+            out = self.new_buffer(x.B, 2 * x.H, 2 * x.W, Cout)
+        if Cout % 32 != 0:
+            raise NotImplementedError("yolov6_amd: training-form ConvTranspose2d needs Cout % 32 == 0")
+        packed = self._add_pack(self.arena.data_ptr(weight), 2, Cout, Cin, 2)
+        d = _lib.ConvTDesc()
+        d.inp, d.out = x.ct(), out.ct()
+        d.w_packed = _ptr(packed)
+        d.bias = self.arena.data_ptr(bias)
+        self._f(self.lib.y6_plan_add_convt(self.fwd, C.byref(d)), "plan_add_convt")
+        self.fwd_flops += 2.0 * out.B * out.H * out.W * Cout * Cin
+        self.tape.append(lambda: self._convt_backward(x, out, weight, bias))
+        return out
+
+    def head_pack(self, cls: List[TRef], reg: List[TRef], nc: int, nreg: int):
+        B = cls[0].B
+        A = sum(c.H * c.W for c in cls)
+        self.scores = torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
+        self.distri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
+        self.dscores = torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
+        self.ddistri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
+        d = _lib.HeadPackDesc()
+        d.n_levels = len(cls)
+        for i, (c, r) in enumerate(zip(cls, reg)):
+            d.cls[i], d.reg[i] = c.ct(), r.ct()
+        d.scores, d.distri = _ptr(self.scores), _ptr(self.distri)
+        d.nc, d.nreg = nc, nreg
+        self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack")
+
+        def bwd():
+            g = _lib.HeadPackDesc()
+            g.n_levels = len(cls)
+            for i, (c, r) in enumerate(zip(cls, reg)):
+                for t, slot in ((c, g.cls), (r, g.reg)):
+                    rec = t._conv
+                    cp = _rup(t.C, 8)                       # conv inputs need 8-channel views: pad channels stay zero
+                    buf = self.new_buffer(t.B, t.H, t.W, cp, zero=True)
+                    rec.dy, rec.dy_dil, rec.cpad = buf, 1, cp
+                    slot[i] = TRef(buf.buf, t.B, t.H, t.W, t.C, cp, 0).ct()
+            g.scores = _ptr(self.scores)
+            g.dscores, g.ddistri = _ptr(self.dscores), _ptr(self.ddistri)
+            g.nc, g.nreg = nc, nreg
+            self._b(self.lib.y6_plan_add_head_unpack_backward(self.bwd, C.byref(g)), "plan_add_head_unpack_backward")
+        self.tape.append(bwd)
+        return self.scores, self.distri
+
+    # ------------------------------------------------------------------ backward emitters
+    def _bnact_backward(self, fwd_desc, branches, out: TRef, res, alpha):
+        n = len(branches)
+        g = _lib.BnActBwdDesc()
+        g.fwd = fwd_desc
+        gout = self.grad(out)
+        self.grad_ready(gout)
+        g.dout = gout.ct()
+        finals = []
+        for i, (t, st) in enumerate(branches):
+            if st is not None:
+                g.mean[i], g.invstd[i] = st.mean.data_ptr(), st.invstd.data_ptr()
+                bn = st.module
+                if bn.weight is not None:
+                    g.gamma[i] = self.arena.data_ptr(bn.weight).value
+                    g.dgamma[i] = self.arena.grad_ptr(bn.weight).value
+                    finals.append(bn.weight)
+                if bn.bias is not None:
+                    g.dbeta[i] = self.arena.grad_ptr(bn.bias).value
+                    finals.append(bn.bias)
+            rec = getattr(t, "_conv", None)
+            if rec is not None:                      # a conv output: its gradient lives in a private buffer
+                if rec.stride == 2:
+                    xin = rec.x
+                    Hd, Wd = (xin.shape[2], xin.shape[3]) if isinstance(xin, NCHWInput) else (xin.H, xin.W)
+                    if Hd % 2 or Wd % 2:
+                        raise NotImplementedError("yolov6_amd: stride-2 convs need even input sizes in training form")
+                    dy = self.new_buffer(t.B, Hd, Wd, t.C, zero=True)     # zero-inserted: only (2y, 2x) is ever written
+                    rec.dy, rec.dy_dil = dy, 2
+                else:
+                    dy = self.new_buffer(t.B, t.H, t.W, t.C)
+                    rec.dy, rec.dy_dil = dy, 1
+                rec.cpad = t.C
+                g.dx[i] = dy.ct()
+                g.dx_dil[i] = rec.dy_dil
+                g.dx_acc[i] = 0
+            else:                                    # an activation that is also read elsewhere (RepVGG identity, raw branches)
+                gx = self.grad(t)
+                g.dx[i] = gx.ct()
+                g.dx_dil[i] = 1
+                g.dx_acc[i] = self.grad_mode(gx)
+        if res is not None:
+            gr = self.grad(res)
+            g.dres = gr.ct()
+            g.dres_acc = self.grad_mode(gr)
+            if alpha is not None:
+                g.dalpha = self.arena.grad_ptr(alpha).value
+                finals.append(alpha)
+        ws = self.bytes_(int(self.lib.y6_bnact_bwd_workspace_bytes(out.C)))
+        g.workspace, g.workspace_bytes = _ptr(ws), ws.numel()
+        self._b(self.lib.y6_plan_add_bnact_backward(self.bwd, C.byref(g)), "plan_add_bnact_backward")
+        self.bwd_marks.append((self.n_bwd_ops, finals))
+
+    def _transpose(self, view: Optional[TRef], sy, sx, oy, ox, R, Q, Cn, B, nchw_t=None) -> torch.Tensor:
+        """Channel-major sampling dst[c][b][r][q] = src(b, r*sy+oy, q*sx+ox, c) into a private fp16 buffer."""
+        dst = torch.empty(Cn * B * R * Q, dtype=torch.float16, device=self.device)
+        self.keep.append(dst)
+        d = _lib.WgradTDesc()
+        if nchw_t is not None:
+            Bn, Cc, Hn, Wn = nchw_t.shape
+            d.src = _lib.Tensor(C.c_void_p(nchw_t.data_ptr()), Bn, Hn, Wn, Cc, Cc, 0)
+            d.nchw, d.src_dtype = 1, _dtype_tag(nchw_t)
+        else:
+            d.src = view.ct()
+            d.nchw, d.src_dtype = 0, Y6_F16
+        d.sy, d.sx, d.oy, d.ox, d.R, d.Q = sy, sx, oy, ox, R, Q
+        d.dst = dst.data_ptr()
+        self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose")
+        return dst
+
+    def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops):
+        w = _lib.WgradDesc()
+        w.mode = mode
+        w.a = a.data_ptr()
+        w.M, w.N, w.B, w.Q, w.rows, w.a_rows = M, N, B, Q, rows, rows
+        for i, (t, prow, drow) in enumerate(planes):
+            w.plane[i] = t.data_ptr()
+            w.plane_rows[i] = prow
+            w.drow[i] = drow
+        w.out = out_ptr
+        w.sm, w.sn, w.st = N * T, T, 1
+        w.flops = flops
+        self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad")
+        self.bwd_flops += flops
+
+    def _conv_backward(self, rec: ConvRec):
+        """dW (+ db) and dx of one conv, given rec.dy."""
+        x, y, K, s = rec.x, rec.y, rec.k, rec.stride
+        if rec.dy is None:       # consumed directly by something that wrote grad(y)
+            gy = self.grad(y)
+            self.grad_ready(gy)
+            rec.dy, rec.dy_dil, rec.cpad = gy, 1, y.C
+        dy = rec.dy
+        Cout, Cin = rec.weight.shape[0], rec.weight.shape[1]
+        B, Ho, Wo = y.B, y.H, y.W
+        Q = _rup(Wo, 16)
+        is_stem = isinstance(x, NCHWInput)
+        xt = x.t if is_stem else None
+        xv = None if is_stem else x
+        # A operand: dy, channel-major (a dilated gradient is sampled back with stride 2)
+        dyv = TRef(dy.buf, dy.B, dy.H, dy.W, rec.cpad or dy.C, dy.cstride, dy.coff)
+        a = self._transpose(dyv, rec.dy_dil, rec.dy_dil, 0, 0, Ho, Q, dyv.C, B)
+        if s == 1 and K == 3:
+            mode = _lib.WG_3X3S1
+            p = self._transpose(xv, 1, 1, -1, 0, Ho + 2, Q, Cin, B, xt)      # one zero row above and below
+            planes = [(p, Ho + 2, ky) for ky in range(3)]
+        elif s == 1 and K == 1:
+            mode = _lib.WG_1X1
+            planes = [(self._transpose(xv, 1, 1, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
+        elif s == 2 and K == 3:
+            mode = _lib.WG_3X3S2
+            pe = [self._transpose(xv, 2, 2, 0, cp, Ho, Q, Cin, B, xt) for cp in (0, 1)]          # even rows  x[2r][2q+cp]
+            po = [self._transpose(xv, 2, 2, -1, cp, Ho + 1, Q, Cin, B, xt) for cp in (0, 1)]     # odd rows   x[2r-1][2q+cp]
+            planes = []
+            for ky in range(3):
+                for cp in range(2):
+                    planes.append((pe[cp], Ho, 0) if ky == 1 else (po[cp], Ho + 1, 0 if ky == 0 else 1))
+        else:                      # 1x1 stride 2: x[2y, 2x]
+            mode = _lib.WG_1X1
+            planes = [(self._transpose(xv, 2, 2, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
+        self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight),
+                    2.0 * Cout * Cin * K * K * B * Ho * Wo)
+        finals = [rec.weight]
+        if rec.bias is not None:
+            ws = self.bytes_(8 * max(y.C, 1))
+            ct = TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff).ct()
+            self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(rec.bias), _ptr(ws), ws.numel()),
+                    "plan_add_channel_sum")
+            finals.append(rec.bias)
+        # data gradient: the forward conv kernel on the flipped / transposed weights, stride 1 over the (dilated) dy
+        if not is_stem:
+            gx = self.grad(x)
+            acc = self.grad_mode(gx)
+            # padded prediction-conv gradients (68 -> 72 channels): the packed image is zero beyond Cout and the
+            # 32-channel chunk counts of 68 and 72 agree
+            assert (dyv.C + 31) // 32 == (Cout + 31) // 32
+            packed = self._add_pack(self.arena.data_ptr(rec.weight), 1, Cout, Cin, K)
+            self._conv_op(self.bwd, dyv, gx, packed, K, 1, res=gx if acc else None)
+        self.bwd_marks.append((self.n_bwd_ops, finals))
+
+    def _sppf_backward(self, x, y1, y2, y3):
+        d = _lib.SppfBwdDesc()
+        d.x, d.y1, d.y2 = x.ct(), y1.ct(), y2.ct()
+        g1, g2, g3, gx = self.grad(y1), self.grad(y2), self.grad(y3), self.grad(x)
+        for g in (g1, g2, g3, gx):
+            self.grad_ready(g)
+        d.dy1, d.dy2, d.dy3, d.dx = g1.ct(), g2.ct(), g3.ct(), gx.ct()
+        d.dx_acc = 1
+        self._b(self.lib.y6_plan_add_sppf_backward(self.bwd, C.byref(d)), "plan_add_sppf_backward")
+
+    def _convt_backward(self, x: TRef, out: TRef, weight, bias):
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        gout = self.grad(out)
+        self.grad_ready(gout)
+        B, H, W = x.B, x.H, x.W
+        Q = _rup(W, 16)
+        ws = self.bytes_(8 * Cout)
+        ct = gout.ct()
+        self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(bias), _ptr(ws), ws.numel()),
+                "plan_add_channel_sum")
+        a = self._transpose(x, 1, 1, 0, 0, H, Q, Cin, B)
+        planes = [(self._transpose(gout, 2, 2, sub >> 1, sub & 1, H, Q, Cout, B), H, 0) for sub in range(4)]
+        self._wgrad(_lib.WG_CONVT, a, planes, Cin, Cout, B, Q, H, 4, self.arena.grad_ptr(weight), 2.0 * Cin * Cout * 4 * B * H * W)
+        # dx = 1x1 conv over space-to-depth(dout) with W'[ci][sub*Cout + co]
+        s2d = self.new_buffer(B, H, W, 4 * Cout)
+        ca, cb = gout.ct(), s2d.ct()
+        self._b(self.lib.y6_plan_add_space_to_depth2(self.bwd, C.byref(ca), C.byref(cb)), "plan_add_space_to_depth2")
+        gx = self.grad(x)
+        acc = self.grad_mode(gx)
+        packed = self._add_pack(self.arena.data_ptr(weight), 3, Cout, Cin, 2)
+        self._conv_op(self.bwd, s2d, gx, packed, 1, 1, res=gx if acc else None)
+        self.bwd_marks.append((self.n_bwd_ops, [weight, bias]))
+
+    # ------------------------------------------------------------------ finish
+    def finalize(self):
+        """Emit the backward plan from the tape (reverse order) and build the per-step weight-packing table."""
+        for closure in reversed(self.tape):
+            closure()
+        jobs = (_lib.PackJob * len(self.pack_jobs))()
+        first = 0
+        for j, (src, dst, kind, Cout, Cin, K, n) in enumerate(self.pack_jobs):
+            jobs[j].src = src
+            jobs[j].dst = dst.data_ptr()
+            jobs[j].kind, jobs[j].Cout, jobs[j].Cin, jobs[j].K = kind, Cout, Cin, K
+            jobs[j].first = first
+            first += n
+        raw = bytes(jobs)
+        self.jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.keep.append(self.jobs_dev)
+        self.pack = C.c_void_p(self.lib.y6_plan_create())
+        d = _lib.PackBatchDesc()
+        d.jobs, d.njobs, d.total = self.jobs_dev.data_ptr(), len(self.pack_jobs), first
+        _lib.check(self.lib.y6_plan_add_pack_batch(self.pack, C.byref(d)), "plan_add_pack_batch")
+        plans = [Plan(h, self.keep, None, ()) for h in (self.pack, self.fwd, self.bwd)]
+        self.pack = self.fwd = self.bwd = None
+        return plans
+
+
+# ---------------------------------------------------------------------------------------------------- the graph
+class _LazyNCHW(list):
+    """NHWC plan buffers presented as the NCHW tensors the reference returns, converted on first access."""
+
+    def __init__(self, refs, dtype):
+        super().__init__()
+        self._refs, self._dtype = refs, dtype
+
+    def _fill(self):
+        if self._refs is not None:
+            refs, self._refs = self._refs, None
+            for r in refs:
+                super().append(r.to_nhwc_tensor().permute(0, 3, 1, 2).contiguous().to(self._dtype))
+
+    def __len__(self):
+        return len(self._refs) if self._refs is not None else super().__len__()
+
+    def feat_sizes(self):
+        """(H, W) per level without converting anything (ComputeLoss only needs the sizes, loss.py:63-69)."""
+        if self._refs is not None:
+            return [torch.Size((r.H, r.W)) for r in self._refs]
+        return [t.shape[2:] for t in list.__iter__(self)]
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+
+class TrainGraph:
+    """Forward + backward native plans of one model for one input shape."""
+
+    def __init__(self, model, x: torch.Tensor):
+        arena = model.__dict__.get("_y6_arena")
+        if arena is None:
+            arena = model.__dict__["_y6_arena"] = ParamArena(model, x.device)
+        self.arena = arena
+        self.model = model
+        self.input = x.contiguous()
+        tb = TrainBuilder(x.device, arena)
+        stems, necks, scores, distri = model.lower_train(tb, NCHWInput(self.input))
+        self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
+        self.tb = tb
+        self.stem_refs, self.neck_refs = stems, necks
+        self.scores, self.distri = scores, distri
+        self.dscores, self.ddistri = tb.dscores, tb.ddistri
+        self.fwd_flops, self.bwd_flops = tb.fwd_flops, tb.bwd_flops
+        self.bwd_marks = tb.bwd_marks
+        self.n_bwd_ops = self.bwd_plan.num_ops
+        self.anchor = torch.zeros((), dtype=torch.float32, device=x.device, requires_grad=True)
+
+    def forward(self, x):
+        if x.data_ptr() != self.input.data_ptr():
+            self.input.copy_(x)
+        self.pack_plan.run()
+        self.fwd_plan.run()
+        return self.scores, self.distri
+
+    def backward(self, dscores=None, ddistri=None, first=0, last=None):
+        """Run backward ops [first, last) (default: all).  Gradients wrt the head outputs are read from
+        self.dscores / self.ddistri (other tensors are copied in)."""
+        if dscores is not None and dscores.data_ptr() != self.dscores.data_ptr():
+            self.dscores.copy_(dscores)
+        if ddistri is not None and ddistri.data_ptr() != self.ddistri.data_ptr():
+            self.ddistri.copy_(ddistri)
+        if first == 0:
+            p0 = self.arena.params[0]
+            if p0.grad is None:                 # optimizer.zero_grad(set_to_none=True): same as zeroing
+                self.arena.zero_grad()
+                self.arena.reattach()
+        self.bwd_plan.run_range(first, self.n_bwd_ops if last is None else last)
+
+
+class _TrainStepFn(torch.autograd.Function):
+    """Autograd bridge: `loss.backward()` reaches the native backward plan through this node.  Parameter gradients are
+    accumulated by the kernels straight into `p.grad` (arena views); nothing flows back through autograd."""
+
+    @staticmethod
+    def forward(ctx, graph, x, anchor):
+        ctx.graph = graph
+        scores, distri = graph.forward(x)
+        return scores.view_as(scores), distri.view_as(distri)
+
+    @staticmethod
+    def backward(ctx, dscores, ddistri):
+        g = ctx.graph
+        if dscores is None:
+            dscores = torch.zeros_like(g.scores)
+        if ddistri is None:
+            ddistri = torch.zeros_like(g.distri)
+        hook = g.model.__dict__.get("_y6_backward_hook")
+        if hook is not None:
+            hook(g, dscores.contiguous(), ddistri.contiguous())      # e.g. DataParallel: segmented backward + all-reduce
+        else:
+            g.backward(dscores.contiguous(), ddistri.contiguous())
+        return None, None, None
+
+
+def train_forward(model, x):
+    """Model.forward in training mode (reference yolov6/models/yolo.py:33-41 with Detect's training branch):
+    returns [(head stem features, cls_scores [B,A,nc], reg_distri [B,A,nreg]), neck feature maps]."""
+    key = (tuple(x.shape), x.dtype, x.device)
+    graphs = model.__dict__.setdefault("_y6_train_graphs", {})
+    g = graphs.get(key)
+    if g is None:
+        graphs.clear()
+        g = graphs[key] = TrainGraph(model, x)
+    if torch.is_grad_enabled():
+        scores, distri = _TrainStepFn.apply(g, x, g.anchor)
+    else:
+        scores, distri = g.forward(x)
+    for t in (scores, distri):
+        t._y6_graph = g                      # lets ComputeLoss write its gradients straight into the graph's buffers
+    return [(_LazyNCHW(g.stem_refs, x.dtype), scores, distri), _LazyNCHW(g.neck_refs, x.dtype)]
