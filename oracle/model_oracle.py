@@ -78,6 +78,13 @@ class Oracle:
     def q(self, t):
         return t.half().float() if self.fp16 else t
 
+    # hooks of the training oracle (identity here): conv / block-output rounding of an AMP-style fp16 pipeline
+    def c2d(self, x, w, b=None, **kw):
+        return F.conv2d(x, w, b, **kw)
+
+    def r16(self, t):
+        return t
+
     @staticmethod
     def act(x, kind):
         if kind == "relu":
@@ -162,20 +169,20 @@ class Oracle:
     def repvgg_train_form(self, x, p, stride):
         """Eval forward of the un-fused multi-branch block (common.py:250-255, :341-347, :416-426)."""
         sd = self.sd
-        d = self.bn(F.conv2d(x, sd[p + ".rbr_dense.conv.weight"], None, stride=stride, padding=1), p + ".rbr_dense.bn")
+        d = self.bn(self.c2d(x, sd[p + ".rbr_dense.conv.weight"], None, stride=stride, padding=1), p + ".rbr_dense.bn")
         cin, cout = sd[p + ".rbr_dense.conv.weight"].shape[1], sd[p + ".rbr_dense.conv.weight"].shape[0]
         has_id = cin == cout and stride == 1
         if self.a.mode.startswith("qarepvgg"):
-            y = d + F.conv2d(x, sd[p + ".rbr_1x1.weight"], None, stride=stride)
+            y = d + self.c2d(x, sd[p + ".rbr_1x1.weight"], None, stride=stride)
             if has_id:
                 y = y + x
                 if self.a.mode == "qarepvggv2":
                     y = y + F.avg_pool2d(x, 3, stride, 1)
-            return F.relu(self.bn(y, p + ".bn"))
-        y = d + self.bn(F.conv2d(x, sd[p + ".rbr_1x1.conv.weight"], None, stride=stride), p + ".rbr_1x1.bn")
+            return self.r16(F.relu(self.bn(y, p + ".bn")))
+        y = d + self.bn(self.c2d(x, sd[p + ".rbr_1x1.conv.weight"], None, stride=stride), p + ".rbr_1x1.bn")
         if has_id:
             y = y + self.bn(x, p + ".rbr_identity")
-        return F.relu(y)
+        return self.r16(F.relu(y))
 
     def block(self, x, p, stride=1):
         """`block = get_block(training_mode)` (common.py:721-737): RepVGG family or plain ConvBN{ReLU,SiLU}."""
@@ -401,10 +408,27 @@ class TrainOracle(Oracle):
     the step (unbiased variance in the running estimate, biased in the normalisation - torch semantics)."""
     BN_MOMENTUM = 0.03
 
-    def __init__(self, cfg, sd, num_classes=80):
+    def __init__(self, cfg, sd, num_classes=80, amp_fp16=False):
+        """amp_fp16=True: conv outputs and block outputs are rounded to fp16 (weights too, as autocast casts them), with a
+        straight-through gradient - the noise floor of ANY fp16-activation training pipeline (the reference under
+        torch.cuda.amp, this package's HIP path) relative to the fp32 graph.  Used to put measured deviations in scale."""
         super().__init__(cfg, sd, num_classes, emulate_fp16=False)
         self.train_form = True
         self.new_stats = {}
+        self.amp = amp_fp16
+
+    def r16(self, t):
+        return t + (t.half().float() - t).detach() if self.amp else t
+
+    def c2d(self, x, w, b=None, **kw):
+        if not self.amp:
+            return F.conv2d(x, w, b, **kw)
+        return self.r16(F.conv2d(x, self.r16(w), None if b is None else self.r16(b), **kw))
+
+    def transpose(self, x, p):
+        y = F.conv_transpose2d(x, self.r16(self.sd[p + ".upsample_transpose.weight"]), self.r16(self.sd[p + ".upsample_transpose.bias"]),
+                               stride=2)
+        return self.r16(y)
 
     def bn(self, x, p):
         sd = self.sd
@@ -420,10 +444,10 @@ class TrainOracle(Oracle):
     def convbn(self, x, p, act, stride=1):
         sd = self.sd
         w = sd[p + ".block.conv.weight"]
-        y = F.conv2d(x, w, sd.get(p + ".block.conv.bias"), stride=stride, padding=w.shape[-1] // 2)
+        y = self.c2d(x, w, sd.get(p + ".block.conv.bias"), stride=stride, padding=w.shape[-1] // 2)
         if p + ".block.bn.weight" in sd:
             y = self.bn(y, p + ".block.bn")
-        return self.act(y, act)
+        return self.r16(self.act(y, act))
 
     def block(self, x, p, stride=1):
         mode = self.a.mode
@@ -438,8 +462,8 @@ class TrainOracle(Oracle):
             f = self.convbn(x, f"detect.stems.{i}", "silu")
             c = self.convbn(f, f"detect.cls_convs.{i}", "silu")
             r = self.convbn(f, f"detect.reg_convs.{i}", "silu")
-            co = F.conv2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])
-            ro = F.conv2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"])
+            co = self.c2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])
+            ro = self.c2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"])
             xs.append(f)
             cls_l.append(torch.sigmoid(co).flatten(2).permute(0, 2, 1))
             reg_l.append(ro.flatten(2).permute(0, 2, 1))

@@ -264,7 +264,7 @@ def test_bnact_forward_backward_vs_autograd(act, with_res, dil):
         got = _back(dxs[i])
         if i == 0 and dil == 2:
             full = got
-            got = full[:, :, ::2, ::2]
+            got = full[:, :, ::2, ::2].clone()
             full[:, :, ::2, ::2] = 0
             assert float(full.abs().max()) == 0.0           # nothing but the (2y, 2x) positions is written
         if i == 2:
@@ -411,25 +411,46 @@ def _tiny_train_model(case):
     return cfg, meta, sd, model
 
 
-@pytest.mark.parametrize("case", ["tiny"])
-def test_training_graph_forward_backward_vs_oracle(case):
-    """Whole model, train form: head outputs, BatchNorm running statistics and EVERY parameter gradient vs TrainOracle
-    (fp32 CPU autograd, pinned to the reference's goldens), for the scalar the reference goldens back-propagate."""
-    from oracle import synth
+def _oracle_run(cfg, sd, nc, x, amp):
+    """TrainOracle forward + backward of the goldens' scalar; returns (scalar, cls, reg, stems, {param: grad}, new_stats)."""
     from oracle.model_oracle import TrainOracle
-    cfg, meta, sd, model = _tiny_train_model(case)
-    gold = np.load(os.path.join(GOLDEN, f"train_{case}.npz"))
-    x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
-    # ---- oracle
     params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
-    osd = dict(sd)
-    osd.update(params)
-    orc = TrainOracle(cfg, osd, meta["num_classes"])
+    orc = TrainOracle(cfg, sd, nc, amp_fp16=amp)
     orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
-    (xs, cls_o, reg_o), feats_o = orc.forward_train(x)
-    scalar_o = (cls_o * cls_o).sum() + reg_o.square().mean()
-    scalar_o.backward()
-    np.testing.assert_allclose(float(scalar_o), float(gold["scalar"]), rtol=1e-4)     # the oracle run IS the golden run
+    (xs, cls_o, reg_o), _ = orc.forward_train(x)
+    scalar = (cls_o * cls_o).sum() + reg_o.square().mean()
+    scalar.backward()
+    grads = {k: p.grad.detach() for k, p in params.items() if p.grad is not None}
+    return float(scalar), cls_o.detach(), reg_o.detach(), [t.detach() for t in xs], grads, orc.new_stats
+
+
+def _rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+@pytest.mark.parametrize("case,size,batch", [("tiny", 64, 2), ("tiny", 192, 4)])
+def test_training_graph_forward_backward_vs_oracle(case, size, batch):
+    """Whole model, train form: head outputs, BatchNorm running statistics and EVERY parameter gradient.
+
+    Reference point: TrainOracle in fp32 (CPU autograd; at the golden size it IS the run that produced the reference's
+    goldens: scalar, outputs, running statistics and three reference gradients are pinned by tests/test_oracle_cpu.py).
+    fp16 activations put any AMP-style pipeline a few 1e-2 away from the fp32 graph on this random-weight network (batch
+    statistics re-normalise every layer, so rounding noise is not damped); the bar is therefore stated against the noise
+    floor measured with the same oracle run with fp16-rounded activations (`amp_fp16=True`, straight-through gradients):
+        err(HIP, fp32 oracle) <= 2 x err(fp16-activation oracle, fp32 oracle) + 2e-3      (relative L2 per tensor)
+    A wiring error (missing branch, wrong accumulation, flipped kernel) shows up as an O(0.3 ... 1) deviation."""
+    from oracle import synth
+    cfg, meta, sd, model = _tiny_train_model(case)
+    nc = meta["num_classes"]
+    x = synth.synth_images(batch, size, seed=21)
+    xh = x.half().float()
+    sc32, cls32, reg32, xs32, g32, stats32 = _oracle_run(cfg, sd, nc, xh, amp=False)
+    sc16, cls16, reg16, xs16, g16, stats16 = _oracle_run(cfg, sd, nc, xh, amp=True)
+    if size == 64 and batch == 2:
+        gold = np.load(os.path.join(GOLDEN, f"train_{case}.npz"))
+        sc_g, *_ = _oracle_run(cfg, sd, nc, x, amp=False)
+        np.testing.assert_allclose(sc_g, float(gold["scalar"]), rtol=1e-4)        # the oracle run IS the golden run
     # ---- HIP
     model = model.to(DEV).train()
     out, featmaps = model(x.to(DEV).half())
@@ -438,39 +459,163 @@ def test_training_graph_forward_backward_vs_oracle(case):
     scalar = (scores * scores).sum() + distri.square().mean()
     (scalar * S).backward()
     torch.cuda.synchronize()
-    assert float((scores.detach().cpu() - cls_o.detach()).abs().max()) < 5e-3
-    assert float((distri.detach().cpu() - reg_o.detach()).abs().max()) < 2e-2 * max(1.0, float(reg_o.abs().max()))
-    np.testing.assert_allclose(float(scalar), float(scalar_o), rtol=5e-3)
-    for f, r in zip(list(stems), xs):
+    rep = dict(case=case, size=size, batch=batch)
+    for name, got, r32, r16 in (("cls_scores", scores.detach().cpu(), cls32, cls16), ("reg_distri", distri.detach().cpu(), reg32, reg16)):
+        e_hip, e_ref = _rel_l2(got, r32), _rel_l2(r16, r32)
+        rep[name] = dict(hip=e_hip, fp16_floor=e_ref)
+        assert e_hip <= 2 * e_ref + 2e-3, f"{name}: HIP {e_hip:.3e} vs fp16 noise floor {e_ref:.3e}"
+    for f, r in zip(list(stems), xs32):
         assert f.shape == r.shape
     # running statistics after one step (momentum 0.03, unbiased variance)
     msd = model.state_dict()
-    for k in gold.files:
-        if k.endswith("running_mean") or k.endswith("running_var"):
-            assert float(np.abs(msd[k].cpu().numpy() - gold[k]).max()) < 3e-3 * max(1.0, float(np.abs(gold[k]).max())), k
-    assert int(msd["backbone.stem.rbr_dense.bn.num_batches_tracked"]) == int(sd["backbone.stem.rbr_dense.bn.num_batches_tracked"]) + 1
+    worst_stat = floor_stat = 0.0
+    for p, (rm, rv) in stats32.items():
+        for j, (key, ref) in enumerate(((p + ".running_mean", rm), (p + ".running_var", rv))):
+            den = max(1.0, float(ref.abs().max()))
+            worst_stat = max(worst_stat, float((msd[key].cpu() - ref.detach()).abs().max()) / den)
+            floor_stat = max(floor_stat, float((stats16[p][j].detach() - ref.detach()).abs().max()) / den)
+    rep["running_stats_worst"] = dict(hip=worst_stat, fp16_floor=floor_stat)
+    assert worst_stat < 2 * floor_stat + 1e-3, f"running statistics deviate by {worst_stat:.3e} (fp16 floor {floor_stat:.3e})"
+    k0 = "backbone.stem.rbr_dense.bn.num_batches_tracked"
+    assert int(msd[k0]) == int(sd[k0]) + 1
     # every parameter gradient
     named = dict(model.named_parameters())
-    report, worst = {}, ("", 0.0)
-    for k, p in params.items():
-        if p.grad is None or k == "detect.proj" or k.startswith("detect.proj_conv"):
+    errs, floors, bad = {}, {}, []
+    for k, ref in g32.items():
+        if k == "detect.proj" or k.startswith("detect.proj_conv") or float(ref.norm()) == 0.0:
             continue
         got = named[k].grad.detach().float().cpu() / S
-        ref = p.grad
-        scale = max(float(ref.abs().max()), 1e-8)
-        err = float((got - ref).abs().max()) / scale
-        report[k] = err
+        errs[k], floors[k] = _rel_l2(got, ref), _rel_l2(g16[k], ref)
+        if floors[k] > 1.0:
+            # the fp32 value is rounding noise around a mathematically zero gradient (a ConvTranspose bias in front of a
+            # 1x1 conv + BatchNorm: the batch mean removes it exactly) - nothing to compare
+            del errs[k], floors[k]
+            continue
+        if errs[k] > 2 * floors[k] + 2e-3:
+            bad.append((k, errs[k], floors[k]))
+    worst = max(errs, key=errs.get)
+    rep.update(n_params=len(errs), grad_worst=dict(name=worst, hip=errs[worst], fp16_floor=floors[worst]),
+               grad_median=dict(hip=float(np.median([v for v in errs.values() if v == v])),
+                                fp16_floor=float(np.median([v for v in floors.values() if v == v]))))
+    out_dir = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"train_grad_report_{case}_{size}_b{batch}.json"), "w") as f:
+        json.dump(dict(summary=rep, errs=errs, floors=floors), f, indent=1)
+    print(json.dumps(rep))
+    assert not bad, f"{len(bad)} parameter gradients above twice the fp16 noise floor, e.g. {bad[:5]}"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Block-level training graphs: the wiring of every block type (branches, accumulation, dilation, concat slices,
+# flipped / transposed weight images) against torch autograd of the oracle's functional statement.  A block is only a few
+# layers deep, so fp16 storage keeps everything within ~1e-2 of fp32 and a wiring error cannot hide in rounding noise.
+def _block_case(kind):
+    from yolov6_amd.layers import common as L
+    if kind == "repvgg_s1":
+        return L.RepVGGBlock(32, 32), [(2, 32, 12, 20)], lambda o, xs: o.block(xs[0], "m", 1), "repvgg"
+    if kind == "repvgg_s2":
+        return L.RepVGGBlock(16, 32, stride=2), [(2, 16, 12, 20)], lambda o, xs: o.block(xs[0], "m", 2), "repvgg"
+    if kind == "repvgg_widen":
+        return L.RepVGGBlock(16, 48), [(3, 16, 9, 11)], lambda o, xs: o.block(xs[0], "m", 1), "repvgg"
+    if kind == "convbnsilu3":
+        return L.ConvBNSiLU(24, 40, 3, 1), [(2, 24, 10, 10)], lambda o, xs: o.convbn(xs[0], "m", "silu"), "repvgg"
+    if kind == "convbnrelu1":
+        return L.ConvBNReLU(64, 24, 1, 1), [(2, 64, 7, 9)], lambda o, xs: o.convbn(xs[0], "m", "relu"), "repvgg"
+    if kind == "convbnrelu3s2":
+        return L.ConvBNReLU(16, 16, 3, 2), [(2, 16, 8, 12)], lambda o, xs: o.convbn(xs[0], "m", "relu", stride=2), "repvgg"
+    if kind == "repblock":
+        return L.RepBlock(16, 32, n=3), [(2, 16, 10, 14)], lambda o, xs: o.repblock(xs[0], "m", 3), "repvgg"
+    if kind == "simsppf":
+        return L.SimSPPF(32, 32), [(2, 32, 9, 9)], lambda o, xs: o.sppf(xs[0], "m.sppf", "relu"), "repvgg"
+    if kind == "simcspsppf":
+        return L.SimCSPSPPF(32, 32), [(2, 32, 8, 8)], lambda o, xs: o.cspsppf(xs[0], "m.cspsppf", "relu"), "repvgg"
+    if kind == "transpose":
+        return L.Transpose(32, 32), [(2, 32, 5, 7)], lambda o, xs: o.transpose(xs[0], "m"), "repvgg"
+    if kind == "bifusion":
+        return (L.BiFusion([32, 16], 16), [(2, 16, 4, 6), (2, 32, 8, 12), (2, 16, 16, 24)],
+                lambda o, xs: o.bifusion(xs, "m"), "repvgg")
+    if kind == "bottlerep":
+        return L.BottleRep(16, 16, basic_block=L.RepVGGBlock, weight=True), [(2, 16, 8, 8)], lambda o, xs: o.bottlerep(xs[0], "m"), "repvgg"
+    if kind == "bepc3":
+        return L.BepC3(32, 32, n=2, block=L.RepVGGBlock), [(2, 32, 8, 8)], lambda o, xs: o.bepc3(xs[0], "m", 2), "repvgg"
+    if kind == "bepc3_silu":
+        return L.BepC3(32, 32, n=2, block=L.ConvBNSiLU), [(2, 32, 8, 8)], lambda o, xs: o.bepc3(xs[0], "m", 2), "conv_silu"
+    raise KeyError(kind)
+
+
+BLOCKS = ["repvgg_s1", "repvgg_s2", "repvgg_widen", "convbnsilu3", "convbnrelu1", "convbnrelu3s2", "repblock", "simsppf", "simcspsppf",
+          "transpose", "bifusion", "bottlerep", "bepc3", "bepc3_silu"]
+
+
+@pytest.mark.parametrize("kind", BLOCKS)
+def test_block_training_graph_vs_autograd(kind):
+    from oracle import synth
+    from oracle.model_oracle import TrainOracle
+    from yolov6_amd.configs import tiny_config
+    from yolov6_amd.train_engine import ModuleTrainGraph
+    from yolov6_amd.utils.torch_utils import initialize_weights
+    torch.manual_seed(0)
+    module, shapes, fn, mode = _block_case(kind)
+    initialize_weights(module)                       # eps 1e-3, momentum 0.03 as in the model
+    sd_m = synth.synth_state_dict(module.state_dict(), seed=4)
+    if "alpha" in sd_m:
+        sd_m["alpha"] = torch.tensor([0.8])
+    module.load_state_dict(sd_m)
+    g = torch.Generator().manual_seed(1)
+    xs = [(torch.randn(s, generator=g)).half().float() for s in shapes]
+    # ---- torch autograd of the oracle statement (fp32)
+    cfg = tiny_config()
+    cfg["training_mode"] = mode
+    sd = {"m." + k: v for k, v in sd_m.items()}
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    orc = TrainOracle(cfg, sd, 80)
+    orc.a.mode = mode
+    orc.a.silu_body = mode == "conv_silu"
+    orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+    xv = [x.clone().requires_grad_(True) for x in xs]
+    out_ref = fn(orc, xv)
+    dout = torch.randn(out_ref.shape, generator=g).half().float()
+    out_ref.backward(dout)
+    # the same statement with fp16-rounded activations (straight-through): the noise floor of an fp16 pipeline.  ReLU masks
+    # and max-pool winners that flip under rounding re-route gradient, which dominates cancelling sums (BN biases).
+    p16 = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    o16 = TrainOracle(cfg, sd, 80, amp_fp16=True)
+    o16.a.mode, o16.a.silu_body = mode, mode == "conv_silu"
+    o16.sd = {k: (p16[k] if k in p16 else v.float()) for k, v in sd.items()}
+    x16 = [x.clone().requires_grad_(True) for x in xs]
+    fn(o16, x16).backward(dout)
+    # ---- HIP
+    module = module.to(DEV).train()
+    graph = ModuleTrainGraph(module, [x.to(DEV).half() for x in xs])
+    out = graph.forward()[0]
+    dxs = graph.backward([dout.to(DEV)])
+    torch.cuda.synchronize()
+    e_out = _rel_l2(out.cpu(), out_ref.detach())
+    assert e_out < 5e-3, f"{kind}: forward deviates by {e_out:.3e}"
+    named = dict(module.named_parameters())
+    worst = ("", 0.0, 0.0)
+    bad = []
+
+    def judge(name, got, ref, ref16):
+        nonlocal worst
+        floor = _rel_l2(ref16, ref)
+        if floor > 1.0:
+            return                                    # mathematically zero gradient (a bias in front of conv + BatchNorm)
+        err = _rel_l2(got, ref)
         if err > worst[1]:
-            worst = (k, err)
-    os.makedirs(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", f"train_grad_report_{case}.json"), "w") as f:
-        json.dump(dict(worst=worst, errs=report), f, indent=1)
-    print(f"{case}: {len(report)} parameter gradients, worst {worst[0]} {worst[1]:.3e}, median {float(np.median(list(report.values()))):.3e}")
-    # the reference's own gradient goldens (three probes at different depths)
-    for k in gold.files:
-        if k.startswith("grad:"):
-            name = k[5:]
-            got = named[name].grad.detach().float().cpu().numpy() / S
-            scale = max(float(np.abs(gold[k]).max()), 1e-8)
-            assert float(np.abs(got - gold[k]).max()) / scale < 3e-2, name
-    assert worst[1] < 3e-2, f"worst parameter gradient {worst}"
+            worst = (name, err, floor)
+        if err > 3 * floor + 3e-3:
+            bad.append((name, err, floor))
+    for k, p in params.items():
+        if p.grad is not None:
+            judge(k, named[k[2:]].grad.detach().float().cpu(), p.grad, p16[k].grad)
+    for i, (dx, xr, xr16) in enumerate(zip(dxs, xv, x16)):
+        assert dx is not None, f"{kind}: no gradient reached input {i}"
+        judge(f"dx{i}", dx.cpu(), xr.grad, xr16.grad)
+    # running statistics
+    msd = module.state_dict()
+    for p_, (rm, rv) in orc.new_stats.items():
+        assert float((msd[p_[2:] + ".running_mean"].cpu() - rm.detach()).abs().max()) < 3e-3 * max(1.0, float(rm.abs().max()))
+        assert float((msd[p_[2:] + ".running_var"].cpu() - rv.detach()).abs().max()) < 3e-3 * max(1.0, float(rv.abs().max()))
+    print(f"{kind}: forward {e_out:.2e}, worst gradient {worst[0]} {worst[1]:.2e} (fp16 floor {worst[2]:.2e})")
+    assert not bad, f"{kind}: gradients above 3x the fp16 noise floor: {bad[:4]}"

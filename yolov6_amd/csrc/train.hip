@@ -572,6 +572,20 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
             continue;
         }
         const int K = jb.K, NT = K * K;
+        if (jb.kind == 2 && (jb.Cout % 32) != 0) {    // un-fused ConvTranspose2d image: four separately padded 1x1 weights
+            const int nchunk2 = (jb.Cin + 31) / 32;
+            const uint64_t per = (uint64_t)((((jb.Cout + 31) / 32 + 3) / 4) * 4) * nchunk2 * 1024;
+            const int sub = (int)(e / per);
+            const uint64_t ii = e - (uint64_t)sub * per;
+            const int j2 = (int)(ii & 7), lane2 = (int)((ii >> 3) & 63), ks2 = (int)((ii >> 9) & 1);
+            const uint64_t r2 = ii >> 10;
+            const int chunk2 = (int)(r2 % nchunk2), cfr2 = (int)(r2 / nchunk2);
+            const int co = cfr2 * 32 + (lane2 & 31), ci = chunk2 * 32 + ks2 * 16 + (lane2 >> 5) * 8 + j2;
+            float v2 = 0.f;
+            if (co < jb.Cout && ci < jb.Cin) v2 = jb.src[((size_t)ci * jb.Cout + co) * 4 + sub];
+            reinterpret_cast<__half*>(jb.dst)[e] = __float2half(v2);
+            continue;
+        }
         // logical output-channel / input-channel counts of the packed matrix
         int O = jb.Cout, I = jb.Cin;
         if (jb.kind == 1) { O = jb.Cin; I = jb.Cout; }
@@ -1026,6 +1040,7 @@ extern "C" int y6_wgrad_transpose(const y6_wgrad_t_desc* d, void* stream) {
 }
 extern "C" size_t y6_pack_job_elems(int kind, int Cout, int Cin, int K) {
     if (kind == 4) return (size_t)Cout * Cin * 9;
+    if (kind == 2 && (Cout % 32) != 0) return (size_t)4 * (y6_cdiv(y6_cdiv(Cout, 32), 4) * 4) * y6_cdiv(Cin, 32) * 1024;
     int O = Cout, I = Cin, nt = K * K;
     if (kind == 1) { O = Cin; I = Cout; }
     if (kind == 2) { O = 4 * Cout; I = Cin; nt = 1; }

@@ -38,10 +38,15 @@ class _PyramidBackbone(HipModule):
 
     def lower(self, pb, x, out=None):
         outs = []
+        trace = getattr(pb, "trace", None)      # optional {name: activation view}, filled for tools/train_trace.py
         x = self.stem.lower(pb, x)
+        if trace is not None:
+            trace["backbone.stem"] = x
         for k in range(2, self.last + 1):
-            for layer in getattr(self, f"ERBlock_{k}"):
+            for i, layer in enumerate(getattr(self, f"ERBlock_{k}")):
                 x = layer.lower(pb, x)
+                if trace is not None:
+                    trace[f"backbone.ERBlock_{k}.{i}"] = x
             if k >= self._first_out():
                 outs.append(x)
         return tuple(outs)

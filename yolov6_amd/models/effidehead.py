@@ -58,6 +58,8 @@ class Detect(HipModule):
             cp, rp = self.cls_preds[i], self.reg_preds[i]
             cls_out.append(tb.conv(c, cp.weight, 1, bias=cp.bias))
             reg_out.append(tb.conv(r, rp.weight, 1, bias=rp.bias))
+            tb.trace.update({f"detect.stem{i}": f, f"detect.cls_conv{i}": c, f"detect.reg_conv{i}": r,
+                             f"detect.cls_logit{i}": cls_out[-1], f"detect.reg_raw{i}": reg_out[-1]})
         scores, distri = tb.head_pack(cls_out, reg_out, self.nc, self.reg_preds[0].out_channels)
         return stems, scores, distri
 

@@ -132,6 +132,7 @@ class TrainBuilder:
         self.bwd_flops = 0.0
         self.n_fwd_ops = 0
         self.n_bwd_ops = 0
+        self.trace = {}              # name -> activation view (filled by the composite modules; tools/train_trace.py)
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -153,6 +154,15 @@ class TrainBuilder:
         if isinstance(x, TRef):
             return x
         raise RuntimeError("yolov6_amd: in training form only the stem reads the caller's NCHW tensor")
+
+    def input(self, t: torch.Tensor) -> TRef:
+        """An NCHW tensor entering the graph as an NHWC fp16 activation (block-level graphs: ModuleTrainGraph)."""
+        B, C_, H, W = t.shape
+        out = self.new_buffer(B, H, W, C_)
+        ct = out.ct()
+        self._f(self.lib.y6_plan_add_nchw2nhwc(self.fwd, C.c_void_p(t.data_ptr()), _dtype_tag(t), C.byref(ct)), "plan_add_nchw2nhwc")
+        self.inputs.append(t)
+        return out
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def grad(self, t: TRef) -> TRef:
@@ -330,8 +340,6 @@ class TrainBuilder:
         Cin, Cout = weight.shape[0], weight.shape[1]
         if out is None:
             out = self.new_buffer(x.B, 2 * x.H, 2 * x.W, Cout)
-        if Cout % 32 != 0:
-            raise NotImplementedError("yolov6_amd: training-form ConvTranspose2d needs Cout % 32 == 0")
         packed = self._add_pack(self.arena.data_ptr(weight), 2, Cout, Cin, 2)
         d = _lib.ConvTDesc()
         d.inp, d.out = x.ct(), out.ct()
@@ -646,6 +654,42 @@ class TrainGraph:
                 self.arena.zero_grad()
                 self.arena.reattach()
         self.bwd_plan.run_range(first, self.n_bwd_ops if last is None else last)
+
+
+class ModuleTrainGraph:
+    """Training graph of ONE block (any HipModule) on NCHW inputs: forward, then backward from caller-supplied output
+    gradients.  Test harness for the wiring of every block type against autograd (tests/test_gpu_training.py); the model
+    path is TrainGraph."""
+
+    def __init__(self, module, inputs):
+        self.arena = ParamArena(module, inputs[0].device)
+        tb = TrainBuilder(inputs[0].device, self.arena)
+        self.inputs = [t.contiguous() for t in inputs]
+        self.in_refs = [tb.input(t) for t in self.inputs]
+        outs = module.lower(tb, self.in_refs[0] if len(self.in_refs) == 1 else list(self.in_refs))
+        self.out_refs = [outs] if isinstance(outs, TRef) else list(outs)
+        self.dout_refs = []
+        for o in self.out_refs:
+            g = tb.grad(o)
+            tb.grad_mode(g)                   # written by the caller (set_output_grads) before the backward plan runs
+            self.dout_refs.append(g)
+        self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
+        self.tb = tb
+
+    def forward(self):
+        self.pack_plan.run()
+        self.fwd_plan.run()
+        return [r.to_nhwc_tensor().permute(0, 3, 1, 2).float() for r in self.out_refs]
+
+    def backward(self, douts):
+        for g, d in zip(self.dout_refs, douts):
+            g.to_nhwc_tensor().copy_(d.permute(0, 2, 3, 1).to(torch.float16))
+        self.bwd_plan.run()
+        res = []
+        for r in self.in_refs:
+            g = self.tb.grad(r)
+            res.append(g.to_nhwc_tensor().permute(0, 3, 1, 2).float() if self.tb.gspans.get(g.buf.data_ptr()) else None)
+        return res
 
 
 class _TrainStepFn(torch.autograd.Function):
