@@ -383,34 +383,39 @@ typedef struct y6_bnact_bwd_desc {
 size_t y6_bnact_bwd_workspace_bytes(int C);
 int y6_bnact_backward(const y6_bnact_bwd_desc* d, void* stream);
 
-/* Channel-major ("transposed") sampling of an activation for the weight-gradient GEMM:
- *   dst[c][b][r][q] = src(b, r*sy + oy, q*sx + ox, c)   (0 outside the image),  r < R, q < Q (Q % 16 == 0)
+/* Pixel-run-major ("transposed") sampling of an activation for the weight-gradient GEMM:
+ *   dst[b][r][q/8][c][q%8] = src(b, r*sy + oy, q*sx + ox, c)   (0 outside the image),  r < R, q < Q (Q % 16 == 0)
+ * - 8 consecutive columns of a channel are one 16-byte MFMA operand, the operands of consecutive channels are contiguous.
  * src: an NHWC fp16 view, or (nchw != 0) the caller's NCHW image tensor (fp16 / fp32) - the stem's input. */
 typedef struct y6_wgrad_t_desc {
     y6_tensor src;                 /* NHWC view; for nchw: data = NCHW base, C/H/W/B filled, cstride/coff ignored */
     int32_t nchw, src_dtype;       /* src_dtype: Y6_F16 / Y6_F32 (nchw only) */
     int32_t sy, sx, oy, ox, R, Q;
-    void* dst;                     /* fp16 [C][B][R][Q] */
+    void* dst;                     /* fp16 [B][R][Q/8][C][8] */
 } y6_wgrad_t_desc;
 int y6_wgrad_transpose(const y6_wgrad_t_desc* d, void* stream);
 
 /* Weight gradient as a tap-table GEMM over pixels on the matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate):
- *   out[m*sm + n*sn + t*st] += sum_{b, y<rows, q<Q} A[m][b][y][q] * P_t[n][b][y + drow_t][q + shift_t]
+ *   out[m*sm + n*sn + t*st] += sum_{b, y<rows, q<Q} A(m; b, y, q) * P_t(n; b, y + drow_t, q + shift_t)
  * A and the planes P are y6_wgrad_transpose outputs (q contiguous: both operands are read straight from memory as MFMA
- * fragments, the +-1 column shifts are built in registers).  Replaces the weight half of autograd's conv backward for
+ * fragments, the +-1 column shifts are built in registers; slices of the pixel range are summed by a second small kernel,
+ * deterministically, without atomics).  Replaces the weight half of autograd's conv backward for
  *   3x3 s1 (mode 0: one plane with a zero row above/below, 9 taps), 1x1 (mode 1), 3x3 s2 (mode 2: four row/column parity
  *   planes), ConvTranspose2d k2 s2 (mode 3: A = input, planes = the four parities of dout).                          */
 enum { Y6_WG_3X3S1 = 0, Y6_WG_1X1 = 1, Y6_WG_3X3S2 = 2, Y6_WG_CONVT = 3 };
 typedef struct y6_wgrad_desc {
     int32_t mode;
-    const void* a;                 /* [M][B][a_rows][Q] */
+    const void* a;                 /* y6_wgrad_transpose output with a_channels channels, a_rows rows */
     int32_t M, N, B, Q, rows, a_rows;
-    const void* plane[6];          /* per stream (mode table in wgrad.hip): [N][B][plane_rows[s]][Q] */
+    int32_t a_channels, plane_channels;   /* channels the A plane / the B planes were transposed with (>= M / N) */
+    const void* plane[6];          /* per stream (mode table in wgrad.hip): y6_wgrad_transpose outputs with plane_rows[s] rows */
     int32_t plane_rows[6];
     int32_t drow[6];
     float* out;
     int32_t sm, sn, st;            /* element strides of the output (OIHW: sm = N*T, sn = T, st = 1) */
     double flops;                  /* algorithmic FLOPs (2*M*N*T*B*Ho*Wo), for the timing table */
+    void* workspace;               /* partial sums of the (image,row) slices: >= T*M*N*4 bytes, more allows more slices */
+    size_t workspace_bytes;        /* (ops on one stream may share one workspace)                                       */
 } y6_wgrad_desc;
 int y6_wgrad(const y6_wgrad_desc* d, void* stream);
 
@@ -492,6 +497,12 @@ int y6_loss_backward(const y6_loss_grad_desc* d, void* stream);
 int y6_grad_finite_check(const float* grad, size_t n, int32_t* found_inf, void* stream);
 int y6_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, float weight_decay,
                 int nesterov, int first_step, const float* scale, const int32_t* found_inf, void* stream);
+/* the same step over an arena that mixes the reference's three parameter groups (yolov6/solver/build.py:12-29):
+ * group[i] = 0 BatchNorm weight, 1 conv / convT weight (weight decay), 2 bias, >= 3 not optimised;  lr3 / wd3: HOST arrays
+ * of three values;  grad_mul multiplies every gradient (1 / world size: the DDP average folded into the step) */
+int y6_sgd_step_grouped(float* param, const float* grad, float* momentum_buf, const uint8_t* group, size_t n, const float* lr3_host,
+                        const float* wd3_host, float momentum, int nesterov, int first_step, float grad_mul, const float* scale,
+                        const int32_t* found_inf, void* stream);
 int y6_scaler_update(float* scale, int32_t* found_inf, int32_t* growth_tracker, float growth, float backoff, int interval,
                      void* stream);
 

@@ -31,17 +31,36 @@ def act_fn(y, act):
     return {None: lambda t: t, "relu": F.relu, "silu": F.silu, "hardswish": F.hardswish}[act](y)
 
 
+def q16(t):
+    return t.half().float()
+
+
 def conv_reference(x_nchw, w, b, stride, act, post=None, res=None, alpha=None):
-    """fp32 CPU statement of the fused op with fp16-rounded parameters (what model.half() holds)."""
+    """fp32 CPU statement of the fused op with fp16-rounded parameters (what model.half() holds), rounded to fp16 at the op
+    boundaries of the reference's half-precision graph (conv | BatchNorm | activation | residual add are separate fp16
+    ops there): the fused HIP epilogue rounds at the same places (yolov6_amd/csrc/common.hpp::y6_round_f16)."""
     k = w.shape[-1]
     y = F.conv2d(x_nchw, w.half().float(), None if b is None else b.half().float(), stride=stride, padding=k // 2)
     if post is not None:
-        y = y * post[0].half().float().view(1, -1, 1, 1) + post[1].half().float().view(1, -1, 1, 1)
+        y = q16(y) * post[0].half().float().view(1, -1, 1, 1) + post[1].half().float().view(1, -1, 1, 1)
+    if act in ("silu", "hardswish"):
+        y = q16(y)                       # ReLU commutes with the rounding
     y = act_fn(y, act)
     if res is not None:
         a = 1.0 if alpha is None else float(alpha.half().float())
-        y = y + a * res
+        y = q16(y) + q16(a * res)
     return y
+
+
+def op_tolerance(act, with_res=False):
+    """Bound of |hip - ref| / max(1, |ref|) for ONE fused op against the statement above.  Both sides round to fp16 at the
+    same places; fp32 accumulation-order differences flip isolated roundings by one ulp (2^-10 relative, < 1e-3 - the
+    north_star's bar, met by conv + bias (+ ReLU)).  A flipped fp16 INPUT of SiLU / hardswish moves the output by up to
+    one input-ulp, which is two ulps of an output that sits one binade lower (silu(2.1) = 1.87): 2 ulp = 1.96e-3; the
+    residual add rounds once more: 3 ulp."""
+    ulp = 2.0 ** -10
+    n = 1 + (1 if act in ("silu", "hardswish") else 0) + (1 if with_res else 0)
+    return 1e-3 if n == 1 else n * ulp * 1.002
 
 
 def run_conv(x: TRef, w, b, stride, act, variant, out=None, post=None, res=None, alpha=None):

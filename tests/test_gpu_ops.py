@@ -113,7 +113,7 @@ def test_conv_epilogue_variants(act):
         outbuf.buf.copy_(before)
         o, _ = G.run_conv(xin, w, b, 1, act, v, out=out, post=post, res=res, alpha=alpha)
         err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
-        assert err < TOL, f"{name}/{act}: {err:.3e}"
+        assert err < G.op_tolerance(act, with_res=True), f"{name}/{act}: {err:.3e}"
         # channels outside the slice are untouched (concat-free writes must not spill)
         assert torch.equal(outbuf.buf[..., :64], before[..., :64]) and torch.equal(outbuf.buf[..., 128:], before[..., 128:])
 
@@ -209,10 +209,10 @@ def test_head_decode(use_dfl, nc, sizes):
     cl, rl, pts, st = [], [], [], []
     for c, r, (h, w), s in zip(cls, reg, sizes, strides):
         cn, rn = G.nhwc_to_nchw_f32(c), G.nhwc_to_nchw_f32(r)
-        if use_dfl:
+        if use_dfl:    # F.softmax and proj_conv return fp16 tensors in the reference's half model (effidehead.py:107-109)
             rn = rn.reshape(-1, 4, reg_max + 1, h * w).permute(0, 2, 1, 3)
-            rn = F.conv2d(F.softmax(rn, dim=1), proj.view(1, -1, 1, 1))
-        cl.append(torch.sigmoid(cn).reshape(B, nc, h * w))
+            rn = G.q16(F.conv2d(G.q16(F.softmax(rn, dim=1)), proj.view(1, -1, 1, 1)))
+        cl.append(G.q16(torch.sigmoid(cn)).reshape(B, nc, h * w))
         rl.append(rn.reshape(B, 4, h * w))
         gy, gx = torch.meshgrid(torch.arange(h) + 0.5, torch.arange(w) + 0.5, indexing="ij")
         pts.append(torch.stack([gx, gy], -1).reshape(-1, 2))

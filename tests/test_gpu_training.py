@@ -67,10 +67,13 @@ def _wgrad(mode, a, planes, M, N, B, Q, rows, T):
     w.mode = mode
     w.a = a.data_ptr()
     w.M, w.N, w.B, w.Q, w.rows, w.a_rows = M, N, B, Q, rows, rows
+    w.a_channels, w.plane_channels = M, N
     for i, (t, prow, drow) in enumerate(planes):
         w.plane[i], w.plane_rows[i], w.drow[i] = t.data_ptr(), prow, drow
     w.out = out.data_ptr()
     w.sm, w.sn, w.st = N * T, T, 1
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device=DEV)
+    w.workspace, w.workspace_bytes = ws.data_ptr(), ws.numel()
     _lib.check(lib.y6_wgrad(C.byref(w), _stream()), "wgrad")
     torch.cuda.synchronize()
     return out.cpu()
@@ -81,7 +84,7 @@ def test_transpose_sampling_exact():
     x = torch.rand((2, 24, 7, 11), generator=g).half().float()
     xr = _nhwc(x)
     for (sy, sx, oy, ox, R, Q) in [(1, 1, -1, 0, 9, 16), (1, 1, 0, 0, 7, 16), (2, 2, 0, 1, 4, 16), (2, 2, -1, 0, 5, 16)]:
-        t = _transpose(xr, sy, sx, oy, ox, R, Q).float().cpu().view(24, 2, R, Q)
+        t = _transpose(xr, sy, sx, oy, ox, R, Q).float().cpu().view(2, R, Q // 8, 24, 8).permute(3, 0, 1, 2, 4).reshape(24, 2, R, Q)
         ref = torch.zeros(24, 2, R, Q)
         for r in range(R):
             for q in range(Q):
@@ -90,7 +93,7 @@ def test_transpose_sampling_exact():
                     ref[:, :, r, q] = x[:, :, y, xx].t()
         assert torch.equal(t, ref), (sy, sx, oy, ox)
     img = torch.rand((2, 3, 8, 12), generator=g)
-    t = _transpose(None, 2, 2, -1, 1, 5, 16, nchw=img.to(DEV)).float().cpu().view(3, 2, 5, 16)
+    t = _transpose(None, 2, 2, -1, 1, 5, 16, nchw=img.to(DEV)).float().cpu().view(2, 5, 2, 3, 8).permute(3, 0, 1, 2, 4).reshape(3, 2, 5, 16)
     ref = torch.zeros(3, 2, 5, 16)
     for r in range(5):
         for q in range(16):
@@ -619,3 +622,55 @@ def test_block_training_graph_vs_autograd(kind):
         assert float((msd[p_[2:] + ".running_var"].cpu() - rv.detach()).abs().max()) < 3e-3 * max(1.0, float(rv.abs().max()))
     print(f"{kind}: forward {e_out:.2e}, worst gradient {worst[0]} {worst[1]:.2e} (fp16 floor {worst[2]:.2e})")
     assert not bad, f"{kind}: gradients above 3x the fp16 noise floor: {bad[:4]}"
+
+
+def test_full_training_steps_loss_backward_sgd():
+    """model(x) -> ComputeLoss -> scaler.scale(loss).backward() -> fused SGD, three steps on a fixed batch: the loss gradient
+    lands in the graph's own head-gradient buffers (no copy), gradients are finite, parameters move, the loss goes down, and
+    one step equals torch.optim.SGD applied to the same arena gradients."""
+    from oracle import synth
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.solver import FusedSGD, LossScaler, param_groups
+    cfg, meta, sd, model = _tiny_train_model("tiny")
+    model = model.to(DEV).train()
+    x = synth.synth_images(4, 128, seed=3).to(DEV).half()
+    g = torch.Generator().manual_seed(0)
+    n = 12
+    targets = torch.cat([torch.randint(0, 4, (n, 1), generator=g).float(), torch.randint(0, 80, (n, 1), generator=g).float(),
+                         torch.rand((n, 2), generator=g) * 0.6 + 0.2, torch.rand((n, 2), generator=g) * 0.3 + 0.1], 1).to(DEV)
+    h = cfg.model.head
+    crit = ComputeLoss(num_classes=80, ori_img_size=128, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    (feats, scores, distri), _ = model(x)
+    graph = scores._y6_graph
+    arena = graph.arena
+    opt = FusedSGD(model, arena, lr=0.02, momentum=0.9, weight_decay=5e-4)
+    scaler = LossScaler(DEV, init_scale=1024.0)
+    losses = []
+    for i in range(4):
+        opt.zero_grad()
+        (feats, scores, distri), _ = model(x)
+        loss, items = crit((feats, scores, distri), targets, 10, i, 128, 128)
+        scaler.scale_loss(loss).backward()
+        assert torch.isfinite(arena.grad).all()
+        assert float(arena.grad.abs().max()) > 0
+        if i == 0:
+            # reference optimizer on the same gradients: torch.optim.SGD with the reference's three groups
+            before = arena.data.clone()
+            g_bnw, g_w, g_b = param_groups(model)
+            ref_p = {id(p): p.detach().clone() for p in arena.params}
+            grads = {id(p): p.grad.detach().clone() / 1024.0 for p in arena.params}
+        opt.step(scaler)
+        scaler.update()
+        if i == 0:
+            for k, (ps, wd) in enumerate(((g_bnw, 0.0), (g_w, 5e-4), (g_b, 0.0))):
+                for p in ps:
+                    if id(p) not in ref_p:
+                        continue
+                    d = grads[id(p)] + wd * ref_p[id(p)]
+                    want = ref_p[id(p)] - 0.02 * (d + 0.9 * d)          # first Nesterov step: buf = d
+                    assert torch.allclose(p.detach(), want, rtol=1e-4, atol=1e-6)
+            assert not torch.equal(before, arena.data)
+        losses.append(float(loss))
+    print("losses", losses, "scale", float(scaler.scale))
+    assert losses[-1] < losses[0], losses
+    assert float(scaler.scale) == 1024.0           # no overflow happened

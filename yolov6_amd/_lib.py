@@ -112,9 +112,10 @@ class WgradTDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("B", C.c_int32), ("Q", C.c_int32),
-                ("rows", C.c_int32), ("a_rows", C.c_int32), ("plane", C.c_void_p * 6), ("plane_rows", C.c_int32 * 6),
+                ("rows", C.c_int32), ("a_rows", C.c_int32), ("a_channels", C.c_int32), ("plane_channels", C.c_int32),
+                ("plane", C.c_void_p * 6), ("plane_rows", C.c_int32 * 6),
                 ("drow", C.c_int32 * 6), ("out", C.c_void_p), ("sm", C.c_int32), ("sn", C.c_int32), ("st", C.c_int32),
-                ("flops", C.c_double)]
+                ("flops", C.c_double), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class PackJob(C.Structure):
@@ -197,6 +198,8 @@ SIGNATURES = {
     "y6_grad_finite_check": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "y6_sgd_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "y6_sgd_step_grouped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                      C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_scaler_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "y6_plan_add_bn_train_stats": (C.c_int, [C.c_void_p, C.POINTER(BnTrainDesc)]),
     "y6_plan_add_bnact_forward": (C.c_int, [C.c_void_p, C.POINTER(BnActDesc)]),

@@ -321,66 +321,105 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BnActBwdArg
 }
 
 // pass 2: gradients wrt every branch input (and the shortcut)
-__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs a) {
-    const int C = a.f.C, G = C >> 3, n = a.f.n;
-    const long total = a.f.npix * G;
+struct BwdConsts {          // per 8-channel group: everything that does not depend on the pixel
+    float sc[3][8], sh[3][8], mu[3][8], is[3][8], k1[3][8], mdz[8], mxy[3][8];
+};
+__device__ __forceinline__ void load_bwd_consts(const BnActBwdArgs& a, int g, BwdConsts& c) {
+    const int C = a.f.C;
     const double invN = 1.0 / (double)a.f.npix;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.mdz[j] = (float)(a.ws[g * 8 + j] * invN);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b >= a.f.n) break;
+        loadf8(a.f.scale[b] ? a.f.scale[b] + g * 8 : nullptr, c.sc[b], 1.f);
+        loadf8(a.f.shift[b] ? a.f.shift[b] + g * 8 : nullptr, c.sh[b], 0.f);
+        if (a.mean[b]) {
+            float ga[8];
+            loadf8(a.mean[b] + g * 8, c.mu[b], 0.f);
+            loadf8(a.invstd[b] + g * 8, c.is[b], 0.f);
+            loadf8(a.gamma[b] ? a.gamma[b] + g * 8 : nullptr, ga, 1.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                c.k1[b][j] = ga[j] * c.is[b][j];
+                c.mxy[b][j] = (float)(a.ws[(1 + b) * C + g * 8 + j] * invN);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void bwd_apply_one(const BnActBwdArgs& a, long p, int g, const BwdConsts& c, float alpha) {
+    const int n = a.f.n;
+    float z[8], xb[3][8], go[8], dz[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b >= n) break;
+        load8(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + g * 8, xb[b]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) z[j] += xb[b][j] * c.sc[b][j] + c.sh[b][j];
+    }
+    load8(a.dout + p * a.dcs + a.dco + g * 8, go);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
+    if (a.dres) {
+        __half* q = a.dres + p * a.rcs + a.rco + g * 8;
+        float r[8];
+        if (a.racc) load8(q, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
+        store8(q, r);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (b >= n) break;
+        if (!a.dx[b]) continue;
+        float d[8];
+        if (a.mean[b]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xb[b][j] - c.mu[b][j]) * c.is[b][j];
+                d[j] = c.k1[b][j] * (dz[j] - c.mdz[j] - xh * c.mxy[b][j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = dz[j] * c.sc[b][j];
+        }
+        long q = p;
+        if (a.xdil[b] == 2) {       // (b, y, x) of the logical grid -> (b, 2y, 2x) of the dilated buffer
+            const long hw = (long)a.H * a.W;
+            const long bi = p / hw, rem = p - bi * hw;
+            const long y = rem / a.W, x = rem - y * a.W;
+            q = (bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
+        }
+        __half* dst = a.dx[b] + q * a.xcs[b] + a.xco[b] + g * 8;
+        if (a.xacc[b]) {
+            float old[8];
+            load8(dst, old);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += old[j];
+        }
+        store8(dst, d);
+    }
+}
+
+__global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs a) {
+    const int G = a.f.C >> 3;
     const float alpha = a.f.res ? (a.f.alpha ? *a.f.alpha : 1.f) : 0.f;
+    BwdConsts c;
+    if (256 % G == 0) {            // a thread keeps ONE channel group: the per-channel constants stay in registers
+        const int g = threadIdx.x % G, rpb = 256 / G;
+        load_bwd_consts(a, g, c);
+        for (long p = (long)blockIdx.x * rpb + threadIdx.x / G; p < a.f.npix; p += (long)gridDim.x * rpb) bwd_apply_one(a, p, g, c, alpha);
+        return;
+    }
+    const long total = a.f.npix * G;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long p = i / G;
         const int g = (int)(i - p * G);
-        float z[8], xb[3][8], go[8], dz[8];
-        preact8(a.f, p, g, z, xb);
-        load8(a.dout + p * a.dcs + a.dco + g * 8, go);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
-        if (a.dres) {
-            __half* q = a.dres + p * a.rcs + a.rco + g * 8;
-            float r[8];
-            if (a.racc) load8(q, r);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
-            store8(q, r);
-        }
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            if (b >= n) break;
-            if (!a.dx[b]) continue;
-            float d[8];
-            if (a.mean[b]) {
-                float mu[8], is[8], ga[8];
-                loadf8(a.mean[b] + g * 8, mu, 0.f);
-                loadf8(a.invstd[b] + g * 8, is, 0.f);
-                loadf8(a.gamma[b] ? a.gamma[b] + g * 8 : nullptr, ga, 1.f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float mdz = (float)(a.ws[g * 8 + j] * invN);
-                    const float mxy = (float)(a.ws[(1 + b) * C + g * 8 + j] * invN);
-                    const float xh = (xb[b][j] - mu[j]) * is[j];
-                    d[j] = ga[j] * is[j] * (dz[j] - mdz - xh * mxy);
-                }
-            } else {
-                float sc[8];
-                loadf8(a.f.scale[b] ? a.f.scale[b] + g * 8 : nullptr, sc, 1.f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = dz[j] * sc[j];
-            }
-            long q = p;
-            if (a.xdil[b] == 2) {       // (b, y, x) of the logical grid -> (b, 2y, 2x) of the dilated buffer
-                const long hw = (long)a.H * a.W;
-                const long bi = p / hw, rem = p - bi * hw;
-                const long y = rem / a.W, x = rem - y * a.W;
-                q = (bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
-            }
-            __half* dst = a.dx[b] + q * a.xcs[b] + a.xco[b] + g * 8;
-            if (a.xacc[b]) {
-                float old[8];
-                load8(dst, old);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] += old[j];
-            }
-            store8(dst, d);
-        }
+        load_bwd_consts(a, g, c);
+        bwd_apply_one(a, p, g, c, alpha);
     }
 }
 
@@ -464,8 +503,12 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     return Y6_OK;
 }
 
-// ------------------------------------------------------------------ channel-major sampling for the weight gradient
-// block = (b, r, 64-column tile, 64-channel tile): NHWC rows -> LDS -> 16-byte runs along q per channel
+// ------------------------------------------------------------------ pixel-run-major sampling for the weight gradient
+// dst[b][r][q/8][c][q%8]: 8 consecutive columns of one channel form a 16-byte run (an MFMA operand of one lane), and the runs
+// of consecutive channels are contiguous, so a wave's fragment load is 512 contiguous bytes per half (4 full cache lines).
+// (A [c][b][r][q] layout made every lane of a load touch its own 128-byte line, 16 bytes at a time: the L1 thrashed and
+// the big layers ran at 70 TFLOP/s.)
+// block = (b, r, 64-column tile, 64-channel tile): NHWC rows -> LDS -> runs
 __global__ __launch_bounds__(256) void wt_nhwc_kernel(const __half* __restrict__ src, int cs, int co, int B, int H, int W, int C,
                                                       int sy, int sx, int oy, int ox, int R, int Q, __half* __restrict__ dst,
                                                       int qtiles, int ctiles) {
@@ -491,29 +534,30 @@ __global__ __launch_bounds__(256) void wt_nhwc_kernel(const __half* __restrict__
         *reinterpret_cast<uint4*>(&tile[ql][cg * 8]) = v;
     }
     __syncthreads();
+    // destination layout [b][r][run = q/8][c][8]: the 32 channels of an MFMA fragment are 512 contiguous bytes
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const int item = tid + it * 256;          // 64 channels x 8 runs
-        const int run = item & 7, cl = item >> 3;
+        const int item = tid + it * 256;          // 8 runs x 64 channels, channel fastest (1 KiB contiguous per 64 threads)
+        const int cl = item & 63, run = item >> 6;
         if (c0 + cl >= C || q0 + run * 8 >= Q) continue;
         h8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const _Float16*>(&tile[run * 8 + j][cl]);
-        *reinterpret_cast<h8_t*>(dst + (((size_t)(c0 + cl) * B + b) * R + r) * Q + q0 + run * 8) = o;
+        *reinterpret_cast<h8_t*>(dst + ((((size_t)b * R + r) * (Q >> 3) + (q0 >> 3) + run) * C + c0 + cl) * 8) = o;
     }
 }
 
 template <typename T>
 __global__ void wt_nchw_kernel(const T* __restrict__ src, int B, int H, int W, int C, int sy, int sx, int oy, int ox, int R, int Q,
                                __half* __restrict__ dst) {
-    const size_t total = (size_t)C * B * R * (Q / 8);
+    const size_t total = (size_t)C * B * R * (Q / 8);        // destination [b][r][run][c][8]
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int run = (int)(i % (Q / 8));
-        size_t t = i / (Q / 8);
+        const int c = (int)(i % C);
+        size_t t = i / C;
+        const int run = (int)(t % (Q / 8));
+        t /= (Q / 8);
         const int r = (int)(t % R);
-        t /= R;
-        const int b = (int)(t % B);
-        const int c = (int)(t / B);
+        const int b = (int)(t / R);
         const int y = r * sy + oy;
         h8_t o;
 #pragma unroll
@@ -957,6 +1001,27 @@ int chan_sum_launch(const ChanSum* d, hipStream_t s) {
     Y6_REQUIRE(t.data && d->out && d->ws && t.C >= 1 && t.C <= 4096, "channel_sum: bad arguments (1..4096 channels)");
     Y6_REQUIRE(d->ws_bytes >= (size_t)t.C * sizeof(double), "channel_sum: workspace too small");
     const long npix = (long)t.B * t.H * t.W;
+    // 16-byte path: the view padded up to a multiple of 8 channels lies inside the buffer (the prediction-conv gradients are
+    // stored 8-padded with zero pad channels) and is aligned -> the BatchNorm statistics kernel, sums only
+    const int C8 = (t.C + 7) / 8 * 8;
+    if (t.coff % 8 == 0 && t.cstride % 8 == 0 && t.coff + C8 <= t.cstride && (((uintptr_t)t.data) & 15) == 0 && C8 <= 2048 &&
+        d->ws_bytes >= (size_t)2 * C8 * sizeof(double)) {
+        double* ws = (double*)d->ws;
+        Y6_HIP(hipMemsetAsync(ws, 0, (size_t)2 * C8 * sizeof(double), s));
+        const int G = C8 / 8, R = 256 / G;
+        long ppb = (long)R * 64;
+        long blocks = (npix + ppb - 1) / ppb;
+        if (blocks > 2048) {
+            blocks = 2048;
+            ppb = (npix + blocks - 1) / blocks;
+        }
+        hipLaunchKernelGGL(bn_sum_kernel, dim3((unsigned)blocks), dim3(256), (size_t)2 * C8 * sizeof(double), s, (const __half*)t.data,
+                           t.cstride, t.coff, npix, G, ppb, ws, C8);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((unsigned)((t.C + 255) / 256)), dim3(256), 0, s, (const double*)ws, t.C, d->out);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
     Y6_HIP(hipMemsetAsync(d->ws, 0, (size_t)t.C * sizeof(double), s));
     long g = (npix + 63) / 64;
     if (g > 1024) g = 1024;
@@ -1003,6 +1068,34 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
             if (nesterov) b = d + mom * b;
         }
         p[i] = w - lr * b;
+    }
+}
+
+struct SgdGroups {
+    float lr[4];
+    float wd[4];
+};
+// per-element parameter group (0: BatchNorm weights, 1: conv / convT weights, 2: biases, >= 3: not optimised), the three
+// groups of yolov6/solver/build.py:12-29; grad_mul folds the DDP average (1 / world size) into the same pass
+__global__ __launch_bounds__(256) void sgd_grouped_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          const uint8_t* __restrict__ group, size_t n, const SgdGroups gr, float mom, int nesterov,
+                                                          int first, float grad_mul, const float* __restrict__ scale,
+                                                          const int32_t* __restrict__ found_inf) {
+    if (found_inf && *found_inf) return;
+    const float inv = (scale ? 1.f / *scale : 1.f) * grad_mul;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = group[i];
+        if (k > 2) continue;
+        const float w = p[i];
+        float d = g[i] * inv;
+        if (gr.wd[k] != 0.f) d += gr.wd[k] * w;
+        float b = d;
+        if (mom != 0.f) {
+            b = first ? d : mom * m[i] + d;
+            m[i] = b;
+            if (nesterov) b = d + mom * b;
+        }
+        p[i] = w - gr.lr[k] * b;
     }
 }
 
@@ -1103,6 +1196,23 @@ extern "C" int y6_sgd_step(float* param, const float* grad, float* momentum_buf,
     if (n == 0) return Y6_OK;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, n, lr, momentum,
                        weight_decay, nesterov, first_step, scale, found_inf);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+extern "C" int y6_sgd_step_grouped(float* param, const float* grad, float* momentum_buf, const uint8_t* group, size_t n, const float* lr3,
+                                   const float* wd3, float momentum, int nesterov, int first_step, float grad_mul, const float* scale,
+                                   const int32_t* found_inf, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(param && grad && group && lr3 && wd3 && (momentum == 0.f || momentum_buf), "sgd_step_grouped: null argument");
+    if (n == 0) return Y6_OK;
+    SgdGroups gr;
+    for (int i = 0; i < 3; ++i) {
+        gr.lr[i] = lr3[i];
+        gr.wd[i] = wd3[i];
+    }
+    gr.lr[3] = gr.wd[3] = 0.f;
+    hipLaunchKernelGGL(sgd_grouped_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, group, n,
+                       gr, momentum, nesterov, first_step, grad_mul, scale, found_inf);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

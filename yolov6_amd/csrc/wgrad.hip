@@ -7,9 +7,10 @@
 //
 // Design (MI355X-first, not a cuDNN wgrad port):
 //  * The reduction runs over PIXELS, and NHWC keeps channels contiguous - the wrong way round for an MFMA operand
-//    (a lane holds 8 consecutive k of one row).  y6_wgrad_transpose (train.hip) therefore writes channel-major copies
-//    with the image row as the contiguous axis; both operands of v_mfma_f32_32x32x16_f16 are then plain 16-byte global
-//    loads of one lane - no LDS, no barrier, no bank conflicts anywhere in this kernel.
+//    (a lane holds 8 consecutive k of one row).  y6_wgrad_transpose (train.hip) therefore writes copies in
+//    [image][row][8-pixel run][channel][8] order: a lane's operand (8 consecutive pixels of one channel) is one 16-byte word
+//    and the words of the 32 channels of a fragment are contiguous - both operands of v_mfma_f32_32x32x16_f16 are plain,
+//    fully coalesced 16-byte global loads; no LDS, no barrier, no bank conflicts anywhere in this kernel.
 //  * A 3x3 kernel's column taps (kx = 0 / 2) read the SAME 16-byte runs shifted by one element: the shifted fragments
 //    are built in registers from the previous / current / next run with v_alignbit_b32 (4 VALU ops per fragment,
 //    co-issued with the MFMAs); row taps are row offsets into a plane that carries one zero row above and below.
@@ -17,8 +18,10 @@
 //    contiguous aligned run.
 //  * k order inside a row: lanes 0-31 walk the runs of the first half of the row, lanes 32-63 the second half, so a
 //    lane's previous/next run is its own previous/next k-step (any k permutation is legal as long as A and B agree).
-//  * One wave = one 32x32 (m, n) tile x all taps (9 x 16 accumulator registers) x one slice of the (image, row) range;
-//    slices are summed with fp32 atomics straight into the OIHW gradient array (zeroed once per step by the caller).
+//  * One wave = one 32x32 (m, n) tile x one kernel row of taps (3 x 16 accumulator registers, 4 waves per SIMD) x one
+//    slice of the (image, row) range;
+//    each slice stores its partial tile to a workspace and a small second kernel sums the slices into the OIHW
+//    gradient array (+=; zeroed once per step by the caller) - deterministic, no atomics.
 #include "common.hpp"
 #include "plan_internal.hpp"
 
@@ -36,29 +39,34 @@ struct WgArgs {
     float* out;
     int sm, sn, st;
     int mtiles, ntiles, nsplit, rows_per;   // work split
+    float* ws;                  // partial sums [nsplit][T][M][N]
+    int T;
+    int a_ch, b_ch;             // channels of the A plane / of the B planes (>= M, N: padded views)
 };
 
-// per-mode stream table: for stream s, the tap fed by the run shifted by -1 / 0 / +1 (-1: unused)
+// per-mode tables.  The taps of a mode are split into NG groups (one kernel row ky each for the 3x3 modes); a wave owns
+// ONE group: 3 x 16 accumulator registers instead of 9 x 16, i.e. <= 128 registers and 4 waves per SIMD - the load latency
+// of this LDS-free kernel is hidden by occupancy.  Group g reads streams [g*NSG, (g+1)*NSG); tap(s, sh) is the tap (within
+// the group) fed by stream s of the group shifted by sh-1 columns, or -1.
 template <int MODE> struct Mode;
 template <> struct Mode<Y6_WG_3X3S1> {
-    static constexpr int NS = 3, NT = 9;
-    static constexpr int tap(int s, int sh) { return s * 3 + sh; }          // sh: 0 = shift -1 (kx 0), 1 = none, 2 = shift +1
+    static constexpr int NG = 3, NSG = 1, NTG = 3;
+    static constexpr int tap(int, int sh) { return sh; }                     // kx = sh (shift -1, 0, +1)
 };
 template <> struct Mode<Y6_WG_1X1> {
-    static constexpr int NS = 1, NT = 1;
+    static constexpr int NG = 1, NSG = 1, NTG = 1;
     static constexpr int tap(int, int sh) { return sh == 1 ? 0 : -1; }
 };
 template <> struct Mode<Y6_WG_3X3S2> {
-    // streams: s = ky*2 + colpar.  colpar 0 = even columns (kx 1, no shift); colpar 1 = odd columns (kx 0: shift -1, kx 2: none)
-    static constexpr int NS = 6, NT = 9;
+    // group = ky; stream 0 = even columns (kx 1, no shift); stream 1 = odd columns (kx 0: shift -1, kx 2: none)
+    static constexpr int NG = 3, NSG = 2, NTG = 3;
     static constexpr int tap(int s, int sh) {
-        const int ky = s >> 1, cp = s & 1;
-        if (cp == 0) return sh == 1 ? ky * 3 + 1 : -1;
-        return sh == 0 ? ky * 3 + 0 : (sh == 1 ? ky * 3 + 2 : -1);
+        if (s == 0) return sh == 1 ? 1 : -1;
+        return sh == 0 ? 0 : (sh == 1 ? 2 : -1);
     }
 };
 template <> struct Mode<Y6_WG_CONVT> {
-    static constexpr int NS = 4, NT = 4;
+    static constexpr int NG = 1, NSG = 4, NTG = 4;
     static constexpr int tap(int s, int sh) { return sh == 1 ? s : -1; }
 };
 
@@ -83,18 +91,23 @@ __device__ __forceinline__ u32x4 shift_p1(const u32x4 cur, const u32x4 next) {
     return o;
 }
 
+// waves per SIMD the register budget is cut for: the two-stream / four-stream modes would spill at 128 registers
+template <int MODE> constexpr int kWavesPerSimd = (MODE == Y6_WG_3X3S1 || MODE == Y6_WG_1X1) ? 4 : 2;
+
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
+__global__ __launch_bounds__(256, kWavesPerSimd<MODE>) void wgrad_kernel(const WgArgs a) {
     using MD = Mode<MODE>;
-    constexpr int NS = MD::NS, NT = MD::NT;
+    constexpr int NG = MD::NG, NSG = MD::NSG, NTG = MD::NTG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const long unit = (long)blockIdx.x * 4 + wave;
-    const long units = (long)a.mtiles * a.ntiles * a.nsplit;
+    const long units = (long)a.mtiles * a.ntiles * NG * a.nsplit;
     if (unit >= units) return;
+    // nt fastest, then the tap group: the waves of a block read the same A rows (L1 hits)
     const int nt = (int)(unit % a.ntiles);
-    const int mt = (int)((unit / a.ntiles) % a.mtiles);
-    const int ks = (int)(unit / ((long)a.ntiles * a.mtiles));
+    const int grp = (int)((unit / a.ntiles) % NG);
+    const int mt = (int)((unit / ((long)a.ntiles * NG)) % a.mtiles);
+    const int ks = (int)(unit / ((long)a.ntiles * NG * a.mtiles));
     const long total_rows = (long)a.B * a.rows;
     const long r0 = (long)ks * a.rows_per;
     long r1 = r0 + a.rows_per;
@@ -107,38 +120,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
     const int Qh = Qr >> 1;             // k-steps per row (Q % 16 == 0)
     const int j0 = half * Qh;           // first run of this half
 
-    f32x16_t acc[NT];
+    f32x16_t acc[NTG];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTG; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const __half* pl[NSG];
+    int prow[NSG], drow[NSG];
+#pragma unroll
+    for (int s = 0; s < NSG; ++s) {
+        pl[s] = a.plane[grp * NSG + s];
+        prow[s] = a.plane_rows[grp * NSG + s];
+        drow[s] = a.drow[grp * NSG + s];
+    }
 
     const u32x4 zero = {0u, 0u, 0u, 0u};
     for (long r = r0; r < r1; ++r) {
         const int b = (int)(r / a.rows), y = (int)(r - (long)b * a.rows);
-        const u32x4* ap = reinterpret_cast<const u32x4*>(a.a + (((size_t)m * a.B + b) * a.a_rows + y) * a.Q) + j0;
-        const u32x4* bp[NS];
+        // planes are [b][row][run][channel][8]: run j of channel c is the 16-byte word ((b*rows + row)*Qr + j)*ch + c
+        const u32x4* ap = reinterpret_cast<const u32x4*>(a.a) + (((size_t)b * a.a_rows + y) * Qr + j0) * a.a_ch + m;
+        const u32x4* bp[NSG];
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-            bp[s] = reinterpret_cast<const u32x4*>(a.plane[s] + (((size_t)n * a.B + b) * a.plane_rows[s] + y + a.drow[s]) * a.Q) + j0;
-        u32x4 prev[NS], cur[NS];
+        for (int s = 0; s < NSG; ++s)
+            bp[s] = reinterpret_cast<const u32x4*>(pl[s]) + (((size_t)b * prow[s] + y + drow[s]) * Qr + j0) * a.b_ch + n;
+        const long sa = a.a_ch, sb = a.b_ch;      // word strides between consecutive runs
+        u32x4 prev[NSG], cur[NSG];
+        u32x4 av = ap[0];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = 0; s < NSG; ++s) {
             cur[s] = bp[s][0];
             prev[s] = zero;
-            if (MD::tap(s, 0) >= 0 && j0 > 0) prev[s] = bp[s][-1];
+            if (MD::tap(s, 0) >= 0 && j0 > 0) prev[s] = bp[s][-sb];
         }
         for (int k = 0; k < Qh; ++k) {
-            const u32x4 av = ap[k];
-            u32x4 next[NS];
+            // loads of the NEXT k-step are issued before this step's MFMAs
+            u32x4 next[NSG];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < NSG; ++s) {
                 next[s] = zero;
-                if ((MD::tap(s, 2) >= 0 || k + 1 < Qh) && (j0 + k + 1 < Qr)) next[s] = bp[s][k + 1];
+                if ((MD::tap(s, 2) >= 0 || k + 1 < Qh) && (j0 + k + 1 < Qr)) next[s] = bp[s][(k + 1) * sb];
             }
+            u32x4 an = zero;
+            if (k + 1 < Qh) an = ap[(k + 1) * sa];
             const h8_t af = as_h8(av);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s = 0; s < NSG; ++s) {
                 if (MD::tap(s, 0) >= 0)
                     acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
                         af, as_h8(shift_m1(prev[s], cur[s])), acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0], 0, 0, 0);
@@ -151,18 +178,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgArgs a) {
                 prev[s] = cur[s];
                 cur[s] = next[s];
             }
+            av = an;
         }
     }
-    // C/D layout: column n = lane & 31, row m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)
+    // C/D layout: column n = lane & 31, row m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).
+    // The slice's partial tile goes to the workspace with plain stores (n contiguous across lanes); wgrad_reduce_kernel
+    // sums the slices.  (Device-scope float atomics from eight XCDs resolve at the memory side: 25 M of them per launch
+    // cost more than the MFMAs - measured 53 TFLOP/s with atomics.)
     const int n_out = nt * 32 + l31;
     if (n_out >= a.N) return;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTG; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int m_out = mt * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-            if (m_out < a.M) atomicAdd(a.out + (size_t)m_out * a.sm + (size_t)n_out * a.sn + (size_t)t * a.st, acc[t][q]);
+            if (m_out < a.M) a.ws[(((size_t)ks * a.T + (grp * NTG + t)) * a.M + m_out) * a.N + n_out] = acc[t][q];
         }
+}
+
+// out[m*sm + n*sn + t*st] += sum_ks ws[ks][t][m][n]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int T, int M, int N, float* __restrict__ out,
+                                                           int sm, int sn, int st) {
+    const size_t per = (size_t)T * M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * per + i];
+        const int n = (int)(i % N);
+        const int m = (int)((i / N) % M);
+        const int t = (int)(i / ((size_t)N * M));
+        out[(size_t)m * sm + (size_t)n * sn + (size_t)t * st] += s;
+    }
 }
 
 int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
@@ -188,17 +233,31 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
         a.plane_rows[i] = d->plane_rows[i];
         a.drow[i] = d->drow[i];
     }
+    Y6_REQUIRE(d->a_channels >= d->M && d->plane_channels >= d->N, "wgrad: plane channel counts smaller than M / N");
+    a.a_ch = d->a_channels;
+    a.b_ch = d->plane_channels;
     a.out = d->out;
     a.sm = d->sm;
     a.sn = d->sn;
     a.st = d->st;
     a.mtiles = y6_cdiv(d->M, 32);
     a.ntiles = y6_cdiv(d->N, 32);
+    const int ng = (d->mode == Y6_WG_3X3S1 || d->mode == Y6_WG_3X3S2) ? 3 : 1;
+    const int T = d->mode == Y6_WG_1X1 ? 1 : (d->mode == Y6_WG_CONVT ? 4 : 9);
     const long total_rows = (long)d->B * d->rows;
-    const long tiles = (long)a.mtiles * a.ntiles;
-    long nsplit = (4096 + tiles - 1) / tiles;        // ~4 waves per SIMD of work items over the chip
+    const long tiles = (long)a.mtiles * a.ntiles * ng;
+    long nsplit = (8192 + tiles - 1) / tiles;        // ~8 waves per SIMD of work items over the chip (4 resident)
+    // ... but a slice should hold >= ~256 MFMAs (its fixed costs: pointer set-up, first-load latency per row, the partial tile)
+    const long mfma_per_row = (long)(d->Q / 16) * (T / ng);
+    const long max_by_work = (total_rows * mfma_per_row + 255) / 256;
+    if (nsplit > max_by_work) nsplit = max_by_work;
+    Y6_REQUIRE(d->workspace && d->workspace_bytes >= (size_t)T * d->M * d->N * sizeof(float), "wgrad: workspace missing or too small");
+    const long max_by_ws = (long)(d->workspace_bytes / ((size_t)T * d->M * d->N * sizeof(float)));
+    if (nsplit > max_by_ws) nsplit = max_by_ws;
     if (nsplit > total_rows) nsplit = total_rows;
     if (nsplit < 1) nsplit = 1;
+    a.ws = (float*)d->workspace;
+    a.T = T;
     a.rows_per = (int)((total_rows + nsplit - 1) / nsplit);
     a.nsplit = (int)((total_rows + a.rows_per - 1) / a.rows_per);
     const long units = tiles * a.nsplit;
@@ -209,6 +268,11 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
         case Y6_WG_3X3S2: hipLaunchKernelGGL(wgrad_kernel<Y6_WG_3X3S2>, dim3(grid), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL(wgrad_kernel<Y6_WG_CONVT>, dim3(grid), dim3(256), 0, s, a); break;
     }
+    Y6_LAUNCH_CHECK();
+    const size_t per = (size_t)T * d->M * d->N;
+    unsigned rg = (unsigned)((per + 255) / 256);
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, a.ws, a.nsplit, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

@@ -132,6 +132,10 @@ class TrainBuilder:
         self.bwd_flops = 0.0
         self.n_fwd_ops = 0
         self.n_bwd_ops = 0
+        # partial sums of the weight-gradient slices: one workspace shared by every wgrad op (they run in stream order)
+        self.wgrad_ws = torch.empty(256 << 20, dtype=torch.uint8, device=self.device) if self.device.type == "cuda" else \
+            torch.empty(64 << 20, dtype=torch.uint8)
+        self.keep.append(self.wgrad_ws)
         self.trace = {}              # name -> activation view (filled by the composite modules; tools/train_trace.py)
 
     # ------------------------------------------------------------------ memory
@@ -404,7 +408,7 @@ class TrainBuilder:
                     finals.append(bn.bias)
             rec = getattr(t, "_conv", None)
             if rec is not None:                      # a conv output: its gradient lives in a private buffer
-                if rec.stride == 2:
+                if rec.stride == 2 and not isinstance(rec.x, NCHWInput):     # (the stem has no data gradient: compact dy)
                     xin = rec.x
                     Hd, Wd = (xin.shape[2], xin.shape[3]) if isinstance(xin, NCHWInput) else (xin.H, xin.W)
                     if Hd % 2 or Wd % 2:
@@ -452,11 +456,12 @@ class TrainBuilder:
         self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose")
         return dst
 
-    def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops):
+    def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops, a_ch=None, b_ch=None):
         w = _lib.WgradDesc()
         w.mode = mode
         w.a = a.data_ptr()
         w.M, w.N, w.B, w.Q, w.rows, w.a_rows = M, N, B, Q, rows, rows
+        w.a_channels, w.plane_channels = a_ch or M, b_ch or N
         for i, (t, prow, drow) in enumerate(planes):
             w.plane[i] = t.data_ptr()
             w.plane_rows[i] = prow
@@ -464,6 +469,7 @@ class TrainBuilder:
         w.out = out_ptr
         w.sm, w.sn, w.st = N * T, T, 1
         w.flops = flops
+        w.workspace, w.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
         self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad")
         self.bwd_flops += flops
 
@@ -503,10 +509,10 @@ class TrainBuilder:
             mode = _lib.WG_1X1
             planes = [(self._transpose(xv, 2, 2, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
         self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight),
-                    2.0 * Cout * Cin * K * K * B * Ho * Wo)
+                    2.0 * Cout * Cin * K * K * B * Ho * Wo, a_ch=dyv.C, b_ch=Cin)
         finals = [rec.weight]
         if rec.bias is not None:
-            ws = self.bytes_(8 * max(y.C, 1))
+            ws = self.bytes_(16 * _rup(max(y.C, 1), 8))
             ct = TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff).ct()
             self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(rec.bias), _ptr(ws), ws.numel()),
                     "plan_add_channel_sum")
@@ -538,7 +544,7 @@ class TrainBuilder:
         self.grad_ready(gout)
         B, H, W = x.B, x.H, x.W
         Q = _rup(W, 16)
-        ws = self.bytes_(8 * Cout)
+        ws = self.bytes_(16 * _rup(Cout, 8))
         ct = gout.ct()
         self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(bias), _ptr(ws), ws.numel()),
                 "plan_add_channel_sum")
