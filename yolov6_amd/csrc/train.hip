@@ -260,10 +260,24 @@ struct BnActBwdArgs {
     int H, W;
 };
 
-// pass 1: per-channel sums of dz and dz*xhat_b (double), optional sum dout*res
+__device__ __forceinline__ void load4(const __half* p, float (&v)[4]) {
+    const uint2 raw = *reinterpret_cast<const uint2*>(p);
+    const __half* h = reinterpret_cast<const __half*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __half2float(h[j]);
+}
+__device__ __forceinline__ void store4(__half* p, const float (&v)[4]) {
+    h4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[j];
+    *reinterpret_cast<h4_t*>(p) = o;
+}
+// pass 1: per-channel sums of dz and dz*x_b (RAW branch inputs; double), optional sum dout*res.
+// sum dz*xhat_b = (sum dz*x_b - mean_b * sum dz) * invstd_b is formed afterwards: the loop needs no statistics, which keeps
+// it at ~100 registers (4 waves per SIMD in flight instead of 2 - this pass is pure HBM streaming).
 __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BnActBwdArgs a, long pix_per_block) {
     extern __shared__ double s_acc[];   // [(1+n)*C]
-    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const int C = a.f.C, G = C >> 2, n = a.f.n;      // 4 channels per thread (8-byte loads)
     const int tid = threadIdx.x;
     const int nacc = (1 + n) * C;
     for (int i = tid; i < nacc; i += 256) s_acc[i] = 0.0;
@@ -271,155 +285,167 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BnActBwdArg
     const int R = 256 / G;
     double s_alpha = 0.0;
     if (tid < R * G) {
-        const int g = tid % G, prow = tid / G;
+        const int g = tid % G, prow = tid / G, c0 = g * 4;
         const long p0 = (long)blockIdx.x * pix_per_block;
         const long p1 = p0 + pix_per_block < a.f.npix ? p0 + pix_per_block : a.f.npix;
-        double sdz[8], sxy[3][8];
+        double sdz[4], sxy[3][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sdz[j] = sxy[0][j] = sxy[1][j] = sxy[2][j] = 0.0;
-        float mu[3][8], is[3][8];
+        for (int j = 0; j < 4; ++j) sdz[j] = sxy[0][j] = sxy[1][j] = sxy[2][j] = 0.0;
+        float sc[3][4], sht[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sht[j] = 0.f;
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
             if (b >= n) break;
-            loadf8(a.mean[b] ? a.mean[b] + g * 8 : nullptr, mu[b], 0.f);
-            loadf8(a.invstd[b] ? a.invstd[b] + g * 8 : nullptr, is[b], 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[b][j] = a.f.scale[b] ? a.f.scale[b][c0 + j] : 1.f;
+                sht[j] += a.f.shift[b] ? a.f.shift[b][c0 + j] : 0.f;
+            }
         }
         for (long p = p0 + prow; p < p1; p += R) {
-            float z[8], xb[3][8], go[8];
-            preact8(a.f, p, g, z, xb);
-            load8(a.dout + p * a.dcs + a.dco + g * 8, go);
-            if (a.dalpha) {
-                float r[8];
-                load8(a.f.res + p * a.f.rcs + a.f.rco + g * 8, r);
+            float z[4], xb[3][4], go[4];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s_alpha += (double)(go[j] * r[j]);
+            for (int j = 0; j < 4; ++j) z[j] = sht[j];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                if (b >= n) break;
+                load4(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + c0, xb[b]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[j] += xb[b][j] * sc[b][j];
+            }
+            load4(a.dout + p * a.dcs + a.dco + c0, go);
+            if (a.dalpha) {
+                float r[4];
+                load4(a.f.res + p * a.f.rcs + a.f.rco + c0, r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_alpha += (double)(go[j] * r[j]);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 const float dz = go[j] * act_grad(z[j], a.f.act);
                 sdz[j] += (double)dz;
 #pragma unroll
                 for (int b = 0; b < 3; ++b)
-                    if (b < n) sxy[b][j] += (double)(dz * ((xb[b][j] - mu[b][j]) * is[b][j]));
+                    if (b < n) sxy[b][j] += (double)(dz * xb[b][j]);
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            atomicAdd(&s_acc[g * 8 + j], sdz[j]);
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(&s_acc[c0 + j], sdz[j]);
             for (int b = 0; b < n; ++b)
-                if (a.mean[b]) atomicAdd(&s_acc[(1 + b) * C + g * 8 + j], sxy[b][j]);
+                if (a.mean[b]) atomicAdd(&s_acc[(1 + b) * C + c0 + j], sxy[b][j]);
         }
     }
     __syncthreads();
     for (int i = tid; i < nacc; i += 256) atomicAdd(&a.ws[i], s_acc[i]);
     if (a.dalpha) {
-        // wave reduce then one atomic per wave
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s_alpha += __shfl_xor(s_alpha, o, 64);
         if ((tid & 63) == 0) atomicAdd(&a.ws[nacc], s_alpha);
     }
 }
 
-// pass 2: gradients wrt every branch input (and the shortcut)
-struct BwdConsts {          // per 8-channel group: everything that does not depend on the pixel
-    float sc[3][8], sh[3][8], mu[3][8], is[3][8], k1[3][8], mdz[8], mxy[3][8];
+// pass 2: gradients wrt every branch input (and the shortcut), 4 channels per thread (8-byte accesses: the per-channel
+// constants of 4 channels x 3 branches stay in ~50 registers).  With dz the activation gradient,
+//   dx_b = k1_b*(dz - mean(dz) - xhat_b*mean(dz*xhat_b)) = k1_b*dz + A_b*x_b + B_b,
+//   k1 = gamma*invstd,  m2 = (S_b - mu*S0)*invstd/N,  A = -k1*m2*invstd,  B = -k1*S0/N - A*mu     (S0 = sum dz, S_b = sum dz*x_b)
+struct BwdConsts4 {
+    float sc[3][4], k1[3][4], A[3][4], B[3][4], sht[4];
 };
-__device__ __forceinline__ void load_bwd_consts(const BnActBwdArgs& a, int g, BwdConsts& c) {
+__device__ __forceinline__ void load_bwd_consts4(const BnActBwdArgs& a, int c0, BwdConsts4& c) {
     const int C = a.f.C;
     const double invN = 1.0 / (double)a.f.npix;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c.mdz[j] = (float)(a.ws[g * 8 + j] * invN);
+    for (int j = 0; j < 4; ++j) c.sht[j] = 0.f;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         if (b >= a.f.n) break;
-        loadf8(a.f.scale[b] ? a.f.scale[b] + g * 8 : nullptr, c.sc[b], 1.f);
-        loadf8(a.f.shift[b] ? a.f.shift[b] + g * 8 : nullptr, c.sh[b], 0.f);
-        if (a.mean[b]) {
-            float ga[8];
-            loadf8(a.mean[b] + g * 8, c.mu[b], 0.f);
-            loadf8(a.invstd[b] + g * 8, c.is[b], 0.f);
-            loadf8(a.gamma[b] ? a.gamma[b] + g * 8 : nullptr, ga, 1.f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                c.k1[b][j] = ga[j] * c.is[b][j];
-                c.mxy[b][j] = (float)(a.ws[(1 + b) * C + g * 8 + j] * invN);
+        for (int j = 0; j < 4; ++j) {
+            const int ch = c0 + j;
+            c.sc[b][j] = a.f.scale[b] ? a.f.scale[b][ch] : 1.f;
+            c.sht[j] += a.f.shift[b] ? a.f.shift[b][ch] : 0.f;
+            if (a.mean[b]) {
+                const double s0 = a.ws[ch], sb = a.ws[(1 + b) * C + ch];
+                const float mu = a.mean[b][ch], is = a.invstd[b][ch];
+                const float k1 = (a.gamma[b] ? a.gamma[b][ch] : 1.f) * is;
+                const float m2 = (float)((sb - (double)mu * s0) * (double)is * invN);
+                c.k1[b][j] = k1;
+                c.A[b][j] = -k1 * m2 * is;
+                c.B[b][j] = -k1 * (float)(s0 * invN) - c.A[b][j] * mu;
+            } else {
+                c.k1[b][j] = c.sc[b][j];
+                c.A[b][j] = c.B[b][j] = 0.f;
             }
         }
     }
 }
 
-__device__ __forceinline__ void bwd_apply_one(const BnActBwdArgs& a, long p, int g, const BwdConsts& c, float alpha) {
+__device__ __forceinline__ void bwd_apply_one4(const BnActBwdArgs& a, long p, int c0, const BwdConsts4& c, float alpha) {
     const int n = a.f.n;
-    float z[8], xb[3][8], go[8], dz[8];
+    float z[4], xb[3][4], go[4], dz[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = 0.f;
+    for (int j = 0; j < 4; ++j) z[j] = c.sht[j];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         if (b >= n) break;
-        load8(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + g * 8, xb[b]);
+        load4(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + c0, xb[b]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) z[j] += xb[b][j] * c.sc[b][j] + c.sh[b][j];
+        for (int j = 0; j < 4; ++j) z[j] += xb[b][j] * c.sc[b][j];
     }
-    load8(a.dout + p * a.dcs + a.dco + g * 8, go);
+    load4(a.dout + p * a.dcs + a.dco + c0, go);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
+    for (int j = 0; j < 4; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
     if (a.dres) {
-        __half* q = a.dres + p * a.rcs + a.rco + g * 8;
-        float r[8];
-        if (a.racc) load8(q, r);
+        __half* q = a.dres + p * a.rcs + a.rco + c0;
+        float r[4];
+        if (a.racc) load4(q, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
-        store8(q, r);
+        for (int j = 0; j < 4; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
+        store4(q, r);
     }
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
         if (b >= n) break;
         if (!a.dx[b]) continue;
-        float d[8];
-        if (a.mean[b]) {
+        float d[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = (xb[b][j] - c.mu[b][j]) * c.is[b][j];
-                d[j] = c.k1[b][j] * (dz[j] - c.mdz[j] - xh * c.mxy[b][j]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] = dz[j] * c.sc[b][j];
-        }
+        for (int j = 0; j < 4; ++j) d[j] = c.k1[b][j] * dz[j] + c.A[b][j] * xb[b][j] + c.B[b][j];
         long q = p;
         if (a.xdil[b] == 2) {       // (b, y, x) of the logical grid -> (b, 2y, 2x) of the dilated buffer
-            const long hw = (long)a.H * a.W;
-            const long bi = p / hw, rem = p - bi * hw;
-            const long y = rem / a.W, x = rem - y * a.W;
-            q = (bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
+            const int hw = a.H * a.W;
+            const int bi = (int)(p / hw), rem = (int)(p - (long)bi * hw);
+            const int y = rem / a.W, x = rem - y * a.W;
+            q = ((long)bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
         }
-        __half* dst = a.dx[b] + q * a.xcs[b] + a.xco[b] + g * 8;
+        __half* dst = a.dx[b] + q * a.xcs[b] + a.xco[b] + c0;
         if (a.xacc[b]) {
-            float old[8];
-            load8(dst, old);
+            float old[4];
+            load4(dst, old);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] += old[j];
+            for (int j = 0; j < 4; ++j) d[j] += old[j];
         }
-        store8(dst, d);
+        store4(dst, d);
     }
 }
 
 __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs a) {
-    const int G = a.f.C >> 3;
+    const int G4 = a.f.C >> 2;
     const float alpha = a.f.res ? (a.f.alpha ? *a.f.alpha : 1.f) : 0.f;
-    BwdConsts c;
-    if (256 % G == 0) {            // a thread keeps ONE channel group: the per-channel constants stay in registers
-        const int g = threadIdx.x % G, rpb = 256 / G;
-        load_bwd_consts(a, g, c);
-        for (long p = (long)blockIdx.x * rpb + threadIdx.x / G; p < a.f.npix; p += (long)gridDim.x * rpb) bwd_apply_one(a, p, g, c, alpha);
+    BwdConsts4 c;
+    if (256 % G4 == 0) {            // a thread keeps ONE 4-channel group: its constants stay in registers
+        const int g = threadIdx.x % G4, rpb = 256 / G4;
+        load_bwd_consts4(a, g * 4, c);
+        for (long p = (long)blockIdx.x * rpb + threadIdx.x / G4; p < a.f.npix; p += (long)gridDim.x * rpb) bwd_apply_one4(a, p, g * 4, c, alpha);
         return;
     }
-    const long total = a.f.npix * G;
+    const long total = a.f.npix * G4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i / G;
-        const int g = (int)(i - p * G);
-        load_bwd_consts(a, g, c);
-        bwd_apply_one(a, p, g, c, alpha);
+        const long p = i / G4;
+        const int g = (int)(i - p * G4);
+        load_bwd_consts4(a, g * 4, c);
+        bwd_apply_one4(a, p, g * 4, c, alpha);
     }
 }
 
@@ -430,8 +456,9 @@ __global__ void bnact_bwd_params_kernel(const BnActBwdArgs a) {
     if (c >= C) return;
     for (int b = 0; b < a.f.n; ++b) {
         if (!a.mean[b]) continue;
-        if (a.dgamma[b]) a.dgamma[b][c] += (float)a.ws[(1 + b) * C + c];
-        if (a.dbeta[b]) a.dbeta[b][c] += (float)a.ws[c];
+        const double s0 = a.ws[c], sb = a.ws[(1 + b) * C + c];
+        if (a.dgamma[b]) a.dgamma[b][c] += (float)((sb - (double)a.mean[b][c] * s0) * (double)a.invstd[b][c]);
+        if (a.dbeta[b]) a.dbeta[b][c] += (float)s0;
     }
 }
 
@@ -443,7 +470,7 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     if (rc) return rc;
     const y6_tensor& ref = d->fwd.x[0];
     const int C = ref.C, n = d->fwd.n;
-    Y6_REQUIRE(C <= 2048, "bnact_backward: at most 2048 channels");
+    Y6_REQUIRE(C <= 1024, "bnact_backward: at most 1024 channels");
     Y6_REQUIRE(d->workspace_bytes >= y6_bnact_bwd_workspace_bytes(C), "bnact_backward: workspace too small");
     Y6_REQUIRE(view_ok(d->dout) && same_shape(d->dout, ref), "bnact_backward: bad dout view");
     a.dout = (const __half*)d->dout.data;
@@ -487,7 +514,7 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     a.ws = (double*)d->workspace;
     const size_t nacc = (size_t)(1 + n) * C + 1;
     Y6_HIP(hipMemsetAsync(a.ws, 0, nacc * sizeof(double), s));
-    const int G = C / 8, R = 256 / G;
+    const int G = C / 8, R = 256 / (C / 4);
     long ppb = (long)R * 32;
     long blocks = (a.f.npix + ppb - 1) / ppb;
     if (blocks > 2048) {
@@ -496,7 +523,7 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     }
     hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double), s, a, ppb);
     Y6_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid_for((size_t)a.f.npix * G, 256, 256 * 16)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid_for((size_t)a.f.npix * G * 2, 256, 256 * 16)), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();
     hipLaunchKernelGGL(bnact_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();

@@ -72,6 +72,18 @@ template <> struct Mode<Y6_WG_CONVT> {
 
 __device__ __forceinline__ h8_t as_h8(const u32x4 v) { return __builtin_bit_cast(h8_t, v); }
 
+// 16-byte global load the compiler cannot move or merge (see the operand-stream comment in the kernel); completion is
+// awaited explicitly with wait_vmcnt<N>, which also ties the awaited register so that its uses stay behind the wait.
+__device__ __forceinline__ void gload(u32x4& dst, const u32x4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt(u32x4& x) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N) : "memory");
+}
+// order a register of the same slot behind the wait that was tied to `w`
+__device__ __forceinline__ void tie(u32x4& x, u32x4& w) { asm volatile("" : "+v"(x), "+v"(w)::"memory"); }
+
 // [prev[7], cur[0..6]]  (element e of the result = element e-1 of the run sequence)
 __device__ __forceinline__ u32x4 shift_m1(const u32x4 prev, const u32x4 cur) {
     u32x4 o;
@@ -100,14 +112,21 @@ __global__ __launch_bounds__(256, kWavesPerSimd<MODE>) void wgrad_kernel(const W
     constexpr int NG = MD::NG, NSG = MD::NSG, NTG = MD::NTG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const long unit = (long)blockIdx.x * 4 + wave;
-    const long units = (long)a.mtiles * a.ntiles * NG * a.nsplit;
-    if (unit >= units) return;
+    // XCD-aware placement.  Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own
+    // L2.  Every (m, n, tap-group) tile of one pixel slice `ks` reads the SAME operand rows, so all tiles of a slice are
+    // put on one XCD, consecutively: the rows are fetched from HBM / Infinity Cache once instead of once per XCD
+    // (measured: the 8x redundant fetch, not the MFMA rate, bounded the large layers at ~330 TFLOP/s).
+    const int tg = a.mtiles * a.ntiles * NG;             // tiles x groups of one slice
+    const int bps = (tg + 3) >> 2;                        // blocks per slice (4 waves each)
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int slot = bi % bps;
+    const int ks = (bi / bps) * 8 + xcd;
+    const int u = slot * 4 + wave;
+    if (ks >= a.nsplit || u >= tg) return;
     // nt fastest, then the tap group: the waves of a block read the same A rows (L1 hits)
-    const int nt = (int)(unit % a.ntiles);
-    const int grp = (int)((unit / a.ntiles) % NG);
-    const int mt = (int)((unit / ((long)a.ntiles * NG)) % a.mtiles);
-    const int ks = (int)(unit / ((long)a.ntiles * NG * a.mtiles));
+    const int nt = u % a.ntiles;
+    const int grp = (u / a.ntiles) % NG;
+    const int mt = u / (a.ntiles * NG);
     const long total_rows = (long)a.B * a.rows;
     const long r0 = (long)ks * a.rows_per;
     long r1 = r0 + a.rows_per;
@@ -135,52 +154,103 @@ __global__ __launch_bounds__(256, kWavesPerSimd<MODE>) void wgrad_kernel(const W
         drow[s] = a.drow[grp * NSG + s];
     }
 
-    const u32x4 zero = {0u, 0u, 0u, 0u};
-    for (long r = r0; r < r1; ++r) {
-        const int b = (int)(r / a.rows), y = (int)(r - (long)b * a.rows);
-        // planes are [b][row][run][channel][8]: run j of channel c is the 16-byte word ((b*rows + row)*Qr + j)*ch + c
-        const u32x4* ap = reinterpret_cast<const u32x4*>(a.a) + (((size_t)b * a.a_rows + y) * Qr + j0) * a.a_ch + m;
-        const u32x4* bp[NSG];
+    // ---- operand stream ---------------------------------------------------------------------------------------------
+    // A row is walked in Qh + 2 "slots": slot i fetches run i-1 of A and of every B stream (clamped into the row), so the
+    // runs left and right of this half's range (the -1 / +1 column taps need them) arrive through the same stream.  The
+    // fetches run ahead of the MFMAs ACROSS row boundaries (rows are only 2 ... 10 k-steps long: a per-row prologue would
+    // expose one memory round trip per row).  Loads are issued from inline asm and awaited with an explicit s_waitcnt
+    // vmcnt(N): left to itself hipcc sinks prefetch loads down to their uses (to meet the occupancy target) and every
+    // k-step then waits a full round trip (measured 2200 cycles per k-step, 17 % MFMA duty).
+    // Ring of R = 5 slots, addressed statically (the loop is unrolled by R): when slot t has arrived, the ring holds slots
+    // t-2, t-1, t (= the -1 / 0 / +1 taps' runs, used in place - no copies) and t+1, t+2 in flight; entry (t-2) % R is
+    // refilled with slot t+3 after the MFMAs of step t.  A register with a load in flight is never read or moved.
+    constexpr int R = 5, LPS = NSG + 1;
+    const int nslot = Qh + 2;
+    const int lo = half ? -1 : 0;                      // first fetchable run relative to j0 (run -1 exists for the upper half)
+    const int hi = Qr - 1 - j0;                        // last run inside the row
+    const u32x4* const abase = reinterpret_cast<const u32x4*>(a.a);
+    const int sa = a.a_ch, sb = a.b_ch;                // 16-byte words between consecutive runs
+    long fr = r0;
+    int fi = 0;
+    int fb_ = (int)(r0 / a.rows), fy = (int)(r0 - (long)fb_ * a.rows);     // (image, row) of the fetch stream: no division in the loop
+    const u32x4* fap = abase;
+    const u32x4* fbp[NSG];
+    auto set_row_ptrs = [&]() {
+        fap = abase + (((size_t)fb_ * a.a_rows + fy) * Qr + j0) * sa + m;
 #pragma unroll
         for (int s = 0; s < NSG; ++s)
-            bp[s] = reinterpret_cast<const u32x4*>(pl[s]) + (((size_t)b * prow[s] + y + drow[s]) * Qr + j0) * a.b_ch + n;
-        const long sa = a.a_ch, sb = a.b_ch;      // word strides between consecutive runs
-        u32x4 prev[NSG], cur[NSG];
-        u32x4 av = ap[0];
+            fbp[s] = reinterpret_cast<const u32x4*>(pl[s]) + (((size_t)fb_ * prow[s] + fy + drow[s]) * Qr + j0) * sb + n;
+    };
+    set_row_ptrs();
+    auto fetch = [&](u32x4& fa, u32x4 (&fb)[NSG]) {    // issue the loads of slot (fr, fi), advance the stream
+        int ra = fi - 1;
+        ra = ra < 0 ? 0 : (ra > Qh - 1 ? Qh - 1 : ra);
+        int rb = fi - 1;
+        rb = rb < lo ? lo : (rb > hi ? hi : rb);
+        gload(fa, fap + ra * sa);
 #pragma unroll
-        for (int s = 0; s < NSG; ++s) {
-            cur[s] = bp[s][0];
-            prev[s] = zero;
-            if (MD::tap(s, 0) >= 0 && j0 > 0) prev[s] = bp[s][-sb];
+        for (int s = 0; s < NSG; ++s) gload(fb[s], fbp[s] + rb * sb);
+        if (++fi == nslot) {
+            fi = 0;
+            if (++fr < r1) {                           // past the end the stream re-reads the last row (never consumed)
+                if (++fy == a.rows) {
+                    fy = 0;
+                    ++fb_;
+                }
+                set_row_ptrs();
+            }
         }
-        for (int k = 0; k < Qh; ++k) {
-            // loads of the NEXT k-step are issued before this step's MFMAs
-            u32x4 next[NSG];
+    };
+    u32x4 qa[R], qb[R][NSG];
 #pragma unroll
-            for (int s = 0; s < NSG; ++s) {
-                next[s] = zero;
-                if ((MD::tap(s, 2) >= 0 || k + 1 < Qh) && (j0 + k + 1 < Qr)) next[s] = bp[s][(k + 1) * sb];
-            }
-            u32x4 an = zero;
-            if (k + 1 < Qh) an = ap[(k + 1) * sa];
-            const h8_t af = as_h8(av);
+    for (int d = 0; d < 3; ++d) fetch(qa[d], qb[d]);   // slots 0, 1, 2
+
+    const unsigned mlo = half ? 0xffffffffu : 0u, mhi = half ? 0u : 0xffffffffu;   // validity of run -1 / run Qh for this lane
+    const long nslots = (r1 - r0) * nslot;
+    int ci = 0;                                        // slot index inside the current row (compute stream)
+    for (long g = 0; g < nslots; g += R) {
 #pragma unroll
-            for (int s = 0; s < NSG; ++s) {
-                if (MD::tap(s, 0) >= 0)
-                    acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        af, as_h8(shift_m1(prev[s], cur[s])), acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0], 0, 0, 0);
-                if (MD::tap(s, 1) >= 0)
-                    acc[MD::tap(s, 1) >= 0 ? MD::tap(s, 1) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        af, as_h8(cur[s]), acc[MD::tap(s, 1) >= 0 ? MD::tap(s, 1) : 0], 0, 0, 0);
-                if (MD::tap(s, 2) >= 0)
-                    acc[MD::tap(s, 2) >= 0 ? MD::tap(s, 2) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                        af, as_h8(shift_p1(cur[s], next[s])), acc[MD::tap(s, 2) >= 0 ? MD::tap(s, 2) : 0], 0, 0, 0);
-                prev[s] = cur[s];
-                cur[s] = next[s];
+        for (int d = 0; d < R; ++d) {
+            if (g + d >= nslots) break;
+            constexpr int dummy = 0;
+            // entries: next = d, cur = d-1, prev = d-2 (mod R); refill target = d+3 (mod R) = prev's successor cycle
+            const int e_next = d, e_cur = (d + R - 1) % R, e_prev = (d + R - 2) % R, e_fill = (d + 3) % R;
+            wait_vmcnt<2 * LPS>(qa[e_next]);           // slots t+1, t+2 may be in flight; slot t has arrived
+#pragma unroll
+            for (int s = 0; s < NSG; ++s) tie(qb[e_next][s], qa[e_next]);
+            const int i = ci;
+            ci = ci + 1 == nslot ? 0 : ci + 1;
+            if (i >= 2) {                              // k = i - 2: A run k (slot t-1), B runs k-1, k, k+1 (slots t-2, t-1, t)
+                const h8_t af = as_h8(qa[e_cur]);
+                const bool first = i == 2, last = i == nslot - 1;
+#pragma unroll
+                for (int s = 0; s < NSG; ++s) {
+                    if (MD::tap(s, 0) >= 0) {
+                        u32x4 pv = qb[e_prev][s];
+                        if (first) pv[3] &= mlo;       // only element 7 of the previous run is used
+                        acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            af, as_h8(shift_m1(pv, qb[e_cur][s])), acc[MD::tap(s, 0) >= 0 ? MD::tap(s, 0) : 0], 0, 0, 0);
+                    }
+                    if (MD::tap(s, 1) >= 0)
+                        acc[MD::tap(s, 1) >= 0 ? MD::tap(s, 1) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            af, as_h8(qb[e_cur][s]), acc[MD::tap(s, 1) >= 0 ? MD::tap(s, 1) : 0], 0, 0, 0);
+                    if (MD::tap(s, 2) >= 0) {
+                        u32x4 nx = qb[e_next][s];
+                        if (last) nx[0] &= mhi;        // only element 0 of the next run is used
+                        acc[MD::tap(s, 2) >= 0 ? MD::tap(s, 2) : 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            af, as_h8(shift_p1(qb[e_cur][s], nx)), acc[MD::tap(s, 2) >= 0 ? MD::tap(s, 2) : 0], 0, 0, 0);
+                    }
+                }
             }
-            av = an;
+            // entry e_fill held slot t-2 (consumed above as `prev`): refill it with slot t+3.  The MFMAs that read it were
+            // issued; the in-order VMEM return writes it long after they have read their operands.
+            fetch(qa[e_fill], qb[e_fill]);
+            (void)dummy;
         }
     }
+    wait_vmcnt<0>(qa[0]);                              // drain the look-ahead fetches before the registers die
+#pragma unroll
+    for (int d = 1; d < R; ++d) tie(qa[d], qa[0]);
     // C/D layout: column n = lane & 31, row m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).
     // The slice's partial tile goes to the workspace with plain stores (n contiguous across lanes); wgrad_reduce_kernel
     // sums the slices.  (Device-scope float atomics from eight XCDs resolve at the memory side: 25 M of them per launch
@@ -260,8 +330,8 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     a.T = T;
     a.rows_per = (int)((total_rows + nsplit - 1) / nsplit);
     a.nsplit = (int)((total_rows + a.rows_per - 1) / a.rows_per);
-    const long units = tiles * a.nsplit;
-    const unsigned grid = (unsigned)((units + 3) / 4);
+    const long bps = (tiles + 3) / 4;                               // blocks per slice; slices are dealt to the 8 XCDs
+    const unsigned grid = (unsigned)(8 * ((a.nsplit + 7) / 8) * bps);
     switch (d->mode) {
         case Y6_WG_3X3S1: hipLaunchKernelGGL(wgrad_kernel<Y6_WG_3X3S1>, dim3(grid), dim3(256), 0, s, a); break;
         case Y6_WG_1X1: hipLaunchKernelGGL(wgrad_kernel<Y6_WG_1X1>, dim3(grid), dim3(256), 0, s, a); break;
