@@ -37,7 +37,7 @@ enum { Y6_OK = 0, Y6_EINVAL = -1, Y6_EHIP = -2, Y6_EUNSUPPORTED = -3, Y6_ENOMEM 
 enum { Y6_ACT_NONE = 0, Y6_ACT_RELU = 1, Y6_ACT_SILU = 2, Y6_ACT_HARDSWISH = 3 };
 
 /* dtype tags for boundary tensors */
-enum { Y6_F16 = 0, Y6_F32 = 1 };
+enum { Y6_F16 = 0, Y6_F32 = 1, Y6_U8 = 2 /* stem input only: uint8 pixels, read as imgs.half()/255 (core/evaler.py:121-123) */ };
 
 int y6_abi_version(void);
 const char* y6_last_error(void);
@@ -112,7 +112,8 @@ int y6_convt2x2(const y6_convt_desc* d, void* stream);
 /* Stem: 3x3 stride-2 pad-1 conv reading the caller's NCHW image directly (Cin <= 4) and
  * writing NHWC fp16, + bias + activation (+ optional post affine).
  * Replaces: EfficientRep.stem (RepVGGBlock deploy form)  yolov6/models/efficientrep.py:28-33
- * in_nchw: [B][Cin][H][W] fp16 or fp32 (in_dtype); w: OIHW fp32 [Cout][Cin][3][3].         */
+ * in_nchw: [B][Cin][H][W] fp16, fp32 or uint8 (in_dtype; uint8 pixels enter as the fp16 value of u/255,
+ * the `imgs.half(); imgs /= 255` of core/evaler.py:121-123 folded into the load); w: OIHW fp32 [Cout][Cin][3][3]. */
 typedef struct y6_stem_desc {
     const void* in_nchw;
     int32_t in_dtype;

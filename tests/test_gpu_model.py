@@ -185,3 +185,27 @@ def test_block_level_forward_matches_oracle():
     out = blk.to(DEV).half()(x.to(DEV).half())
     assert out.shape == ref.shape and out.dtype == torch.float16
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) < 3e-3   # unfused fp32 vs fused fp16 weights
+
+
+def test_uint8_images_equal_half_div255():
+    """Input boundary: uint8 pixels fed straight to the stem == `imgs.half(); imgs /= 255` (core/evaler.py:121-123)
+    followed by the fp16 path, bit for bit - the conversion pass and the fp16 copy of the batch disappear."""
+    cfg, meta, sd, m = _build("tiny", deploy=True)
+    g = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (2, 3, 64, 64), generator=g, dtype=torch.uint8).to(DEV)
+    ref, _ = m(u8.half() / 255)
+    got, _ = m(u8)
+    assert torch.equal(got, ref)
+    # the non-vectorised stem kernels too (width not a multiple of 8 / unaligned rows)
+    from yolov6_amd.engine import NCHWInput, PlanBuilder
+    w = torch.randn((16, 3, 3, 3), generator=g) * 0.2
+    b = torch.randn((16,), generator=g) * 0.1
+    u8b = torch.randint(0, 256, (2, 3, 18, 22), generator=g, dtype=torch.uint8).to(DEV)
+    outs = []
+    for x in (u8b, (u8b.half() / 255).contiguous()):
+        pb = PlanBuilder(DEV)
+        o = pb.conv(NCHWInput(x), w, b, stride=2, act="relu")
+        pb.finalize(o, autotune=False).run()
+        torch.cuda.synchronize()
+        outs.append(o.to_nhwc_tensor().clone())
+    assert torch.equal(outs[0], outs[1])

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # Y6_LIB_PATH: developer override (e.g. a ceiling-probe build from tools/build_probe_libs.py); never a fallback
 LIB_PATH = os.environ.get("Y6_LIB_PATH") or os.path.join(_HERE, "lib", "libyolov6_hip.so")
 
-Y6_F16, Y6_F32 = 0, 1
+Y6_F16, Y6_F32, Y6_U8 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_HARDSWISH = 0, 1, 2, 3
 ACT_BY_NAME = {None: ACT_NONE, "relu": ACT_RELU, "silu": ACT_SILU, "hardswish": ACT_HARDSWISH}
 MAX_LEVELS = 4

@@ -101,6 +101,14 @@ __global__ void conv_naive_kernel(const __half* __restrict__ in, __half* __restr
 // ------------------------------------------------------------------ stem conv (NCHW in, NHWC out)
 // One thread = one output pixel x CO couts.  Weights are read with wave-uniform indices
 // (scalar loads); the 27 input taps are per-lane loads of neighbouring NCHW elements.
+// Input element of the caller's image as the fp16 value the reference's model sees: fp16 / fp32 tensors as they are,
+// uint8 pixels as `imgs.half() / 255` (core/evaler.py:121-123) = the fp16 rounding of u / 255 - computed in the kernel, so
+// the uint8 batch is read once (1 byte per element) and no converted copy is ever written.
+template <typename TI>
+__device__ __forceinline__ float stem_in(TI v) { return (float)v; }
+template <>
+__device__ __forceinline__ float stem_in<uint8_t>(uint8_t v) { return (float)(_Float16)((float)v / 255.f); }
+
 template <typename TI, int CO>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ in, __half* __restrict__ out,
                                                         const float* __restrict__ w /*[CO][Cin][3][3]*/,
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TI* __restrict__ i
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * 2 - 1 + kx;
                 float v = 0.f;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (float)in[(((size_t)b * Cin + ci) * H + iy) * W + ix];
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = stem_in<TI>(in[(((size_t)b * Cin + ci) * H + iy) * W + ix]);
                 const float* wp = w + (ci * 3 + ky) * 3 + kx;
 #pragma unroll
                 for (int c = 0; c < CO; ++c) acc[c] = fmaf(v, wp[(size_t)c * Cin * 9], acc[c]);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
         const int yy = r / STEM_IW, xx = r - yy * STEM_IW;
         const int iy = iy0 + yy, ix = ix0 + xx;
         float v = 0.f;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = (float)in[((size_t)b * Cin + ci) * HW + (size_t)iy * W + ix];
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = stem_in<TI>(in[((size_t)b * Cin + ci) * HW + (size_t)iy * W + ix]);
         s_in[(ci * STEM_IH + yy) * STEM_PITCH + xx] = (_Float16)v;
     }
 
@@ -319,6 +327,22 @@ struct StemPiece<float> {
     __device__ __forceinline__ uint4 as_half8() const {
         h8_t h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
                   (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+        return *reinterpret_cast<const uint4*>(&h);
+    }
+};
+
+template <>
+struct StemPiece<uint8_t> {      // 8 pixels = 8 bytes; converted to the fp16 values of `imgs.half() / 255`
+    uint2 v;
+    __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint2*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint2(0u, 0u); }
+    __device__ __forceinline__ uint4 as_half8() const {
+        h8_t h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned b = ((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xffu;
+            h[j] = (_Float16)((float)b / 255.f);
+        }
         return *reinterpret_cast<const uint4*>(&h);
     }
 };
@@ -764,10 +788,11 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     hipLaunchKernelGGL((stem_mfma_kernel<TI, CF_>), g, blk, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data,      \
                        d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo, CO, \
                        d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
-        const size_t esz = d->in_dtype == Y6_F16 ? 2 : 4;
+        const size_t esz = d->in_dtype == Y6_F16 ? 2 : (d->in_dtype == Y6_U8 ? 1 : 4);
         static const bool no_v4 = getenv("Y6_STEM_NO_V4") != nullptr;   // A/B switch for profiling
-        if (!no_v4 && d->Cin == 3 && d->W % 8 == 0 && ((uintptr_t)d->in_nchw & 15) == 0 && ((size_t)d->H * d->W * esz) % 16 == 0 &&
-            (d->in_dtype == Y6_F16 || d->in_dtype == Y6_F32)) {
+        const size_t palign = 8 * esz;     // one piece = 8 pixels
+        if (!no_v4 && d->Cin == 3 && d->W % 8 == 0 && ((uintptr_t)d->in_nchw % palign) == 0 && ((size_t)d->H * d->W * esz) % palign == 0 &&
+            (d->in_dtype == Y6_F16 || d->in_dtype == Y6_F32 || d->in_dtype == Y6_U8)) {
             static int n_cu = 0;
             if (n_cu == 0) {
                 int dev = 0;
@@ -783,6 +808,8 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
                        Ho, Wo, CO, d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
             if (d->in_dtype == Y6_F16) {
                 if (CO <= 32) Y6_STEM_V4(__half, 1); else Y6_STEM_V4(__half, 2);
+            } else if (d->in_dtype == Y6_U8) {
+                if (CO <= 32) Y6_STEM_V4(uint8_t, 1); else Y6_STEM_V4(uint8_t, 2);
             } else {
                 if (CO <= 32) Y6_STEM_V4(float, 1); else Y6_STEM_V4(float, 2);
             }
@@ -794,6 +821,8 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
             if (CO <= 32) Y6_STEM_MFMA(__half, 1); else Y6_STEM_MFMA(__half, 2);
         } else if (d->in_dtype == Y6_F32) {
             if (CO <= 32) Y6_STEM_MFMA(float, 1); else Y6_STEM_MFMA(float, 2);
+        } else if (d->in_dtype == Y6_U8) {
+            if (CO <= 32) Y6_STEM_MFMA(uint8_t, 1); else Y6_STEM_MFMA(uint8_t, 2);
         } else {
             Y6_REQUIRE(false, "stem_conv: bad input dtype");
         }
@@ -813,6 +842,15 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
             case 32: Y6_STEM_CASE(__half, 32); break;
             case 48: Y6_STEM_CASE(__half, 48); break;
             case 64: Y6_STEM_CASE(__half, 64); break;
+            default: Y6_REQUIRE(false, "stem_conv: Cout %d unsupported (8,16,32,48,64)", CO);
+        }
+    } else if (d->in_dtype == Y6_U8) {
+        switch (CO) {
+            case 8: Y6_STEM_CASE(uint8_t, 8); break;
+            case 16: Y6_STEM_CASE(uint8_t, 16); break;
+            case 32: Y6_STEM_CASE(uint8_t, 32); break;
+            case 48: Y6_STEM_CASE(uint8_t, 48); break;
+            case 64: Y6_STEM_CASE(uint8_t, 64); break;
             default: Y6_REQUIRE(false, "stem_conv: Cout %d unsupported (8,16,32,48,64)", CO);
         }
     } else if (d->in_dtype == Y6_F32) {

@@ -591,7 +591,10 @@ __global__ void wt_nchw_kernel(const T* __restrict__ src, int B, int H, int W, i
         for (int j = 0; j < 8; ++j) {
             const int x = (run * 8 + j) * sx + ox;
             float v = 0.f;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = (float)src[(((size_t)b * C + c) * H + y) * W + x];
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                if constexpr (sizeof(T) == 1) v = (float)src[(((size_t)b * C + c) * H + y) * W + x] / 255.f;   // uint8 pixels -> u/255
+                else v = (float)src[(((size_t)b * C + c) * H + y) * W + x];
+            }
             o[j] = (_Float16)v;
         }
         *reinterpret_cast<h8_t*>(dst + i * 8) = o;
@@ -610,6 +613,9 @@ int wgrad_transpose_launch(const y6_wgrad_t_desc* d, hipStream_t s) {
                                t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst);
         else if (d->src_dtype == Y6_F32)
             hipLaunchKernelGGL(wt_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)t.data, t.B, t.H,
+                               t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst);
+        else if (d->src_dtype == Y6_U8)
+            hipLaunchKernelGGL(wt_nchw_kernel<uint8_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const uint8_t*)t.data, t.B, t.H,
                                t.W, t.C, d->sy, d->sx, d->oy, d->ox, d->R, d->Q, (__half*)d->dst);
         else
             Y6_REQUIRE(false, "wgrad_transpose: bad dtype %d", d->src_dtype);

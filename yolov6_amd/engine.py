@@ -11,7 +11,7 @@ from typing import List, Optional
 import torch
 
 from . import _lib
-from ._lib import ACT_BY_NAME, Y6_F16, Y6_F32
+from ._lib import ACT_BY_NAME, Y6_F16, Y6_F32, Y6_U8
 
 
 @dataclass
@@ -52,7 +52,9 @@ def _dtype_tag(t: torch.Tensor) -> int:
         return Y6_F16
     if t.dtype == torch.float32:
         return Y6_F32
-    raise RuntimeError(f"yolov6_amd: unsupported dtype {t.dtype} (fp16 / fp32 only)")
+    if t.dtype == torch.uint8:
+        return Y6_U8            # the stem only: pixels enter as imgs.half() / 255 (core/evaler.py:121-123)
+    raise RuntimeError(f"yolov6_amd: unsupported dtype {t.dtype} (fp16 / fp32, uint8 images at the stem)")
 
 
 def _null_tensor() -> _lib.Tensor:
