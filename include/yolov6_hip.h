@@ -276,6 +276,9 @@ typedef struct y6_loss_desc {
     double* out;                   /* [6] */
     void* workspace;
     size_t workspace_bytes;
+    int32_t box_mode;              /* 0: pred_distri are (l,t,r,b) distances / DFL logits (loss.py:194-198);
+                                      1: (dx, dy, w, h) around the anchor point, the anchor-based branch of loss_fuseab.py:75-76
+                                         (`pred_distri[..., :2] += anchor_points_s; xywh2xyxy`) - gradient only, use_dfl must be 0 */
 } y6_loss_desc;
 int y6_bbox_decode(const float* pred_distri, const float* anchor_points_s, int B, int A, int use_dfl, int reg_max,
                    float* pred_bboxes, void* stream);
@@ -466,6 +469,24 @@ typedef struct y6_head_pack_desc {
 int y6_head_pack(const y6_head_pack_desc* d, void* stream);
 int y6_head_unpack_backward(const y6_head_pack_desc* d, void* stream);
 
+/* fuse_ab head, anchor-based auxiliary branch of the training step (yolov6/models/heads/effidehead_fuseab.py:110-124):
+ * per level cls_ab [B,H,W,na*nc] -> sigmoid -> scores [B, A_ab, nc] with anchors ordered (level, anchor, pixel);
+ * reg_ab [B,H,W,na*4] -> (dx, dy, (2 sigmoid(w))^2 * aw, (2 sigmoid(h))^2 * ah) -> distri [B, A_ab, 4]; and the backward
+ * (cls / reg then hold the GRADIENT maps; reg_fwd the forward reg maps the box transform's derivative needs).
+ * anchors: HOST values [level][3][2] = anchors_init / stride. */
+typedef struct y6_head_ab_desc {
+    int32_t n_levels, nc, na;
+    y6_tensor cls[4], reg[4];
+    y6_tensor reg_fwd[4];          /* backward only */
+    float anchors[24];
+    float* scores;                 /* [B, A_ab, nc] */
+    float* distri;                 /* [B, A_ab, 4] */
+    const float* dscores;          /* backward only */
+    const float* ddistri;
+} y6_head_ab_desc;
+int y6_head_ab_pack(const y6_head_ab_desc* d, void* stream);
+int y6_head_ab_unpack_backward(const y6_head_ab_desc* d, void* stream);
+
 /* space-to-depth for ConvTranspose2d's data gradient: dst[b,y,x,sub*C + c] = src[b,2y+dy,2x+dx,c], sub = dy*2+dx */
 int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, void* stream);
 /* dst[b,y,x,:] = src[b,2y,2x,:] - the input sampling of a 1x1 stride-2 conv (RepVGG's rbr_1x1 in the stride-2 blocks,
@@ -517,6 +538,8 @@ int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d);
 int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
 int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);
 int y6_plan_add_head_unpack_backward(y6_plan* p, const y6_head_pack_desc* d);
+int y6_plan_add_head_ab_pack(y6_plan* p, const y6_head_ab_desc* d);
+int y6_plan_add_head_ab_unpack_backward(y6_plan* p, const y6_head_ab_desc* d);
 int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
 int y6_plan_add_subsample2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
 int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes);

@@ -60,7 +60,7 @@ def iou_loss(b1, b2, iou_type, eps=1e-10):
 
 
 def loss_and_grads(pred_scores, pred_distri, anchor_points_s, target_labels, target_bboxes_s, target_scores, fg_mask,
-                   num_classes, use_dfl, reg_max, iou_type, loss_weight=None, dtype=torch.float64):
+                   num_classes, use_dfl, reg_max, iou_type, loss_weight=None, dtype=torch.float64, ab=False):
     """target_bboxes_s: already divided by the stride (loss.py:154).  Returns (loss, items[iou,dfl,cls], dscores, ddistri)."""
     lw = loss_weight or {"class": 1.0, "iou": 2.5, "dfl": 0.5}
     ps = torch.as_tensor(np.asarray(pred_scores), dtype=dtype).clone().requires_grad_(True)
@@ -71,12 +71,16 @@ def loss_and_grads(pred_scores, pred_distri, anchor_points_s, target_labels, tar
     ts = torch.as_tensor(np.asarray(target_scores), dtype=dtype)
     fg = torch.as_tensor(np.asarray(fg_mask)).bool()
     B, A, _ = ps.shape
-    if use_dfl:
-        prob = F.softmax(pdist.view(B, A, 4, reg_max + 1), dim=-1)
-        dist = prob.matmul(torch.linspace(0, reg_max, reg_max + 1, dtype=dtype))
+    if ab:        # loss_fuseab.py:75-76: (dx, dy, w, h) around the anchor point; xywh2xyxy with x2 = x1 + w
+        x1y1 = pdist[..., :2] + pts - pdist[..., 2:] * 0.5
+        pb = torch.cat([x1y1, x1y1 + pdist[..., 2:]], -1)
     else:
-        dist = pdist
-    pb = torch.cat([pts - dist[..., :2], pts + dist[..., 2:]], -1)
+        if use_dfl:
+            prob = F.softmax(pdist.view(B, A, 4, reg_max + 1), dim=-1)
+            dist = prob.matmul(torch.linspace(0, reg_max, reg_max + 1, dtype=dtype))
+        else:
+            dist = pdist
+        pb = torch.cat([pts - dist[..., :2], pts + dist[..., 2:]], -1)
     tl = torch.where(fg, tl, torch.full_like(tl, num_classes))
     one_hot = F.one_hot(tl, num_classes + 1)[..., :-1].to(dtype)
     weight = 0.75 * ps.pow(2.0) * (1 - one_hot) + ts * one_hot
@@ -110,8 +114,9 @@ def compute_loss_with_grads(feat_sizes, pred_scores, pred_distri, targets, epoch
     """The whole ComputeLoss call: numpy oracle for the assignment, autograd restatement for the value and gradients."""
     r = loss_oracle.compute_loss(feat_sizes, pred_scores, pred_distri, targets, epoch_num, batch_height, batch_width, **kw)
     strides = kw.get("fpn_strides", (8, 16, 32))
-    _, pts, _, st = loss_oracle.generate_anchors(feat_sizes, strides, kw.get("grid_cell_size", 5.0), kw.get("grid_cell_offset", 0.5))
+    _, pts, _, st = loss_oracle.generate_anchors(feat_sizes, strides, kw.get("grid_cell_size", 5.0), kw.get("grid_cell_offset", 0.5),
+                                                 rep=3 if kw.get("ab") else 1)
     out = loss_and_grads(pred_scores, pred_distri, pts / st, r["target_labels"], r["target_bboxes"], r["target_scores"], r["fg_mask"],
                          kw.get("num_classes", 80), kw.get("use_dfl", True), kw.get("reg_max", 16), kw.get("iou_type", "giou"),
-                         kw.get("loss_weight"))
+                         kw.get("loss_weight"), ab=bool(kw.get("ab")))
     return dict(loss=out[0], loss_items=out[1], dscores=out[2], ddistri=out[3], assign=r)

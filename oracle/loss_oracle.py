@@ -135,8 +135,9 @@ def df_loss(pred_dist, target, reg_max):
     return ((ce_l * wl + ce_r * wr).mean(-1, keepdims=True, dtype=f32)).astype(f32)
 
 
-def generate_anchors(feat_sizes, strides, grid_cell_size=5.0, grid_cell_offset=0.5):
-    """Train-form anchors (anchor_generator.py:35-63): anchors [A,4], points [A,2] px, per-level counts, stride [A,1]."""
+def generate_anchors(feat_sizes, strides, grid_cell_size=5.0, grid_cell_offset=0.5, rep=1):
+    """Train-form anchors (anchor_generator.py:35-63): anchors [A,4], points [A,2] px, per-level counts, stride [A,1].
+    rep=3 is mode='ab' (:52-60): every level's grid repeated three times (anchor-major), as loss_fuseab.py:60-61 asks."""
     anchors, points, n_list, stride_t = [], [], [], []
     for (h, w), s in zip(feat_sizes, strides):
         cell_half = grid_cell_size * s * 0.5
@@ -144,34 +145,41 @@ def generate_anchors(feat_sizes, strides, grid_cell_size=5.0, grid_cell_offset=0
         sy = (np.arange(h, dtype=f32) + f32(grid_cell_offset)) * f32(s)
         yy, xx = np.meshgrid(sy, sx, indexing="ij")
         a = np.stack([xx - f32(cell_half), yy - f32(cell_half), xx + f32(cell_half), yy + f32(cell_half)], -1)
-        anchors.append(a.reshape(-1, 4).astype(f32))
-        points.append(np.stack([xx, yy], -1).reshape(-1, 2).astype(f32))
-        n_list.append(h * w)
-        stride_t.append(np.full((h * w, 1), s, f32))
+        anchors.append(np.tile(a.reshape(-1, 4).astype(f32), (rep, 1)))
+        points.append(np.tile(np.stack([xx, yy], -1).reshape(-1, 2).astype(f32), (rep, 1)))
+        n_list.append(h * w * rep)
+        stride_t.append(np.full((h * w * rep, 1), s, f32))
     return np.concatenate(anchors), np.concatenate(points), n_list, np.concatenate(stride_t)
 
 
 def compute_loss(feat_sizes, pred_scores, pred_distri, targets, epoch_num, batch_height, batch_width,
                  fpn_strides=(8, 16, 32), grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, warmup_epoch=4,
-                 use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None):
-    """loss.py:52-182.  Returns dict(loss, loss_items[iou, dfl, cls] (weighted), plus the intermediates)."""
+                 use_dfl=True, reg_max=16, iou_type="giou", loss_weight=None, ab=False):
+    """loss.py:52-182.  Returns dict(loss, loss_items[iou, dfl, cls] (weighted), plus the intermediates).
+    ab=True: the anchor-based variant, loss_fuseab.py:39-147 (anchors x3, boxes from (dx,dy,w,h), TAL topk 26, no warm-up)."""
     lw = loss_weight or {"class": 1.0, "iou": 2.5, "dfl": 0.5}
     pred_scores = np.asarray(pred_scores, f32)
     pred_distri = np.asarray(pred_distri, f32)
     B = pred_scores.shape[0]
-    anchors, anchor_points, n_list, stride_t = generate_anchors(feat_sizes, fpn_strides, grid_cell_size, grid_cell_offset)
+    anchors, anchor_points, n_list, stride_t = generate_anchors(feat_sizes, fpn_strides, grid_cell_size, grid_cell_offset,
+                                                                 rep=3 if ab else 1)
     scale = np.asarray([batch_width, batch_height, batch_width, batch_height], f32)
     tg = preprocess(targets, B, scale)
     gt_labels, gt_bboxes = tg[:, :, :1], tg[:, :, 1:]
     mask_gt = (gt_bboxes.sum(-1, keepdims=True) > 0).astype(f32)
     anchor_points_s = anchor_points / stride_t
-    pred_bboxes = bbox_decode(anchor_points_s, pred_distri, use_dfl, reg_max)
-    if epoch_num < warmup_epoch:
+    if ab:        # loss_fuseab.py:75-76 (+ general.py:52-58: x2 = x1 + w)
+        cxy = pred_distri[..., :2] + anchor_points_s
+        x1y1 = cxy - pred_distri[..., 2:] * f32(0.5)
+        pred_bboxes = np.concatenate([x1y1, x1y1 + pred_distri[..., 2:]], -1).astype(f32)
+    else:
+        pred_bboxes = bbox_decode(anchor_points_s, pred_distri, use_dfl, reg_max)
+    if epoch_num < warmup_epoch and not ab:
         tl, tb, ts, fg = atss_oracle.assign(anchors, n_list, gt_labels, gt_bboxes, mask_gt, pred_bboxes * stride_t,
                                             topk=9, num_classes=num_classes)
     else:
         tl, tb, ts, fg = tal_oracle.assign(pred_scores, pred_bboxes * stride_t, anchor_points, gt_labels, gt_bboxes,
-                                           mask_gt, topk=13, num_classes=num_classes, alpha=1.0, beta=6.0)
+                                           mask_gt, topk=26 if ab else 13, num_classes=num_classes, alpha=1.0, beta=6.0)
     tb = (tb / stride_t).astype(f32)
     fg = fg.astype(bool)
     tl = np.where(fg, tl, num_classes)

@@ -469,6 +469,34 @@ class TrainOracle(Oracle):
             reg_l.append(ro.flatten(2).permute(0, 2, 1))
         return xs, torch.cat(cls_l, 1), torch.cat(reg_l, 1)
 
+    def head_train_fuseab(self, feats, anchors_init, na=3):
+        """Detect training branch with the anchor-based auxiliary predictions (heads/effidehead_fuseab.py:94-139).
+        -> stems, cls_ab [B,na*A,nc], reg_ab [B,na*A,4], cls_af [B,A,nc], reg_af [B,A,4*(reg_max+1)]"""
+        sd = self.sd
+        anc = torch.as_tensor(anchors_init, dtype=torch.float32).reshape(len(feats), na, 2) / \
+            torch.tensor(self.a.strides, dtype=torch.float32).view(-1, 1, 1)
+        xs, cab, rab, caf, raf = [], [], [], [], []
+        for i, x in enumerate(feats):
+            b, _, h, w = x.shape
+            f = self.convbn(x, f"detect.stems.{i}", "silu")
+            c = self.convbn(f, f"detect.cls_convs.{i}", "silu")
+            r = self.convbn(f, f"detect.reg_convs.{i}", "silu")
+            xs.append(f)
+            co = torch.sigmoid(self.c2d(c, sd[f"detect.cls_preds_ab.{i}.weight"], sd[f"detect.cls_preds_ab.{i}.bias"]))
+            cab.append(co.reshape(b, na, -1, h, w).permute(0, 1, 3, 4, 2).flatten(1, 3))
+            ro = self.c2d(r, sd[f"detect.reg_preds_ab.{i}.weight"], sd[f"detect.reg_preds_ab.{i}.bias"])
+            ro = ro.reshape(b, na, -1, h, w).permute(0, 1, 3, 4, 2)
+            wh = ((ro[..., 2:4].sigmoid() * 2) ** 2) * anc[i].reshape(1, na, 1, 1, 2)
+            rab.append(torch.cat([ro[..., :2], wh], -1).flatten(1, 3))
+            caf.append(torch.sigmoid(self.c2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])).flatten(2).permute(0, 2, 1))
+            raf.append(self.c2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"]).flatten(2).permute(0, 2, 1))
+        return xs, torch.cat(cab, 1), torch.cat(rab, 1), torch.cat(caf, 1), torch.cat(raf, 1)
+
+    def forward_train_fuseab(self, x, anchors_init):
+        self.new_stats = {}
+        feats = self.neck(self.backbone(x.float()))
+        return self.head_train_fuseab(list(feats), anchors_init), feats
+
     def forward_train(self, x):
         """-> (head stem outputs per level, cls_scores [B,A,nc], reg_distri [B,A,4*(reg_max+1)]), neck featmaps."""
         self.new_stats = {}

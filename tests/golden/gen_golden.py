@@ -281,9 +281,67 @@ def gen_loss():
                             dscores=ps.grad.numpy(), ddistri=pd.grad.numpy())
 
 
+FUSEAB_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "neck.Rep_p3.conv1.rbr_1x1.bn.weight", "detect.cls_convs.1.block.conv.weight",
+                      "detect.cls_preds_ab.0.weight", "detect.reg_preds_ab.1.bias", "detect.reg_preds_ab.2.weight", "detect.cls_preds.2.bias"]
+LOSSAB_CASES = {
+    # name: (B, feat sizes, strides, C, iou_type, seed)
+    "giou": (3, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 20, "giou", 0),
+    "siou": (2, [(16, 16), (8, 8), (4, 4)], [8, 16, 32], 80, "siou", 1),
+}
+
+
+def gen_fuseab():
+    """fuse_ab: reference Model(fuse_ab=True) in TRAINING mode - the five head outputs of
+    models/heads/effidehead_fuseab.py:139 - with reference gradients, the state_dict keys, and the anchor-based
+    ComputeLoss (models/losses/loss_fuseab.py) value + gradients."""
+    import torch.nn as nn
+    from yolov6.models.yolo import Model
+    cfile, over, size, batch, nc = MODEL_CASES["tiny"]
+    cfg = ref_config(cfile, over)
+    torch.manual_seed(0)
+    model = Model(cfg, channels=3, num_classes=nc, fuse_ab=True)
+    sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    with open(os.path.join(HERE, "keys_tiny_fuseab.json"), "w") as f:
+        json.dump(dict(config=cfile, overrides=over, size=size, batch=batch, num_classes=nc, training_mode=cfg.training_mode,
+                       train={k: list(v.shape) for k, v in model.state_dict().items()},
+                       anchors_init=cfg.model.head.anchors_init), f)
+    model.train()
+    x = synth.synth_images(max(batch, 2), size, seed=21)
+    (xs, cls_ab, reg_ab, cls_af, reg_af), featmaps = model(x)
+    scalar = (cls_ab * cls_ab).sum() + reg_ab.square().mean() + (cls_af * cls_af).sum() + reg_af.square().mean()
+    model.zero_grad()
+    scalar.backward()
+    params = dict(model.named_parameters())
+    out = dict(cls_ab=cls_ab.detach().numpy(), reg_ab=reg_ab.detach().numpy(), cls_af=cls_af.detach().numpy(),
+               reg_af=reg_af.detach().numpy(), scalar=np.float64(float(scalar)))
+    for q in FUSEAB_GRAD_PROBES:
+        out["grad:" + q] = params[q].grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "fuseab_train_tiny.npz"), **out)
+    print(f"train_tiny_fuseab: cls_ab {tuple(cls_ab.shape)} reg_ab {tuple(reg_ab.shape)} scalar {float(scalar):.4f}")
+    nn.Module.cuda = lambda self, device=None: self
+    from yolov6.models.losses.loss_fuseab import ComputeLoss
+    for name, (B, fs, st, C, iou_type, seed) in LOSSAB_CASES.items():
+        inp = synth.synth_loss_inputs_ab(B, fs, st, C, seed=seed)
+        crit = ComputeLoss(fpn_strides=st, num_classes=C, ori_img_size=inp["img"], warmup_epoch=0, use_dfl=False, reg_max=0,
+                           iou_type=iou_type)
+        feats = [torch.zeros(B, 1, h, w) for h, w in fs]
+        ps = inp["pred_scores"].clone().requires_grad_(True)
+        pd = inp["pred_distri"].clone().requires_grad_(True)
+        # the reference adds the anchor points to pred_distri IN PLACE (loss_fuseab.py:75): feed a non-leaf copy
+        loss, items = crit((feats, ps * 1.0, pd * 1.0), inp["targets"].clone(), 10, 1, inp["img"], inp["img"])
+        loss.backward()
+        np.savez_compressed(os.path.join(HERE, f"lossab_{name}.npz"), loss=np.float64(float(loss)), items=items.numpy().astype(np.float64),
+                            dscores=ps.grad.numpy(), ddistri=pd.grad.numpy(),
+                            meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, iou_type=iou_type, seed=seed)))
+        print(f"lossab_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
+
+
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train", "fuseab"]
+    if "fuseab" in which:
+        gen_fuseab()
     if "models" in which:
         gen_models()
     if "nms" in which:

@@ -92,14 +92,14 @@ params = list(net.parameters())
 marks = [(i + 1, [p]) for i, p in enumerate(arena.params)]
 calls = []
 class FakeGraph:
-    def backward(self, ds, dd, first=0, last=None):
+    def backward(self, grads, first=0, last=None):
         calls.append((first, last))
         if first == 0:                               # the shard's gradient (autograd accumulates into the arena views)
             sh = r.shard(8)
             arena.zero_grad()
             loss_of(x[sh.start:sh.stop], y[sh.start:sh.stop]).backward()
 red = GradReducer(arena, marks, len(arena.params), r, chunks=3, average=True)
-red.run_backward(FakeGraph(), None, None)
+red.run_backward(FakeGraph(), None)
 err = max(float((p.grad - g).abs().max()) for p, g in zip(params, ref))
 cover = sorted((lo, hi) for _, _, lo, hi in red.segments)
 print("RESULT " + json.dumps(dict(rank=r.rank, err=err, calls=calls, segments=red.segments, numel=arena.numel,

@@ -674,3 +674,77 @@ def test_full_training_steps_loss_backward_sgd():
     print("losses", losses, "scale", float(scaler.scale))
     assert losses[-1] < losses[0], losses
     assert float(scaler.scale) == 1024.0           # no overflow happened
+
+
+# ------------------------------------------------------------------ fuse_ab (anchor-based auxiliary branch)
+@pytest.mark.parametrize("case", ["giou", "siou"])
+def test_fuseab_loss_and_gradient_vs_reference(case):
+    """loss_fuseab.ComputeLoss on the HIP path == the unmodified reference (value, items, gradients)."""
+    from yolov6_amd.models.losses.loss_fuseab import ComputeLoss
+    from yolov6_amd.utils import synth
+    g = np.load(os.path.join(GOLDEN, f"lossab_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp = synth.synth_loss_inputs_ab(m["B"], m["feat_sizes"], m["strides"], m["C"], seed=m["seed"])
+    crit = ComputeLoss(fpn_strides=m["strides"], num_classes=m["C"], ori_img_size=inp["img"], warmup_epoch=0, use_dfl=False, reg_max=0,
+                       iou_type=m["iou_type"])
+    feats = [torch.zeros(m["B"], 1, h, w, device=DEV) for h, w in m["feat_sizes"]]
+    ps = inp["pred_scores"].to(DEV).requires_grad_(True)
+    pd = inp["pred_distri"].to(DEV).requires_grad_(True)
+    loss, items = crit((feats, ps, pd), inp["targets"].to(DEV), 10, 1, inp["img"], inp["img"])
+    loss.backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(items.cpu().numpy(), g["items"], rtol=1e-4, atol=1e-6)
+    for got, name in ((ps.grad, "dscores"), (pd.grad, "ddistri")):
+        ref = g[name].astype(np.float64)
+        err = float(np.abs(got.cpu().numpy().astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+        assert err < 1e-4, f"{case}: {name} deviates by {err:.3e} of its max"
+
+
+def test_fuseab_training_graph_vs_oracle():
+    """Model(fuse_ab=True) in training mode: the four head outputs (effidehead_fuseab.py:139) and every parameter gradient
+    against TrainOracle.head_train_fuseab (pinned to the reference's goldens), same noise-floor criterion as the base model."""
+    from oracle import synth
+    from oracle.model_oracle import TrainOracle
+    from tests.helpers import case_config, synth_sd_from_keys
+    from yolov6_amd.models.yolo import build_model
+    with open(os.path.join(GOLDEN, "keys_tiny_fuseab.json")) as f:
+        meta = json.load(f)
+    cfg, _ = case_config("tiny")
+    sd = synth_sd_from_keys(meta["train"])
+    x = synth.synth_images(4, 192, seed=21)
+    xh = x.half().float()
+
+    def run(amp):
+        params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        orc = TrainOracle(cfg, sd, meta["num_classes"], amp_fp16=amp)
+        orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+        (xs, cab, rab, caf, raf), _ = orc.forward_train_fuseab(xh, meta["anchors_init"])
+        ((cab * cab).sum() + rab.square().mean() + (caf * caf).sum() + raf.square().mean()).backward()
+        return [t.detach() for t in (cab, rab, caf, raf)], {k: p.grad.detach() for k, p in params.items() if p.grad is not None}
+    o32, g32 = run(False)
+    o16, g16 = run(True)
+    model = build_model(cfg, meta["num_classes"], "cpu", fuse_ab=True)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    (stems, cab, rab, caf, raf), _ = model(x.to(DEV).half())
+    S = 256.0
+    (((cab * cab).sum() + rab.square().mean() + (caf * caf).sum() + raf.square().mean()) * S).backward()
+    torch.cuda.synchronize()
+    for name, got, r32, r16 in zip(("cls_ab", "reg_ab", "cls_af", "reg_af"), (cab, rab, caf, raf), o32, o16):
+        e, fl = _rel_l2(got.detach().cpu(), r32), _rel_l2(r16, r32)
+        assert e <= 2 * fl + 2e-3, f"{name}: HIP {e:.3e} vs fp16 noise floor {fl:.3e}"
+    named = dict(model.named_parameters())
+    bad = []
+    for k, ref in g32.items():
+        if k == "detect.proj" or k.startswith("detect.proj_conv") or float(ref.norm()) == 0.0:
+            continue
+        fl = _rel_l2(g16[k], ref)
+        if fl > 1.0:
+            continue
+        e = _rel_l2(named[k].grad.detach().float().cpu() / S, ref)
+        if e > 2 * fl + 2e-3:
+            bad.append((k, e, fl))
+    assert not bad, f"{len(bad)} gradients above twice the fp16 floor, e.g. {bad[:4]}"
+    ab = [k for k in g32 if "_ab" in k]
+    assert len(ab) == 12 and all(float(named[k].grad.abs().max()) > 0 for k in ab)

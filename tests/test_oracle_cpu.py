@@ -257,3 +257,59 @@ def test_int8_oracle_spec_properties():
     e = float((d8[..., 5:] - d32[..., 5:]).abs().max())
     print(f"int8 vs fp32 class scores: max abs diff {e:.3e}")
     assert e < 0.1
+
+
+# ------------------------------------------------------------------ fuse_ab
+def test_fuseab_train_oracle_matches_reference_golden():
+    """TrainOracle.head_train_fuseab vs the unmodified reference Model(fuse_ab=True) in training mode: the four head outputs
+    and seven reference parameter gradients."""
+    from oracle.model_oracle import TrainOracle
+    with open(os.path.join(GOLDEN, "keys_tiny_fuseab.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "fuseab_train_tiny.npz"))
+    cfg, _ = case_config("tiny")
+    sd = synth_sd_from_keys(meta["train"])
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    orc = TrainOracle(cfg, sd, meta["num_classes"])
+    orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+    x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
+    (xs, cab, rab, caf, raf), _ = orc.forward_train_fuseab(x, meta["anchors_init"])
+    for name, t in (("cls_ab", cab), ("reg_ab", rab), ("cls_af", caf), ("reg_af", raf)):
+        np.testing.assert_allclose(t.detach().numpy(), g[name], rtol=2e-4, atol=1e-4, err_msg=name)
+    scalar = (cab * cab).sum() + rab.square().mean() + (caf * caf).sum() + raf.square().mean()
+    scalar.backward()
+    np.testing.assert_allclose(float(scalar), float(g["scalar"]), rtol=1e-5)
+    for k in g.files:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = params[k[5:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), k
+
+
+@pytest.mark.parametrize("case", ["giou", "siou"])
+def test_fuseab_loss_oracles_match_reference(case):
+    """oracle/loss_oracle.py (ab=True) and oracle/loss_grad_oracle.py vs the reference's loss_fuseab.ComputeLoss (value, items,
+    gradients wrt pred_scores / pred_distri)."""
+    from oracle import loss_grad_oracle
+    g = np.load(os.path.join(GOLDEN, f"lossab_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp = synth.synth_loss_inputs_ab(m["B"], m["feat_sizes"], m["strides"], m["C"], seed=m["seed"])
+    out = loss_grad_oracle.compute_loss_with_grads(
+        m["feat_sizes"], inp["pred_scores"].numpy(), inp["pred_distri"].numpy(), inp["targets"].numpy(), 10, inp["img"], inp["img"],
+        fpn_strides=m["strides"], num_classes=m["C"], warmup_epoch=0, use_dfl=False, reg_max=0, iou_type=m["iou_type"], ab=True)
+    np.testing.assert_allclose(out["loss"], float(g["loss"]), rtol=2e-5)
+    np.testing.assert_allclose(out["loss_items"], g["items"], rtol=2e-5, atol=1e-6)
+    for name in ("dscores", "ddistri"):
+        ref = g[name].astype(np.float64)
+        err = float(np.abs(out[name] - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
+        assert err < 2e-4, f"{case}: {name} {err:.3e}"
+
+
+def test_fuseab_state_dict_keys_match_reference():
+    from yolov6_amd.models.yolo import build_model
+    with open(os.path.join(GOLDEN, "keys_tiny_fuseab.json")) as f:
+        meta = json.load(f)
+    cfg, _ = case_config("tiny")
+    model = build_model(cfg, meta["num_classes"], "cpu", fuse_ab=True)
+    got = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(got) == list(meta["train"]) and got == meta["train"]

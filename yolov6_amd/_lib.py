@@ -78,7 +78,7 @@ class LossDesc(C.Structure):
                 ("target_bboxes", C.c_void_p), ("target_scores", C.c_void_p), ("fg_mask", C.c_void_p),
                 ("B", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
                 ("iou_type", C.c_int32), ("w_class", C.c_float), ("w_iou", C.c_float), ("w_dfl", C.c_float),
-                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("box_mode", C.c_int32)]
 
 
 class BnApplyDesc(C.Structure):
@@ -137,6 +137,12 @@ class HeadPackDesc(C.Structure):
                 ("distri", C.c_void_p), ("dscores", C.c_void_p), ("ddistri", C.c_void_p), ("nc", C.c_int32), ("nreg", C.c_int32)]
 
 
+class HeadAbDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("nc", C.c_int32), ("na", C.c_int32), ("cls", Tensor * 4), ("reg", Tensor * 4),
+                ("reg_fwd", Tensor * 4), ("anchors", C.c_float * 24), ("scores", C.c_void_p), ("distri", C.c_void_p),
+                ("dscores", C.c_void_p), ("ddistri", C.c_void_p)]
+
+
 class LossGradDesc(C.Structure):
     _fields_ = [("fwd", LossDesc), ("grad_scale", C.c_void_p), ("dpred_scores", C.c_void_p), ("dpred_distri", C.c_void_p)]
 
@@ -188,6 +194,10 @@ SIGNATURES = {
     "y6_sppf_pool_backward": (C.c_int, [C.POINTER(SppfBwdDesc), C.c_void_p]),
     "y6_head_pack": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
     "y6_head_unpack_backward": (C.c_int, [C.POINTER(HeadPackDesc), C.c_void_p]),
+    "y6_head_ab_pack": (C.c_int, [C.POINTER(HeadAbDesc), C.c_void_p]),
+    "y6_head_ab_unpack_backward": (C.c_int, [C.POINTER(HeadAbDesc), C.c_void_p]),
+    "y6_plan_add_head_ab_pack": (C.c_int, [C.c_void_p, C.POINTER(HeadAbDesc)]),
+    "y6_plan_add_head_ab_unpack_backward": (C.c_int, [C.c_void_p, C.POINTER(HeadAbDesc)]),
     "y6_space_to_depth2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
     "y6_subsample2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
     "y6_plan_add_subsample2": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor)]),

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void loss_box_bwd_kernel(const float* __restri
                                                            const float* __restrict__ tboxes, const float* __restrict__ tscore,
                                                            const uint8_t* __restrict__ fg, int B, int A, int C, int use_dfl, int reg_max,
                                                            int iou_type, const double* __restrict__ fin, float w_iou, float w_dfl,
-                                                           const float* __restrict__ grad_scale, float* __restrict__ ddistri) {
+                                                           const float* __restrict__ grad_scale, float* __restrict__ ddistri, int box_mode) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * A) return;
     const int nb = use_dfl ? reg_max + 1 : 1;
@@ -350,6 +350,13 @@ __global__ __launch_bounds__(256) void loss_box_bwd_kernel(const float* __restri
     const D4 l = iou_loss_dual(pb, tb, iou_type);
     const float ci = w * w_iou * norm;
     // dist2bbox (general.py:32-43): x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3
+    if (box_mode == 1) {   // (cx, cy, w, h): x1 = cx - w/2, x2 = x1 + w (general.py:52-58)
+        out[0] = ci * (l.d[0] + l.d[2]);
+        out[1] = ci * (l.d[1] + l.d[3]);
+        out[2] = ci * 0.5f * (l.d[2] - l.d[0]);
+        out[3] = ci * 0.5f * (l.d[3] - l.d[1]);
+        return;
+    }
     const float dd[4] = {-ci * l.d[0], -ci * l.d[1], ci * l.d[2], ci * l.d[3]};
     if (!use_dfl) {
 #pragma unroll
@@ -446,7 +453,8 @@ extern "C" int y6_loss_backward(const y6_loss_grad_desc* g, void* stream) {
     Y6_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_box_bwd_kernel, dim3((unsigned)((n_ba + 255) / 256)), dim3(256), 0, s, d->pred_distri, d->pred_bboxes,
                        d->anchor_points_s, d->stride, d->target_bboxes, d->target_scores, d->fg_mask, d->B, d->A, d->C, d->use_dfl,
-                       d->reg_max, d->iou_type, d->out, d->w_iou, d->w_dfl, g->grad_scale, g->dpred_distri);
+                       d->reg_max, d->iou_type, d->out, d->w_iou, d->w_dfl, g->grad_scale, g->dpred_distri, d->box_mode);
+    Y6_REQUIRE(d->box_mode == 0 || !d->use_dfl, "loss_backward: the anchor-based box form has no DFL");
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

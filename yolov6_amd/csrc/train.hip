@@ -921,6 +921,147 @@ int head_unpack_launch(const y6_head_pack_desc* d, hipStream_t s) {
     return Y6_OK;
 }
 
+// ------------------------------------------------------------------ fuse_ab head: anchor-based auxiliary branch
+// Detect (effidehead_fuseab.py:110-124): per level cls_ab [B,H,W,na*nc] -> sigmoid -> scores [B, na*HW (anchor-major), nc];
+// reg_ab [B,H,W,na*4] -> (dx, dy, (2 sigmoid(w))^2 * aw, (2 sigmoid(h))^2 * ah) -> distri [B, na*HW, 4]
+struct HeadAbArgs {
+    int n_levels, nc, na, B, A;          // A = sum_l na * H_l * W_l
+    __half* cls[4];
+    __half* reg[4];
+    int ccs[4], cco[4], rcs[4], rco[4], hw[4], a0[5];
+    float anchors[4][3][2];
+    float* scores;
+    float* distri;
+    const float* dscores;
+    const float* ddistri;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void head_ab_kernel(const HeadAbArgs a) {
+    const int per = a.nc + 4;
+    const size_t total = (size_t)a.B * a.A * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % per);
+        const size_t ba = i / per;
+        const int an = (int)(ba % a.A), b = (int)(ba / a.A);
+        int l = 0;
+        while (l + 1 < a.n_levels && an >= a.a0[l + 1]) ++l;
+        const int local = an - a.a0[l];
+        const int anc = local / a.hw[l], pixl = local - anc * a.hw[l];
+        const size_t pix = (size_t)b * a.hw[l] + pixl;
+        if (c < a.nc) {
+            __half* q = a.cls[l] + pix * a.ccs[l] + a.cco[l] + anc * a.nc + c;
+            if (!BWD) {
+                a.scores[ba * a.nc + c] = 1.f / (1.f + expf(-__half2float(*q)));
+            } else {
+                const float p = a.scores[ba * a.nc + c];
+                *q = __float2half(a.dscores[ba * a.nc + c] * p * (1.f - p));
+            }
+        } else {
+            const int j = c - a.nc;
+            __half* q = a.reg[l] + pix * a.rcs[l] + a.rco[l] + anc * 4 + j;
+            if (!BWD) {
+                const float v = __half2float(*q);
+                float o = v;
+                if (j >= 2) {
+                    const float sg = 1.f / (1.f + expf(-v));
+                    o = (2.f * sg) * (2.f * sg) * a.anchors[l][anc][j - 2];
+                }
+                a.distri[ba * 4 + j] = o;
+            }
+        }
+    }
+}
+
+// backward of the box transform reads the forward reg maps (the gradient maps are separate buffers)
+struct HeadAbBwdArgs {
+    HeadAbArgs f;
+    const __half* reg_fwd[4];
+    int fcs[4], fco[4];
+};
+__global__ __launch_bounds__(256) void head_ab_regbwd_kernel(const HeadAbBwdArgs g) {
+    const HeadAbArgs& a = g.f;
+    const size_t total = (size_t)a.B * a.A * 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 3);
+        const size_t ba = i >> 2;
+        const int an = (int)(ba % a.A), b = (int)(ba / a.A);
+        int l = 0;
+        while (l + 1 < a.n_levels && an >= a.a0[l + 1]) ++l;
+        const int local = an - a.a0[l];
+        const int anc = local / a.hw[l], pixl = local - anc * a.hw[l];
+        const size_t pix = (size_t)b * a.hw[l] + pixl;
+        float d = a.ddistri[ba * 4 + j];
+        if (j >= 2) {
+            const float v = __half2float(g.reg_fwd[l][pix * g.fcs[l] + g.fco[l] + anc * 4 + j]);
+            const float sg = 1.f / (1.f + expf(-v));
+            d *= 8.f * sg * sg * (1.f - sg) * a.anchors[l][anc][j - 2];
+        }
+        a.reg[l][pix * a.rcs[l] + a.rco[l] + anc * 4 + j] = __float2half(d);
+    }
+}
+
+int fill_head_ab(const y6_head_ab_desc* d, HeadAbArgs* a, bool bwd) {
+    Y6_REQUIRE(d && d->n_levels >= 1 && d->n_levels <= 4 && d->na >= 1 && d->na <= 3 && d->scores, "head_ab: bad descriptor");
+    Y6_REQUIRE(bwd ? (d->dscores && d->ddistri) : (d->distri != nullptr), "head_ab: null buffer");
+    memset(a, 0, sizeof(*a));
+    a->n_levels = d->n_levels;
+    a->nc = d->nc;
+    a->na = d->na;
+    int A = 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor &c = d->cls[l], &r = d->reg[l];
+        Y6_REQUIRE(c.data && r.data && c.C == d->na * d->nc && r.C == d->na * 4, "head_ab: level %d channels", l);
+        Y6_REQUIRE(c.B == r.B && c.H == r.H && c.W == r.W && c.B == d->cls[0].B, "head_ab: level %d shape mismatch", l);
+        a->cls[l] = (__half*)c.data;
+        a->reg[l] = (__half*)r.data;
+        a->ccs[l] = c.cstride;
+        a->cco[l] = c.coff;
+        a->rcs[l] = r.cstride;
+        a->rco[l] = r.coff;
+        a->hw[l] = c.H * c.W;
+        a->a0[l] = A;
+        A += d->na * c.H * c.W;
+        for (int k = 0; k < d->na; ++k) {
+            a->anchors[l][k][0] = d->anchors[(l * 3 + k) * 2];
+            a->anchors[l][k][1] = d->anchors[(l * 3 + k) * 2 + 1];
+        }
+    }
+    a->a0[d->n_levels] = A;
+    a->B = d->cls[0].B;
+    a->A = A;
+    a->scores = d->scores;
+    a->distri = d->distri;
+    a->dscores = d->dscores;
+    a->ddistri = d->ddistri;
+    return Y6_OK;
+}
+int head_ab_pack_launch(const y6_head_ab_desc* d, hipStream_t s) {
+    HeadAbArgs a;
+    int rc = fill_head_ab(d, &a, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_ab_kernel<false>, dim3(grid_for((size_t)a.B * a.A * (a.nc + 4), 256, 256 * 32)), dim3(256), 0, s, a);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+int head_ab_unpack_launch(const y6_head_ab_desc* d, hipStream_t s) {
+    HeadAbBwdArgs g;
+    memset(&g, 0, sizeof(g));
+    int rc = fill_head_ab(d, &g.f, true);
+    if (rc) return rc;
+    for (int l = 0; l < d->n_levels; ++l) {
+        Y6_REQUIRE(d->reg_fwd[l].data, "head_ab: backward needs the forward reg maps");
+        g.reg_fwd[l] = (const __half*)d->reg_fwd[l].data;
+        g.fcs[l] = d->reg_fwd[l].cstride;
+        g.fco[l] = d->reg_fwd[l].coff;
+    }
+    hipLaunchKernelGGL(head_ab_kernel<true>, dim3(grid_for((size_t)g.f.B * g.f.A * (g.f.nc + 4), 256, 256 * 32)), dim3(256), 0, s, g.f);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_ab_regbwd_kernel, dim3(grid_for((size_t)g.f.B * g.f.A * 4, 256, 256 * 8)), dim3(256), 0, s, g);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 // ------------------------------------------------------------------ small data movers
 struct TwoT {
     y6_tensor a, b;
@@ -1189,6 +1330,22 @@ extern "C" int y6_head_pack(const y6_head_pack_desc* d, void* stream) {
 extern "C" int y6_head_unpack_backward(const y6_head_pack_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
     return head_unpack_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_head_ab_pack(const y6_head_ab_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return head_ab_pack_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_head_ab_unpack_backward(const y6_head_ab_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return head_ab_unpack_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_plan_add_head_ab_pack(y6_plan* p, const y6_head_ab_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, head_ab_pack_launch, d, Y6_TOP_HEAD_PACK, 0.0, 0.0);
+}
+extern "C" int y6_plan_add_head_ab_unpack_backward(y6_plan* p, const y6_head_ab_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    return y6_plan_push(p, head_ab_unpack_launch, d, Y6_TOP_HEAD_UNPACK, 0.0, 0.0);
 }
 extern "C" int y6_space_to_depth2(const y6_tensor* src, const y6_tensor* dst, void* stream) {
     Y6_CLEAR_STALE_ERROR();

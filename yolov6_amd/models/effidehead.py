@@ -60,8 +60,7 @@ class Detect(HipModule):
             reg_out.append(tb.conv(r, rp.weight, 1, bias=rp.bias))
             tb.trace.update({f"detect.stem{i}": f, f"detect.cls_conv{i}": c, f"detect.reg_conv{i}": r,
                              f"detect.cls_logit{i}": cls_out[-1], f"detect.reg_raw{i}": reg_out[-1]})
-        scores, distri = tb.head_pack(cls_out, reg_out, self.nc, self.reg_preds[0].out_channels)
-        return stems, scores, distri
+        return stems, tb.head_pack(cls_out, reg_out, self.nc, self.reg_preds[0].out_channels)
 
     def lower(self, pb, x, out=None):
         if self.training:

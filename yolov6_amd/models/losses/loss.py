@@ -46,6 +46,9 @@ class _LossFn(torch.autograd.Function):
 
 class ComputeLoss:
     """Loss computation func."""
+    anchor_mode = "af"     # generate_anchors mode
+    box_mode = 0           # 0: (l,t,r,b) distances / DFL logits;  1: (dx, dy, w, h) around the anchor point (loss_fuseab.py)
+    formal_topk = 13
 
     def __init__(self, fpn_strides=[8, 16, 32], grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80,
                  ori_img_size=640, warmup_epoch=4, use_dfl=True, reg_max=16, iou_type='giou',
@@ -59,7 +62,7 @@ class ComputeLoss:
         self.ori_img_size = ori_img_size
         self.warmup_epoch = warmup_epoch
         self.warmup_assigner = ATSSAssigner(9, num_classes=self.num_classes)
-        self.formal_assigner = TaskAlignedAssigner(topk=13, num_classes=self.num_classes, alpha=1.0, beta=6.0)
+        self.formal_assigner = TaskAlignedAssigner(topk=self.formal_topk, num_classes=self.num_classes, alpha=1.0, beta=6.0)
         self.use_dfl = use_dfl
         self.reg_max = reg_max
         self.iou_type = iou_type.lower()
@@ -118,7 +121,7 @@ class ComputeLoss:
             self.cached_feat_sizes = [torch.Size(sz) for sz in sizes]
             shape_feats = [torch.zeros(1, device=dev).expand(1, 1, int(sz[0]), int(sz[1])) for sz in sizes]
             anchors, anchor_points, n_anchors_list, stride_tensor = generate_anchors(
-                shape_feats, self.fpn_strides, self.grid_cell_size, self.grid_cell_offset, device=dev)
+                shape_feats, self.fpn_strides, self.grid_cell_size, self.grid_cell_offset, device=dev, mode=self.anchor_mode)
             anchors, anchor_points, stride_tensor = (t.float().to(dev) for t in (anchors, anchor_points, stride_tensor))
             self.cached_anchors = anchors, anchor_points, n_anchors_list, stride_tensor
         assert pred_scores.type() == pred_distri.type()
@@ -132,7 +135,12 @@ class ComputeLoss:
         mask_gt = (gt_bboxes.sum(-1, keepdim=True) > 0).float()
 
         anchor_points_s = (anchor_points / stride_tensor).contiguous()
-        pred_bboxes = self.bbox_decode(anchor_points_s, pred_distri)
+        if self.box_mode == 1:      # loss_fuseab.py:75-76: pred_distri[..., :2] += anchor_points_s; xywh2xyxy (x2 = x1 + w)
+            cxy = pred_distri[..., :2] + anchor_points_s
+            x1y1 = cxy - pred_distri[..., 2:] * 0.5
+            pred_bboxes = torch.cat([x1y1, x1y1 + pred_distri[..., 2:]], -1).contiguous()
+        else:
+            pred_bboxes = self.bbox_decode(anchor_points_s, pred_distri)
         if epoch_num < self.warmup_epoch:
             target_labels, target_bboxes, target_scores, fg_mask = self.warmup_assigner(
                 anchors, n_anchors_list, gt_labels, gt_bboxes, mask_gt, pred_bboxes * stride_tensor)
@@ -160,14 +168,15 @@ class ComputeLoss:
         d.use_dfl, d.reg_max, d.iou_type = int(self.use_dfl), int(self.reg_max), _lib.IOU_TYPES[self.iou_type]
         d.w_class, d.w_iou, d.w_dfl = (float(self.loss_weight[k]) for k in ("class", "iou", "dfl"))
         d.workspace_bytes = ws.numel()
+        d.box_mode = self.box_mode
         _lib.check(lib.y6_loss_forward(C.byref(d), _lib.current_stream_ptr()), "loss_forward")
         res = out.float()
         ps_in, pd_in = outputs[1], outputs[2]
         if torch.is_grad_enabled() and (ps_in.requires_grad or pd_in.requires_grad):
             graph = getattr(ps_in, "_y6_graph", None)
-            if graph is not None and graph.dscores.shape == pred_scores.shape:
-                dscores, ddistri = graph.dscores, graph.ddistri       # the native backward plan reads these directly
-            else:
+            dscores = graph.grad_buffer_of(ps_in) if graph is not None else None     # the native backward plan reads these directly
+            ddistri = graph.grad_buffer_of(pd_in) if graph is not None else None
+            if dscores is None or ddistri is None:
                 dscores, ddistri = torch.empty_like(pred_scores), torch.empty_like(pred_distri)
             g = _lib.LossGradDesc()
             g.fwd = d

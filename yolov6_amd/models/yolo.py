@@ -62,8 +62,8 @@ class Model(HipModule):
 
     def lower_train(self, tb, x):
         feats = list(self.neck.lower(tb, self.backbone.lower(tb, x)))
-        stems, scores, distri = self.detect.lower_train(tb, feats)
-        return stems, feats, scores, distri
+        stems, heads = self.detect.lower_train(tb, feats)
+        return stems, feats, heads
 
     def forward(self, x):
         if torch.onnx.is_in_onnx_export() or self.export:
@@ -111,8 +111,8 @@ def build_network(config, channels, num_classes, num_layers, fuse_ab=False, dist
     neck_cls = getattr(reppan, m.neck.type, None)
     if backbone_cls is None or neck_cls is None:
         raise NotImplementedError(f"yolov6_amd: backbone/neck {m.backbone.type}/{m.neck.type} is outside the HIP hot path")
-    if fuse_ab or distill_ns:
-        raise NotImplementedError("yolov6_amd: fuse_ab / distill heads are scheduled after the base hot path (SURVEY §8f)")
+    if distill_ns:
+        raise NotImplementedError("yolov6_amd: the distillation head is outside the hot path (SURVEY §8f rank 4)")
     bkw = dict(in_channels=channels, channels_list=channels_list, num_repeats=num_repeat, block=block,
                fuse_P2=m.backbone.get('fuse_P2'), cspsppf=m.backbone.get('cspsppf'))
     nkw = dict(channels_list=channels_list, num_repeats=num_repeat, block=block)
@@ -121,6 +121,10 @@ def build_network(config, channels, num_classes, num_layers, fuse_ab=False, dist
         bkw.update(csp_e=m.backbone.csp_e, stage_block_type=stage_block_type)
         nkw.update(csp_e=m.neck.csp_e, stage_block_type=stage_block_type)
     backbone, neck = backbone_cls(**bkw), neck_cls(**nkw)
+    if fuse_ab:      # yolo.py:122-126: the head with the anchor-based auxiliary branch (training recipe `--fuse_ab`)
+        from .heads.effidehead_fuseab import Detect as DetectAB, build_effidehead_layer as build_ab
+        head_layers = build_ab(channels_list, 3, num_classes, reg_max=m.head.reg_max, num_layers=num_layers)
+        return backbone, neck, DetectAB(num_classes, m.head.anchors_init, num_layers, head_layers=head_layers, use_dfl=m.head.use_dfl)
     head_layers = build_effidehead_layer(channels_list, 1, num_classes, reg_max=m.head.reg_max, num_layers=num_layers)
     # like the reference (yolo.py:128-130) Detect keeps its default reg_max=16 (proj has 17 bins even
     # when use_dfl is False); only build_effidehead_layer sees the config's reg_max

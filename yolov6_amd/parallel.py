@@ -119,14 +119,14 @@ class GradReducer:
         if self.average:
             t.mul_(1.0 / self.rep.world)
 
-    def run_backward(self, graph, dscores, ddistri):
+    def run_backward(self, graph, grads):
         """Segmented backward: launch the ops of segment k, then hand its arena chunk to RCCL on the side stream."""
         cuda = self.arena.grad.is_cuda
         if cuda and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
         for first, last, lo, hi in self.segments:
             if last > first or first == 0:
-                graph.backward(dscores if first == 0 else None, ddistri if first == 0 else None, first=first, last=last)
+                graph.backward(grads if first == 0 else None, first=first, last=last)
             if self.rep.dist is None:
                 continue
             if cuda:

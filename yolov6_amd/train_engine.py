@@ -127,6 +127,7 @@ class TrainBuilder:
         self.gbuf = {}               # forward buffer data_ptr -> gradient buffer
         self.gspans = {}             # gradient buffer data_ptr -> list[(c0, c1)] already written
         self.inputs: List[torch.Tensor] = []
+        self.head_outputs = []       # (output tensor, buffer its gradient is read from), in the order the model returns them
         self.bwd_marks = []          # (bwd op index after a closure, params finalised by it)
         self.fwd_flops = 0.0
         self.bwd_flops = 0.0
@@ -368,6 +369,7 @@ class TrainBuilder:
         d.scores, d.distri = _ptr(self.scores), _ptr(self.distri)
         d.nc, d.nreg = nc, nreg
         self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack")
+        self.head_outputs += [(self.scores, self.dscores), (self.distri, self.ddistri)]
 
         def bwd():
             g = _lib.HeadPackDesc()
@@ -385,6 +387,41 @@ class TrainBuilder:
             self._b(self.lib.y6_plan_add_head_unpack_backward(self.bwd, C.byref(g)), "plan_add_head_unpack_backward")
         self.tape.append(bwd)
         return self.scores, self.distri
+
+    def head_pack_ab(self, cls: List[TRef], reg: List[TRef], nc: int, na: int, anchors_init: torch.Tensor):
+        """Anchor-based auxiliary branch of the fuse_ab head (effidehead_fuseab.py:110-124)."""
+        B = cls[0].B
+        A = sum(na * c.H * c.W for c in cls)
+        scores = torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
+        distri = torch.zeros((B, A, 4), dtype=torch.float32, device=self.device)
+        dscores, ddistri = torch.zeros_like(scores), torch.zeros_like(distri)
+        anc = anchors_init.detach().float().cpu().reshape(len(cls), na, 2)
+
+        def desc(cls_t, reg_t):
+            d = _lib.HeadAbDesc()
+            d.n_levels, d.nc, d.na = len(cls), nc, na
+            for i in range(len(cls)):
+                d.cls[i], d.reg[i] = cls_t[i].ct(), reg_t[i].ct()
+                d.reg_fwd[i] = reg[i].ct()
+                for k in range(na):
+                    d.anchors[(i * 3 + k) * 2], d.anchors[(i * 3 + k) * 2 + 1] = float(anc[i, k, 0]), float(anc[i, k, 1])
+            d.scores, d.distri = _ptr(scores), _ptr(distri)
+            d.dscores, d.ddistri = _ptr(dscores), _ptr(ddistri)
+            return d
+        self._f(self.lib.y6_plan_add_head_ab_pack(self.fwd, C.byref(desc(cls, reg))), "plan_add_head_ab_pack")
+        self.head_outputs += [(scores, dscores), (distri, ddistri)]
+
+        def bwd():
+            gc, gr = [], []
+            for t, out in [(c, gc) for c in cls] + [(r, gr) for r in reg]:
+                rec = t._conv
+                cp = _rup(t.C, 8)
+                buf = self.new_buffer(t.B, t.H, t.W, cp, zero=True)
+                rec.dy, rec.dy_dil, rec.cpad = buf, 1, cp
+                out.append(TRef(buf.buf, t.B, t.H, t.W, t.C, cp, 0))
+            self._b(self.lib.y6_plan_add_head_ab_unpack_backward(self.bwd, C.byref(desc(gc, gr))), "plan_add_head_ab_unpack_backward")
+        self.tape.append(bwd)
+        return scores, distri
 
     # ------------------------------------------------------------------ backward emitters
     def _bnact_backward(self, fwd_desc, branches, out: TRef, res, alpha):
@@ -629,12 +666,16 @@ class TrainGraph:
         self.model = model
         self.input = x.contiguous()
         tb = TrainBuilder(x.device, arena)
-        stems, necks, scores, distri = model.lower_train(tb, NCHWInput(self.input))
+        stems, necks, heads = model.lower_train(tb, NCHWInput(self.input))
         self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
         self.tb = tb
         self.stem_refs, self.neck_refs = stems, necks
-        self.scores, self.distri = scores, distri
-        self.dscores, self.ddistri = tb.dscores, tb.ddistri
+        # head outputs in the order the model returns them, each with the buffer the backward plan reads its gradient from
+        by_ptr = {o.data_ptr(): g for o, g in tb.head_outputs}
+        self.outputs = list(heads)
+        self.grad_inputs = [by_ptr[o.data_ptr()] for o in self.outputs]
+        self.scores, self.distri = self.outputs[-2], self.outputs[-1]            # the anchor-free pair
+        self.dscores, self.ddistri = self.grad_inputs[-2], self.grad_inputs[-1]
         self.fwd_flops, self.bwd_flops = tb.fwd_flops, tb.bwd_flops
         self.bwd_marks = tb.bwd_marks
         self.n_bwd_ops = self.bwd_plan.num_ops
@@ -645,15 +686,24 @@ class TrainGraph:
             self.input.copy_(x)
         self.pack_plan.run()
         self.fwd_plan.run()
-        return self.scores, self.distri
+        return tuple(self.outputs)
 
-    def backward(self, dscores=None, ddistri=None, first=0, last=None):
-        """Run backward ops [first, last) (default: all).  Gradients wrt the head outputs are read from
-        self.dscores / self.ddistri (other tensors are copied in)."""
-        if dscores is not None and dscores.data_ptr() != self.dscores.data_ptr():
-            self.dscores.copy_(dscores)
-        if ddistri is not None and ddistri.data_ptr() != self.ddistri.data_ptr():
-            self.ddistri.copy_(ddistri)
+    def grad_buffer_of(self, out):
+        """The buffer the backward plan reads d loss / d `out` from (ComputeLoss writes there directly)."""
+        for o, g in zip(self.outputs, self.grad_inputs):
+            if o.data_ptr() == out.data_ptr():
+                return g
+        return None
+
+    def backward(self, grads=None, first=0, last=None):
+        """Run backward ops [first, last) (default: all).  `grads`: gradients wrt the head outputs, in output order
+        (None entries mean zero); tensors that are not the graph's own gradient buffers are copied in."""
+        if grads is not None:
+            for g, buf in zip(grads, self.grad_inputs):
+                if g is None:
+                    buf.zero_()
+                elif g.data_ptr() != buf.data_ptr():
+                    buf.copy_(g)
         if first == 0:
             p0 = self.arena.params[0]
             if p0.grad is None:                 # optimizer.zero_grad(set_to_none=True): same as zeroing
@@ -705,21 +755,17 @@ class _TrainStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, graph, x, anchor):
         ctx.graph = graph
-        scores, distri = graph.forward(x)
-        return scores.view_as(scores), distri.view_as(distri)
+        return tuple(o.view_as(o) for o in graph.forward(x))
 
     @staticmethod
-    def backward(ctx, dscores, ddistri):
+    def backward(ctx, *grads):
         g = ctx.graph
-        if dscores is None:
-            dscores = torch.zeros_like(g.scores)
-        if ddistri is None:
-            ddistri = torch.zeros_like(g.distri)
+        grads = [None if t is None else t.contiguous() for t in grads]
         hook = g.model.__dict__.get("_y6_backward_hook")
         if hook is not None:
-            hook(g, dscores.contiguous(), ddistri.contiguous())      # e.g. DataParallel: segmented backward + all-reduce
+            hook(g, grads)                       # e.g. GradReducer: segmented backward + all-reduce
         else:
-            g.backward(dscores.contiguous(), ddistri.contiguous())
+            g.backward(grads)
         return None, None, None
 
 
@@ -732,10 +778,8 @@ def train_forward(model, x):
     if g is None:
         graphs.clear()
         g = graphs[key] = TrainGraph(model, x)
-    if torch.is_grad_enabled():
-        scores, distri = _TrainStepFn.apply(g, x, g.anchor)
-    else:
-        scores, distri = g.forward(x)
-    for t in (scores, distri):
+    outs = _TrainStepFn.apply(g, x, g.anchor) if torch.is_grad_enabled() else g.forward(x)
+    for t in outs:
         t._y6_graph = g                      # lets ComputeLoss write its gradients straight into the graph's buffers
-    return [(_LazyNCHW(g.stem_refs, x.dtype), scores, distri), _LazyNCHW(g.neck_refs, x.dtype)]
+    # base head: (feats, cls_scores, reg_distri); fuse_ab head: (feats, cls_ab, reg_ab, cls_af, reg_af) - effidehead_fuseab.py:139
+    return [(_LazyNCHW(g.stem_refs, x.dtype),) + tuple(outs), _LazyNCHW(g.neck_refs, x.dtype)]

@@ -162,3 +162,18 @@ def synth_loss_inputs(B, feat_sizes, strides, C, reg_max, use_dfl, seed=0, boxes
     targets = np.asarray(rows, np.float32).reshape(-1, 6)
     t = torch.from_numpy
     return dict(pred_scores=t(pred_scores), pred_distri=t(pred_distri), targets=t(targets), img=int(img))
+
+
+def synth_loss_inputs_ab(B, feat_sizes, strides, C, seed=0, boxes_per_image=(1, 6), img=None):
+    """Inputs of the anchor-based ComputeLoss (reference models/losses/loss_fuseab.py:43-51): pred_scores [B,3A,C] and
+    pred_distri [B,3A,4] = (dx, dy, w, h) in stride units around the anchor point (anchors ordered level, anchor, pixel),
+    targets as in synth_loss_inputs."""
+    base = synth_loss_inputs(B, feat_sizes, strides, C, 0, False, seed=seed, boxes_per_image=boxes_per_image, img=img)
+    r = np.random.RandomState(seed + 977)
+    A = 3 * sum(h * w for h, w in feat_sizes)
+    pred_scores = r.uniform(0.005, 0.95, size=(B, A, C)).astype(np.float32)
+    dxy = r.uniform(-1.0, 1.0, size=(B, A, 2))
+    wh = r.uniform(1.0, 7.0, size=(B, A, 2))
+    pred_distri = np.concatenate([dxy, wh], -1).astype(np.float32)
+    return dict(pred_scores=torch.from_numpy(pred_scores), pred_distri=torch.from_numpy(pred_distri), targets=base["targets"],
+                img=base["img"])
