@@ -11,7 +11,7 @@ distillation models - keeps loading from the reference checkout):
     yolov6.layers.common            -> yolov6_amd.layers.common      (+ the reference's other block classes, untouched,
                                                                       so `from yolov6.layers.common import *` stays complete)
     yolov6.models.{yolo,efficientrep,reppan,effidehead}              -> yolov6_amd.models.*
-    yolov6.models.losses.loss       -> yolov6_amd.models.losses.loss
+    yolov6.models.losses.{loss,loss_fuseab}, yolov6.models.heads.effidehead_fuseab -> yolov6_amd.models.*
     yolov6.assigners[.tal_assigner/.atss_assigner/.anchor_generator] -> yolov6_amd.assigners.*
     yolov6.utils.nms                -> yolov6_amd.utils.nms          (the reference's imports cv2 + torchvision at the top)
     yolov6.utils.checkpoint         -> yolov6_amd.utils.checkpoint   (same functions; torch>=2.6-safe un-pickling)
@@ -37,6 +37,8 @@ REPLACED = {
     "models.reppan": "models.reppan",
     "models.effidehead": "models.effidehead",
     "models.losses.loss": "models.losses.loss",
+    "models.losses.loss_fuseab": "models.losses.loss_fuseab",
+    "models.heads.effidehead_fuseab": "models.heads.effidehead_fuseab",
     "assigners": "assigners",
     "assigners.tal_assigner": "assigners.tal_assigner",
     "assigners.atss_assigner": "assigners.atss_assigner",
@@ -91,7 +93,8 @@ def install(root=None, strict=False):
             raise ImportError("yolov6_amd: no reference checkout found (pass its root, or put it on sys.path)")
         base = sys.modules[_PKG]
         sys.modules.setdefault("yolov6", base)
-        for sub in list(REPLACED.values()) + ["layers", "models", "models.losses", "utils", "utils.torch_utils", "utils.general"]:
+        for sub in list(REPLACED.values()) + ["layers", "models", "models.losses", "models.heads", "utils", "utils.torch_utils",
+                                              "utils.general"]:
             sys.modules.setdefault(f"yolov6.{sub}", _ours(sub))
         return None
 
