@@ -68,6 +68,16 @@ def test_nms_edge_cases():
         non_max_suppression(s.to(DEV), conf_thres=1.5)
 
 
+def test_nms_large_max_det():
+    """max_det beyond the former 2048 limit (kept boxes stay in LDS: up to 8192): many survivors with a permissive IoU
+    threshold; 8193 is refused loudly."""
+    p = synth.synth_predictions(2, 8400, 20, seed=9, frac=0.05)
+    _check_vs_oracle(p, conf_thres=0.03, iou_thres=0.9, multi_label=True, max_det=5000)
+    _check_vs_oracle(p, conf_thres=0.03, iou_thres=0.95, multi_label=True, max_det=8192)
+    with pytest.raises(RuntimeError):
+        non_max_suppression(p.to(DEV), 0.03, 0.9, multi_label=True, max_det=8193)
+
+
 def test_nms_idempotent_and_sorted():
     """Size-independent properties at the full size: output sorted by confidence; re-running NMS on the
     survivors (as a prediction tensor) keeps all of them."""

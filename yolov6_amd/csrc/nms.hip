@@ -215,8 +215,9 @@ __device__ __forceinline__ void bitonic_desc_lds(u64* keys, int P) {
 }
 
 constexpr int kWin = 1024;        // sweep window: sorted candidates resident in LDS at a time (one per thread)
-constexpr int kKeptCap = 2048;    // kept boxes resident in LDS (max_det limit)
-constexpr size_t kSweepLds = (size_t)(kWin + kKeptCap) * 16 + (kWin / 64) * 8;
+constexpr int kKeptCap = 8192;    // most kept boxes LDS can hold next to the window (160 KiB per CU): the max_det limit
+// LDS of the sweep for a given kept-box capacity (max_det rounded up to 256): window boxes + kept boxes + alive words
+static inline size_t sweep_lds(int kept_cap) { return (size_t)(kWin + kept_cap) * 16 + (kWin / 64) * 8; }
 
 __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
     // torchvision devIoU / cpu kernel arithmetic, fp32, unfused
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void nms_merge_rank_kernel(const u64* __restri
 // then settled in batches of 64 (see below).  Boxes are only ever built for the windows the sweep reaches
 // before max_det boxes are kept.
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict__ pred, int A, int nc,
-                                                         float iou_thres, int agnostic, int max_det, int max_nms,
+                                                         float iou_thres, int agnostic, int max_det, int max_nms, int kept_cap,
                                                          float max_wh, const u64* __restrict__ sorted,
                                                          const int* __restrict__ counts,
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
 
     float4* wbox = reinterpret_cast<float4*>(smem);
     float4* kbox = wbox + kWin;
-    u64* walive = reinterpret_cast<u64*>(kbox + kKeptCap);
+    u64* walive = reinterpret_cast<u64*>(kbox + kept_cap);
     int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids at the end
     const int no = nc + 5;
     int kept = 0;
@@ -616,14 +617,17 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
                        sorted, d->max_nms);
     Y6_LAUNCH_CHECK();
     if (stop_after < 4) return Y6_OK;
-    const size_t lds = kSweepLds;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // kept boxes live in LDS: capacity = max_det rounded up to 256 (2048 boxes = 48 KiB as before; 8192 = 148 KiB, one block per CU)
+    int kept_cap = (d->max_det + 255) / 256 * 256;
+    if (kept_cap < 2048) kept_cap = 2048;
+    const size_t lds = sweep_lds(kept_cap);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         Y6_HIP(hipFuncSetAttribute((const void*)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_lds = lds;
     }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
-                       d->max_det, d->max_nms, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
+                       d->max_det, d->max_nms, kept_cap, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
