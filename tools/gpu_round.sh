@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # One GPU-box visit: smoke, -m gpu tests, bench (+ autotune log, per-op table), rocprofv3 kernel stats.
 # Everything of interest lands under gpurun_out/ (merged back by gpurun).
-#   usage: tools/gpu_round.sh [tag] [what...]    what in {smoke,tests,bench,prof,pmc} (default: all but pmc)
+#   usage: tools/gpu_round.sh [tag] [what...]    what in {smoke,tests,bench,prof,pmc,train,trainprof,l6} (default: smoke tests bench prof)
 set -u
 TAG=${1:-r01}
 shift || true
@@ -27,23 +27,39 @@ if has tests; then
 fi
 if has bench; then
   echo "== bench"; rm -f "$OUT/autotune.log" "$OUT/autotune.cache"
-  Y6_AUTOTUNE_CACHE="$PWD/$OUT/autotune.cache" Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 1200 python bench.py --steps 20 --warmup 3 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+  Y6_AUTOTUNE_CACHE="$PWD/$OUT/autotune.cache" Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 1200 python bench.py --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
   echo "bench rc=$?"; tail -2 "$OUT/bench.err"; cat "$OUT/bench.json"
 fi
 if has prof; then
   echo "== rocprofv3 kernel stats"
   # the bench leg's tuning choices are reused, so the stats hold the chosen kernels only
-  ( cd /tmp && Y6_AUTOTUNE_CACHE="$OLDPWD/$OUT/autotune.cache" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
+  ( cd /tmp && Y6_AUTOTUNE_CACHE="$OLDPWD/$OUT/autotune.cache" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 8 --warmup 2 --no-cpu-baseline --dropin-steps 0 --no-verify > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" )
   echo "prof rc=$?"; find "$OUT/prof" -name "*kernel_stats*" | head -3
   f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
   # keep the merge-back small: drop the raw trace, keep stats
   find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has train; then
+  echo "== train bench (configs[2])"
+  timeout 1200 python bench.py --mode train --profile-out "$OUT/train_ops.json" > "$OUT/bench_train.json" 2> "$OUT/bench_train.err"
+  echo "train bench rc=$?"; tail -2 "$OUT/bench_train.err"; cut -c1-900 "$OUT/bench_train.json"
+fi
+if has trainprof; then
+  echo "== rocprofv3 kernel stats of the training step"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof_train" -o train -- python "$OLDPWD/bench.py" --mode train --steps 5 --warmup 2 --no-autotune > "$OLDPWD/$OUT/prof_train.json" 2> "$OLDPWD/$OUT/prof_train.err" )
+  echo "trainprof rc=$?"; f=$(find "$OUT/prof_train" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f"
+  find "$OUT/prof_train" -name "*kernel_trace.csv" -size +20M -delete
+fi
+if has l6; then
+  echo "== L6 1280 b8 (configs[3])"
+  timeout 1200 python bench.py --model yolov6l6 --size 1280 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline --dropin-steps 10 > "$OUT/bench_l6.json" 2> "$OUT/bench_l6.err"
+  echo "l6 rc=$?"; tail -2 "$OUT/bench_l6.err"; cut -c1-700 "$OUT/bench_l6.json"
+fi
 if has pmc; then
   echo "== rocprofv3 pmc (separate passes)"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" )
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err" )
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$OLDPWD/$OUT/pmc_sq" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OLDPWD/$OUT/pmc_fetch" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dropin-steps 0 --no-verify > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OLDPWD/$OUT/pmc_write" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dropin-steps 0 --no-verify > /dev/null 2> "$OLDPWD/$OUT/pmc_write.err" )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$OLDPWD/$OUT/pmc_sq" -o b -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --dropin-steps 0 --no-verify > /dev/null 2> "$OLDPWD/$OUT/pmc_sq.err" )
   ls "$OUT"/pmc_*
 fi
 du -sh "$OUT"

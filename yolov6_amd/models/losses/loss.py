@@ -17,7 +17,6 @@ O(B*G*A) temporaries; the HIP assigners do not).
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from ... import _lib
@@ -73,26 +72,33 @@ class ComputeLoss:
 
     # ------------------------------------------------------------------ host pieces, as in the reference
     def preprocess(self, targets, batch_size, scale_tensor):
-        """loss.py:184-192 (the packing runs on the host there too).  -> [B,G,5] fp32 (label, x1,y1,x2,y2 px)."""
-        rows = targets.detach().cpu().numpy().astype(np.float32).reshape(-1, 6)
-        img = rows[:, 0].astype(np.int64)
-        if rows.shape[0] and (img.min() < 0 or img.max() >= batch_size):
-            raise IndexError(f"targets name image {int(img.max())} but the batch holds {batch_size} images")
-        counts = np.bincount(img, minlength=batch_size)[:batch_size] if rows.shape[0] else np.zeros(batch_size, np.int64)
-        max_len = int(counts.max()) if rows.shape[0] else 0
-        out = np.zeros((batch_size, max_len, 5), np.float32)
+        """loss.py:184-192: targets [N,6] = (image, class, cx, cy, w, h in 0..1) -> [B,G,5] fp32 (label, x1,y1,x2,y2 px), rows of
+        an image in their original order, padding rows (-1, 0,0,0,0).  The reference packs through Python lists on the host
+        (`targets.cpu().numpy().tolist()`); here the packing stays on the device (stable sort by image + scatter) and the only
+        host round trip is the scalar G = most boxes in one image, which sizes the result."""
+        dev = scale_tensor.device
+        rows = targets.detach().to(dev, torch.float32).reshape(-1, 6)
+        n = rows.shape[0]
+        if n == 0:
+            return torch.zeros((batch_size, 0, 5), dtype=torch.float32, device=dev)
+        img = rows[:, 0].to(torch.int64)
+        lo, hi = torch.aminmax(img)
+        counts = torch.bincount(img.clamp(0, batch_size - 1), minlength=batch_size)
+        lo, hi, max_len = (int(v) for v in torch.stack([lo, hi, counts.max()]).tolist())      # one host sync
+        if lo < 0 or hi >= batch_size:
+            raise IndexError(f"targets name image {hi if hi >= batch_size else lo} but the batch holds {batch_size} images")
+        out = torch.zeros((batch_size, max_len, 5), dtype=torch.float32, device=dev)
         out[:, :, 0] = -1
-        if rows.shape[0]:
-            order = np.argsort(img, kind="stable")          # per image, rows keep their order (the reference appends in order)
-            starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
-            pos = np.arange(rows.shape[0]) - starts[img[order]]
-            out[img[order], pos] = rows[order, 1:]
-        t = torch.from_numpy(out).to(scale_tensor.device)
-        box = t[:, :, 1:5] * scale_tensor
+        order = torch.argsort(img, stable=True)          # per image, rows keep their order (the reference appends in order)
+        starts = torch.cumsum(counts, 0) - counts
+        simg = img[order]
+        pos = torch.arange(n, device=dev) - starts[simg]
+        out[simg, pos] = rows[order, 1:]
+        box = out[:, :, 1:5] * scale_tensor
         x1 = box[..., 0] - box[..., 2] * 0.5          # xywh2xyxy exactly as general.py:52-58 (x2 = x1 + w)
         y1 = box[..., 1] - box[..., 3] * 0.5
-        t[:, :, 1:5] = torch.stack([x1, y1, x1 + box[..., 2], y1 + box[..., 3]], -1)
-        return t
+        out[:, :, 1:5] = torch.stack([x1, y1, x1 + box[..., 2], y1 + box[..., 3]], -1)
+        return out
 
     def bbox_decode(self, anchor_points, pred_dist):
         lib = _lib.load()
