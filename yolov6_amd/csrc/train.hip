@@ -65,7 +65,23 @@ __global__ __launch_bounds__(256) void bn_sum_kernel(const __half* __restrict__ 
         double s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
-        for (long p = p0 + prow; p < p1; p += R) {
+        // four independent 16-byte loads in flight per thread (a one-load-per-iteration loop ran at 1.3 TB/s); partial sums of
+        // the four pixels are formed in fp32 (exact enough: fp16 inputs, 4 terms) before they enter the double accumulators
+        long p = p0 + prow;
+        for (; p + 3 * (long)R < p1; p += 4 * (long)R) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8(x + p * cs + co + g * 8, v0);
+            load8(x + (p + R) * cs + co + g * 8, v1);
+            load8(x + (p + 2 * (long)R) * cs + co + g * 8, v2);
+            load8(x + (p + 3 * (long)R) * cs + co + g * 8, v3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)((v0[j] + v1[j]) + (v2[j] + v3[j]));
+                q[j] += (double)v0[j] * (double)v0[j] + (double)v1[j] * (double)v1[j] + (double)v2[j] * (double)v2[j] +
+                        (double)v3[j] * (double)v3[j];
+            }
+        }
+        for (; p < p1; p += R) {
             float v[8];
             load8(x + p * cs + co + g * 8, v);
 #pragma unroll

@@ -266,13 +266,27 @@ __global__ __launch_bounds__(256, kWavesPerSimd<MODE>) void wgrad_kernel(const W
         }
 }
 
-// out[m*sm + n*sn + t*st] += sum_ks ws[ks][t][m][n]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int nsplit, int T, int M, int N, float* __restrict__ out,
-                                                           int sm, int sn, int st) {
+// Two-level, deterministic sum of the slice partials (a single level - one thread walking all `nsplit` slices of an element -
+// is a serial chain of strided loads: 0.77 ms for the 683 slices of the 64->64 @160x160 layers):
+//   level 1: chunk c of kRedChunk slices -> ws2[c][t][m][n]              (grid: elements x chunks)
+//   level 2: out[m*sm + n*sn + t*st] += sum_c ws2[c][t][m][n]
+constexpr int kRedChunk = 16;
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ ws, int nsplit, size_t per, float* __restrict__ ws2) {
+    const int c = blockIdx.y;
+    const int k0 = c * kRedChunk, k1 = (k0 + kRedChunk < nsplit) ? k0 + kRedChunk : nsplit;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) s += ws[(size_t)k * per + i];
+        ws2[(size_t)c * per + i] = s;
+    }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ ws2, int nchunk, int T, int M, int N, float* __restrict__ out,
+                                                            int sm, int sn, int st) {
     const size_t per = (size_t)T * M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * per + i];
+        for (int c = 0; c < nchunk; ++c) s += ws2[(size_t)c * per + i];
         const int n = (int)(i % N);
         const int m = (int)((i / N) % M);
         const int t = (int)(i / ((size_t)N * M));
@@ -321,8 +335,11 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     const long mfma_per_row = (long)(d->Q / 16) * (T / ng);
     const long max_by_work = (total_rows * mfma_per_row + 255) / 256;
     if (nsplit > max_by_work) nsplit = max_by_work;
-    Y6_REQUIRE(d->workspace && d->workspace_bytes >= (size_t)T * d->M * d->N * sizeof(float), "wgrad: workspace missing or too small");
-    const long max_by_ws = (long)(d->workspace_bytes / ((size_t)T * d->M * d->N * sizeof(float)));
+    Y6_REQUIRE(d->workspace && d->workspace_bytes >= 2 * (size_t)T * d->M * d->N * sizeof(float), "wgrad: workspace missing or too small");
+    // workspace: nsplit slice partials + ceil(nsplit / kRedChunk) chunk sums
+    long max_by_ws = (long)(d->workspace_bytes / ((size_t)T * d->M * d->N * sizeof(float)));
+    max_by_ws = max_by_ws * kRedChunk / (kRedChunk + 1) - 1;
+    if (max_by_ws < 1) max_by_ws = 1;
     if (nsplit > max_by_ws) nsplit = max_by_ws;
     if (nsplit > total_rows) nsplit = total_rows;
     if (nsplit < 1) nsplit = 1;
@@ -342,7 +359,11 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     const size_t per = (size_t)T * d->M * d->N;
     unsigned rg = (unsigned)((per + 255) / 256);
     if (rg > 4096) rg = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, s, a.ws, a.nsplit, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
+    const int nchunk = (a.nsplit + kRedChunk - 1) / kRedChunk;
+    float* ws2 = a.ws + (size_t)a.nsplit * per;
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(rg, (unsigned)nchunk), dim3(256), 0, s, a.ws, a.nsplit, per, ws2);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(rg), dim3(256), 0, s, ws2, nchunk, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
