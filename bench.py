@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the bf16/fp16 rate (MI355X_MICROARCH.md dtype table: ubench >= 3944 TOPS)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
 CONF, IOU, MAX_DET = 0.03, 0.65, 300
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 32 for infer, 64 for train)")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--model", default="yolov6s")
+    ap.add_argument("--int8", action="store_true", help="BASELINE configs[4]: int8 plan (use with --model yolov6s_qa): max-"
+                    "calibration on 4 synthetic batches, backbone + neck convs on the int8 MFMA kernels, head fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32, help="images in the CPU-baseline sample")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
@@ -332,6 +335,11 @@ def main():
     from yolov6_amd.utils.nms import nms_raw
     cfg, sd_train, model, x = build_model_and_input(args, device)
     shift = calibrate_head_bias(model, x)
+    if args.int8:
+        from yolov6_amd import quant
+        from yolov6_amd.utils import synth as _synth
+        cal = [_synth.synth_images(8, args.size, seed=100 + i).to(device).half() for i in range(4)]
+        quant.quantize(model, quant.calibrate(model, cal))
     plan = model.compile(x, autotune=not args.no_autotune)
 
     def step(timed=False):
@@ -404,38 +412,41 @@ def main():
             c["bytes"] += r["bytes"]
             c["launches"] += 1
         by_class["nms"] = dict(ms=nms_ms, flops=0.0, bytes=float(args.batch * 8400 * 85 * 4), launches=2)
-        dom = by_class.get("conv3x3s1", dict(ms=0.0, flops=0.0, launches=0))
+        dom_class = "conv_i8" if args.int8 else "conv3x3s1"
+        peak = INT8_PEAK_TOPS if args.int8 else MFMA_PEAK_TFLOPS
+        dom = by_class.get(dom_class, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         headline = (args.model == "yolov6s" and args.size == 640 and args.batch == 32)
         # the committed PMC summary was collected on the headline configuration only
         traffic, traffic_src = pmc_traffic("conv3x3s1") if headline else (None, "PMC summary exists for the headline configuration only")
         dom_variants = {}
         for r in rows:
-            if classify(r) == "conv3x3s1":
-                n = str(r["variant"])
+            if classify(r) == dom_class:
+                n = str(r["variant"]) or "heuristic tile"
                 dom_variants[n] = dom_variants.get(n, 0) + 1
         total_flops = sum(r["flops"] for r in rows)
         fwd_ms = sum(r["ms"] for r in rows)
         ms_per_step = elapsed / args.steps * 1e3
         res = {
             "metric": ("images/sec (b32, 640x640) YOLOv6-S fp16 inference (forward + NMS)" if headline else
-                       f"images/sec (b{args.batch}, {args.size}x{args.size}) {args.model} fp16 inference (forward + NMS)"),
+                       f"images/sec (b{args.batch}, {args.size}x{args.size}) {args.model} {'int8' if args.int8 else 'fp16'} inference (forward + NMS)"),
             "value": round(rep.throughput(args.batch, args.steps, elapsed), 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.size}x{args.size} b{args.batch}/GPU fp16 inference: "
+            "dtype": "int8 (backbone + neck convs; image conv, convT, head, decode fp16)" if args.int8 else "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.size}x{args.size} b{args.batch}/GPU {'int8' if args.int8 else 'fp16'} inference: "
                                    "forward (deploy form) + NMS conf 0.03 / IoU 0.65 / multi-label / max_det 300; timed through the "
                                    "plan API (model.compile(x) once, then plan.run() + nms_raw() per step: no output clone, no host "
                                    "sync per step); the reference-signature API step is reported under dropin_api",
                        "global_batch": world * args.batch, "parallelism": f"replicas x{world} (no collective)",
                        "weights": "random (oracle/synth.py), cls bias calibrated to ~2% candidates"},
-            "roofline": {"bound": "mfma", "kernel": "3x3 stride-1 conv+bias+act (conv_mfma.hip); variants chosen per layer: "
-                                                    + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items())),
-                         "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+            "roofline": {"bound": "mfma", "kernel": ("int8 convs 3x3 / 3x3 s2 / 1x1 (conv_i8_kernel, conv_mfma.hip), all launches" if args.int8 else
+                                                     "3x3 stride-1 conv+bias+act (conv_mfma.hip); variants chosen per layer: "
+                                                     + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items()))),
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TOP/s" if args.int8 else "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(dom["bytes"] / max(dom["launches"], 1)),
                          "event_sampled_steps": len(sampled), "launches_per_step": dom["launches"], "gflop_per_step": round(dom["flops"] / 1e9, 2),

@@ -100,6 +100,41 @@ const char* y6_conv_variant_name(int i);
 /* 1 if variant i can run desc d */
 int y6_conv_variant_supports(const y6_conv_desc* d, int i);
 
+/* ------------------------------------------------------------------------------------ */
+/* int8 convolution (BASELINE configs[4]: YOLOv6-S QARepVGG int8 inference).
+ * The reference tree holds NO int8 arithmetic: its int8 numbers come from TensorRT engines / NVIDIA
+ * pytorch_quantization fake-quant (deploy/TensorRT/onnx_to_trt.py:62-112, tools/qat/qat_utils.py:61-146:
+ * per-channel 8-bit weights, per-tensor 8-bit activations).  This entry point is the arithmetic those describe,
+ * defined here and in oracle/int8_oracle.py (PARITY UNPINNED by construction):
+ *   weights      symmetric per output channel, quantised on the host: s_w[c] = max|w[c]| / 127,
+ *                w_q = clamp(rne(w / s_w[c]), -127, 127)  ->  y6_pack_conv_weight_i8
+ *   activations  symmetric per tensor, amax from calibration (y6_absmax over the conv's input view):
+ *                a = fp16(amax), inv = fp16(127 / a), x_q = clamp(rne(x * inv), -127, 127) with x the fp16 activation
+ *                (exact product, one rounding) - applied while the conv stages its input, or by the PRODUCER's
+ *                epilogue into an int8 twin tensor (q_out of the producer = q_in here: half the fill traffic)
+ *   accumulate   int8 x int8 -> int32, exact (v_mfma_i32_32x32x32_i8)
+ *   epilogue     fp32: y = fp32(acc) * dequant[c] + bias[c], dequant[c] = (fp32(a) / 127) * s_w[c]; then exactly the
+ *                fp16 conv's epilogue (kept post-BN affine of QARepVGG common.py:338-339, activation, residual)
+ * conv.in / conv.out are fp16 NHWC views as for y6_conv2d (conv.out.data may be NULL when only q_out is wanted);
+ * conv.w_packed is the y6_pack_conv_weight_i8 image; conv.variant: 0 = heuristic tile shape, 1..6 force.          */
+typedef struct y6_conv_i8_desc {
+    y6_conv_desc conv;
+    const float* dequant;      /* [Cout]                                                          */
+    float in_amax;             /* calibrated max|x| of the input view (ignored when q_in is given) */
+    y6_tensor q_in;            /* optional int8 NHWC view of the already quantised input (data NULL: none) */
+    y6_tensor q_out;           /* optional int8 NHWC twin of the output, quantised with q_out_amax  */
+    float q_out_amax;
+    void* acc_out;             /* optional int32 [B*Ho*Wo][Cout]: raw accumulators (parity tests)   */
+} y6_conv_i8_desc;
+int y6_conv2d_i8(const y6_conv_i8_desc* d, void* stream);
+/* src: int8 OIHW [Cout][Cin][K][K] -> [cout/32][cin/64][tap][kstep=2][lane=64][16] (zero padded); bytes of the image: */
+size_t y6_packed_weight_i8_bytes(int Cout, int Cin, int K);
+int y6_pack_conv_weight_i8(const void* src_i8_oihw, int Cout, int Cin, int K, void* dst, void* stream);
+/* Calibration: *out = max(*out, max|x|) over the fp16 view (device float, zero it before the first batch).       */
+int y6_absmax(const y6_tensor* x, float* out, void* stream);
+/* Quantise an fp16 view into an int8 view with the rule above (for tensors whose producer is not an int8 conv).  */
+int y6_quantize_i8(const y6_tensor* x, float amax, const y6_tensor* q, void* stream);
+
 /* ConvTranspose2d(k=2, s=2, bias) : out[b,2y+dy,2x+dx,:] = bias + in[b,y,x,:] @ W[:,:,dy,dx]
  * Replaces: Transpose.forward  yolov6/layers/common.py:193-194                           */
 typedef struct y6_convt_desc {
@@ -321,7 +356,8 @@ typedef struct y6_plan y6_plan;
 /* tags of training ops inside a plan (y6_plan_op_info reports them in `ksize` for Y6_OP_GENERIC) */
 enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_WGRAD_T = 4, Y6_TOP_WGRAD = 5,
        Y6_TOP_PACK = 6, Y6_TOP_POOL_BWD = 7, Y6_TOP_HEAD_PACK = 8, Y6_TOP_HEAD_UNPACK = 9, Y6_TOP_S2D = 10,
-       Y6_TOP_BIAS_GRAD = 11, Y6_TOP_FILL = 12, Y6_TOP_ADD = 13 };
+       Y6_TOP_BIAS_GRAD = 11, Y6_TOP_FILL = 12, Y6_TOP_ADD = 13,
+       Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16 };
 
 /* Batch statistics of a conv output + everything derived from them, on device:
  *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
@@ -557,6 +593,9 @@ y6_plan* y6_plan_create(void);
 void y6_plan_destroy(y6_plan* p);
 int y6_plan_add_conv(y6_plan* p, const y6_conv_desc* d);
 int y6_plan_add_convt(y6_plan* p, const y6_convt_desc* d);
+int y6_plan_add_conv_i8(y6_plan* p, const y6_conv_i8_desc* d);            /* generic op, tag Y6_TOP_CONV_I8 */
+int y6_plan_add_absmax(y6_plan* p, const y6_tensor* x, float* out);      /* calibration plans */
+int y6_plan_add_quantize_i8(y6_plan* p, const y6_tensor* x, float amax, const y6_tensor* q);
 int y6_plan_add_stem(y6_plan* p, const y6_stem_desc* d);
 int y6_plan_add_sppf(y6_plan* p, const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3);
 int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);

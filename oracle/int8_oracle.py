@@ -1,21 +1,27 @@
 """ORACLE (test infrastructure - never imported by the product path).  PARITY UNPINNED BY CONSTRUCTION.
 
-int8 inference of the QARepVGG deploy graph (BASELINE configs[4]).  The reference tree contains no
-int8 arithmetic: its int8 numbers come from TensorRT engines / NVIDIA pytorch_quantization fake-quant
-(deploy/TensorRT/onnx_to_trt.py:62-112, tools/qat/qat_utils.py:61-146), neither of which is in the tree or
-installed.  This file therefore DEFINES the quantisation the HIP int8 path will be held to:
+int8 inference of a deploy-form graph (BASELINE configs[4]: YOLOv6-S QARepVGG).  The reference tree
+contains no int8 arithmetic: its int8 numbers come from TensorRT engines / NVIDIA pytorch_quantization fake-quant
+(deploy/TensorRT/onnx_to_trt.py:62-112, tools/qat/qat_utils.py:61-146: per-channel 8-bit weights, per-tensor 8-bit
+activations, head skipped - configs/repopt/yolov6s_opt_qat.py:70-76), neither of which is in the tree or installed.
+This file therefore DEFINES the arithmetic the HIP int8 path is held to (the same rule is written in
+include/yolov6_hip.h next to y6_conv_i8_desc):
 
-  * weights      symmetric, per output channel:  s_w[c] = max|w[c]| / 127,  w_q = clamp(round_half_even(w / s_w), +-127)
-  * activations  symmetric, per tensor (the input of every quantised conv):  s_x = amax / 127 with amax the largest
-                 |x| seen over the calibration batches (4 synthetic batches, `calibrate`)
+  * the graph is the half-precision deploy graph (`Oracle(emulate_fp16=True)`: activations are fp16 tensors between ops);
+  * quantised: every conv of backbone and neck EXCEPT the one that reads the image; fp16 as before: that first conv, the
+    transposed convs, the whole detection head, the decode;
+  * weights      symmetric per output channel from the fp32 deploy weights:
+                 s_w[c] = max|w[c]| / 127,  w_q = clamp(rne(w / s_w[c]), -127, 127)
+  * activations  symmetric per tensor, amax = largest |x| the conv's input saw during calibration:
+                 a = fp16(amax), inv = fp16(127 / a),  x_q = clamp(rne(x * inv), -127, 127)
+                 (x, inv fp16 values; the product is taken exactly and rounded ONCE, half to even)
   * accumulate   int8 x int8 -> int32, exact (evaluated here as a float64 convolution of integer-valued tensors)
-  * epilogue     fp32:  y = acc * (s_x * s_w[c]) + bias[c], then the kept post-BatchNorm affine of QARepVGG
-                 (common.py:338-339) and the activation, exactly as the fp graph
-  * not quantised  the transposed convolutions, the whole detection head (stems, cls/reg convs, preds, proj_conv -
-                 the `skip` list of configs/repopt/yolov6s_opt_qat.py:70-76) and the decode
+  * epilogue     fp32, every operation rounded separately:  y = fp32(acc) * d[c] + bias[c],  d[c] = (fp32(a) / 127) * s_w[c];
+                 then the fp16 graph's tail: (round to fp16, kept post-BN affine of QARepVGG common.py:338-339),
+                 round to fp16, activation, round to fp16.
 
-The layer order (hence the key of every activation scale) is the call order of Oracle.conv_fused, which is
-deterministic for a given config.
+`int8_conv` is the single-op form (tests replay a native plan op by op with it); `Int8Oracle` walks the whole model.  The
+table of activation scales is a list in call order of the quantised convs.
 """
 import torch
 import torch.nn.functional as F
@@ -24,53 +30,93 @@ from .model_oracle import Oracle
 
 
 def quantize_sym(t, scale):
-    """clamp(round_half_even(t / scale), -127, 127) as an integer-valued fp32 tensor."""
+    """clamp(round_half_even(t / scale), -127, 127) as an integer-valued fp32 tensor (weights)."""
     return torch.clamp(torch.round(t / scale), -127, 127)
+
+
+def quantize_weight(w):
+    w = w.detach().float()
+    s_w = w.abs().amax(dim=(1, 2, 3)).clamp_min(1e-12) / 127.0
+    return quantize_sym(w, s_w.view(-1, 1, 1, 1)), s_w
+
+
+def act_constants(amax):
+    """(a, inv) as fp16-valued python floats."""
+    a = torch.tensor(float(amax), dtype=torch.float32).half()
+    inv = (torch.tensor(127.0, dtype=torch.float32) / a.float()).half()
+    return float(a), float(inv)
+
+
+def quantize_act(x, amax):
+    """x: fp16-valued tensor.  Exact product in float64 (11-bit x 11-bit significands), one half-to-even rounding."""
+    a, inv = act_constants(amax)
+    xc = torch.clamp(x.double(), -a, a)
+    return torch.round(xc * inv)          # |xc * inv| <= 127.07: never reaches +-128
+
+
+def int8_accumulate(x, w, stride, amax):
+    xq = quantize_act(x, amax)
+    wq, s_w = quantize_weight(w)
+    acc = F.conv2d(xq, wq.double(), None, stride=stride, padding=w.shape[-1] // 2)    # exact integers
+    return acc, s_w
+
+
+def int8_conv(orc, x, w, b, stride, act, post, amax):
+    """One quantised conv + its fused tail; `orc` supplies the fp16 rounding (`q`) and the activation."""
+    acc, s_w = int8_accumulate(x, w, stride, amax)
+    a, _ = act_constants(amax)
+    d = (torch.tensor(a, dtype=torch.float32) / 127.0) * s_w.float()
+    y = acc.float() * d.view(1, -1, 1, 1)
+    if b is not None:
+        y = y + b.detach().float().view(1, -1, 1, 1)
+    if post is not None:
+        y = orc.q(y) * orc.q(post[0]).view(1, -1, 1, 1) + orc.q(post[1]).view(1, -1, 1, 1)
+    return orc.q(orc.act(orc.q(y), act)), acc
 
 
 class Int8Oracle(Oracle):
     def __init__(self, cfg, sd_deploy, num_classes=80):
-        super().__init__(cfg, sd_deploy, num_classes, emulate_fp16=False)
-        self.amax = {}            # conv index -> calibrated |x| max of its input
+        super().__init__(cfg, sd_deploy, num_classes, emulate_fp16=True)
+        self.amax = None          # list, call order of the quantised convs
         self.calibrating = False
-        self._idx = 0
+        self._calls = 0           # conv_fused calls of the current forward (call 0 reads the image)
+        self._qidx = 0
         self._in_head = False
-        self.stats = {}           # conv index -> dict(s_x, acc_absmax) of the last forward
+        self.layers = []          # per quantised conv: dict(cin, cout, k, stride) - compared with the product's lowering order
+        self.stats = []           # per quantised conv of the last forward: dict(acc_absmax)
 
     # ------------------------------------------------------------------ calibration
     def calibrate(self, batches):
         self.calibrating = True
-        self.amax = {}
+        self.amax = []
         with torch.no_grad():
             for x in batches:
-                self._idx = 0
-                super().forward(x)
+                self.forward(x)
         self.calibrating = False
-        return dict(self.amax)
+        return list(self.amax)
 
     # ------------------------------------------------------------------ the quantised conv
     def conv_fused(self, x, w, b, stride, act, post=None):
-        i = self._idx
-        self._idx += 1
-        if self._in_head:
+        first = self._calls == 0
+        self._calls += 1
+        if self._in_head or first:
             return super().conv_fused(x, w, b, stride, act, post)
+        i = self._qidx
+        self._qidx += 1
+        if i == len(self.layers):
+            self.layers.append(dict(cin=w.shape[1], cout=w.shape[0], k=w.shape[-1], stride=stride))
         if self.calibrating:
-            self.amax[i] = max(self.amax.get(i, 0.0), float(x.abs().max()))
+            m = float(x.abs().max())
+            if i == len(self.amax):
+                self.amax.append(m)
+            else:
+                self.amax[i] = max(self.amax[i], m)
             return super().conv_fused(x, w, b, stride, act, post)
-        if i not in self.amax:
-            raise RuntimeError("Int8Oracle: call calibrate() before forward()")
-        s_x = max(self.amax[i], 1e-12) / 127.0
-        s_w = w.abs().amax(dim=(1, 2, 3)).clamp_min(1e-12) / 127.0
-        xq = quantize_sym(x, s_x)
-        wq = quantize_sym(w, s_w.view(-1, 1, 1, 1))
-        acc = F.conv2d(xq.double(), wq.double(), None, stride=stride, padding=w.shape[-1] // 2)   # exact int32 values
-        self.stats[i] = dict(s_x=s_x, acc_absmax=float(acc.abs().max()))
-        y = acc.float() * (s_x * s_w).view(1, -1, 1, 1)
-        if b is not None:
-            y = y + b.view(1, -1, 1, 1)
-        if post is not None:
-            y = y * post[0].view(1, -1, 1, 1) + post[1].view(1, -1, 1, 1)
-        return self.act(y, act)
+        if self.amax is None or i >= len(self.amax):
+            raise RuntimeError("Int8Oracle: call calibrate() (or set .amax) before forward()")
+        y, acc = int8_conv(self, x, w, b, stride, act, post, self.amax[i])
+        self.stats.append(dict(acc_absmax=float(acc.abs().max())))
+        return y
 
     def head(self, feats):
         self._in_head = True
@@ -81,6 +127,8 @@ class Int8Oracle(Oracle):
 
     def forward(self, x, train_form=False):
         assert not train_form, "the int8 graph is the deploy form"
-        self._idx = 0
-        self.stats = {}
-        return super().forward(x, train_form=False)
+        self._calls = 0
+        self._qidx = 0
+        self.layers = []
+        self.stats = []
+        return super().forward(self.q(x), train_form=False)

@@ -55,6 +55,15 @@ class OracleChain:
                 a = 1.0 if e["alpha"] is None else o.q(e["alpha"].detach().float().cpu())
                 y = o.q(y + o.q(a * self._get(e["res"])))
             return [(e["out"], y)]
+        if k == "conv_i8":       # int8 conv (oracle/int8_oracle.py defines the arithmetic; scales come from the plan's op log)
+            from oracle.int8_oracle import int8_conv
+            b = None if e["b"] is None else e["b"].detach().float().cpu()
+            post = None if e["post"] is None else tuple(t.detach().float().cpu() for t in e["post"])
+            y, _ = int8_conv(o, self._get(e["x"]), e["w"].detach().float().cpu(), b, e["stride"], e["act"], post, e["amax"])
+            if e["res"] is not None:
+                a = 1.0 if e["alpha"] is None else o.q(e["alpha"].detach().float().cpu())
+                y = o.q(y + o.q(a * self._get(e["res"])))
+            return [(e["out"], y)]
         if k == "convt":
             y = F.conv_transpose2d(self._get(e["x"]), o.q(e["w"].detach().float().cpu()),
                                    o.q(e["b"].detach().float().cpu()), stride=2)
@@ -72,7 +81,7 @@ class OracleChain:
         plan = self.plan
         for i, e in enumerate(plan.op_log):
             k = e["kind"]
-            if k == "nhwc2nchw":
+            if k in ("nhwc2nchw", "absmax"):
                 continue
             if k == "decode":
                 cls = [self._get(r) for r in e["cls"]]
@@ -95,6 +104,10 @@ class OracleChain:
                     r = e.get(key)
                     if r is not None and not isinstance(r, torch.Tensor):
                         self._upload(r, self._get(r))
+                if e.get("q_in") is not None:        # the op reads the producer's int8 twin: teacher-force that too
+                    from oracle.int8_oracle import quantize_act
+                    qv = quantize_act(self._get(e["x"]), e["amax"]).to(torch.int8)
+                    e["q_in"].to_nhwc_tensor().copy_(qv.permute(0, 2, 3, 1).to(e["q_in"].buf.device))
             outs = self._oracle_op(e)
             for r, v in outs:
                 self._put(r, v)
@@ -102,17 +115,29 @@ class OracleChain:
                 plan.run_range(i, i + 1)
                 torch.cuda.synchronize()
                 err = err_abs = 0.0
-                for r, v in outs:
-                    d = (self._download(r) - v).abs()
-                    err = max(err, float((d / v.abs().clamp(min=1.0)).max()))
-                    err_abs = max(err_abs, float(d.max()))
-                self.rows.append(dict(op=i, kind=k, desc=_describe(e), err=err, err_abs=err_abs))
+                twin_mismatch = None
+                if e.get("q_out") is not None:       # the int8 copy for the consumers must be the quantised oracle output, exactly
+                    from oracle.int8_oracle import quantize_act
+                    want = quantize_act(outs[0][1], e["q_out_amax"]).to(torch.int8)
+                    got = e["q_out"].to_nhwc_tensor().cpu().permute(0, 3, 1, 2)
+                    twin_mismatch = float((got != want).float().mean())
+                    a16 = float(torch.tensor(e["q_out_amax"]).half())
+                    err = max(err, float((got.float() - want.float()).abs().max()) * a16 / 127.0 / max(1.0, a16))
+                if e.get("has_out", True):
+                    for r, v in outs:
+                        d = (self._download(r) - v).abs()
+                        err = max(err, float((d / v.abs().clamp(min=1.0)).max()))
+                        err_abs = max(err_abs, float(d.max()))
+                row = dict(op=i, kind=k, desc=_describe(e), err=err, err_abs=err_abs)
+                if twin_mismatch is not None:
+                    row["twin_mismatch"] = twin_mismatch
+                self.rows.append(row)
         return self.rows
 
 
 def _describe(e):
     k = e["kind"]
-    if k in ("conv", "stem"):
+    if k in ("conv", "stem", "conv_i8"):
         w = e["w"]
         o = e["out"]
         extra = ("+post" if e["post"] is not None else "") + ("+res" if e["res"] is not None else "")

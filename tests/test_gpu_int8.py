@@ -1,0 +1,246 @@
+"""GPU: the int8 path (BASELINE configs[4]) against oracle/int8_oracle.py.
+
+The reference tree holds no int8 arithmetic (its int8 numbers are TensorRT engines), so the oracle DEFINES the rule
+(parity unpinned by construction) and these tests hold the HIP kernels to it:
+  * single ops through the C ABI: int32 accumulators bit-exact, fp16 outputs bit-exact for conv+bias(+ReLU);
+  * the producer-side int8 twin (q_out -> q_in) equals quantise-on-load bit for bit;
+  * calibration reductions / the stand-alone quantiser bit-exact;
+  * the whole S-qa model: device calibration vs the oracle's, per-layer teacher-forced replay, end to end.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.int8_oracle import Int8Oracle, act_constants, int8_accumulate, int8_conv, quantize_act
+from oracle.model_oracle import Oracle, deploy_state_dict
+from tests.gpu_utils import DEV, rand_nhwc
+from tests.helpers import case_config, synth_sd_from_keys
+from yolov6_amd import _lib, quant
+from yolov6_amd.engine import ACT_BY_NAME, PlanBuilder, TRef
+
+pytestmark = pytest.mark.gpu
+
+
+def _nchw(ref):
+    return ref.to_nhwc_tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _run_i8(x, w, b, stride, act, amax, post=None, variant=0, q_in=None, q_out=None, q_out_amax=0.0, want_out=True):
+    """One y6_conv2d_i8 call; returns (out TRef or None, int32 accumulators [B,Cout,Ho,Wo])."""
+    lib = _lib.load()
+    pb = PlanBuilder(DEV)
+    Cout, Cin, K, _ = w.shape
+    Ho = (x.H + 2 * (K // 2) - K) // stride + 1
+    Wo = (x.W + 2 * (K // 2) - K) // stride + 1
+    out = pb.new_buffer(x.B, Ho, Wo, Cout)
+    wq, s_w = quant.quantize_weight(w)
+    wq_d = wq.to(DEV)
+    packed = torch.empty(lib.y6_packed_weight_i8_bytes(Cout, Cin, K), dtype=torch.int8, device=DEV)
+    _lib.check(lib.y6_pack_conv_weight_i8(C.c_void_p(wq_d.data_ptr()), Cout, Cin, K, C.c_void_p(packed.data_ptr()), None), "pack")
+    dq = quant.dequant_vector(amax, s_w).to(DEV)
+    acc = torch.full((x.B, Ho, Wo, Cout), -7, dtype=torch.int32, device=DEV)
+    d = _lib.ConvI8Desc()
+    c = d.conv
+    c.inp = x.ct()
+    c.out = out.ct() if want_out else _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+    c.w_packed = C.c_void_p(packed.data_ptr())
+    bias = None if b is None else b.float().to(DEV)
+    ps = pt = None
+    if post is not None:
+        ps, pt = post[0].half().float().to(DEV), post[1].half().float().to(DEV)
+    c.bias = C.c_void_p(bias.data_ptr()) if bias is not None else None
+    c.post_scale = C.c_void_p(ps.data_ptr()) if ps is not None else None
+    c.post_shift = C.c_void_p(pt.data_ptr()) if pt is not None else None
+    c.res = _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+    c.ksize, c.stride, c.act, c.variant = K, stride, ACT_BY_NAME[act], variant
+    d.dequant = C.c_void_p(dq.data_ptr())
+    d.in_amax = float(amax)
+    d.q_in = q_in.ct() if q_in is not None else _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+    d.q_out = q_out.ct() if q_out is not None else _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+    d.q_out_amax = float(q_out_amax)
+    d.acc_out = C.c_void_p(acc.data_ptr())
+    _lib.check(lib.y6_conv2d_i8(C.byref(d), None), "conv2d_i8")
+    torch.cuda.synchronize()
+    return (out if want_out else None), acc.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _i8_buffer(B, H, W, Cn):
+    t = torch.zeros((B, H, W, Cn), dtype=torch.int8, device=DEV)
+    return TRef(t, B, H, W, Cn, Cn, 0)
+
+
+CASES = [  # B, H, W, Cin, Cout, K, stride, act, variant
+    (2, 20, 20, 64, 64, 3, 1, "relu", 0),
+    (1, 17, 23, 32, 48, 3, 1, "relu", 0),        # ragged map, Cin below one 64-channel chunk, Cout not a fragment multiple
+    (1, 12, 12, 96, 128, 3, 1, None, 5),         # one and a half chunks
+    (2, 16, 16, 128, 256, 3, 2, "relu", 0),      # stride 2, four cout fragments per block
+    (1, 21, 19, 64, 32, 3, 2, "relu", 1),
+    (2, 13, 11, 192, 96, 1, 1, "relu", 0),
+    (1, 40, 40, 256, 64, 1, 1, None, 2),
+    (1, 10, 10, 64, 64, 3, 1, "relu", 4),
+    (1, 10, 10, 64, 128, 3, 1, "relu", 6),
+    (1, 9, 9, 72, 40, 3, 1, "relu", 0),          # 8-channel granular Cin / Cout
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv_i8_accumulators_and_outputs_bit_exact(case):
+    B, H, W, Cin, Cout, K, stride, act, variant = case
+    g = torch.Generator().manual_seed(sum(hash(str(v)) % 1000 for v in case))
+    x = rand_nhwc(B, H, W, Cin, seed=3, scale=4.0)
+    w = torch.randn((Cout, Cin, K, K), generator=g) * 0.2
+    b = torch.randn((Cout,), generator=g)
+    amax = 3.1                                   # below the data's range: exercises the clamp
+    out, acc = _run_i8(x, w, b, stride, act, amax, variant=variant)
+    xin = _nchw(x)
+    ref_acc, _ = int8_accumulate(xin, w, stride, amax)
+    assert torch.equal(acc.double(), ref_acc), "int32 accumulators differ"
+    ref, _ = int8_conv(_Q16(), xin, w, b, stride, act, None, amax)
+    got = _nchw(out)
+    assert torch.equal(got, ref), f"fp16 outputs differ: max {float((got - ref).abs().max()):.3e}"
+
+
+class _Q16:
+    """The two hooks int8_conv needs from an oracle: fp16 rounding and the activation."""
+    fp16 = True
+
+    @staticmethod
+    def q(t):
+        return t.half().float()
+
+    act = staticmethod(Oracle.act)
+
+
+def test_conv_i8_post_affine_and_silu_within_one_rounding():
+    """QARepVGG's kept post-BN (common.py:338-339) and SiLU: the epilogue contracts `x*s + t` into one fma and uses the fast
+    exponential, the oracle rounds twice / uses torch's: isolated one-ulp differences of the fp16 result are allowed."""
+    g = torch.Generator().manual_seed(5)
+    x = rand_nhwc(2, 18, 18, 64, seed=9, scale=2.0)
+    w = torch.randn((96, 64, 3, 3), generator=g) * 0.1
+    b = torch.randn((96,), generator=g) * 0.5
+    post = (torch.rand((96,), generator=g) + 0.5, torch.randn((96,), generator=g) * 0.2)
+    for act, tol in (("relu", 2.0 ** -10), ("silu", 2 * 2.0 ** -10)):
+        out, acc = _run_i8(x, w, b, 1, act, 2.0, post=post)
+        ref, racc = int8_conv(_Q16(), _nchw(x), w, b, 1, act, post, 2.0)
+        assert torch.equal(acc.double(), racc)
+        got = _nchw(out)
+        rel = ((got - ref).abs() / ref.abs().clamp(min=1.0))
+        assert float(rel.max()) <= tol * 1.002
+        assert float((got != ref).float().mean()) < 2e-2
+
+
+def test_int8_twin_output_equals_quantise_on_load():
+    """Producer epilogue writes the int8 twin (q_out); a consumer reading it (q_in) must give the SAME accumulators as a
+    consumer that quantises the fp16 tensor while loading it.  Also the stand-alone quantiser."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    x = rand_nhwc(2, 24, 24, 64, seed=4, scale=3.0)
+    w1 = torch.randn((128, 64, 3, 3), generator=g) * 0.1
+    b1 = torch.randn((128,), generator=g) * 0.3
+    w2 = torch.randn((64, 128, 3, 3), generator=g) * 0.1
+    a_in, a_mid = 2.5, 4.0
+    twin = _i8_buffer(2, 24, 24, 128)
+    mid, _ = _run_i8(x, w1, b1, 1, "relu", a_in, q_out=twin, q_out_amax=a_mid)
+    # (1) the twin holds quantize_act(fp16 output)
+    want = quantize_act(_nchw(mid), a_mid).to(torch.int8)
+    got = twin.buf.cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, want)
+    # (2) stand-alone quantiser
+    q2 = _i8_buffer(2, 24, 24, 128)
+    mt, qt = mid.ct(), q2.ct()
+    _lib.check(lib.y6_quantize_i8(C.byref(mt), C.c_float(a_mid), C.byref(qt), None), "quantize_i8")
+    torch.cuda.synchronize()
+    assert torch.equal(q2.buf, twin.buf)
+    # (3) consumer through the twin == consumer quantising on load; int8-only output (no fp16 tensor written)
+    o_a, acc_a = _run_i8(mid, w2, None, 1, "relu", a_mid)
+    o_b, acc_b = _run_i8(mid, w2, None, 1, "relu", a_mid, q_in=twin)
+    assert torch.equal(acc_a, acc_b) and torch.equal(o_a.buf, o_b.buf)
+    only = _i8_buffer(2, 24, 24, 64)
+    _, acc_c = _run_i8(mid, w2, None, 1, "relu", a_mid, q_in=twin, q_out=only, q_out_amax=5.0, want_out=False)
+    assert torch.equal(acc_c, acc_a)
+    assert torch.equal(only.buf.cpu().permute(0, 3, 1, 2), quantize_act(_nchw(o_a), 5.0).to(torch.int8))
+
+
+def test_absmax_exact_on_views():
+    lib = _lib.load()
+    x = rand_nhwc(3, 15, 17, 40, cstride=64, coff=16, seed=8, scale=9.0)
+    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    xt = x.ct()
+    _lib.check(lib.y6_absmax(C.byref(xt), C.c_void_p(out.data_ptr()), None), "absmax")
+    _lib.check(lib.y6_absmax(C.byref(xt), C.c_void_p(out.data_ptr()), None), "absmax")   # idempotent (running max)
+    torch.cuda.synchronize()
+    assert float(out) == float(x.to_nhwc_tensor().float().abs().max())
+
+
+def _qa_model(case="s_qa_tiny"):
+    from yolov6_amd.models.yolo import build_model
+    from yolov6_amd.utils import synth
+    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+    cfg, meta = case_config(case)
+    sd_train = synth_sd_from_keys(meta["train"])
+    model = build_model(cfg, meta["num_classes"], "cpu").eval()
+    model.load_state_dict(sd_train)
+    switch_to_deploy(fuse_model(model))
+    sd = deploy_state_dict(cfg, sd_train, meta["num_classes"])
+    return cfg, meta, sd, model.to(DEV).half(), synth
+
+
+def test_int8_model_calibration_layers_and_end_to_end():
+    cfg, meta, sd, model, _ = _qa_model()
+    from oracle import synth
+    nc, size = meta["num_classes"], meta["size"]
+    cal = [synth.synth_images(2, size, seed=100 + i) for i in range(4)]
+    x = synth.synth_images(max(meta["batch"], 2), size, seed=1)
+    orc = Int8Oracle(cfg, sd, nc)
+    table_ref = orc.calibrate(cal)
+    # (a) device calibration: same convs in the same order, scales equal up to the fp16 noise of the fp16 forward
+    table = quant.calibrate(model, [c.to(DEV).half() for c in cal])
+    assert len(table) == len(table_ref)
+    rel = max(abs(a - b) / b for a, b in zip(table, table_ref))
+    assert rel < 5e-3, f"device calibration deviates from the oracle's by {rel:.3e}"
+    # (b) int8 plan with the ORACLE's table: lowering order == oracle call order.  First with fp16-only activations
+    # (every int8 conv quantises while loading), then with int8 twins written by the producers: bit-identical detections
+    xd = x.to(DEV).half()
+    quant.quantize(model, table_ref, twins=False)
+    det_plain = model.compile(xd, autotune=False).run().clone()
+    quant.quantize(model, table_ref, twins=True)
+    plan = model.compile(xd, autotune=False)
+    st_layers = model.__dict__["_y6_quant"].layers
+    with torch.no_grad():
+        ref, _ = orc.forward(x)
+    assert [(l["cin"], l["cout"], l["k"], l["stride"]) for l in st_layers] == [(l["cin"], l["cout"], l["k"], l["stride"]) for l in orc.layers]
+    n_i8 = sum(1 for e in plan.op_log if e["kind"] == "conv_i8")
+    assert n_i8 == len(table_ref) and n_i8 > 20
+    det = plan.run().clone()
+    torch.cuda.synchronize()
+    n_twin_in = sum(1 for e in plan.op_log if e["kind"] == "conv_i8" and e["q_in"] is not None)
+    n_no_fp16 = sum(1 for e in plan.op_log if e["kind"] == "conv_i8" and not e["has_out"])
+    print(f"int8 convs {n_i8}: {n_twin_in} read an int8 twin, {n_no_fp16} write no fp16 tensor")
+    assert n_twin_in > n_i8 // 2 and n_no_fp16 > 0
+    assert torch.equal(det, det_plain), "int8 twins changed the result"
+    # (c) per layer, teacher-forced on the oracle's activations
+    from tests.plan_replay import OracleChain
+    with torch.no_grad():
+        free = OracleChain(plan, orc)
+        free.run(teacher_force=False)
+        sync = float(((free.final - ref).abs() / ref.abs().clamp(min=1.0)).max())
+        assert sync < 2e-3, f"op-by-op oracle walk deviates from Int8Oracle.forward by {sync:.3e}"
+        rows = OracleChain(plan, orc).run(teacher_force=True)
+    worst = max((r for r in rows if r["kind"] == "conv_i8"), key=lambda r: r["err"])
+    print(f"int8 per-layer worst: {worst['desc']} err {worst['err']:.3e}")
+    assert worst["err"] <= 2.0 ** -10 * 1.002, worst           # one fp16 ulp (fma contraction in the kept post-BN)
+    tm = [r["twin_mismatch"] for r in rows if "twin_mismatch" in r]
+    assert tm and max(tm) < 2e-2, f"int8 twins: fraction of codes off by one step {max(tm):.3e}"
+    # (d) end to end, free running: a one-ulp fp16 flip upstream can move an int8 code by one step downstream
+    d = (det.float().cpu() - ref).abs()
+    e_cls, e_box = float(d[..., 5:].max()), float(d[..., :4].max())
+    with torch.no_grad():
+        d16, _ = Oracle(cfg, sd, nc, emulate_fp16=True).forward(x)
+    q_cls = float((ref[..., 5:] - d16[..., 5:]).abs().max())
+    print(f"int8 HIP vs int8 oracle: cls {e_cls:.3e} box {e_box:.3e} px; quantisation error of the oracle itself vs fp16: cls {q_cls:.3e}")
+    assert e_cls < max(0.25 * q_cls, 4e-3)
+    quant.dequantize(model)
+    det16 = model(xd)[0]
+    assert float((det16.float().cpu()[..., 5:] - d16[..., 5:]).abs().max()) < 5e-3      # back on the fp16 plan

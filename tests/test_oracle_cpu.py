@@ -234,28 +234,37 @@ def test_train_mode_forward_oracle_matches_reference_golden(case):
 # ------------------------------------------------------------------ int8 QARepVGG oracle (a17: parity unpinned, spec only)
 def test_int8_oracle_spec_properties():
     """The int8 oracle DEFINES the quantisation (no int8 exists in the reference tree): check what a definition can
-    be checked for - exact integer accumulators inside int32, determinism, sensible accuracy against the fp32 graph."""
-    from oracle.int8_oracle import Int8Oracle, quantize_sym
+    be checked for - exact integer accumulators inside int32, determinism, the rounding rules, sensible accuracy against
+    the fp16 graph it is derived from."""
+    from oracle.int8_oracle import Int8Oracle, quantize_sym, quantize_act, act_constants
     cfg, meta = case_config("s_qa_tiny")
     sd = deploy_state_dict(cfg, synth_sd_from_keys(meta["train"]), meta["num_classes"])
     cal = [synth.synth_images(2, meta["size"], seed=100 + i) for i in range(4)]
     x = synth.synth_images(meta["batch"], meta["size"], seed=1)
     q = Int8Oracle(cfg, sd, meta["num_classes"])
     amax = q.calibrate(cal)
-    assert len(amax) > 20 and all(v > 0 for v in amax.values())
+    assert len(amax) > 20 and all(v > 0 for v in amax)
     with torch.no_grad():
         d8, _ = q.forward(x)
+        n_q = len(q.stats)
         d8b, _ = q.forward(x)
-        d32, _ = Oracle(cfg, sd, meta["num_classes"]).forward(x)
+        d16, _ = Oracle(cfg, sd, meta["num_classes"], emulate_fp16=True).forward(x)
     assert torch.equal(d8, d8b)                                               # deterministic
-    assert all(s["acc_absmax"] < 2 ** 31 for s in q.stats.values())           # fits the int32 accumulator
-    assert set(q.stats) == set(amax)                                          # every calibrated conv ran quantised
-    # round-half-even and clamping
+    assert n_q == len(amax) == len(q.layers)                                  # every calibrated conv ran quantised
+    assert all(s["acc_absmax"] < 2 ** 31 for s in q.stats)                    # fits the int32 accumulator
+    assert q.layers[0]["cin"] >= 8                                            # the image-reading conv is not in the table
+    # weights: round-half-even and clamping
     t = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 300.0, -300.0])
     assert quantize_sym(t, 1.0).tolist() == [0.0, 2.0, 2.0, -0.0, -2.0, 127.0, -127.0]
-    # accuracy against the fp32 deploy graph on this random-weight model: class scores within a few 1e-2
-    e = float((d8[..., 5:] - d32[..., 5:]).abs().max())
-    print(f"int8 vs fp32 class scores: max abs diff {e:.3e}")
+    # activations: fp16 constants, exact product, ONE half-to-even rounding, never +-128
+    a, inv = act_constants(3.0)
+    assert a == 3.0 and inv == float(torch.tensor(127.0 / 3.0).half())
+    xs = torch.tensor([3.0, -3.0, 10.0, -10.0, 0.0, 1.5 / inv, 2.5 / inv]).half().float()
+    got = quantize_act(xs, 3.0).tolist()
+    assert got[:5] == [127.0, -127.0, 127.0, -127.0, 0.0] and all(abs(v) <= 127 for v in got)
+    # accuracy against the fp16 deploy graph on this random-weight model: class scores within a few 1e-2
+    e = float((d8[..., 5:] - d16[..., 5:]).abs().max())
+    print(f"int8 vs fp16 class scores: max abs diff {e:.3e}")
     assert e < 0.1
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # One GPU-box visit: smoke, -m gpu tests, bench (+ autotune log, per-op table), rocprofv3 kernel stats.
 # Everything of interest lands under gpurun_out/ (merged back by gpurun).
-#   usage: tools/gpu_round.sh [tag] [what...]    what in {smoke,tests,bench,prof,pmc,train,trainprof,l6} (default: smoke tests bench prof)
+#   usage: tools/gpu_round.sh [tag] [what...]    what in {smoke,tests,bench,prof,pmc,train,trainprof,l6,int8} (default: smoke tests bench prof)
 set -u
 TAG=${1:-r01}
 shift || true
@@ -54,6 +54,15 @@ if has l6; then
   echo "== L6 1280 b8 (configs[3])"
   timeout 1200 python bench.py --model yolov6l6 --size 1280 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline --dropin-steps 10 > "$OUT/bench_l6.json" 2> "$OUT/bench_l6.err"
   echo "l6 rc=$?"; tail -2 "$OUT/bench_l6.err"; cut -c1-700 "$OUT/bench_l6.json"
+fi
+if has int8; then
+  echo "== int8 (configs[4]): tests, then fp16 and int8 plans of the same S-qa model in one visit"
+  timeout 900 python -m pytest tests/test_gpu_int8.py -q --tb=short --timeout 600 -p no:cacheprovider -s > "$OUT/pytest_int8.log" 2>&1
+  echo "pytest int8 rc=$?" | tee -a "$OUT/pytest_int8.log"; tail -25 "$OUT/pytest_int8.log"
+  timeout 900 python bench.py --model yolov6s_qa --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/bench_qa_fp16_ops.json" > "$OUT/bench_qa_fp16.json" 2> "$OUT/bench_qa_fp16.err"
+  echo "qa fp16 rc=$?"; tail -2 "$OUT/bench_qa_fp16.err"; cut -c1-400 "$OUT/bench_qa_fp16.json"
+  timeout 900 python bench.py --model yolov6s_qa --int8 --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/bench_qa_int8_ops.json" > "$OUT/bench_qa_int8.json" 2> "$OUT/bench_qa_int8.err"
+  echo "qa int8 rc=$?"; tail -2 "$OUT/bench_qa_int8.err"; cut -c1-1500 "$OUT/bench_qa_int8.json"
 fi
 if has pmc; then
   echo "== rocprofv3 pmc (separate passes)"

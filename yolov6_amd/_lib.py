@@ -29,6 +29,11 @@ class ConvDesc(C.Structure):
                 ("variant", C.c_int32)]
 
 
+class ConvI8Desc(C.Structure):
+    _fields_ = [("conv", ConvDesc), ("dequant", C.c_void_p), ("in_amax", C.c_float), ("q_in", Tensor), ("q_out", Tensor),
+                ("q_out_amax", C.c_float), ("acc_out", C.c_void_p)]
+
+
 class ConvTDesc(C.Structure):
     _fields_ = [("inp", Tensor), ("out", Tensor), ("w_packed", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -149,7 +154,7 @@ class LossGradDesc(C.Structure):
 
 WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
 TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
-             8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add"}
+             8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize"}
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
@@ -162,6 +167,11 @@ SIGNATURES = {
     "y6_pack_conv_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_pack_convt2x2_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "y6_conv2d_i8": (C.c_int, [C.POINTER(ConvI8Desc), C.c_void_p]),
+    "y6_packed_weight_i8_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "y6_pack_conv_weight_i8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "y6_absmax": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p]),
+    "y6_quantize_i8": (C.c_int, [C.POINTER(Tensor), C.c_float, C.POINTER(Tensor), C.c_void_p]),
     "y6_conv_variants": (C.c_int, []),
     "y6_conv_variant_name": (C.c_char_p, [C.c_int]),
     "y6_conv_variant_supports": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
@@ -227,6 +237,9 @@ SIGNATURES = {
     "y6_plan_create": (C.c_void_p, []),
     "y6_plan_destroy": (None, [C.c_void_p]),
     "y6_plan_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvDesc)]),
+    "y6_plan_add_conv_i8": (C.c_int, [C.c_void_p, C.POINTER(ConvI8Desc)]),
+    "y6_plan_add_absmax": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_void_p]),
+    "y6_plan_add_quantize_i8": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_float, C.POINTER(Tensor)]),
     "y6_plan_add_convt": (C.c_int, [C.c_void_p, C.POINTER(ConvTDesc)]),
     "y6_plan_add_stem": (C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
     "y6_plan_add_sppf": (C.c_int, [C.c_void_p] + [C.POINTER(Tensor)] * 4),

@@ -33,6 +33,7 @@ SOURCES = {
     "bn_train.hip": [],
     "train.hip": [],
     "wgrad.hip": [],
+    "quant.hip": [],
     "plan.hip": [],
 }
 HEADERS = ["common.hpp", "plan_internal.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]

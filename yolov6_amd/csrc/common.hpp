@@ -75,5 +75,7 @@ int y6_conv_naive_launch(const y6_conv_desc* d, hipStream_t s);                 
 int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s,      // conv_mfma.hip
                         int up, int updy, int updx);
 int y6_conv_mfma_supports(const y6_conv_desc* d, int variant);
+int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s);             // conv_mfma.hip (int8 kernels)
+int y6_conv_i8_variant(const y6_conv_i8_desc* q);
 double y6_conv_flops(const y6_conv_desc* d);
 double y6_conv_bytes(const y6_conv_desc* d);

@@ -45,6 +45,15 @@ struct ConvKArgs {
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
     unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
+    // int8 kernels (conv_i8_kernel) only
+    const float* qscale;            // [Cout] s_x * s_w[c]
+    unsigned q_inv2, q_lo2, q_hi2;  // half2 constants of the input quantiser: 127/amax, -amax, +amax
+    const signed char* qin;         // optional int8 NHWC input view (then `in` is not read)
+    int qin_cs, qin_co;
+    signed char* qout;              // optional int8 NHWC copy of the output, quantised for its consumers
+    int qout_cs, qout_co;
+    unsigned qo_inv2, qo_lo2, qo_hi2;
+    int* acc_out;                   // optional raw int32 accumulators [pixel][Cout] (parity tests)
 };
 
 // LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it
@@ -476,6 +485,290 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
         conv_epilogue_lds<CF, PF>(a, acc, opix, cb, upc0, lane, wave, bz, smem);
     else
         conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane, bz);
+}
+
+// ------------------------------------------------------------------------------------------
+// int8 conv (BASELINE configs[4]): int8 x int8 -> int32 on v_mfma_i32_32x32x32_i8, fp32 requantisation in
+// the epilogue.  Same structure as conv_mfma_kernel (one block per (tile, cout block), halo chunk staged once and re-used
+// by all taps, weights by LDS-DMA through a 3-slot ring) with a chunk of 64 INPUT CHANNELS = 64 B per halo pixel, i.e.
+// the LDS images, pitches and fragment addresses are those of the fp16 kernel's 32-channel chunk and every MFMA does
+// twice the work.
+// The input is either the fp16 activation tensor, quantised on its way into LDS -
+//     q = clamp(rne(x * inv), -127, 127),  inv = fp16(127 / fp16(amax))      (exact product, ONE rounding: v_pk_fma_f16
+//     with the addend 1536 = 1.5 * 2^10, whose fp16 ulp is 1: the low byte of the result IS the two's-complement q)
+// - or an int8 twin written by the producer's epilogue with the same formula (`qin`; halves the fill traffic).
+// Operand K order: lane half h of k-step ks holds channels 64*chunk + 32*ks + 16*h + (0..15) for the pixel operand and
+// for the weight operand alike (y6_pack_conv_weight_i8), so whatever K index the hardware assigns to (h, byte) is the
+// same on both sides.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned q8_pair(unsigned x2, unsigned inv2, unsigned lo2, unsigned hi2) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3\n\tv_pk_fma_f16 %0, %0, %4, %5"
+        : "=&v"(r)
+        : "v"(x2), "v"(lo2), "v"(hi2), "v"(inv2), "v"(0x66006600u));
+    return r;   // two fp16 values 1536 + q: low bytes are the int8 codes
+}
+__device__ __forceinline__ unsigned q8_quad(unsigned a, unsigned b, unsigned inv2, unsigned lo2, unsigned hi2) {
+    return __builtin_amdgcn_perm(q8_pair(b, inv2, lo2, hi2), q8_pair(a, inv2, lo2, hi2), 0x06040200u);
+}
+__device__ __forceinline__ uint4 q8_piece(const uint4& lo, const uint4& hi, unsigned inv2, unsigned lo2, unsigned hi2) {
+    return make_uint4(q8_quad(lo.x, lo.y, inv2, lo2, hi2), q8_quad(lo.z, lo.w, inv2, lo2, hi2),
+                      q8_quad(hi.x, hi.y, inv2, lo2, hi2), q8_quad(hi.z, hi.w, inv2, lo2, hi2));
+}
+
+template <int CF, int PF, int KS, int ST>
+__global__ __launch_bounds__(256, (CF * PF <= 4 ? 2 : 1)) void conv_i8_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = KS * KS;
+    constexpr int WIMG = CF * 2 * 1024;  // bytes of one tap's weight image [cf][ks][lane][16 B]
+    constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
+    constexpr int NP = (MAXHP * 4 + 255) / 256;  // 16-byte LDS pieces (16 channels) per thread
+    constexpr int NWJ = (CF * 2 + 3) / 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile, cb;
+    {
+        const int id = blockIdx.x;
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    }
+    if (tile >= a.ntiles) return;
+    const int tx_i = tile % a.tiles_x;
+    const int t2 = tile / a.tiles_x;
+    const int ty_i = t2 % a.tiles_y;
+    const int b = t2 / a.tiles_y;
+    const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
+    const int iy0 = oy0 * ST - KS / 2, ix0 = ox0 * ST - KS / 2;
+
+    char* ldsA = smem;
+    char* ldsW = smem + a.ldsA_bytes;
+
+    const bool from_q = a.qin != nullptr;
+    const int ics = from_q ? a.qin_cs : a.in_cs, ico = from_q ? a.qin_co : a.in_co;
+    const int npieces = a.HH * a.HWd * 4;
+    int goff[NP];   // element offset of the piece's first channel in chunk 0 (<0: zero fill)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        int g = -2;
+        if (idx < npieces) {
+            const int hp = idx >> 2, q = idx & 3;
+            const int hy = hp / a.HWd, hx = hp - hy * a.HWd;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool v = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
+            g = v ? (((b * a.H + iy) * a.W + ix) * ics + ico + q * 16) : -1;
+        }
+        goff[i] = g;
+    }
+
+    int pixoff[PF];
+    int opix[PF];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+        const int npx = a.TH * a.TW;
+        bool v = m < npx;
+        const int mm = v ? m : npx - 1;
+        const int ty = mm / a.TW, tx = mm - ty * a.TW;
+        const int oy = oy0 + ty, ox = ox0 + tx;
+        v = v && (oy < a.Ho) && (ox < a.Wo);
+        pixoff[pf] = ((ty * ST) * a.HWd + tx * ST) * PIXB + (lane >> 5) * 16;
+        opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
+    }
+
+    i32x16_t acc[CF][PF];
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0;
+
+    const char* wbase = reinterpret_cast<const char*>(a.wpk);
+    auto issue_w = [&](int step, int buf) {
+        const int chunk = step / NT, tap = step - chunk * NT;
+#pragma unroll
+        for (int j = 0; j < NWJ; ++j) {
+            const int p = wave + 4 * j;
+            if (p < CF * 2) {
+                const int cf = p >> 1, ks = p & 1;
+                const size_t cfg = (size_t)cb * CF + cf;
+                const char* src = wbase + (((cfg * a.nchunk + chunk) * NT + tap) * 2 + ks) * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ldsW + buf * WIMG + p * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    // fp16 source: two 16-byte loads (16 channels) per LDS piece, quantised when they are written to LDS
+    // int8 source: one 16-byte load per piece
+    auto load_A = [&](int chunk, uint4 (&lo)[NP], uint4 (&hi)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
+            const int c0 = chunk * 64 + ((tid + i * 256) & 3) * 16;
+            if (goff[i] >= 0 && c0 < a.Cin) {
+                if (from_q) {
+                    v0 = *reinterpret_cast<const uint4*>(a.qin + goff[i] + chunk * 64);   // Cin % 16 == 0 on this path
+                } else {
+                    v0 = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 64);
+                    if (c0 + 8 < a.Cin) v1 = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 64 + 8);
+                }
+            }
+            lo[i] = v0;
+            hi[i] = v1;
+        }
+    };
+    auto store_A = [&](const uint4 (&lo)[NP], const uint4 (&hi)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < npieces)
+                *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) =
+                    from_q ? lo[i] : q8_piece(lo[i], hi[i], a.q_inv2, a.q_lo2, a.q_hi2);
+        }
+    };
+
+    const int nsteps = a.nchunk * NT;
+    uint4 alo[NP], ahi[NP];
+    load_A(0, alo, ahi);
+    issue_w(0, 0);
+    if (nsteps > 1) issue_w(1, 1);
+    store_A(alo, ahi);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int step = 0;
+    int buf = 0;
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        const bool more = (chunk + 1) < a.nchunk;
+        if (more) load_A(chunk + 1, alo, ahi);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap, ++step) {
+            const int buf2 = (buf >= 1) ? buf - 1 : 2;
+            const bool ahead = (step + 2) < nsteps;
+            if (ahead) issue_w(step + 2, buf2);
+            const int dy = tap / KS, dx = tap - dy * KS;
+            const int tapoff = (dy * a.HWd + dx) * PIXB;
+            const char* wb = ldsW + buf * WIMG + lane * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x4_t af[CF], bf[PF];
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) af[cf] = *reinterpret_cast<const i32x4_t*>(wb + (cf * 2 + ks) * 1024);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf)
+                    bf[pf] = *reinterpret_cast<const i32x4_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf)
+                        acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[cf], bf[pf], acc[cf][pf], 0, 0, 0);
+            }
+            if (ahead) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NWJ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            buf = (buf == 2) ? 0 : buf + 1;
+        }
+        if (more) {
+            store_A(alo, ahi);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+
+    // ---- epilogue, one cout fragment at a time (16 bias + 16 scale registers live next to the accumulators):
+    // exact int32 -> fp32 (one rounding), * s_x*s_w[c] (one rounding), then the arithmetic of the fp16 path's epilogue
+    const int kh = lane >> 5;
+    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+#pragma unroll
+    for (int cf = 0; cf < CF; ++cf) {
+        const int cfrag = (cb * CF + cf) * 32;
+        BiasRegs<1> bz, qs;
+        load_bias<1>(a, cb * CF + cf, 0, lane, bz);
+        {
+            ConvKArgs t = a;
+            t.bias = a.qscale;
+            load_bias<1>(t, cb * CF + cf, 0, lane, qs);
+        }
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            const bool pvalid = opix[pf] >= 0;
+            const size_t prow = pvalid ? (size_t)opix[pf] : 0;
+            if (a.acc_out != nullptr && pvalid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    if (c < a.Cout) a.acc_out[prow * a.Cout + c] = acc[cf][pf][r];
+                }
+            }
+            f32x16_t accf;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (float)acc[cf][pf][r] * qs.v[0][r];
+                asm volatile("" : "+v"(v));     // keep the product a separate rounding (no fma with the bias add)
+                accf[r] = v;
+            }
+            const __half* rrow = (a.res && pvalid) ? a.res + prow * a.res_cs + a.res_co : nullptr;
+            float v[16];
+            finish16_any(a, accf, bz.v[0], cfrag, kh, a.Cout, rrow, ralpha, v);
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    h2_t t;
+                    t[0] = (_Float16)v[g * 4 + h * 2];
+                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                    pk[g][h] = __builtin_bit_cast(unsigned, t);
+                }
+            if (a.qout != nullptr) {
+                // int8 twin for quantised consumers: the SAME fp16 values that go to `out`, quantised with their scale
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned q = q8_quad(pk[g][0], pk[g][1], a.qo_inv2, a.qo_lo2, a.qo_hi2);
+                    const int c0 = cfrag + 8 * g + 4 * kh;
+                    if (pvalid && c0 + 3 < a.Cout) *reinterpret_cast<unsigned*>(a.qout + prow * a.qout_cs + a.qout_co + c0) = q;
+                }
+            }
+            if (a.out == nullptr) continue;
+            __half* orow = a.out + prow * a.out_cs + a.out_co;
+            if (a.vec16_ok && (cfrag + 32) <= a.Cout) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+                    if (pvalid) *reinterpret_cast<uint4*>(orow + cfrag + 16 * gp + 8 * kh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            } else if (pvalid) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = cfrag + 8 * g + 4 * kh;
+                    if (c0 >= a.Cout) continue;
+                    if (a.vec_ok && (c0 + 3) < a.Cout) {
+                        *reinterpret_cast<uint2*>(orow + c0) = make_uint2(pk[g][0], pk[g][1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c0 + j < a.Cout) orow[c0 + j] = __float2half(v[g * 4 + j]);
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1478,6 +1771,116 @@ int launch_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 }
 
 }  // namespace
+
+// ---- int8 launcher -----------------------------------------------------------------------
+namespace {
+unsigned half2_bits(float v) {
+    const _Float16 h = (_Float16)v;
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return (unsigned)b | ((unsigned)b << 16);
+}
+// fp16(amax) and fp16(127 / fp16(amax)): the quantiser constants of include/yolov6_hip.h (y6_conv_i8_desc)
+void quantiser_consts(float amax, unsigned* inv2, unsigned* lo2, unsigned* hi2) {
+    const float ah = (float)(_Float16)amax;
+    *inv2 = half2_bits(127.0f / ah);
+    *lo2 = half2_bits(-ah);
+    *hi2 = half2_bits(ah);
+}
+template <int CF, int PF, int KS, int ST>
+int launch_i8(const Launch& L, hipStream_t s) {
+    static bool big_lds_enabled = false;
+    if (L.lds > 64 * 1024 && !big_lds_enabled) {
+        Y6_HIP(hipFuncSetAttribute((const void*)conv_i8_kernel<CF, PF, KS, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   128 * 1024));
+        big_lds_enabled = true;
+    }
+    Y6_REQUIRE(L.lds <= 128 * 1024, "conv_i8: tile needs %zu bytes of LDS", L.lds);
+    hipLaunchKernelGGL((conv_i8_kernel<CF, PF, KS, ST>), dim3(L.grid), dim3(256), L.lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+template <int CF, int PF>
+int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
+    if (ks == 1 && st == 1) return launch_i8<CF, PF, 1, 1>(L, s);
+    if (ks == 3 && st == 1) return launch_i8<CF, PF, 3, 1>(L, s);
+    if constexpr (PF == 1) {
+        if (ks == 3 && st == 2) return launch_i8<CF, 1, 3, 2>(L, s);
+    }
+    y6_set_error("conv_i8: unsupported ksize/stride %d/%d for this tile shape", ks, st);
+    return Y6_EUNSUPPORTED;
+}
+}  // namespace
+
+int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
+    const y6_conv_desc* d = &q->conv;
+    if (d->variant >= 1 && d->variant <= 6) return d->variant;
+    const int co = d->out.data ? d->out.C : q->q_out.C;
+    if (d->ksize == 3 && d->stride == 1) return co >= 64 ? 5 : 4;            // c2p2 / c1p2
+    return co >= 256 ? 3 : (co >= 64 ? 2 : 1);                                // c4p1 / c2p1 / c1p1
+}
+
+int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
+    y6_conv_desc d = q->conv;
+    const bool has_out = d.out.data != nullptr, has_qout = q->q_out.data != nullptr, has_qin = q->q_in.data != nullptr;
+    Y6_REQUIRE(has_out || has_qout, "conv_i8: neither an fp16 nor an int8 output");
+    Y6_REQUIRE(d.w_packed && q->dequant, "conv_i8: packed int8 weights and the dequantisation vector are required");
+    Y6_REQUIRE((d.ksize == 1 && d.stride == 1) || (d.ksize == 3 && (d.stride == 1 || d.stride == 2)), "conv_i8: k%d s%d", d.ksize,
+               d.stride);
+    if (!has_out) {   // geometry comes from the int8 output view
+        d.out = q->q_out;
+        d.out.data = nullptr;
+    }
+    if (has_qin) {
+        const y6_tensor& t = q->q_in;
+        Y6_REQUIRE(t.C % 16 == 0 && t.cstride % 16 == 0 && t.coff % 16 == 0 && ((uintptr_t)t.data & 15) == 0,
+                   "conv_i8: the int8 input view needs 16-channel alignment");
+        if (!d.in.data) d.in = t;
+        Y6_REQUIRE(t.B == d.in.B && t.H == d.in.H && t.W == d.in.W && t.C == d.in.C, "conv_i8: int8 input view shape");
+    } else {
+        Y6_REQUIRE(d.in.data && d.in.C % 8 == 0 && d.in.cstride % 8 == 0 && d.in.coff % 8 == 0 && ((uintptr_t)d.in.data & 15) == 0,
+                   "conv_i8: the fp16 input view needs 8-channel alignment");
+        Y6_REQUIRE(q->in_amax > 0.f, "conv_i8: in_amax must be positive");
+    }
+    Y6_REQUIRE(((uintptr_t)d.w_packed & 15) == 0, "conv_i8: unaligned weights");
+    Y6_REQUIRE(y6_tensor_elems(d.in) < ((size_t)1 << 31) && y6_tensor_elems(d.out) < ((size_t)1 << 31), "conv_i8: tensor too large");
+    if (has_qout) {
+        const y6_tensor& t = q->q_out;
+        Y6_REQUIRE(t.B == d.out.B && t.H == d.out.H && t.W == d.out.W && t.C == d.out.C && t.C % 4 == 0 && t.cstride % 4 == 0 &&
+                       t.coff % 4 == 0 && q->q_out_amax > 0.f,
+                   "conv_i8: int8 output view");
+    }
+    const int variant = y6_conv_i8_variant(q);
+    Y6_REQUIRE(!(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
+    Launch L;
+    int rc = build_launch(&d, variant, 0, 0, 0, &L);
+    if (rc) return rc;
+    ConvKArgs& k = L.k;
+    k.nchunk = y6_cdiv(k.Cin, 64);
+    k.qscale = q->dequant;
+    quantiser_consts(has_qin ? 1.f : q->in_amax, &k.q_inv2, &k.q_lo2, &k.q_hi2);
+    k.qin = (const signed char*)q->q_in.data;
+    k.qin_cs = q->q_in.cstride;
+    k.qin_co = q->q_in.coff;
+    k.qout = (signed char*)q->q_out.data;
+    k.qout_cs = q->q_out.cstride;
+    k.qout_co = q->q_out.coff;
+    if (has_qout) quantiser_consts(q->q_out_amax, &k.qo_inv2, &k.qo_lo2, &k.qo_hi2);
+    k.acc_out = (int*)q->acc_out;
+    if (!has_out) {
+        k.out = nullptr;
+        k.epi_lds = 0;
+    }
+    switch (variant) {
+        case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
+        case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
+        case 3: return launch_i8_cfg<4, 1>(L, d.ksize, d.stride, s);
+        case 4: return launch_i8_cfg<1, 2>(L, d.ksize, d.stride, s);
+        case 5: return launch_i8_cfg<2, 2>(L, d.ksize, d.stride, s);
+        case 6: return launch_i8_cfg<4, 2>(L, d.ksize, d.stride, s);
+    }
+    return Y6_EINVAL;
+}
 
 extern "C" int y6_conv_variants(void) { return kNumVariants; }
 extern "C" const char* y6_conv_variant_name(int i) {

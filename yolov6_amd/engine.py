@@ -165,9 +165,11 @@ class Plan:
 
 
 class PlanBuilder:
-    def __init__(self, device):
+    def __init__(self, device, quant=None):
         self.lib = _lib.load()
         self.device = torch.device(device)
+        self.quant = quant       # yolov6_amd.quant.QuantState or None: calibration pass / int8 lowering
+        self._no_quant = 0       # depth of `with pb.no_quant():` (detection head: kept in fp16)
         if self.device.type != "cuda":
             raise RuntimeError("yolov6_amd: the HIP hot path needs a ROCm device; there is no CPU fallback")
         self.h = C.c_void_p(self.lib.y6_plan_create())
@@ -177,12 +179,39 @@ class PlanBuilder:
         self.conv_log = []       # (Cin, Cout, k, s, H, W) per conv, for reporting
         self.op_log = []         # one dict per plan op, in plan order: what it reads / writes and its parameters
                                  # (tests replay single ops against the oracle with these)
+        self.buf_ids = {}        # data_ptr of an activation buffer -> allocation index (stable between two lowerings)
+        self.fp16_reads = []     # views read outside the plan (lazy feature maps): their fp16 form must exist
+        self.twins = {}          # buffer index -> (int8 tensor [B,H,W,cstride], amax): int8 twins written by producers
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:                    # a builder that was never finalized (scan pass of the int8 lowering) owns its plan
+            self.lib.y6_plan_destroy(h)
 
     # ---------------------------------------------------------------- memory
     def new_buffer(self, B, H, W, C_) -> TRef:
         t = torch.empty((B, H, W, C_), dtype=torch.float16, device=self.device)
         self.keep.append(t)
+        self.buf_ids[t.data_ptr()] = len(self.buf_ids)
         return TRef(t, B, H, W, C_, C_, 0)
+
+    def buf_id(self, ref: "TRef"):
+        return self.buf_ids.get(ref.buf.data_ptr())
+
+    def keep_fp16(self, refs):
+        """Declare views that are read outside the plan (Model's lazily converted feature maps)."""
+        self.fp16_reads += list(refs)
+
+    def _twin(self, ref: "TRef", amax: float) -> "TRef":
+        """The int8 twin view of `ref` (allocated with the fp16 buffer's geometry on first use)."""
+        bid = self.buf_id(ref)
+        if bid not in self.twins:
+            t = torch.zeros((ref.B, ref.H, ref.W, ref.cstride), dtype=torch.int8, device=self.device)
+            self.keep.append(t)
+            self.twins[bid] = (t, float(amax))
+        t, a = self.twins[bid]
+        assert a == float(amax), "one activation scale per int8 twin buffer"
+        return TRef(t, ref.B, ref.H, ref.W, ref.C, ref.cstride, ref.coff)
 
     def _f32(self, t: Optional[torch.Tensor], fp16_round=True):
         if t is None:
@@ -226,12 +255,26 @@ class PlanBuilder:
         return out
 
     # ---------------------------------------------------------------- ops
+    def no_quant(self):
+        """Context: convs lowered inside stay fp16 under an int8 lowering (the detection head, like the `skip` list of
+        the reference's QAT config configs/repopt/yolov6s_opt_qat.py:70-76)."""
+        pb = self
+
+        class _Ctx:
+            def __enter__(self):
+                pb._no_quant += 1
+
+            def __exit__(self, *exc):
+                pb._no_quant -= 1
+        return _Ctx()
+
     def conv(self, x, weight, bias, stride=1, act=None, out: Optional[TRef] = None, post=None,
              res: Optional[TRef] = None, res_alpha: Optional[torch.Tensor] = None) -> TRef:
         """conv(k in {1,3}, pad=k//2) + bias (+post affine) + act (+alpha*res). weight: OIHW."""
         Cout, Cin, K, K2 = weight.shape
         assert K == K2
-        if isinstance(x, NCHWInput):
+        reads_image = isinstance(x, NCHWInput)      # the network's first conv stays fp16 (its input is 8-bit pixels already)
+        if reads_image:
             if K == 3 and stride == 2 and x.shape[1] <= 4 and Cout in (8, 16, 32, 48, 64) and res is None:
                 return self._stem(x, weight, bias, act, out, post)
             x = self.as_nhwc(x)
@@ -243,6 +286,15 @@ class PlanBuilder:
         if out is None:
             out = self.new_buffer(x.B, Ho, Wo, Cout)
         assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), "conv output slice has the wrong shape"
+        if self.quant is not None and not self._no_quant and not reads_image:
+            idx = self.quant.next_index(dict(cin=Cin, cout=Cout, k=K, stride=stride))
+            if self.quant.mode == "calibrate":
+                xt = x.ct()
+                _lib.check(self.lib.y6_plan_add_absmax(self.h, C.byref(xt), C.c_void_p(self.quant.slot_ptr(idx, self.device))),
+                           "plan_add_absmax")
+                self.op_log.append(dict(kind="absmax", x=x, index=idx))
+            else:
+                return self._conv_i8(x, weight, bias, stride, act, out, post, res, res_alpha, self.quant.amax_of(idx))
         w32 = weight.detach().to(self.device, torch.float32).contiguous()
         w16 = w32.half().contiguous()
         n = self.lib.y6_packed_weight_elems(Cout, Cin, K)
@@ -265,6 +317,57 @@ class PlanBuilder:
         self.conv_log.append((Cin, Cout, K, stride, x.H, x.W))
         self.op_log.append(dict(kind="conv", x=x, out=out, w=w32, b=bias, stride=stride, act=act, post=post, res=res,
                                 alpha=res_alpha))
+        return out
+
+    def _conv_i8(self, x: TRef, weight, bias, stride, act, out: TRef, post, res, res_alpha, amax: float) -> TRef:
+        """int8 conv (include/yolov6_hip.h y6_conv_i8_desc): weights quantised here per output channel, the fp16
+        input quantised by the kernel with the calibrated `amax`."""
+        from .quant import quantize_weight, dequant_vector
+        Cout, Cin, K, _ = weight.shape
+        wq, s_w = quantize_weight(weight)                       # CPU: int8 OIHW, fp32 [Cout]
+        wq_d = wq.to(self.device).contiguous()
+        packed = torch.empty(self.lib.y6_packed_weight_i8_bytes(Cout, Cin, K), dtype=torch.int8, device=self.device)
+        _lib.check(self.lib.y6_pack_conv_weight_i8(self._ptr(wq_d), Cout, Cin, K, self._ptr(packed), _lib.current_stream_ptr()),
+                   "pack_conv_weight_i8")
+        dq = dequant_vector(amax, s_w).to(self.device).contiguous()
+        self.keep += [wq_d, packed, dq]
+        d = _lib.ConvI8Desc()
+        c = d.conv
+        c.inp, c.out = x.ct(), out.ct()
+        c.w_packed, c.w_oihw = self._ptr(packed), None
+        c.bias = self._ptr(self._f32(bias, fp16_round=False))
+        c.post_scale = self._ptr(self._f32(post[0])) if post is not None else None
+        c.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
+        c.res = res.ct() if res is not None else _null_tensor()
+        c.res_alpha = self._ptr(self._f32(res_alpha.reshape(1), fp16_round=True)) if res_alpha is not None else None
+        c.ksize, c.stride, c.act, c.variant = K, stride, ACT_BY_NAME[act], 0
+        d.dequant = self._ptr(dq)
+        d.in_amax = float(amax)
+        d.q_in, d.q_out, d.q_out_amax, d.acc_out = _null_tensor(), _null_tensor(), 0.0, None
+        # int8 twins (yolov6_amd.quant.plan_twins decided them in a scan lowering): read the producer's int8 copy of the
+        # input instead of quantising fp16 on load; write an int8 copy of the output for its quantised consumers and
+        # drop the fp16 store when nothing reads it
+        q_in = q_out = None
+        q_out_amax, has_out = 0.0, True
+        dec = getattr(self.quant, "decisions", None)
+        if dec:
+            di = dec.get(self.buf_id(x))
+            if di is not None and di["twin"]:
+                q_in = self._twin(x, di["amax"])
+                assert di["amax"] == float(amax)
+                d.q_in = q_in.ct()
+            do = dec.get(self.buf_id(out))
+            if do is not None and do["twin"]:
+                q_out, q_out_amax = self._twin(out, do["amax"]), do["amax"]
+                d.q_out, d.q_out_amax = q_out.ct(), q_out_amax
+                if not do["fp16"]:
+                    has_out = False
+                    c.out = _lib.Tensor(None, out.B, out.H, out.W, out.C, out.cstride, out.coff)
+        _lib.check(self.lib.y6_plan_add_conv_i8(self.h, C.byref(d)), "plan_add_conv_i8")
+        self.conv_log.append((Cin, Cout, K, stride, x.H, x.W))
+        self.op_log.append(dict(kind="conv_i8", x=x, out=out, w=weight.detach().float().cpu(), b=bias, stride=stride, act=act,
+                                post=post, res=res, alpha=res_alpha, amax=float(amax), wq=wq, s_w=s_w, dequant=dq,
+                                q_in=q_in, q_out=q_out, q_out_amax=q_out_amax, has_out=has_out))
         return out
 
     def _stem(self, x: NCHWInput, weight, bias, act, out, post) -> TRef:

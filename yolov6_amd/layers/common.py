@@ -104,6 +104,7 @@ class HipModule(nn.Module):
         st.pop("_y6_plans", None)
         st.pop("_featrefs", None)
         st.pop("_last_featmaps", None)
+        st.pop("_y6_quant", None)
         return st
 
     def invalidate_plans(self):
@@ -142,13 +143,26 @@ class HipModule(nn.Module):
                 raise RuntimeError("yolov6_amd: the HIP hot path needs ROCm tensors; there is no CPU fallback "
                                    f"(got a tensor on {t.device})")
         contig = [t.contiguous() for t in flat]
-        key = (tuple((tuple(t.shape), t.dtype) for t in flat), _params_version(self), self.training, autotune)
+        quant = self.__dict__.get("_y6_quant")       # yolov6_amd.quant: calibration pass / int8 lowering
+        key = (tuple((tuple(t.shape), t.dtype) for t in flat), _params_version(self), self.training, autotune,
+               None if quant is None else quant.key())
         cache = self.__dict__.setdefault("_y6_plans", {})
         plan = cache.get(key)
         if plan is None:
             self._check_runnable()
             cache.clear()  # one live plan per module: buffers are large
-            pb = PlanBuilder(flat[0].device)
+            if quant is not None:
+                quant.decisions = None
+                if quant.mode == "int8" and quant.twins:
+                    # scan lowering: who reads / writes which buffer with which scale -> int8 twins (quant.plan_twins)
+                    from ..quant import plan_twins
+                    quant.begin_lowering()
+                    scan = PlanBuilder(flat[0].device, quant=quant)
+                    self.lower(scan, _wrap(x, iter(contig)))
+                    quant.decisions = plan_twins(scan)
+                    del scan
+                quant.begin_lowering()
+            pb = PlanBuilder(flat[0].device, quant=quant)
             outs = self.lower(pb, _wrap(x, iter(contig)))
             odt = flat[0].dtype if flat[0].dtype in (torch.float16, torch.float32) else torch.float16
             outs = self._finish_outputs(pb, outs, odt)

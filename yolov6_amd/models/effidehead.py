@@ -69,14 +69,15 @@ class Detect(HipModule):
         if self.export:
             raise NotImplementedError("yolov6_amd: export mode (ONNX tracing) is out of scope of the HIP path")
         cls_out, reg_out = [], []
-        for i in range(self.nl):
-            f = self.stems[i].lower(pb, x[i])
-            c = self.cls_convs[i].lower(pb, f)
-            cp = self.cls_preds[i]
-            cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
-            r = self.reg_convs[i].lower(pb, f)
-            rp = self.reg_preds[i]
-            reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
+        with pb.no_quant():        # the head stays fp16 under an int8 lowering (yolov6_amd/quant.py)
+            for i in range(self.nl):
+                f = self.stems[i].lower(pb, x[i])
+                c = self.cls_convs[i].lower(pb, f)
+                cp = self.cls_preds[i]
+                cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
+                r = self.reg_convs[i].lower(pb, f)
+                rp = self.reg_preds[i]
+                reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
         use_dfl = bool(self.use_dfl)
         # the reference's eval branch projects with proj_conv.weight (effidehead.py:107-109), not with self.proj;
         # the bin count comes from the loaded weight, not from the constructor default

@@ -58,6 +58,7 @@ class Model(HipModule):
     def lower(self, pb, x, out=None):
         feats = self.neck.lower(pb, self.backbone.lower(pb, x))
         self._featrefs = list(feats)
+        pb.keep_fp16(self._featrefs)          # read lazily by the caller (int8 lowering: keep their fp16 form)
         return self.detect.lower(pb, list(feats))
 
     def lower_train(self, tb, x):
