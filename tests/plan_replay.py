@@ -50,7 +50,10 @@ class OracleChain:
             x = o.q(e["x"].float().cpu()) if k == "stem" else self._get(e["x"])
             b = None if e["b"] is None else e["b"].detach().float().cpu()
             post = None if e["post"] is None else tuple(t.detach().float().cpu() for t in e["post"])
-            y = o.conv_fused(x, e["w"].detach().float().cpu(), b, e["stride"], e["act"], post)
+            # the op log says this op is an fp16 conv: use the base oracle's arithmetic even when `o` is an Int8Oracle
+            # (whose own conv_fused decides by call order, which an op-by-op walk does not reproduce)
+            from oracle.model_oracle import Oracle
+            y = Oracle.conv_fused(o, x, e["w"].detach().float().cpu(), b, e["stride"], e["act"], post)
             if e["res"] is not None:       # BottleRep shortcut: q(y + q(alpha * x)), oracle.bottlerep / common.py:608
                 a = 1.0 if e["alpha"] is None else o.q(e["alpha"].detach().float().cpu())
                 y = o.q(y + o.q(a * self._get(e["res"])))
