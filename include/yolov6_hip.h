@@ -99,6 +99,10 @@ int y6_conv_variants(void);
 const char* y6_conv_variant_name(int i);
 /* 1 if variant i can run desc d */
 int y6_conv_variant_supports(const y6_conv_desc* d, int i);
+/* Self-test of the LDS-DMA addressing the "dma*" conv variants rely on (csrc/conv_dma.hip): one wave copies 1 KiB from
+ * src into LDS at byte offset lds_off (< 160 KiB) by `buffer_load_dwordx4 ... lds` and writes it to dst; lanes whose bit
+ * is set in oob_mask request a piece beyond `bytes` and must read zeros.  No reference counterpart (diagnostic).       */
+int y6_dma_probe(const void* src, unsigned bytes, unsigned lds_off, unsigned long long oob_mask, void* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* int8 convolution (BASELINE configs[4]: YOLOv6-S QARepVGG int8 inference).
@@ -116,7 +120,7 @@ int y6_conv_variant_supports(const y6_conv_desc* d, int i);
  *   epilogue     fp32: y = fp32(acc) * dequant[c] + bias[c], dequant[c] = (fp32(a) / 127) * s_w[c]; then exactly the
  *                fp16 conv's epilogue (kept post-BN affine of QARepVGG common.py:338-339, activation, residual)
  * conv.in / conv.out are fp16 NHWC views as for y6_conv2d (conv.out.data may be NULL when only q_out is wanted);
- * conv.w_packed is the y6_pack_conv_weight_i8 image; conv.variant: 0 = heuristic tile shape, 1..6 force.          */
+ * conv.w_packed is the y6_pack_conv_weight_i8 image; conv.variant: 0 = heuristic, 1..6 force a per-tap tile, 7 / 8 the LDS-DMA kernels (512 / 256 pixel blocks; need q_in, k3 s1, Cin % 32 == 0).          */
 typedef struct y6_conv_i8_desc {
     y6_conv_desc conv;
     const float* dequant;      /* [Cout]                                                          */

@@ -163,6 +163,27 @@ def test_int8_twin_output_equals_quantise_on_load():
     assert torch.equal(only.buf.cpu().permute(0, 3, 1, 2), quantize_act(_nchw(o_a), 5.0).to(torch.int8))
 
 
+@pytest.mark.parametrize("variant", [7, 8])
+def test_conv_i8_dma_variants_bit_exact(variant):
+    """The LDS-DMA int8 kernels (conv_dma.hip) read the producer's int8 twin: same accumulators / outputs as the oracle."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(31)
+    for (B, H, W, Cin, Cout, act) in [(3, 40, 40, 64, 128, "relu"), (2, 21, 37, 32, 64, None), (5, 80, 80, 96, 72, "relu")]:
+        x = rand_nhwc(B, H, W, Cin, seed=13, scale=4.0)
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.2
+        b = torch.randn((Cout,), generator=g)
+        amax = 3.1
+        twin = _i8_buffer(B, H, W, Cin)
+        xt, qt = x.ct(), twin.ct()
+        _lib.check(lib.y6_quantize_i8(C.byref(xt), C.c_float(amax), C.byref(qt), None), "quantize_i8")
+        out, acc = _run_i8(x, w, b, 1, act, amax, variant=variant, q_in=twin)
+        xin = _nchw(x)
+        ref_acc, _ = int8_accumulate(xin, w, 1, amax)
+        assert torch.equal(acc.double(), ref_acc), f"int32 accumulators differ {(B, H, W, Cin, Cout)}"
+        ref, _ = int8_conv(_Q16(), xin, w, b, 1, act, None, amax)
+        assert torch.equal(_nchw(out), ref)
+
+
 def test_absmax_exact_on_views():
     lib = _lib.load()
     x = rand_nhwc(3, 15, 17, 40, cstride=64, coff=16, seed=8, scale=9.0)

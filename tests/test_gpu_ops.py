@@ -55,6 +55,44 @@ def test_conv_all_variants(shape):
     assert "naive" in ran and len(ran) >= 2, ran
 
 
+def test_lds_dma_addressing():
+    """What the dma* conv variants rely on: `buffer_load_dwordx4 ... lds` lands at LDS offsets above 64 KiB (a block may
+    own 160 KiB) and a piece past the descriptor's num_records reads zeros."""
+    import ctypes as C
+    from yolov6_amd import _lib
+    lib = _lib.load()
+    src = torch.arange(1024, dtype=torch.int32, device=G.DEV).to(torch.uint8)      # 0..255 pattern, 1 KiB
+    src = (torch.arange(1024, device=G.DEV) * 7 + 3).to(torch.uint8)
+    for lds_off in (0, 16, 1024, 65536 - 1024, 65536, 100 * 1024, 159 * 1024):
+        for mask in (0, 0x8000000000000001, 0x00FF00FF00FF00FF):
+            dst = torch.full((1024,), 0xAB, dtype=torch.uint8, device=G.DEV)
+            _lib.check(lib.y6_dma_probe(C.c_void_p(src.data_ptr()), 1024, lds_off, mask, C.c_void_p(dst.data_ptr()), None), "dma_probe")
+            torch.cuda.synchronize()
+            want = src.clone().view(64, 16)
+            for lane in range(64):
+                if (mask >> lane) & 1:
+                    want[lane] = 0
+            assert torch.equal(dst.view(64, 16), want), f"lds_off {lds_off} mask {mask:#x}"
+
+
+def test_conv_dma_variants_full_tiles():
+    """The LDS-DMA kernels on shapes with several work items per block and several cout blocks (persistent walk, stage
+    ping-pong across items, XCD-aware id decoding), incl. a 1-chunk layer and tile overhang on both axes."""
+    names = G.variant_names()
+    dma = [v for v, n in enumerate(names) if n.startswith("dma")]
+    assert len(dma) >= 3
+    for (Cin, Cout, H, W, B) in [(64, 128, 80, 80, 6), (16, 64, 50, 70, 5), (128, 64, 36, 52, 4), (32, 160, 21, 19, 9)]:
+        x = G.rand_nhwc(B, H, W, Cin, seed=21)
+        w, b = _mk_weights(Cout, Cin, 3, 22)
+        ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, 1, "relu")
+        for v in dma:
+            if not G.supports(x, w, 1, v):
+                continue
+            o, _ = G.run_conv(x, w, b, 1, "relu", v)
+            err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+            assert err < TOL, f"{names[v]}: max rel err {err:.3e} on {(Cin, Cout, H, W, B)}"
+
+
 def test_conv_mfma_layout_is_not_transposed():
     """Asymmetric weights: output channel c copies input channel (c+1)%C of the centre tap only."""
     C_, H, W = 64, 16, 16

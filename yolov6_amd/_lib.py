@@ -175,6 +175,7 @@ SIGNATURES = {
     "y6_conv_variants": (C.c_int, []),
     "y6_conv_variant_name": (C.c_char_p, [C.c_int]),
     "y6_conv_variant_supports": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "y6_dma_probe": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "y6_convt2x2": (C.c_int, [C.POINTER(ConvTDesc), C.c_void_p]),
     "y6_stem_conv": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     "y6_sppf_pool": (C.c_int, [C.POINTER(Tensor)] * 4 + [C.c_void_p]),

@@ -25,6 +25,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 # per-file extra flags: index parity needs the reference's unfused fp32 arithmetic
 SOURCES = {
     "conv_mfma.hip": [],
+    "conv_dma.hip": [],
     "conv_misc.hip": [],
     "head_decode.hip": [],
     "nms.hip": ["-ffp-contract=off"],
@@ -36,7 +37,7 @@ SOURCES = {
     "quant.hip": [],
     "plan.hip": [],
 }
-HEADERS = ["common.hpp", "plan_internal.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
+HEADERS = ["common.hpp", "conv_common.hpp", "plan_internal.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
 
 
 def hipcc():

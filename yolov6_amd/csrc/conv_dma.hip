@@ -1,0 +1,426 @@
+// conv_dma.hip — 3x3 stride-1 convolution (fp16 and int8) fed entirely by LDS-DMA.
+//
+// Replaces the same aten compositions as conv_mfma.hip (reference yolov6/layers/common.py:51-54, :247-248, :338-339,
+// :605-608): RepVGG / ConvBNReLU / BottleRep 3x3 convs in deploy form, 84 % of the FLOPs of YOLOv6-S.
+//
+// Why another kernel.  The pipelined kernel (conv_mfma_pipe_kernel) stages every byte through registers: global load ->
+// VGPR -> ds_write_b128.  The probes in DESIGN.md §6 put the fill at 43 % of its time, overlapping the MFMAs by a fifth:
+// ds_write_b128 moves 79 B/clk/CU (MI355X_MICROARCH.md, LDS table) against 256 B/clk for the fragment reads, the staging
+// registers cap the kernel at 2 waves per SIMD, and every staged load drags VALU address selects with it.  Here
+//   * BOTH operands arrive by `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, no VGPR, no ds_write); image
+//     borders and tile overhang are zero-filled by the buffer descriptor's range check (voffset past num_records);
+//   * the LDS image of the halo is two planes (channels 0-7 / 8-15 of the 16-channel chunk; int8: 0-15 / 16-31), 16 B per
+//     pixel per plane, row-major with the halo width as pitch - lane-linear, so a DMA piece is 64 consecutive slots and
+//     the source address does the gather.  Fragment pixel q of a 32-pixel MFMA fragment sits in lane frag_lane(q) such that
+//     the two 16-lane groups ds_read_b128 serves per cycle ({0-3,12-15,20-27} / {4-11,16-19,28-31}) each read 16
+//     CONSECUTIVE pixels: conflict-free for every tile width that is a multiple of 16, whatever the row pitch;
+//   * no staging registers -> 8 waves x c2p2 fit at 4 waves per SIMD: a block is 512 pixels x 64 couts (two blocks per
+//     CU), the weight image of a chunk is shared by twice the pixels of the pipe kernel (fill bytes per MFMA x 0.65);
+//   * one barrier per 16-channel chunk: `s_waitcnt vmcnt(0)` (the wave's own pieces of THIS chunk, issued a whole chunk
+//     of MFMAs ago) + s_barrier, then the pieces of the next chunk are issued into the other stage and the nine taps
+//     run.  The stream crosses work items, so the first chunk of the next (tile, cout block) lands during the epilogue.
+// The int8 form (v_mfma_i32_32x32x32_i8, BASELINE configs[4]) is the same data movement byte for byte: a chunk is 32
+// int8 channels = 32 B per pixel; it reads the int8 twin its producer wrote (include/yolov6_hip.h y6_conv_i8_desc.q_in).
+#include "common.hpp"
+#include "conv_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)(uintptr_t)base;
+    i32x4_t r;
+    r[0] = (int)(unsigned)(p & 0xffffffffu);
+    r[1] = (int)(unsigned)((p >> 32) & 0xffffu);   // stride 0: raw buffer, byte offsets, range check against num_records
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+
+// one LDS-DMA piece: lane i writes 16 B to lds_dst + 16*i from rsrc.base + voff(lane) + soff; out of range -> zeros.
+// Issued from inline asm (hipcc neither counts it nor fences later ds_reads against it; completion = the kernel's own
+// vmcnt(0) + barrier).  M0 is saved/restored inside the statement (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void dma16(const i32x4_t& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
+        : "memory");
+}
+
+// The argument block again, loaded where it is used.  The epilogue reads two dozen fields of ConvKArgs; taken from the
+// by-value kernel parameter they are loaded at kernel entry and stay live across the chunk loop (200+ spilled SGPRs,
+// v_readlane traffic inside the loop).  Re-reading the kernarg segment through a laundered pointer gives the epilogue
+// its own short-lived copies (scalar loads, once per work item).
+__device__ __forceinline__ ConvKArgs reload_args() {
+    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(v));
+    const __attribute__((address_space(4))) unsigned* src = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(v);
+    static_assert(sizeof(ConvKArgs) % 4 == 0, "ConvKArgs is copied dword by dword");
+    ConvKArgs r;
+    unsigned* dst = reinterpret_cast<unsigned*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(ConvKArgs) / 4; ++i) dst[i] = src[i];   // scalar loads of the fields the caller uses
+    return r;
+}
+
+constexpr unsigned kOob = 0xffffff00u;   // voffset of a piece that must read zeros
+
+// lane (0..31) -> pixel of the fragment it holds (see the header comment)
+__device__ __forceinline__ int frag_pixel(int l) {
+    return l < 4 ? l : (l < 12 ? l + 12 : (l < 16 ? l - 8 : (l < 20 ? l + 8 : (l < 28 ? l - 12 : l))));
+}
+
+template <int BP>
+struct DmaHaloCap {   // halo pixels per plane for BP output pixels
+    static constexpr int value = BP <= 128 ? 208 : (BP <= 256 ? 352 : (BP <= 512 ? 672 : 1216));
+};
+
+template <bool I8>
+struct AccT {
+    typedef f32x16_t type;
+};
+template <>
+struct AccT<true> {
+    typedef i32x16_t type;
+};
+
+template <int CF, int PF, int NW, int WPS, bool I8>
+__global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename AccT<I8>::type acc_t;
+    constexpr int NT = 9;
+    constexpr int WP = CF * NT;                                   // weight pieces (1 KiB) per chunk
+    constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32>::value * 2 + 63) / 64;
+    constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RP = a.dma_rp, PLs = a.dma_pls, NHP = a.dma_nhp;
+    const int stage_bytes = (NHP + WP) * 1024;
+    const unsigned smem_base = lds_addr(smem);
+    float* ldsBias = reinterpret_cast<float*>(smem + 2 * stage_bytes);   // [2][CF*32] bias, then [2][CF*32] dequant scales (int8)
+    const int nch = a.Cin / (I8 ? 32 : 16);
+    const int nids = a.nids;
+    const int gstride = gridDim.x;
+
+    const char* inb = I8 ? reinterpret_cast<const char*>(a.qin) : reinterpret_cast<const char*>(a.in);
+    const int ics = I8 ? a.qin_cs : a.in_cs, ico = I8 ? a.qin_co : a.in_co;
+    const i32x4_t rsA = make_rsrc(inb, (unsigned)((size_t)a.B * a.H * a.W * ics * ES));
+    const i32x4_t rsW = make_rsrc(a.wpk, 0xfffffe00u);
+
+    auto decode = [&](int id, int& tile, int& cb) {
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    };
+    auto next_valid = [&](int id) {
+        for (id += gstride; id < nids; id += gstride) {
+            int t, c;
+            decode(id, t, c);
+            if (t < a.ntiles) break;
+        }
+        return id;
+    };
+    int id = blockIdx.x;
+    {
+        int t, c;
+        decode(id, t, c);
+        if (t >= a.ntiles) id = next_valid(id);
+    }
+    if (id >= nids) return;
+
+    // ---- this wave's pieces of a chunk image  [halo plane 0 | halo plane 1 | pad to 1 KiB][CF x 9 weight fragments]:
+    //      halo pieces P = wave + NW*i < NHP, weight fragments q = wave + NW*j < CF*9.
+    // Halo: slot s = 64*P + lane -> (plane h, halo row hy, halo column hx) is fixed for the whole kernel (hinfo, computed
+    // once with the divisions); per work item only the tile origin changes: a scalar base offset plus two range checks.
+    constexpr int NPWH = (MAXNHP + NW - 1) / NW;
+    constexpr int NPWW = (WP + NW - 1) / NW;
+    unsigned hinfo[NPWH], hvoff[NPWH];
+#pragma unroll
+    for (int i = 0; i < NPWH; ++i) {
+        const int P = wave + NW * i;
+        const int s = P * 64 + lane;
+        const int h = s >= PLs ? 1 : 0;
+        const int r = s - h * PLs;
+        const int hy = r / RP, hx = r - hy * RP;
+        const bool v = (P < NHP) && (s < 2 * PLs) && (hx < a.HWd);
+        hinfo[i] = v ? (unsigned)((hy << 16) | (hx << 1) | h) : 0xffffffffu;
+        hvoff[i] = kOob;
+    }
+    unsigned wsoff[NPWW];   // scalar part of the weight fragment addresses (cf, tap of this wave's j-th fragment)
+#pragma unroll
+    for (int j = 0; j < NPWW; ++j) {
+        const int q = wave + NW * j;
+        const int cf = q / NT, tap = q - cf * NT;
+        wsoff[j] = (unsigned)(((cf * a.nchunk * NT + tap) * 2) * 1024);
+    }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto setup_halo = [&](int item) {
+        int tile, cbx;
+        decode(item, tile, cbx);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int iy0 = ty_i * a.TH - 1, ix0 = tx_i * a.TW - 1;
+        const int base = (((b * a.H + iy0) * a.W + ix0) * ics + ico) * ES;   // may be negative; valid pieces end up >= 0
+#pragma unroll
+        for (int i = 0; i < NPWH; ++i) {
+            const int hy = (int)(hinfo[i] >> 16), hx = (int)((hinfo[i] >> 1) & 0x7fffu), h = (int)(hinfo[i] & 1u);
+            const bool v = (hinfo[i] != 0xffffffffu) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
+            hvoff[i] = v ? (unsigned)(base + (hy * a.W + hx) * ics * ES + h * 16) : kOob;
+        }
+    };
+    auto issue = [&](int chunk, int wcb, int buf) {
+        const unsigned dst0 = smem_base + buf * stage_bytes;
+        const unsigned soffA = (unsigned)chunk * 32u;
+        const unsigned soffW = (unsigned)(((wcb * CF * a.nchunk + (chunk >> 1)) * NT * 2 + (chunk & 1)) * 1024);
+#pragma unroll
+        for (int i = 0; i < NPWH; ++i) {
+            const int P = wave + NW * i;
+            if (P < NHP) dma16(rsA, hvoff[i], soffA, dst0 + P * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NPWW; ++j) {
+            const int q = wave + NW * j;
+            if (q < WP) dma16(rsW, lane16, soffW + wsoff[j], dst0 + (NHP + q) * 1024);
+        }
+    };
+
+    // ---- LDS offsets of this lane's pixels (whole loop) / output pixel indices (epilogue only)
+    const int fq = frag_pixel(lane & 31);
+    int pixoff[PF], cb = 0;
+    auto setup_pix = [&](int item) {
+        int tile;
+        decode(item, tile, cb);
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            const int m = wave * (PF * 32) + pf * 32 + fq;
+            const int npx = a.TH * a.TW;
+            const int mm = m < npx ? m : npx - 1;
+            const int ty = mm / a.TW, tx = mm - ty * a.TW;
+            pixoff[pf] = ((lane >> 5) * PLs + ty * RP + tx) * 16;
+        }
+    };
+    auto out_pix = [&](const ConvKArgs& a, int item, int (&opix)[PF]) {
+        int tile = item;
+        if (a.ncb != 1) tile = ((item >> 3) / a.ncb) * 8 + (item & 7);
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            const int m = wave * (PF * 32) + pf * 32 + fq;
+            const int npx = a.TH * a.TW;
+            bool v = m < npx;
+            const int mm = v ? m : npx - 1;
+            const int ty = mm / a.TW, tx = mm - ty * a.TW;
+            const int oy = oy0 + ty, ox = ox0 + tx;
+            v = v && (oy < a.Ho) && (ox < a.Wo);
+            opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
+        }
+    };
+
+    setup_halo(id);
+    setup_pix(id);
+    issue(0, cb, 0);
+
+    int pb = 0, item_parity = 0;
+    while (true) {
+        acc_t acc[CF][PF];
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0;
+        float* lbias = ldsBias + (item_parity ? CF * 32 : 0);
+        if (tid < CF * 32) {
+            const int c = cb * CF * 32 + tid;
+            lbias[tid] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
+            if (I8) lbias[2 * CF * 32 + tid] = (c < a.Cout) ? a.qscale[c] : 0.f;
+        }
+        const int nid = next_valid(id);
+        for (int chunk = 0; chunk < nch; ++chunk) {
+            // this wave's pieces of `chunk` have landed; after the barrier everybody's have, and nobody reads the other
+            // stage any more (its last fragment reads fed MFMAs that were issued before the barrier)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (chunk + 1 < nch) {
+                issue(chunk + 1, cb, pb ^ 1);
+            } else if (nid < nids) {
+                int t, ncb_;
+                decode(nid, t, ncb_);
+                setup_halo(nid);   // the current item's offsets are dead: all its chunks have been requested
+                issue(0, ncb_, pb ^ 1);
+            }
+            const char* Ab = smem + pb * stage_bytes;
+            const char* Wb = Ab + NHP * 1024 + lane * 16;
+            // fragment reads run one tap ahead of the MFMAs when only two or three waves share a SIMD; at four waves the
+            // other waves' MFMAs cover the LDS latency and the 16 registers are worth more
+            constexpr int LA = WPS >= 4 ? 1 : 2;
+            i32x4_t fa[LA][CF], fb[LA][PF];
+            auto ldfragW = [&](int t, int buf) {
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const i32x4_t*>(Wb + (cf * NT + t) * 1024);
+            };
+            auto ldfragA = [&](int t, int buf) {
+                const int tapoff = ((t / 3) * RP + (t % 3)) * 16;
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
+            };
+            if (LA == 2) {
+                ldfragA(0, 0);
+                ldfragW(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (LA == 1) {
+                    ldfragA(t, 0);
+                    ldfragW(t, 0);
+                } else if (t + 1 < NT) {
+                    ldfragA(t + 1, (t + 1) & 1);
+                    ldfragW(t + 1, (t + 1) & 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
+#pragma unroll
+                for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) {
+                        if constexpr (I8) {
+                            acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t & (LA - 1)][cf], fb[t & (LA - 1)][pf], acc[cf][pf], 0, 0, 0);
+                        } else {
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fa[t & (LA - 1)][cf]),
+                                                                                 __builtin_bit_cast(h8_t, fb[t & (LA - 1)][pf]), acc[cf][pf], 0, 0, 0);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            pb ^= 1;
+        }
+        const ConvKArgs ea = reload_args();
+        int opix[PF];
+        out_pix(ea, id, opix);
+        // one cout fragment at a time: 16 bias registers live instead of 16*CF next to 16*CF*PF accumulators
+#pragma unroll
+        for (int cf = 0; cf < CF; ++cf) {
+            BiasRegs<1> bz;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
+                bz.v[0][g * 4 + 0] = t.x;
+                bz.v[0][g * 4 + 1] = t.y;
+                bz.v[0][g * 4 + 2] = t.z;
+                bz.v[0][g * 4 + 3] = t.w;
+            }
+            if constexpr (I8) {
+                BiasRegs<1> qs;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 t = *reinterpret_cast<const float4*>(lbias + 2 * CF * 32 + cf * 32 + 8 * g + 4 * (lane >> 5));
+                    qs.v[0][g * 4 + 0] = t.x;
+                    qs.v[0][g * 4 + 1] = t.y;
+                    qs.v[0][g * 4 + 2] = t.z;
+                    qs.v[0][g * 4 + 3] = t.w;
+                }
+                conv_i8_epilogue<PF>(ea, acc[cf], opix, cb * CF + cf, lane, bz.v[0], qs.v[0]);
+            } else {
+                conv_epilogue<1, PF>(ea, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
+            }
+        }
+        if (nid >= nids) break;
+        id = nid;
+        item_parity ^= 1;
+        setup_pix(id);
+    }
+}
+
+// Probe / self-test of the DMA addressing (tests/test_gpu_ops.py): one wave copies 1 KiB from `src` into LDS at byte
+// offset `lds_off` (a block may own up to 160 KiB: the destination base in M0 must take offsets above 64 KiB), lanes with
+// (oob_mask >> lane) & 1 ask for an out-of-range piece and must see zeros.
+__global__ void dma_probe_kernel(const char* src, unsigned bytes, unsigned lds_off, unsigned long long oob_mask, char* dst) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    for (unsigned i = lane; i < 1024 / 4; i += 64) reinterpret_cast<unsigned*>(smem + lds_off)[i] = 0xdeadbeefu;
+    __syncthreads();
+    const i32x4_t rs = make_rsrc(src, bytes);
+    const unsigned v = ((oob_mask >> lane) & 1ull) ? kOob : (unsigned)(lane * 16);
+    dma16(rs, v, 0u, lds_addr(smem) + lds_off);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    *reinterpret_cast<uint4*>(dst + lane * 16) = *reinterpret_cast<const uint4*>(smem + lds_off + lane * 16);
+}
+
+template <int CF, int PF, int NW, int WPS, bool I8>
+int launch_dma(const Launch& L, hipStream_t s) {
+    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, I8>;
+    static bool big_lds_enabled = false;
+    if (L.lds > 64 * 1024 && !big_lds_enabled) {
+        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big_lds_enabled = true;
+    }
+    Y6_REQUIRE(L.lds <= 160 * 1024, "conv_dma: tile needs %zu bytes of LDS", L.lds);
+    static size_t cached_lds = 0;
+    static int cached_bpc = 0, n_cu = 0;
+    if (cached_lds != L.lds) {
+        int bpc = 0;
+        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, L.lds));
+        if (n_cu == 0) {
+            int dev = 0;
+            Y6_HIP(hipGetDevice(&dev));
+            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        cached_bpc = bpc < 1 ? 1 : bpc;
+        cached_lds = L.lds;
+    }
+    int grid = n_cu * cached_bpc;
+    grid -= grid % 8;                 // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple
+    if (grid < 8) grid = 8;
+    if (grid > L.grid) grid = L.grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), L.lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+template <bool I8>
+int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, hipStream_t s) {
+    if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, I8>(L, s);
+    if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, I8>(L, s);
+    if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 3, I8>(L, s);
+    if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, I8>(L, s);
+    if (cf == 2 && pf == 4 && nw == 4) return launch_dma<2, 4, 4, 2, I8>(L, s);
+    y6_set_error("conv_dma: no instantiation c%dp%d x %d waves", cf, pf, nw);
+    return Y6_EUNSUPPORTED;
+}
+
+}  // namespace
+
+// L points at conv_mfma.hip's launch record (same struct: conv_common.hpp)
+int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int i8, hipStream_t s) {
+    const Launch& l = *static_cast<const Launch*>(L);
+    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, s) : launch_dma_cfg<false>(l, cf, pf, nw, s);
+}
+
+int y6_conv_dma_halo_cap(int bp) { return bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 672 : 1216)); }
+
+extern "C" int y6_dma_probe(const void* src, unsigned bytes, unsigned lds_off, unsigned long long oob_mask, void* dst, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(src && dst && (lds_off % 16) == 0 && lds_off + 1024 <= 160 * 1024, "dma_probe: bad arguments");
+    static bool big = false;
+    if (!big) {
+        Y6_HIP(hipFuncSetAttribute((const void*)dma_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        big = true;
+    }
+    hipLaunchKernelGGL(dma_probe_kernel, dim3(1), dim3(64), lds_off + 1024, (hipStream_t)stream, (const char*)src, bytes, lds_off,
+                       oob_mask, (char*)dst);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}

@@ -17,278 +17,9 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "conv_common.hpp"
 
 namespace {
-
-constexpr int PIXB = 80;  // LDS bytes per halo pixel: 32 ch * 2 B + 16 B pad (bank spread)
-
-struct ConvKArgs {
-    const __half* in;
-    __half* out;
-    const __half* wpk;
-    const float* bias;
-    const float* pscale;
-    const float* pshift;
-    const __half* res;
-    const float* res_alpha;
-    int B, H, W, Ho, Wo;
-    int Cin, Cout;
-    int in_cs, in_co, out_cs, out_co, res_cs, res_co;
-    int TH, TW, tiles_x, tiles_y, ntiles;
-    int HH, HWd;
-    int nchunk, ncb;
-    int ldsA_bytes;
-    int act;
-    int vec_ok;    // 8-byte stores legal (cstride/coff % 4 == 0)
-    int vec16_ok;  // 16-byte stores legal (cstride/coff % 8 == 0, base 16-byte aligned)
-    int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
-    int nids;  // padded (tile, cout-block) id space of the 1-D grid
-    unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
-    int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
-    // int8 kernels (conv_i8_kernel) only
-    const float* qscale;            // [Cout] s_x * s_w[c]
-    unsigned q_inv2, q_lo2, q_hi2;  // half2 constants of the input quantiser: 127/amax, -amax, +amax
-    const signed char* qin;         // optional int8 NHWC input view (then `in` is not read)
-    int qin_cs, qin_co;
-    signed char* qout;              // optional int8 NHWC copy of the output, quantised for its consumers
-    int qout_cs, qout_co;
-    unsigned qo_inv2, qo_lo2, qo_hi2;
-    int* acc_out;                   // optional raw int32 accumulators [pixel][Cout] (parity tests)
-};
-
-// LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it
-// cannot (a) insert a conservative `s_waitcnt vmcnt(0)` before every later ds_read because the DMA
-// "might alias", nor (b) count it - completion is awaited by the kernel's own vmcnt(0) at the chunk
-// boundary.  M0 (the LDS destination base) is saved/restored inside the statement
-// (cdna_hip_programming.md §5.7).  `lds_dst` must be wave-uniform.
-__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc_lane), "s"(lds_dst)
-        : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
-
-template <int KS, int ST, int PF>
-struct HaloCap {
-    static constexpr int value = (KS == 1) ? PF * 128 : (ST == 1 ? (PF == 2 ? 352 : 208) : 576);
-};
-
-// Epilogue: bias (+affine) + activation (+residual) -> fp16 NHWC.
-// C/D layout: col = pixel (lane&31), row = cout = (r&3) + 8*(r>>2) + 4*(lane>>5): a lane holds four
-// consecutive couts of ONE pixel per group of 4 accumulator registers (group g = r>>2), and lane^32
-// holds the next four couts of the same pixel.
-//   * bias values are fetched up front by load_bias() (4 x 16-byte loads per fragment, issued before
-//     the main loop) instead of 4 dependent loads in front of every store group;
-//   * v_permlane32_swap pairs groups (g, g+1): afterwards lanes 0-31 own couts 8g..8g+7 and lanes 32-63
-//     own 8(g+1)..8(g+1)+7 of their pixel -> ONE 16-byte store per lane per pair instead of two 8-byte
-//     ones (the scattered 8-byte stores were store-issue bound: profiles/r01/conv_ablation_abl01.log).
-// finish(): acc + bias -> (affine) -> activation -> (+alpha*residual), for the 16 values a lane holds of one
-// fragment.  All mode decisions are wave-uniform and hoisted out of the element loop (the r07 trace
-// showed ~4000 cycles per fragment when `switch(act)` / affine / residual were tested per element).
-template <int ACT>
-__device__ __forceinline__ float act_const(float v) {
-    if constexpr (ACT == Y6_ACT_RELU) return v > 0.f ? v : 0.f;
-    if constexpr (ACT == Y6_ACT_SILU) {
-        v = y6_round_f16(v);            // the conv output is an fp16 tensor in the reference (common.hpp)
-        return v / (1.f + __expf(-v));
-    }
-    if constexpr (ACT == Y6_ACT_HARDSWISH) {
-        v = y6_round_f16(v);
-        float r = v + 3.f;
-        r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r);
-        return v * r * (1.f / 6.f);
-    }
-    return v;
-}
-
-template <int ACT>
-__device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc, const float (&bias)[16], int cfrag,
-                                         int kh, int cend, const __half* rrow, float ralpha, float (&v)[16]) {
-    if (a.pscale == nullptr && rrow == nullptr) {   // the common case: conv + bias + act
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = act_const<ACT>(acc[r] + bias[r]);
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
-        float x = acc[r] + bias[r];
-        if (c < cend) {
-            if (a.pscale) x = y6_round_f16(x) * a.pscale[c] + a.pshift[c];      // QARepVGG: conv -> BN are two fp16 ops
-            x = act_const<ACT>(x);
-            if (rrow) x = y6_round_f16(x) + y6_round_f16(ralpha * __half2float(rrow[c]));   // BottleRep: out + alpha*x
-        } else {
-            x = act_const<ACT>(x);
-        }
-        v[r] = x;
-    }
-}
-
-__device__ __forceinline__ void finish16_any(const ConvKArgs& a, const f32x16_t& acc, const float (&bias)[16], int cfrag,
-                                             int kh, int cend, const __half* rrow, float ralpha, float (&v)[16]) {
-    switch (a.act) {   // one wave-uniform branch per fragment
-        case Y6_ACT_RELU: finish16<Y6_ACT_RELU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
-        case Y6_ACT_SILU: finish16<Y6_ACT_SILU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
-        case Y6_ACT_HARDSWISH: finish16<Y6_ACT_HARDSWISH>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
-        default: finish16<Y6_ACT_NONE>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
-    }
-}
-
-template <int CF>
-struct BiasRegs {
-    float v[CF][16];
-};
-
-template <int CF>
-__device__ __forceinline__ void load_bias(const ConvKArgs& a, int cb, int upc0, int lane, BiasRegs<CF>& bz) {
-#pragma unroll
-    for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = (cb * CF + cf) * 32 + 8 * g + 4 * (lane >> 5) - upc0;
-            const int cend = a.up == 2 ? a.upC : a.Cout;
-            if (a.bias != nullptr && c0 + 3 < cend && c0 >= 0) {
-                const float4 t = *reinterpret_cast<const float4*>(a.bias + c0);
-                bz.v[cf][g * 4 + 0] = t.x;
-                bz.v[cf][g * 4 + 1] = t.y;
-                bz.v[cf][g * 4 + 2] = t.z;
-                bz.v[cf][g * 4 + 3] = t.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    bz.v[cf][g * 4 + j] = (a.bias != nullptr && c0 + j < cend && c0 + j >= 0) ? a.bias[c0 + j] : 0.f;
-            }
-        }
-}
-
-template <int CF, int PF>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF], const int (&opix)[PF],
-                                              int cb, int upc0, int lane, const BiasRegs<CF>& bz) {
-    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
-    const int cend = a.up == 2 ? a.upC : a.Cout;
-    const int kh = lane >> 5;
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const bool pvalid = opix[pf] >= 0;
-        const size_t prow = pvalid ? (size_t)opix[pf] : 0;
-        __half* orow = a.out + prow * a.out_cs + a.out_co;
-        const __half* rrow = a.res ? a.res + prow * a.res_cs + a.res_co : nullptr;
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
-            const int cfrag = (cb * CF + cf) * 32 - upc0;   // first output channel of this fragment
-            // 1) finish the 16 values of this lane
-            float v[16];
-            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
-            // 2) pack to fp16 pairs: group g -> dwords pk[g][0..1]
-            unsigned pk[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                    h2_t t;
-                    t[0] = (_Float16)v[g * 4 + h * 2];
-                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
-                    pk[g][h] = __builtin_bit_cast(unsigned, t);
-                }
-            if (a.vec16_ok && (cfrag + 32) <= cend && cfrag >= 0) {
-                // 3) pair groups across the two half-waves, 16-byte stores
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    unsigned lo0 = pk[2 * gp][0], lo1 = pk[2 * gp][1], hi0 = pk[2 * gp + 1][0], hi1 = pk[2 * gp + 1][1];
-                    auto s0 = __builtin_amdgcn_permlane32_swap(lo0, hi0, false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(lo1, hi1, false, false);
-                    // lanes 0-31: {own g, partner's g} = couts 8g..8g+7 ; lanes 32-63: couts 8(g+1)..8(g+1)+7
-                    if (pvalid) {
-                        uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                        *reinterpret_cast<uint4*>(orow + cfrag + 16 * gp + 8 * kh) = o;
-                    }
-                }
-            } else if (pvalid) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = cfrag + 8 * g + 4 * kh;
-                    if (c0 >= cend || c0 < 0) continue;
-                    if (a.vec_ok && (c0 + 3) < cend) {
-                        *reinterpret_cast<uint2*>(orow + c0) = make_uint2(pk[g][0], pk[g][1]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (c0 + j < cend) orow[c0 + j] = __float2half(v[g * 4 + j]);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// LDS-staged epilogue: the direct path above makes every store instruction touch 32 different cache
-// lines with 16-32 bytes each (store-issue / request-rate bound: the 210 MB stem output ran at
-// ~550 GB/s).  Here each wave writes its [PF*32 pixels][CF*32 couts] fp16 tile into its own LDS
-// region, then reads it back so that consecutive lanes hold consecutive 16-byte pieces of one pixel's
-// channel row: a store instruction now covers 64*16 B of (at most 64/(CF*4)) complete NHWC rows.
-// Wave-private region -> no block barrier (LDS ops of one wave complete in order; lgkmcnt(0) between
-// the phases).  Callers must have passed a block barrier after the last main-loop LDS read.
-template <int CF, int PF>
-__device__ __forceinline__ void conv_epilogue_lds(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF],
-                                                  const int (&opix)[PF], int cb, int upc0, int lane, int wave,
-                                                  const BiasRegs<CF>& bz, char* lds) {
-    constexpr int RS = CF * 64 + 16;                 // row pitch: CF*32 couts * 2 B + 16 B (bank spread)
-    constexpr int ROWS = PF * 32;
-    constexpr int REGION = ROWS * RS + ROWS * 4;      // tile + one int (output pixel index) per row
-    char* tile = lds + wave * REGION;
-    int* rowpix = reinterpret_cast<int*>(tile + ROWS * RS);
-    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
-    const int cend = a.up == 2 ? a.upC : a.Cout;
-    const int kh = lane >> 5;
-    const int cblock = cb * CF * 32 - upc0;           // first output channel of this block's tile
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const bool pvalid = opix[pf] >= 0;
-        const size_t prow = pvalid ? (size_t)opix[pf] : 0;
-        const __half* rrow = a.res ? a.res + prow * a.res_cs + a.res_co : nullptr;
-        const int row = pf * 32 + (lane & 31);
-        if (kh == 0) rowpix[row] = opix[pf];
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
-            const int cfrag = cblock + cf * 32;
-            float v[16];
-            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-                h4v o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[g * 4 + j];
-                *reinterpret_cast<h4v*>(tile + row * RS + cf * 64 + g * 16 + kh * 8) = o;
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    constexpr int PPR = CF * 4;                        // 16-byte pieces per row
-    constexpr int NPC = ROWS * PPR;                    // pieces per wave tile
-#pragma unroll
-    for (int i = 0; i < NPC / 64; ++i) {
-        const int q = lane + 64 * i;
-        const int row = q / PPR, pc = q - row * PPR;
-        const int op = rowpix[row];
-        const int c0 = cblock + pc * 8;
-        if (op >= 0 && c0 + 8 <= cend) {
-            const uint4 v = *reinterpret_cast<const uint4*>(tile + row * RS + pc * 16);
-            *reinterpret_cast<uint4*>(a.out + (size_t)op * a.out_cs + a.out_co + c0) = v;
-        }
-    }
-}
-
-template <int CF, int PF>
-constexpr int epi_lds_bytes() {
-    return 4 * (PF * 32 * (CF * 64 + 16) + PF * 32 * 4);
-}
 
 template <int CF, int PF, int KS, int ST>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
@@ -500,23 +231,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 // Operand K order: lane half h of k-step ks holds channels 64*chunk + 32*ks + 16*h + (0..15) for the pixel operand and
 // for the weight operand alike (y6_pack_conv_weight_i8), so whatever K index the hardware assigns to (h, byte) is the
 // same on both sides.
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-typedef int i32x16_t __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ unsigned q8_pair(unsigned x2, unsigned inv2, unsigned lo2, unsigned hi2) {
-    unsigned r;
-    asm("v_pk_max_f16 %0, %1, %2\n\tv_pk_min_f16 %0, %0, %3\n\tv_pk_fma_f16 %0, %0, %4, %5"
-        : "=&v"(r)
-        : "v"(x2), "v"(lo2), "v"(hi2), "v"(inv2), "v"(0x66006600u));
-    return r;   // two fp16 values 1536 + q: low bytes are the int8 codes
-}
-__device__ __forceinline__ unsigned q8_quad(unsigned a, unsigned b, unsigned inv2, unsigned lo2, unsigned hi2) {
-    return __builtin_amdgcn_perm(q8_pair(b, inv2, lo2, hi2), q8_pair(a, inv2, lo2, hi2), 0x06040200u);
-}
-__device__ __forceinline__ uint4 q8_piece(const uint4& lo, const uint4& hi, unsigned inv2, unsigned lo2, unsigned hi2) {
-    return make_uint4(q8_quad(lo.x, lo.y, inv2, lo2, hi2), q8_quad(lo.z, lo.w, inv2, lo2, hi2),
-                      q8_quad(hi.x, hi.y, inv2, lo2, hi2), q8_quad(hi.z, hi.w, inv2, lo2, hi2));
-}
 
 template <int CF, int PF, int KS, int ST>
 __global__ __launch_bounds__(256, (CF * PF <= 4 ? 2 : 1)) void conv_i8_kernel(const ConvKArgs a) {
@@ -689,13 +403,9 @@ __global__ __launch_bounds__(256, (CF * PF <= 4 ? 2 : 1)) void conv_i8_kernel(co
         }
     }
 
-    // ---- epilogue, one cout fragment at a time (16 bias + 16 scale registers live next to the accumulators):
-    // exact int32 -> fp32 (one rounding), * s_x*s_w[c] (one rounding), then the arithmetic of the fp16 path's epilogue
-    const int kh = lane >> 5;
-    const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
+    // ---- epilogue, one cout fragment at a time (16 bias + 16 scale registers live next to the accumulators)
 #pragma unroll
     for (int cf = 0; cf < CF; ++cf) {
-        const int cfrag = (cb * CF + cf) * 32;
         BiasRegs<1> bz, qs;
         load_bias<1>(a, cb * CF + cf, 0, lane, bz);
         {
@@ -703,71 +413,7 @@ __global__ __launch_bounds__(256, (CF * PF <= 4 ? 2 : 1)) void conv_i8_kernel(co
             t.bias = a.qscale;
             load_bias<1>(t, cb * CF + cf, 0, lane, qs);
         }
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {
-            const bool pvalid = opix[pf] >= 0;
-            const size_t prow = pvalid ? (size_t)opix[pf] : 0;
-            if (a.acc_out != nullptr && pvalid) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    if (c < a.Cout) a.acc_out[prow * a.Cout + c] = acc[cf][pf][r];
-                }
-            }
-            f32x16_t accf;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (float)acc[cf][pf][r] * qs.v[0][r];
-                asm volatile("" : "+v"(v));     // keep the product a separate rounding (no fma with the bias add)
-                accf[r] = v;
-            }
-            const __half* rrow = (a.res && pvalid) ? a.res + prow * a.res_cs + a.res_co : nullptr;
-            float v[16];
-            finish16_any(a, accf, bz.v[0], cfrag, kh, a.Cout, rrow, ralpha, v);
-            unsigned pk[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                    h2_t t;
-                    t[0] = (_Float16)v[g * 4 + h * 2];
-                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
-                    pk[g][h] = __builtin_bit_cast(unsigned, t);
-                }
-            if (a.qout != nullptr) {
-                // int8 twin for quantised consumers: the SAME fp16 values that go to `out`, quantised with their scale
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned q = q8_quad(pk[g][0], pk[g][1], a.qo_inv2, a.qo_lo2, a.qo_hi2);
-                    const int c0 = cfrag + 8 * g + 4 * kh;
-                    if (pvalid && c0 + 3 < a.Cout) *reinterpret_cast<unsigned*>(a.qout + prow * a.qout_cs + a.qout_co + c0) = q;
-                }
-            }
-            if (a.out == nullptr) continue;
-            __half* orow = a.out + prow * a.out_cs + a.out_co;
-            if (a.vec16_ok && (cfrag + 32) <= a.Cout) {
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
-                    auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-                    if (pvalid) *reinterpret_cast<uint4*>(orow + cfrag + 16 * gp + 8 * kh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                }
-            } else if (pvalid) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = cfrag + 8 * g + 4 * kh;
-                    if (c0 >= a.Cout) continue;
-                    if (a.vec_ok && (c0 + 3) < a.Cout) {
-                        *reinterpret_cast<uint2*>(orow + c0) = make_uint2(pk[g][0], pk[g][1]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (c0 + j < a.Cout) orow[c0 + j] = __float2half(v[g * 4 + j]);
-                    }
-                }
-            }
-        }
+        conv_i8_epilogue<PF>(a, acc[cf], opix, cb * CF + cf, lane, bz.v[0], qs.v[0]);
     }
 }
 
@@ -1482,13 +1128,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
     }
 }
 
-struct VariantCfg {
-    int cf, pf, persist;
-    const char* name;
-    int nw = 4;      // waves per block (pipe kernels: 4 or 8)
-    int st = 1;      // pipe kernels: the stride they are built for
-    int depth = 2;   // pipe kernels: chunks the halo fill runs ahead
-};
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
 // 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
 const VariantCfg kVariants[] = {
@@ -1498,7 +1137,9 @@ const VariantCfg kVariants[] = {
     {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
     {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8},
     {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}, {2, 2, 2, "pipe3_c2p2", 4, 1, 3}, {2, 1, 2, "pipe3_c2p1", 4, 1, 3},
-    {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"}};   // persist == 3: the streaming 1x1 kernel
+    {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"},    // persist == 3: the streaming 1x1 kernel
+    // persist == 4: LDS-DMA fed 3x3 stride-1 kernels (conv_dma.hip)
+    {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4}, {2, 4, 4, "dma_c2p4", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1508,7 +1149,7 @@ int halo_cap(int ks, int st, int pf) {
 }
 
 // choose the spatial tile (TH x TW outputs) for a block of `bp` pixel slots
-void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int* pTW) {
+void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int* pTW, int tw_mult = 0) {
     double best = -1.0;
     int bTH = 1, bTW = 1;
     const int maxTW = Wo < bp ? Wo : bp;
@@ -1530,7 +1171,8 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         // such tiles (Y6_CONV_TW32=1) cuts the conflict cycles from 0.41 to 0.15 per access and does not move
         // the time (tools/gpu_pmc2.sh), so it is off by default.
         static const int tw32 = getenv("Y6_CONV_TW32") ? atoi(getenv("Y6_CONV_TW32")) : 0;
-        const double rowfit = (tw32 == 0 || TW % 32 == 0) ? 1.0 : 0.90;
+        // tw_mult (LDS-DMA kernels): widths that keep the 16-lane read groups on one halo row are conflict-free
+        const double rowfit = tw_mult ? (TW % tw_mult == 0 ? 1.0 : 0.95) : ((tw32 == 0 || TW % 32 == 0) ? 1.0 : 0.90);
         const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
@@ -1542,11 +1184,6 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
     *pTW = bTW;
 }
 
-struct Launch {
-    ConvKArgs k;
-    int grid;
-    size_t lds;
-};
 
 int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx, Launch* L) {
     const VariantCfg& vc = kVariants[variant];
@@ -1600,8 +1237,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.W = d->in.W;
         k.Ho = d->out.H;
         k.Wo = d->out.W;
-        const int cap = vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
-        choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW);
+        const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
+        choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
     }
     k.tiles_x = y6_cdiv(k.Wo, k.TW);
     k.tiles_y = y6_cdiv(k.Ho, k.TH);
@@ -1618,7 +1255,12 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
     L->grid = k.nids;
-    if (vc.persist == 2)
+    if (vc.persist == 4) {
+        k.dma_rp = k.HWd;
+        k.dma_pls = k.HH * k.HWd;
+        k.dma_nhp = y6_cdiv(2 * k.dma_pls, 64);
+        L->lds = 2 * (size_t)(k.dma_nhp + 9 * vc.cf) * 1024 + 4 * vc.cf * 32 * 4;   // two stages of (halo planes + nine tap images), bias / scales x2
+    } else if (vc.persist == 2)
         L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
     else if (vc.persist)
         L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
@@ -1814,8 +1456,14 @@ int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 
 int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     const y6_conv_desc* d = &q->conv;
-    if (d->variant >= 1 && d->variant <= 6) return d->variant;
+    if (d->variant >= 1 && d->variant <= 8) return d->variant;
     const int co = d->out.data ? d->out.C : q->q_out.C;
+    static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
+    // 7 / 8: the LDS-DMA kernels (conv_dma.hip) - need the producer's int8 twin and whole 32-channel chunks
+    if (!no_dma && d->ksize == 3 && d->stride == 1 && q->q_in.data && q->q_in.C % 32 == 0 && co >= 64) {
+        const long npix = (long)q->q_in.B * q->q_in.H * q->q_in.W;
+        return npix * y6_cdiv(co, 64) >= 512L * 256 ? 7 : 8;       // enough 512-pixel items for every CU, else 256-pixel tiles
+    }
     if (d->ksize == 3 && d->stride == 1) return co >= 64 ? 5 : 4;            // c2p2 / c1p2
     return co >= 256 ? 3 : (co >= 64 ? 2 : 1);                                // c4p1 / c2p1 / c1p1
 }
@@ -1851,9 +1499,13 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
                    "conv_i8: int8 output view");
     }
     const int variant = y6_conv_i8_variant(q);
-    Y6_REQUIRE(!(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
+    const bool dma = variant >= 7;
+    if (dma)
+        Y6_REQUIRE(d.ksize == 3 && d.stride == 1 && has_qin && q->q_in.C % 32 == 0, "conv_i8: the LDS-DMA variants need k3 s1, an int8 input view and Cin %% 32 == 0");
+    Y6_REQUIRE(dma || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
     Launch L;
-    int rc = build_launch(&d, variant, 0, 0, 0, &L);
+    const int kv = dma ? (variant == 7 ? 24 : 25) : variant;   // kVariants row that sizes the tile
+    int rc = build_launch(&d, kv, 0, 0, 0, &L);
     if (rc) return rc;
     ConvKArgs& k = L.k;
     k.nchunk = y6_cdiv(k.Cin, 64);
@@ -1871,6 +1523,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
+    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 1, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
         case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
@@ -1904,6 +1557,13 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist && ks != 3) return 0;
+    if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
+        if (st != 1 || d->w_packed == nullptr) return 0;
+        if (d->in.C % 16 || d->in.cstride % 8 || d->in.coff % 8) return 0;
+        if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
+        if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
+        return vc.cf <= y6_cdiv(d->out.C, 32);
+    }
     if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
     if (vc.persist == 2 && st != vc.st) return 0;
     if (vc.persist == 2 && vc.depth == 3 && (y6_cdiv(d->in.C, 16) & 1)) return 0;   // two chunks per loop trip
@@ -1956,6 +1616,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
+        case 24: case 25: case 26: case 27: case 28:
+            return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, 0, s);
     }
     return Y6_EINVAL;
 }
