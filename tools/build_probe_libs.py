@@ -24,6 +24,25 @@ def one(n):
     return lib
 
 
+def one_dma(n):
+    """conv_dma.hip rebuilt with -DY6_DMA_PROBE=n -> tools/_build/libyolov6_hip_dmaprobe<n>.so"""
+    oth = [o for o in glob.glob(os.path.join(B.OBJ_DIR, "*.o")) if not os.path.basename(o).startswith("conv_dma.")]
+    obj = os.path.join(out, f"conv_dma_probe{n}.o")
+    lib = os.path.join(out, f"libyolov6_hip_dmaprobe{n}.so")
+    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_dma.hip"] + [f"-DY6_DMA_PROBE={n}", "-c",
+                    os.path.join(B.HERE, "conv_dma.hip"), "-o", obj], check=True, capture_output=True)
+    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + sorted(oth), check=True)
+    os.remove(obj)
+    return lib
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--dma":
+    probes = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 5, 6]
+    with cf.ThreadPoolExecutor(max_workers=len(probes)) as ex:
+        for lib in ex.map(one_dma, probes):
+            print("built", lib)
+    sys.exit(0)
+
 probes = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 5, 6]
 with cf.ThreadPoolExecutor(max_workers=len(probes)) as ex:
     for lib in ex.map(one, probes):

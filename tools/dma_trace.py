@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""s_memtime timeline of block 0 / thread 0 of the LDS-DMA conv kernel (needs the trace build:
+   python tools/build_probe_libs.py --dma 1;  Y6_LIB_PATH=tools/_build/libyolov6_hip_dmaprobe1.so python tools/dma_trace.py 128,128,3,1,80,80,32 dma_c2p2)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+buf = torch.zeros(512, dtype=torch.int64, device="cuda:0")
+os.environ["Y6_CONV_TRACE"] = str(buf.data_ptr())
+from yolov6_amd import _lib
+from yolov6_amd.engine import PlanBuilder, TRef
+lib = _lib.load()
+names = [lib.y6_conv_variant_name(i).decode() for i in range(lib.y6_conv_variants())]
+spec, vname = sys.argv[1], sys.argv[2]
+variant = names.index(vname)
+cin, cout, k, s, H, W, B = (int(v) for v in spec.split(","))
+x = torch.randn((B, H, W, cin), device="cuda:0").half()
+w = torch.randn((cout, cin, k, k)) / (cin * k * k) ** 0.5
+pb = PlanBuilder("cuda:0"); pb.force_variant = variant
+pb.conv(TRef(x, B, H, W, cin, cin, 0), w, torch.zeros(cout), stride=s, act="relu")
+plan = pb.finalize(None, autotune=False)
+for _ in range(3):
+    plan.run()
+torch.cuda.synchronize()
+t = buf.cpu().view(256, 2).tolist()
+tags = {1: "kernel start", 2: "prologue done", 9: "chunk top (after prev taps/epilogue)", 10: "barrier passed", 11: "taps issued", 19: "chunk loop done",
+        20: "epilogue issued", 21: "args reloaded + output pixels", 22: "cout fragment 0 stored", 23: "cout fragment 1 stored"}
+prev = t[0][0]
+acc = {}
+for ts, tag in t:
+    if tag == 0: break
+    acc.setdefault(tag, []).append(ts - prev); prev = ts
+n = sum(len(v) for v in acc.values())
+print(spec, vname, "events", n, "span", (prev - t[0][0]))
+for tag, v in sorted(acc.items()):
+    print("  -> %-40s n=%3d mean %8.0f  min %8.0f max %8.0f" % (tags.get(tag, tag), len(v), sum(v) / len(v), min(v), max(v)))
+print("  first 60:", [(int(tag), int(b - a)) for (a, _), (b, tag) in zip(t[:60], t[1:61]) if tag])

@@ -21,6 +21,8 @@
 //     run.  The stream crosses work items, so the first chunk of the next (tile, cout block) lands during the epilogue.
 // The int8 form (v_mfma_i32_32x32x32_i8, BASELINE configs[4]) is the same data movement byte for byte: a chunk is 32
 // int8 channels = 32 B per pixel; it reads the int8 twin its producer wrote (include/yolov6_hip.h y6_conv_i8_desc.q_in).
+#include <type_traits>
+
 #include "common.hpp"
 #include "conv_common.hpp"
 
@@ -44,8 +46,8 @@ __device__ __forceinline__ void dma16(const i32x4_t& rsrc, unsigned voff, unsign
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
-        : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst)
-        : "memory");
+        : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+        : "memory");   // (both are wave-uniform by construction; under register pressure hipcc may still carry them in VGPRs)
 }
 
 // The argument block again, loaded where it is used.  The epilogue reads two dozen fields of ConvKArgs; taken from the
@@ -63,6 +65,15 @@ __device__ __forceinline__ ConvKArgs reload_args() {
     for (unsigned i = 0; i < sizeof(ConvKArgs) / 4; ++i) dst[i] = src[i];   // scalar loads of the fields the caller uses
     return r;
 }
+
+// Ceiling probes / trace (tools/build_probe_libs.py --dma; WRONG RESULTS for n >= 2, timing only), compile-time:
+//   1 = s_memtime trace of block 0 / thread 0 into a.dbg (tools/dma_trace.py); 2 = no epilogue; 3 = no MFMAs;
+//   4 = no LDS-DMA requests after the prologue; 5 = fragment reads of tap 0 only (MFMAs on stale operands);
+//   6 = no chunk barrier / vmcnt wait
+#ifndef Y6_DMA_PROBE
+#define Y6_DMA_PROBE 0
+#endif
+constexpr int kDmaProbe = Y6_DMA_PROBE;
 
 constexpr unsigned kOob = 0xffffff00u;   // voffset of a piece that must read zeros
 
@@ -158,6 +169,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         if (t >= a.ntiles) id = next_valid(id);
     }
     if (id >= nids) return;
+    int dbg_n = 0;
+    const bool tracing = kDmaProbe == 1 && a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+#define DT(tag)                                                              \
+    do {                                                                     \
+        if (kDmaProbe == 1 && tracing && dbg_n < 256) {                      \
+            a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                 \
+            a.dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                \
+            ++dbg_n;                                                         \
+        }                                                                    \
+    } while (0)
+    DT(1);
 
     // ---- this wave's pieces of a chunk image  [halo plane 0 | halo plane 1 | pad to 1 KiB][CF x 9 weight fragments]:
     //      halo pieces P = wave + NW*i < NHP, weight fragments q = wave + NW*j < CF*9.
@@ -211,14 +233,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         c_soffW = (unsigned)(((c_cb * CF * a.nchunk + (c_chunk >> 1)) * NT * 2 + (c_chunk & 1)) * 1024);
     };
     constexpr int NPIECE = NPWH + NPWW;
+    bool in_loop = false;
     auto issue_piece = [&](int k) {   // k: compile-time index, halo pieces first (longest latency)
         if (k < NPWH) {
             const int P = wave + NW * k;
-            if (P < NHP) dma16(rsA, hvoff[k < NPWH ? k : 0], c_soffA, c_dst0 + P * 1024);
+            if (P < NHP && (kDmaProbe != 4 || !in_loop)) dma16(rsA, hvoff[k < NPWH ? k : 0], c_soffA, c_dst0 + P * 1024);
         } else if (k < NPIECE) {
             const int j = k - NPWH;
             const int q = wave + NW * j;
-            if (q < WP) dma16(rsW, lane16, c_soffW + wsoff[j < NPWW ? j : 0], c_dst0 + (NHP + q) * 1024);
+            if (q < WP && (kDmaProbe != 4 || !in_loop)) dma16(rsW, lane16, c_soffW + wsoff[j < NPWW ? j : 0], c_dst0 + (NHP + q) * 1024);
         }
     };
     auto cursor_advance = [&]() {
@@ -293,10 +316,100 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         }
     }
 
+    in_loop = true;
+    DT(2);
     int pb = 0, item_parity = 0;
     bool prev_issued = c_valid || STG == 2;   // did the previous iteration put pieces of a YOUNGER chunk in flight
-    while (true) {
-        acc_t acc[CF][PF];
+
+    // ---- epilogues.
+    // General (any activation, QARepVGG post-affine, residual, ragged channel counts, int8): after the item's last chunk, one
+    // (cout fragment, pixel fragment) unit after the other, on arguments re-read from the kernarg segment.
+    // Fast + deferred (conv + bias + ReLU / identity into a 16-byte aligned view with whole 32-channel fragments - every
+    // RepVGG / ConvBNReLU 3x3 of the deploy graphs): the finished accumulators of item k stay in their registers while item
+    // k+1 accumulates into a second set, and the units of item k are issued one per tap BEHIND the MFMAs of item k+1's first
+    // chunk - the matrix pipe keeps running while the wave does bias / max / pack / store (before: the epilogue took 20 % of
+    // an item's time at Cin 128 and 33 % at Cin 64 with the matrix pipe waiting, tools/dma_trace.py).  Stores go through a
+    // buffer descriptor: 32-bit byte offsets, overhang pixels dropped by the range check.  Needs 2 x CF*PF*16 accumulator
+    // registers: variants with at most three waves per SIMD.
+    constexpr bool DEFER = WPS <= 3 && !I8 && CF * PF <= 4;
+    constexpr int NUNIT = CF * PF;
+    static_assert(!DEFER || NUNIT <= NT - 1, "one deferred epilogue unit per tap 1..8");
+    auto epi_unit = [&](const ConvKArgs& ea, const acc_t (&accP)[CF][PF], const int (&opx)[PF], int cbq, const float* lb, int u) {
+        const int cf = u / PF, pf = u - cf * PF;
+        BiasRegs<1> bz;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(lb + cf * 32 + 8 * g + 4 * (lane >> 5));
+            bz.v[0][g * 4 + 0] = t.x;
+            bz.v[0][g * 4 + 1] = t.y;
+            bz.v[0][g * 4 + 2] = t.z;
+            bz.v[0][g * 4 + 3] = t.w;
+        }
+        if (kDmaProbe == 2) return;
+        const int op1[1] = {opx[pf]};
+        if constexpr (I8) {
+            BiasRegs<1> qs;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(lb + 2 * CF * 32 + cf * 32 + 8 * g + 4 * (lane >> 5));
+                qs.v[0][g * 4 + 0] = t.x;
+                qs.v[0][g * 4 + 1] = t.y;
+                qs.v[0][g * 4 + 2] = t.z;
+                qs.v[0][g * 4 + 3] = t.w;
+            }
+            conv_i8_epilogue<1>(ea, *reinterpret_cast<const i32x16_t(*)[1]>(&accP[cf][pf]), op1, cbq * CF + cf, lane, bz.v[0], qs.v[0]);
+        } else {
+            conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&accP[cf][pf]), op1, cbq * CF + cf, 0, lane, bz);
+        }
+    };
+    const bool fast = DEFER && a.pscale == nullptr && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && a.vec16_ok &&
+                      (a.Cout & 31) == 0 && a.up == 0 && a.out != nullptr;
+    const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
+    const __amdgpu_buffer_rsrc_t rsO =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
+    unsigned obyteP[PF];   // byte offset of the lane's output pixels of the PREVIOUS item (kOob: none)
+    unsigned ocolP = 0;    // + byte offset of its cout block and of this lane's 8-channel piece
+    const float* lbP = ldsBias;
+    bool haveP = false;
+    auto fast_unit = [&](const acc_t (&accP)[CF][PF], int u) {
+        if constexpr (!I8) {
+            const int cf = u / PF, pf = u - cf * PF;
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(lbP + cf * 32 + 8 * g + 4 * (lane >> 5));
+                v[g * 4 + 0] = fmaxf(accP[cf][pf][g * 4 + 0] + t.x, fast_lo);
+                v[g * 4 + 1] = fmaxf(accP[cf][pf][g * 4 + 1] + t.y, fast_lo);
+                v[g * 4 + 2] = fmaxf(accP[cf][pf][g * 4 + 2] + t.z, fast_lo);
+                v[g * 4 + 3] = fmaxf(accP[cf][pf][g * 4 + 3] + t.w, fast_lo);
+            }
+            if (kDmaProbe == 2) return;
+            unsigned pk[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    h2_t t;
+                    t[0] = (_Float16)v[g * 4 + h * 2];
+                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                    pk[g][h] = __builtin_bit_cast(unsigned, t);
+                }
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+                auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyteP[pf] + ocolP + (unsigned)((cf * 32 + 16 * gp) * 2)), 0, 0);
+            }
+        }
+    };
+
+    // one work item: accumulate into `acc`; (fast path) finish the previous item out of `accP` on the way.  Returns true
+    // after the block's last item.  FAST is a compile-time tag so that the two forms are separate loops.
+    auto do_item = [&](auto fast_tag, acc_t (&acc)[CF][PF], acc_t (&accP)[CF][PF]) __attribute__((always_inline)) -> bool {
+        constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
         for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
@@ -313,13 +426,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         for (int chunk = 0; chunk < nch; ++chunk) {
             // this wave's pieces of `chunk` have landed; after the barrier everybody's have, and nobody reads the other
             // stage any more (its last fragment reads fed MFMAs that were issued before the barrier)
-            // (3 stages, inside an item: the younger chunk's pieces stay in flight; at an item's first chunk the epilogue's
-            // stores are outstanding too and loads / stores retire out of order with respect to each other: wait for all)
-            if (STG == 3 && chunk > 0 && prev_issued) {
+            // (3 stages, inside an item: the younger chunk's pieces stay in flight; while epilogue stores may be outstanding -
+            // an item's first chunk, the second one too with the deferred epilogue - wait for everything: loads and stores
+            // retire out of order with respect to each other)
+            DT(9);
+            if (kDmaProbe == 6) {
+            } else if (STG == 3 && chunk > (FAST ? 1 : 0) && prev_issued) {
                 wait_vm_barrier(npw);
             } else {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            DT(10);
             const bool issuing = c_valid;
             if (issuing) {
                 cursor_target(pb == 0 ? STG - 1 : pb - 1);   // the stage read in the previous iteration
@@ -328,11 +445,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                     for (int k = 0; k < NPIECE; ++k) issue_piece(k);
                 }
             }
+            const bool epi_now = FAST && haveP && chunk == 0;
             const char* Ab = smem + pb * stage_bytes;
             const char* Wb = Ab + NHP * 1024 + lane * 16;
-            // fragment reads run one tap ahead of the MFMAs when only two or three waves share a SIMD; at four waves the
-            // other waves' MFMAs cover the LDS latency and the 16 registers are worth more
-            constexpr int LA = 2;
+            constexpr int LA = 2;                               // fragment reads run one tap ahead of the MFMAs
             constexpr int PPT = (NPIECE + NT - 2) / (NT - 1);   // pieces per tap: all requested by tap 7
             i32x4_t fa[LA][CF], fb[LA][PF];
             auto ldfragW = [&](int t, int buf) {
@@ -344,17 +460,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
             };
-            if (LA == 2) {
-                ldfragA(0, 0);
-                ldfragW(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            ldfragA(0, 0);
+            ldfragW(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (LA == 1) {
-                    ldfragA(t, 0);
-                    ldfragW(t, 0);
-                } else if (t + 1 < NT) {
+                if (t + 1 < NT && kDmaProbe != 5) {
                     ldfragA(t + 1, (t + 1) & 1);
                     ldfragW(t + 1, (t + 1) & 1);
                 }
@@ -363,58 +474,79 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                 for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) {
+                        if (kDmaProbe == 3) continue;
                         if constexpr (I8) {
-                            acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t & (LA - 1)][cf], fb[t & (LA - 1)][pf], acc[cf][pf], 0, 0, 0);
+                            acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t & 1][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
                         } else {
-                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fa[t & (LA - 1)][cf]),
-                                                                                 __builtin_bit_cast(h8_t, fb[t & (LA - 1)][pf]), acc[cf][pf], 0, 0, 0);
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fa[t & 1][cf]),
+                                                                                 __builtin_bit_cast(h8_t, fb[t & 1][pf]), acc[cf][pf], 0, 0, 0);
                         }
                     }
                 if (IL && issuing) {
 #pragma unroll
                     for (int u = 0; u < PPT; ++u) issue_piece(t * PPT + u);
                 }
+                if constexpr (FAST) {
+                    if (t >= 1 && t - 1 < NUNIT) {
+                        if (epi_now) fast_unit(accP, t - 1);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            DT(11);
             prev_issued = issuing;
             if (issuing) cursor_advance();
             pb = (pb + 1 == STG) ? 0 : pb + 1;
         }
-        const ConvKArgs ea = reload_args();
-        int opix[PF];
-        out_pix(ea, id, opix);
-        // one cout fragment at a time: 16 bias registers live instead of 16*CF next to 16*CF*PF accumulators
+        DT(19);
+        if constexpr (FAST) {
+            int opix[PF];
+            out_pix(a, id, opix);
 #pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
-            BiasRegs<1> bz;
+            for (int pf = 0; pf < PF; ++pf) obyteP[pf] = opix[pf] >= 0 ? (unsigned)((opix[pf] * a.out_cs + a.out_co) * 2) : kOob;
+            ocolP = (unsigned)((cb * CF * 32 + 8 * (lane >> 5)) * 2);
+            lbP = lbias;
+            haveP = true;
+        } else {
+            const ConvKArgs ea = reload_args();
+            int opix[PF];
+            out_pix(ea, id, opix);
+            DT(21);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
-                bz.v[0][g * 4 + 0] = t.x;
-                bz.v[0][g * 4 + 1] = t.y;
-                bz.v[0][g * 4 + 2] = t.z;
-                bz.v[0][g * 4 + 3] = t.w;
-            }
-            if constexpr (I8) {
-                BiasRegs<1> qs;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 t = *reinterpret_cast<const float4*>(lbias + 2 * CF * 32 + cf * 32 + 8 * g + 4 * (lane >> 5));
-                    qs.v[0][g * 4 + 0] = t.x;
-                    qs.v[0][g * 4 + 1] = t.y;
-                    qs.v[0][g * 4 + 2] = t.z;
-                    qs.v[0][g * 4 + 3] = t.w;
-                }
-                conv_i8_epilogue<PF>(ea, acc[cf], opix, cb * CF + cf, lane, bz.v[0], qs.v[0]);
-            } else {
-                conv_epilogue<1, PF>(ea, *reinterpret_cast<const f32x16_t(*)[1][PF]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
-            }
+            for (int u = 0; u < NUNIT; ++u) epi_unit(ea, acc, opix, cb, lbias, u);
         }
-        if (nid >= nids) break;
+        DT(20);
+        if (nid >= nids) return true;
         id = nid;
         item_parity ^= 1;
         setup_pix(id);
+        return false;
+    };
+
+    acc_t acc0[CF][PF];
+    if (DEFER && fast) {
+        if constexpr (DEFER) {
+            acc_t acc1[CF][PF];
+            typedef std::integral_constant<bool, true> yes_t;
+            while (true) {
+                if (do_item(yes_t{}, acc0, acc1)) {
+#pragma unroll
+                    for (int u = 0; u < NUNIT; ++u) fast_unit(acc0, u);
+                    break;
+                }
+                if (do_item(yes_t{}, acc1, acc0)) {
+#pragma unroll
+                    for (int u = 0; u < NUNIT; ++u) fast_unit(acc1, u);
+                    break;
+                }
+            }
+        }
+    } else {
+        typedef std::integral_constant<bool, false> no_t;
+        while (!do_item(no_t{}, acc0, acc0)) {
+        }
     }
+#undef DT
 }
 
 // Probe / self-test of the DMA addressing (tests/test_gpu_ops.py): one wave copies 1 KiB from `src` into LDS at byte
