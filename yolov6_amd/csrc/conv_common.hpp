@@ -380,7 +380,8 @@ struct VariantCfg {
     const char* name;
     int nw = 4;      // waves per block (pipe / dma kernels: 4 or 8)
     int st = 1;      // pipe kernels: the stride they are built for
-    int depth = 2;   // pipe kernels: chunks the halo fill runs ahead
+    int depth = 2;   // pipe kernels: chunks the halo fill runs ahead; dma kernels: LDS stages
+    int hc = 16;     // dma kernels: input channels per chunk
 };
 
 struct Launch {

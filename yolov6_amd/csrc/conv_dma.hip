@@ -75,7 +75,7 @@ __device__ __forceinline__ ConvKArgs reload_args() {
 #endif
 constexpr int kDmaProbe = Y6_DMA_PROBE;
 
-constexpr unsigned kOob = 0xffffff00u;   // voffset of a piece that must read zeros
+constexpr unsigned kOob = 0xf0000000u;   // voffset of a piece that must read zeros / a store that must be dropped (tensors stay below 3.5 GiB)
 
 // lane (0..31) -> pixel of the fragment it holds (see the header comment)
 __device__ __forceinline__ int frag_pixel(int l) {
@@ -119,13 +119,23 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 //      pieces in flight).  IL: 1 = the requests are issued one or two per tap BETWEEN the MFMAs of the running chunk (an
 //      LDS-DMA instruction occupies the issuing wave for 60-180 cycles - MI355X_MICROARCH.md; behind four MFMAs that time
 //      is covered by the matrix pipe), 0 = all of them right after the barrier (A/B).
-template <int CF, int PF, int NW, int WPS, int STG, int IL, bool I8>
+// HC: input channels per chunk (int8: twice that).  16: a pixel's chunk is 32 B in two planes (see the header).  32: 64 B per
+//     pixel, i.e. FOUR lanes of a DMA instruction read one pixel and an instruction touches 16 cache lines instead of 64 -
+//     the halo pieces were the expensive ones (about 100 cycles each against about 16 for a weight piece: the vector memory
+//     path serves one cache line per cycle or so; the fill alone ran at 18.7 B/clk/CU = 9.6 TB/s).  The LDS image is
+//     pixel-major there, [halo pixel][4 pieces of 16 B], with the piece index XOR-swizzled by bits 2-3 of the pixel index
+//     on the SOURCE side (cdna_hip_programming.md rule 21): a fragment read of 16 consecutive pixels still covers all 16
+//     bank groups, for any alignment.
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8>
 __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename AccT<I8>::type acc_t;
     constexpr int NT = 9;
-    constexpr int WP = CF * NT;                                   // weight pieces (1 KiB) per chunk
-    constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32>::value * 2 + 63) / 64;
+    constexpr int KS = HC / 16;                                   // MFMA k-steps per chunk and tap
+    constexpr int SPP = HC / 8;                                   // 16-byte pieces per halo pixel and chunk
+    constexpr int JB = HC == 16 ? 1 : 2;                          // bits of the piece index
+    constexpr int WP = CF * NT * KS;                              // weight pieces (1 KiB) per chunk
+    constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32>::value * SPP + 63) / 64;
     constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
 
     const int tid = threadIdx.x;
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     const int stage_bytes = (NHP + WP) * 1024;
     const unsigned smem_base = lds_addr(smem);
     float* ldsBias = reinterpret_cast<float*>(smem + STG * stage_bytes);   // [2][CF*32] bias, then [2][CF*32] dequant scales (int8)
-    const int nch = a.Cin / (I8 ? 32 : 16);
+    const int nch = a.Cin / (I8 ? 2 * HC : HC);
     const int nids = a.nids;
     const int gstride = gridDim.x;
 
@@ -192,19 +202,26 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     for (int i = 0; i < NPWH; ++i) {
         const int P = wave + NW * i;
         const int s = P * 64 + lane;
-        const int h = s >= PLs ? 1 : 0;
-        const int r = s - h * PLs;
+        int r, j;   // halo pixel (linear) and piece of LDS slot s
+        if (HC == 16) {
+            j = s >= PLs ? 1 : 0;
+            r = s - j * PLs;
+        } else {
+            r = s >> 2;
+            j = (s & 3) ^ ((r >> 2) & 3);
+        }
         const int hy = r / RP, hx = r - hy * RP;
-        const bool v = (P < NHP) && (s < 2 * PLs) && (hx < a.HWd);
-        hinfo[i] = v ? (unsigned)((hy << 16) | (hx << 1) | h) : 0xffffffffu;
+        const bool v = (P < NHP) && (s < SPP * PLs) && (hx < a.HWd);
+        hinfo[i] = v ? (unsigned)((hy << 16) | (hx << JB) | j) : 0xffffffffu;
         hvoff[i] = kOob;
     }
     unsigned wsoff[NPWW];   // scalar part of the weight fragment addresses (cf, tap of this wave's j-th fragment)
 #pragma unroll
     for (int j = 0; j < NPWW; ++j) {
         const int q = wave + NW * j;
-        const int cf = q / NT, tap = q - cf * NT;
-        wsoff[j] = (unsigned)(((cf * a.nchunk * NT + tap) * 2) * 1024);
+        const int ct = q / KS, ks = q - ct * KS;   // LDS image [cf][tap][k-step]
+        const int cf = ct / NT, tap = ct - cf * NT;
+        wsoff[j] = (unsigned)(((cf * a.nchunk * NT + tap) * 2 + ks) * 1024);
     }
     const unsigned lane16 = (unsigned)lane * 16u;
     auto setup_halo = [&](int item) {
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int base = (((b * a.H + iy0) * a.W + ix0) * ics + ico) * ES;   // may be negative; valid pieces end up >= 0
 #pragma unroll
         for (int i = 0; i < NPWH; ++i) {
-            const int hy = (int)(hinfo[i] >> 16), hx = (int)((hinfo[i] >> 1) & 0x7fffu), h = (int)(hinfo[i] & 1u);
+            const int hy = (int)(hinfo[i] >> 16), hx = (int)((hinfo[i] & 0xffffu) >> JB), h = (int)(hinfo[i] & ((1u << JB) - 1u));
             const bool v = (hinfo[i] != 0xffffffffu) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
             hvoff[i] = v ? (unsigned)(base + (hy * a.W + hx) * ics * ES + h * 16) : kOob;
         }
@@ -229,8 +246,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     unsigned c_dst0 = 0, c_soffA = 0, c_soffW = 0;
     auto cursor_target = [&](int stage) {
         c_dst0 = smem_base + stage * stage_bytes;
-        c_soffA = (unsigned)c_chunk * 32u;
-        c_soffW = (unsigned)(((c_cb * CF * a.nchunk + (c_chunk >> 1)) * NT * 2 + (c_chunk & 1)) * 1024);
+        c_soffA = (unsigned)c_chunk * (unsigned)(SPP * 16);
+        c_soffW = KS == 1 ? (unsigned)(((c_cb * CF * a.nchunk + (c_chunk >> 1)) * NT * 2 + (c_chunk & 1)) * 1024)
+                          : (unsigned)(((c_cb * CF * a.nchunk + c_chunk) * NT * 2) * 1024);
     };
     constexpr int NPIECE = NPWH + NPWW;
     bool in_loop = false;
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             const int npx = a.TH * a.TW;
             const int mm = m < npx ? m : npx - 1;
             const int ty = mm / a.TW, tx = mm - ty * a.TW;
-            pixoff[pf] = ((lane >> 5) * PLs + ty * RP + tx) * 16;
+            pixoff[pf] = HC == 16 ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // HC 32: the pixel's linear index
         }
     };
     auto out_pix = [&](const ConvKArgs& a, int item, int (&opix)[PF]) {
@@ -363,7 +381,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         }
     };
     const bool fast = DEFER && a.pscale == nullptr && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && a.vec16_ok &&
-                      (a.Cout & 31) == 0 && a.up == 0 && a.out != nullptr;
+                      (a.Cout & 31) == 0 && a.up == 0 && a.out != nullptr && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
@@ -448,47 +466,58 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             const bool epi_now = FAST && haveP && chunk == 0;
             const char* Ab = smem + pb * stage_bytes;
             const char* Wb = Ab + NHP * 1024 + lane * 16;
-            constexpr int LA = 2;                               // fragment reads run one tap ahead of the MFMAs
-            constexpr int PPT = (NPIECE + NT - 2) / (NT - 1);   // pieces per tap: all requested by tap 7
-            i32x4_t fa[LA][CF], fb[LA][PF];
-            auto ldfragW = [&](int t, int buf) {
+            constexpr int NU = NT * KS;                               // MFMA units (tap, k-step) per chunk
+            constexpr int PPU = (NPIECE + NU - 2) / (NU - 1);         // DMA pieces per unit: all requested before the last one
+            i32x4_t fa[2][CF], fb[2][PF];                             // fragment reads run one unit ahead of the MFMAs
+            int plc[PF];
 #pragma unroll
-                for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const i32x4_t*>(Wb + (cf * NT + t) * 1024);
-            };
-            auto ldfragA = [&](int t, int buf) {
-                const int tapoff = ((t / 3) * RP + (t % 3)) * 16;
+            for (int pf = 0; pf < PF; ++pf) {
+                plc[pf] = pixoff[pf];
+                // opaque per chunk: otherwise hipcc hoists the 9 x PF swizzled tap addresses out of the chunk loop and spills
+                if (HC == 32) asm volatile("" : "+v"(plc[pf]));
+            }
+            auto ldfrag = [&](int u, int buf) {
+                const int t = u / KS, ks = u - t * KS;
 #pragma unroll
-                for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
+                for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const i32x4_t*>(Wb + ((cf * NT + t) * KS + ks) * 1024);
+                if constexpr (HC == 16) {
+                    const int tapoff = ((t / 3) * RP + (t % 3)) * 16;
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
+                } else {
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) {
+                        const int p = plc[pf] + (t / 3) * RP + (t % 3);
+                        const int sw = (p >> 2) & 3;
+                        fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + p * 64 + ((((ks << 1) | (lane >> 5)) ^ sw) << 4));
+                    }
+                }
             };
-            ldfragA(0, 0);
-            ldfragW(0, 0);
+            ldfrag(0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT && kDmaProbe != 5) {
-                    ldfragA(t + 1, (t + 1) & 1);
-                    ldfragW(t + 1, (t + 1) & 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of tap t+1 AHEAD of tap t's MFMAs
+            for (int u = 0; u < NU; ++u) {
+                if (u + 1 < NU && kDmaProbe != 5) ldfrag(u + 1, (u + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep the fragment reads of unit u+1 AHEAD of unit u's MFMAs
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf)
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) {
                         if (kDmaProbe == 3) continue;
                         if constexpr (I8) {
-                            acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[t & 1][cf], fb[t & 1][pf], acc[cf][pf], 0, 0, 0);
+                            acc[cf][pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u & 1][cf], fb[u & 1][pf], acc[cf][pf], 0, 0, 0);
                         } else {
-                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fa[t & 1][cf]),
-                                                                                 __builtin_bit_cast(h8_t, fb[t & 1][pf]), acc[cf][pf], 0, 0, 0);
+                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, fa[u & 1][cf]),
+                                                                                 __builtin_bit_cast(h8_t, fb[u & 1][pf]), acc[cf][pf], 0, 0, 0);
                         }
                     }
                 if (IL && issuing) {
 #pragma unroll
-                    for (int u = 0; u < PPT; ++u) issue_piece(t * PPT + u);
+                    for (int v = 0; v < PPU; ++v) issue_piece(u * PPU + v);
                 }
                 if constexpr (FAST) {
-                    if (t >= 1 && t - 1 < NUNIT) {
-                        if (epi_now) fast_unit(accP, t - 1);
+                    if (u % KS == KS - 1 && u / KS >= 1 && u / KS - 1 < NUNIT) {
+                        if (epi_now) fast_unit(accP, u / KS - 1);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -564,9 +593,9 @@ __global__ void dma_probe_kernel(const char* src, unsigned bytes, unsigned lds_o
     *reinterpret_cast<uint4*>(dst + lane * 16) = *reinterpret_cast<const uint4*>(smem + lds_off + lane * 16);
 }
 
-template <int CF, int PF, int NW, int WPS, int STG, int IL, bool I8>
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8>
 int launch_dma(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, I8>;
+    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -596,34 +625,33 @@ int launch_dma(const Launch& L, hipStream_t s) {
 }
 
 template <bool I8>
-int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, hipStream_t s) {
-    if (stg == 2 && il == 1) {
-        if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, I8>(L, s);
-        if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, I8>(L, s);
+int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, hipStream_t s) {
+    if (hc == 16 && stg == 2 && il == 1) {
+        if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, 16, I8>(L, s);
+        if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, 16, I8>(L, s);
     }
     if constexpr (!I8) {
-        if (stg == 2 && il == 1) {
-            if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 3, 2, 1, false>(L, s);
-            if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, false>(L, s);
-            if (cf == 2 && pf == 4 && nw == 4) return launch_dma<2, 4, 4, 2, 2, 1, false>(L, s);
+        if (hc == 16 && stg == 2 && il == 1) {
+            if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 3, 2, 1, 16, false>(L, s);
+            if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 16, false>(L, s);
         }
-        if (stg == 2 && il == 0 && cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 0, false>(L, s);
-        if (stg == 3 && il == 1) {
-            if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 3, 1, false>(L, s);
-            if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 3, 1, false>(L, s);
-            if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 1, 3, 1, false>(L, s);
+        if (hc == 32 && stg == 2 && il == 1) {
+            if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, false>(L, s);
+            if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 32, false>(L, s);
+            if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 2, 1, 32, false>(L, s);
+            if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 1, 2, 1, 32, false>(L, s);
         }
     }
-    y6_set_error("conv_dma: no instantiation c%dp%d x %d waves, %d stages, il %d", cf, pf, nw, stg, il);
+    y6_set_error("conv_dma: no instantiation c%dp%d x %d waves, %d stages, il %d, %d-channel chunks", cf, pf, nw, stg, il, hc);
     return Y6_EUNSUPPORTED;
 }
 
 }  // namespace
 
 // L points at conv_mfma.hip's launch record (same struct: conv_common.hpp)
-int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int i8, hipStream_t s) {
+int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int hc, int i8, hipStream_t s) {
     const Launch& l = *static_cast<const Launch*>(L);
-    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, s) : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, s);
+    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, hc, s) : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, hc, s);
 }
 
 int y6_conv_dma_halo_cap(int bp) { return bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 672 : 1216)); }

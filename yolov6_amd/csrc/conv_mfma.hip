@@ -1140,8 +1140,9 @@ const VariantCfg kVariants[] = {
     {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"},    // persist == 3: the streaming 1x1 kernel
     // persist == 4: LDS-DMA fed 3x3 stride-1 kernels (conv_dma.hip)
     // (depth = LDS stages; st = 1: requests interleaved with the MFMAs, 0: issued in a burst after the barrier)
-    {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4}, {2, 4, 4, "dma_c2p4", 4},
-    {2, 2, 4, "dmab_c2p2", 4, 0}, {2, 1, 4, "dma3_c2p1", 4, 1, 3}, {2, 2, 4, "dma83_c2p2", 8, 1, 3}, {2, 2, 4, "dma3_c2p2", 4, 1, 3}};
+    {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4},
+    // hc = 32: 32-channel chunks, four lanes of a request per pixel (16 cache lines per request instead of 64)
+    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 1, 4, "dmaw_c2p1", 4, 1, 2, 32}, {2, 2, 4, "dmaw_c2p2", 4, 1, 2, 32}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1260,8 +1261,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     if (vc.persist == 4) {
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
-        k.dma_nhp = y6_cdiv(2 * k.dma_pls, 64);
-        L->lds = vc.depth * (size_t)(k.dma_nhp + 9 * vc.cf) * 1024 + 4 * vc.cf * 32 * 4;   // stages of (halo planes + nine tap images), bias / scales x2
+        k.dma_nhp = y6_cdiv((vc.hc / 8) * k.dma_pls, 64);
+        L->lds = vc.depth * (size_t)(k.dma_nhp + 9 * vc.cf * (vc.hc / 16)) * 1024 + 4 * vc.cf * 32 * 4;   // stages of (halo planes + nine tap images), bias / scales x2
     } else if (vc.persist == 2)
         L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
     else if (vc.persist)
@@ -1525,7 +1526,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
-    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, 1, s);
+    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, 16, 1, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
         case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
@@ -1561,9 +1562,9 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
         if (st != 1 || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here, not a stride)
-        if (d->in.C % 16 || d->in.cstride % 8 || d->in.coff % 8) return 0;
+        if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
-        if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
+        if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;   // byte offsets + the range-check sentinel
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
@@ -1618,9 +1619,9 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
-                                      kVariants[variant].st, 0, s);
+                                      kVariants[variant].st, kVariants[variant].hc, 0, s);
     }
     return Y6_EINVAL;
 }
