@@ -10,7 +10,7 @@ include/yolov6_hip.h next to y6_conv_i8_desc):
   * the graph is the half-precision deploy graph (`Oracle(emulate_fp16=True)`: activations are fp16 tensors between ops);
   * quantised: every conv of backbone and neck EXCEPT the one that reads the image; fp16 as before: that first conv, the
     transposed convs, the whole detection head, the decode;
-  * weights      symmetric per output channel from the fp32 deploy weights:
+  * weights      symmetric per output channel from the deploy weights as the half-precision model holds them (fp16 values):
                  s_w[c] = max|w[c]| / 127,  w_q = clamp(rne(w / s_w[c]), -127, 127)
   * activations  symmetric per tensor, amax = largest |x| the conv's input saw during calibration:
                  a = fp16(amax), inv = fp16(127 / a),  x_q = clamp(rne(x * inv), -127, 127)
@@ -114,7 +114,8 @@ class Int8Oracle(Oracle):
             return super().conv_fused(x, w, b, stride, act, post)
         if self.amax is None or i >= len(self.amax):
             raise RuntimeError("Int8Oracle: call calibrate() (or set .amax) before forward()")
-        y, acc = int8_conv(self, x, w, b, stride, act, post, self.amax[i])
+        # the half-precision model holds fp16 weights and biases: they are what gets quantised (as the product does)
+        y, acc = int8_conv(self, x, self.q(w), None if b is None else self.q(b), stride, act, post, self.amax[i])
         self.stats.append(dict(acc_absmax=float(acc.abs().max())))
         return y
 

@@ -285,20 +285,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
     for (int j = 0; j < NPWW; ++j) npw += (wave + NW * j < WP) ? 1 : 0;
 
-    // ---- LDS offsets of this lane's pixels (whole loop) / output pixel indices (epilogue only)
+    // ---- this lane's pixels: position in the tile (fixed for the whole kernel: computed once, with the divisions), LDS
+    //      offsets of the fragment reads; per work item only the tile origin changes (scalar) - output offsets are one
+    //      multiply-add and two range checks per pixel
     const int fq = frag_pixel(lane & 31);
-    int pixoff[PF], cb = 0;
+    int pixoff[PF], ptytx[PF], cb = 0;   // ptytx: ty << 16 | tx, -1 for a lane beyond the tile
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wave * (PF * 32) + pf * 32 + fq;
+        const int npx = a.TH * a.TW;
+        const int mm = m < npx ? m : npx - 1;
+        const int ty = mm / a.TW, tx = mm - ty * a.TW;
+        pixoff[pf] = HC == 16 ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // HC 32: the pixel's linear index
+        ptytx[pf] = m < npx ? ((ty << 16) | tx) : -1;
+    }
     auto setup_pix = [&](int item) {
         int tile;
         decode(item, tile, cb);
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {
-            const int m = wave * (PF * 32) + pf * 32 + fq;
-            const int npx = a.TH * a.TW;
-            const int mm = m < npx ? m : npx - 1;
-            const int ty = mm / a.TW, tx = mm - ty * a.TW;
-            pixoff[pf] = HC == 16 ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // HC 32: the pixel's linear index
-        }
     };
     auto out_pix = [&](const ConvKArgs& a, int item, int (&opix)[PF]) {
         int tile = item;
@@ -308,16 +311,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
         const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
+        const int base = (b * a.Ho + oy0) * a.Wo + ox0;
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf) {
-            const int m = wave * (PF * 32) + pf * 32 + fq;
-            const int npx = a.TH * a.TW;
-            bool v = m < npx;
-            const int mm = v ? m : npx - 1;
-            const int ty = mm / a.TW, tx = mm - ty * a.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            v = v && (oy < a.Ho) && (ox < a.Wo);
-            opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
+            const int ty = ptytx[pf] >> 16, tx = ptytx[pf] & 0xffff;
+            const bool v = ptytx[pf] >= 0 && (oy0 + ty < a.Ho) && (ox0 + tx < a.Wo);
+            opix[pf] = v ? base + ty * a.Wo + tx : -1;
         }
     };
 
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         }
     };
     const bool fast = DEFER && a.pscale == nullptr && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && a.vec16_ok &&
-                      (a.Cout & 31) == 0 && a.up == 0 && a.out != nullptr && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
+                      (a.Cout % (CF * 32)) == 0 && a.up == 0 && a.out != nullptr && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
@@ -467,7 +466,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             const char* Ab = smem + pb * stage_bytes;
             const char* Wb = Ab + NHP * 1024 + lane * 16;
             constexpr int NU = NT * KS;                               // MFMA units (tap, k-step) per chunk
-            constexpr int PPU = (NPIECE + NU - 2) / (NU - 1);         // DMA pieces per unit: all requested before the last one
+            constexpr int PPU0 = (NPIECE + NU - 2) / (NU - 1);        // DMA pieces per unit: all requested before the last one,
+            constexpr int PPU = IL > PPU0 ? IL : PPU0;                // or IL per unit (front-loaded)
             i32x4_t fa[2][CF], fb[2][PF];                             // fragment reads run one unit ahead of the MFMAs
             int plc[PF];
 #pragma unroll
@@ -638,9 +638,8 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
         if (hc == 32 && stg == 2 && il == 1) {
             if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, false>(L, s);
             if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 32, false>(L, s);
-            if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 2, 1, 32, false>(L, s);
-            if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 1, 2, 1, 32, false>(L, s);
         }
+        if (hc == 32 && stg == 2 && il == 3 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 3, 32, false>(L, s);
     }
     y6_set_error("conv_dma: no instantiation c%dp%d x %d waves, %d stages, il %d, %d-channel chunks", cf, pf, nw, stg, il, hc);
     return Y6_EUNSUPPORTED;

@@ -1142,7 +1142,7 @@ const VariantCfg kVariants[] = {
     // (depth = LDS stages; st = 1: requests interleaved with the MFMAs, 0: issued in a burst after the barrier)
     {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4},
     // hc = 32: 32-channel chunks, four lanes of a request per pixel (16 cache lines per request instead of 64)
-    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 1, 4, "dmaw_c2p1", 4, 1, 2, 32}, {2, 2, 4, "dmaw_c2p2", 4, 1, 2, 32}};
+    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 2, 4, "dmaw8f_c2p2", 8, 3, 2, 32}};   // f: three requests per unit (front-loaded)
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1619,7 +1619,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, 0, s);
     }
