@@ -23,6 +23,7 @@ class OracleChain:
         self.cpu = {}        # buffer data_ptr -> oracle activation, NCHW fp32 [B, cstride, H, W]
         self.rows = []       # per op: dict(op, kind, desc, err, err_abs)
         self.final = None
+        self.i8_stats = []   # per int8 conv, plan order: accumulator abs-max (compared with Int8Oracle.stats)
 
     # ---------------------------------------------------------------- buffer bookkeeping
     def _get(self, ref):
@@ -62,7 +63,8 @@ class OracleChain:
             from oracle.int8_oracle import int8_conv
             b = None if e["b"] is None else e["b"].detach().float().cpu()
             post = None if e["post"] is None else tuple(t.detach().float().cpu() for t in e["post"])
-            y, _ = int8_conv(o, self._get(e["x"]), e["w"].detach().float().cpu(), b, e["stride"], e["act"], post, e["amax"])
+            y, acc = int8_conv(o, self._get(e["x"]), e["w"].detach().float().cpu(), b, e["stride"], e["act"], post, e["amax"])
+            self.i8_stats.append(dict(acc_absmax=float(acc.abs().max()), desc=_describe(e), amax=e["amax"]))
             if e["res"] is not None:
                 a = 1.0 if e["alpha"] is None else o.q(e["alpha"].detach().float().cpu())
                 y = o.q(y + o.q(a * self._get(e["res"])))

@@ -27,7 +27,7 @@ def _nchw(ref):
     return ref.to_nhwc_tensor().float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
-def _run_i8(x, w, b, stride, act, amax, post=None, variant=0, q_in=None, q_out=None, q_out_amax=0.0, want_out=True):
+def _run_i8(x, w, b, stride, act, amax, post=None, variant=0, q_in=None, q_out=None, q_out_amax=0.0, want_out=True, want_acc=True):
     """One y6_conv2d_i8 call; returns (out TRef or None, int32 accumulators [B,Cout,Ho,Wo])."""
     lib = _lib.load()
     pb = PlanBuilder(DEV)
@@ -60,7 +60,7 @@ def _run_i8(x, w, b, stride, act, amax, post=None, variant=0, q_in=None, q_out=N
     d.q_in = q_in.ct() if q_in is not None else _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
     d.q_out = q_out.ct() if q_out is not None else _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
     d.q_out_amax = float(q_out_amax)
-    d.acc_out = C.c_void_p(acc.data_ptr())
+    d.acc_out = C.c_void_p(acc.data_ptr()) if want_acc else None
     _lib.check(lib.y6_conv2d_i8(C.byref(d), None), "conv2d_i8")
     torch.cuda.synchronize()
     return (out if want_out else None), acc.cpu().permute(0, 3, 1, 2).contiguous()
@@ -163,12 +163,39 @@ def test_int8_twin_output_equals_quantise_on_load():
     assert torch.equal(only.buf.cpu().permute(0, 3, 1, 2), quantize_act(_nchw(o_a), 5.0).to(torch.int8))
 
 
-@pytest.mark.parametrize("variant", [7, 8])
+@pytest.mark.parametrize("variant", [8, 9])
+def test_conv_i8_dma_deferred_epilogue_equals_general(variant):
+    """Without the accumulator dump the LDS-DMA kernels take their fast path (epilogue of item k issued behind the MFMAs of
+    item k+1, buffer-descriptor stores): fp16 output and int8 twin must equal the general epilogue's, bit for bit, with and
+    without the kept post-BN affine, with and without an fp16 output."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(41)
+    for (B, H, W, Cin, Cout, act, with_post) in [(6, 80, 80, 64, 128, "relu", True), (9, 40, 40, 128, 64, None, False), (3, 23, 31, 64, 192, "relu", True)]:
+        x = rand_nhwc(B, H, W, Cin, seed=17, scale=3.0)
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.15
+        b = torch.randn((Cout,), generator=g)
+        post = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.2) if with_post else None
+        twin = _i8_buffer(B, H, W, Cin)
+        xt, qt = x.ct(), twin.ct()
+        _lib.check(lib.y6_quantize_i8(C.byref(xt), C.c_float(2.7), C.byref(qt), None), "quantize_i8")
+        qa, qb = _i8_buffer(B, H, W, Cout), _i8_buffer(B, H, W, Cout)
+        o_gen, _ = _run_i8(x, w, b, 1, act, 2.7, post=post, variant=variant, q_in=twin, q_out=qa, q_out_amax=4.2)
+        o_fast, _ = _run_i8(x, w, b, 1, act, 2.7, post=post, variant=variant, q_in=twin, q_out=qb, q_out_amax=4.2, want_acc=False)
+        assert torch.equal(o_gen.buf, o_fast.buf), f"fp16 outputs differ {(B, H, W, Cin, Cout)}"
+        assert torch.equal(qa.buf, qb.buf), "int8 twins differ"
+        qc = _i8_buffer(B, H, W, Cout)
+        _run_i8(x, w, b, 1, act, 2.7, post=post, variant=variant, q_in=twin, q_out=qc, q_out_amax=4.2, want_out=False, want_acc=False)
+        assert torch.equal(qa.buf, qc.buf), "int8-only output differs"
+
+
+@pytest.mark.parametrize("variant", [7, 8, 9])
 def test_conv_i8_dma_variants_bit_exact(variant):
     """The LDS-DMA int8 kernels (conv_dma.hip) read the producer's int8 twin: same accumulators / outputs as the oracle."""
     lib = _lib.load()
     g = torch.Generator().manual_seed(31)
-    for (B, H, W, Cin, Cout, act) in [(3, 40, 40, 64, 128, "relu"), (2, 21, 37, 32, 64, None), (5, 80, 80, 96, 72, "relu")]:
+    for (B, H, W, Cin, Cout, act) in [(3, 40, 40, 64, 128, "relu"), (2, 21, 37, 32, 64, None), (5, 80, 80, 96, 72, "relu"), (2, 30, 50, 128, 64, "relu")]:
+        if variant == 9 and Cin % 64:
+            continue
         x = rand_nhwc(B, H, W, Cin, seed=13, scale=4.0)
         w = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.2
         b = torch.randn((Cout,), generator=g)
@@ -204,8 +231,14 @@ def _qa_model(case="s_qa_tiny"):
     model = build_model(cfg, meta["num_classes"], "cpu").eval()
     model.load_state_dict(sd_train)
     switch_to_deploy(fuse_model(model))
-    sd = deploy_state_dict(cfg, sd_train, meta["num_classes"])
-    return cfg, meta, sd, model.to(DEV).half(), synth
+    model = model.to(DEV).half()
+    # the oracle gets the model's OWN deploy weights (the fp16 values the int8 path quantises): the oracle's re-parametrisation
+    # of sd_train can differ from the module's by one fp16 ulp in a few weights, which is invisible at fp16 tolerances but moves
+    # per-channel weight scales - and with them a few percent of the int8 weight codes by one step
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ref_sd = deploy_state_dict(cfg, sd_train, meta["num_classes"])
+    assert set(ref_sd.keys()) <= set(sd.keys())
+    return cfg, meta, sd, model, synth
 
 
 def test_int8_model_calibration_layers_and_end_to_end():
@@ -246,6 +279,11 @@ def test_int8_model_calibration_layers_and_end_to_end():
     with torch.no_grad():
         free = OracleChain(plan, orc)
         free.run(teacher_force=False)
+        for i, (c_, o_) in enumerate(zip(free.i8_stats, orc.stats)):
+            if c_["acc_absmax"] != o_["acc_absmax"]:
+                print(f"first int8 conv whose accumulators differ between the op-by-op walk and Int8Oracle.forward: #{i} {c_['desc']} "
+                      f"amax walk {c_['amax']} oracle {orc.amax[i]} acc {c_['acc_absmax']} vs {o_['acc_absmax']}")
+                break
         sync = float(((free.final - ref).abs() / ref.abs().clamp(min=1.0)).max())
         assert sync < 2e-3, f"op-by-op oracle walk deviates from Int8Oracle.forward by {sync:.3e}"
         rows = OracleChain(plan, orc).run(teacher_force=True)

@@ -93,6 +93,25 @@ def test_conv_dma_variants_full_tiles():
             assert err < TOL, f"{names[v]}: max rel err {err:.3e} on {(Cin, Cout, H, W, B)}"
 
 
+def test_conv_dma_fast_epilogue_with_post_affine():
+    """conv + bias + kept post-BN affine + ReLU without a residual (the QARepVGG deploy block): the dma variants' deferred
+    fast epilogue against the fp32 statement, several items per block."""
+    names = G.variant_names()
+    B, H, W, Cin, Cout = 6, 80, 80, 64, 128
+    x = G.rand_nhwc(B, H, W, Cin, seed=31)
+    w, b = _mk_weights(Cout, Cin, 3, 32)
+    g = torch.Generator().manual_seed(33)
+    post = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1)
+    for act in ("relu", None):
+        ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, 1, act, post)
+        for v, n in enumerate(names):
+            if not n.startswith("dma") or not G.supports(x, w, 1, v):
+                continue
+            o, _ = G.run_conv(x, w, b, 1, act, v, post=post)
+            err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+            assert err < 2.01 * 2.0 ** -10, f"{n}/{act}: {err:.3e}"   # two fp16 roundings (conv output, affine output)
+
+
 def test_conv_mfma_layout_is_not_transposed():
     """Asymmetric weights: output channel c copies input channel (c+1)%C of the centre tap only."""
     C_, H, W = 64, 16, 16

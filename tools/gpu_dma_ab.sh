@@ -10,7 +10,7 @@ timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_int8.py -q --t
   -k "dma or conv_all_variants or tap_geometry or layout or epilogue_variants or i8 or int8" > "$OUT/pytest.log" 2>&1
 echo "pytest rc=$?"; tail -30 "$OUT/pytest.log"
 rm -f "$OUT/autotune.log"
-Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 600 python bench.py --steps 100 --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
+Y6_AUTOTUNE_LOG="$OUT/autotune.log" timeout 600 python bench.py --steps 200 --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/bench_ops.json" > "$OUT/bench.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"; tail -3 "$OUT/bench.err"; cut -c1-300 "$OUT/bench.json"; python - <<PY
 import json
 d=json.load(open("$OUT/bench.json"))

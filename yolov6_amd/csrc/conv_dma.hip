@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     const int RP = a.dma_rp, PLs = a.dma_pls, NHP = a.dma_nhp;
     const int stage_bytes = (NHP + WP) * 1024;
     const unsigned smem_base = lds_addr(smem);
-    float* ldsBias = reinterpret_cast<float*>(smem + STG * stage_bytes);   // [2][CF*32] bias, then [2][CF*32] dequant scales (int8)
+    float* ldsBias = reinterpret_cast<float*>(smem + STG * stage_bytes);   // [item parity][bias | post scale | post shift | dequant scale][CF*32]
     const int nch = a.Cin / (I8 ? 2 * HC : HC);
     const int nids = a.nids;
     const int gstride = gridDim.x;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     // an item's time at Cin 128 and 33 % at Cin 64 with the matrix pipe waiting, tools/dma_trace.py).  Stores go through a
     // buffer descriptor: 32-bit byte offsets, overhang pixels dropped by the range check.  Needs 2 x CF*PF*16 accumulator
     // registers: variants with at most three waves per SIMD.
-    constexpr bool DEFER = WPS <= 3 && !I8 && CF * PF <= 4;
+    constexpr bool DEFER = WPS <= 3 && CF * PF <= 4;
     constexpr int NUNIT = CF * PF;
     static_assert(!DEFER || NUNIT <= NT - 1, "one deferred epilogue unit per tap 1..8");
     auto epi_unit = [&](const ConvKArgs& ea, const acc_t (&accP)[CF][PF], const int (&opx)[PF], int cbq, const float* lb, int u) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             BiasRegs<1> qs;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(lb + 2 * CF * 32 + cf * 32 + 8 * g + 4 * (lane >> 5));
+                const float4 t = *reinterpret_cast<const float4*>(lb + 3 * CF * 32 + cf * 32 + 8 * g + 4 * (lane >> 5));
                 qs.v[0][g * 4 + 0] = t.x;
                 qs.v[0][g * 4 + 1] = t.y;
                 qs.v[0][g * 4 + 2] = t.z;
@@ -379,46 +379,86 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&accP[cf][pf]), op1, cbq * CF + cf, 0, lane, bz);
         }
     };
-    const bool fast = DEFER && a.pscale == nullptr && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && a.vec16_ok &&
-                      (a.Cout % (CF * 32)) == 0 && a.up == 0 && a.out != nullptr && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
+    // fast path: bias (+ int8 dequantisation) (+ QARepVGG post-affine) + ReLU / identity, no residual, whole cout blocks,
+    // 16-byte aligned fp16 view and / or 4-byte aligned int8 twin
+    const bool has_out = a.out != nullptr, has_post = a.pscale != nullptr;
+    const bool has_qout = I8 && a.qout != nullptr;
+    const bool fast = DEFER && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && (a.Cout % (CF * 32)) == 0 && a.up == 0 &&
+                      (has_out || has_qout) && (!has_out || a.vec16_ok) && (!has_qout || ((a.qout_cs | a.qout_co) & 3) == 0) &&
+                      (!I8 || a.acc_out == nullptr) && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
-    unsigned obyteP[PF];   // byte offset of the lane's output pixels of the PREVIOUS item (kOob: none)
-    unsigned ocolP = 0;    // + byte offset of its cout block and of this lane's 8-channel piece
+    const __amdgpu_buffer_rsrc_t rsQ =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.qout, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * (I8 ? a.qout_cs : 0)), 0x00020000);
+    unsigned obyteP[PF];   // byte offset of the lane's output pixels of the PREVIOUS item in the fp16 view (kOob: none)
+    unsigned qbyteP[PF];   // ... in the int8 twin
+    unsigned ocolP = 0;    // + channel offset of its cout block and of this lane's piece (in channels)
     const float* lbP = ldsBias;
     bool haveP = false;
     auto fast_unit = [&](const acc_t (&accP)[CF][PF], int u) {
-        if constexpr (!I8) {
-            const int cf = u / PF, pf = u - cf * PF;
-            float v[16];
+        const int cf = u / PF, pf = u - cf * PF;
+        const int kh = lane >> 5;
+        float v[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(lbP + cf * 32 + 8 * g + 4 * (lane >> 5));
-                v[g * 4 + 0] = fmaxf(accP[cf][pf][g * 4 + 0] + t.x, fast_lo);
-                v[g * 4 + 1] = fmaxf(accP[cf][pf][g * 4 + 1] + t.y, fast_lo);
-                v[g * 4 + 2] = fmaxf(accP[cf][pf][g * 4 + 2] + t.z, fast_lo);
-                v[g * 4 + 3] = fmaxf(accP[cf][pf][g * 4 + 3] + t.w, fast_lo);
+        for (int g = 0; g < 4; ++g) {
+            const float4 bz = *reinterpret_cast<const float4*>(lbP + cf * 32 + 8 * g + 4 * kh);
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = (float)accP[cf][pf][g * 4 + j];
+            if constexpr (I8) {   // exact int32 -> fp32, * s_x*s_w[c] as a rounding of its own (include/yolov6_hip.h)
+                const float4 qs = *reinterpret_cast<const float4*>(lbP + 3 * CF * 32 + cf * 32 + 8 * g + 4 * kh);
+                x[0] *= qs.x;
+                x[1] *= qs.y;
+                x[2] *= qs.z;
+                x[3] *= qs.w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(x[j]));
             }
-            if (kDmaProbe == 2) return;
-            unsigned pk[4][2];
+            x[0] += bz.x;
+            x[1] += bz.y;
+            x[2] += bz.z;
+            x[3] += bz.w;
+            if (has_post) {   // QARepVGG: conv -> BatchNorm are two fp16 ops (finish16 in conv_common.hpp)
+                const float4 ps = *reinterpret_cast<const float4*>(lbP + CF * 32 + cf * 32 + 8 * g + 4 * kh);
+                const float4 pt = *reinterpret_cast<const float4*>(lbP + 2 * CF * 32 + cf * 32 + 8 * g + 4 * kh);
+                x[0] = y6_round_f16(x[0]) * ps.x + pt.x;
+                x[1] = y6_round_f16(x[1]) * ps.y + pt.y;
+                x[2] = y6_round_f16(x[2]) * ps.z + pt.z;
+                x[3] = y6_round_f16(x[3]) * ps.w + pt.w;
+            }
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
+        }
+        if (kDmaProbe == 2) return;
+        unsigned pk[4][2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                    h2_t t;
-                    t[0] = (_Float16)v[g * 4 + h * 2];
-                    t[1] = (_Float16)v[g * 4 + h * 2 + 1];
-                    pk[g][h] = __builtin_bit_cast(unsigned, t);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                h2_t t;
+                t[0] = (_Float16)v[g * 4 + h * 2];
+                t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                pk[g][h] = __builtin_bit_cast(unsigned, t);
+            }
+        if constexpr (I8) {
+            if (has_qout) {   // the int8 twin for quantised consumers: the SAME fp16 values, quantised with their scale
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned q = q8_quad(pk[g][0], pk[g][1], a.qo_inv2, a.qo_lo2, a.qo_hi2);
+                    __builtin_amdgcn_raw_buffer_store_b32(q, rsQ, (int)(qbyteP[pf] + ocolP + (unsigned)(cf * 32 + 8 * g - 4 * kh)), 0, 0);
                 }
+            }
+        }
+        if (has_out) {
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
                 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                 const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyteP[pf] + ocolP + (unsigned)((cf * 32 + 16 * gp) * 2)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyteP[pf] + (ocolP + (unsigned)(cf * 32 + 16 * gp)) * 2), 0, 0);
             }
         }
     };
@@ -433,11 +473,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0;
-        float* lbias = ldsBias + (item_parity ? CF * 32 : 0);
+        float* lbias = ldsBias + (item_parity ? 4 * CF * 32 : 0);
         if (tid < CF * 32) {
             const int c = cb * CF * 32 + tid;
             lbias[tid] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
-            if (I8) lbias[2 * CF * 32 + tid] = (c < a.Cout) ? a.qscale[c] : 0.f;
+            if (a.pscale != nullptr) {
+                lbias[CF * 32 + tid] = c < a.Cout ? a.pscale[c] : 0.f;
+                lbias[2 * CF * 32 + tid] = c < a.Cout ? a.pshift[c] : 0.f;
+            }
+            if (I8) lbias[3 * CF * 32 + tid] = (c < a.Cout) ? a.qscale[c] : 0.f;
         }
         const int nid = next_valid(id);
         for (int chunk = 0; chunk < nch; ++chunk) {
@@ -532,8 +576,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             int opix[PF];
             out_pix(a, id, opix);
 #pragma unroll
-            for (int pf = 0; pf < PF; ++pf) obyteP[pf] = opix[pf] >= 0 ? (unsigned)((opix[pf] * a.out_cs + a.out_co) * 2) : kOob;
-            ocolP = (unsigned)((cb * CF * 32 + 8 * (lane >> 5)) * 2);
+            for (int pf = 0; pf < PF; ++pf) {
+                obyteP[pf] = opix[pf] >= 0 ? (unsigned)((opix[pf] * a.out_cs + a.out_co) * 2) : kOob;
+                qbyteP[pf] = (I8 && opix[pf] >= 0) ? (unsigned)(opix[pf] * a.qout_cs + a.qout_co) : kOob;
+            }
+            ocolP = (unsigned)(cb * CF * 32 + 8 * (lane >> 5));
             lbP = lbias;
             haveP = true;
         } else {
@@ -630,13 +677,13 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
         if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, 16, I8>(L, s);
         if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, 16, I8>(L, s);
     }
+    if (hc == 32 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, I8>(L, s);
     if constexpr (!I8) {
         if (hc == 16 && stg == 2 && il == 1) {
             if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 3, 2, 1, 16, false>(L, s);
             if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 16, false>(L, s);
         }
         if (hc == 32 && stg == 2 && il == 1) {
-            if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, false>(L, s);
             if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 32, false>(L, s);
         }
         if (hc == 32 && stg == 2 && il == 3 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 3, 32, false>(L, s);

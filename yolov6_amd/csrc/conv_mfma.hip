@@ -1262,7 +1262,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
         k.dma_nhp = y6_cdiv((vc.hc / 8) * k.dma_pls, 64);
-        L->lds = vc.depth * (size_t)(k.dma_nhp + 9 * vc.cf * (vc.hc / 16)) * 1024 + 4 * vc.cf * 32 * 4;   // stages of (halo planes + nine tap images), bias / scales x2
+        L->lds = vc.depth * (size_t)(k.dma_nhp + 9 * vc.cf * (vc.hc / 16)) * 1024 + 8 * vc.cf * 32 * 4;   // stages of (halo + tap images), per-channel vectors [2 parities][bias | post scale | post shift | dequant]
     } else if (vc.persist == 2)
         L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
     else if (vc.persist)
@@ -1459,13 +1459,14 @@ int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 
 int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     const y6_conv_desc* d = &q->conv;
-    if (d->variant >= 1 && d->variant <= 8) return d->variant;
+    if (d->variant >= 1 && d->variant <= 9) return d->variant;
     const int co = d->out.data ? d->out.C : q->q_out.C;
     static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
-    // 7 / 8: the LDS-DMA kernels (conv_dma.hip) - need the producer's int8 twin and whole 32-channel chunks
+    // 7 / 8 / 9: the LDS-DMA kernels (conv_dma.hip) - need the producer's int8 twin and whole 32- (9: 64-) channel chunks
     if (!no_dma && d->ksize == 3 && d->stride == 1 && q->q_in.data && q->q_in.C % 32 == 0 && co >= 64) {
         const long npix = (long)q->q_in.B * q->q_in.H * q->q_in.W;
-        return npix * y6_cdiv(co, 64) >= 512L * 256 ? 7 : 8;       // enough 512-pixel items for every CU, else 256-pixel tiles
+        if (q->q_in.C % 64 == 0 && npix * y6_cdiv(co, 64) >= 512L * 128) return 9;   // 512-pixel blocks, 64-channel chunks
+        return 8;                                                                  // 256-pixel blocks
     }
     if (d->ksize == 3 && d->stride == 1) return co >= 64 ? 5 : 4;            // c2p2 / c1p2
     return co >= 256 ? 3 : (co >= 64 ? 2 : 1);                                // c4p1 / c2p1 / c1p1
@@ -1507,7 +1508,8 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         Y6_REQUIRE(d.ksize == 3 && d.stride == 1 && has_qin && q->q_in.C % 32 == 0, "conv_i8: the LDS-DMA variants need k3 s1, an int8 input view and Cin %% 32 == 0");
     Y6_REQUIRE(dma || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
     Launch L;
-    const int kv = dma ? (variant == 7 ? 24 : 25) : variant;   // kVariants row that sizes the tile
+    const int kv = dma ? (variant == 7 ? 24 : (variant == 8 ? 25 : 28)) : variant;   // kVariants row that sizes the tile
+    if (variant == 9) Y6_REQUIRE(q->q_in.C % 64 == 0, "conv_i8: variant 9 needs Cin %% 64 == 0");
     int rc = build_launch(&d, kv, 0, 0, 0, &L);
     if (rc) return rc;
     ConvKArgs& k = L.k;
@@ -1526,7 +1528,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
-    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, 16, 1, s);
+    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
         case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
