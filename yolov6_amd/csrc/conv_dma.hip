@@ -379,14 +379,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&accP[cf][pf]), op1, cbq * CF + cf, 0, lane, bz);
         }
     };
-    // fast path: bias (+ int8 dequantisation) (+ QARepVGG post-affine) + ReLU / identity, no residual, whole cout blocks,
+    // fast path: bias (+ int8 dequantisation) (+ QARepVGG post-affine) + activation, no residual, whole cout blocks,
     // 16-byte aligned fp16 view and / or 4-byte aligned int8 twin
     const bool has_out = a.out != nullptr, has_post = a.pscale != nullptr;
     const bool has_qout = I8 && a.qout != nullptr;
-    const bool fast = DEFER && a.res == nullptr && (a.act == Y6_ACT_RELU || a.act == Y6_ACT_NONE) && (a.Cout % (CF * 32)) == 0 && a.up == 0 &&
+    const bool fast = DEFER && a.res == nullptr && (a.Cout % (CF * 32)) == 0 && a.up == 0 &&
                       (has_out || has_qout) && (!has_out || a.vec16_ok) && (!has_qout || ((a.qout_cs | a.qout_co) & 3) == 0) &&
                       (!I8 || a.acc_out == nullptr) && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
+    const bool smooth_act = a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH;
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsQ =
@@ -427,8 +428,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                 x[2] = y6_round_f16(x[2]) * ps.z + pt.z;
                 x[3] = y6_round_f16(x[3]) * ps.w + pt.w;
             }
+            if (smooth_act) {   // SiLU / hardswish: one wave-uniform branch per group, the arithmetic of act_const<>
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
+                for (int j = 0; j < 4; ++j) v[g * 4 + j] = a.act == Y6_ACT_SILU ? act_const<Y6_ACT_SILU>(x[j]) : act_const<Y6_ACT_HARDSWISH>(x[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
+            }
         }
         if (kDmaProbe == 2) return;
         unsigned pk[4][2];

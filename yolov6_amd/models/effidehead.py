@@ -62,6 +62,30 @@ class Detect(HipModule):
                              f"detect.cls_logit{i}": cls_out[-1], f"detect.reg_raw{i}": reg_out[-1]})
         return stems, tb.head_pack(cls_out, reg_out, self.nc, self.reg_preds[0].out_channels)
 
+    def _lower_cls_reg_convs(self, pb, i, f):
+        """cls_conv and reg_conv of one level (effidehead.py:95-99) read the same stem output with the same geometry and
+        activation: ONE launch over the concatenated output channels (twice the work items per launch on the small maps,
+        three launches fewer per forward); the two results are channel slices of one buffer."""
+        cc, rc = getattr(self.cls_convs[i], "block", None), getattr(self.reg_convs[i], "block", None)
+        same = (cc is not None and rc is not None and hasattr(cc, "fused_weight_bias") and hasattr(rc, "fused_weight_bias")
+                and cc.conv.kernel_size == rc.conv.kernel_size == (3, 3) and cc.conv.stride == rc.conv.stride == (1, 1)
+                and cc.conv.padding == rc.conv.padding == (1, 1) and cc.conv.groups == rc.conv.groups == 1
+                and cc.conv.dilation == rc.conv.dilation == (1, 1) and cc.conv.in_channels == rc.conv.in_channels
+                and cc._activation_name() == rc._activation_name() and cc.conv.out_channels % 8 == 0)
+        if not same:
+            return self.cls_convs[i].lower(pb, f), self.reg_convs[i].lower(pb, f)
+        (wc, bc), (wr, br) = cc.fused_weight_bias(), rc.fused_weight_bias()
+        nc_, nr_ = wc.shape[0], wr.shape[0]
+        zeros = lambda n, ref: torch.zeros(n, dtype=torch.float32, device=ref.device)
+        bc = zeros(nc_, wc) if bc is None else bc
+        br = zeros(nr_, wr) if br is None else br
+        w = torch.cat([wc.float(), wr.float()], 0)
+        b = torch.cat([bc.float(), br.float()], 0)
+        f = pb.as_nhwc(f)
+        both = pb.new_buffer(f.B, f.H, f.W, nc_ + nr_)
+        pb.conv(f, w, b, stride=1, act=cc._activation_name(), out=both)
+        return both.slice(0, nc_), both.slice(nc_, nr_)
+
     def lower(self, pb, x, out=None):
         if self.training:
             raise NotImplementedError("yolov6_amd: Detect's training branch runs through Model.forward in train mode "
@@ -72,10 +96,9 @@ class Detect(HipModule):
         with pb.no_quant():        # the head stays fp16 under an int8 lowering (yolov6_amd/quant.py)
             for i in range(self.nl):
                 f = self.stems[i].lower(pb, x[i])
-                c = self.cls_convs[i].lower(pb, f)
+                c, r = self._lower_cls_reg_convs(pb, i, f)
                 cp = self.cls_preds[i]
                 cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
-                r = self.reg_convs[i].lower(pb, f)
                 rp = self.reg_preds[i]
                 reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
         use_dfl = bool(self.use_dfl)
