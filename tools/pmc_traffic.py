@@ -10,6 +10,8 @@ out = sys.argv[1]
 def classify(name):
     if "conv1x1_stream_kernel" in name:
         return "conv1x1s1"
+    if "conv3x3_dma_kernel" in name:     # conv_dma.hip: 3x3 stride 1 only
+        return "conv3x3s1"
     m = re.search(r"conv_mfma_pipe_kernel<\d+, \d+, \d+, \d+, (\d)", name)
     if m:
         return "conv3x3s%s" % m.group(1)

@@ -623,7 +623,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // built, tested and selectable: Y6_AUTOTUNE_EXCLUDE="" allows all, "15,16" excludes just those.
     std::vector<char> excluded(nv, 0);
     const char* ex = getenv("Y6_AUTOTUNE_EXCLUDE");
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21";
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,30";   // 24 / 30: dma8_c2p2 (4 waves per SIMD) and the front-loaded request form never won
     {
         for (const char* c = ex; *c;) {
             char* end = nullptr;
