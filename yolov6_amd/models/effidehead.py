@@ -6,6 +6,7 @@ as five fused conv kernels, then ONE decode kernel for all levels (sigmoid, DFL,
 x stride, concat) that writes the reference's [B, A, 5+nc] fp32 tensor directly.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -72,7 +73,7 @@ class Detect(HipModule):
                 and cc.conv.padding == rc.conv.padding == (1, 1) and cc.conv.groups == rc.conv.groups == 1
                 and cc.conv.dilation == rc.conv.dilation == (1, 1) and cc.conv.in_channels == rc.conv.in_channels
                 and cc._activation_name() == rc._activation_name() and cc.conv.out_channels % 8 == 0)
-        if not same:
+        if not same or os.environ.get("Y6_HEAD_NO_MERGE"):      # (A/B switch)
             return self.cls_convs[i].lower(pb, f), self.reg_convs[i].lower(pb, f)
         (wc, bc), (wr, br) = cc.fused_weight_bias(), rc.fused_weight_bias()
         nc_, nr_ = wc.shape[0], wr.shape[0]
