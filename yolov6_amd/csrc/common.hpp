@@ -68,7 +68,7 @@ __device__ __forceinline__ float y6_div_tame(float n, float d) {
 __device__ __forceinline__ float y6_act(float v, int act) {
     switch (act) {
         case Y6_ACT_RELU: return v > 0.f ? v : 0.f;
-        case Y6_ACT_SILU: v = y6_round_f16(v); return y6_div_tame(v, 1.f + __expf(-v));
+        case Y6_ACT_SILU: v = y6_round_f16(v); return y6_div_tame(v, 1.f + __expf(fminf(-v, 80.f)))   /* exp stays finite: v / inf = -0 either way after the fp16 rounding */;
         case Y6_ACT_HARDSWISH: {
             v = y6_round_f16(v);
             float r = v + 3.f;

@@ -89,7 +89,7 @@ __device__ __forceinline__ float act_const(float v) {
     if constexpr (ACT == Y6_ACT_RELU) return v > 0.f ? v : 0.f;
     if constexpr (ACT == Y6_ACT_SILU) {
         v = y6_round_f16(v);            // the conv output is an fp16 tensor in the reference (common.hpp)
-        return y6_div_tame(v, 1.f + __expf(-v));
+        return y6_div_tame(v, 1.f + __expf(fminf(-v, 80.f)))   /* exp stays finite: v / inf = -0 either way after the fp16 rounding */;
     }
     if constexpr (ACT == Y6_ACT_HARDSWISH) {
         v = y6_round_f16(v);
