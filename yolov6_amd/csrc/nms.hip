@@ -218,7 +218,10 @@ constexpr int kBatch = 256;       // candidates settled per round of the sweep (
 constexpr int kWin = 1024;        // sweep window: sorted candidates resident in LDS at a time (one per thread)
 constexpr int kKeptCap = 8192;    // most kept boxes LDS can hold next to the window (160 KiB per CU): the max_det limit
 // LDS of the sweep for a given kept-box capacity (max_det rounded up to 256): window boxes + kept boxes + alive words
-static inline size_t sweep_lds(int kept_cap) { return (size_t)(kWin + kept_cap) * 16 + (kWin / 64) * 8; }
+// (+ with class chains: class per window candidate, next-of-same-class link per kept box, chain head per class)
+static inline size_t sweep_lds(int kept_cap, int nheads) {
+    return (size_t)(kWin + kept_cap) * 16 + (kWin / 64) * 8 + (nheads > 0 ? (size_t)(kWin + kept_cap + nheads) * 4 : 0);
+}
 
 __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
     // torchvision devIoU / cpu kernel arithmetic, fp32, unfused
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void nms_merge_rank_kernel(const u64* __restri
 // before max_det boxes are kept.
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict__ pred, int A, int nc,
                                                          float iou_thres, int agnostic, int max_det, int max_nms, int kept_cap,
-                                                         float max_wh, const u64* __restrict__ sorted,
+                                                         int nheads, float max_wh, const u64* __restrict__ sorted,
                                                          const int* __restrict__ counts,
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
                                                               int* __restrict__ out_count) {
@@ -388,6 +391,16 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     float4* wbox = reinterpret_cast<float4*>(smem);
     float4* kbox = wbox + kWin;
     u64* walive = reinterpret_cast<u64*>(kbox + kept_cap);
+    // Class chains (nheads > 0).  With the class offset of nms.py:94-95 only boxes of ONE class can overlap, so a
+    // candidate is tested against the kept boxes of its class only: every kept box carries the index of the previously
+    // kept box of its class, khead[c] is the newest.  Testing all 1024 window candidates against all (up to 300) kept
+    // boxes was the sweep's floor: 300 k box tests on one CU = 36 us of VALU issue; with 80 classes it is 1/80 of that.
+    int* wcls = reinterpret_cast<int*>(walive + kWin / 64);
+    int* knext = wcls + kWin;
+    int* khead = knext + kept_cap;
+    const bool chains = nheads > 0;
+    if (chains)
+        for (int c = tid; c < nheads; c += T) khead[c] = -1;
     int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids at the end
     const int no = nc + 5;
     int kept = 0;
@@ -407,6 +420,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             q.z = (x + w / 2.f) + off;
             q.w = (y + h / 2.f) + off;
             wbox[t] = q;
+            if (chains) wcls[t] = agnostic ? 0 : (int)cls;
         }
         __syncthreads();
         // survivors of the boxes kept in earlier windows
@@ -416,11 +430,19 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             bool alive = t < wn;
             if (alive) {
                 const float4 bj = wbox[t];
-                for (int k = 0; k < kept; ++k)
-                    if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                        alive = false;
-                        break;
-                    }
+                if (chains) {
+                    for (int k = khead[wcls[t]]; k >= 0; k = knext[k])
+                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                            alive = false;
+                            break;
+                        }
+                } else {
+                    for (int k = 0; k < kept; ++k)
+                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                            alive = false;
+                            break;
+                        }
+                }
             }
             const u64 bal = __ballot(alive);
             if (lane == 0) walive[r * 16 + wave] = bal;   // bit (t & 63) of word (t >> 6)
@@ -529,6 +551,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                             const int kp = kept + before[q] + __popcll(kv[q] & ((1ull << lane) - 1ull));
                             kbox[kp] = wbox[idx];
                             kept_pos[kp] = pos + idx;
+                            if (chains) knext[kp] = atomicExch(&khead[wcls[idx]], kp);   // newest first; this round's boxes all have kp >= k0
                         }
                         atomicAnd(&walive[idx >> 6], ~(1ull << (idx & 63)));   // decided either way
                     }
@@ -548,11 +571,19 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                 const int t = tid + r * 1024;
                 if (t > last && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
                     const float4 bj = wbox[t];
-                    for (int k = k0; k < kept; ++k)
-                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                            atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
-                            break;
-                        }
+                    if (chains) {
+                        for (int k = khead[wcls[t]]; k >= k0; k = knext[k])   // the chain is newest-first: stop at the older rounds
+                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                                atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                                break;
+                            }
+                    } else {
+                        for (int k = k0; k < kept; ++k)
+                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                                atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                                break;
+                            }
+                    }
                 }
             }
             __syncthreads();
@@ -658,14 +689,16 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     // kept boxes live in LDS: capacity = max_det rounded up to 256 (2048 boxes = 48 KiB as before; 8192 = 148 KiB, one block per CU)
     int kept_cap = (d->max_det + 255) / 256 * 256;
     if (kept_cap < 2048) kept_cap = 2048;
-    const size_t lds = sweep_lds(kept_cap);
+    int nheads = d->agnostic ? 1 : d->nc;
+    if (nheads > 4096 || sweep_lds(kept_cap, nheads) + 16 * 1024 > 160 * 1024) nheads = 0;   // no room (max_det in the thousands): linear scans
+    const size_t lds = sweep_lds(kept_cap, nheads);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         Y6_HIP(hipFuncSetAttribute((const void*)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
-                       d->max_det, d->max_nms, kept_cap, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
+                       d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
