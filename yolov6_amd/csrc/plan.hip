@@ -623,7 +623,12 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // built, tested and selectable: Y6_AUTOTUNE_EXCLUDE="" allows all, "15,16" excludes just those.
     std::vector<char> excluded(nv, 0);
     const char* ex = getenv("Y6_AUTOTUNE_EXCLUDE");
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,30";   // 24 / 30: dma8_c2p2 (4 waves per SIMD) and the front-loaded request form never won
+    // 24 / 30 (dma8_c2p2 at 4 waves per SIMD, the front-loaded request form) never won.  28 / 29 (32-channel chunks, one
+    // 157 KB block per CU) are the fastest 3x3 kernels on a warm chip (-5 % on the 60-GFLOP layers) but on most boxes of
+    // this pool their FIRST launch after a memory-bound op costs +25-50 us (r02b: 118 us for a 69 us layer), which eats
+    // the gain; the 16-channel-chunk forms (two / three blocks per CU, < 64 KB of LDS per block) do not show it
+    // (same-box A/B tools/gpu_ab_firstop.sh: 11.0 k img/s without them, 10.8 k with).
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30";
     {
         for (const char* c = ex; *c;) {
             char* end = nullptr;
