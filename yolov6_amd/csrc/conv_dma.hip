@@ -75,6 +75,12 @@ __device__ __forceinline__ ConvKArgs reload_args() {
 #endif
 constexpr int kDmaProbe = Y6_DMA_PROBE;
 
+// A/B switch (tools/build_probe_libs.py --dma-planar): 1 = the 16-channel-chunk kernels keep the first cut's planar halo image
+// (one cache line per lane of a request) instead of the pixel-major swizzled one (two lanes per pixel)
+#ifndef Y6_DMA_PLANAR16
+#define Y6_DMA_PLANAR16 0
+#endif
+
 constexpr unsigned kOob = 0xf0000000u;   // voffset of a piece that must read zeros / a store that must be dropped (tensors stay below 3.5 GiB)
 
 // lane (0..31) -> pixel of the fragment it holds (see the header comment)
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     constexpr int KS = HC / 16;                                   // MFMA k-steps per chunk and tap
     constexpr int SPP = HC / 8;                                   // 16-byte pieces per halo pixel and chunk
     constexpr int JB = HC == 16 ? 1 : 2;                          // bits of the piece index
+    constexpr bool PLANAR = HC == 16 && Y6_DMA_PLANAR16 != 0;     // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
     constexpr int WP = CF * NT * KS;                              // weight pieces (1 KiB) per chunk
     constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32>::value * SPP + 63) / 64;
     constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
@@ -203,12 +210,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int P = wave + NW * i;
         const int s = P * 64 + lane;
         int r, j;   // halo pixel (linear) and piece of LDS slot s
-        if (HC == 16) {
+        if (PLANAR) {
             j = s >= PLs ? 1 : 0;
             r = s - j * PLs;
         } else {
-            r = s >> 2;
-            j = (s & 3) ^ ((r >> 2) & 3);
+            r = s >> JB;
+            j = (s & (SPP - 1)) ^ ((r >> (4 - JB)) & (SPP - 1));
         }
         const int hy = r / RP, hx = r - hy * RP;
         const bool v = (P < NHP) && (s < SPP * PLs) && (hx < a.HWd);
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int npx = a.TH * a.TW;
         const int mm = m < npx ? m : npx - 1;
         const int ty = mm / a.TW, tx = mm - ty * a.TW;
-        pixoff[pf] = HC == 16 ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // HC 32: the pixel's linear index
+        pixoff[pf] = PLANAR ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // pixel-major: the pixel's linear index
         ptytx[pf] = m < npx ? ((ty << 16) | tx) : -1;
     }
     auto setup_pix = [&](int item) {
@@ -524,13 +531,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             for (int pf = 0; pf < PF; ++pf) {
                 plc[pf] = pixoff[pf];
                 // opaque per chunk: otherwise hipcc hoists the 9 x PF swizzled tap addresses out of the chunk loop and spills
-                if (HC == 32) asm volatile("" : "+v"(plc[pf]));
+                if (!PLANAR) asm volatile("" : "+v"(plc[pf]));
             }
             auto ldfrag = [&](int u, int buf) {
                 const int t = u / KS, ks = u - t * KS;
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const i32x4_t*>(Wb + ((cf * NT + t) * KS + ks) * 1024);
-                if constexpr (HC == 16) {
+                if constexpr (PLANAR) {
                     const int tapoff = ((t / 3) * RP + (t % 3)) * 16;
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
@@ -538,8 +545,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) {
                         const int p = plc[pf] + (t / 3) * RP + (t % 3);
-                        const int sw = (p >> 2) & 3;
-                        fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + p * 64 + ((((ks << 1) | (lane >> 5)) ^ sw) << 4));
+                        const int sw = (p >> (4 - JB)) & (SPP - 1);
+                        fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + p * (SPP * 16) + ((((ks << 1) | (lane >> 5)) ^ sw) << 4));
                     }
                 }
             };
