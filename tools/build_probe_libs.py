@@ -36,11 +36,11 @@ def one_dma(n):
     return lib
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "--dma-planar":   # A/B: 16-channel-chunk kernels with the planar halo image
+if len(sys.argv) > 1 and sys.argv[1] == "--dma-pixmajor":   # A/B: 16-channel-chunk kernels with the pixel-major swizzled halo image (default build: planar)
     oth = [o for o in glob.glob(os.path.join(B.OBJ_DIR, "*.o")) if not os.path.basename(o).startswith("conv_dma.")]
-    obj = os.path.join(out, "conv_dma_planar.o")
-    lib = os.path.join(out, "libyolov6_hip_dmaplanar.so")
-    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_dma.hip"] + ["-DY6_DMA_PLANAR16=1", "-c", os.path.join(B.HERE, "conv_dma.hip"), "-o", obj],
+    obj = os.path.join(out, "conv_dma_pixmajor.o")
+    lib = os.path.join(out, "libyolov6_hip_dmapixmajor.so")
+    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_dma.hip"] + ["-DY6_DMA_PLANAR16=0", "-c", os.path.join(B.HERE, "conv_dma.hip"), "-o", obj],
                    check=True, capture_output=True)
     subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + sorted(oth), check=True)
     os.remove(obj)

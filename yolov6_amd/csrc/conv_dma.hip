@@ -75,10 +75,13 @@ __device__ __forceinline__ ConvKArgs reload_args() {
 #endif
 constexpr int kDmaProbe = Y6_DMA_PROBE;
 
-// A/B switch (tools/build_probe_libs.py --dma-planar): 1 = the 16-channel-chunk kernels keep the first cut's planar halo image
-// (one cache line per lane of a request) instead of the pixel-major swizzled one (two lanes per pixel)
+// Halo image of the 16-channel-chunk kernels: 1 = two planes (channels 0-7 / 8-15), one cache line per lane of a request but
+// fragment addresses that are a constant offset per tap; 0 = pixel-major with the piece index XOR bit 3 of the pixel index
+// (two lanes of a request per pixel, four VALU instructions per fragment address).  Same-box A/B (tools/gpu_ab_layout.sh,
+// profiles/r02/ab_layout_ablayout1.txt): planar 1.85 ms for the 35 launches, pixel-major 1.92-2.01 ms - the address
+// arithmetic costs more than the request rate gains at this chunk size.  (The 32-channel-chunk kernels are pixel-major.)
 #ifndef Y6_DMA_PLANAR16
-#define Y6_DMA_PLANAR16 0
+#define Y6_DMA_PLANAR16 1
 #endif
 
 constexpr unsigned kOob = 0xf0000000u;   // voffset of a piece that must read zeros / a store that must be dropped (tensors stay below 3.5 GiB)
