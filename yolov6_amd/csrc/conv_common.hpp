@@ -382,6 +382,7 @@ struct VariantCfg {
     int st = 1;      // pipe kernels: the stride they are built for
     int depth = 2;   // pipe kernels: chunks the halo fill runs ahead; dma kernels: LDS stages
     int hc = 16;     // dma kernels: input channels per chunk
+    int cs = 1;      // dma kernels: the conv stride they are built for
 };
 
 struct Launch {

@@ -91,9 +91,9 @@ __device__ __forceinline__ int frag_pixel(int l) {
     return l < 4 ? l : (l < 12 ? l + 12 : (l < 16 ? l - 8 : (l < 20 ? l + 8 : (l < 28 ? l - 12 : l))));
 }
 
-template <int BP>
-struct DmaHaloCap {   // halo pixels per plane for BP output pixels
-    static constexpr int value = BP <= 128 ? 208 : (BP <= 256 ? 352 : (BP <= 512 ? 672 : 1216));
+template <int BP, int ST = 1>
+struct DmaHaloCap {   // halo pixels per plane for BP output pixels (stride 2: (2 TH + 1) x (2 TW + 1) input pixels)
+    static constexpr int value = ST == 2 ? (BP <= 128 ? 576 : 1152) : (BP <= 128 ? 208 : (BP <= 256 ? 352 : (BP <= 512 ? 672 : 1216)));
 };
 
 template <bool I8>
@@ -135,8 +135,13 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 //     pixel-major there, [halo pixel][4 pieces of 16 B], with the piece index XOR-swizzled by bits 2-3 of the pixel index
 //     on the SOURCE side (cdna_hip_programming.md rule 21): a fragment read of 16 consecutive pixels still covers all 16
 //     bank groups, for any alignment.
-template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8>
+// ST: conv stride.  2 (planar 16-channel chunks only): the halo rows are stored with their even columns first, then the odd
+//     ones (slot = hy * RP + (hx & 1 ? RPE : 0) + (hx >> 1), RPE = number of even columns) - the source address does the
+//     de-interleave - so that the 16 consecutive output pixels of a read group (input columns 2 tx + kx) read 16 CONSECUTIVE
+//     slots for every tap, as with stride 1: kx = 0 -> even slot tx, kx = 1 -> odd slot tx, kx = 2 -> even slot tx + 1.
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1>
 __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKArgs a) {
+    static_assert(ST == 1 || (HC == 16 && Y6_DMA_PLANAR16 != 0), "stride 2 is built on the planar 16-channel-chunk image");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename AccT<I8>::type acc_t;
     constexpr int NT = 9;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     constexpr int JB = HC == 16 ? 1 : 2;                          // bits of the piece index
     constexpr bool PLANAR = HC == 16 && Y6_DMA_PLANAR16 != 0;     // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
     constexpr int WP = CF * NT * KS;                              // weight pieces (1 KiB) per chunk
-    constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32>::value * SPP + 63) / 64;
+    constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32, ST>::value * SPP + 63) / 64;
     constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
 
     const int tid = threadIdx.x;
@@ -220,7 +225,12 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             r = s >> JB;
             j = (s & (SPP - 1)) ^ ((r >> (4 - JB)) & (SPP - 1));
         }
-        const int hy = r / RP, hx = r - hy * RP;
+        const int hy = r / RP;
+        int hx = r - hy * RP;
+        if (ST == 2) {   // slot column -> image column: evens first
+            const int rpe = (a.HWd + 1) >> 1;
+            hx = hx < rpe ? 2 * hx : 2 * (hx - rpe) + 1;
+        }
         const bool v = (P < NHP) && (s < SPP * PLs) && (hx < a.HWd);
         hinfo[i] = v ? (unsigned)((hy << 16) | (hx << JB) | j) : 0xffffffffu;
         hvoff[i] = kOob;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int t2 = tile / a.tiles_x;
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
-        const int iy0 = ty_i * a.TH - 1, ix0 = tx_i * a.TW - 1;
+        const int iy0 = ty_i * a.TH * ST - 1, ix0 = tx_i * a.TW * ST - 1;
         const int base = (((b * a.H + iy0) * a.W + ix0) * ics + ico) * ES;   // may be negative; valid pieces end up >= 0
 #pragma unroll
         for (int i = 0; i < NPWH; ++i) {
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int npx = a.TH * a.TW;
         const int mm = m < npx ? m : npx - 1;
         const int ty = mm / a.TW, tx = mm - ty * a.TW;
-        pixoff[pf] = PLANAR ? ((lane >> 5) * PLs + ty * RP + tx) * 16 : (ty * RP + tx);   // pixel-major: the pixel's linear index
+        pixoff[pf] = PLANAR ? ((lane >> 5) * PLs + ty * ST * RP + tx) * 16 : (ty * RP + tx);   // pixel-major: the pixel's linear index
         ptytx[pf] = m < npx ? ((ty << 16) | tx) : -1;
     }
     auto setup_pix = [&](int item) {
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
                 for (int cf = 0; cf < CF; ++cf) fa[buf][cf] = *reinterpret_cast<const i32x4_t*>(Wb + ((cf * NT + t) * KS + ks) * 1024);
                 if constexpr (PLANAR) {
-                    const int tapoff = ((t / 3) * RP + (t % 3)) * 16;
+                    const int tapoff = ((t / 3) * RP + (ST == 1 ? (t % 3) : ((t % 3) == 1 ? ((a.HWd + 1) >> 1) : ((t % 3) >> 1)))) * 16;
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
                 } else {
@@ -656,9 +666,9 @@ __global__ void dma_probe_kernel(const char* src, unsigned bytes, unsigned lds_o
     *reinterpret_cast<uint4*>(dst + lane * 16) = *reinterpret_cast<const uint4*>(smem + lds_off + lane * 16);
 }
 
-template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8>
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1>
 int launch_dma(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8>;
+    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8, ST>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -688,7 +698,15 @@ int launch_dma(const Launch& L, hipStream_t s) {
 }
 
 template <bool I8>
-int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, hipStream_t s) {
+int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, int stride, hipStream_t s) {
+    if (stride == 2) {
+        if constexpr (!I8) {
+            if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 2, 1, 16, false, 2>(L, s);
+            if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 1 && nw == 8) return launch_dma<2, 1, 8, 2, 2, 1, 16, false, 2>(L, s);
+        }
+        y6_set_error("conv_dma: no stride-2 instantiation c%dp%d x %d waves", cf, pf, nw);
+        return Y6_EUNSUPPORTED;
+    }
     if (hc == 16 && stg == 2 && il == 1) {
         if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, 16, I8>(L, s);
         if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, 16, I8>(L, s);
@@ -711,12 +729,16 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
 }  // namespace
 
 // L points at conv_mfma.hip's launch record (same struct: conv_common.hpp)
-int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int hc, int i8, hipStream_t s) {
+int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int hc, int stride, int i8, hipStream_t s) {
     const Launch& l = *static_cast<const Launch*>(L);
-    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, hc, s) : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, hc, s);
+    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, hc, stride, s)
+              : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, hc, stride, s);
 }
 
-int y6_conv_dma_halo_cap(int bp) { return bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 672 : 1216)); }
+int y6_conv_dma_halo_cap(int bp, int stride) {
+    if (stride == 2) return bp <= 128 ? 576 : 1152;
+    return bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 672 : 1216));
+}
 
 extern "C" int y6_dma_probe(const void* src, unsigned bytes, unsigned lds_off, unsigned long long oob_mask, void* dst, void* stream) {
     Y6_CLEAR_STALE_ERROR();

@@ -1142,7 +1142,9 @@ const VariantCfg kVariants[] = {
     // (depth = LDS stages; st = 1: requests interleaved with the MFMAs, 0: issued in a burst after the barrier)
     {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4},
     // hc = 32: 32-channel chunks, four lanes of a request per pixel (16 cache lines per request instead of 64)
-    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 2, 4, "dmaw8f_c2p2", 8, 3, 2, 32}};   // f: three requests per unit (front-loaded)
+    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 2, 4, "dmaw8f_c2p2", 8, 3, 2, 32},   // f: three requests per unit (front-loaded)
+    // cs = 2: stride-2 forms (parity-split halo rows): 128 output pixels x 64 couts, two blocks per CU / 256 pixels, one block
+    {2, 1, 4, "dmas2_c2p1", 4, 1, 2, 16, 2}, {2, 1, 4, "dma8s2_c2p1", 8, 1, 2, 16, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1240,7 +1242,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.W = d->in.W;
         k.Ho = d->out.H;
         k.Wo = d->out.W;
-        const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
+        const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp, vc.cs) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
         choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
     }
     k.tiles_x = y6_cdiv(k.Wo, k.TW);
@@ -1528,7 +1530,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
-    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, s);
+    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, 1, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
         case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
@@ -1563,7 +1565,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
-        if (st != 1 || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here, not a stride)
+        if (st != vc.cs || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here; vc.cs the stride)
         if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
         if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;   // byte offsets + the range-check sentinel
@@ -1621,9 +1623,9 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
-                                      kVariants[variant].st, kVariants[variant].hc, 0, s);
+                                      kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, s);
     }
     return Y6_EINVAL;
 }
