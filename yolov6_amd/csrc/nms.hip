@@ -215,12 +215,14 @@ __device__ __forceinline__ void bitonic_desc_lds(u64* keys, int P) {
 }
 
 constexpr int kBatch = 256;       // candidates settled per round of the sweep (kBatch / 64 mask words per candidate)
-constexpr int kWin = 1024;        // sweep window: sorted candidates resident in LDS at a time (one per thread)
+constexpr int kWin = 1024;        // sweep window: sorted candidates resident in LDS at a time (one per thread) when max_det is in the thousands,
+constexpr int kWinBig = 4096;     // ... four per thread otherwise: with many same-class overlaps (the bench's decode output keeps ~3 % of the
+                                  // candidates) the sweep walks ten 1024-windows to find 300 boxes, each paying box gather + barriers
 constexpr int kKeptCap = 8192;    // most kept boxes LDS can hold next to the window (160 KiB per CU): the max_det limit
 // LDS of the sweep for a given kept-box capacity (max_det rounded up to 256): window boxes + kept boxes + alive words
 // (+ with class chains: class per window candidate, next-of-same-class link per kept box, chain head per class)
-static inline size_t sweep_lds(int kept_cap, int nheads) {
-    return (size_t)(kWin + kept_cap) * 16 + (kWin / 64) * 8 + (nheads > 0 ? (size_t)(kWin + kept_cap + nheads) * 4 : 0);
+static inline size_t sweep_lds(int kept_cap, int nheads, int win = kWin) {
+    return (size_t)(win + kept_cap) * 16 + (win / 64) * 8 + (nheads > 0 ? (size_t)(win + kept_cap + nheads) * 4 : 0);
 }
 
 __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(256) void nms_merge_rank_kernel(const u64* __restri
 // candidates at a time become class-offset boxes in LDS, are first tested against the boxes kept so far,
 // then settled in batches of 64 (see below).  Boxes are only ever built for the windows the sweep reaches
 // before max_det boxes are kept.
+template <int WIN>
 __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict__ pred, int A, int nc,
                                                          float iou_thres, int agnostic, int max_det, int max_nms, int kept_cap,
                                                          int nheads, float max_wh, const u64* __restrict__ sorted,
@@ -389,14 +392,14 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     if (n > max_nms) n = max_nms;
 
     float4* wbox = reinterpret_cast<float4*>(smem);
-    float4* kbox = wbox + kWin;
+    float4* kbox = wbox + WIN;
     u64* walive = reinterpret_cast<u64*>(kbox + kept_cap);
     // Class chains (nheads > 0).  With the class offset of nms.py:94-95 only boxes of ONE class can overlap, so a
     // candidate is tested against the kept boxes of its class only: every kept box carries the index of the previously
     // kept box of its class, khead[c] is the newest.  Testing all 1024 window candidates against all (up to 300) kept
     // boxes was the sweep's floor: 300 k box tests on one CU = 36 us of VALU issue; with 80 classes it is 1/80 of that.
-    int* wcls = reinterpret_cast<int*>(walive + kWin / 64);
-    int* knext = wcls + kWin;
+    int* wcls = reinterpret_cast<int*>(walive + WIN / 64);
+    int* knext = wcls + WIN;
     int* khead = knext + kept_cap;
     const bool chains = nheads > 0;
     if (chains)
@@ -404,8 +407,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     int* kept_pos = out_index + (size_t)b * max_det;   // sorted positions first; converted to flat ids at the end
     const int no = nc + 5;
     int kept = 0;
-    for (int pos = 0; pos < n && kept < max_det; pos += kWin) {
-        const int wn = (n - pos) < kWin ? (n - pos) : kWin;
+    for (int pos = 0; pos < n && kept < max_det; pos += WIN) {
+        const int wn = (n - pos) < WIN ? (n - pos) : WIN;
         // window boxes: xywh2xyxy (nms.py:72) + class offset (nms.py:94-95)
         for (int t = tid; t < wn; t += T) {
             const u64 key = gk[pos + t];
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
         __syncthreads();
         // survivors of the boxes kept in earlier windows
 #pragma unroll
-        for (int r = 0; r < kWin / 1024; ++r) {
+        for (int r = 0; r < WIN / 1024; ++r) {
             const int t = tid + r * 1024;
             bool alive = t < wn;
             if (alive) {
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
         while (kept < max_det) {
             if (wave == 0) {
                 u64 w = 0ull;
-                if (lane < kWin / 64) {
+                if (lane < WIN / 64) {
                     w = walive[lane];
                     if (lane < (cur >> 6)) w = 0ull;
                     if (lane == (cur >> 6)) w &= ~((1ull << (cur & 63)) - 1ull);
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             kept = s_kept;
             if (kept >= max_det) break;
 #pragma unroll
-            for (int r = 0; r < kWin / 1024; ++r) {
+            for (int r = 0; r < WIN / 1024; ++r) {
                 const int t = tid + r * 1024;
                 if (t > last && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
                     const float4 bj = wbox[t];
@@ -691,14 +694,21 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     if (kept_cap < 2048) kept_cap = 2048;
     int nheads = d->agnostic ? 1 : d->nc;
     if (nheads > 4096 || sweep_lds(kept_cap, nheads) + 16 * 1024 > 160 * 1024) nheads = 0;   // no room (max_det in the thousands): linear scans
-    const size_t lds = sweep_lds(kept_cap, nheads);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        Y6_HIP(hipFuncSetAttribute((const void*)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
+    static const bool small_win = getenv("Y6_NMS_WIN1024") != nullptr;   // A/B switch
+    const bool big = !small_win && sweep_lds(kept_cap, nheads, kWinBig) + 16 * 1024 <= 160 * 1024;
+    const size_t lds = sweep_lds(kept_cap, nheads, big ? kWinBig : kWin);
+    static size_t attr_lds[2] = {0, 0};
+    if (lds > attr_lds[big]) {
+        Y6_HIP(hipFuncSetAttribute(big ? (const void*)nms_sweep_kernel<kWinBig> : (const void*)nms_sweep_kernel<kWin>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds[big] = lds;
     }
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
-                       d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
+    if (big)
+        hipLaunchKernelGGL(nms_sweep_kernel<kWinBig>, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
+                           d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
+    else
+        hipLaunchKernelGGL(nms_sweep_kernel<kWin>, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
+                           d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
