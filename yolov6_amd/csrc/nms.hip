@@ -368,10 +368,24 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                                                          int nheads, float max_wh, const u64* __restrict__ sorted,
                                                          const int* __restrict__ counts,
                                                               float* __restrict__ out_dets, int* __restrict__ out_index,
-                                                              int* __restrict__ out_count) {
+                                                              int* __restrict__ out_count, unsigned long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // optional s_memtime trace of block 0 / thread 0 (tools/nms_trace.py, env Y6_NMS_TRACE = device address of 512 words)
+    int dbg_n = 0;
+#define NT_(tag)                                                             \
+    do {                                                                     \
+        if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0 && dbg_n < 250) { \
+            dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                   \
+            dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                  \
+            ++dbg_n;                                                         \
+        }                                                                    \
+    } while (0)
+    NT_(1);
     __shared__ int s_batch[kBatch];
     __shared__ u64 s_col[kBatch * 4];
+    __shared__ float4 s_bbox[kBatch];
+    __shared__ u64 s_wm[64];
+    __shared__ int s_wpre[64];
     __shared__ int s_nb, s_k0, s_kept, s_last;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -425,50 +439,66 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             wbox[t] = q;
             if (chains) wcls[t] = agnostic ? 0 : (int)cls;
         }
-        __syncthreads();
-        // survivors of the boxes kept in earlier windows
-#pragma unroll
-        for (int r = 0; r < WIN / 1024; ++r) {
-            const int t = tid + r * 1024;
-            bool alive = t < wn;
-            if (alive) {
-                const float4 bj = wbox[t];
-                if (chains) {
-                    for (int k = khead[wcls[t]]; k >= 0; k = knext[k])
-                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                            alive = false;
-                            break;
-                        }
-                } else {
-                    for (int k = 0; k < kept; ++k)
-                        if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                            alive = false;
-                            break;
-                        }
-                }
-            }
-            const u64 bal = __ballot(alive);
-            if (lane == 0) walive[r * 16 + wave] = bal;   // bit (t & 63) of word (t >> 6)
+        // every candidate of the window starts alive; alive bits are only brought up to date (tested against the boxes kept
+        // so far) for the prefix of the window the sweep actually needs - see below
+        for (int w = tid; w < WIN / 64; w += T) {
+            const int lo = w * 64;
+            walive[w] = wn >= lo + 64 ? ~0ull : (wn > lo ? ((1ull << (wn - lo)) - 1ull) : 0ull);
         }
         __syncthreads();
-        // Greedy sweep inside the window, kBatch (256) undecided candidates at a time.  Wave 0 collects the first (up to)
-        // kBatch alive candidates; all threads compute the batch's suppression matrix in COLUMN form (bit j of col[i] <=>
-        // j < i and IoU(j, i) > thr); wave 0 then solves  kept[i] = no kept j < i suppresses i  by fixed-point iteration:
-        // start from "all kept", re-evaluate every candidate against the current kept set (one AND per 64 candidates and
-        // lane, four ballots per round) until nothing changes.  The greedy solution is the unique fixed point (candidate 0
-        // is right from the start, candidate i once 0..i-1 are: at most nb rounds, in practice the depth of the longest
-        // suppression chain, 2-4) - this replaces a 64-step scalar scan per 64 candidates (~2500 cycles each; the sweep
-        // was 110 us with one block per image).  Then every thread tests the window's later alive candidates against the
-        // new boxes.  Exactly the sequential greedy order: a candidate left outside a batch is alive only if it lies
-        // behind every member of that batch.
-        int cur = 0;
-        while (kept < max_det) {
-            if (wave == 0) {
+        NT_(2);
+        // Greedy sweep inside the window, kBatch (256) undecided candidates at a time, over a LAZILY tested prefix.
+        //   * `tested`: candidates [0, tested) have been tested against every box kept so far.  Before a round the prefix
+        //     is extended to cur + need + need/4 + 64 (need = boxes still wanted): the new candidates are tested against
+        //     ALL kept boxes of their class.  With well separated boxes (the bench's decode output keeps every one of its
+        //     first 300 candidates) that is 375 tests of nothing instead of testing all 1024 window candidates against the
+        //     256 boxes of the first round (115 k of the sweep's 216 k cycles, tools/nms_trace.py).
+        //   * gather: every thread ranks its own candidate among the alive ones of [cur, tested) from per-word prefix counts
+        //     (was: wave 0 peeling set bits one at a time, 10.8 k cycles per round) and copies its box into a compact
+        //     batch array, so the suppression matrix reads one LDS location per pair.
+        //   * matrix in COLUMN form (bit j of col[i] <=> j < i and IoU(j, i) > thr); wave 0 solves
+        //     kept[i] = no kept j < i suppresses i  by fixed-point iteration from "all kept" (the greedy solution is the
+        //     unique fixed point: candidate 0 is right from the start, candidate i once 0..i-1 are; in practice the depth
+        //     of the longest suppression chain, 2-4 rounds of four ballots) instead of a 64-step scalar scan per 64 candidates.
+        //   * then the alive candidates of (last, tested) are tested against the new boxes.
+        // Exactly the sequential greedy order: a candidate enters a round only after it has been tested against every
+        // box kept before that round.
+        int cur = 0, tested = 0;
+        NT_(3);
+        while (kept < max_det && cur < wn) {
+            const int need = max_det - kept;
+            int upto = cur + need + (need >> 2) + 64;
+            if (upto > wn) upto = wn;
+            if (upto > tested) {
+                for (int t = tested + tid; t < upto; t += T) {
+                    const float4 bj = wbox[t];
+                    bool dead = false;
+                    if (chains) {
+                        for (int k = khead[wcls[t]]; k >= 0; k = knext[k])
+                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                                dead = true;
+                                break;
+                            }
+                    } else {
+                        for (int k = 0; k < kept; ++k)
+                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                                dead = true;
+                                break;
+                            }
+                    }
+                    if (dead) atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                }
+                tested = upto;
+                __syncthreads();
+            }
+            if (wave == 0) {   // alive words restricted to [cur, tested), their exclusive prefix counts
                 u64 w = 0ull;
                 if (lane < WIN / 64) {
                     w = walive[lane];
-                    if (lane < (cur >> 6)) w = 0ull;
-                    if (lane == (cur >> 6)) w &= ~((1ull << (cur & 63)) - 1ull);
+                    const int lo = lane * 64;
+                    if (lo + 64 <= cur || lo >= tested) w = 0ull;
+                    if (lo < cur && cur < lo + 64) w &= ~((1ull << (cur - lo)) - 1ull);
+                    if (lo < tested && tested < lo + 64) w &= (1ull << (tested - lo)) - 1ull;
                 }
                 const int pc = __popcll(w);
                 int incl = pc;
@@ -477,32 +507,50 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                     const int v = __shfl_up(incl, o, 64);
                     if (lane >= o) incl += v;
                 }
-                const int total = __shfl(incl, 63, 64);
-                int p = incl - pc;
-                u64 ww = w;
-                while (ww != 0ull && p < kBatch) {
-                    s_batch[p++] = (lane << 6) + (__ffsll((long long)ww) - 1);
-                    ww &= ww - 1ull;
-                }
-                if (lane == 0) s_nb = total < kBatch ? total : kBatch;
+                s_wm[lane] = w;
+                s_wpre[lane] = incl - pc;
+                if (lane == 63) s_nb = incl;   // alive candidates in the range (may exceed kBatch)
             }
             __syncthreads();
-            const int nb = s_nb;
-            if (nb == 0) break;
+            const int total = s_nb;
+            const int nb = total < kBatch ? total : kBatch;
+            NT_(10 + (nb << 8));
+            if (nb == 0) {   // nothing alive in the tested prefix: move on (extends the prefix, or ends the window)
+                cur = tested;
+                __syncthreads();
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < (WIN + 1023) / 1024; ++r) {
+                const int t = tid + r * 1024;
+                if (t < WIN) {
+                    const u64 w = s_wm[t >> 6];
+                    if ((w >> (t & 63)) & 1ull) {
+                        const int rank = s_wpre[t >> 6] + __popcll(w & ((1ull << (t & 63)) - 1ull));
+                        if (rank < kBatch) {
+                            s_batch[rank] = t;
+                            s_bbox[rank] = wbox[t];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
             {   // column masks: thread (i, jq) tests candidate i against the earlier candidates 64*jq .. 64*jq+63
                 const int i = tid >> 2, jq = tid & 3;
                 if (i < kBatch) {
                     u64 bits = 0ull;
                     if (i < nb && jq * 64 < i) {
-                        const float4 bi = wbox[s_batch[i]];
+                        const float4 bi = s_bbox[i];
                         const int jend = (i < jq * 64 + 64) ? i : jq * 64 + 64;
+#pragma unroll 8
                         for (int j = jq * 64; j < jend; ++j)
-                            if (nms_suppresses(wbox[s_batch[j]], bi, iou_thres)) bits |= 1ull << (j & 63);
+                            if (nms_suppresses(s_bbox[j], bi, iou_thres)) bits |= 1ull << (j & 63);
                     }
                     s_col[i * 4 + jq] = bits;
                 }
             }
             __syncthreads();
+            NT_(11);
             if (wave == 0) {
                 // lane l owns candidates l, l+64, l+128, l+192
                 u64 col[4][4];
@@ -552,7 +600,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                         const int idx = s_batch[i];
                         if ((kv[q] >> lane) & 1ull) {
                             const int kp = kept + before[q] + __popcll(kv[q] & ((1ull << lane) - 1ull));
-                            kbox[kp] = wbox[idx];
+                            kbox[kp] = s_bbox[i];
                             kept_pos[kp] = pos + idx;
                             if (chains) knext[kp] = atomicExch(&khead[wcls[idx]], kp);   // newest first; this round's boxes all have kp >= k0
                         }
@@ -568,11 +616,10 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             __syncthreads();
             const int k0 = s_k0, last = s_last;
             kept = s_kept;
+            NT_(12 + (kept << 8));
             if (kept >= max_det) break;
-#pragma unroll
-            for (int r = 0; r < WIN / 1024; ++r) {
-                const int t = tid + r * 1024;
-                if (t > last && t < wn && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
+            for (int t = last + 1 + tid; t < tested; t += T) {
+                if ((walive[t >> 6] >> (t & 63)) & 1ull) {
                     const float4 bj = wbox[t];
                     if (chains) {
                         for (int k = khead[wcls[t]]; k >= k0; k = knext[k])   // the chain is newest-first: stop at the older rounds
@@ -590,8 +637,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                 }
             }
             __syncthreads();
-            cur = last + 1;
-            if (cur >= wn) break;
+            NT_(13);
+            cur = total <= kBatch ? tested : last + 1;   // everything alive in the prefix was in this round: skip the rest of it
         }
         __syncthreads();
     }
@@ -614,6 +661,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     }
     pad_outputs(kept);
     if (tid == 0) out_count[b] = kept;
+    NT_(20);
+#undef NT_
 }
 
 inline size_t next_pow2(size_t v) {
@@ -694,21 +743,27 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     if (kept_cap < 2048) kept_cap = 2048;
     int nheads = d->agnostic ? 1 : d->nc;
     if (nheads > 4096 || sweep_lds(kept_cap, nheads) + 16 * 1024 > 160 * 1024) nheads = 0;   // no room (max_det in the thousands): linear scans
-    static const bool small_win = getenv("Y6_NMS_WIN1024") != nullptr;   // A/B switch
-    const bool big = !small_win && sweep_lds(kept_cap, nheads, kWinBig) + 16 * 1024 <= 160 * 1024;
-    const size_t lds = sweep_lds(kept_cap, nheads, big ? kWinBig : kWin);
-    static size_t attr_lds[2] = {0, 0};
-    if (lds > attr_lds[big]) {
-        Y6_HIP(hipFuncSetAttribute(big ? (const void*)nms_sweep_kernel<kWinBig> : (const void*)nms_sweep_kernel<kWin>,
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds[big] = lds;
+    // window size (candidates resident in LDS at a time): A/B switch Y6_NMS_WIN = 256 | 512 | 1024 | 4096
+    static const int win_env = getenv("Y6_NMS_WIN") ? atoi(getenv("Y6_NMS_WIN")) : 0;
+    int win = win_env ? win_env : kWin;
+    if (win != 256 && win != 512 && win != 4096) win = kWin;
+    if (sweep_lds(kept_cap, nheads, win) + 16 * 1024 > 160 * 1024) win = kWin;
+    const size_t lds = sweep_lds(kept_cap, nheads, win);
+    static unsigned long long* const trace = getenv("Y6_NMS_TRACE") ? (unsigned long long*)(uintptr_t)strtoull(getenv("Y6_NMS_TRACE"), nullptr, 10) : nullptr;
+    auto launch = [&](auto kern) -> int {
+        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 12 * 1024)));
+        hipLaunchKernelGGL(kern, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic, d->max_det, d->max_nms,
+                           kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count, trace);
+        return Y6_OK;
+    };
+    int rc;
+    switch (win) {
+        case 256: rc = launch(nms_sweep_kernel<256>); break;
+        case 512: rc = launch(nms_sweep_kernel<512>); break;
+        case 4096: rc = launch(nms_sweep_kernel<kWinBig>); break;
+        default: rc = launch(nms_sweep_kernel<kWin>); break;
     }
-    if (big)
-        hipLaunchKernelGGL(nms_sweep_kernel<kWinBig>, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
-                           d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
-    else
-        hipLaunchKernelGGL(nms_sweep_kernel<kWin>, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic,
-                           d->max_det, d->max_nms, kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count);
+    if (rc) return rc;
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
