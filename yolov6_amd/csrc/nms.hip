@@ -751,7 +751,11 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     const size_t lds = sweep_lds(kept_cap, nheads, win);
     static unsigned long long* const trace = getenv("Y6_NMS_TRACE") ? (unsigned long long*)(uintptr_t)strtoull(getenv("Y6_NMS_TRACE"), nullptr, 10) : nullptr;
     auto launch = [&](auto kern) -> int {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 12 * 1024)));
+        static size_t attr_lds = 0;   // one per instantiation of this lambda, i.e. per kernel
+        if (lds > attr_lds) {
+            Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_lds = lds;
+        }
         hipLaunchKernelGGL(kern, dim3(d->B), dim3(1024), lds, s, d->pred, d->A, d->nc, d->iou_thres, d->agnostic, d->max_det, d->max_nms,
                            kept_cap, nheads, d->max_wh, sorted, counts, d->out_dets, d->out_index, d->out_count, trace);
         return Y6_OK;
