@@ -222,7 +222,7 @@ constexpr int kKeptCap = 8192;    // most kept boxes LDS can hold next to the wi
 // LDS of the sweep for a given kept-box capacity (max_det rounded up to 256): window boxes + kept boxes + alive words
 // (+ with class chains: class per window candidate, next-of-same-class link per kept box, chain head per class)
 static inline size_t sweep_lds(int kept_cap, int nheads, int win = kWin) {
-    return (size_t)(win + kept_cap) * 16 + (win / 64) * 8 + (nheads > 0 ? (size_t)(win + kept_cap + nheads) * 4 : 0);
+    return (size_t)(win + kept_cap) * 16 + (win / 64) * 8 + (nheads > 0 ? (size_t)(win + 2 * kept_cap + nheads) * 4 : 0);
 }
 
 __device__ __forceinline__ float nms_iou(const float4 bi, const float4 bj) {
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     // boxes was the sweep's floor: 300 k box tests on one CU = 36 us of VALU issue; with 80 classes it is 1/80 of that.
     int* wcls = reinterpret_cast<int*>(walive + WIN / 64);
     int* knext = wcls + WIN;
-    int* khead = knext + kept_cap;
+    int* kcls = knext + kept_cap;     // class of every kept box: short linear scans filter on it instead of chasing the chain
+    int* khead = kcls + kept_cap;
     const bool chains = nheads > 0;
     if (chains)
         for (int c = tid; c < nheads; c += T) khead[c] = -1;
@@ -473,9 +474,16 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                 for (int t = tested + tid; t < upto; t += T) {
                     const float4 bj = wbox[t];
                     bool dead = false;
-                    if (chains) {
+                    if (chains && kept > 512) {   // long lists: only the boxes of this class (pointer chase, ~400 cycles a hop)
                         for (int k = khead[wcls[t]]; k >= 0; k = knext[k])
                             if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                                dead = true;
+                                break;
+                            }
+                    } else if (chains) {          // short lists: linear, class compare first (broadcast reads, no dependent loads)
+                        const int c = wcls[t];
+                        for (int k = 0; k < kept; ++k)
+                            if (kcls[k] == c && nms_suppresses(kbox[k], bj, iou_thres)) {
                                 dead = true;
                                 break;
                             }
@@ -602,7 +610,10 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                             const int kp = kept + before[q] + __popcll(kv[q] & ((1ull << lane) - 1ull));
                             kbox[kp] = s_bbox[i];
                             kept_pos[kp] = pos + idx;
-                            if (chains) knext[kp] = atomicExch(&khead[wcls[idx]], kp);   // newest first; this round's boxes all have kp >= k0
+                            if (chains) {
+                                knext[kp] = atomicExch(&khead[wcls[idx]], kp);   // newest first
+                                kcls[kp] = wcls[idx];
+                            }
                         }
                         atomicAnd(&walive[idx >> 6], ~(1ull << (idx & 63)));   // decided either way
                     }
@@ -621,9 +632,10 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             for (int t = last + 1 + tid; t < tested; t += T) {
                 if ((walive[t >> 6] >> (t & 63)) & 1ull) {
                     const float4 bj = wbox[t];
-                    if (chains) {
-                        for (int k = khead[wcls[t]]; k >= k0; k = knext[k])   // the chain is newest-first: stop at the older rounds
-                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
+                    if (chains) {   // this round's boxes are kbox[k0, kept): at most kBatch, scanned linearly with a class filter
+                        const int c = wcls[t];
+                        for (int k = k0; k < kept; ++k)
+                            if (kcls[k] == c && nms_suppresses(kbox[k], bj, iou_thres)) {
                                 atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
                                 break;
                             }
