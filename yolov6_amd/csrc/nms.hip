@@ -245,7 +245,21 @@ __device__ __forceinline__ bool nms_suppresses(const float4 bi, const float4 bj,
     if (!(dw > 0.f)) return false;
     const float dh = fminf(bi.w, bj.w) - fmaxf(bi.y, bj.y);
     if (!(dh > 0.f)) return false;
-    return nms_iou(bi, bj) > thr;
+    // Overlapping boxes: decide without the division whenever the comparison is not borderline.  inter, union are the
+    // reference's own values (dw, dh > 0: the clamps are no-ops); with p = fl(thr * union), inter < p (1 - 2^-20) implies
+    // fl(inter / union) < thr and inter > p (1 + 2^-20) implies fl(inter / union) > thr (each fl() is within 2^-24), so only
+    // the sliver in between needs the exact quotient.  The sweep's pair loops were VALU-bound on the ~30-instruction
+    // division sequence (same-class neighbours overlap without reaching the threshold).
+    const float inter = dw * dh;
+    const float area_i = (bi.z - bi.x) * (bi.w - bi.y);
+    const float area_j = (bj.z - bj.x) * (bj.w - bj.y);
+    const float uni = area_i + area_j - inter;
+    if (uni > 0.f && thr > 0.f) {
+        const float p = thr * uni;
+        if (inter < p * 0.99999905f) return false;
+        if (inter > p * 1.00000095f) return true;
+    }
+    return inter / uni > thr;
 }
 
 // ---- sort, spread over the whole chip -------------------------------------------------------------
@@ -465,36 +479,46 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
         // Exactly the sequential greedy order: a candidate enters a round only after it has been tested against every
         // box kept before that round.
         int cur = 0, tested = 0;
+        // candidates [t0, t1) of the window against kept boxes [ka, kb): spread over all 1024 threads as (candidate, slice of
+        // the box range) - with a few hundred candidates and a few hundred boxes a thread per candidate left most of the
+        // block idle and every scan was a serial chain of LDS round trips (100 k cycles for 183 x 256 tests)
+        auto test_range = [&](int t0, int t1, int ka, int kb) {
+            const int ncand = t1 - t0;
+            if (ncand <= 0 || kb <= ka) return;
+            int cr = 64;
+            while (cr < ncand && cr < 1024) cr <<= 1;
+            const int slices = 1024 / cr, per = (kb - ka + slices - 1) / slices;
+            const int ci = tid & (cr - 1), si = tid / cr;
+            const int k_lo = ka + si * per, k_hi = (k_lo + per < kb) ? k_lo + per : kb;
+            for (int base = 0; base < ncand; base += cr) {
+                const int t = t0 + base + ci;
+                if (base + ci < ncand && ((walive[t >> 6] >> (t & 63)) & 1ull)) {
+                    const float4 bj = wbox[t];
+                    const int c = chains ? wcls[t] : 0;
+                    bool hit = false;
+                    for (int k = k_lo; k < k_hi && !hit; ++k)
+                        if ((!chains || kcls[k] == c) && nms_suppresses(kbox[k], bj, iou_thres)) hit = true;
+                    if (hit) atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                }
+            }
+        };
         NT_(3);
         while (kept < max_det && cur < wn) {
             const int need = max_det - kept;
             int upto = cur + need + (need >> 2) + 64;
             if (upto > wn) upto = wn;
             if (upto > tested) {
-                for (int t = tested + tid; t < upto; t += T) {
-                    const float4 bj = wbox[t];
-                    bool dead = false;
-                    if (chains && kept > 512) {   // long lists: only the boxes of this class (pointer chase, ~400 cycles a hop)
+                if (chains && kept > 512) {   // long kept lists: walk the class chain (one thread per candidate)
+                    for (int t = tested + tid; t < upto; t += T) {
+                        const float4 bj = wbox[t];
                         for (int k = khead[wcls[t]]; k >= 0; k = knext[k])
                             if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                                dead = true;
-                                break;
-                            }
-                    } else if (chains) {          // short lists: linear, class compare first (broadcast reads, no dependent loads)
-                        const int c = wcls[t];
-                        for (int k = 0; k < kept; ++k)
-                            if (kcls[k] == c && nms_suppresses(kbox[k], bj, iou_thres)) {
-                                dead = true;
-                                break;
-                            }
-                    } else {
-                        for (int k = 0; k < kept; ++k)
-                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                                dead = true;
+                                atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
                                 break;
                             }
                     }
-                    if (dead) atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
+                } else {
+                    test_range(tested, upto, 0, kept);
                 }
                 tested = upto;
                 __syncthreads();
@@ -629,25 +653,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             kept = s_kept;
             NT_(12 + (kept << 8));
             if (kept >= max_det) break;
-            for (int t = last + 1 + tid; t < tested; t += T) {
-                if ((walive[t >> 6] >> (t & 63)) & 1ull) {
-                    const float4 bj = wbox[t];
-                    if (chains) {   // this round's boxes are kbox[k0, kept): at most kBatch, scanned linearly with a class filter
-                        const int c = wcls[t];
-                        for (int k = k0; k < kept; ++k)
-                            if (kcls[k] == c && nms_suppresses(kbox[k], bj, iou_thres)) {
-                                atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
-                                break;
-                            }
-                    } else {
-                        for (int k = k0; k < kept; ++k)
-                            if (nms_suppresses(kbox[k], bj, iou_thres)) {
-                                atomicAnd(&walive[t >> 6], ~(1ull << (t & 63)));
-                                break;
-                            }
-                    }
-                }
-            }
+            test_range(last + 1, tested, k0, kept);   // this round's boxes are kbox[k0, kept)
             __syncthreads();
             NT_(13);
             cur = total <= kBatch ? tested : last + 1;   // everything alive in the prefix was in this round: skip the rest of it
