@@ -545,7 +545,10 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             }
             __syncthreads();
             const int total = s_nb;
-            const int nb = total < kBatch ? total : kBatch;
+            // round size: no more candidates than could still be wanted (the suppression matrix costs nb^2 pair tests)
+            int cap = need + (need >> 2) + 32;
+            if (cap > kBatch) cap = kBatch;
+            const int nb = total < cap ? total : cap;
             NT_(10 + (nb << 8));
             if (nb == 0) {   // nothing alive in the tested prefix: move on (extends the prefix, or ends the window)
                 cur = tested;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
                     const u64 w = s_wm[t >> 6];
                     if ((w >> (t & 63)) & 1ull) {
                         const int rank = s_wpre[t >> 6] + __popcll(w & ((1ull << (t & 63)) - 1ull));
-                        if (rank < kBatch) {
+                        if (rank < nb) {
                             s_batch[rank] = t;
                             s_bbox[rank] = wbox[t];
                         }
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
             test_range(last + 1, tested, k0, kept);   // this round's boxes are kbox[k0, kept)
             __syncthreads();
             NT_(13);
-            cur = total <= kBatch ? tested : last + 1;   // everything alive in the prefix was in this round: skip the rest of it
+            cur = total <= nb ? tested : last + 1;   // everything alive in the prefix was in this round: skip the rest of it
         }
         __syncthreads();
     }
