@@ -182,3 +182,70 @@ def test_compute_loss_target_packing_matches_oracle():
     assert crit.preprocess(inp["targets"][:0], 4, scale).shape == (4, 0, 5)
     with pytest.raises(ValueError):
         ComputeLoss(iou_type="eiou")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# int8 lowering: which activation buffers get a producer-written int8 twin (yolov6_amd/quant.py::plan_twins) - host logic
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeRef:
+    def __init__(self, bid, C, cstride=None, coff=0):
+        self.bid, self.C, self.cstride, self.coff = bid, C, (C if cstride is None else cstride), coff
+
+
+class _FakePB:
+    def __init__(self, op_log, fp16_reads=()):
+        self.op_log, self.fp16_reads = op_log, list(fp16_reads)
+
+    @staticmethod
+    def buf_id(ref):
+        return ref.bid
+
+
+def test_int8_twin_planning_rules():
+    from yolov6_amd.quant import plan_twins
+    a, b, c, d, e = (_FakeRef(i, 64) for i in range(5))
+    cat = _FakeRef(7, 128)                       # a concat buffer written in two slices
+    cat_lo, cat_hi = _FakeRef(7, 64, 128, 0), _FakeRef(7, 64, 128, 64)
+    odd = _FakeRef(9, 24)                        # 24 channels: not a whole number of 16-byte int8 pieces
+    log = [
+        dict(kind="stem", out=a),                                                    # fp16 producer: `a` cannot have a twin
+        dict(kind="conv_i8", x=a, out=b, amax=2.0, res=None),
+        dict(kind="conv_i8", x=b, out=c, amax=3.0, res=None),                        # b: one int8 reader, int8 writer -> twin, no fp16
+        dict(kind="conv_i8", x=c, out=cat_lo, amax=1.5, res=None),
+        dict(kind="conv_i8", x=c, out=cat_hi, amax=1.5, res=None),                   # c: two readers, ONE scale -> twin
+        dict(kind="conv_i8", x=cat, out=d, amax=4.0, res=None),                      # cat: both writers int8, one reader scale -> twin
+        dict(kind="convt", x=d, out=e),                                              # d: read by an fp16 op only -> no twin
+        dict(kind="conv_i8", x=e, out=odd, amax=1.0, res=None),                      # e: written by an fp16 op -> no twin
+        dict(kind="conv_i8", x=odd, out=_FakeRef(11, 64), amax=1.0, res=None),       # odd: misaligned -> no twin
+        dict(kind="conv_i8", x=b, out=_FakeRef(12, 64), amax=3.0, res=c),            # c also read as an fp16 residual
+    ]
+    dec = plan_twins(_FakePB(log, fp16_reads=[d]))
+    assert dec[0]["twin"] is False                                   # written by the stem
+    assert dec[1]["twin"] and dec[1]["amax"] == 3.0 and dec[1]["fp16"] is False
+    assert dec[2]["twin"] and dec[2]["amax"] == 1.5 and dec[2]["fp16"] is True     # the residual read keeps its fp16 form
+    assert dec[7]["twin"] and dec[7]["amax"] == 4.0 and dec[7]["fp16"] is False
+    assert dec[3]["twin"] is False and dec[3]["fp16"] is True        # d: fp16 reader (convT) and a lazy feature-map read
+    assert dec[4]["twin"] is False
+    assert dec[9]["twin"] is False
+    # two int8 readers with DIFFERENT scales: no twin
+    log2 = [dict(kind="conv_i8", x=a, out=b, amax=2.0, res=None), dict(kind="conv_i8", x=b, out=c, amax=3.0, res=None),
+            dict(kind="conv_i8", x=b, out=d, amax=3.5, res=None)]
+    assert plan_twins(_FakePB(log2))[1]["twin"] is False
+
+
+def test_pmc_kernel_classification():
+    """tools/pmc_traffic.py maps rocprofv3 kernel names to the bench's kernel classes (roofline.traffic depends on it)."""
+    import importlib.util, os, sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pmc_traffic.py")
+    src = open(path).read()
+    ns = {}
+    exec(src[src.index("def classify"):src.index("res = {}")], {"re": __import__("re")}, ns)
+    classify = ns["classify"]
+    ns_ = "void (anonymous namespace)::"
+    assert classify(ns_ + "conv3x3_dma_kernel<2, 2, 4, 2, 2, 1, 16, false, 1>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
+    assert classify(ns_ + "conv3x3_dma_kernel<2, 1, 8, 2, 2, 1, 16, false, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s2"
+    assert classify(ns_ + "conv_mfma_pipe_kernel<2, 2, 2, 4, 1, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
+    assert classify(ns_ + "conv_mfma_kernel<4, 1, 3, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s2"
+    assert classify(ns_ + "conv_mfma_kernel<2, 1, 1, 1>((anonymous namespace)::ConvKArgs)") == "conv1x1s1"
+    assert classify(ns_ + "conv1x1_stream_kernel<1, 4>((anonymous namespace)::ConvKArgs)") == "conv1x1s1"
+    assert classify("(anonymous namespace)::nms_sweep_kernel<1024>(float const*, int)") == "nms"
