@@ -53,6 +53,7 @@ class Arch:
         self.neck = m["neck"]["type"]
         self.csp = "CSP" in self.backbone
         self.csp_e = m["backbone"].get("csp_e", 0.5)
+        self.mbla = m["backbone"].get("stage_block_type", "BepC3") == "MBLABlock"   # models/yolo.py:75-78
         self.fuse_P2 = bool(m["backbone"].get("fuse_P2"))
         self.cspsppf = bool(m["backbone"].get("cspsppf"))
         self.nl = m["head"]["num_layers"]
@@ -225,7 +226,41 @@ class Oracle:
         b = self.convbn(x, p + ".cv2", act)
         return self.convbn(torch.cat((a, b), 1), p + ".cv3", act)
 
+    def bottlerep3(self, x, p):
+        """BottleRep3 (common.py:611-632): three basic blocks, shortcut weighted by alpha (in == out channels here)."""
+        y = self.block(self.block(self.block(x, p + ".conv1"), p + ".conv2"), p + ".conv3")
+        alpha = self.sd.get(p + ".alpha")
+        a = self.q(alpha) if alpha is not None else 1.0
+        return self.q(y + self.q(a * x))
+
+    def mbla(self, x, p, n):
+        """MBLABlock (common.py:653-692)."""
+        act = self._body_act()
+        n = n // 2
+        if n <= 0:
+            n = 1
+        if n == 1:
+            n_list = [0, 1]
+        else:
+            e = 1
+            while e * 2 < n:
+                e *= 2
+            n_list = [0, e, n]
+        w, b = self.conv_module_wb(p + ".cv1")
+        y = self.conv_fused(x, w, b, 1, act)
+        c = y.shape[1] // len(n_list)
+        ys = list(y.split(c, 1))
+        all_y = [ys[0]]
+        for mi, steps in enumerate(n_list[1:]):
+            all_y.append(ys[mi + 1])
+            for j in range(steps):
+                all_y.append(self.bottlerep3(all_y[-1], f"{p}.m.{mi}.{j}"))
+        w2, b2 = self.conv_module_wb(p + ".cv2")
+        return self.conv_fused(torch.cat(all_y, 1), w2, b2, 1, act)
+
     def stage(self, x, p, n):
+        if self.a.csp and self.a.mbla:
+            return self.mbla(x, p, n)
         return self.bepc3(x, p, n) if self.a.csp else self.repblock(x, p, n)
 
     def pool5(self, x):

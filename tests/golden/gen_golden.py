@@ -66,6 +66,9 @@ MODEL_CASES = {
     "s_qa_tiny": ("configs/qarepvgg/yolov6s_qa.py", dict(width_multiple=0.125, depth_multiple=0.17), 64, 2, 80),
     "l6_tiny": ("configs/yolov6l6.py", dict(width_multiple=0.125, depth_multiple=0.34), 128, 1, 80),
     "m_tiny": ("configs/yolov6m.py", dict(width_multiple=0.125, depth_multiple=0.34), 64, 1, 20),
+    # MBLABlock stages (conv_silu): width 0.25 keeps the branch width a multiple of 8; depth 0.5 gives both branch shapes
+    # (n_list [0, 1] and [0, 1, 2])
+    "s_mbla_tiny": ("configs/mbla/yolov6s_mbla.py", dict(width_multiple=0.25, depth_multiple=0.5), 64, 1, 20),
 }
 
 
@@ -81,7 +84,10 @@ def gen_models():
     from yolov6.models.yolo import Model
     from yolov6.utils.torch_utils import fuse_model
 
+    only = os.environ.get("GOLDEN_ONLY")      # e.g. GOLDEN_ONLY=s_mbla_tiny: (re)generate one model case
     for name, (cfile, over, size, batch, nc) in MODEL_CASES.items():
+        if only and name != only:
+            continue
         cfg = ref_config(cfile, over)
         torch.manual_seed(0)
         model = Model(cfg, channels=3, num_classes=nc).eval()

@@ -20,7 +20,7 @@ from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny"]
+CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny"]
 
 
 def _build(case, deploy, half=True):

@@ -18,7 +18,7 @@ from yolov6_amd.layers import common
 from yolov6_amd.models.yolo import Model, build_model
 from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
 
-CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny"]
+CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny"]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -58,7 +58,8 @@ def test_builtin_configs_equal_reference_files():
     if not os.path.isdir(ref):
         pytest.skip("reference tree not present (GPU box)")
     pairs = {"yolov6n": "yolov6n.py", "yolov6s": "yolov6s.py", "yolov6m": "yolov6m.py", "yolov6l": "yolov6l.py",
-             "yolov6l6": "yolov6l6.py", "yolov6s_qa": "qarepvgg/yolov6s_qa.py"}
+             "yolov6l6": "yolov6l6.py", "yolov6s_qa": "qarepvgg/yolov6s_qa.py", "yolov6s_mbla": "mbla/yolov6s_mbla.py",
+             "yolov6m_mbla": "mbla/yolov6m_mbla.py", "yolov6l_mbla": "mbla/yolov6l_mbla.py", "yolov6x_mbla": "mbla/yolov6x_mbla.py"}
     for name, f in pairs.items():
         a, b = get_config(name), load_config(os.path.join(ref, f))
         assert a.training_mode == b.training_mode, name

@@ -5,8 +5,8 @@ yolov6/utils/config.py:33-63 (which needs the `addict` package).  `load_config(p
 executes such a file unchanged; `get_config(name)` returns the built-in restatement of the
 BASELINE configurations' `model` dicts (so nothing under /root/reference is needed at run
 time): yolov6n / yolov6s (configs/yolov6n.py, yolov6s.py), yolov6m / yolov6l
-(configs/yolov6m.py, yolov6l.py), yolov6l6 (configs/yolov6l6.py) and yolov6s_qa
-(configs/qarepvgg/yolov6s_qa.py).
+(configs/yolov6m.py, yolov6l.py), yolov6l6 (configs/yolov6l6.py) yolov6s_qa
+(configs/qarepvgg/yolov6s_qa.py) and yolov6{s,m,l,x}_mbla (configs/mbla/).
 """
 import copy
 import os
@@ -89,6 +89,17 @@ _MODELS = {
     "yolov6l": dict(model=dict(type='YOLOv6l', **_p5(1.0, 1.0, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(1) / 2,
                                                       'giou', use_dfl=True, reg_max=16, cspsppf=False)),
                     training_mode="conv_silu"),
+    # *_mbla (configs/mbla/yolov6{s,m,l,x}_mbla.py): CSP backbone / neck whose stage block is the MBLABlock
+    **{f"yolov6{k}_mbla": dict(model=dict(
+        type=f'YOLOv6{k}_mbla', pretrained=None, depth_multiple=d, width_multiple=w,
+        backbone=dict(type='CSPBepBackbone', num_repeats=[1, 4, 8, 8, 4], out_channels=[64, 128, 256, 512, 1024],
+                      csp_e=float(1) / 2, fuse_P2=True, stage_block_type="MBLABlock"),
+        neck=dict(type='CSPRepBiFPANNeck', num_repeats=[8, 8, 8, 8], out_channels=[256, 128, 128, 256, 256, 512],
+                  csp_e=float(1) / 2, stage_block_type="MBLABlock"),
+        head=dict(type='EffiDeHead', in_channels=[128, 256, 512], num_layers=3, begin_indices=24, anchors=3,
+                  anchors_init=_ANCHORS, out_indices=[17, 20, 23], strides=[8, 16, 32], atss_warmup_epoch=0,
+                  iou_type='giou', use_dfl=True, reg_max=16, distill_weight={'class': 2.0, 'dfl': 1.0})),
+        training_mode="conv_silu") for k, d, w in (("s", 0.5, 0.5), ("m", 0.5, 0.75), ("l", 0.5, 1.0), ("x", 1.0, 1.0))},
     "yolov6l6": dict(model=dict(
         type='YOLOv6l6', pretrained=None, depth_multiple=1.0, width_multiple=1.0,
         backbone=dict(type='CSPBepBackbone_P6', num_repeats=[1, 6, 12, 18, 6, 6],

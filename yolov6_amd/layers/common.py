@@ -598,6 +598,82 @@ class BepC3(HipModule):
         return self.cv3.lower(pb, cat, out=out)
 
 
+class BottleRep3(HipModule):
+    '''Three basic blocks + weighted shortcut (the unit of MBLABlock).  Reference: common.py:611-632.'''
+
+    def __init__(self, in_channels, out_channels, basic_block=RepVGGBlock, weight=False):
+        super().__init__()
+        self.conv1 = basic_block(in_channels, out_channels)
+        self.conv2 = basic_block(out_channels, out_channels)
+        self.conv3 = basic_block(out_channels, out_channels)
+        self.shortcut = in_channels == out_channels
+        self.alpha = nn.Parameter(torch.ones(1)) if weight else 1.0
+
+    def lower(self, pb, x, out=None):
+        x = pb.as_nhwc(x)
+        t = self.conv2.lower(pb, self.conv1.lower(pb, x))
+        if not self.shortcut:
+            return self.conv3.lower(pb, t, out=out)
+        alpha = self.alpha if isinstance(self.alpha, torch.Tensor) else None
+        return self.conv3.lower(pb, t, out=out, res=x, res_alpha=alpha)
+
+
+class MBLABlock(HipModule):
+    '''Multi Branch Layer Aggregation block of the *_mbla models: cv1 (1x1) splits into 2-3 branches, branch b > 0 runs a
+    chain of BottleRep3 whose EVERY intermediate result joins the concatenation, cv2 (1x1) merges.  Reference:
+    common.py:653-692.  Lowering is concat-free: cv1 is issued as one 1x1 conv per branch (its output channels are
+    independent), each writing its slot of the buffer cv2 reads; every BottleRep3 writes the next slot.'''
+
+    def __init__(self, in_channels, out_channels, n=1, e=0.5, block=RepVGGBlock):
+        super().__init__()
+        n = n // 2
+        if n <= 0:
+            n = 1
+        if n == 1:                      # at most one extra branch
+            n_list = [0, 1]
+        else:
+            extra_branch_steps = 1
+            while extra_branch_steps * 2 < n:
+                extra_branch_steps *= 2
+            n_list = [0, extra_branch_steps, n]
+        branch_num = len(n_list)
+        self.c = int(out_channels * e)
+        act = "silu" if block == ConvBNSiLU else "relu"
+        self.cv1 = ConvModule(in_channels, branch_num * self.c, 1, 1, act, bias=False)
+        self.cv2 = ConvModule((sum(n_list) + branch_num) * self.c, out_channels, 1, 1, act, bias=False)
+        self.m = nn.ModuleList()
+        for n_i in n_list[1:]:
+            self.m.append(nn.Sequential(*(BottleRep3(self.c, self.c, basic_block=block, weight=True) for _ in range(n_i))))
+        self.split_num = tuple([self.c] * branch_num)
+
+    def lower(self, pb, x, out=None):
+        if getattr(pb, "is_train", False):
+            raise NotImplementedError("yolov6_amd: the training graph of MBLABlock is not on the HIP path yet")
+        x = pb.as_nhwc(x)
+        c = self.c
+        if c % 8:
+            raise NotImplementedError(f"yolov6_amd: MBLABlock branches of {c} channels (channel slices need a multiple of 8)")
+        total = self.cv2.conv.in_channels
+        cat = pb.new_buffer(x.B, x.H, x.W, total)
+        w, b = self.cv1.fused_weight_bias()
+        act = self.cv1._activation_name()
+
+        def branch(bi, off):            # y[bi] of the reference's split: rows bi*c .. (bi+1)*c of cv1
+            bb = None if b is None else b[bi * c:(bi + 1) * c]
+            return pb.conv(x, w[bi * c:(bi + 1) * c], bb, stride=1, act=act, out=cat.slice(off, c))
+
+        branch(0, 0)
+        off = c
+        for bi, seq in enumerate(self.m):
+            prev = branch(bi + 1, off)
+            off += c
+            for blk in seq:
+                prev = blk.lower(pb, prev, out=cat.slice(off, c))
+                off += c
+        assert off == total
+        return self.cv2.lower(pb, cat, out=out)
+
+
 class BiFusion(HipModule):
     '''cv3(cat(upsample(x0), cv1(x1), downsample(cv2(x2)))).  Reference: common.py:695-718.'''
 

@@ -7,7 +7,7 @@ stage block(, channel-merge layer on the last one)].  They differ in the stage b
 """
 from torch import nn
 
-from ..layers.common import (BepC3, ConvBNSiLU, CSPSPPF, HipModule, RepBlock, RepVGGBlock, SimCSPSPPF, SimSPPF, SPPF)
+from ..layers.common import (BepC3, ConvBNSiLU, CSPSPPF, HipModule, MBLABlock, RepBlock, RepVGGBlock, SimCSPSPPF, SimSPPF, SPPF)
 
 
 def _merge_layer(block, cspsppf):
@@ -73,10 +73,11 @@ class CSPBepBackbone(_PyramidBackbone):
     def __init__(self, in_channels=3, channels_list=None, num_repeats=None, block=RepVGGBlock, csp_e=float(1) / 2,
                  fuse_P2=False, cspsppf=False, stage_block_type="BepC3"):
         super().__init__()
-        if stage_block_type != "BepC3":
-            raise NotImplementedError  # MBLABlock: outside the BASELINE configs
+        if stage_block_type not in ("BepC3", "MBLABlock"):
+            raise NotImplementedError
+        stage_block = BepC3 if stage_block_type == "BepC3" else MBLABlock      # efficientrep.py:271-276
         self._build(in_channels, channels_list, num_repeats, block,
-                    lambda c, n: BepC3(in_channels=c, out_channels=c, n=n, e=csp_e, block=block), cspsppf, fuse_P2)
+                    lambda c, n: stage_block(in_channels=c, out_channels=c, n=n, e=csp_e, block=block), cspsppf, fuse_P2)
 
 
 class CSPBepBackbone_P6(CSPBepBackbone):

@@ -4,7 +4,7 @@ The bi-directional FPN is lowered concat-free: every `torch.cat` of the referenc
 (reppan.py:228,232 and common.py:718) becomes a pre-allocated NHWC buffer whose channel
 slices the producers write directly (conv epilogues take an output channel offset/stride).
 """
-from ..layers.common import BepC3, BiFusion, BottleRep, ConvBNReLU, HipModule, RepBlock, RepVGGBlock
+from ..layers.common import BepC3, BiFusion, BottleRep, ConvBNReLU, HipModule, MBLABlock, RepBlock, RepVGGBlock
 
 
 class _BiFPAN(HipModule):
@@ -73,10 +73,11 @@ class CSPRepBiFPANNeck(_BiFPAN):
         super().__init__()
         assert channels_list is not None
         assert num_repeats is not None
-        if stage_block_type != "BepC3":
+        if stage_block_type not in ("BepC3", "MBLABlock"):
             raise NotImplementedError
+        stage_block = BepC3 if stage_block_type == "BepC3" else MBLABlock      # reppan.py:559-564, :684-689
         c, n = channels_list, num_repeats
-        stage = lambda i, o, r: BepC3(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
+        stage = lambda i, o, r: stage_block(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
         self.reduce_layer0 = ConvBNReLU(in_channels=c[4], out_channels=c[5], kernel_size=1, stride=1)
         self.Bifusion0 = BiFusion(in_channels=[c[3], c[2]], out_channels=c[5])
         self.Rep_p4 = stage(c[5], c[5], n[5])
@@ -100,10 +101,11 @@ class CSPRepBiFPANNeck_P6(_BiFPAN):
         super().__init__()
         assert channels_list is not None
         assert num_repeats is not None
-        if stage_block_type != "BepC3":
+        if stage_block_type not in ("BepC3", "MBLABlock"):
             raise NotImplementedError
+        stage_block = BepC3 if stage_block_type == "BepC3" else MBLABlock      # reppan.py:559-564, :684-689
         c, n = channels_list, num_repeats
-        stage = lambda i, o, r: BepC3(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
+        stage = lambda i, o, r: stage_block(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
         self.reduce_layer0 = ConvBNReLU(in_channels=c[5], out_channels=c[6], kernel_size=1, stride=1)
         self.Bifusion0 = BiFusion(in_channels=[c[4], c[6]], out_channels=c[6])
         self.Rep_p5 = stage(c[6], c[6], n[6])
