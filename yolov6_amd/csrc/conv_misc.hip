@@ -686,12 +686,15 @@ static int check_conv_desc(const y6_conv_desc* d) {
 
 // default variant when a plan was not autotuned
 static int default_variant(const y6_conv_desc* d) {
-    // measured (profiles/r01 autotune logs): the pipelined persistent kernel wins 3x3 stride 1 (variants 10-12 are
+    // measured (profiles/r02 autotune logs): the LDS-DMA kernels win 3x3 stride 1 - 256-pixel blocks (variant 25) when
+    // there are at least two of them per CU slot, else 128-pixel blocks (26); then round 1's pipelined kernel (10-12 are
     // skipped by `supports` for 1x1); elsewhere high-occupancy small tiles win
-    const int prefs_s1[] = {10, 11, 12, 2, 1, 5, 4, 3, 6, 0};
+    const long items256 = ((long)d->out.B * d->out.H * d->out.W + 255) / 256 * ((d->out.C + 63) / 64);
+    const int dma_a = items256 >= 512 ? 25 : 26, dma_b = items256 >= 512 ? 26 : 25;
+    const int prefs_s1[] = {dma_a, dma_b, 10, 11, 12, 2, 1, 5, 4, 3, 6, 0};
     const int prefs_s2[] = {2, 1, 3, 0};
     const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
-    const int n = d->stride == 1 ? 10 : 4;
+    const int n = d->stride == 1 ? 12 : 4;
     for (int i = 0; i < n; ++i)
         if (y6_conv_variant_supports(d, prefs[i])) return prefs[i];
     return -1;
