@@ -252,12 +252,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
         const int iy0 = ty_i * a.TH * ST - 1, ix0 = tx_i * a.TW * ST - 1;
-        const int base = (((b * a.H + iy0) * a.W + ix0) * ics + ico) * ES;   // may be negative; valid pieces end up >= 0
+        // byte offsets are computed modulo 2^32 (tensors up to 3.5 GiB): unsigned arithmetic, the tile origin may lie one row /
+        // column outside the image and a valid piece still ends up at its true offset
+        const unsigned base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)ico) * (unsigned)ES;
 #pragma unroll
         for (int i = 0; i < NPWH; ++i) {
             const int hy = (int)(hinfo[i] >> 16), hx = (int)((hinfo[i] & 0xffffu) >> JB), h = (int)(hinfo[i] & ((1u << JB) - 1u));
             const bool v = (hinfo[i] != 0xffffffffu) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
-            hvoff[i] = v ? (unsigned)(base + (hy * a.W + hx) * ics * ES + h * 16) : kOob;
+            hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * ES) + (unsigned)(h * 16) : kOob;
         }
     };
     // the request cursor: the chunk whose pieces are requested next, STG-1 chunks ahead of the one being multiplied
@@ -603,8 +605,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             out_pix(a, id, opix);
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
-                obyteP[pf] = opix[pf] >= 0 ? (unsigned)((opix[pf] * a.out_cs + a.out_co) * 2) : kOob;
-                qbyteP[pf] = (I8 && opix[pf] >= 0) ? (unsigned)(opix[pf] * a.qout_cs + a.qout_co) : kOob;
+                obyteP[pf] = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;
+                qbyteP[pf] = (I8 && opix[pf] >= 0) ? (unsigned)opix[pf] * (unsigned)a.qout_cs + (unsigned)a.qout_co : kOob;
             }
             ocolP = (unsigned)(cb * CF * 32 + 8 * (lane >> 5));
             lbP = lbias;
