@@ -1,26 +1,29 @@
-// conv_dma.hip — 3x3 stride-1 convolution (fp16 and int8) fed entirely by LDS-DMA.
+// conv_dma.hip — 3x3 convolution (stride 1, fp16 and int8; a stride-2 form) fed entirely by LDS-DMA.
 //
 // Replaces the same aten compositions as conv_mfma.hip (reference yolov6/layers/common.py:51-54, :247-248, :338-339,
-// :605-608): RepVGG / ConvBNReLU / BottleRep 3x3 convs in deploy form, 84 % of the FLOPs of YOLOv6-S.
+// :605-608): RepVGG / QARepVGG / ConvBN{ReLU,SiLU} / BottleRep 3x3 convs in deploy form, 84 % of the FLOPs of YOLOv6-S.
 //
-// Why another kernel.  The pipelined kernel (conv_mfma_pipe_kernel) stages every byte through registers: global load ->
-// VGPR -> ds_write_b128.  The probes in DESIGN.md §6 put the fill at 43 % of its time, overlapping the MFMAs by a fifth:
+// Why another kernel.  Round 1's pipelined kernel (conv_mfma_pipe_kernel) stages every byte through registers: global load
+// -> VGPR -> ds_write_b128.  Its probes put the fill at 43 % of its time, overlapping the MFMAs by a fifth:
 // ds_write_b128 moves 79 B/clk/CU (MI355X_MICROARCH.md, LDS table) against 256 B/clk for the fragment reads, the staging
-// registers cap the kernel at 2 waves per SIMD, and every staged load drags VALU address selects with it.  Here
+// registers cap it at 2 waves per SIMD, and every staged load drags VALU address selects with it.  Here
 //   * BOTH operands arrive by `buffer_load_dwordx4 ... lds` (1 KiB per wave instruction, no VGPR, no ds_write); image
 //     borders and tile overhang are zero-filled by the buffer descriptor's range check (voffset past num_records);
-//   * the LDS image of the halo is two planes (channels 0-7 / 8-15 of the 16-channel chunk; int8: 0-15 / 16-31), 16 B per
-//     pixel per plane, row-major with the halo width as pitch - lane-linear, so a DMA piece is 64 consecutive slots and
-//     the source address does the gather.  Fragment pixel q of a 32-pixel MFMA fragment sits in lane frag_lane(q) such that
-//     the two 16-lane groups ds_read_b128 serves per cycle ({0-3,12-15,20-27} / {4-11,16-19,28-31}) each read 16
-//     CONSECUTIVE pixels: conflict-free for every tile width that is a multiple of 16, whatever the row pitch;
-//   * no staging registers -> 8 waves x c2p2 fit at 4 waves per SIMD: a block is 512 pixels x 64 couts (two blocks per
-//     CU), the weight image of a chunk is shared by twice the pixels of the pipe kernel (fill bytes per MFMA x 0.65);
-//   * one barrier per 16-channel chunk: `s_waitcnt vmcnt(0)` (the wave's own pieces of THIS chunk, issued a whole chunk
-//     of MFMAs ago) + s_barrier, then the pieces of the next chunk are issued into the other stage and the nine taps
-//     run.  The stream crosses work items, so the first chunk of the next (tile, cout block) lands during the epilogue.
-// The int8 form (v_mfma_i32_32x32x32_i8, BASELINE configs[4]) is the same data movement byte for byte: a chunk is 32
-// int8 channels = 32 B per pixel; it reads the int8 twin its producer wrote (include/yolov6_hip.h y6_conv_i8_desc.q_in).
+//   * halo image, 16-channel chunks: two planes (channels 0-7 / 8-15; int8: 0-15 / 16-31), 16 B per pixel per plane,
+//     row-major with the halo width as pitch - lane-linear, so a DMA piece is 64 consecutive slots and the SOURCE address
+//     does the gather; 32-channel chunks: pixel-major with a source-side XOR swizzle (template parameter HC below);
+//   * fragment pixel q of a 32-pixel MFMA fragment sits in the lane (frag_pixel) that puts the two 16-lane groups
+//     ds_read_b128 serves per cycle ({0-3,12-15,20-27} / {4-11,16-19,28-31}) on 16 CONSECUTIVE pixels each:
+//     conflict-free for every tile width that is a multiple of 16, whatever the row pitch;
+//   * one barrier per chunk: `s_waitcnt vmcnt(0)` (the wave's own pieces of THIS chunk, requested a whole chunk of MFMAs
+//     ago) + s_barrier; the pieces of the next chunk are requested one per MFMA unit into the other stage while the nine
+//     taps run.  The request stream crosses work items: the first chunk of the next (tile, cout block) lands early;
+//   * the epilogue of item k is deferred into item k+1's first chunk (second accumulator set; see `fast_unit`).
+// Production forms (autotuned per layer): 4 waves x (64 couts x 64 / 32 pixels per wave) = 256- / 128-pixel blocks, two /
+// three blocks per CU, 16-channel chunks; the 8-wave 512-pixel block with 32-channel chunks is the fastest in steady state
+// but pays a stage-start penalty on most boxes of this pool and is opt-in for fp16; int8 uses it.
+// The int8 form (v_mfma_i32_32x32x32_i8, BASELINE configs[4]) is the same data movement byte for byte: a chunk is 32 (64)
+// int8 channels = 32 (64) B per pixel; it reads the int8 twin its producer wrote (include/yolov6_hip.h y6_conv_i8_desc.q_in).
 #include <type_traits>
 
 #include "common.hpp"
@@ -206,8 +209,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     } while (0)
     DT(1);
 
-    // ---- this wave's pieces of a chunk image  [halo plane 0 | halo plane 1 | pad to 1 KiB][CF x 9 weight fragments]:
-    //      halo pieces P = wave + NW*i < NHP, weight fragments q = wave + NW*j < CF*9.
+    // ---- this wave's pieces of a chunk image  [halo (planes or pixel-major) | pad to 1 KiB][CF x 9 x KS weight fragments]:
+    //      halo pieces P = wave + NW*i < NHP, weight fragments q = wave + NW*j < WP.
     // Halo: slot s = 64*P + lane -> (plane h, halo row hy, halo column hx) is fixed for the whole kernel (hinfo, computed
     // once with the divisions); per work item only the tile origin changes: a scalar base offset plus two range checks.
     constexpr int NPWH = (MAXNHP + NW - 1) / NW;
@@ -363,8 +366,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     // ---- epilogues.
     // General (any activation, QARepVGG post-affine, residual, ragged channel counts, int8): after the item's last chunk, one
     // (cout fragment, pixel fragment) unit after the other, on arguments re-read from the kernarg segment.
-    // Fast + deferred (conv + bias + ReLU / identity into a 16-byte aligned view with whole 32-channel fragments - every
-    // RepVGG / ConvBNReLU 3x3 of the deploy graphs): the finished accumulators of item k stay in their registers while item
+    // Fast + deferred (conv + bias (+ int8 dequantisation) (+ QARepVGG post-affine) + activation, no residual, into a 16-byte
+    // aligned fp16 view and / or a 4-byte aligned int8 twin, whole cout blocks - every 3x3 of the deploy graphs but the
+    // BottleRep shortcut convs): the finished accumulators of item k stay in their registers while item
     // k+1 accumulates into a second set, and the units of item k are issued one per tap BEHIND the MFMAs of item k+1's first
     // chunk - the matrix pipe keeps running while the wave does bias / max / pack / store (before: the epilogue took 20 % of
     // an item's time at Cin 128 and 33 % at Cin 64 with the matrix pipe waiting, tools/dma_trace.py).  Stores go through a
