@@ -14,9 +14,10 @@
 //   chip: 2048-key chunks by bitonic networks in LDS, then a rank merge that also applies the
 //   max_nms cap (:90-91).
 // Stage 3 (nms_sweep_kernel): one 1024-thread block per image, windowed greedy sweep over the sorted
-//   list: xyxy boxes (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95) are built 2048 at a time
-//   in LDS, tested against the boxes already kept, and settled 64 candidates at a time, until
-//   max_det (:97-98) boxes are kept.
+//   list: xyxy boxes (:72, xywh2xyxy :21-28) offset by cls*max_wh (:94-95) are built 1024 at a time
+//   in LDS; only the prefix of the window that can still be needed is tested against the boxes already
+//   kept; up to 256 candidates per round are settled by a fixed-point iteration on their suppression
+//   matrix (= the sequential greedy order), until max_det (:97-98) boxes are kept.
 // Compile with -ffp-contract=off: index parity needs the reference's unfused fp32 arithmetic.
 #include "common.hpp"
 
