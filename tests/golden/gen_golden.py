@@ -287,6 +287,52 @@ def gen_loss():
                             dscores=ps.grad.numpy(), ddistri=pd.grad.numpy())
 
 
+LOSSDISTILL_CASES = {
+    # name: (B, feat sizes, C, iou_type, epoch, max_epoch, warmup_epoch, temperature, distill_feat, seed)
+    "tal_giou": (3, [(16, 16), (8, 8), (4, 4)], 20, "giou", 10, 100, 0, 20.0, False, 0),
+    "atss_warmup_feat": (2, [(16, 16), (8, 8), (4, 4)], 20, "giou", 1, 50, 4, 20.0, True, 1),
+    "siou_feat_late": (2, [(16, 16), (8, 8), (4, 4)], 80, "siou", 90, 100, 0, 10.0, True, 2),
+    "no_targets": (2, [(8, 8), (4, 4), (2, 2)], 20, "giou", 10, 100, 0, 20.0, True, 3),
+}
+
+
+def gen_loss_distill():
+    """reference self-distillation ComputeLoss (models/losses/loss_distill.py) on CPU (`.cuda()` of its two param-less
+    modules patched to a no-op): loss value, loss items, and the gradients it back-propagates to the STUDENT's class scores,
+    DFL logits and the three feature maps.  Teacher outputs / feature maps are a second synthetic draw."""
+    import torch.nn as nn
+    nn.Module.cuda = lambda self, device=None: self
+    from yolov6.models.losses.loss_distill import ComputeLoss
+    st, reg_max = [8, 16, 32], 16
+    for name, (B, fs, C, iou_type, epoch, max_epoch, warmup, temp, dfeat, seed) in LOSSDISTILL_CASES.items():
+        inp = synth.synth_loss_inputs(B, fs, st, C, reg_max, True, seed=seed)
+        tea = synth.synth_loss_inputs(B, fs, st, C, reg_max, True, seed=seed + 50)
+        if name == "no_targets":
+            inp["targets"] = inp["targets"][:0]
+        g = torch.Generator().manual_seed(1000 + seed)
+        chans = [16, 24, 32]
+        s_feats = [torch.randn((B, c, h, w), generator=g) for c, (h, w) in zip(chans, fs)]
+        t_feats = [torch.randn((B, c, h, w), generator=g) for c, (h, w) in zip(chans, fs)]
+        crit = ComputeLoss(fpn_strides=st, num_classes=C, ori_img_size=inp["img"], warmup_epoch=warmup, use_dfl=True,
+                           reg_max=reg_max, iou_type=iou_type, distill_feat=dfeat)
+        feats = [torch.zeros(B, 1, h, w) for h, w in fs]
+        ps = inp["pred_scores"].clone().requires_grad_(True)
+        pd = inp["pred_distri"].clone().requires_grad_(True)
+        sf = [f.clone().requires_grad_(True) for f in s_feats]
+        loss, items = crit((feats, ps, pd), (feats, tea["pred_scores"].clone(), tea["pred_distri"].clone()), sf, t_feats,
+                           inp["targets"].clone(), epoch, max_epoch, temp, 1, inp["img"], inp["img"])
+        loss.backward()
+        out = dict(loss=np.float64(float(loss)), items=items.numpy().astype(np.float64), dscores=ps.grad.numpy(),
+                   ddistri=pd.grad.numpy(),
+                   meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, reg_max=reg_max, iou_type=iou_type, epoch=epoch,
+                                        max_epoch=max_epoch, warmup_epoch=warmup, temperature=temp, distill_feat=dfeat,
+                                        seed=seed, feat_channels=chans)))
+        for i, f in enumerate(sf):
+            out[f"dfeat{i}"] = (f.grad if f.grad is not None else torch.zeros_like(f)).numpy()
+        np.savez_compressed(os.path.join(HERE, f"lossdistill_{name}.npz"), **out)
+        print(f"lossdistill_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
+
+
 FUSEAB_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "neck.Rep_p3.conv1.rbr_1x1.bn.weight", "detect.cls_convs.1.block.conv.weight",
                       "detect.cls_preds_ab.0.weight", "detect.reg_preds_ab.1.bias", "detect.reg_preds_ab.2.weight", "detect.cls_preds.2.bias"]
 LOSSAB_CASES = {
@@ -345,9 +391,11 @@ def gen_fuseab():
 
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train", "fuseab"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train", "fuseab", "lossdistill"]
     if "fuseab" in which:
         gen_fuseab()
+    if "lossdistill" in which:
+        gen_loss_distill()
     if "models" in which:
         gen_models()
     if "nms" in which:

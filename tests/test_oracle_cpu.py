@@ -322,3 +322,52 @@ def test_fuseab_state_dict_keys_match_reference():
     model = build_model(cfg, meta["num_classes"], "cpu", fuse_ab=True)
     got = {k: list(v.shape) for k, v in model.state_dict().items()}
     assert list(got) == list(meta["train"]) and got == meta["train"]
+
+
+# ------------------------------------------------------------------ self-distillation loss (f4 groundwork)
+LOSSDISTILL_GOLDEN = sorted(f[len("lossdistill_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("lossdistill_"))
+
+
+def _distill_inputs(m):
+    inp = synth.synth_loss_inputs(m["B"], m["feat_sizes"], m["strides"], m["C"], m["reg_max"], True, seed=m["seed"])
+    tea = synth.synth_loss_inputs(m["B"], m["feat_sizes"], m["strides"], m["C"], m["reg_max"], True, seed=m["seed"] + 50)
+    g = torch.Generator().manual_seed(1000 + m["seed"])
+    s_feats = [torch.randn((m["B"], c, h, w), generator=g) for c, (h, w) in zip(m["feat_channels"], m["feat_sizes"])]
+    t_feats = [torch.randn((m["B"], c, h, w), generator=g) for c, (h, w) in zip(m["feat_channels"], m["feat_sizes"])]
+    return inp, tea, [f.numpy() for f in s_feats], [f.numpy() for f in t_feats]
+
+
+@pytest.mark.parametrize("case", LOSSDISTILL_GOLDEN)
+def test_distill_loss_oracle_matches_reference_golden(case):
+    """oracle/loss_distill_oracle.py vs the unmodified reference's self-distillation ComputeLoss
+    (models/losses/loss_distill.py; tests/golden/gen_golden.py::gen_loss_distill): loss value and the four loss items; the
+    gradient golden of the feature maps against the closed form of the channel-wise term."""
+    from oracle import loss_distill_oracle as ldo
+    g = np.load(os.path.join(GOLDEN, f"lossdistill_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp, tea, s_feats, t_feats = _distill_inputs(m)
+    targets = inp["targets"].numpy()
+    if case == "no_targets":
+        targets = targets[:0]
+    out = ldo.compute_loss_distill(m["feat_sizes"], inp["pred_scores"].numpy(), inp["pred_distri"].numpy(),
+                                   tea["pred_scores"].numpy(), tea["pred_distri"].numpy(), s_feats, t_feats, targets,
+                                   m["epoch"], m["max_epoch"], m["temperature"], inp["img"], inp["img"],
+                                   fpn_strides=m["strides"], num_classes=m["C"], warmup_epoch=m["warmup_epoch"],
+                                   reg_max=m["reg_max"], iou_type=m["iou_type"], distill_feat=m["distill_feat"])
+    # fp32 reductions of ~1e3-sized sums in the reference: 5e-5 relative
+    np.testing.assert_allclose(out["loss"], float(g["loss"]), rtol=5e-5, atol=1e-5)
+    np.testing.assert_allclose(out["loss_items"], g["items"], rtol=5e-5, atol=1e-5)
+    assert (out["d_loss_cw"] > 0) == bool(m["distill_feat"])
+    # d loss / d student feature map = cwd * decay * (softmax_hw(s) - softmax_hw(t)) / (N C)   (temperature 1)
+    for i, (s, t) in enumerate(zip(s_feats, t_feats)):
+        ref = g[f"dfeat{i}"].astype(np.float64)
+        if not m["distill_feat"]:
+            assert not ref.any()
+            continue
+        N, C_, H, W = s.shape
+        ps = ldo._softmax64(s.reshape(N, C_, H * W), 2).reshape(s.shape)
+        pt = ldo._softmax64(t.reshape(N, C_, H * W), 2).reshape(s.shape)
+        want = 10.0 * out["decay"] * (ps - pt) / (N * C_)
+        assert float(np.abs(want - ref).max()) < 2e-4 * max(float(np.abs(ref).max()), 1e-12)
+    # the class-score gradient carries the KL term everywhere (also on images without targets)
+    assert float(np.abs(g["dscores"]).min()) >= 0.0 and float(np.abs(g["dscores"]).max()) > 0.0
