@@ -20,8 +20,10 @@ import numpy as np
 f32 = np.float32
 
 
-def nms(boxes, scores, iou_threshold):
-    """boxes [n,4] fp32 xyxy, scores [n] fp32 -> kept indices (int64) in descending-score order."""
+def nms(boxes, scores, iou_threshold, max_keep=None):
+    """boxes [n,4] fp32 xyxy, scores [n] fp32 -> kept indices (int64) in descending-score order.
+    max_keep: stop after that many kept boxes - the greedy sweep never looks back, so the first max_keep entries are the
+    same as those of the full result (the caller slices `[:max_det]`, nms.py:97-98); it only saves the oracle's time."""
     boxes = np.asarray(boxes, dtype=f32)
     scores = np.asarray(scores, dtype=f32)
     n = boxes.shape[0]
@@ -38,7 +40,7 @@ def nms(boxes, scores, iou_threshold):
         if suppressed[i]:
             continue
         keep.append(order[i])
-        if i + 1 == n:
+        if i + 1 == n or (max_keep is not None and len(keep) >= max_keep):
             break
         xx1 = np.maximum(x1[i], x1[i + 1:])
         yy1 = np.maximum(y1[i], y1[i + 1:])
@@ -102,7 +104,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             o = np.argsort(-det[:, 4], kind="stable")[:max_nms]
             det, flat = det[o], flat[o]
         off = det[:, 5:6] * (f32(0) if agnostic else max_wh)                              # :94
-        keep = nms(det[:, :4] + off, det[:, 4], iou_thres)                                # :95-96
+        keep = nms(det[:, :4] + off, det[:, 4], iou_thres, max_keep=max_det)              # :95-96
         keep = keep[:max_det]                                                             # :97-98
         out.append(det[keep].astype(f32))
         out_idx.append(flat[keep].astype(np.int64))
