@@ -333,6 +333,25 @@ def gen_loss_distill():
         print(f"lossdistill_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
 
 
+def gen_distill_ns():
+    """Model(..., distill_ns=True) (heads/effidehead_distill_ns.py): state_dict keys and the EVAL output of the tiny S graph."""
+    from yolov6.models.yolo import Model
+    cfile, over, size, batch, nc = MODEL_CASES["tiny"]
+    cfg = ref_config(cfile, over)
+    torch.manual_seed(0)
+    model = Model(cfg, channels=3, num_classes=nc, distill_ns=True).eval()
+    sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    x = synth.synth_images(batch, size, seed=1)
+    with torch.no_grad():
+        det, feats = model(x)
+    with open(os.path.join(HERE, "keys_tiny_distill_ns.json"), "w") as f:
+        json.dump(dict(config=cfile, overrides=over, size=size, batch=batch, num_classes=nc, training_mode=cfg.training_mode,
+                       train={k: list(v.shape) for k, v in model.state_dict().items()}), f)
+    np.savez_compressed(os.path.join(HERE, "model_tiny_distill_ns.npz"), det_train=det.numpy())
+    print(f"model_tiny_distill_ns: det {tuple(det.shape)} keys {len(model.state_dict())}")
+
+
 FUSEAB_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "neck.Rep_p3.conv1.rbr_1x1.bn.weight", "detect.cls_convs.1.block.conv.weight",
                       "detect.cls_preds_ab.0.weight", "detect.reg_preds_ab.1.bias", "detect.reg_preds_ab.2.weight", "detect.cls_preds.2.bias"]
 LOSSAB_CASES = {
@@ -391,11 +410,13 @@ def gen_fuseab():
 
 if __name__ == "__main__":
     install_stubs()
-    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train", "fuseab", "lossdistill"]
+    which = sys.argv[1:] or ["models", "nms", "tal", "atss", "loss", "train", "fuseab", "lossdistill", "distill_ns"]
     if "fuseab" in which:
         gen_fuseab()
     if "lossdistill" in which:
         gen_loss_distill()
+    if "distill_ns" in which:
+        gen_distill_ns()
     if "models" in which:
         gen_models()
     if "nms" in which:

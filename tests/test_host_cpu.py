@@ -250,3 +250,36 @@ def test_pmc_kernel_classification():
     assert classify(ns_ + "conv_mfma_kernel<2, 1, 1, 1>((anonymous namespace)::ConvKArgs)") == "conv1x1s1"
     assert classify(ns_ + "conv1x1_stream_kernel<1, 4>((anonymous namespace)::ConvKArgs)") == "conv1x1s1"
     assert classify("(anonymous namespace)::nms_sweep_kernel<1024>(float const*, int)") == "nms"
+
+
+def test_distill_ns_head_state_dict_abi_and_eval_oracle():
+    """Model(distill_ns=True) (heads/effidehead_distill_ns.py): parameter names / shapes / order equal the reference's, and the
+    eval branch (plain distances from reg_preds, no DFL) is the oracle's non-DFL head on the same weights, equal to the
+    reference's eval output (tests/golden/model_tiny_distill_ns.npz)."""
+    import copy
+    import json
+    import numpy as np
+    from oracle import synth
+    from oracle.model_oracle import Oracle
+    from tests.helpers import GOLDEN, synth_sd_from_keys
+    from yolov6_amd.configs import tiny_config
+    from yolov6_amd.models.yolo import build_model
+    with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+        meta = json.load(f)
+    cfg = tiny_config()
+    m = build_model(cfg, meta["num_classes"], "cpu", distill_ns=True)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(got.keys()) == list(meta["train"].keys())
+    assert got == meta["train"]
+    assert m.detect._eval_use_dfl() is False
+    sd = synth_sd_from_keys(meta["train"])
+    m.load_state_dict(sd)
+    ocfg = copy.deepcopy(cfg)
+    ocfg.model.head.use_dfl = False          # the distillation head's eval decode never projects DFL bins
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    with torch.no_grad():
+        det, _ = Oracle(ocfg, sd, meta["num_classes"]).forward(x, train_form=True)
+    g = np.load(os.path.join(GOLDEN, "model_tiny_distill_ns.npz"))["det_train"]
+    assert float(np.abs(det.numpy() - g).max() / max(1.0, float(np.abs(g).max()))) < 1e-4
+    with pytest.raises(NotImplementedError):
+        m.detect.lower_train(None, None)

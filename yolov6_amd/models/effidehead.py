@@ -87,6 +87,10 @@ class Detect(HipModule):
         pb.conv(f, w, b, stride=1, act=cc._activation_name(), out=both)
         return both.slice(0, nc_), both.slice(nc_, nr_)
 
+    def _eval_use_dfl(self):
+        """Does the EVAL branch decode DFL bins (effidehead.py:107-110)?  The distillation head never does."""
+        return bool(self.use_dfl)
+
     def lower(self, pb, x, out=None):
         if self.training:
             raise NotImplementedError("yolov6_amd: Detect's training branch runs through Model.forward in train mode "
@@ -102,7 +106,7 @@ class Detect(HipModule):
                 cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
                 rp = self.reg_preds[i]
                 reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
-        use_dfl = bool(self.use_dfl)
+        use_dfl = self._eval_use_dfl()
         # the reference's eval branch projects with proj_conv.weight (effidehead.py:107-109), not with self.proj;
         # the bin count comes from the loaded weight, not from the constructor default
         proj = self.proj_conv.weight.detach().reshape(-1) if use_dfl else None

@@ -112,8 +112,6 @@ def build_network(config, channels, num_classes, num_layers, fuse_ab=False, dist
     neck_cls = getattr(reppan, m.neck.type, None)
     if backbone_cls is None or neck_cls is None:
         raise NotImplementedError(f"yolov6_amd: backbone/neck {m.backbone.type}/{m.neck.type} is outside the HIP hot path")
-    if distill_ns:
-        raise NotImplementedError("yolov6_amd: the distillation head is outside the hot path (SURVEY §8f rank 4)")
     bkw = dict(in_channels=channels, channels_list=channels_list, num_repeats=num_repeat, block=block,
                fuse_P2=m.backbone.get('fuse_P2'), cspsppf=m.backbone.get('cspsppf'))
     nkw = dict(channels_list=channels_list, num_repeats=num_repeat, block=block)
@@ -122,6 +120,12 @@ def build_network(config, channels, num_classes, num_layers, fuse_ab=False, dist
         bkw.update(csp_e=m.backbone.csp_e, stage_block_type=stage_block_type)
         nkw.update(csp_e=m.neck.csp_e, stage_block_type=stage_block_type)
     backbone, neck = backbone_cls(**bkw), neck_cls(**nkw)
+    if distill_ns:   # yolo.py:114-120: the N / S head with an extra DFL branch for self-distillation (inference: plain distances)
+        from .heads.effidehead_distill_ns import Detect as DetectNS, build_effidehead_layer as build_ns
+        if num_layers != 3:
+            raise NotImplementedError("yolov6_amd: distill_ns needs a three-level head (the reference exits here, yolo.py:116-118)")
+        head_layers = build_ns(channels_list, 1, num_classes, reg_max=m.head.reg_max)
+        return backbone, neck, DetectNS(num_classes, num_layers, head_layers=head_layers, use_dfl=m.head.use_dfl)
     if fuse_ab:      # yolo.py:122-126: the head with the anchor-based auxiliary branch (training recipe `--fuse_ab`)
         from .heads.effidehead_fuseab import Detect as DetectAB, build_effidehead_layer as build_ab
         head_layers = build_ab(channels_list, 3, num_classes, reg_max=m.head.reg_max, num_layers=num_layers)
