@@ -17,6 +17,10 @@ its goldens are the groundwork):
   distill_weightdecay    :193-197  ((1 - cos(epoch pi / max_epoch)) / 2) (0.01 - 1) + 1 on the three distillation terms
   loss = class (cls + d_cls w_class) + iou iou + dfl (dfl + d_dfl w_dfl) + cwd d_cw          loss weights 1.0 / 2.5 / 0.5 / 10.0
 
+`pred_lrtb` given = the N / S variant, reference yolov6/models/losses/loss_distill_ns.py:59-200 (the head of
+heads/effidehead_distill_ns.py has a fourth training output, plain (l, t, r, b) distances from `reg_preds`): no ATSS warm-up
+(:96-104), and the IoU loss is the SUM of the DFL-decoded boxes' and the plain-distance boxes' losses (BboxLoss :265-325).
+
 Pinned to the unmodified reference: tests/golden/gen_golden.py `lossdistill` -> tests/golden/lossdistill_*.npz (values and the
 gradients the reference back-propagates to the student's scores, DFL logits and feature maps).
 """
@@ -77,7 +81,7 @@ def distill_loss_cw(s_feats, t_feats, temperature=1.0):
 def compute_loss_distill(feat_sizes, pred_scores, pred_distri, t_pred_scores, t_pred_distri, s_feats, t_feats, targets,
                          epoch_num, max_epoch, temperature, batch_height, batch_width, fpn_strides=(8, 16, 32),
                          grid_cell_size=5.0, grid_cell_offset=0.5, num_classes=80, warmup_epoch=0, use_dfl=True, reg_max=16,
-                         iou_type="giou", loss_weight=None, distill_feat=False, distill_weight=None):
+                         iou_type="giou", loss_weight=None, distill_feat=False, distill_weight=None, pred_lrtb=None):
     lw = loss_weight or {"class": 1.0, "iou": 2.5, "dfl": 0.5, "cwd": 10.0}
     dw = distill_weight or {"class": 1.0, "dfl": 1.0}
     pred_scores = np.asarray(pred_scores, f32)
@@ -92,7 +96,7 @@ def compute_loss_distill(feat_sizes, pred_scores, pred_distri, t_pred_scores, t_
     mask_gt = (gt_bboxes.sum(-1, keepdims=True) > 0).astype(f32)
     anchor_points_s = anchor_points / stride_t
     pred_bboxes = bbox_decode(anchor_points_s, pred_distri, use_dfl, reg_max)
-    if epoch_num < warmup_epoch:
+    if epoch_num < warmup_epoch and pred_lrtb is None:
         tl, tb, ts, fg = atss_oracle.assign(anchors, n_list, gt_labels, gt_bboxes, mask_gt, pred_bboxes * stride_t,
                                             topk=9, num_classes=num_classes)
     else:
@@ -112,6 +116,10 @@ def compute_loss_distill(feat_sizes, pred_scores, pred_distri, t_pred_scores, t_
     if int(fg.sum()) > 0:
         w = ts.sum(-1, dtype=f32)[fg][:, None]
         loss_iou = float((iou_loss(pred_bboxes[fg], tb[fg], iou_type) * w).sum(dtype=np.float64))
+        if pred_lrtb is not None:                     # loss_distill_ns.py:93, :284-292: dist2bbox(..., 'xyxy') of the plain distances
+            d = np.asarray(pred_lrtb, f32)
+            boxes_lrtb = np.concatenate([anchor_points_s[None] - d[..., :2], anchor_points_s[None] + d[..., 2:]], -1).astype(f32)
+            loss_iou += float((iou_loss(boxes_lrtb[fg], tb[fg], iou_type) * w).sum(dtype=np.float64))
         if ts_sum != 0:
             loss_iou /= ts_sum
         if use_dfl:

@@ -333,6 +333,41 @@ def gen_loss_distill():
         print(f"lossdistill_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
 
 
+def gen_loss_distill_ns():
+    """reference ComputeLoss of models/losses/loss_distill_ns.py (the N / S self-distillation loss: a fourth student output,
+    plain (l, t, r, b) distances): value, items, gradients to the student's scores, DFL logits and distances."""
+    import torch.nn as nn
+    nn.Module.cuda = lambda self, device=None: self
+    from yolov6.models.losses.loss_distill_ns import ComputeLoss
+    st, reg_max = [8, 16, 32], 16
+    for name in ("tal_giou", "atss_warmup_feat", "siou_feat_late"):
+        B, fs, C, iou_type, epoch, max_epoch, warmup, temp, dfeat, seed = LOSSDISTILL_CASES[name]
+        inp = synth.synth_loss_inputs(B, fs, st, C, reg_max, True, seed=seed)
+        tea = synth.synth_loss_inputs(B, fs, st, C, reg_max, True, seed=seed + 50)
+        g = torch.Generator().manual_seed(2000 + seed)
+        A = inp["pred_scores"].shape[1]
+        lrtb = (torch.rand((B, A, 4), generator=g) * 3.0 + 0.2)
+        chans = [16, 24, 32]
+        s_feats = [torch.randn((B, c, h, w), generator=g) for c, (h, w) in zip(chans, fs)]
+        t_feats = [torch.randn((B, c, h, w), generator=g) for c, (h, w) in zip(chans, fs)]
+        crit = ComputeLoss(fpn_strides=st, num_classes=C, ori_img_size=inp["img"], warmup_epoch=warmup, use_dfl=True,
+                           reg_max=reg_max, iou_type=iou_type, distill_feat=dfeat)
+        feats = [torch.zeros(B, 1, h, w) for h, w in fs]
+        ps = inp["pred_scores"].clone().requires_grad_(True)
+        pd = inp["pred_distri"].clone().requires_grad_(True)
+        pl = lrtb.clone().requires_grad_(True)
+        loss, items = crit((feats, ps, pd, pl), (feats, tea["pred_scores"].clone(), tea["pred_distri"].clone()), s_feats, t_feats,
+                           inp["targets"].clone(), epoch, max_epoch, temp, 1, inp["img"], inp["img"])
+        loss.backward()
+        np.savez_compressed(os.path.join(HERE, f"lossdistillns_{name}.npz"), loss=np.float64(float(loss)),
+                            items=items.numpy().astype(np.float64), dscores=ps.grad.numpy(), ddistri=pd.grad.numpy(),
+                            dlrtb=pl.grad.numpy(), lrtb=lrtb.numpy(),
+                            meta=json.dumps(dict(B=B, feat_sizes=fs, strides=st, C=C, reg_max=reg_max, iou_type=iou_type,
+                                                 epoch=epoch, max_epoch=max_epoch, warmup_epoch=warmup, temperature=temp,
+                                                 distill_feat=dfeat, seed=seed, feat_channels=chans)))
+        print(f"lossdistillns_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
+
+
 def gen_distill_ns():
     """Model(..., distill_ns=True) (heads/effidehead_distill_ns.py): state_dict keys and the EVAL output of the tiny S graph."""
     from yolov6.models.yolo import Model
@@ -417,6 +452,7 @@ if __name__ == "__main__":
         gen_loss_distill()
     if "distill_ns" in which:
         gen_distill_ns()
+        gen_loss_distill_ns()
     if "models" in which:
         gen_models()
     if "nms" in which:

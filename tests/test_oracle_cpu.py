@@ -371,3 +371,36 @@ def test_distill_loss_oracle_matches_reference_golden(case):
         assert float(np.abs(want - ref).max()) < 2e-4 * max(float(np.abs(ref).max()), 1e-12)
     # the class-score gradient carries the KL term everywhere (also on images without targets)
     assert float(np.abs(g["dscores"]).min()) >= 0.0 and float(np.abs(g["dscores"]).max()) > 0.0
+
+
+@pytest.mark.parametrize("case", ["tal_giou", "atss_warmup_feat", "siou_feat_late"])
+def test_distill_ns_loss_oracle_matches_reference_golden(case):
+    """The N / S variant (models/losses/loss_distill_ns.py; gen_golden.py::gen_loss_distill_ns): a fourth student output of plain
+    (l, t, r, b) distances whose IoU loss is added to the DFL branch's, TAL from epoch 0 (`atss_warmup_feat` has warmup_epoch 4
+    and epoch 1: this loss ignores it).  Value and items; the gradient golden of the distances is non-zero exactly on the
+    positives of the assignment."""
+    from oracle import loss_distill_oracle as ldo
+    g = np.load(os.path.join(GOLDEN, f"lossdistillns_{case}.npz"))
+    m = json.loads(str(g["meta"]))
+    inp, tea, _, _ = _distill_inputs(m)
+    gen = torch.Generator().manual_seed(2000 + m["seed"])
+    A = inp["pred_scores"].shape[1]
+    lrtb = (torch.rand((m["B"], A, 4), generator=gen) * 3.0 + 0.2).numpy()
+    np.testing.assert_array_equal(lrtb, g["lrtb"])
+    s_feats = [torch.randn((m["B"], c, h, w), generator=gen).numpy() for c, (h, w) in zip(m["feat_channels"], m["feat_sizes"])]
+    t_feats = [torch.randn((m["B"], c, h, w), generator=gen).numpy() for c, (h, w) in zip(m["feat_channels"], m["feat_sizes"])]
+    kw = dict(fpn_strides=m["strides"], num_classes=m["C"], warmup_epoch=m["warmup_epoch"], reg_max=m["reg_max"],
+              iou_type=m["iou_type"], distill_feat=m["distill_feat"])
+    args = (m["feat_sizes"], inp["pred_scores"].numpy(), inp["pred_distri"].numpy(), tea["pred_scores"].numpy(),
+            tea["pred_distri"].numpy(), s_feats, t_feats, inp["targets"].numpy(), m["epoch"], m["max_epoch"], m["temperature"],
+            inp["img"], inp["img"])
+    out = ldo.compute_loss_distill(*args, pred_lrtb=lrtb, **kw)
+    np.testing.assert_allclose(out["loss"], float(g["loss"]), rtol=5e-5, atol=1e-5)
+    np.testing.assert_allclose(out["loss_items"], g["items"], rtol=5e-5, atol=1e-5)
+    # the extra IoU term is what separates it from loss_distill.py on the same inputs (where the assigner is the same)
+    if m["epoch"] >= m["warmup_epoch"]:
+        base = ldo.compute_loss_distill(*args, **kw)
+        assert out["loss_items"][0] > base["loss_items"][0]
+        np.testing.assert_allclose(out["loss_items"][1:], base["loss_items"][1:], rtol=1e-12)
+    touched = np.abs(g["dlrtb"]).sum(-1) > 0
+    assert int(touched.sum()) == out["num_pos"]
