@@ -69,6 +69,9 @@ MODEL_CASES = {
     # MBLABlock stages (conv_silu): width 0.25 keeps the branch width a multiple of 8; depth 0.5 gives both branch shapes
     # (n_list [0, 1] and [0, 1, 2])
     "s_mbla_tiny": ("configs/mbla/yolov6s_mbla.py", dict(width_multiple=0.25, depth_multiple=0.5), 64, 1, 20),
+    # the other 1280-pixel families: EfficientRep6 + RepBiFPANNeck6 (N6 / S6), CSPBepBackbone_P6 with csp_e 2/3 (M6)
+    "n6": ("configs/yolov6n6.py", {}, 128, 1, 80),
+    "m6_tiny": ("configs/yolov6m6.py", dict(width_multiple=0.125, depth_multiple=0.34), 128, 1, 20),
 }
 
 

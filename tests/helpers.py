@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # golden case -> built-in config name (tests must not read /root/reference)
 CASE_CONFIG = {"tiny": "yolov6s", "n": "yolov6n", "s": "yolov6s", "s_qa_tiny": "yolov6s_qa", "l6_tiny": "yolov6l6",
-               "m_tiny": "yolov6m", "s_mbla_tiny": "yolov6s_mbla"}
+               "m_tiny": "yolov6m", "s_mbla_tiny": "yolov6s_mbla", "n6": "yolov6n6", "m6_tiny": "yolov6m6"}
 
 
 def case_meta(case):

@@ -112,6 +112,30 @@ _MODELS = {
 }
 
 
+def _p6(name, depth, width, backbone, neck, csp, iou, use_dfl, reg_max, extra_backbone=None):
+    """configs/yolov6{n,s,m}6.py: the 1280-pixel models with a stride-64 level."""
+    b = dict(type=backbone, num_repeats=[1, 6, 12, 18, 6, 6], out_channels=[64, 128, 256, 512, 768, 1024], fuse_P2=True)
+    n = dict(type=neck, num_repeats=[12, 12, 12, 12, 12, 12], out_channels=[512, 256, 128, 256, 512, 1024])
+    if csp is not None:
+        b["csp_e"] = csp
+        n["csp_e"] = csp
+    b.update(extra_backbone or {})
+    return dict(type=name, pretrained=None, depth_multiple=depth, width_multiple=width, backbone=b, neck=n,
+                head=dict(type='EffiDeHead', in_channels=[128, 256, 512, 1024], num_layers=4, anchors=1,
+                          strides=[8, 16, 32, 64], atss_warmup_epoch=4, iou_type=iou, use_dfl=use_dfl, reg_max=reg_max,
+                          distill_weight={'class': 1.0, 'dfl': 1.0}))
+
+
+_MODELS.update({
+    "yolov6n6": dict(model=_p6('YOLOv6n6', 0.33, 0.25, 'EfficientRep6', 'RepBiFPANNeck6', None, 'siou', False, 0,
+                               dict(cspsppf=True)), training_mode="repvgg"),
+    "yolov6s6": dict(model=_p6('YOLOv6s6', 0.33, 0.50, 'EfficientRep6', 'RepBiFPANNeck6', None, 'giou', False, 0,
+                               dict(cspsppf=True)), training_mode="repvgg"),
+    "yolov6m6": dict(model=_p6('YOLOv6m6', 0.60, 0.75, 'CSPBepBackbone_P6', 'CSPRepBiFPANNeck_P6', float(2) / 3, 'giou', True, 16),
+                     training_mode="repvgg"),
+})
+
+
 def get_config(name):
     """Built-in model config by name ('yolov6s', ...)."""
     if name not in _MODELS:

@@ -90,22 +90,13 @@ class CSPRepBiFPANNeck(_BiFPAN):
         self.Rep_n4 = stage(c[5] + c[9], c[10], n[8])
 
 
-class CSPRepBiFPANNeck_P6(_BiFPAN):
-    '''CSP RepBiFPAN neck with a P6 level (YOLOv6-M6/L6).  Reference: reppan.py:955-1116.'''
+class _BiFPAN6(_BiFPAN):
+    """Four-level (P3..P6) wiring shared by the plain and the CSP neck (reppan.py:394-541, :955-1116)."""
     _td = (("reduce_layer0", "Bifusion0", "Rep_p5"), ("reduce_layer1", "Bifusion1", "Rep_p4"),
            ("reduce_layer2", "Bifusion2", "Rep_p3"))
     _bu = (("downsample2", "Rep_n4"), ("downsample1", "Rep_n5"), ("downsample0", "Rep_n6"))
 
-    def __init__(self, channels_list=None, num_repeats=None, block=BottleRep, csp_e=float(1) / 2,
-                 stage_block_type="BepC3"):
-        super().__init__()
-        assert channels_list is not None
-        assert num_repeats is not None
-        if stage_block_type not in ("BepC3", "MBLABlock"):
-            raise NotImplementedError
-        stage_block = BepC3 if stage_block_type == "BepC3" else MBLABlock      # reppan.py:559-564, :684-689
-        c, n = channels_list, num_repeats
-        stage = lambda i, o, r: stage_block(in_channels=i, out_channels=o, n=r, e=csp_e, block=block)
+    def _build6(self, c, n, stage):
         self.reduce_layer0 = ConvBNReLU(in_channels=c[5], out_channels=c[6], kernel_size=1, stride=1)
         self.Bifusion0 = BiFusion(in_channels=[c[4], c[6]], out_channels=c[6])
         self.Rep_p5 = stage(c[6], c[6], n[6])
@@ -121,3 +112,28 @@ class CSPRepBiFPANNeck_P6(_BiFPAN):
         self.Rep_n5 = stage(c[7] + c[9], c[10], n[10])
         self.downsample0 = ConvBNReLU(in_channels=c[10], out_channels=c[10], kernel_size=3, stride=2)
         self.Rep_n6 = stage(c[6] + c[10], c[11], n[11])
+
+
+class RepBiFPANNeck6(_BiFPAN6):
+    '''RepBiFPAN neck with a P6 level (YOLOv6-N6/S6).  Reference: reppan.py:394-541.'''
+
+    def __init__(self, channels_list=None, num_repeats=None, block=RepVGGBlock):
+        super().__init__()
+        assert channels_list is not None
+        assert num_repeats is not None
+        self._build6(channels_list, num_repeats, lambda i, o, r: RepBlock(in_channels=i, out_channels=o, n=r, block=block))
+
+
+class CSPRepBiFPANNeck_P6(_BiFPAN6):
+    '''CSP RepBiFPAN neck with a P6 level (YOLOv6-M6/L6).  Reference: reppan.py:955-1116.'''
+
+    def __init__(self, channels_list=None, num_repeats=None, block=BottleRep, csp_e=float(1) / 2,
+                 stage_block_type="BepC3"):
+        super().__init__()
+        assert channels_list is not None
+        assert num_repeats is not None
+        if stage_block_type not in ("BepC3", "MBLABlock"):
+            raise NotImplementedError
+        stage_block = BepC3 if stage_block_type == "BepC3" else MBLABlock      # reppan.py:559-564, :684-689
+        self._build6(channels_list, num_repeats,
+                     lambda i, o, r: stage_block(in_channels=i, out_channels=o, n=r, e=csp_e, block=block))
