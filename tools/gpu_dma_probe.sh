@@ -14,7 +14,7 @@ cat "$OUT/trace.log" | cut -c1-900
 echo "== probes (ms per layer; base first)"
 V="${PROBE_V:-24 25 26}"
 ( echo base; timeout 300 python tools/conv_bench.py --layers $L --variants $V --iters 20 ) > "$OUT/probe_base.log" 2>&1
-for n in ${PROBES:-2 3 4 5 6}; do
+for n in ${PROBES:-2 7 8 3 4 5 6}; do
   ( echo probe $n; Y6_LIB_PATH=tools/_build/libyolov6_hip_dmaprobe$n.so timeout 300 python tools/conv_bench.py --layers $L --variants $V --iters 20 ) > "$OUT/probe_$n.log" 2>&1
 done
 grep -h "probe\|base\|ms" "$OUT"/probe_*.log | grep -v amdgpu

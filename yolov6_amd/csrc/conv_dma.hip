@@ -72,11 +72,14 @@ __device__ __forceinline__ ConvKArgs reload_args() {
 // Ceiling probes / trace (tools/build_probe_libs.py --dma; WRONG RESULTS for n >= 2, timing only), compile-time:
 //   1 = s_memtime trace of block 0 / thread 0 into a.dbg (tools/dma_trace.py); 2 = no epilogue; 3 = no MFMAs;
 //   4 = no LDS-DMA requests after the prologue; 5 = fragment reads of tap 0 only (MFMAs on stale operands);
-//   6 = no chunk barrier / vmcnt wait
+//   6 = no chunk barrier / vmcnt wait; 7 = as 2, and no weight requests (halo requests + barriers only); 8 = as 2, and no halo
+//   requests (weight requests + barriers only).  (With the epilogue gone the compiler drops the MFMAs and fragment reads as
+//   dead code: 2 / 7 / 8 time the requests and the chunk barriers alone.)
 #ifndef Y6_DMA_PROBE
 #define Y6_DMA_PROBE 0
 #endif
 constexpr int kDmaProbe = Y6_DMA_PROBE;
+constexpr bool kProbeNoEpilogue = kDmaProbe == 2 || kDmaProbe == 7 || kDmaProbe == 8;
 
 // Halo image of the 16-channel-chunk kernels: 1 = two planes (channels 0-7 / 8-15), one cache line per lane of a request but
 // fragment addresses that are a constant offset per tap; 0 = pixel-major with the piece index XOR bit 3 of the pixel index
@@ -280,11 +283,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     auto issue_piece = [&](int k) {   // k: compile-time index, halo pieces first (longest latency)
         if (k < NPWH) {
             const int P = wave + NW * k;
-            if (P < NHP && (kDmaProbe != 4 || !in_loop)) dma16(rsA, hvoff[k < NPWH ? k : 0], c_soffA, c_dst0 + P * 1024);
+            if (P < NHP && (kDmaProbe != 4 || !in_loop) && kDmaProbe != 8) dma16(rsA, hvoff[k < NPWH ? k : 0], c_soffA, c_dst0 + P * 1024);
         } else if (k < NPIECE) {
             const int j = k - NPWH;
             const int q = wave + NW * j;
-            if (q < WP && (kDmaProbe != 4 || !in_loop)) dma16(rsW, lane16, c_soffW + wsoff[j < NPWW ? j : 0], c_dst0 + (NHP + q) * 1024);
+            if (q < WP && (kDmaProbe != 4 || !in_loop) && kDmaProbe != 7) dma16(rsW, lane16, c_soffW + wsoff[j < NPWW ? j : 0], c_dst0 + (NHP + q) * 1024);
         }
     };
     auto cursor_advance = [&]() {
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             bz.v[0][g * 4 + 2] = t.z;
             bz.v[0][g * 4 + 3] = t.w;
         }
-        if (kDmaProbe == 2) return;
+        if (kProbeNoEpilogue) return;
         const int op1[1] = {opx[pf]};
         if constexpr (I8) {
             BiasRegs<1> qs;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                 for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
             }
         }
-        if (kDmaProbe == 2) return;
+        if (kProbeNoEpilogue) return;
         unsigned pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
