@@ -1144,7 +1144,10 @@ const VariantCfg kVariants[] = {
     // hc = 32: 32-channel chunks, four lanes of a request per pixel (16 cache lines per request instead of 64)
     {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 2, 4, "dmaw8f_c2p2", 8, 3, 2, 32},   // f: three requests per unit (front-loaded)
     // cs = 2: stride-2 forms (parity-split halo rows): 128 output pixels x 64 couts, two blocks per CU / 256 pixels, one block
-    {2, 1, 4, "dmas2_c2p1", 4, 1, 2, 16, 2}, {2, 1, 4, "dma8s2_c2p1", 8, 1, 2, 16, 2}};
+    {2, 1, 4, "dmas2_c2p1", 4, 1, 2, 16, 2}, {2, 1, 4, "dma8s2_c2p1", 8, 1, 2, 16, 2},
+    // 128 couts x 256 pixels on eight waves: the halo requests of a chunk feed twice the MFMAs of dma_c2p2 (DESIGN.md 6b.7;
+    // written after round 2's last GPU visit - not in the default candidate set until it has been measured)
+    {4, 1, 4, "dma8_c4p1", 8}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1623,7 +1626,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, s);
     }
