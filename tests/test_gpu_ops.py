@@ -1,5 +1,7 @@
 """GPU: every HIP kernel against a plain fp32 CPU statement of the same op, through the C ABI.
 Tolerance (north_star): 1e-3 on values (relative to max(1,|ref|)); exact for pooling/layout."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -81,7 +83,10 @@ def test_conv_dma_variants_full_tiles():
     names = G.variant_names()
     dma = [v for v, n in enumerate(names) if n.startswith("dma")]
     assert len(dma) >= 3
-    for (Cin, Cout, H, W, B) in [(64, 128, 80, 80, 6), (16, 64, 50, 70, 5), (128, 64, 36, 52, 4), (32, 160, 21, 19, 9)]:
+    shapes = [(64, 128, 80, 80, 6), (16, 64, 50, 70, 5), (128, 64, 36, 52, 4), (32, 160, 21, 19, 9)]
+    if os.environ.get("Y6_TEST_UNSEEN") == "1":   # the 512-pixel one-block-per-CU forms: more than 256 work items, two / one cout blocks
+        shapes += [(64, 128, 96, 96, 10), (64, 64, 160, 160, 8)]
+    for (Cin, Cout, H, W, B) in shapes:
         x = G.rand_nhwc(B, H, W, Cin, seed=21)
         w, b = _mk_weights(Cout, Cin, 3, 22)
         ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, 1, "relu")

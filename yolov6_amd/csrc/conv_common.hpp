@@ -383,6 +383,7 @@ struct VariantCfg {
     int depth = 2;   // pipe kernels: chunks the halo fill runs ahead; dma kernels: LDS stages
     int hc = 16;     // dma kernels: input channels per chunk
     int cs = 1;      // dma kernels: the conv stride they are built for
+    int wres = 0;    // dma kernels: 1 = the block's tap images stay in LDS for all its work items (Cin <= 64)
 };
 
 struct Launch {

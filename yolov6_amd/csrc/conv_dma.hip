@@ -145,9 +145,14 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 //     ones (slot = hy * RP + (hx & 1 ? RPE : 0) + (hx >> 1), RPE = number of even columns) - the source address does the
 //     de-interleave - so that the 16 consecutive output pixels of a read group (input columns 2 tx + kx) read 16 CONSECUTIVE
 //     slots for every tap, as with stride 1: kx = 0 -> even slot tx, kx = 1 -> odd slot tx, kx = 2 -> even slot tx + 1.
-template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1>
+// WRES: the block's weights stay in LDS for all its work items (layers of at most 64 input channels: 9 x Cin x CF*32 fp16 =
+//     72 KB at CF 2) - a stage holds the halo only, and the host sizes the grid so that every item of a block has the same
+//     cout block.  Without it 62-75 % of the bytes a block requests are tap images re-fetched from L2 for every tile
+//     (tools/dma_model.py).
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1, bool WRES = false>
 __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKArgs a) {
     static_assert(ST == 1 || (HC == 16 && Y6_DMA_PLANAR16 != 0), "stride 2 is built on the planar 16-channel-chunk image");
+    static_assert(!WRES || (!I8 && ST == 1 && STG == 2), "resident weights: fp16, stride 1, two halo stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename AccT<I8>::type acc_t;
     constexpr int NT = 9;
@@ -163,10 +168,11 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RP = a.dma_rp, PLs = a.dma_pls, NHP = a.dma_nhp;
-    const int stage_bytes = (NHP + WP) * 1024;
+    const int stage_bytes = (NHP + (WRES ? 0 : WP)) * 1024;
     const unsigned smem_base = lds_addr(smem);
     float* ldsBias = reinterpret_cast<float*>(smem + STG * stage_bytes);   // [item parity][bias | post scale | post shift | dequant scale][CF*32]
     const int nch = a.Cin / (I8 ? 2 * HC : HC);
+    if constexpr (WRES) ldsBias += nch * WP * 256;   // resident tap images [chunk][cf][tap][k-step] sit between the halo stages and these vectors
     const int nids = a.nids;
     const int gstride = gridDim.x;
 
@@ -278,13 +284,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         c_soffW = KS == 1 ? (unsigned)(((c_cb * CF * a.nchunk + (c_chunk >> 1)) * NT * 2 + (c_chunk & 1)) * 1024)
                           : (unsigned)(((c_cb * CF * a.nchunk + c_chunk) * NT * 2) * 1024);
     };
-    constexpr int NPIECE = NPWH + NPWW;
+    constexpr int NPIECE = NPWH + (WRES ? 0 : NPWW);
     bool in_loop = false;
     auto issue_piece = [&](int k) {   // k: compile-time index, halo pieces first (longest latency)
         if (k < NPWH) {
             const int P = wave + NW * k;
             if (P < NHP && (kDmaProbe != 4 || !in_loop) && kDmaProbe != 8) dma16(rsA, hvoff[k < NPWH ? k : 0], c_soffA, c_dst0 + P * 1024);
-        } else if (k < NPIECE) {
+        } else if (!WRES && k < NPIECE) {
             const int j = k - NPWH;
             const int q = wave + NW * j;
             if (q < WP && (kDmaProbe != 4 || !in_loop) && kDmaProbe != 7) dma16(rsW, lane16, c_soffW + wsoff[j < NPWW ? j : 0], c_dst0 + (NHP + q) * 1024);
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
 #pragma unroll
     for (int k = 0; k < NPWH; ++k) npw += (wave + NW * k < NHP) ? 1 : 0;
 #pragma unroll
-    for (int j = 0; j < NPWW; ++j) npw += (wave + NW * j < WP) ? 1 : 0;
+    for (int j = 0; j < NPWW; ++j) npw += (!WRES && wave + NW * j < WP) ? 1 : 0;
 
     // ---- this lane's pixels: position in the tile (fixed for the whole kernel: computed once, with the divisions), LDS
     //      offsets of the fragment reads; per work item only the tile origin changes (scalar) - output offsets are one
@@ -351,6 +357,23 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     setup_halo(id);
     setup_pix(id);
     c_cb = cb;
+    if constexpr (WRES) {   // every tap image of this block's cout block, once; they land before the first chunk barrier
+        constexpr int MAXCH = 64 / HC;
+        constexpr int NPWR = (MAXCH * WP + NW - 1) / NW;
+        const unsigned dstR = smem_base + STG * stage_bytes;
+#pragma unroll
+        for (int j = 0; j < NPWR; ++j) {
+            const int q = wave + NW * j;
+            if (q < nch * WP) {
+                const int c = q / WP, f = q - c * WP;
+                const int ct = f / KS, ks = f - ct * KS;
+                const int cfi = ct / NT, tap = ct - cfi * NT;
+                const unsigned chunk_off = KS == 1 ? (unsigned)(((cb * CF * a.nchunk + (c >> 1)) * NT * 2 + (c & 1)) * 1024)
+                                                   : (unsigned)(((cb * CF * a.nchunk + c) * NT * 2) * 1024);
+                dma16(rsW, lane16, chunk_off + (unsigned)(((cfi * a.nchunk * NT + tap) * 2 + ks) * 1024), dstR + q * 1024);
+            }
+        }
+    }
 #pragma unroll
     for (int st = 0; st < STG - 1; ++st) {
         if (c_valid) {
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             }
             const bool epi_now = FAST && haveP && chunk == 0;
             const char* Ab = smem + pb * stage_bytes;
-            const char* Wb = Ab + NHP * 1024 + lane * 16;
+            const char* Wb = WRES ? smem + STG * stage_bytes + chunk * (WP * 1024) + lane * 16 : Ab + NHP * 1024 + lane * 16;
             constexpr int NU = NT * KS;                               // MFMA units (tap, k-step) per chunk
             constexpr int PPU0 = (NPIECE + NU - 2) / (NU - 1);        // DMA pieces per unit: all requested before the last one,
             constexpr int PPU = IL > PPU0 ? IL : PPU0;                // or IL per unit (front-loaded)
@@ -675,9 +698,9 @@ __global__ void dma_probe_kernel(const char* src, unsigned bytes, unsigned lds_o
     *reinterpret_cast<uint4*>(dst + lane * 16) = *reinterpret_cast<const uint4*>(smem + lds_off + lane * 16);
 }
 
-template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1>
+template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1, bool WRES = false>
 int launch_dma(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8, ST>;
+    auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8, ST, WRES>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -698,8 +721,11 @@ int launch_dma(const Launch& L, hipStream_t s) {
         cached_lds = L.lds;
     }
     int grid = n_cu * cached_bpc;
-    grid -= grid % 8;                 // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple
-    if (grid < 8) grid = 8;
+    // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple.  Resident weights: a multiple of 8 * ncb,
+    // so that (id >> 3) % ncb - the cout block - is the same for every item of a block
+    const int gq = (WRES && L.k.ncb > 1) ? 8 * L.k.ncb : 8;
+    grid -= grid % gq;
+    if (grid < gq) grid = gq;
     if (grid > L.grid) grid = L.grid;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), L.lds, s, L.k);
     Y6_LAUNCH_CHECK();
@@ -707,7 +733,17 @@ int launch_dma(const Launch& L, hipStream_t s) {
 }
 
 template <bool I8>
-int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, int stride, hipStream_t s) {
+int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, int stride, int wres, hipStream_t s) {
+    if (wres) {
+        if constexpr (!I8) {
+            if (stride == 1 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) {
+                if (hc == 16) return launch_dma<2, 2, 8, 2, 2, 1, 16, false, 1, true>(L, s);
+                if (hc == 32) return launch_dma<2, 2, 8, 2, 2, 1, 32, false, 1, true>(L, s);
+            }
+        }
+        y6_set_error("conv_dma: no resident-weight instantiation c%dp%d x %d waves, %d-channel chunks", cf, pf, nw, hc);
+        return Y6_EUNSUPPORTED;
+    }
     if (stride == 2) {
         if constexpr (!I8) {
             if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 2, 1, 16, false, 2>(L, s);
@@ -739,10 +775,10 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
 }  // namespace
 
 // L points at conv_mfma.hip's launch record (same struct: conv_common.hpp)
-int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int hc, int stride, int i8, hipStream_t s) {
+int y6_conv_dma_launch(const void* L, int cf, int pf, int nw, int stages, int interleave, int hc, int stride, int i8, int wres, hipStream_t s) {
     const Launch& l = *static_cast<const Launch*>(L);
-    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, hc, stride, s)
-              : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, hc, stride, s);
+    return i8 ? launch_dma_cfg<true>(l, cf, pf, nw, stages, interleave, hc, stride, wres, s)
+              : launch_dma_cfg<false>(l, cf, pf, nw, stages, interleave, hc, stride, wres, s);
 }
 
 int y6_conv_dma_halo_cap(int bp, int stride) {

@@ -1147,7 +1147,10 @@ const VariantCfg kVariants[] = {
     {2, 1, 4, "dmas2_c2p1", 4, 1, 2, 16, 2}, {2, 1, 4, "dma8s2_c2p1", 8, 1, 2, 16, 2},
     // 128 couts x 256 pixels on eight waves: the halo requests of a chunk feed twice the MFMAs of dma_c2p2 (DESIGN.md 6b.7;
     // written after round 2's last GPU visit - not in the default candidate set until it has been measured)
-    {4, 1, 4, "dma8_c4p1", 8}};
+    {4, 1, 4, "dma8_c4p1", 8},
+    // wres = 1: resident weights (layers of at most 64 input channels), 512 pixels x 64 couts on eight waves, one block per CU;
+    // 16-channel chunks (planar halo) / 32-channel chunks (pixel-major halo).  Also written after the last GPU visit.
+    {2, 2, 4, "dmar8_c2p2", 8, 1, 2, 16, 1, 1}, {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1267,7 +1270,9 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
         k.dma_nhp = y6_cdiv((vc.hc / 8) * k.dma_pls, 64);
-        L->lds = vc.depth * (size_t)(k.dma_nhp + 9 * vc.cf * (vc.hc / 16)) * 1024 + 8 * vc.cf * 32 * 4;   // stages of (halo + tap images), per-channel vectors [2 parities][bias | post scale | post shift | dequant]
+        const size_t wp = 9 * vc.cf * (vc.hc / 16);   // tap images of a chunk, KiB
+        L->lds = vc.wres ? vc.depth * (size_t)k.dma_nhp * 1024 + (size_t)(k.Cin / vc.hc) * wp * 1024 + 8 * vc.cf * 32 * 4   // halo stages, resident tap images of all chunks
+                         : vc.depth * (size_t)(k.dma_nhp + wp) * 1024 + 8 * vc.cf * 32 * 4;   // stages of (halo + tap images), per-channel vectors [2 parities][bias | post scale | post shift | dequant]
     } else if (vc.persist == 2)
         L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
     else if (vc.persist)
@@ -1533,7 +1538,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
-    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, 1, s);
+    if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, 1, 0, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
         case 2: return launch_i8_cfg<2, 1>(L, d.ksize, d.stride, s);
@@ -1570,6 +1575,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
         if (st != vc.cs || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here; vc.cs the stride)
         if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
+        if (vc.wres && d->in.C > 64) return 0;   // 9 x Cin x 64 couts of fp16 must fit beside two halo stages
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
         if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;   // byte offsets + the range-check sentinel
         return vc.cf <= y6_cdiv(d->out.C, 32);
@@ -1626,9 +1632,9 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
-                                      kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, s);
+                                      kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
     }
     return Y6_EINVAL;
 }
