@@ -319,7 +319,7 @@ class Oracle:
         a = self.a
         nb = 6 if a.p6 else 5  # number of backbone entries in channels_list / num_repeats
         if not a.p6:
-            x3, x2, x1, x0 = feats
+            x3, x2, x1, x0 = feats if len(feats) == 4 else [None] + list(feats)     # the PAN necks take three maps (no fuse_P2)
             names = dict(td=[("reduce_layer0", "Bifusion0", "Rep_p4", nb + 0), ("reduce_layer1", "Bifusion1", "Rep_p3", nb + 1)],
                          bu=[("downsample2", "Rep_n3", nb + 2), ("downsample1", "Rep_n4", nb + 3)])
             pyr = [x3, x2, x1, x0]
@@ -331,9 +331,14 @@ class Oracle:
             pyr = list(feats)
         cur = pyr[-1]
         laterals = []
+        pan = "BiFPAN" not in a.neck      # RepPANNeck / RepPANNeck6 / CSPRepPANNeck / CSPRepPANNeck_P6 (reppan.py:81-102, :352-391)
         for i, (red, fus, stg, ri) in enumerate(names["td"]):
             fpn = self.convbn(cur, "neck." + red, "relu")
             laterals.append(fpn)
+            if pan:     # cat([upsample_i(fpn_out_i), backbone map]) -> stage
+                up = self.transpose(fpn, f"neck.upsample{i}")
+                cur = self.stage(torch.cat([up, pyr[-2 - i]], 1), "neck." + stg, a.n[ri])
+                continue
             cur = self.stage(self.bifusion([fpn, pyr[-2 - i], pyr[-3 - i]], "neck." + fus), "neck." + stg, a.n[ri])
         outs = [cur]
         for j, (down, stg, ri) in enumerate(names["bu"]):

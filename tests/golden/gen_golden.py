@@ -72,13 +72,22 @@ MODEL_CASES = {
     # the other 1280-pixel families: EfficientRep6 + RepBiFPANNeck6 (N6 / S6), CSPBepBackbone_P6 with csp_e 2/3 (M6)
     "n6": ("configs/yolov6n6.py", {}, 128, 1, 80),
     "m6_tiny": ("configs/yolov6m6.py", dict(width_multiple=0.125, depth_multiple=0.34), 128, 1, 20),
+    # the uni-directional PAN necks of the v2.0 models (dotted keys override nested config entries)
+    "t_pan": ("configs/experiment/yolov6t.py", {}, 64, 1, 80),
+    "s_csp_pan_tiny": ("configs/experiment/yolov6s_csp_scaled.py", dict(width_multiple=0.125, depth_multiple=0.34), 64, 1, 20),
+    "n6_pan": ("configs/yolov6n6.py", {"neck.type": "RepPANNeck6", "backbone.fuse_P2": False}, 128, 1, 80),
+    # (CSPRepPANNeck_P6 has no backbone in the reference that feeds it four maps: CSPBepBackbone_P6 always returns five)
 }
 
 
 def ref_config(path, overrides):
     cfg = load_config(os.path.join(REF, path))
     for k, v in overrides.items():
-        cfg.model[k] = v
+        node = cfg.model
+        *path, leaf = k.split(".")
+        for part in path:
+            node = node[part]
+        node[leaf] = v
     return cfg
 
 

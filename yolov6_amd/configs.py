@@ -126,6 +126,23 @@ def _p6(name, depth, width, backbone, neck, csp, iou, use_dfl, reg_max, extra_ba
                           distill_weight={'class': 1.0, 'dfl': 1.0}))
 
 
+def _v2(name, depth, width, backbone, neck, csp, iou):
+    """configs/experiment/yolov6t.py, yolov6s_csp_scaled.py: v2.0-style models (three backbone maps, uni-directional PAN neck)."""
+    b = dict(type=backbone, num_repeats=[1, 6, 12, 18, 6], out_channels=[64, 128, 256, 512, 1024])
+    n = dict(type=neck, num_repeats=[12, 12, 12, 12], out_channels=[256, 128, 128, 256, 256, 512])
+    if csp is not None:
+        b["csp_e"] = csp
+        n["csp_e"] = csp
+    return dict(type=name, pretrained=None, depth_multiple=depth, width_multiple=width, backbone=b, neck=n,
+                head=dict(type='EffiDeHead', in_channels=[128, 256, 512], num_layers=3, begin_indices=24, anchors=1,
+                          out_indices=[17, 20, 23], strides=[8, 16, 32], iou_type=iou, use_dfl=False, reg_max=0))
+
+
+_MODELS.update({
+    "yolov6t": dict(model=_v2('YOLOv6t', 0.33, 0.375, 'EfficientRep', 'RepPANNeck', None, 'siou'), training_mode="repvgg"),
+    "yolov6s_csp": dict(model=_v2('YOLOv6s_csp', 0.70, 0.50, 'CSPBepBackbone', 'CSPRepPANNeck', float(1) / 2, 'giou'),
+                        training_mode="repvgg"),
+})
 _MODELS.update({
     "yolov6n6": dict(model=_p6('YOLOv6n6', 0.33, 0.25, 'EfficientRep6', 'RepBiFPANNeck6', None, 'siou', False, 0,
                                dict(cspsppf=True)), training_mode="repvgg"),
