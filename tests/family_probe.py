@@ -1,6 +1,6 @@
 """Run as a script by tests/test_gpu_families.py, one case per process:
 
-    python tests/family_probe.py n6 | m6_tiny | tiny_distill_ns | t_pan | s_csp_pan_tiny | n6_pan
+    python tests/family_probe.py n6 | m6_tiny | tiny_distill_ns | t_pan | s_csp_pan_tiny | n6_pan | n_base | s_base_tiny | s_qav1_tiny
 
 Whole-model parity of the model families added after the round's last GPU visit (EfficientRep6 + RepBiFPANNeck6, the M6 CSP
 graph, the self-distillation head's eval branch, the v2.0 PAN necks): same bar as tests/test_gpu_model.py::test_model_vs_oracle_and_golden.  A

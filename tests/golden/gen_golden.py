@@ -76,6 +76,10 @@ MODEL_CASES = {
     "t_pan": ("configs/experiment/yolov6t.py", {}, 64, 1, 80),
     "s_csp_pan_tiny": ("configs/experiment/yolov6s_csp_scaled.py", dict(width_multiple=0.125, depth_multiple=0.34), 64, 1, 20),
     "n6_pan": ("configs/yolov6n6.py", {"neck.type": "RepPANNeck6", "backbone.fuse_P2": False}, 128, 1, 80),
+    # conv_relu models (configs/base) and the first QARepVGG block version (no config selects it; get_block does)
+    "n_base": ("configs/base/yolov6n_base.py", {}, 64, 1, 80),
+    "s_base_tiny": ("configs/base/yolov6s_base.py", dict(width_multiple=0.125, depth_multiple=0.34), 64, 1, 20),
+    "s_qav1_tiny": ("configs/qarepvgg/yolov6s_qa.py", dict(width_multiple=0.125, depth_multiple=0.17, training_mode="qarepvgg"), 64, 2, 80),
     # (CSPRepPANNeck_P6 has no backbone in the reference that feeds it four maps: CSPBepBackbone_P6 always returns five)
 }
 
@@ -83,6 +87,9 @@ MODEL_CASES = {
 def ref_config(path, overrides):
     cfg = load_config(os.path.join(REF, path))
     for k, v in overrides.items():
+        if k == "training_mode":
+            cfg.training_mode = v
+            continue
         node = cfg.model
         *path, leaf = k.split(".")
         for part in path:

@@ -13,7 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # golden case -> built-in config name (tests must not read /root/reference)
 CASE_CONFIG = {"tiny": "yolov6s", "n": "yolov6n", "s": "yolov6s", "s_qa_tiny": "yolov6s_qa", "l6_tiny": "yolov6l6",
                "m_tiny": "yolov6m", "s_mbla_tiny": "yolov6s_mbla", "n6": "yolov6n6", "m6_tiny": "yolov6m6",
-               "t_pan": "yolov6t", "s_csp_pan_tiny": "yolov6s_csp", "n6_pan": "yolov6n6"}
+               "t_pan": "yolov6t", "s_csp_pan_tiny": "yolov6s_csp", "n6_pan": "yolov6n6",
+               "n_base": "yolov6n_base", "s_base_tiny": "yolov6s_base", "s_qav1_tiny": "yolov6s_qa"}
 
 
 def case_meta(case):
@@ -25,6 +26,9 @@ def case_config(case):
     meta = case_meta(case)
     cfg = get_config(CASE_CONFIG[case])
     for k, v in meta["overrides"].items():      # dotted keys reach nested entries ("neck.type")
+        if k == "training_mode":
+            cfg.training_mode = v
+            continue
         node = cfg.model
         *path, leaf = k.split(".")
         for part in path:

@@ -1,5 +1,5 @@
 """GPU: model families whose host side and oracle were pinned on the CPU (tests/test_host_cpu.py, tests/test_oracle_cpu.py:
-cases n6, m6_tiny, tiny_distill_ns, t_pan, s_csp_pan_tiny, n6_pan) AFTER this round's last GPU visit.  Their lowerings only compose ops the GPU suite already
+cases n6, m6_tiny, tiny_distill_ns, t_pan, s_csp_pan_tiny, n6_pan, n_base, s_base_tiny, s_qav1_tiny) AFTER this round's last GPU visit.  Their lowerings only compose ops the GPU suite already
 covers (the L6 wiring with RepBlock stages; the N / S head's non-DFL decode), but the combination has not been seen on
 hardware: each case runs in its own process (tests/family_probe.py) and is reported as xfail/xpass, not as a hard failure,
 until a GPU visit has seen it green."""
@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.xfail(strict=False, reason="added after the round's last GPU visit; promote to a hard test once seen green")
-@pytest.mark.parametrize("case", ["n6", "m6_tiny", "tiny_distill_ns", "t_pan", "s_csp_pan_tiny", "n6_pan"])
+@pytest.mark.parametrize("case", ["n6", "m6_tiny", "tiny_distill_ns", "t_pan", "s_csp_pan_tiny", "n6_pan",
+                                  "n_base", "s_base_tiny", "s_qav1_tiny"])
 def test_new_family_in_subprocess(case):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "family_probe.py"), case], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)

@@ -18,7 +18,7 @@ from yolov6_amd.layers import common
 from yolov6_amd.models.yolo import Model, build_model
 from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
 
-CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny", "n6", "m6_tiny", "t_pan", "s_csp_pan_tiny", "n6_pan"]
+CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny", "n6", "m6_tiny", "t_pan", "s_csp_pan_tiny", "n6_pan", "n_base", "s_base_tiny", "s_qav1_tiny"]
 
 
 @pytest.mark.parametrize("case", CASES)

@@ -11,7 +11,7 @@ from oracle import nms_oracle, synth, tal_oracle
 from oracle.model_oracle import Oracle, deploy_state_dict
 from tests.helpers import GOLDEN, case_config, case_golden, rel_err, synth_sd_from_keys
 
-MODEL_CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny", "n6", "m6_tiny", "t_pan", "s_csp_pan_tiny", "n6_pan"]
+MODEL_CASES = ["tiny", "n", "s", "s_qa_tiny", "l6_tiny", "m_tiny", "s_mbla_tiny", "n6", "m6_tiny", "t_pan", "s_csp_pan_tiny", "n6_pan", "n_base", "s_base_tiny", "s_qav1_tiny"]
 
 
 @pytest.mark.parametrize("case", MODEL_CASES)

@@ -126,6 +126,16 @@ def _p6(name, depth, width, backbone, neck, csp, iou, use_dfl, reg_max, extra_ba
                           distill_weight={'class': 1.0, 'dfl': 1.0}))
 
 
+# configs/base/yolov6{n,s,m,l}_base.py: plain ConvBNReLU blocks ("conv_relu"), DFL head; N on the N / S graph, S / M / L on CSP
+_MODELS.update({
+    f"yolov6{k}_base": dict(model=dict(type=f'YOLOv6{k}_base', **_p5(d, w, bb, nk, csp, 'giou', use_dfl=True, reg_max=16,
+                                                                     cspsppf=sp)), training_mode="conv_relu")
+    for k, d, w, bb, nk, csp, sp in (("n", 0.33, 0.25, 'EfficientRep', 'RepBiFPANNeck', None, True),
+                                     ("s", 0.70, 0.50, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(1) / 2, True),
+                                     ("m", 0.80, 0.75, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(1) / 2, False),
+                                     ("l", 1.0, 1.0, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(1) / 2, False))})
+
+
 def _v2(name, depth, width, backbone, neck, csp, iou):
     """configs/experiment/yolov6t.py, yolov6s_csp_scaled.py: v2.0-style models (three backbone maps, uni-directional PAN neck)."""
     b = dict(type=backbone, num_repeats=[1, 6, 12, 18, 6], out_channels=[64, 128, 256, 512, 1024])
