@@ -59,15 +59,19 @@ def test_builtin_configs_equal_reference_files():
         pytest.skip("reference tree not present (GPU box)")
     pairs = {"yolov6n": "yolov6n.py", "yolov6s": "yolov6s.py", "yolov6m": "yolov6m.py", "yolov6l": "yolov6l.py",
              "yolov6l6": "yolov6l6.py", "yolov6s_qa": "qarepvgg/yolov6s_qa.py", "yolov6s_mbla": "mbla/yolov6s_mbla.py",
-             "yolov6m_mbla": "mbla/yolov6m_mbla.py", "yolov6l_mbla": "mbla/yolov6l_mbla.py", "yolov6x_mbla": "mbla/yolov6x_mbla.py"}
+             "yolov6m_mbla": "mbla/yolov6m_mbla.py", "yolov6l_mbla": "mbla/yolov6l_mbla.py", "yolov6x_mbla": "mbla/yolov6x_mbla.py",
+             "yolov6n6": "yolov6n6.py", "yolov6s6": "yolov6s6.py", "yolov6m6": "yolov6m6.py",
+             "yolov6n_qa": "qarepvgg/yolov6n_qa.py", "yolov6m_qa": "qarepvgg/yolov6m_qa.py",
+             "yolov6n_base": "base/yolov6n_base.py", "yolov6s_base": "base/yolov6s_base.py", "yolov6m_base": "base/yolov6m_base.py",
+             "yolov6l_base": "base/yolov6l_base.py", "yolov6t": "experiment/yolov6t.py", "yolov6s_csp": "experiment/yolov6s_csp_scaled.py"}
     for name, f in pairs.items():
         a, b = get_config(name), load_config(os.path.join(ref, f))
-        assert a.training_mode == b.training_mode, name
+        assert a.training_mode == (b.get("training_mode") or "repvgg"), name      # tools/train.py:99-100 default
         for part in ("backbone", "neck"):
             for k, v in b.model[part].items():
                 assert a.model[part].get(k) == v or (not a.model[part].get(k) and not v), (name, part, k)
         for k in ("num_layers", "use_dfl", "reg_max", "strides", "atss_warmup_epoch", "iou_type"):
-            assert a.model.head[k] == b.model.head[k], (name, k)
+            assert a.model.head.get(k) == b.model.head.get(k), (name, k)
         assert (a.model.depth_multiple, a.model.width_multiple) == (b.model.depth_multiple, b.model.width_multiple)
 
 

@@ -126,6 +126,13 @@ def _p6(name, depth, width, backbone, neck, csp, iou, use_dfl, reg_max, extra_ba
                           distill_weight={'class': 1.0, 'dfl': 1.0}))
 
 
+# configs/qarepvgg/yolov6{n,m}_qa.py (yolov6s_qa above): the N / M graphs with QARepVGGBlockV2
+_MODELS.update({
+    "yolov6n_qa": dict(model=dict(type='YOLOv6n', **_p5(0.33, 0.25, 'EfficientRep', 'RepBiFPANNeck', None, 'siou')),
+                       training_mode="qarepvggv2"),
+    "yolov6m_qa": dict(model=dict(type='YOLOv6m', **_p5(0.60, 0.75, 'CSPBepBackbone', 'CSPRepBiFPANNeck', float(2) / 3, 'giou',
+                                                         use_dfl=True, reg_max=16, cspsppf=False)), training_mode="qarepvggv2"),
+})
 # configs/base/yolov6{n,s,m,l}_base.py: plain ConvBNReLU blocks ("conv_relu"), DFL head; N on the N / S graph, S / M / L on CSP
 _MODELS.update({
     f"yolov6{k}_base": dict(model=dict(type=f'YOLOv6{k}_base', **_p5(d, w, bb, nk, csp, 'giou', use_dfl=True, reg_max=16,
