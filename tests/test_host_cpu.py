@@ -287,3 +287,47 @@ def test_distill_ns_head_state_dict_abi_and_eval_oracle():
     assert float(np.abs(det.numpy() - g).max() / max(1.0, float(np.abs(g).max()))) < 1e-4
     with pytest.raises(NotImplementedError):
         m.detect.lower_train(None, None)
+
+
+WIRING_CASES = CASES + ["tiny_distill_ns"]
+
+
+@pytest.mark.parametrize("case", WIRING_CASES)
+def test_lowering_wiring_matches_reference_golden(case):
+    """Every model family's `lower()` graph, executed op by op on the CPU by tests/mock_plan.py (fp32 torch ops on the same
+    buffer / channel-slice views the real builder hands out), reproduces the REFERENCE's deploy-form output: concat-free
+    slice wiring, re-parameterised weights, epilogue order, decode arguments.  The HIP kernels are not involved."""
+    import copy
+    import json
+    import numpy as np
+    from tests.helpers import GOLDEN, case_golden, rel_err, synth_sd_from_keys
+    from tests.mock_plan import MockBuilder
+    from yolov6_amd.configs import tiny_config
+    from yolov6_amd.engine import NCHWInput
+    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+    if case == "tiny_distill_ns":
+        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+            meta = json.load(f)
+        m = build_model(tiny_config(), meta["num_classes"], "cpu", distill_ns=True).eval()
+        gold, gfeats = np.load(os.path.join(GOLDEN, "model_tiny_distill_ns.npz"))["det_train"], None
+    else:
+        cfg, meta = case_config(case)
+        m = build_model(cfg, meta["num_classes"], "cpu").eval()
+        g = case_golden(case)
+        gold, gfeats = g["det_deploy"], [g[k] for k in sorted(k for k in g.files if k.startswith("feat"))]
+    m.load_state_dict(synth_sd_from_keys(meta["train"]))
+    if case != "tiny_distill_ns":
+        m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
+    switch_to_deploy(fuse_model(m))
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    pb = MockBuilder()
+    with torch.no_grad():
+        det = m.lower(pb, NCHWInput(x))
+    assert rel_err(det.numpy(), gold) < 2e-4
+    if gfeats is not None:
+        feats = [pb.to_nchw(r).numpy() for r in m._featrefs]
+        assert len(feats) == len(gfeats)
+        for f, gf in zip(feats, gfeats):
+            assert rel_err(f, gf) < 2e-4
+    kinds = [e["kind"] for e in pb.op_log]
+    assert kinds.count("decode") == 1 and kinds.count("conv") > 20
