@@ -1,6 +1,6 @@
 """Run as a script by tests/test_gpu_families.py, one case per process:
 
-    python tests/family_probe.py n6 | m6_tiny | tiny_distill_ns | t_pan | s_csp_pan_tiny | n6_pan | n_base | s_base_tiny | s_qav1_tiny
+    python tests/family_probe.py n6 | m6_tiny | tiny_distill_ns | t_pan | s_csp_pan_tiny | n6_pan | n_base | s_base_tiny | s_qav1_tiny | tiny_fuseab_eval
 
 Whole-model parity of the model families added after the round's last GPU visit (EfficientRep6 + RepBiFPANNeck6, the M6 CSP
 graph, the self-distillation head's eval branch, the v2.0 PAN necks): same bar as tests/test_gpu_model.py::test_model_vs_oracle_and_golden.  A
@@ -26,14 +26,15 @@ DEV = "cuda:0"
 
 
 def main(case):
-    if case == "tiny_distill_ns":
-        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+    special = case in ("tiny_distill_ns", "tiny_fuseab_eval")
+    if special:
+        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json" if case == "tiny_distill_ns" else "keys_tiny_fuseab.json")) as f:
             meta = json.load(f)
         cfg = tiny_config()
-        m = build_model(cfg, meta["num_classes"], "cpu", distill_ns=True).eval()
-        gold = np.load(os.path.join(GOLDEN, "model_tiny_distill_ns.npz"))["det_train"]
+        m = build_model(cfg, meta["num_classes"], "cpu", distill_ns=case == "tiny_distill_ns", fuse_ab=case == "tiny_fuseab_eval").eval()
+        gold = np.load(os.path.join(GOLDEN, f"model_{case}.npz"))["det_train"]
         ocfg = copy.deepcopy(cfg)
-        ocfg.model.head.use_dfl = False
+        ocfg.model.head.use_dfl = False      # both eval branches decode plain distances from reg_preds
     else:
         cfg, meta = case_config(case)
         m = build_model(cfg, meta["num_classes"], "cpu").eval()
@@ -41,7 +42,7 @@ def main(case):
         ocfg = cfg
     sd = synth_sd_from_keys(meta["train"])
     m.load_state_dict(sd)
-    if case != "tiny_distill_ns":
+    if not special:
         m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
     switch_to_deploy(fuse_model(m))
     m = m.to(DEV).half()

@@ -352,6 +352,22 @@ def gen_loss_distill():
         print(f"lossdistill_{name}: loss {float(loss):.6f} items {items.numpy().tolist()}")
 
 
+def gen_fuseab_eval():
+    """Model(fuse_ab=True) in EVAL mode (effidehead_fuseab.py: the anchor-free branch alone): train-form weights, eval output."""
+    from yolov6.models.yolo import Model
+    cfile, over, size, batch, nc = MODEL_CASES["tiny"]
+    cfg = ref_config(cfile, over)
+    torch.manual_seed(0)
+    model = Model(cfg, channels=3, num_classes=nc, fuse_ab=True)
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=0))
+    model.eval()
+    x = synth.synth_images(batch, size, seed=1)
+    with torch.no_grad():
+        det, feats = model(x)
+    np.savez_compressed(os.path.join(HERE, "model_tiny_fuseab_eval.npz"), det_train=det.numpy())
+    print(f"model_tiny_fuseab_eval: det {tuple(det.shape)}")
+
+
 def gen_loss_distill_ns():
     """reference ComputeLoss of models/losses/loss_distill_ns.py (the N / S self-distillation loss: a fourth student output,
     plain (l, t, r, b) distances): value, items, gradients to the student's scores, DFL logits and distances."""
@@ -472,6 +488,8 @@ if __name__ == "__main__":
     if "distill_ns" in which:
         gen_distill_ns()
         gen_loss_distill_ns()
+    if "fuseab_eval" in which or "fuseab" in which:
+        gen_fuseab_eval()
     if "models" in which:
         gen_models()
     if "nms" in which:

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.xfail(strict=False, reason="added after the round's last GPU visit; promote to a hard test once seen green")
 @pytest.mark.parametrize("case", ["n6", "m6_tiny", "tiny_distill_ns", "t_pan", "s_csp_pan_tiny", "n6_pan",
-                                  "n_base", "s_base_tiny", "s_qav1_tiny"])
+                                  "n_base", "s_base_tiny", "s_qav1_tiny", "tiny_fuseab_eval"])
 def test_new_family_in_subprocess(case):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "family_probe.py"), case], cwd=ROOT, capture_output=True,
                        text=True, timeout=600)

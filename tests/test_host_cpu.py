@@ -289,7 +289,7 @@ def test_distill_ns_head_state_dict_abi_and_eval_oracle():
         m.detect.lower_train(None, None)
 
 
-WIRING_CASES = CASES + ["tiny_distill_ns"]
+WIRING_CASES = CASES + ["tiny_distill_ns", "tiny_fuseab_eval"]
 
 
 @pytest.mark.parametrize("case", WIRING_CASES)
@@ -305,18 +305,20 @@ def test_lowering_wiring_matches_reference_golden(case):
     from yolov6_amd.configs import tiny_config
     from yolov6_amd.engine import NCHWInput
     from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
-    if case == "tiny_distill_ns":
-        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+    special = case in ("tiny_distill_ns", "tiny_fuseab_eval")     # heads selected by a Model() flag: train-form goldens only
+    if special:
+        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json" if case == "tiny_distill_ns" else "keys_tiny_fuseab.json")) as f:
             meta = json.load(f)
-        m = build_model(tiny_config(), meta["num_classes"], "cpu", distill_ns=True).eval()
-        gold, gfeats = np.load(os.path.join(GOLDEN, "model_tiny_distill_ns.npz"))["det_train"], None
+        m = build_model(tiny_config(), meta["num_classes"], "cpu", distill_ns=case == "tiny_distill_ns",
+                        fuse_ab=case == "tiny_fuseab_eval").eval()
+        gold, gfeats = np.load(os.path.join(GOLDEN, f"model_{case}.npz"))["det_train"], None
     else:
         cfg, meta = case_config(case)
         m = build_model(cfg, meta["num_classes"], "cpu").eval()
         g = case_golden(case)
         gold, gfeats = g["det_deploy"], [g[k] for k in sorted(k for k in g.files if k.startswith("feat"))]
     m.load_state_dict(synth_sd_from_keys(meta["train"]))
-    if case != "tiny_distill_ns":
+    if not special:
         m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
     switch_to_deploy(fuse_model(m))
     x = synth.synth_images(meta["batch"], meta["size"], seed=1)
