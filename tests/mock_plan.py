@@ -50,6 +50,7 @@ class MockBuilder:
         B, C_, H, W = t.shape
         out = self.new_buffer(B, H, W, C_)
         self._write(out, t)
+        self.op_log.append(dict(kind="nchw2nhwc", x=x.t, out=out))
         return out
 
     def to_nchw(self, x, dtype=torch.float32):
@@ -71,9 +72,11 @@ class MockBuilder:
 
     # ---------------------------------------------------------------- ops
     def conv(self, x, weight, bias, stride=1, act=None, out=None, post=None, res=None, res_alpha=None):
+        image = None
         if isinstance(x, NCHWInput):
             t = x.t
-            x = self.as_nhwc(NCHWInput(t.float() / 255.0) if t.dtype == torch.uint8 else x)
+            image = t.float() / 255.0 if t.dtype == torch.uint8 else t
+            x = self.as_nhwc(NCHWInput(image))
         w = weight.detach().float()
         Cout, Cin, K, _ = w.shape
         assert x.C == Cin
@@ -87,7 +90,9 @@ class MockBuilder:
         if out is None:
             out = self.new_buffer(x.B, y.shape[2], y.shape[3], Cout)
         self._write(out, y)
-        self.op_log.append(dict(kind="conv", cin=Cin, cout=Cout, k=K, stride=stride))
+        # same schema as engine.PlanBuilder.op_log (tests/plan_replay.py walks either)
+        self.op_log.append(dict(kind="stem" if image is not None else "conv", x=image if image is not None else x, out=out, w=w,
+                                b=bias, stride=stride, act=act, post=post, res=res, alpha=res_alpha))
         return out
 
     def convt2x2(self, x, weight, bias, out=None):
@@ -96,7 +101,7 @@ class MockBuilder:
         if out is None:
             out = self.new_buffer(x.B, 2 * x.H, 2 * x.W, weight.shape[1])
         self._write(out, y)
-        self.op_log.append(dict(kind="convt"))
+        self.op_log.append(dict(kind="convt", x=x, out=out, w=weight, b=bias))
         return out
 
     def sppf_pool(self, x, y1, y2, y3):
@@ -104,7 +109,7 @@ class MockBuilder:
         for dst in (y1, y2, y3):
             p = F.max_pool2d(p, 5, 1, 2)
             self._write(dst, p)
-        self.op_log.append(dict(kind="sppf"))
+        self.op_log.append(dict(kind="sppf", x=x, outs=[y1, y2, y3]))
 
     def head_decode(self, cls, reg, strides, use_dfl, reg_max, proj, nc, grid_cell_offset=0.5):
         """Eval branch of Detect (effidehead.py:104-139), restated with torch ops on the lowered head outputs."""
@@ -127,5 +132,7 @@ class MockBuilder:
             x1y1, x2y2 = pts - d[..., :2], pts + d[..., 2:]
             box = torch.cat([(x1y1 + x2y2) / 2, x2y2 - x1y1], -1) * float(s)
             outs.append(torch.cat([box, torch.ones(B, H * W, 1), score], -1))
-        self.op_log.append(dict(kind="decode"))
-        return torch.cat(outs, 1)
+        det = torch.cat(outs, 1)
+        self.op_log.append(dict(kind="decode", cls=list(cls), reg=list(reg), out=det, strides=list(strides), use_dfl=bool(use_dfl),
+                                reg_max=int(reg_max), proj=proj, nc=nc))
+        return det

@@ -333,3 +333,20 @@ def test_lowering_wiring_matches_reference_golden(case):
             assert rel_err(f, gf) < 2e-4
     kinds = [e["kind"] for e in pb.op_log]
     assert kinds.count("decode") == 1 and kinds.count("conv") > 20
+    # the same op sequence under the fp16-emulating oracle's per-op arithmetic (tests/plan_replay.py - what the GPU parity tests
+    # compare each HIP op with) must give the oracle's own whole-model forward: the lowering's op boundaries ARE the oracle's
+    # rounding points.  Bit-exact here: the oracle reads the model's own deploy-form state_dict, so both multiply the same folded weights.
+    import types
+    from oracle.model_oracle import Oracle
+    from tests.plan_replay import OracleChain
+    ocfg = copy.deepcopy(tiny_config() if special else cfg)
+    if special:
+        ocfg.model.head.use_dfl = False
+    orc = Oracle(ocfg, m.state_dict(), meta["num_classes"], emulate_fp16=True)
+    xq = x.half().float()
+    with torch.no_grad():
+        ref, _ = orc.forward(xq)
+        chain = OracleChain(types.SimpleNamespace(op_log=pb.op_log), orc)
+        chain.run(teacher_force=False)
+    sync = float(((chain.final - ref).abs() / ref.abs().clamp(min=1.0)).max())
+    assert sync == 0.0, f"{case}: lowered op chain vs Oracle.forward {sync:.3e}"
