@@ -249,6 +249,9 @@ def test_pmc_kernel_classification():
     ns_ = "void (anonymous namespace)::"
     assert classify(ns_ + "conv3x3_dma_kernel<2, 2, 4, 2, 2, 1, 16, false, 1>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
     assert classify(ns_ + "conv3x3_dma_kernel<2, 1, 8, 2, 2, 1, 16, false, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s2"
+    assert classify(ns_ + "conv3x3_dma_kernel<2, 1, 8, 2, 2, 1, 16, false, 2, false>((anonymous namespace)::ConvKArgs)") == "conv3x3s2"
+    assert classify(ns_ + "conv3x3_dma_kernel<2, 2, 8, 2, 2, 1, 32, false, 1, true>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
+    assert classify(ns_ + "conv3x3_dma_kernel<2, 2, 8, 2, 2, 1, 32, true, 1, false>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
     assert classify(ns_ + "conv_mfma_pipe_kernel<2, 2, 2, 4, 1, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s1"
     assert classify(ns_ + "conv_mfma_kernel<4, 1, 3, 2>((anonymous namespace)::ConvKArgs)") == "conv3x3s2"
     assert classify(ns_ + "conv_mfma_kernel<2, 1, 1, 1>((anonymous namespace)::ConvKArgs)") == "conv1x1s1"
