@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
                                   "n_base", "s_base_tiny", "s_qav1_tiny", "tiny_fuseab_eval"])
 def test_new_family_in_subprocess(case):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "family_probe.py"), case], cwd=ROOT, capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=300)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "FAMILY_PROBE_OK" in r.stdout
 
@@ -29,6 +29,6 @@ def test_unseen_conv_variants_in_subprocess():
     env = dict(os.environ, Y6_TEST_UNSEEN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-x", "-q", "-m", "gpu", "-p",
                         "no:cacheprovider", "-k", "conv_all_variants or conv_dma or tap_geometry or epilogue_variants or not_transposed"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-3000:], r.stderr[-1500:])
     assert r.returncode == 0
