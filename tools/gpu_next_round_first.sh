@@ -3,8 +3,12 @@
 #   1. the probes / tests of everything written after round 2's last visit (model families, dma8_c4p1) - reported, not fatal
 #   2. fill pricing: LDS-DMA requests + barriers only, all / halo only / weights only (probe builds 2 / 7 / 8), four layers
 #   3. same-box A/B of the candidate set: default / + dma8_c4p1 (33) / + resident-weight forms (34, 35) / + all three
+# Before the visit, in the build container:  python tools/build_probe_libs.py --dma 2 7 8   (tools/_build/ travels with the snapshot)
 set -u
 OUT=gpurun_out/${1:-next1}; mkdir -p "$OUT"; export TMPDIR=/tmp
+for n in 2 7 8; do
+  [ -f tools/_build/libyolov6_hip_dmaprobe$n.so ] || { echo "probe lib $n missing: building on the box"; python tools/build_probe_libs.py --dma $n > "$OUT/build_probe_$n.log" 2>&1; }
+done
 timeout 900 python -m pytest tests/test_gpu_families.py -q -m gpu -rxX -p no:cacheprovider > "$OUT/pytest_families.log" 2>&1
 tail -8 "$OUT/pytest_families.log"
 L="64,64,3,1,160,160,32 64,64,3,1,80,80,32 64,128,3,1,80,80,32 128,128,3,1,80,80,32 256,256,3,1,40,40,32 512,512,3,1,20,20,32 128,128,3,1,40,40,32"
