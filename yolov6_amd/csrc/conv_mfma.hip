@@ -1150,7 +1150,10 @@ const VariantCfg kVariants[] = {
     {4, 1, 4, "dma8_c4p1", 8},
     // wres = 1: resident weights (layers of at most 64 input channels), 512 pixels x 64 couts on eight waves, one block per CU;
     // 16-channel chunks (planar halo) / 32-channel chunks (pixel-major halo).  Also written after the last GPU visit.
-    {2, 2, 4, "dmar8_c2p2", 8, 1, 2, 16, 1, 1}, {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1}};
+    {2, 2, 4, "dmar8_c2p2", 8, 1, 2, 16, 1, 1}, {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1},
+    // 64 couts x 512 pixels on four waves (two blocks per CU): the tap images of a chunk feed twice the MFMAs of dma_c2p2
+    // (39 KB per 288 MFMAs instead of 29 KB per 144); eight accumulator fragments per wave, so the epilogue is not deferred
+    {2, 4, 4, "dma_c2p4", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1632,7 +1635,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
     }
