@@ -14,6 +14,7 @@ floors, the weight share of the fill bytes, the measured time and its ratio to m
 their sum (1.0 = not overlapped at all).
 
     python tools/dma_model.py profiles/r02/bench_infer_ops_r02d.json
+    python tools/dma_model.py --what-if        # both floors for every variant, incl. the ones not measured yet
 """
 import json
 import math
@@ -49,7 +50,9 @@ def choose_tile(Ho, Wo, bp, cap, tw_mult=16):
     return bt
 
 
-VARIANTS = {"dma_c2p2": dict(cf=2, pf=2, nw=4), "dma_c2p1": dict(cf=2, pf=1, nw=4), "dma8_c2p2": dict(cf=2, pf=2, nw=8)}
+VARIANTS = {"dma_c2p2": dict(cf=2, pf=2, nw=4), "dma_c2p1": dict(cf=2, pf=1, nw=4), "dma8_c2p2": dict(cf=2, pf=2, nw=8),
+            # written after round 2's last GPU visit (not measured yet): --what-if prices them with the same two rates
+            "dma_c2p4": dict(cf=2, pf=4, nw=4), "dma8_c4p1": dict(cf=4, pf=1, nw=8), "dmar8_c2p2": dict(cf=2, pf=2, nw=8, wres=1)}
 
 
 def launch_geometry(B, C, K, H, W, variant):
@@ -60,14 +63,19 @@ def launch_geometry(B, C, K, H, W, variant):
     ncb = cdiv(cdiv(K, 32), v["cf"])
     nids = tiles if ncb == 1 else cdiv(tiles, 8) * 8 * ncb
     nhp = cdiv(2 * (TH + 2) * (TW + 2), 64)
-    lds = 2 * (nhp + 9 * v["cf"]) * 1024 + 8 * v["cf"] * 32 * 4
+    wres = v.get("wres", 0)
+    if wres and C > 64:
+        return None
+    if v["cf"] > cdiv(K, 32):
+        return None
+    lds = (2 * nhp + cdiv(C, 16) * 9 * v["cf"]) * 1024 + 8 * v["cf"] * 32 * 4 if wres else 2 * (nhp + 9 * v["cf"]) * 1024 + 8 * v["cf"] * 32 * 4
     bpc = max(1, min(LDS_KB * 1024 // lds, 32 // v["nw"]))
     grid = min(nids, CUS * bpc - (CUS * bpc) % 8)
     rounds = cdiv(nids, grid)
     chunks = cdiv(C, 16)
     waves_per_simd = bpc * v["nw"] / 4.0 if grid >= CUS * bpc - 8 else max(1.0, nids / CUS) * v["nw"] / 4.0
     chunk_cycles = waves_per_simd * 9 * v["cf"] * v["pf"] * 32 / E_CHUNK
-    fill_bytes = nids * chunks * (nhp + 9 * v["cf"]) * 1024
+    fill_bytes = nids * chunks * (nhp + (0 if wres else 9 * v["cf"])) * 1024 + (grid * chunks * 9 * v["cf"] * 1024 if wres else 0)
     t_fill_us = fill_bytes / (FILL_B_PER_CLK_CU * CUS * CLOCK_GHZ * 1e3)
     return dict(tile=(TH, TW), tiles=tiles, items=nids, lds=lds, bpc=bpc, grid=grid, rounds=rounds, t_fill_us=t_fill_us,
                 w_share=9 * v["cf"] / (nhp + 9 * v["cf"]),
@@ -111,5 +119,22 @@ def main(path):
           f"{tot['meas']:.0f} us (in-chunk efficiency {E_CHUNK:.2f}, fill {FILL_B_PER_CLK_CU} B/clk/CU)")
 
 
+def what_if():
+    """max(matrix floor, fill floor) of every variant on the seven 3x3 stride-1 shapes of YOLOv6-S b32 (byte pricing of the fill)."""
+    shapes = [(64, 64, 160), (128, 128, 80), (256, 256, 40), (512, 512, 20), (64, 64, 80), (128, 128, 40), (256, 256, 20),
+              (64, 128, 80), (128, 256, 40), (256, 512, 20)]
+    print(f"{'layer':>16} " + " ".join(f"{v[3:]:>12}" for v in VARIANTS))
+    for C, K, H in shapes:
+        cells = []
+        for v in VARIANTS:
+            g = launch_geometry(32, C, K, H, H, v)
+            cells.append(f"{'-':>12}" if g is None else f"{g['t_model_us']:5.1f}|{g['t_fill_us']:5.1f}".rjust(12))
+        print(f"{f'{C}->{K}@{H}':>16} " + " ".join(cells))
+    print("(matrix floor | fill floor, us; the measured launches sit at 1.2-1.7 x the larger one)")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r02/bench_infer_ops_r02d.json")
+    if len(sys.argv) > 1 and sys.argv[1] == "--what-if":
+        what_if()
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else "profiles/r02/bench_infer_ops_r02d.json")
