@@ -25,7 +25,7 @@ def test_new_family_in_subprocess(case):
 
 @pytest.mark.xfail(strict=False, reason="kernel variants written after the round's last GPU visit (tests/gpu_utils.py::UNSEEN_VARIANTS)")
 def test_unseen_conv_variants_in_subprocess():
-    """The conv-op tests once more with the not-yet-measured variants included (dma8_c4p1: 128 couts x 256 pixels on eight waves; dmar8 / dmarw8_c2p2: tap images resident in LDS; dma_c2p4: 512-pixel blocks on four waves)."""
+    """The conv-op tests once more with the not-yet-measured variants included (dma8_c4p1: 128 couts x 256 pixels on eight waves; dmar8 / dmarw8_c2p2: tap images resident in LDS; dma_c2p4: 512-pixel blocks on four waves; dma8s2_c4p1: stride 2, 128 couts)."""
     env = dict(os.environ, Y6_TEST_UNSEEN="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-x", "-q", "-m", "gpu", "-p",
                         "no:cacheprovider", "-k", "conv_all_variants or conv_dma or tap_geometry or epilogue_variants or not_transposed"],

@@ -748,6 +748,7 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
         if constexpr (!I8) {
             if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 2, 2, 1, 16, false, 2>(L, s);
             if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 1 && nw == 8) return launch_dma<2, 1, 8, 2, 2, 1, 16, false, 2>(L, s);
+            if (hc == 16 && stg == 2 && il == 1 && cf == 4 && pf == 1 && nw == 8) return launch_dma<4, 1, 8, 2, 2, 1, 16, false, 2>(L, s);
         }
         y6_set_error("conv_dma: no stride-2 instantiation c%dp%d x %d waves", cf, pf, nw);
         return Y6_EUNSUPPORTED;

@@ -1153,7 +1153,10 @@ const VariantCfg kVariants[] = {
     {2, 2, 4, "dmar8_c2p2", 8, 1, 2, 16, 1, 1}, {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1},
     // 64 couts x 512 pixels on four waves (two blocks per CU): the tap images of a chunk feed twice the MFMAs of dma_c2p2
     // (39 KB per 288 MFMAs instead of 29 KB per 144); eight accumulator fragments per wave, so the epilogue is not deferred
-    {2, 4, 4, "dma_c2p4", 4}};
+    {2, 4, 4, "dma_c2p4", 4},
+    // stride 2, 128 couts x 256 output pixels on eight waves: a stride-2 block stages four times the halo of a stride-1 one
+    // per MFMA, so twice the couts per halo is where the stride-2 form can gain (it only won on the first layer)
+    {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1635,7 +1638,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
     }

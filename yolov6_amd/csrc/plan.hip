@@ -628,9 +628,9 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // this pool their FIRST launch after a memory-bound op costs +25-50 us (r02b: 118 us for a 69 us layer), which eats
     // the gain; the 16-channel-chunk forms (two / three blocks per CU, < 64 KB of LDS per block) do not show it
     // (same-box A/B tools/gpu_ab_firstop.sh: 11.0 k img/s without them, 10.8 k with).
-    // 33-36 (dma8_c4p1, the resident-weight forms, dma_c2p4) were written after round 2's last GPU visit: selectable, not
-    // default candidates until measured.
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,33,34,35,36";
+    // 33-37 (dma8_c4p1, the resident-weight forms, dma_c2p4, dma8s2_c4p1) were written after round 2's last GPU visit:
+    // selectable, not default candidates until measured.
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,33,34,35,36,37";
     {
         for (const char* c = ex; *c;) {
             char* end = nullptr;
