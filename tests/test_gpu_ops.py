@@ -31,6 +31,8 @@ CONV_SHAPES = [
     (128, 96, 1, 1, 20, 23, 2),    # streaming 1x1 kernel: 8 k-steps, ragged last pixel fragment, three cout fragments
     (256, 64, 1, 1, 10, 14, 3),    # streaming 1x1 kernel: 16 k-steps
 ]
+if os.environ.get("Y6_TEST_UNSEEN") == "1":   # isolated probe of not-yet-measured variants: a stride-2 layer with more work items than blocks
+    CONV_SHAPES.append((64, 128, 3, 2, 192, 192, 12))
 
 
 def _mk_weights(Cout, Cin, k, seed):
