@@ -19,7 +19,7 @@ for n in 2 7 8; do
 done
 grep -h "probe\|base\|ms" "$OUT"/probe_*.log | grep -v amdgpu
 BASE="7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30"
-for cfg in default:$BASE,33,34,35,36,37 c4p1:$BASE,34,35,36,37 wres:$BASE,33,36,37 c2p4:$BASE,33,34,35,37 s2c4:$BASE,33,34,35,36 all:$BASE; do
+for cfg in default:$BASE,33,34,35,36,37 all:$BASE; do
   name=${cfg%%:*}; ex=${cfg#*:}
   Y6_AUTOTUNE_EXCLUDE="$ex" Y6_AUTOTUNE_LOG="$OUT/autotune_$name.log" timeout 600 python bench.py --steps 200 --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/ops_$name.json" > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
   python - <<PY
