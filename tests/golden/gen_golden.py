@@ -8,6 +8,7 @@ What is pinned
   model_<name>.npz  reference Model (yolov6/models/yolo.py) built from the reference's own
                     configs/*.py, weights from oracle/synth.py, eval forward in train form and
                     after fuse_model + switch_to_deploy (detections + neck feature maps)
+  model_<name>_half.npz  the same deploy-form model after the reference's `model.half()`, run on CPU in fp16
   keys_<name>.json  the reference state_dict keys/shapes (train form and deploy form)
   nms_<case>.npz    reference yolov6/utils/nms.py::non_max_suppression.  torchvision is absent,
                     so `torchvision.ops.nms` is served by oracle/nms_oracle.py::nms - the
@@ -133,6 +134,41 @@ def gen_models():
         d = float((det_train - det_dep).abs().max())
         print(f"model_{name}: det {tuple(det_dep.shape)} train-vs-deploy max diff {d:.3e} "
               f"params {sum(p.numel() for p in model.parameters()) / 1e6:.3f}M keys {len(keys_train)}/{len(keys_dep)}")
+
+
+def gen_models_half():
+    """The reference's OWN half-precision path on the CPU: the deploy-form model after `model.half()` on `x.half()`
+    (what tools/eval.py --half / core/evaler.py:86-88 run on the GPU).  Pins the rounding points of
+    oracle.model_oracle.Oracle(emulate_fp16=True), which every GPU parity test compares with.
+    Separate files (model_<name>_half.npz) so that the fp32 goldens stay byte-identical."""
+    from yolov6.layers.common import RepVGGBlock
+    from yolov6.models.yolo import Model
+    from yolov6.utils.torch_utils import fuse_model
+
+    only = os.environ.get("GOLDEN_ONLY")
+    for name, (cfile, over, size, batch, nc) in MODEL_CASES.items():
+        if only and name != only:
+            continue
+        cfg = ref_config(cfile, over)
+        torch.manual_seed(0)
+        model = Model(cfg, channels=3, num_classes=nc).eval()
+        model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=0))
+        model.detect.proj_conv.weight.data = model.detect.proj.view(1, -1, 1, 1).clone()
+        x = synth.synth_images(batch, size, seed=1)
+        with torch.no_grad():
+            fuse_model(model)
+            for m in model.modules():
+                if isinstance(m, RepVGGBlock):
+                    m.switch_to_deploy()
+            det32, _ = model(x)
+            model.half()
+            det, feats = model(x.half())
+        out = dict(det_half=det.float().numpy(), det_dtype=str(det.dtype))
+        for i, f in enumerate(feats):
+            out[f"feat{i}_half"] = f.float().numpy()
+        np.savez_compressed(os.path.join(HERE, f"model_{name}_half.npz"), **out)
+        d = (det.float() - det32).abs()
+        print(f"model_{name}_half: det {tuple(det.shape)} {det.dtype}; half-vs-fp32 scores {float(d[..., 5:].max()):.3e} boxes {float(d[..., :4].max()):.3e}")
 
 
 NMS_CASES = {
@@ -492,6 +528,8 @@ if __name__ == "__main__":
         gen_fuseab_eval()
     if "models" in which:
         gen_models()
+    if "models_half" in which or "models" in which:
+        gen_models_half()
     if "nms" in which:
         gen_nms()
     if "tal" in which:

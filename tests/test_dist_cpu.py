@@ -92,6 +92,7 @@ params = list(net.parameters())
 marks = [(i + 1, [p]) for i, p in enumerate(arena.params)]
 calls = []
 class FakeGraph:
+    arena, bwd_marks, n_bwd_ops = arena, marks, len(arena.params)
     def backward(self, grads, first=0, last=None):
         calls.append((first, last))
         if first == 0:                               # the shard's gradient (autograd accumulates into the arena views)
@@ -128,3 +129,98 @@ def test_two_rank_gloo_gradient_exchange_equals_concatenated_batch():
         assert segs[0][0] == 0 and segs[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
         assert segs[0][2] == 0 and segs[-1][3] == res["numel"] and all(a[3] == b[2] for a, b in zip(segs, segs[1:]))
         assert [c[0] for c in res["calls"]] == [s[0] for s in segs if s[1] > s[0] or s[0] == 0]
+
+
+SEAM_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+MODE = %r
+import torch, torch.nn as nn, torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+from yolov6_amd.parallel import Replicas, install_grad_reducer
+from yolov6_amd.train_engine import ParamArena, run_train_graph
+torch.manual_seed(0)
+torch.set_num_threads(1)
+
+
+class StandInGraph:
+    # What train_engine.TrainGraph is to the model, with torch CPU ops in place of the native plans: forward without
+    # autograd, backward writes the parameter gradients straight into the arena views (never through autograd).
+    def __init__(self, model):
+        self.model, self.arena = model, ParamArena(model, "cpu")
+        self.anchor = torch.zeros((), requires_grad=True)
+        self.bwd_marks = [(i + 1, [p]) for i, p in enumerate(self.arena.params)]
+        self.n_bwd_ops = len(self.arena.params)
+    def forward(self, x):
+        self.x = x
+        with torch.no_grad():
+            return (self.model.net(x),)
+    def backward(self, grads, first=0, last=None):
+        if first != 0:
+            return
+        if self.arena.params[0].grad is None:
+            self.arena.zero_grad(); self.arena.reattach()
+        with torch.enable_grad():
+            gs = torch.autograd.grad(self.model.net(self.x), list(self.model.net.parameters()), grads[0])
+        for p, g in zip(self.model.net.parameters(), gs):
+            p.grad.add_(g)                               # accumulate into the arena view, as the kernels do
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 4, 1))
+    def forward(self, x):
+        g = self.__dict__.get("_graph")
+        if g is None:
+            g = self.__dict__["_graph"] = StandInGraph(self)
+        return run_train_graph(self, g, x)[0]
+
+
+x, y = torch.randn(8, 3, 12, 12), torch.randn(8, 4, 12, 12)
+ref_net = Net()
+ref = torch.autograd.grad(((ref_net.net(x) - y) ** 2).mean(), list(ref_net.net.parameters()))
+r = Replicas(backend="gloo")
+model = Net()
+model.load_state_dict(ref_net.state_dict())
+if MODE == "ddp":
+    wrapped = DDP(model)                                 # what core/engine.py:466 does to the model
+else:
+    wrapped = model
+    install_grad_reducer(model, r, chunks=3)
+sh = r.shard(8)
+errs = []
+for it in range(3):                                      # several iterations: DDP re-arms its reducer every forward
+    for p in model.parameters():
+        p.grad = None                                    # optimizer.zero_grad(set_to_none=True)
+    out = wrapped(x[sh.start:sh.stop])
+    ((out - y[sh.start:sh.stop]) ** 2).mean().backward()
+    errs.append(max(float((p.grad - g).abs().max()) for p, g in zip(model.net.parameters(), ref)))
+arena = model.__dict__["_graph"].arena
+views = all(p.grad.data_ptr() == arena.grad.data_ptr() + 4 * arena.offset_of(p) for p in model.net.parameters())
+local = torch.autograd.grad(((ref_net.net(x[sh.start:sh.stop]) - y[sh.start:sh.stop]) ** 2).mean(), list(ref_net.net.parameters()))
+differs = max(float((l - g).abs().max()) for l, g in zip(local, ref))
+print("RESULT " + json.dumps(dict(rank=r.rank, errs=errs, views=views, local_vs_global=differs)), flush=True)
+r.close()
+"""
+
+
+@pytest.mark.parametrize("mode", ["ddp", "reducer"])
+def test_two_rank_gloo_training_seam(mode):
+    """The training drop-in seam on two ranks: (ddp) the module WRAPPED IN torch DistributedDataParallel, exactly as the
+    reference's trainer does (core/engine.py:455-468), although its backward writes `p.grad` outside autograd - the zero
+    gradients _TrainStepFn threads through autograd make DDP's hooks fire; (reducer) the bare module with the native
+    GradReducer installed.  Either way every rank ends with the gradient of the concatenated batch, in the arena views."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", SEAM_WORKER % (ROOT, mode)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert res["local_vs_global"] > 1e-3, res          # the shards really differ: an un-reduced gradient would fail below
+        assert max(res["errs"]) < 1e-6, res
+        assert res["views"], res

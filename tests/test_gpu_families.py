@@ -1,8 +1,9 @@
-"""GPU: model families whose host side and oracle were pinned on the CPU (tests/test_host_cpu.py, tests/test_oracle_cpu.py:
-cases n6, m6_tiny, tiny_distill_ns, t_pan, s_csp_pan_tiny, n6_pan, n_base, s_base_tiny, s_qav1_tiny) AFTER this round's last GPU visit.  Their lowerings only compose ops the GPU suite already
-covers (the L6 wiring with RepBlock stages; the N / S head's non-DFL decode), but the combination has not been seen on
-hardware: each case runs in its own process (tests/family_probe.py) and is reported as xfail/xpass, not as a hard failure,
-until a GPU visit has seen it green."""
+"""GPU: whole-model parity of every model family beyond the five golden cases of tests/test_gpu_model.py (EfficientRep6 +
+RepBiFPANNeck6, the M6 CSP graph, the self-distillation / fuse_ab heads' eval branches, the v2.0 PAN necks, `conv_relu` base
+models, QARepVGG v1), one process per case (tests/family_probe.py): every op teacher-forced against the fp16-emulating oracle
+within its per-op bound, end to end within twice the reference's own fp16-vs-fp32 deviation.  Hard tests since round 3 (in
+round 2 three of them - m6_tiny, s_csp_pan_tiny, s_base_tiny - missed a flat 1e-3 end-to-end bar that the reference's own
+`model.half()` misses by the same amount on these deep random-weight cases: tests/golden/model_*_half.npz)."""
 import os
 import subprocess
 import sys
@@ -22,7 +23,6 @@ def _save_log(name, r):
         f.write(f"returncode {r.returncode}\n---- stdout ----\n{r.stdout}\n---- stderr ----\n{r.stderr}\n")
 
 
-@pytest.mark.xfail(strict=False, reason="added after the round's last GPU visit; promote to a hard test once seen green")
 @pytest.mark.parametrize("case", ["n6", "m6_tiny", "tiny_distill_ns", "t_pan", "s_csp_pan_tiny", "n6_pan",
                                   "n_base", "s_base_tiny", "s_qav1_tiny", "tiny_fuseab_eval"])
 def test_new_family_in_subprocess(case):
@@ -31,15 +31,3 @@ def test_new_family_in_subprocess(case):
     _save_log(f"family_{case}.log", r)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "FAMILY_PROBE_OK" in r.stdout
-
-
-@pytest.mark.xfail(strict=False, reason="kernel variants written after the round's last GPU visit (tests/gpu_utils.py::UNSEEN_VARIANTS)")
-def test_unseen_conv_variants_in_subprocess():
-    """The conv-op tests once more with the not-yet-measured variants included (dma8_c4p1: 128 couts x 256 pixels on eight waves; dmar8 / dmarw8_c2p2: tap images resident in LDS; dma_c2p4: 512-pixel blocks on four waves; dma8s2_c4p1: stride 2, 128 couts)."""
-    env = dict(os.environ, Y6_TEST_UNSEEN="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ops.py"), "-x", "-q", "-m", "gpu", "-p",
-                        "no:cacheprovider", "-k", "conv_all_variants or conv_dma or tap_geometry or epilogue_variants or not_transposed"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    _save_log("family_unseen_variants.log", r)
-    print(r.stdout[-3000:], r.stderr[-1500:])
-    assert r.returncode == 0

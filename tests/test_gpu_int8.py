@@ -303,3 +303,65 @@ def test_int8_model_calibration_layers_and_end_to_end():
     quant.dequantize(model)
     det16 = model(xd)[0]
     assert float((det16.float().cpu()[..., 5:] - d16[..., 5:]).abs().max()) < 5e-3      # back on the fp16 plan
+
+
+def test_int8_fullwidth_640_per_layer_and_end_to_end():
+    """BASELINE configs[4] AT ITS CONFIGURATION: the full-width YOLOv6-S-QA int8 plan at 640x640 (batch 4: the per-image work,
+    tiles and kernel variants are those of the benchmarked b32 plan; the oracle stays in seconds), autotuned as bench.py --int8
+    builds it.  (a) every int8 conv teacher-forced on Int8Oracle's activations: fp16 output within one fp16 ulp (the int32
+    accumulators are exact; the ulp is the fma contraction of the kept post-BN affine), int8 twins equal to the quantised oracle
+    output; (b) end to end against Int8Oracle; (c) reported: what int8 costs against the fp16 graph of the same model at this
+    size (class scores, boxes in pixels) -> gpurun_out/int8_fullwidth_640.json."""
+    import json
+    import os
+    from oracle import synth
+    from tests.plan_replay import OracleChain, box_report
+    from yolov6_amd.configs import get_config
+    from yolov6_amd.models.yolo import build_model
+    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+    B, size = 4, 640
+    cfg = get_config("yolov6s_qa")
+    model = build_model(cfg, 80, "cpu").eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=0))
+    switch_to_deploy(fuse_model(model))
+    model = model.to(DEV).half()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cal = [synth.synth_images(B, size, seed=100 + i) for i in range(2)]
+    x = synth.synth_images(B, size, seed=1)
+    orc = Int8Oracle(cfg, sd, 80)
+    table_ref = orc.calibrate(cal)
+    table = quant.calibrate(model, [c.to(DEV).half() for c in cal])
+    cal_rel = max(abs(a - b) / b for a, b in zip(table, table_ref))
+    assert len(table) == len(table_ref) and cal_rel < 5e-3, cal_rel
+    xd = x.to(DEV).half()
+    quant.quantize(model, table_ref, twins=True)
+    plan = model.compile(xd, autotune=True)
+    det = plan.run().clone()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref, _ = orc.forward(x)
+        d16, _ = Oracle(cfg, sd, 80, emulate_fp16=True).forward(x)
+        rows = OracleChain(plan, orc).run(teacher_force=True)
+    i8 = [r for r in rows if r["kind"] == "conv_i8"]
+    worst = max(i8, key=lambda r: r["err"])
+    tm = [r["twin_mismatch"] for r in rows if "twin_mismatch" in r]
+    variants = {r["op"]: r["variant"] for r in plan.timing_read() if r["variant"]}
+    e2e = box_report(det.float().cpu().numpy(), ref.numpy())
+    qerr = box_report(ref.numpy(), d16.numpy())
+    quant.dequantize(model)
+    det16 = model.compile(xd, autotune=True).run().clone()
+    hip_q = box_report(det.float().cpu().numpy(), det16.float().cpu().numpy())
+    rep = dict(model="yolov6s_qa", size=size, batch=B, int8_convs=len(i8), calibration_device_vs_oracle=cal_rel,
+               per_layer_max=worst["err"], per_layer_worst=worst["desc"], twin_codes_off_by_one_max=max(tm) if tm else None,
+               int8_hip_vs_int8_oracle=e2e, int8_oracle_vs_fp16_oracle=qerr, int8_hip_vs_fp16_hip=hip_q,
+               variants_used=sorted(set(variants.values())))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "int8_fullwidth_640.json"), "w") as f:
+        json.dump(dict(summary=rep, rows=rows), f, indent=1)
+    print(json.dumps(rep))
+    assert len(i8) == len(table_ref) and len(i8) > 30
+    assert worst["err"] <= 2.0 ** -10 * 1.002, worst
+    assert tm and max(tm) < 2e-2, max(tm)
+    # free running: an fp16 flip upstream moves single int8 codes downstream; the scale is the quantisation error itself
+    assert e2e["scores_max"] <= max(0.25 * qerr["scores_max"], 4e-3), (e2e, qerr)

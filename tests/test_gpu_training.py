@@ -748,3 +748,144 @@ def test_fuseab_training_graph_vs_oracle():
     assert not bad, f"{len(bad)} gradients above twice the fp16 floor, e.g. {bad[:4]}"
     ab = [k for k in g32 if "_ab" in k]
     assert len(ab) == 12 and all(float(named[k].grad.abs().max()) > 0 for k in ab)
+
+
+# ------------------------------------------------------------------ the reference trainer's step on the HIP model (seam)
+def _seam_targets(n=12):
+    g = torch.Generator().manual_seed(0)
+    return torch.cat([torch.randint(0, 4, (n, 1), generator=g).float(), torch.randint(0, 80, (n, 1), generator=g).float(),
+                      torch.rand((n, 2), generator=g) * 0.6 + 0.2, torch.rand((n, 2), generator=g) * 0.3 + 0.1], 1).to(DEV)
+
+
+def test_reference_shaped_training_step_equals_fused_path():
+    """The step yolov6/core/engine.py:142-176 runs, on the HIP model: `torch.cuda.amp.autocast`, `torch.cuda.amp.GradScaler`,
+    `torch.optim.SGD` with the three parameter groups of yolov6/solver/build.py:12-21 (Nesterov, weight decay on conv weights
+    only), fp32 `/255` images - three steps - against the fused path (FusedSGD + LossScaler) on a second copy of the same
+    model: same kernels produce the gradients, so the parameters must agree to optimizer rounding."""
+    from oracle import synth
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.solver import FusedSGD, LossScaler, param_groups
+    cfg, meta, sd, model_a = _tiny_train_model("tiny")
+    _, _, _, model_b = _tiny_train_model("tiny")
+    model_a, model_b = model_a.to(DEV).train(), model_b.to(DEV).train()
+    img_u8 = (synth.synth_images(4, 128, seed=3) * 255).round().clamp(0, 255)
+    x32 = (img_u8.to(DEV).float() / 255)                       # engine.py:407-410 prepro_data: .float() / 255
+    targets = _seam_targets()
+    h = cfg.model.head
+    lr, mom, wd, scale0 = 0.02, 0.9, 5e-4, 1024.0
+
+    def crit():
+        return ComputeLoss(num_classes=80, ori_img_size=128, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    # --- A: the reference's objects
+    g_bnw, g_w, g_b = param_groups(model_a)                     # build.py:12-21
+    opt_a = torch.optim.SGD(g_bnw, lr=lr, momentum=mom, nesterov=True)
+    opt_a.add_param_group({'params': g_w, 'weight_decay': wd})
+    opt_a.add_param_group({'params': g_b})
+    scaler_a = torch.cuda.amp.GradScaler(init_scale=scale0)
+    crit_a = crit()
+    losses_a = []
+    for i in range(3):
+        with torch.cuda.amp.autocast(enabled=True):
+            preds, s_featmaps = model_a(x32)
+            total_loss, loss_items = crit_a(preds, targets, 10, i, 128, 128)
+        scaler_a.scale(total_loss).backward()
+        scaler_a.step(opt_a)
+        scaler_a.update()
+        opt_a.zero_grad()                                        # set_to_none=True by default: `.grad` views are re-attached
+        losses_a.append(float(total_loss))
+    # --- B: the fused path
+    (f, s, d), _ = model_b(x32)
+    arena_b = s._y6_graph.arena
+    opt_b = FusedSGD(model_b, arena_b, lr=lr, momentum=mom, weight_decay=wd)
+    scaler_b = LossScaler(DEV, init_scale=scale0)
+    crit_b = crit()
+    losses_b = []
+    for i in range(3):
+        opt_b.zero_grad()
+        (f, s, d), _ = model_b(x32)
+        loss, _ = crit_b((f, s, d), targets, 10, i, 128, 128)
+        scaler_b.scale_loss(loss).backward()
+        opt_b.step(scaler_b)
+        scaler_b.update()
+        losses_b.append(float(loss))
+    torch.cuda.synchronize()
+    assert float(scaler_a.get_scale()) == scale0 and float(scaler_b.scale) == scale0      # no step was skipped on either side
+    assert losses_a == pytest.approx(losses_b, rel=1e-5), (losses_a, losses_b)
+    worst = 0.0
+    moved = 0.0
+    sd0 = {k: v.to(DEV) for k, v in sd.items()}
+    for (na, pa), (nb, pb) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        assert na == nb
+        worst = max(worst, float((pa - pb).abs().max() / pb.abs().max().clamp(min=1e-6)))
+        moved = max(moved, float((pb - sd0[nb]).abs().max()))
+    for (na, ba), (nb, bb) in zip(model_a.named_buffers(), model_b.named_buffers()):
+        assert torch.equal(ba, bb), na                           # running statistics: the same kernels, bit for bit
+    print("reference-shaped vs fused: worst relative parameter difference", worst, "largest parameter move", moved, losses_a)
+    assert moved > 1e-4
+    assert worst <= 1e-5, worst
+    # the parameters of A are still views of its arena (torch.optim.SGD updated the arena in place)
+    arena_a = model_a.__dict__["_y6_arena"]
+    assert all(p.data_ptr() == arena_a.data.data_ptr() + 4 * arena_a.offset_of(p) for p in arena_a.params)
+
+
+def test_checkpoint_paths_after_training_steps(tmp_path):
+    """What the reference does at the end of every epoch (core/engine.py:192-203): `deepcopy(de_parallel(model)).half()`,
+    `torch.save({'model': ..., 'ema': ...})`, and evaluating the model in eval mode between training epochs - after train-mode
+    forwards / backwards have populated the native state (`_y6_train_graphs`, `_y6_arena`, ctypes plan handles).  Also the
+    staleness rules: eval after a natively-updated step must see the NEW parameters; `.half()` on the live model must not
+    leave a training graph pointing at the old storage."""
+    import copy
+    from oracle import synth
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.solver import ArenaEMA, FusedSGD, LossScaler
+    cfg, meta, sd, model = _tiny_train_model("tiny")
+    model = model.to(DEV)
+    x = synth.synth_images(2, 64, seed=5).to(DEV).half()
+    targets = _seam_targets(6)
+    targets[:, 0] = targets[:, 0] % 2
+    h = cfg.model.head
+    crit = ComputeLoss(num_classes=80, ori_img_size=64, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    model.eval()
+    det0 = model(x)[0].clone()                                   # caches an eval plan with the initial weights
+    model.train()
+    (f, s, d), _ = model(x)
+    arena = s._y6_graph.arena
+    opt, scaler, ema = FusedSGD(model, arena, lr=0.05), LossScaler(DEV, init_scale=256.0), ArenaEMA(model, arena)
+    x_first = x.clone()
+    for i in range(2):
+        opt.zero_grad()
+        (f, s, d), _ = model(x if i == 0 else x.flip(0).contiguous())
+        loss, _ = crit((f, s, d), targets, 10, i, 64, 64)
+        scaler.scale_loss(loss).backward()
+        opt.step(scaler)
+        scaler.update()
+        ema.update()
+    assert torch.equal(x, x_first)                               # the caller's first batch is not the graph's staging buffer
+    # eval between epochs: same shape as the cached plan, parameters changed by native kernels only
+    model.eval()
+    det1 = model(x)[0].clone()
+    assert not torch.equal(det0, det1), "eval after a fused SGD step served the stale plan (packed weights of the initial model)"
+    fresh = copy.deepcopy(model)
+    assert not any(k.startswith("_y6_") for m in fresh.modules() for k in m.__dict__)
+    assert torch.allclose(fresh(x)[0], det1, atol=2e-3, rtol=2e-3)          # (the autotuner may pick other kernel variants)
+    # checkpoint
+    ck = copy.deepcopy(model).half()
+    assert all(p.dtype == torch.float16 and p._base is None for p in ck.parameters())       # plain tensors, not arena views
+    em = ema.ema_module(model).half()
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({'model': ck, 'ema': em, 'updates': ema.updates}, path)
+    back = torch.load(path, map_location=DEV, weights_only=False)
+    for (n1, p1), (n2, p2) in zip(ck.named_parameters(), back['model'].named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert back['ema'].float().eval()(x.float())[0].shape == det1.shape
+    # the LIVE model too (torch.save of a model holding native state must not choke on ctypes handles)
+    torch.save(model, str(tmp_path / "live.pt"))
+    # .half() on the live model moves every parameter: the next training forward must rebuild, not reuse stale pointers
+    model.train()
+    model.float()
+    (f2, s2, d2), _ = model(x)
+    g2 = s2._y6_graph
+    assert g2.arena is not arena
+    assert all(p.data_ptr() == g2.arena.data.data_ptr() + 4 * g2.arena.offset_of(p) for p in g2.arena.params)
+    torch.cuda.synchronize()
+    assert torch.isfinite(s2).all()

@@ -353,3 +353,38 @@ def test_lowering_wiring_matches_reference_golden(case):
         chain.run(teacher_force=False)
     sync = float(((chain.final - ref).abs() / ref.abs().clamp(min=1.0)).max())
     assert sync == 0.0, f"{case}: lowered op chain vs Oracle.forward {sync:.3e}"
+
+
+def test_native_state_never_pickled_or_deepcopied():
+    """after a train-mode forward the model's __dict__ holds `_y6_train_graphs` / `_y6_arena` /
+    `_y6_backward_hook` (ctypes handles inside); the reference's epoch-end path `deepcopy(model).half()` + torch.save must not
+    see them.  Every `_y6_*` key is native state and is dropped by HipModule.__getstate__; parameters that are views of a
+    (here: stand-in) arena come out of the copy as plain tensors."""
+    import copy
+    import ctypes
+    import io
+    import torch
+    from yolov6_amd.configs import tiny_config
+    from yolov6_amd.models.yolo import build_model
+    from yolov6_amd.train_engine import ParamArena
+    m = build_model(tiny_config(), 4, "cpu")
+    arena = ParamArena(m, "cpu")
+    m.__dict__["_y6_arena"] = arena
+    m.__dict__["_y6_train_graphs"] = {"k": ctypes.c_void_p(1234)}
+    m.__dict__["_y6_backward_hook"] = lambda g, grads: None
+    m.__dict__["_y6_plans"] = {"k": ctypes.c_void_p(1)}
+    m.backbone.__dict__["_y6_plans"] = {"k": ctypes.c_void_p(2)}
+    c = copy.deepcopy(m).half()
+    assert not any(k.startswith("_y6_") for mod in c.modules() for k in mod.__dict__)
+    assert all(p._base is None and p.dtype == torch.float16 for p in c.parameters())
+    buf = io.BytesIO()
+    torch.save({"model": c, "live": m}, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), back["live"].named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    # the live model still owns its native state
+    assert m.__dict__["_y6_arena"] is arena
+    # ... until something moves the parameters
+    m.half()
+    assert "_y6_arena" not in m.__dict__ and "_y6_train_graphs" not in m.__dict__

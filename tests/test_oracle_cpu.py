@@ -54,6 +54,37 @@ def test_fp16_emulation_stays_close():
     assert rel_err(b.numpy(), a.numpy()) < 2e-2
 
 
+@pytest.mark.parametrize("case", MODEL_CASES)
+def test_fp16_emulation_pinned_to_reference_half_goldens(case):
+    """`Oracle(emulate_fp16=True)` - what every GPU model test compares with - against the REFERENCE'S OWN `model.half()` run
+    on the CPU (tests/golden/model_<case>_half.npz, gen_golden.py::gen_models_half).  The emulation rounds to fp16 where the
+    half model's op boundaries round (conv | BN | act | add | softmax | sigmoid) but accumulates each conv in fp32, as the
+    GPU kernels do and as cuDNN / MIOpen do; torch's CPU half conv does not, so single elements differ by one fp16 ulp and -
+    in the few deep, badly conditioned random-weight cases - those flips are amplified exactly like the half model's own
+    deviation from fp32.  Bars: class scores within one fp16 ulp of a probability (2^-12), feature maps within two ulps at
+    the map's top binade, boxes within one ulp of a pixel coordinate - or, where the reference's own fp16 noise on this
+    input (fp32 oracle vs half golden) is larger than that, within 1.5x (scores) / 2x (boxes, maps) that noise."""
+    cfg, meta = case_config(case)
+    sd = synth_sd_from_keys(meta["train"])
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1).half().float()
+    g = np.load(os.path.join(GOLDEN, f"model_{case}_half.npz"))
+    with torch.no_grad():
+        det, feats = Oracle(cfg, sd, meta["num_classes"], emulate_fp16=True).forward(x)
+        det32, feats32 = Oracle(cfg, sd, meta["num_classes"], emulate_fp16=False).forward(x)
+    half = g["det_half"]
+    assert str(g["det_dtype"]) == "torch.float32"        # the reference's decode promotes to fp32 (anchor points / strides are fp32)
+    e, fl = np.abs(det.numpy() - half), np.abs(det32.numpy() - half)
+    ulp_p = 2.0 ** -12                                     # fp16 ulp of a sigmoid output in [0.25, 0.5); the largest scores sit there
+    assert e[..., 5:].max() <= max(ulp_p * 1.001, 1.5 * fl[..., 5:].max()), (case, e[..., 5:].max(), fl[..., 5:].max())
+    ulp_box = 2.0 ** -10 * 2.0 ** np.floor(np.log2(max(1.0, np.abs(half[..., :4]).max())))
+    assert e[..., :4].max() <= max(ulp_box * 1.001, 2.0 * fl[..., :4].max()), (case, e[..., :4].max(), fl[..., :4].max())
+    for i, (f, f32) in enumerate(zip(feats, feats32)):
+        h = g[f"feat{i}_half"]
+        top = max(1.0, float(np.abs(h).max()))
+        ef, ff = float(np.abs(f.numpy() - h).max()) / top, float(np.abs(f32.numpy() - h).max()) / top
+        assert ef <= max(2.0 * 2.0 ** -10, 2.0 * ff), (case, i, ef, ff)        # two ulps at the top binade: a flipped conv output re-rounded by the activation
+
+
 NMS_CASES = ["eval_multilabel", "infer_single", "agnostic_classes", "max_det_cut", "over_max_nms", "empty"]
 
 
@@ -404,3 +435,22 @@ def test_distill_ns_loss_oracle_matches_reference_golden(case):
         np.testing.assert_allclose(out["loss_items"][1:], base["loss_items"][1:], rtol=1e-12)
     touched = np.abs(g["dlrtb"]).sum(-1) > 0
     assert int(touched.sum()) == out["num_pos"]
+
+
+def test_int8_oracle_exact_int_conv_equals_float64_conv():
+    """oracle/int8_oracle.py::exact_int_conv (grouped fp32 convolutions, every partial sum < 2^24) against the float64
+    convolution it replaces, on worst-case operands (all +-127: the largest partial sums) and on random codes."""
+    import torch.nn.functional as F
+    from oracle.int8_oracle import exact_int_conv
+    g = torch.Generator().manual_seed(0)
+    for cin, cout, k, s, hw in [(200, 24, 3, 1, 9), (64, 16, 3, 2, 12), (1024, 8, 1, 1, 5), (130, 8, 3, 1, 7)]:
+        for worst in (True, False):
+            if worst:
+                x = torch.full((1, cin, hw, hw), 127.0)
+                w = torch.full((cout, cin, k, k), -127.0)
+            else:
+                x = torch.randint(-127, 128, (2, cin, hw, hw), generator=g).float()
+                w = torch.randint(-127, 128, (cout, cin, k, k), generator=g).float()
+            want = F.conv2d(x.double(), w.double(), None, stride=s, padding=k // 2)
+            got = exact_int_conv(x, w, s)
+            assert got.dtype == torch.float64 and torch.equal(got, want), (cin, cout, k, s, worst)

@@ -628,9 +628,11 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // this pool their FIRST launch after a memory-bound op costs +25-50 us (r02b: 118 us for a 69 us layer), which eats
     // the gain; the 16-channel-chunk forms (two / three blocks per CU, < 64 KB of LDS per block) do not show it
     // (same-box A/B tools/gpu_ab_firstop.sh: 11.0 k img/s without them, 10.8 k with).
-    // 33-37 (dma8_c4p1, the resident-weight forms, dma_c2p4, dma8s2_c4p1) were written after round 2's last GPU visit:
-    // selectable, not default candidates until measured.
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,33,34,35,36,37";
+    // 33-37, first measured in round 3 (profiles/r03/ab_variants_r03a.txt, same box, in sequence): 33 dma8_c4p1 (128 couts x
+    // 256 pixels on eight waves) takes 17 of the 35 stride-1 layers from dma_c2p2 / dma_c2p1, 37 dma8s2_c4p1 three stride-2
+    // layers, 35 dmarw8_c2p2 (tap images resident in LDS) wins the 64-channel layers in isolation: candidates (+1.9 % img/s
+    // with all three allowed).  34 dmar8_c2p2 and 36 dma_c2p4 lost on every layer: selectable, never default.
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,34,36";
     {
         for (const char* c = ex; *c;) {
             char* end = nullptr;

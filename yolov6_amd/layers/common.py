@@ -69,6 +69,16 @@ def _wrap(x, it):
     return type(x)(_wrap(e, it) for e in x) if isinstance(x, tuple) else [_wrap(e, it) for e in x]
 
 
+# Kernels that write parameters or buffers behind autograd's back (the fused SGD over the arena, the training forward's
+# running-statistics update, the EMA lerp) do not bump `tensor._version`; they bump this process-wide generation instead,
+# which is part of every plan-cache key: an eval forward after a native update re-derives its packed weights / folded BN.
+_NATIVE_GENERATION = [0]
+
+
+def bump_native_generation():
+    _NATIVE_GENERATION[0] += 1
+
+
 def _params_version(module):
     """Plan-cache key part: identity, version and dtype of every parameter / buffer plus the scalar attributes that
     lowering bakes into the plan.  In-place edits through `.data` do not bump `_version`: after such an edit call
@@ -99,19 +109,26 @@ class HipModule(nn.Module):
         raise NotImplementedError
 
     # plans hold ctypes handles: never pickle them with the module (checkpoints pickle modules)
+    # (`copy.deepcopy(model)` and `torch.save(model)` both go through here: the reference's epoch-end path is
+    # `deepcopy(de_parallel(model)).half()` + save_checkpoint, core/engine.py:192-203.)  Every `_y6_*` entry is native
+    # state: plans, training graphs (ctypes handles), the parameter arena, the int8 calibration, the backward hook.
     def __getstate__(self):
-        st = self.__dict__.copy()
-        st.pop("_y6_plans", None)
+        st = {k: v for k, v in self.__dict__.items() if not k.startswith("_y6_")}
         st.pop("_featrefs", None)
         st.pop("_last_featmaps", None)
-        st.pop("_y6_quant", None)
         return st
 
     def invalidate_plans(self):
         """Drop every cached native plan below this module (packed weights are derived caches: call this after
-        editing parameters through `.data`, which autograd's version counter does not see)."""
+        editing parameters through `.data`, which autograd's version counter does not see) and the training graphs with
+        their parameter arena (their plans hold raw pointers to parameters, BatchNorm buffers and arena slots).  The
+        Parameters keep their values: `p.data` stays a live view of the dropped arena until `_apply` / the next training
+        graph re-points it."""
         for m in self.modules():
-            m.__dict__.pop("_y6_plans", None)
+            d = m.__dict__
+            d.pop("_y6_plans", None)
+            d.pop("_y6_train_graphs", None)
+            d.pop("_y6_arena", None)
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -145,7 +162,7 @@ class HipModule(nn.Module):
         contig = [t.contiguous() for t in flat]
         quant = self.__dict__.get("_y6_quant")       # yolov6_amd.quant: calibration pass / int8 lowering
         key = (tuple((tuple(t.shape), t.dtype) for t in flat), _params_version(self), self.training, autotune,
-               None if quant is None else quant.key())
+               None if quant is None else quant.key(), _NATIVE_GENERATION[0])
         cache = self.__dict__.setdefault("_y6_plans", {})
         plan = cache.get(key)
         if plan is None:

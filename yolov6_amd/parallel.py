@@ -3,8 +3,15 @@
 Inference shards by independent images: every rank owns its own batch and its own
 native plan; there is NO data-path collective.  The process group (backend "nccl" = RCCL on ROCm,
 "gloo" on CPU) is used only for barriers and one MAX all-reduce of the elapsed time, as the bench
-contract requires.  (The DDP gradient all-reduce of the training step - reference
-core/engine.py:463-466 - belongs to the training row and is not part of this module yet.)
+contract requires.
+
+Training has the one exchange step of the path: the DDP gradient all-reduce (reference core/engine.py:455-468).
+Two ways to get it, both covered by world-size-2 gloo tests (tests/test_dist_cpu.py):
+  * `GradReducer` (below; `install_grad_reducer(model)`): the native exchange over the flat gradient arena, chunked and
+    overlapped with the backward plan - what bench.py --mode train --gpus N times;
+  * the reference's own `torch.nn.parallel.DistributedDataParallel(model)` wrapper: its gradient-ready hooks fire because
+    train_engine._TrainStepFn delivers a (zero) gradient to every parameter through autograd when a process group is up and
+    no GradReducer is installed; DDP then averages the arena views in place.
 """
 import os
 
@@ -89,8 +96,17 @@ class GradReducer:
     BatchNorm statistics stay local (no SyncBN in the reference); buffers are not broadcast (rank 0's running statistics
     are what checkpoints keep, exactly as with DDP's rank-0 broadcast)."""
 
-    def __init__(self, arena, bwd_marks, n_bwd_ops, replicas: "Replicas", chunks=4, average=False):
-        self.arena, self.rep, self.average = arena, replicas, average
+    def __init__(self, arena=None, bwd_marks=None, n_bwd_ops=None, replicas: "Replicas" = None, chunks=4, average=False):
+        self.rep, self.average, self.chunks = replicas, average, chunks
+        self.arena, self.segments, self.comm_stream = None, [], None
+        if arena is not None:
+            self.bind(arena, bwd_marks, n_bwd_ops)
+
+    def bind(self, arena, bwd_marks, n_bwd_ops):
+        """(Re)derive the segments for a training graph: which backward ops finalise which chunk of the arena.  Called
+        lazily from run_backward when the model's graph was rebuilt (new input shape, `.half()`, re-parameterisation)."""
+        chunks = self.chunks
+        self.arena = arena
         self.n_bwd_ops = n_bwd_ops
         final_op = {}
         for op_end, params in bwd_marks:
@@ -109,7 +125,6 @@ class GradReducer:
                     end, hi = n_bwd_ops, arena.numel
                 self.segments.append((prev_op, end, lo, hi))
                 prev_op, lo = end, hi
-        self.comm_stream = None
 
     def reduce_range(self, lo, hi, stream_ctx=None):
         if self.rep.dist is None:
@@ -121,6 +136,8 @@ class GradReducer:
 
     def run_backward(self, graph, grads):
         """Segmented backward: launch the ops of segment k, then hand its arena chunk to RCCL on the side stream."""
+        if graph.arena is not self.arena:
+            self.bind(graph.arena, graph.bwd_marks, graph.n_bwd_ops)
         cuda = self.arena.grad.is_cuda
         if cuda and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream()
@@ -142,3 +159,12 @@ class GradReducer:
 
     def install(self, model):
         model.__dict__["_y6_backward_hook"] = self.run_backward
+
+
+def install_grad_reducer(model, replicas: "Replicas" = None, chunks=4, average=True):
+    """The native gradient exchange instead of a `DistributedDataParallel` wrapper: after this, `loss.backward()` on every
+    rank leaves the all-reduced (by default: averaged, DDP's convention) gradient in `p.grad`.  A no-op reducer when the
+    job has one rank.  `model` is the bare module (`de_parallel(model)`), not a DDP wrapper."""
+    red = GradReducer(replicas=replicas or Replicas(), chunks=chunks, average=average)
+    red.install(model)
+    return red

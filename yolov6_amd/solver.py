@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .layers.common import bump_native_generation
 
 
 def param_groups(model):
@@ -83,10 +84,13 @@ class FusedSGD:
                                            C.c_void_p(self.group.data_ptr()), a.numel, lr3, wd3, self.momentum, int(self.nesterov),
                                            int(self.steps == 0), float(grad_mul), scale, found, s), "sgd_step_grouped")
         self.steps += 1                              # (a skipped first step leaves a zero buffer: mom*0 + d == d)
+        bump_native_generation()                     # parameters changed behind autograd's version counters: cached eval plans are stale
 
 
 class ArenaEMA:
-    """EMA of every parameter (one lerp over the arena) and every floating-point buffer; `copy_to(model)` writes them back."""
+    """EMA of every parameter (one lerp over the arena) and every floating-point buffer (ModelEMA.update, utils/ema.py:27-37).
+    `copy_to(model)` writes the averages into a module of the same architecture - the reference evaluates and checkpoints
+    `ema.ema` (core/engine.py:192-203); `ema_module(model)` returns such a module (a deep copy of `model`)."""
 
     def __init__(self, model, arena, decay=0.9999, updates=0):
         self.arena = arena
@@ -103,3 +107,33 @@ class ArenaEMA:
         self.ema.lerp_(self.arena.data, 1.0 - d)
         if self.buffers:
             torch._foreach_lerp_(self.ema_buffers, self.buffers, 1.0 - d)
+
+    @torch.no_grad()
+    def copy_to(self, model):
+        """Write the averaged parameters / buffers into `model` (same architecture as the trained one; parameters are matched
+        by registration order, which is how the arena was laid out)."""
+        a = self.arena
+        params = [p for p in model.parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for p in reversed(params):
+            if id(p) not in seen:
+                seen.add(id(p))
+                uniq.append(p)
+        if [tuple(p.shape) for p in uniq] != [tuple(p.shape) for p in a.params]:
+            raise RuntimeError("yolov6_amd: ArenaEMA.copy_to needs a module with the trained model's parameters")
+        for p, o in zip(uniq, a.offsets):
+            p.data.copy_(self.ema[o:o + p.numel()].view(p.shape))
+        bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+        if len(bufs) != len(self.ema_buffers):
+            raise RuntimeError("yolov6_amd: ArenaEMA.copy_to needs a module with the trained model's buffers")
+        for b, e in zip(bufs, self.ema_buffers):
+            b.copy_(e)
+        if hasattr(model, "invalidate_plans"):
+            model.invalidate_plans()
+        return model
+
+    def ema_module(self, model):
+        """A deep copy of `model` (plain tensors, no arena views, no native state) holding the averages: what the reference
+        keeps as `ema.ema` for evaluation and for `save_checkpoint`."""
+        import copy
+        return self.copy_to(copy.deepcopy(model))

@@ -664,7 +664,9 @@ class TrainGraph:
             arena = model.__dict__["_y6_arena"] = ParamArena(model, x.device)
         self.arena = arena
         self.model = model
-        self.input = x.contiguous()
+        # a private staging tensor: the stem's plan op holds its address, and the caller's first batch must not be
+        # overwritten by later steps (prefetch queues, plotting)
+        self.input = torch.empty_like(x, memory_format=torch.contiguous_format).copy_(x)
         tb = TrainBuilder(x.device, arena)
         stems, necks, heads = model.lower_train(tb, NCHWInput(self.input))
         self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
@@ -680,10 +682,10 @@ class TrainGraph:
         self.bwd_marks = tb.bwd_marks
         self.n_bwd_ops = self.bwd_plan.num_ops
         self.anchor = torch.zeros((), dtype=torch.float32, device=x.device, requires_grad=True)
+        self.signature = model_signature(model)
 
     def forward(self, x):
-        if x.data_ptr() != self.input.data_ptr():
-            self.input.copy_(x)
+        self.input.copy_(x)
         self.pack_plan.run()
         self.fwd_plan.run()
         return tuple(self.outputs)
@@ -748,13 +750,29 @@ class ModuleTrainGraph:
         return res
 
 
+def model_signature(model):
+    """Addresses of every parameter and buffer: the training plans hold them as raw pointers (arena slots, BatchNorm
+    running statistics), so a graph is only valid while they stay where they were (`.half()`, `.to()`, `load_state_dict`
+    with `assign=True`, `switch_to_deploy` on a sub-module move them without telling the root module)."""
+    return tuple(t.data_ptr() for t in model.parameters()) + tuple(t.data_ptr() for t in model.buffers())
+
+
 class _TrainStepFn(torch.autograd.Function):
     """Autograd bridge: `loss.backward()` reaches the native backward plan through this node.  Parameter gradients are
-    accumulated by the kernels straight into `p.grad` (arena views); nothing flows back through autograd."""
+    accumulated by the kernels straight into `p.grad` (arena views).
+
+    Nothing needs to flow back through autograd for that - but torch's `DistributedDataParallel` (what the reference's
+    trainer wraps the model in, core/engine.py:466) learns that a gradient is ready from a hook on each parameter's
+    AccumulateGrad node, which only runs if autograd delivers a gradient to the parameter.  When a process group is up and
+    no native reducer (parallel.GradReducer) owns the exchange, the parameters are therefore inputs of this node and it
+    returns a broadcast ZERO for each: AccumulateGrad adds it to the arena view the kernels just filled (values
+    unchanged, infs / NaNs stay), the DDP hook fires, DDP all-reduces and writes the averages back in place - into the
+    arena, so torch.optim.SGD and FusedSGD both see them (tests/test_dist_cpu.py wraps the module in torch DDP)."""
 
     @staticmethod
-    def forward(ctx, graph, x, anchor):
+    def forward(ctx, graph, x, anchor, *params):
         ctx.graph = graph
+        ctx.n_params = len(params)
         return tuple(o.view_as(o) for o in graph.forward(x))
 
     @staticmethod
@@ -766,19 +784,48 @@ class _TrainStepFn(torch.autograd.Function):
             hook(g, grads)                       # e.g. GradReducer: segmented backward + all-reduce
         else:
             g.backward(grads)
+        if ctx.n_params:
+            g.arena.reattach()                   # `.grad` must BE the arena view before AccumulateGrad adds the zero to it
+            z = g.arena.grad.new_zeros(())
+            return (None, None, None) + tuple(z.expand(p.shape) for p in g.arena.params)
         return None, None, None
+
+
+def _autograd_visible_params(model, graph):
+    """The parameters to thread through autograd (see _TrainStepFn): all of them when this process is one rank of a
+    process group and the gradient exchange is not done natively, else none."""
+    if model.__dict__.get("_y6_backward_hook") is not None:
+        return ()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return tuple(graph.arena.params)
+    return ()
+
+
+def run_train_graph(model, g, x):
+    """One forward of a training graph under autograd (shared by Model.forward and the CPU tests' stand-in graph)."""
+    if not torch.is_grad_enabled():
+        return g.forward(x)
+    return _TrainStepFn.apply(g, x, g.anchor, *_autograd_visible_params(model, g))
 
 
 def train_forward(model, x):
     """Model.forward in training mode (reference yolov6/models/yolo.py:33-41 with Detect's training branch):
     returns [(head stem features, cls_scores [B,A,nc], reg_distri [B,A,nreg]), neck feature maps]."""
+    from .layers.common import bump_native_generation
     key = (tuple(x.shape), x.dtype, x.device)
     graphs = model.__dict__.setdefault("_y6_train_graphs", {})
     g = graphs.get(key)
+    if g is not None and g.signature != model_signature(model):
+        # parameters / buffers moved under the graph (see model_signature): its plans point at stale memory
+        graphs.clear()
+        model.__dict__.pop("_y6_arena", None)
+        g = None
     if g is None:
         graphs.clear()
         g = graphs[key] = TrainGraph(model, x)
-    outs = _TrainStepFn.apply(g, x, g.anchor) if torch.is_grad_enabled() else g.forward(x)
+    bump_native_generation()                 # the forward plan updates the BatchNorm running statistics in place
+    outs = run_train_graph(model, g, x)
     for t in outs:
         t._y6_graph = g                      # lets ComputeLoss write its gradients straight into the graph's buffers
     # base head: (feats, cls_scores, reg_distri); fuse_ab head: (feats, cls_ab, reg_ab, cls_af, reg_af) - effidehead_fuseab.py:139

@@ -48,4 +48,5 @@ def switch_to_deploy(model):
 
 def _invalidate(model):
     for m in model.modules():
-        m.__dict__.pop("_y6_plans", None)
+        for k in ("_y6_plans", "_y6_train_graphs", "_y6_arena"):
+            m.__dict__.pop(k, None)
