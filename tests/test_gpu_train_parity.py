@@ -1,0 +1,105 @@
+"""GPU: parity of the TRAINING step at BASELINE configs[2]'s configuration - YOLOv6-S, full width, 640x640 (batch 8: the same
+planes, tiles and kernel variants per layer as the benchmarked b64 plan; the CPU side stays in minutes).
+
+Every op of the forward and the backward plan (convs, batch statistics, branch-sum + activation and its backward incl.
+d-gamma / d-beta, data gradients incl. the zero-inserted stride-2 forms and accumulating outputs, weight gradients in all
+modes, bias gradients, pool backward, transposed-conv pieces, head pack / unpack) runs ALONE on the teacher's tensors
+(tests/train_replay.py: torch-CPU fp32 / autograd of the op's forward statement on fp16-rounded inputs) and is compared with
+the teacher's result; the teacher's head outputs are tied to `TrainOracle(amp_fp16=True)`, the oracle pinned to the
+reference's training-mode goldens.  Bars (relative to each tensor's largest magnitude): forward convs 1e-3, weight gradients
+1e-3, data gradients / BatchNorm / activations 3e-3, layout ops exact.  The per-op table goes to
+gpurun_out/train_parity_yolov6s_640_b8.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def test_training_step_per_op_teacher_forced_yolov6s_640():
+    import bench
+    from oracle.model_oracle import TrainOracle
+    from tests.train_replay import TrainChain
+    from yolov6_amd.configs import get_config
+    from yolov6_amd.models.losses.loss import ComputeLoss
+    from yolov6_amd.models.yolo import build_model
+    from yolov6_amd.utils import synth
+    B, size, S = 8, 640, 8192.0
+    cfg = get_config("yolov6s")
+    model = build_model(cfg, 80, "cpu")
+    sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    sd = {k: v.clone() for k, v in sd.items()}
+    model = model.to(DEV).train()
+    x = synth.synth_images(B, size, seed=0).half()
+    targets = bench.synth_targets(B, seed=0).to(DEV)
+    h = cfg.model.head
+    crit = ComputeLoss(num_classes=80, ori_img_size=size, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    # ---- the step as bench.py --mode train runs it (free running), autotuned plans
+    xd = x.to(DEV)
+    (feats, scores, distri), _ = model(xd)
+    graph = scores._y6_graph
+    graph.fwd_plan.autotune(2)
+    graph.bwd_plan.autotune(2)
+    graph.arena.zero_grad()
+    (feats, scores, distri), _ = model(xd)
+    loss, items = crit((feats, scores, distri), targets, 10, 0, size, size)
+    (loss * S).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(graph.arena.grad).all()
+    free_grads = {id(p): p.grad.detach().float().cpu().clone() for p in graph.arena.params}
+    free_scores, free_distri = scores.detach().cpu().clone(), distri.detach().cpu().clone()
+    dscores, ddistri = graph.dscores.detach().cpu().clone(), graph.ddistri.detach().cpu().clone()
+    assert float(dscores.abs().max()) > 0 and float(ddistri.abs().max()) > 0
+    # ---- teacher-forced replay of both plans
+    chain = TrainChain(graph)
+    with torch.no_grad():
+        chain.forward()
+    # the teacher IS the fp16-activation oracle (same statement, batch statistics stored in fp32 on both sides)
+    with torch.no_grad():
+        (xs_o, cls_o, reg_o), _ = TrainOracle(cfg, sd, 80, amp_fp16=True).forward_train(x.float())
+    tie = dict(scores=float((chain.scores - cls_o).abs().max()), distri=_rel_l2(chain.distri, reg_o))
+    chain.backward(dscores, ddistri)
+    rows = chain.rows
+    variants = {}
+    for phase, plan in (("fwd", graph.fwd_plan), ("bwd", graph.bwd_plan)):
+        for r in plan.timing_read():
+            if r["variant"]:
+                variants[f"{phase}:{r['op']}"] = r["variant"]
+    # ---- whole step, free running vs the teacher's gradients (two fp16-activation pipelines: rounding flips only)
+    named = {id(p): n for n, p in model.named_parameters()}
+    e2e = {}
+    for pid, ref in chain.param_grads.items():
+        if float(ref.norm()) > 0:
+            e2e[named[pid]] = _rel_l2(free_grads[pid], ref)
+    vals = np.array(list(e2e.values()))
+    by_kind = {}
+    for r in rows:
+        key = f"{r['phase']}.{r['kind']}" + (".params" if r["desc"].endswith("params") else "")
+        d = by_kind.setdefault(key, dict(n=0, worst=0.0, worst_desc="", tol=r["tol"]))
+        d["n"] += 1
+        if r["err"] >= d["worst"]:
+            d["worst"], d["worst_desc"] = r["err"], r["desc"]
+    summary = dict(model="yolov6s", size=size, batch=B, loss=float(loss), loss_scale=S, fwd_ops=len(graph.fwd_log), bwd_ops=len(graph.bwd_log),
+                   rows=len(rows), teacher_vs_train_oracle_amp=tie, per_kind=by_kind,
+                   free_running_head=dict(scores_max=float((free_scores - chain.scores).abs().max()), distri_rel_l2=_rel_l2(free_distri, chain.distri)),
+                   free_running_param_grads=dict(n=len(vals), median=float(np.median(vals)), p90=float(np.quantile(vals, 0.9)), worst=float(vals.max()),
+                                                 worst_name=max(e2e, key=e2e.get)))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, f"train_parity_yolov6s_{size}_b{B}.json"), "w") as f:
+        json.dump(dict(summary=summary, rows=rows, variants=variants, free_running_param_grads=e2e), f, indent=1)
+    print(json.dumps(summary))
+    bad = [r for r in rows if r["err"] > r["tol"]]
+    assert not bad, f"{len(bad)} of {len(rows)} ops above their bound teacher-forced, e.g. {bad[:4]}"
+    assert tie["scores"] < 5e-3 and tie["distri"] < 5e-3, tie

@@ -138,6 +138,10 @@ class TrainBuilder:
             torch.empty(64 << 20, dtype=torch.uint8)
         self.keep.append(self.wgrad_ws)
         self.trace = {}              # name -> activation view (filled by the composite modules; tools/train_trace.py)
+        # what every op of the forward / backward plan reads and writes, index == op index in the plan: the teacher-forced
+        # per-op replay of tests/train_replay.py walks these (test infrastructure only; nothing in the step reads them)
+        self.fwd_log: List[dict] = []
+        self.bwd_log: List[dict] = []
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -165,7 +169,7 @@ class TrainBuilder:
         B, C_, H, W = t.shape
         out = self.new_buffer(B, H, W, C_)
         ct = out.ct()
-        self._f(self.lib.y6_plan_add_nchw2nhwc(self.fwd, C.c_void_p(t.data_ptr()), _dtype_tag(t), C.byref(ct)), "plan_add_nchw2nhwc")
+        self._f(self.lib.y6_plan_add_nchw2nhwc(self.fwd, C.c_void_p(t.data_ptr()), _dtype_tag(t), C.byref(ct)), "plan_add_nchw2nhwc", x=t, out=out)
         self.inputs.append(t)
         return out
 
@@ -201,13 +205,15 @@ class TrainBuilder:
             raise RuntimeError("yolov6_amd: a gradient is read before every consumer wrote it (backward order bug)")
 
     # ------------------------------------------------------------------ plan plumbing
-    def _f(self, rc, what):
+    def _f(self, rc, what, **log):
         _lib.check(rc, what)
         self.n_fwd_ops += 1
+        self.fwd_log.append(dict(kind=what.replace("plan_add_", ""), **log))
 
-    def _b(self, rc, what):
+    def _b(self, rc, what, **log):
         _lib.check(rc, what)
         self.n_bwd_ops += 1
+        self.bwd_log.append(dict(kind=what.replace("plan_add_", ""), **log))
 
     def _add_pack(self, src_ptr, kind, Cout, Cin, K):
         n = int(self.lib.y6_pack_job_elems(kind, Cout, Cin, K))
@@ -219,7 +225,7 @@ class TrainBuilder:
         self.pack_jobs.append((src_ptr, dst, kind, Cout, Cin, K, n))
         return dst
 
-    def _conv_op(self, plan, x: TRef, out: TRef, packed, k, stride, bias_ptr=None, res: Optional[TRef] = None):
+    def _conv_op(self, plan, x: TRef, out: TRef, packed, k, stride, bias_ptr=None, res: Optional[TRef] = None, log=None):
         d = _lib.ConvDesc()
         d.inp, d.out = x.ct(), out.ct()
         d.w_packed = _ptr(packed)
@@ -231,11 +237,12 @@ class TrainBuilder:
         d.ksize, d.stride, d.act, d.variant = k, stride, 0, -1
         rc = self.lib.y6_plan_add_conv(plan, C.byref(d))
         flops = 2.0 * out.B * out.H * out.W * out.C * x.C * k * k
+        log = dict(log or {}, x=x, out=out, k=k, stride=stride, acc=res is not None)
         if plan is self.fwd:
-            self._f(rc, "plan_add_conv")
+            self._f(rc, "plan_add_conv", **log)
             self.fwd_flops += flops
         else:
-            self._b(rc, "plan_add_conv")
+            self._b(rc, "plan_add_conv", **log)
             self.bwd_flops += flops
 
     # ------------------------------------------------------------------ forward ops
@@ -255,10 +262,10 @@ class TrainBuilder:
         if K == 1 and stride == 2:      # the MFMA 1x1 kernels are stride-1 GEMMs: sample x[2y, 2x] first
             xs = self.new_buffer(x.B, Ho, Wo, Cin)
             ca, cb = x.ct(), xs.ct()
-            self._f(self.lib.y6_plan_add_subsample2(self.fwd, C.byref(ca), C.byref(cb)), "plan_add_subsample2")
-            self._conv_op(self.fwd, xs, y, packed, 1, 1, bias_ptr=bptr)
+            self._f(self.lib.y6_plan_add_subsample2(self.fwd, C.byref(ca), C.byref(cb)), "plan_add_subsample2", x=x, out=xs)
+            self._conv_op(self.fwd, xs, y, packed, 1, 1, bias_ptr=bptr, log=dict(role="fwd", weight=weight, bias=bias))
         else:
-            self._conv_op(self.fwd, x, y, packed, K, stride, bias_ptr=bptr)
+            self._conv_op(self.fwd, x, y, packed, K, stride, bias_ptr=bptr, log=dict(role="fwd", weight=weight, bias=bias))
         rec = ConvRec(x, y, weight, bias, K, stride)
         y._conv = rec
         self.tape.append(lambda: self._conv_backward(rec))
@@ -290,7 +297,7 @@ class TrainBuilder:
         d.w_oihw_f32 = wsrc
         d.bias = d.post_scale = d.post_shift = None
         d.act = 0
-        self._f(self.lib.y6_plan_add_stem(self.fwd, C.byref(d)), "plan_add_stem")
+        self._f(self.lib.y6_plan_add_stem(self.fwd, C.byref(d)), "plan_add_stem", x=t, out=y, weight=weight, k=K)
         self.fwd_flops += 2.0 * B * Ho * Wo * Cout * Cin * K * K
         rec = ConvRec(x, y, weight, None, K, 2)
         y._conv = rec
@@ -313,7 +320,7 @@ class TrainBuilder:
         d.eps = float(bn.eps)
         d.scale, d.shift, d.mean, d.invstd = (_ptr(t) for t in (st.scale, st.shift, st.mean, st.invstd))
         d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
-        self._f(self.lib.y6_plan_add_bn_train_stats(self.fwd, C.byref(d)), "plan_add_bn_train_stats")
+        self._f(self.lib.y6_plan_add_bn_train_stats(self.fwd, C.byref(d)), "plan_add_bn_train_stats", x=y, bn=bn, stats=st)
         return st
 
     def bnact(self, branches, act, out: Optional[TRef] = None, res: Optional[TRef] = None,
@@ -332,13 +339,14 @@ class TrainBuilder:
         d.res_alpha = self.arena.data_ptr(alpha) if alpha is not None else None
         d.out = out.ct()
         d.act = ACT_BY_NAME[act]
-        self._f(self.lib.y6_plan_add_bnact_forward(self.fwd, C.byref(d)), "plan_add_bnact_forward")
+        self._f(self.lib.y6_plan_add_bnact_forward(self.fwd, C.byref(d)), "plan_add_bnact_forward", branches=list(branches), act=act,
+                out=out, res=res, alpha=alpha)
         self.tape.append(lambda: self._bnact_backward(d, branches, out, res, alpha))
         return out
 
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
         cts = [t.ct() for t in (x, y1, y2, y3)]
-        self._f(self.lib.y6_plan_add_sppf(self.fwd, *[C.byref(c) for c in cts]), "plan_add_sppf")
+        self._f(self.lib.y6_plan_add_sppf(self.fwd, *[C.byref(c) for c in cts]), "plan_add_sppf", x=x, outs=[y1, y2, y3])
         self.tape.append(lambda: self._sppf_backward(x, y1, y2, y3))
 
     def convt2x2(self, x: TRef, weight: nn.Parameter, bias: nn.Parameter, out: Optional[TRef] = None) -> TRef:
@@ -350,7 +358,7 @@ class TrainBuilder:
         d.inp, d.out = x.ct(), out.ct()
         d.w_packed = _ptr(packed)
         d.bias = self.arena.data_ptr(bias)
-        self._f(self.lib.y6_plan_add_convt(self.fwd, C.byref(d)), "plan_add_convt")
+        self._f(self.lib.y6_plan_add_convt(self.fwd, C.byref(d)), "plan_add_convt", x=x, out=out, weight=weight, bias=bias)
         self.fwd_flops += 2.0 * out.B * out.H * out.W * Cout * Cin
         self.tape.append(lambda: self._convt_backward(x, out, weight, bias))
         return out
@@ -368,7 +376,8 @@ class TrainBuilder:
             d.cls[i], d.reg[i] = c.ct(), r.ct()
         d.scores, d.distri = _ptr(self.scores), _ptr(self.distri)
         d.nc, d.nreg = nc, nreg
-        self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack")
+        self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack", cls=list(cls), reg=list(reg), scores=self.scores,
+                distri=self.distri)
         self.head_outputs += [(self.scores, self.dscores), (self.distri, self.ddistri)]
 
         def bwd():
@@ -384,7 +393,9 @@ class TrainBuilder:
             g.scores = _ptr(self.scores)
             g.dscores, g.ddistri = _ptr(self.dscores), _ptr(self.ddistri)
             g.nc, g.nreg = nc, nreg
-            self._b(self.lib.y6_plan_add_head_unpack_backward(self.bwd, C.byref(g)), "plan_add_head_unpack_backward")
+            self._b(self.lib.y6_plan_add_head_unpack_backward(self.bwd, C.byref(g)), "plan_add_head_unpack_backward",
+                    dcls=[c._conv.dy for c in cls], dreg=[r._conv.dy for r in reg], nc=[c.C for c in cls], nreg=[r.C for r in reg],
+                    scores=self.scores, dscores=self.dscores, ddistri=self.ddistri)
         self.tape.append(bwd)
         return self.scores, self.distri
 
@@ -408,7 +419,8 @@ class TrainBuilder:
             d.scores, d.distri = _ptr(scores), _ptr(distri)
             d.dscores, d.ddistri = _ptr(dscores), _ptr(ddistri)
             return d
-        self._f(self.lib.y6_plan_add_head_ab_pack(self.fwd, C.byref(desc(cls, reg))), "plan_add_head_ab_pack")
+        self._f(self.lib.y6_plan_add_head_ab_pack(self.fwd, C.byref(desc(cls, reg))), "plan_add_head_ab_pack", cls=list(cls), reg=list(reg),
+                scores=scores, distri=distri, na=na, anchors=anc)
         self.head_outputs += [(scores, dscores), (distri, ddistri)]
 
         def bwd():
@@ -419,7 +431,8 @@ class TrainBuilder:
                 buf = self.new_buffer(t.B, t.H, t.W, cp, zero=True)
                 rec.dy, rec.dy_dil, rec.cpad = buf, 1, cp
                 out.append(TRef(buf.buf, t.B, t.H, t.W, t.C, cp, 0))
-            self._b(self.lib.y6_plan_add_head_ab_unpack_backward(self.bwd, C.byref(desc(gc, gr))), "plan_add_head_ab_unpack_backward")
+            self._b(self.lib.y6_plan_add_head_ab_unpack_backward(self.bwd, C.byref(desc(gc, gr))), "plan_add_head_ab_unpack_backward",
+                    dcls=gc, dreg=gr, reg_fwd=list(reg), scores=scores, dscores=dscores, ddistri=ddistri, na=na, anchors=anc)
         self.tape.append(bwd)
         return scores, distri
 
@@ -432,6 +445,7 @@ class TrainBuilder:
         self.grad_ready(gout)
         g.dout = gout.ct()
         finals = []
+        dx_log = []
         for i, (t, st) in enumerate(branches):
             if st is not None:
                 g.mean[i], g.invstd[i] = st.mean.data_ptr(), st.invstd.data_ptr()
@@ -459,21 +473,26 @@ class TrainBuilder:
                 g.dx[i] = dy.ct()
                 g.dx_dil[i] = rec.dy_dil
                 g.dx_acc[i] = 0
+                dx_log.append((dy, rec.dy_dil, 0))
             else:                                    # an activation that is also read elsewhere (RepVGG identity, raw branches)
                 gx = self.grad(t)
                 g.dx[i] = gx.ct()
                 g.dx_dil[i] = 1
                 g.dx_acc[i] = self.grad_mode(gx)
+                dx_log.append((gx, 1, int(g.dx_acc[i])))
+        dres_log = None
         if res is not None:
             gr = self.grad(res)
             g.dres = gr.ct()
             g.dres_acc = self.grad_mode(gr)
+            dres_log = (gr, int(g.dres_acc))
             if alpha is not None:
                 g.dalpha = self.arena.grad_ptr(alpha).value
                 finals.append(alpha)
         ws = self.bytes_(int(self.lib.y6_bnact_bwd_workspace_bytes(out.C)))
         g.workspace, g.workspace_bytes = _ptr(ws), ws.numel()
-        self._b(self.lib.y6_plan_add_bnact_backward(self.bwd, C.byref(g)), "plan_add_bnact_backward")
+        self._b(self.lib.y6_plan_add_bnact_backward(self.bwd, C.byref(g)), "plan_add_bnact_backward", branches=list(branches),
+                act=[k for k, v in ACT_BY_NAME.items() if v == fwd_desc.act][0], out=out, res=res, alpha=alpha, dout=gout, dx=dx_log, dres=dres_log)
         self.bwd_marks.append((self.n_bwd_ops, finals))
 
     def _transpose(self, view: Optional[TRef], sy, sx, oy, ox, R, Q, Cn, B, nchw_t=None) -> torch.Tensor:
@@ -490,10 +509,10 @@ class TrainBuilder:
             d.nchw, d.src_dtype = 0, Y6_F16
         d.sy, d.sx, d.oy, d.ox, d.R, d.Q = sy, sx, oy, ox, R, Q
         d.dst = dst.data_ptr()
-        self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose")
+        self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose", aux=True)
         return dst
 
-    def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops, a_ch=None, b_ch=None):
+    def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops, a_ch=None, b_ch=None, log=None):
         w = _lib.WgradDesc()
         w.mode = mode
         w.a = a.data_ptr()
@@ -507,7 +526,7 @@ class TrainBuilder:
         w.sm, w.sn, w.st = N * T, T, 1
         w.flops = flops
         w.workspace, w.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
-        self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad")
+        self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad", mode=mode, **(log or {}))
         self.bwd_flops += flops
 
     def _conv_backward(self, rec: ConvRec):
@@ -546,13 +565,14 @@ class TrainBuilder:
             mode = _lib.WG_1X1
             planes = [(self._transpose(xv, 2, 2, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
         self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight),
-                    2.0 * Cout * Cin * K * K * B * Ho * Wo, a_ch=dyv.C, b_ch=Cin)
+                    2.0 * Cout * Cin * K * K * B * Ho * Wo, a_ch=dyv.C, b_ch=Cin,
+                    log=dict(weight=rec.weight, x=(xt if is_stem else xv), dy=dyv, dil=rec.dy_dil, k=K, stride=s, cout=Cout))
         finals = [rec.weight]
         if rec.bias is not None:
             ws = self.bytes_(16 * _rup(max(y.C, 1), 8))
             ct = TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff).ct()
             self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(rec.bias), _ptr(ws), ws.numel()),
-                    "plan_add_channel_sum")
+                    "plan_add_channel_sum", x=TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff), param=rec.bias)
             finals.append(rec.bias)
         # data gradient: the forward conv kernel on the flipped / transposed weights, stride 1 over the (dilated) dy
         if not is_stem:
@@ -562,7 +582,8 @@ class TrainBuilder:
             # 32-channel chunk counts of 68 and 72 agree
             assert (dyv.C + 31) // 32 == (Cout + 31) // 32
             packed = self._add_pack(self.arena.data_ptr(rec.weight), 1, Cout, Cin, K)
-            self._conv_op(self.bwd, dyv, gx, packed, K, 1, res=gx if acc else None)
+            self._conv_op(self.bwd, dyv, gx, packed, K, 1, res=gx if acc else None,
+                          log=dict(role="dgrad", weight=rec.weight, dil=rec.dy_dil, fwd_stride=s, fwd_k=K))
         self.bwd_marks.append((self.n_bwd_ops, finals))
 
     def _sppf_backward(self, x, y1, y2, y3):
@@ -573,7 +594,7 @@ class TrainBuilder:
             self.grad_ready(g)
         d.dy1, d.dy2, d.dy3, d.dx = g1.ct(), g2.ct(), g3.ct(), gx.ct()
         d.dx_acc = 1
-        self._b(self.lib.y6_plan_add_sppf_backward(self.bwd, C.byref(d)), "plan_add_sppf_backward")
+        self._b(self.lib.y6_plan_add_sppf_backward(self.bwd, C.byref(d)), "plan_add_sppf_backward", x=x, ys=[y1, y2], dys=[g1, g2, g3], dx=gx)
 
     def _convt_backward(self, x: TRef, out: TRef, weight, bias):
         Cin, Cout = weight.shape[0], weight.shape[1]
@@ -584,18 +605,19 @@ class TrainBuilder:
         ws = self.bytes_(16 * _rup(Cout, 8))
         ct = gout.ct()
         self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(bias), _ptr(ws), ws.numel()),
-                "plan_add_channel_sum")
+                "plan_add_channel_sum", x=gout, param=bias)
         a = self._transpose(x, 1, 1, 0, 0, H, Q, Cin, B)
         planes = [(self._transpose(gout, 2, 2, sub >> 1, sub & 1, H, Q, Cout, B), H, 0) for sub in range(4)]
-        self._wgrad(_lib.WG_CONVT, a, planes, Cin, Cout, B, Q, H, 4, self.arena.grad_ptr(weight), 2.0 * Cin * Cout * 4 * B * H * W)
+        self._wgrad(_lib.WG_CONVT, a, planes, Cin, Cout, B, Q, H, 4, self.arena.grad_ptr(weight), 2.0 * Cin * Cout * 4 * B * H * W,
+                    log=dict(weight=weight, x=x, dy=gout, dil=1, k=2, stride=2, cout=Cout, convt=True))
         # dx = 1x1 conv over space-to-depth(dout) with W'[ci][sub*Cout + co]
         s2d = self.new_buffer(B, H, W, 4 * Cout)
         ca, cb = gout.ct(), s2d.ct()
-        self._b(self.lib.y6_plan_add_space_to_depth2(self.bwd, C.byref(ca), C.byref(cb)), "plan_add_space_to_depth2")
+        self._b(self.lib.y6_plan_add_space_to_depth2(self.bwd, C.byref(ca), C.byref(cb)), "plan_add_space_to_depth2", x=gout, out=s2d)
         gx = self.grad(x)
         acc = self.grad_mode(gx)
         packed = self._add_pack(self.arena.data_ptr(weight), 3, Cout, Cin, 2)
-        self._conv_op(self.bwd, s2d, gx, packed, 1, 1, res=gx if acc else None)
+        self._conv_op(self.bwd, s2d, gx, packed, 1, 1, res=gx if acc else None, log=dict(role="convt_dgrad", weight=weight, dy=gout))
         self.bwd_marks.append((self.n_bwd_ops, [weight, bias]))
 
     # ------------------------------------------------------------------ finish
@@ -680,6 +702,7 @@ class TrainGraph:
         self.dscores, self.ddistri = self.grad_inputs[-2], self.grad_inputs[-1]
         self.fwd_flops, self.bwd_flops = tb.fwd_flops, tb.bwd_flops
         self.bwd_marks = tb.bwd_marks
+        self.fwd_log, self.bwd_log = tb.fwd_log, tb.bwd_log
         self.n_bwd_ops = self.bwd_plan.num_ops
         self.anchor = torch.zeros((), dtype=torch.float32, device=x.device, requires_grad=True)
         self.signature = model_signature(model)
