@@ -616,6 +616,10 @@ int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_ptr);
 /* Re-point the `index`-th boundary-reading op (stem / NCHW->NHWC adapter ops, in plan order) at `new_ptr`.
  * Rebinding by position is safe when the caller permutes its input tensors. Returns 1 if changed, 0 if equal. */
 int y6_plan_rebind_input(y6_plan* p, int index, const void* new_ptr);
+/* Re-point every op that writes the boundary tensor at `old_ptr` (the decode output of Detect.forward, effidehead.py:124-139,
+ * or an NHWC->NCHW adapter's destination) to `new_ptr` (same shape/dtype): `Model.forward` (models/yolo.py:33-41) returns its
+ * result without the copy by alternating between output buffers.  Returns the number of fields changed or a negative error. */
+int y6_plan_rebind_output(y6_plan* p, const void* old_ptr, void* new_ptr);
 /* Launch all ops in order on `stream` (no sync). */
 int y6_plan_run(y6_plan* p, void* stream);
 /* Eager launch of ops [first, last) only (teacher-forced per-layer parity tests, partial re-runs). */

@@ -114,14 +114,32 @@ def test_train_form_eval_equals_deploy(case):
 
 
 def test_rebind_and_repeat():
+    """Model.forward hands out its detections without a copy (yolov6_amd/models/yolo.py: `output_buffers` result tensors per
+    plan, the decode op re-pointed per call): two consecutive results are independent tensors, the third call re-uses the
+    first one's memory (the documented contract), `output_buffers = 0` restores clone-per-call."""
     cfg, meta, sd, m = _build("tiny", deploy=True)
     x1 = synth.synth_images(2, 64, seed=5).to(DEV).half()
     x2 = synth.synth_images(2, 64, seed=6).to(DEV).half()
     a1, _ = m(x1)
+    c1 = a1.clone()
     a2, _ = m(x2)
-    a1b, _ = m(x1.clone())
+    torch.cuda.synchronize()
+    assert a1.data_ptr() != a2.data_ptr()
+    assert torch.equal(a1, c1)           # the previous result survived the next call
     assert not torch.equal(a1, a2)
-    assert torch.equal(a1, a1b)          # deterministic, and the plan followed the new input pointer
+    c2 = a2.clone()
+    a3, _ = m(x1.clone())
+    assert torch.equal(a3, c1)           # deterministic, and the plan followed the new input pointer
+    assert torch.equal(a2, c2)
+    assert a3.data_ptr() == a1.data_ptr()
+    m.output_buffers = 3
+    r = [m(x)[0] for x in (x1, x2, x1)]
+    assert len({t.data_ptr() for t in r}) == 3 and torch.equal(r[0], c1) and torch.equal(r[1], c2)
+    m.output_buffers = 0
+    b1, _ = m(x1)
+    b2, _ = m(x2)
+    b3, _ = m(x2)
+    assert len({b1.data_ptr(), b2.data_ptr(), b3.data_ptr()}) == 3 and torch.equal(b1, c1) and torch.equal(b2, c2)
 
 
 def test_graph_capture_matches_eager():

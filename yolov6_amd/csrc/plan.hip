@@ -336,6 +336,26 @@ extern "C" int y6_plan_rebind_input(y6_plan* p, int index, const void* new_ptr) 
     return Y6_EINVAL;
 }
 
+extern "C" int y6_plan_rebind_output(y6_plan* p, const void* old_ptr, void* new_ptr) {
+    // Point every op that WRITES the caller-visible boundary tensor `old_ptr` (the decode kernel's [B,A,5+nc] output, an
+    // NHWC->NCHW adapter's destination) at `new_ptr` (same shape and dtype): lets the host hand out results without a
+    // copy by alternating between output buffers.  Drops a captured graph: its kernel nodes baked the old address.
+    Y6_REQUIRE(p && old_ptr && new_ptr, "plan_rebind_output: null argument");
+    int n = 0;
+    for (Op& op : p->ops) {
+        if (op.kind == Y6_OP_DECODE && op.dec.out == old_ptr) {
+            op.dec.out = (float*)new_ptr;
+            ++n;
+        }
+        if (op.kind == Y6_OP_NHWC2NCHW && op.dst == old_ptr) {
+            op.dst = new_ptr;
+            ++n;
+        }
+    }
+    if (n) drop_graph(p);
+    return n;
+}
+
 extern "C" int y6_plan_run(y6_plan* p, void* stream) {
     Y6_REQUIRE(p, "plan_run: null plan");
     hipStream_t s = (hipStream_t)stream;

@@ -89,6 +89,23 @@ class Plan:
                 _lib.check(rc, "plan_rebind_input")
             self.inputs[i] = new
 
+    def rebind_output(self, new: torch.Tensor):
+        """Zero-copy results: the op that writes the plan's (single-tensor) output writes `new` from now on."""
+        old = self.outputs
+        if not isinstance(old, torch.Tensor):
+            raise RuntimeError("yolov6_amd: rebind_output needs a plan with one output tensor")
+        if new.data_ptr() == old.data_ptr():
+            return
+        if new.shape != old.shape or new.dtype != old.dtype or not new.is_contiguous():
+            raise RuntimeError("yolov6_amd: rebinding needs a contiguous tensor of the compiled shape/dtype")
+        n = self._lib.y6_plan_rebind_output(self._h, C.c_void_p(old.data_ptr()), C.c_void_p(new.data_ptr()))
+        if n < 0:
+            _lib.check(n, "plan_rebind_output")
+        if n == 0:
+            raise RuntimeError("yolov6_amd: no op of this plan writes its output tensor (rebind_output)")
+        self.outputs = new            # (the caller keeps `new` alive: Model.forward holds its ring of result tensors)
+        self.captured = False
+
     def run(self):
         _lib.check(self._lib.y6_plan_run(self._h, _lib.current_stream_ptr()), "plan_run")
         return self.outputs

@@ -73,6 +73,9 @@ def _wrap(x, it):
 # running-statistics update, the EMA lerp) do not bump `tensor._version`; they bump this process-wide generation instead,
 # which is part of every plan-cache key: an eval forward after a native update re-derives its packed weights / folded BN.
 _NATIVE_GENERATION = [0]
+# Bumped by every `_apply` (.half() / .to() / .cuda()) and every `invalidate_plans()` of ANY HipModule: the fast path of
+# `compile()` below trusts a cached plan only while no module anywhere in the process was moved or re-parameterised.
+_STRUCTURE_GENERATION = [0]
 
 
 def bump_native_generation():
@@ -124,9 +127,11 @@ class HipModule(nn.Module):
         their parameter arena (their plans hold raw pointers to parameters, BatchNorm buffers and arena slots).  The
         Parameters keep their values: `p.data` stays a live view of the dropped arena until `_apply` / the next training
         graph re-points it."""
+        _STRUCTURE_GENERATION[0] += 1
         for m in self.modules():
             d = m.__dict__
             d.pop("_y6_plans", None)
+            d.pop("_y6_fast", None)
             d.pop("_y6_train_graphs", None)
             d.pop("_y6_arena", None)
 
@@ -161,6 +166,18 @@ class HipModule(nn.Module):
                                    f"(got a tensor on {t.device})")
         contig = [t.contiguous() for t in flat]
         quant = self.__dict__.get("_y6_quant")       # yolov6_amd.quant: calibration pass / int8 lowering
+        # Fast path (the per-call cost of the reference-signature API): the full key below walks every module of the tree
+        # (~1 ms of Python for YOLOv6-S); a repeat call is recognised by the input signature, the process-wide
+        # generations and the SUM of the autograd version counters of the tensors the plan was built from (in-place
+        # updates through torch - optimizers, load_state_dict, copy_ - bump them).  Edits through `.data` or of scalar
+        # attributes (eps, use_dfl, ...) need `invalidate_plans()`, as before.
+        sig = (tuple((tuple(t.shape), t.dtype) for t in flat), self.training, autotune, None if quant is None else quant.key(),
+               _NATIVE_GENERATION[0], _STRUCTURE_GENERATION[0])
+        fast = self.__dict__.get("_y6_fast")
+        if fast is not None and fast[0] == sig and sum(t._version for t in fast[1]) == fast[2]:
+            plan = fast[3]
+            plan.bind_inputs([contig[j] for j in plan.input_order])
+            return plan
         key = (tuple((tuple(t.shape), t.dtype) for t in flat), _params_version(self), self.training, autotune,
                None if quant is None else quant.key(), _NATIVE_GENERATION[0])
         cache = self.__dict__.setdefault("_y6_plans", {})
@@ -189,6 +206,8 @@ class HipModule(nn.Module):
             cache[key] = plan
         else:
             plan.bind_inputs([contig[j] for j in plan.input_order])
+        tensors = list(self.parameters()) + list(self.buffers())
+        self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan)
         return plan
 
     def forward(self, *inputs):

@@ -45,6 +45,11 @@ class _LazyFeatmaps(list):
 
 class Model(HipModule):
     export = False
+    # Eval results are handed out WITHOUT a copy: the decode kernel alternates between this many output tensors per plan, so
+    # a returned `det` stays valid until `output_buffers` further eval calls of this model have been made (the reference's
+    # callers - evaler.py:128-132, inferer.py:61-63 - pass it straight to non_max_suppression).  0: clone every result
+    # (the reference's independent-tensor semantics at +91 MB of traffic per b32 call).
+    output_buffers = 2
 
     def __init__(self, config, channels=3, num_classes=None, fuse_ab=False, distill_ns=False):
         super().__init__()
@@ -78,10 +83,19 @@ class Model(HipModule):
         prev = prev() if prev is not None else None
         if prev is not None:
             prev._fill()            # a caller still holds the previous result unread: copy it out before overwriting
+        nbuf = int(self.output_buffers)
+        if nbuf >= 2:
+            ring = getattr(plan, "_det_ring", None)
+            if ring is None or len(ring) != nbuf:
+                first = plan.outputs
+                ring = plan._det_ring = [first] + [torch.empty_like(first) for _ in range(nbuf - 1)]
+                plan._det_pos = 0
+            plan._det_pos = (plan._det_pos + 1) % nbuf
+            plan.rebind_output(ring[plan._det_pos])
         det = plan.run()
         feats = _LazyFeatmaps(self._featrefs, x.dtype)
         self.__dict__["_last_featmaps"] = weakref.ref(feats)
-        return [det.clone(), feats]
+        return [det if nbuf >= 2 else det.clone(), feats]
 
     def _apply(self, fn):
         self = super()._apply(fn)

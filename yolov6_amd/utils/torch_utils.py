@@ -47,6 +47,8 @@ def switch_to_deploy(model):
 
 
 def _invalidate(model):
+    from ..layers.common import _STRUCTURE_GENERATION
+    _STRUCTURE_GENERATION[0] += 1
     for m in model.modules():
-        for k in ("_y6_plans", "_y6_train_graphs", "_y6_arena"):
+        for k in ("_y6_plans", "_y6_fast", "_y6_train_graphs", "_y6_arena"):
             m.__dict__.pop(k, None)
