@@ -130,13 +130,29 @@ def calibrate_head_bias(model, x, target_frac=0.02):
     return shift
 
 
+def pmc_traffic_train():
+    """HBM bytes per launch of the training step's MFMA kernels (and of its memory-bound kernels) from the newest committed
+    profiles/*/pmc_traffic_train_*.json (tools/gpu_pmc_traffic_train.sh: separate FETCH_SIZE / WRITE_SIZE passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic_train_*.json")))
+    if not files:
+        return None, None, "no profiles/*/pmc_traffic_train_*.json committed"
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return (int(d["classes"]["mfma"]["hbm_bytes_per_launch"]), int(d["classes"]["hbm"]["hbm_bytes_per_launch"]),
+                os.path.relpath(files[-1], ROOT))
+    except Exception as e:  # noqa: BLE001
+        return None, None, f"unreadable {files[-1]}: {e}"
+
+
 def pmc_traffic(klass):
     """HBM bytes per launch of a kernel class from the newest committed PMC summary (profiles/*/pmc_traffic_*.json,
     written by tools/gpu_pmc_traffic.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
     command, FETCH_SIZE doubled per MI355X_MICROARCH.md).  Counters cannot be read from inside the timed run, so
     this is the one roofline field that is not measured live; (None, reason) when no summary is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*", "pmc_traffic_*.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic_*.json")) if "pmc_traffic_train" not in f)
     if not files:
         return None, "no profiles/*/pmc_traffic_*.json committed"
     try:
@@ -285,6 +301,15 @@ def train_main(args):
         achieved = mfma_fl / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
         plan_ms = sum(v["ms"] for v in cls.values())
         ms_per_step = elapsed / args.steps * 1e3
+        # the other roofline class of the step: everything that is not an MFMA kernel is HBM-bound glue (BatchNorm statistics /
+        # apply / backward, operand transposes, pools, head pack, loss, optimizer) - algorithmic bytes / event time vs 8 TB/s
+        mfma_keys = {k for k, v in cls.items() if ".conv" in k or k.endswith(".stem") or k == "bwd.wgrad"}
+        hbm_ms = sum(v["ms"] for k, v in cls.items() if k not in mfma_keys)
+        hbm_by = sum(v["bytes"] for k, v in cls.items() if k not in mfma_keys)
+        hbm_n = sum(v["launches"] for k, v in cls.items() if k not in mfma_keys)
+        mfma_n = sum(v["launches"] for k, v in cls.items() if k in mfma_keys)
+        t_mfma, t_hbm, t_src = pmc_traffic_train() if (args.model == "yolov6s" and args.size == 640 and args.batch == 64) else \
+            (None, None, "PMC summary exists for the configs[2] shape only")
         res = {
             "metric": f"images/sec (b{args.batch}/GPU, {args.size}x{args.size}) {args.model} training step (AMP fp16 activations, fp32 master weights)",
             "value": round(rep.throughput(args.batch, args.steps, elapsed), 2), "unit": "images/sec",
@@ -299,9 +324,17 @@ def train_main(args):
             "roofline": {"bound": "mfma", "kernel": "all MFMA kernels of the step: forward convs, data-gradient convs (conv_mfma.hip), "
                                                     "weight-gradient GEMM (wgrad.hip)",
                          "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "gflop_per_step": round(mfma_fl / 1e9, 1), "ms_per_step": round(mfma_ms, 3),
+                         "traffic": t_mfma, "traffic_unit": "bytes/launch (mean over the MFMA kernels)", "traffic_source": t_src,
+                         "launches_per_step": mfma_n,
+                         "gflop_per_step": round(mfma_fl / 1e9, 1), "ms_per_step": round(mfma_ms, 3),
                          "wgrad": {"ms": round(wg["ms"], 3), "launches": wg["launches"],
                                    "tflops": round(wg["flops"] / (wg["ms"] * 1e-3) / 1e12, 2) if wg["ms"] > 0 else 0}},
+            "roofline_hbm": {"bound": "hbm", "kernel": "the step's memory-bound kernels (BatchNorm statistics / apply / backward, wgrad operand "
+                                                       "transposes, pools, head pack / unpack, loss, weight packing)",
+                             "achieved": round(hbm_by / (hbm_ms * 1e-3) / 1e9, 1) if hbm_ms > 0 else 0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(hbm_by / (hbm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if hbm_ms > 0 else 0,
+                             "traffic": t_hbm, "traffic_unit": "bytes/launch (mean)", "launches_per_step": hbm_n,
+                             "algorithmic_bytes_per_launch": round(hbm_by / max(hbm_n, 1)), "ms_per_step": round(hbm_ms, 3)},
             "plans": {"ms_sum_of_ops": round(plan_ms, 3), "fwd_ops": graph.fwd_plan.num_ops, "bwd_ops": graph.bwd_plan.num_ops,
                       "fwd_gflop": round(graph.fwd_flops / 1e9, 1), "bwd_gflop": round(graph.bwd_flops / 1e9, 1)},
             "breakdown": {k: {"ms": round(v["ms"], 3), "launches": v["launches"],

@@ -198,6 +198,33 @@ typedef struct y6_decode_desc {
 } y6_decode_desc;
 int y6_head_decode(const y6_decode_desc* d, void* stream);
 
+/* The same epilogue fused with the two prediction convs in front of it: per level
+ *   cls = cls_pred(cls_feat), reg = reg_pred(reg_feat)   (1x1 convs + bias, effidehead.py:100-101)
+ * then sigmoid / DFL / dist2bbox / concat as y6_head_decode - ONE launch for all levels, the [B,A,nc+4*(reg_max+1)] fp16
+ * logits never reach HBM.  Same rounding points as the unfused ops (conv output fp16, sigmoid fp16, softmax fp16,
+ * projection fp16); the result is bit-identical to y6_conv2d x2 per level + y6_head_decode.
+ * Replaces: Detect.forward eval branch  yolov6/models/effidehead.py:93-139 from cls_preds / reg_preds on.
+ * cls_feat[l] / reg_feat[l]: views [B,Hl,Wl,Cl] (Cl % 16 == 0, 16-byte aligned); w_*: y6_pack_conv_weight images of the
+ * [nc,Cl,1,1] / [4*(reg_max+1),Cl,1,1] weights; b_*: fp32 biases (fp16-rounded values).                          */
+typedef struct y6_pred_decode_desc {
+    int32_t n_levels;
+    y6_tensor cls_feat[Y6_MAX_LEVELS];
+    y6_tensor reg_feat[Y6_MAX_LEVELS];
+    const void* w_cls[Y6_MAX_LEVELS];
+    const void* w_reg[Y6_MAX_LEVELS];
+    const float* b_cls[Y6_MAX_LEVELS];
+    const float* b_reg[Y6_MAX_LEVELS];
+    float stride[Y6_MAX_LEVELS];
+    int32_t use_dfl;
+    int32_t reg_max;
+    const float* proj;
+    float grid_cell_offset;
+    float* out;                /* [B, A, 5+nc] fp32 */
+    int32_t nc;
+} y6_pred_decode_desc;
+int y6_head_pred_decode_supported(const y6_pred_decode_desc* d);   /* 1 if the fused kernel takes this shape */
+int y6_head_pred_decode(const y6_pred_decode_desc* d, void* stream);
+
 /* ------------------------------------------------------------------------------------ */
 /* Batched NMS.  Replaces: non_max_suppression  yolov6/utils/nms.py:31-105 including the
  * torchvision.ops.nms call at :96 (greedy, IoU > thr strict, fp32, boxes offset by
@@ -361,7 +388,9 @@ typedef struct y6_plan y6_plan;
 enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_WGRAD_T = 4, Y6_TOP_WGRAD = 5,
        Y6_TOP_PACK = 6, Y6_TOP_POOL_BWD = 7, Y6_TOP_HEAD_PACK = 8, Y6_TOP_HEAD_UNPACK = 9, Y6_TOP_S2D = 10,
        Y6_TOP_BIAS_GRAD = 11, Y6_TOP_FILL = 12, Y6_TOP_ADD = 13,
-       Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16 };
+       Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16,
+       /* fused inference ops (generic plan ops as well) */
+       Y6_TOP_PRED_DECODE = 17, Y6_TOP_PW_S2 = 18, Y6_TOP_STEM_S2 = 19 };
 
 /* Batch statistics of a conv output + everything derived from them, on device:
  *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
@@ -603,6 +632,7 @@ int y6_plan_add_quantize_i8(y6_plan* p, const y6_tensor* x, float amax, const y6
 int y6_plan_add_stem(y6_plan* p, const y6_stem_desc* d);
 int y6_plan_add_sppf(y6_plan* p, const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3);
 int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);
+int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d);   /* generic op, tag Y6_TOP_PRED_DECODE; its `out` is rebindable */
 int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
 int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);
 int y6_plan_num_ops(const y6_plan* p);

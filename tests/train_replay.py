@@ -61,15 +61,21 @@ class TrainChain:
     def download(r: TRef):
         return r.to_nhwc_tensor().float().cpu().permute(0, 3, 1, 2)
 
-    def _cmp(self, phase, i, e, desc, pairs, kind_tol):
+    def _cmp(self, phase, i, e, desc, pairs, kind_tol, extra=None):
         """pairs: [(name, hip tensor, ref tensor)]"""
         err, worst = 0.0, ""
+        n_over = 0
         for name, hip, ref in pairs:
             den = float(ref.abs().max())
-            v = float((hip.double() - ref.double()).abs().max()) / max(den, 1e-30) if den > 0 else float(hip.abs().max())
+            d = (hip.double() - ref.double()).abs()
+            v = float(d.max()) / max(den, 1e-30) if den > 0 else float(hip.abs().max())
+            n_over += int((d > kind_tol * max(den, 1e-30)).sum()) if den > 0 else int((hip != 0).sum())
             if v >= err:
                 err, worst = v, name
-        self.rows.append(dict(phase=phase, op=i, kind=e["kind"], desc=desc, err=err, worst=worst, tol=kind_tol))
+        row = dict(phase=phase, op=i, kind=e["kind"], desc=desc, err=err, worst=worst, tol=kind_tol, n_over=n_over)
+        if extra:
+            row.update(extra)
+        self.rows.append(row)
 
     # ---------------------------------------------------------------- forward
     def _w16(self, p):
@@ -320,15 +326,29 @@ class TrainChain:
             items.append(("dalpha", e["alpha"], grads[id(alpha_leaf)]))
         plan.run_range(i, i + 1)
         torch.cuda.synchronize()
+        # ReLU ties: where the pre-activation z is zero to within the rounding of its fp32 evaluation order, the mask - and with
+        # it the whole element of dx - is decided by the order of three fused multiply-adds.  Such elements (a handful among
+        # 26 M at 32ch x 320^2 x b8) are excluded from the element-wise comparison and counted; the per-channel sums
+        # (dgamma / dbeta) keep them.
+        keep, n_ties = None, 0
+        if e["act"] == "relu":
+            zd = z.detach()
+            keep = zd.abs() > 1e-5 * float(zd.abs().max())
+            n_ties = int((~keep).sum())
         pairs = []
         for xb, (dref, dil, acc) in zip(leaves, e["dx"]):
             dx = grads[id(xb)]
+            kp = keep
             if dil == 2:
                 full = torch.zeros(dref.B, dref.C, dref.H, dref.W)
                 full[:, :, ::2, ::2] = dx
                 dx = full
+                if keep is not None:
+                    kp = torch.ones(dref.B, dref.C, dref.H, dref.W, dtype=torch.bool)
+                    kp[:, :, ::2, ::2] = keep
             v16 = self.put(dref, dx, acc=bool(acc))
-            pairs.append((f"dx dil{dil} acc{acc}", self.download(dref), v16))
+            hip = self.download(dref)
+            pairs.append((f"dx dil{dil} acc{acc}", hip * kp if kp is not None else hip, v16 * kp if kp is not None else v16))
             self.upload(dref, v16)
         if res_leaf is not None:
             dref, acc = e["dres"]
@@ -337,7 +357,7 @@ class TrainChain:
             self.upload(dref, v16)
         o_ = e["out"]
         desc = f"bnact_bwd x{len(leaves)} {e['act']} C={o_.C} {o_.H}x{o_.W}"
-        self._cmp("bwd", i, e, desc, pairs, 3e-3)
+        self._cmp("bwd", i, e, desc, pairs, 3e-3, extra=dict(relu_ties_excluded=n_ties))
         if items:
             self._check_param("bwd", i, e, desc + " params", items, 3e-3)
 

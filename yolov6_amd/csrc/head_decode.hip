@@ -6,7 +6,10 @@
 //   out[b, a, :] = (cx, cy, w, h, 1.0, cls[0..nc))   fp32, levels concatenated along a.
 // Four output elements per thread -> 16-byte coalesced fp32 stores; the fp16 NHWC logits of a
 // pixel are contiguous so the class reads coalesce too.
+#include <cstddef>
+
 #include "common.hpp"
+#include "plan_internal.hpp"
 
 namespace {
 
@@ -153,6 +156,156 @@ __global__ __launch_bounds__(256) void head_decode_tiled_kernel(const DecodeArgs
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused head tail: cls_pred + reg_pred (the two 1x1 convs of every level, effidehead.py:100-101) + the decode above in
+// ONE launch.  Unfused, YOLOv6-S at b32 spends 7 launches (6 latency-bound 1x1 convs of 9-21 us + the decode) and writes /
+// re-reads the [B,A,84] fp16 logits; here a block owns PD_TA consecutive anchors of one image and one level:
+//   * the MFMA pixel operand of a lane IS a 16-byte piece of the anchor's NHWC feature row, loaded straight from global
+//     memory (as conv1x1_stream_kernel); the weight fragments come from the packed 1x1 images (L2-resident, 10-50 KB);
+//   * wave w multiplies pixel fragment (w & 1) by the cout fragments t = (w >> 1), (w >> 1) + 2, ... of [cls | reg];
+//   * rounding points of the reference's fp16 graph are kept: conv output (+bias) -> fp16, sigmoid -> fp16, DFL softmax ->
+//     fp16, projection -> fp16 (the arithmetic below is the decode kernel's, on the same fp16 values);
+//   * logits never leave the CU: they go through the block's LDS image of the fp32 output rows.
+// The k-step order of the accumulation is the unfused kernels' (one chain, ascending input channel), so the result is
+// bit-identical to conv -> conv -> decode.
+constexpr int PD_TA = 64;
+
+struct PredDecodeArgs {
+    int n_levels;
+    const __half* cf[Y6_MAX_LEVELS];       // cls_conv output view (input of cls_pred)
+    const __half* rf[Y6_MAX_LEVELS];       // reg_conv output view (input of reg_pred)
+    int cf_cs[Y6_MAX_LEVELS], cf_co[Y6_MAX_LEVELS], rf_cs[Y6_MAX_LEVELS], rf_co[Y6_MAX_LEVELS];
+    const __half* wc[Y6_MAX_LEVELS];       // packed 1x1 weights (y6_pack_conv_weight)
+    const __half* wr[Y6_MAX_LEVELS];
+    const float* bc[Y6_MAX_LEVELS];
+    const float* br[Y6_MAX_LEVELS];
+    int C[Y6_MAX_LEVELS];                  // input channels of the level's pred convs (multiple of 16)
+    int H[Y6_MAX_LEVELS], W[Y6_MAX_LEVELS];
+    int astart[Y6_MAX_LEVELS + 1];         // first anchor of each level
+    int bstart[Y6_MAX_LEVELS + 1];         // first block (inside one image) of each level
+    float stride[Y6_MAX_LEVELS];
+    int use_dfl, reg_max, nreg;
+    const float* proj;
+    float cell_offset;
+    float* out;
+    int B, A, nc;
+    int ncf_c, ncf_r;                      // cout fragments (32 channels) of cls_pred / reg_pred
+};
+
+__device__ __forceinline__ float side_dist_lds(const PredDecodeArgs& a, const float* r, int side) {
+    if (!a.use_dfl) return r[side];
+    const int nb = a.reg_max + 1;
+    const float* bins = r + side * nb;
+    float m = -INFINITY;
+    for (int k = 0; k < nb; ++k) m = fmaxf(m, bins[k]);
+    float den = 0.f;
+    for (int k = 0; k < nb; ++k) den += __expf(bins[k] - m);
+    float num = 0.f;
+    for (int k = 0; k < nb; ++k) num += y6_round_f16(__expf(bins[k] - m) / den) * a.proj[k];
+    return y6_round_f16(num);
+}
+
+__global__ __launch_bounds__(256) void head_pred_decode_kernel(const PredDecodeArgs a, int blocks_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [PD_TA][no] output rows, then [PD_TA][nreg] reg values
+    const int no = a.nc + 5;
+    float* s_reg = s_rows + PD_TA * no;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / blocks_per_image;
+    const int rb = blockIdx.x - b * blocks_per_image;
+    int l = 0;
+#pragma unroll
+    for (int t = 1; t < Y6_MAX_LEVELS; ++t)
+        if (t < a.n_levels && rb >= a.bstart[t]) l = t;
+    const int HWl = a.H[l] * a.W[l];
+    const int a0 = (rb - a.bstart[l]) * PD_TA;               // first anchor of this block inside its level
+    const int na = min(PD_TA, HWl - a0);
+
+    // ---- the two 1x1 convs: this wave's pixel fragment x its cout fragments
+    const int pfrag = wave & 1, half = wave >> 1;
+    const int p = pfrag * 32 + (lane & 31);                  // anchor slot of this lane inside the block
+    const int kh = lane >> 5;
+    const int pl = a0 + (p < na ? p : na - 1);               // clamped: rows beyond the level are computed and dropped
+    const size_t pix = (size_t)b * HWl + pl;
+    const __half* crow = a.cf[l] + pix * a.cf_cs[l] + a.cf_co[l] + kh * 8;
+    const __half* rrow = a.rf[l] + pix * a.rf_cs[l] + a.rf_co[l] + kh * 8;
+    const int KS = a.C[l] >> 4;
+    const int nchunk = (a.C[l] + 31) >> 5;
+    const int ntot = a.ncf_c + a.ncf_r;
+    for (int t = half; t < ntot; t += 2) {
+        const bool is_cls = t < a.ncf_c;
+        const int cfi = is_cls ? t : t - a.ncf_c;
+        const __half* xrow = is_cls ? crow : rrow;
+        const __half* wbase = (is_cls ? a.wc[l] : a.wr[l]) + (size_t)cfi * nchunk * 1024 + lane * 8;   // [cfr][chunk][tap=1][ks][lane][8]
+        f32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        int ks = 0;
+        for (; ks + 4 <= KS; ks += 4) {                      // four k-steps of operands in flight
+            h8_t xa[4], wa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xa[j] = *reinterpret_cast<const h8_t*>(xrow + (ks + j) * 16);
+                wa[j] = *reinterpret_cast<const h8_t*>(wbase + (ks + j) * 512);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[j], xa[j], acc, 0, 0, 0);
+        }
+        for (; ks < KS; ++ks) {
+            const h8_t xa = *reinterpret_cast<const h8_t*>(xrow + ks * 16);
+            const h8_t wa = *reinterpret_cast<const h8_t*>(wbase + ks * 512);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, xa, acc, 0, 0, 0);
+        }
+        // C/D layout: col = pixel (lane & 31), row = cout = (r & 3) + 8 * (r >> 2) + 4 * kh
+        if (is_cls) {
+            float* row = s_rows + p * no + 5;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cfi * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                if (c < a.nc) {
+                    const float z = y6_round_f16(acc[r] + a.bc[l][c]);                 // the conv's fp16 output
+                    row[c] = y6_round_f16(1.f / (1.f + __expf(-z)));                   // torch.sigmoid of an fp16 tensor is fp16
+                }
+            }
+        } else {
+            float* row = s_reg + p * a.nreg;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cfi * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                if (c < a.nreg) row[c] = y6_round_f16(acc[r] + a.br[l][c]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- boxes: one thread per anchor (the decode kernel's arithmetic)
+    if (tid < na) {
+        const int local = a0 + tid;
+        const int y = local / a.W[l], x = local - y * a.W[l];
+        const float* rg = s_reg + tid * a.nreg;
+        const float d0 = side_dist_lds(a, rg, 0), d1 = side_dist_lds(a, rg, 1);
+        const float d2 = side_dist_lds(a, rg, 2), d3 = side_dist_lds(a, rg, 3);
+        const float ax = (float)x + a.cell_offset, ay = (float)y + a.cell_offset;
+        const float x1 = ax - d0, y1 = ay - d1, x2 = ax + d2, y2 = ay + d3;
+        float* r = s_rows + tid * no;
+        r[0] = (x1 + x2) / 2.f * a.stride[l];
+        r[1] = (y1 + y2) / 2.f * a.stride[l];
+        r[2] = (x2 - x1) * a.stride[l];
+        r[3] = (y2 - y1) * a.stride[l];
+        r[4] = 1.f;
+    }
+    __syncthreads();
+    const size_t obase = ((size_t)b * a.A + a.astart[l] + a0) * no;
+    const int nfl = na * no;
+    if ((obase & 3) == 0) {
+        const int nv = nfl >> 2;
+        for (int i = tid; i < nv; i += 256)
+            reinterpret_cast<float4*>(a.out + obase)[i] = reinterpret_cast<const float4*>(s_rows)[i];
+        for (int i = (nv << 2) + tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
+    } else {
+        for (int i = tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
+    }
+}
+
 }  // namespace
 
 extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
@@ -212,4 +365,92 @@ extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
     hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, a);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
+}
+
+// ---- fused head tail (descriptor: include/yolov6_hip.h y6_pred_decode_desc)
+extern "C" int y6_head_pred_decode_supported(const y6_pred_decode_desc* d) {
+    if (!d || d->n_levels < 1 || d->n_levels > Y6_MAX_LEVELS || !d->out) return 0;
+    const int nreg = 4 * (d->use_dfl ? d->reg_max + 1 : 1);
+    const size_t lds = (size_t)PD_TA * (d->nc + 5 + nreg) * sizeof(float);
+    if (lds > 64 * 1024) return 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor &c = d->cls_feat[l], &r = d->reg_feat[l];
+        if (!c.data || !r.data || !d->w_cls[l] || !d->w_reg[l]) return 0;
+        if (c.C != r.C || c.C % 16 != 0 || c.B != r.B || c.H != r.H || c.W != r.W || c.B != d->cls_feat[0].B) return 0;
+        if (c.cstride % 8 || c.coff % 8 || r.cstride % 8 || r.coff % 8 || ((uintptr_t)c.data & 15) || ((uintptr_t)r.data & 15)) return 0;
+        if (((uintptr_t)d->w_cls[l] & 15) || ((uintptr_t)d->w_reg[l] & 15)) return 0;
+    }
+    return ((uintptr_t)d->out & 15) == 0;
+}
+
+static int pred_decode_launch(const y6_pred_decode_desc* d, hipStream_t stream) {
+    Y6_REQUIRE(y6_head_pred_decode_supported(d), "head_pred_decode: unsupported descriptor (channels %% 16, 16-byte aligned views)");
+    Y6_REQUIRE(!d->use_dfl || d->proj, "head_pred_decode: use_dfl needs proj");
+    PredDecodeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_levels = d->n_levels;
+    int A = 0, nb = 0;
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor &c = d->cls_feat[l], &r = d->reg_feat[l];
+        a.cf[l] = (const __half*)c.data;
+        a.rf[l] = (const __half*)r.data;
+        a.cf_cs[l] = c.cstride;
+        a.cf_co[l] = c.coff;
+        a.rf_cs[l] = r.cstride;
+        a.rf_co[l] = r.coff;
+        a.wc[l] = (const __half*)d->w_cls[l];
+        a.wr[l] = (const __half*)d->w_reg[l];
+        a.bc[l] = d->b_cls[l];
+        a.br[l] = d->b_reg[l];
+        Y6_REQUIRE(a.bc[l] && a.br[l], "head_pred_decode: level %d bias missing", l);
+        a.C[l] = c.C;
+        a.H[l] = c.H;
+        a.W[l] = c.W;
+        a.astart[l] = A;
+        a.bstart[l] = nb;
+        a.stride[l] = d->stride[l];
+        A += c.H * c.W;
+        nb += (c.H * c.W + PD_TA - 1) / PD_TA;
+    }
+    a.astart[d->n_levels] = A;
+    a.bstart[d->n_levels] = nb;
+    a.use_dfl = d->use_dfl;
+    a.reg_max = d->reg_max;
+    a.nreg = 4 * (d->use_dfl ? d->reg_max + 1 : 1);
+    a.proj = d->proj;
+    a.cell_offset = d->grid_cell_offset;
+    a.out = d->out;
+    a.B = d->cls_feat[0].B;
+    a.A = A;
+    a.nc = d->nc;
+    a.ncf_c = (d->nc + 31) / 32;
+    a.ncf_r = (a.nreg + 31) / 32;
+    const size_t lds = (size_t)PD_TA * (d->nc + 5 + a.nreg) * sizeof(float);
+    hipLaunchKernelGGL(head_pred_decode_kernel, dim3((unsigned)(a.B * nb)), dim3(256), lds, stream, a, nb);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+extern "C" int y6_head_pred_decode(const y6_pred_decode_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(d, "head_pred_decode: null descriptor");
+    return pred_decode_launch(d, (hipStream_t)stream);
+}
+
+extern "C" int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add_pred_decode: null argument");
+    Y6_REQUIRE(y6_head_pred_decode_supported(d), "plan_add_pred_decode: unsupported descriptor");
+    double fl = 0.0, by = 0.0, A = 0.0;
+    const int nreg = 4 * (d->use_dfl ? d->reg_max + 1 : 1);
+    for (int l = 0; l < d->n_levels; ++l) {
+        const y6_tensor& c = d->cls_feat[l];
+        const double px = (double)c.B * c.H * c.W;
+        fl += 2.0 * px * c.C * (d->nc + nreg);
+        by += 2.0 * px * 2.0 * c.C + 2.0 * c.C * (d->nc + nreg);
+        A += (double)c.H * c.W;
+    }
+    by += (double)d->cls_feat[0].B * A * (d->nc + 5) * 4.0;
+    int rc = y6_plan_push(p, pred_decode_launch, d, Y6_TOP_PRED_DECODE, fl, by);
+    if (rc) return rc;
+    return y6_plan_mark_output(p, offsetof(y6_pred_decode_desc, out));
 }

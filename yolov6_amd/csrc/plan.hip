@@ -49,6 +49,7 @@ struct Op {
     y6_generic_fn gfn;
     int gtag;
     double gflops, gbytes;
+    int gout_off;   // >= 0: byte offset inside `blob` of the pointer to a caller-visible output tensor (rebindable)
     alignas(16) unsigned char blob[Y6_GENERIC_BLOB];
 };
 }  // namespace
@@ -297,7 +298,15 @@ int y6_plan_push_generic(y6_plan* p, y6_generic_fn fn, const void* desc, size_t 
     op.gtag = tag;
     op.gflops = flops;
     op.gbytes = bytes;
+    op.gout_off = -1;
     memcpy(op.blob, desc, size);
+    return Y6_OK;
+}
+
+int y6_plan_mark_output(y6_plan* p, size_t offset) {
+    Y6_REQUIRE(p && !p->ops.empty() && p->ops.back().kind == Y6_OP_GENERIC && offset + sizeof(void*) <= Y6_GENERIC_BLOB,
+               "plan_mark_output: no generic op to mark");
+    p->ops.back().gout_off = (int)offset;
     return Y6_OK;
 }
 
@@ -350,6 +359,14 @@ extern "C" int y6_plan_rebind_output(y6_plan* p, const void* old_ptr, void* new_
         if (op.kind == Y6_OP_NHWC2NCHW && op.dst == old_ptr) {
             op.dst = new_ptr;
             ++n;
+        }
+        if (op.kind == Y6_OP_GENERIC && op.gout_off >= 0) {   // fused ops that write the boundary tensor (head_pred_decode)
+            void* cur = nullptr;
+            memcpy(&cur, op.blob + op.gout_off, sizeof(cur));
+            if (cur == old_ptr) {
+                memcpy(op.blob + op.gout_off, &new_ptr, sizeof(new_ptr));
+                ++n;
+            }
         }
     }
     if (n) drop_graph(p);

@@ -10,6 +10,10 @@ constexpr size_t Y6_GENERIC_BLOB = 1024;
 // tag: Y6_TOP_* (include/yolov6_hip.h) for the per-op timing table; flops / bytes: algorithmic work of one launch
 int y6_plan_push_generic(y6_plan* p, y6_generic_fn fn, const void* desc, size_t size, int tag, double flops, double bytes);
 
+// the op pushed last writes a caller-visible boundary tensor through the `void*` at byte `offset` of its descriptor
+// (y6_plan_rebind_output re-points it)
+int y6_plan_mark_output(y6_plan* p, size_t offset);
+
 template <typename D>
 int y6_plan_push(y6_plan* p, int (*fn)(const D*, hipStream_t), const D* d, int tag, double flops, double bytes) {
     static_assert(sizeof(D) <= Y6_GENERIC_BLOB, "descriptor too large for a generic plan op");
