@@ -166,6 +166,28 @@ typedef struct y6_stem_desc {
 } y6_stem_desc;
 int y6_stem_conv(const y6_stem_desc* d, void* stream);
 
+/* Producer -> 3x3 stride-2 conv pairs as ONE launch (csrc/conv_fused.hip): the producer's output tile stays in LDS, the
+ * intermediate tensor is never written to HBM (pw.out / stem.out are IGNORED, their data may be NULL).
+ *   y6_fused_pw_s2   : s2(pw(x)), pw = 1x1 conv + bias + act, s2 = 3x3 stride-2 conv + bias + act.
+ *     Replaces: BiFusion.forward `self.downsample(self.cv2(x[2]))`  yolov6/layers/common.py:711-716 (ConvBNReLU 1x1 -> ConvBNReLU 3x3 s2)
+ *   y6_fused_stem_s2 : s2(stem(image)), stem as y6_stem_conv.
+ *     Replaces: EfficientRep.forward `self.ERBlock_2[0](self.stem(x))`  yolov6/models/efficientrep.py:96-99 (RepVGG deploy forms)
+ * Rounding points are the unfused graph's (producer output rounded to fp16 before the stride-2 conv reads it).
+ * Shapes taken: pw 64->64 / 128->128 into s2 of the same width; stem 3->32 into s2 32->{32,64}; no post affine, no residual.
+ * y6_fused_*_supported() says whether a pair is taken - callers fall back to the two separate ops.                    */
+typedef struct y6_pw_s2_desc {
+    y6_conv_desc pw;           /* ksize 1, stride 1 */
+    y6_conv_desc s2;           /* ksize 3, stride 2; s2.in = the (virtual) pw.out geometry */
+} y6_pw_s2_desc;
+typedef struct y6_stem_s2_desc {
+    y6_stem_desc stem;
+    y6_conv_desc s2;
+} y6_stem_s2_desc;
+int y6_fused_pw_s2_supported(const y6_pw_s2_desc* d);
+int y6_fused_pw_s2(const y6_pw_s2_desc* d, void* stream);
+int y6_fused_stem_s2_supported(const y6_stem_s2_desc* d);
+int y6_fused_stem_s2(const y6_stem_s2_desc* d, void* stream);
+
 /* Three chained MaxPool2d(5, stride 1, pad 2) (-inf padding) of `x`, written to y1,y2,y3.
  * Replaces: SPPFModule.forward  common.py:106-112 ; CSPSPPFModule.forward  :150-158
  * x,y1,y2,y3 are usually the four channel slices of one 4*C buffer (no torch.cat).        */
@@ -632,6 +654,8 @@ int y6_plan_add_quantize_i8(y6_plan* p, const y6_tensor* x, float amax, const y6
 int y6_plan_add_stem(y6_plan* p, const y6_stem_desc* d);
 int y6_plan_add_sppf(y6_plan* p, const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3);
 int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);
+int y6_plan_add_pw_s2(y6_plan* p, const y6_pw_s2_desc* d);       /* generic op, tag Y6_TOP_PW_S2 */
+int y6_plan_add_stem_s2(y6_plan* p, const y6_stem_s2_desc* d);   /* generic op, tag Y6_TOP_STEM_S2; its image pointer is a rebindable input */
 int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d);   /* generic op, tag Y6_TOP_PRED_DECODE; its `out` is rebindable */
 int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
 int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);

@@ -136,3 +136,17 @@ class MockBuilder:
         self.op_log.append(dict(kind="decode", cls=list(cls), reg=list(reg), out=det, strides=list(strides), use_dfl=bool(use_dfl),
                                 reg_max=int(reg_max), proj=proj, nc=nc))
         return det
+
+    def head_pred_decode(self, cls_feat, reg_feat, cls_preds, reg_preds, strides, use_dfl, reg_max, proj, nc, grid_cell_offset=0.5):
+        """The fused head tail (engine.PlanBuilder.head_pred_decode): cls_pred / reg_pred 1x1 convs of every level + decode,
+        logged as ONE op."""
+        n0 = len(self.op_log)
+        cls = [self.conv(c, w, b, 1, None) for c, (w, b) in zip(cls_feat, cls_preds)]
+        reg = [self.conv(r, w, b, 1, None) for r, (w, b) in zip(reg_feat, reg_preds)]
+        det = self.head_decode(cls, reg, strides, use_dfl, reg_max, proj, nc, grid_cell_offset)
+        del self.op_log[n0:]
+        self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat), reg_feat=list(reg_feat),
+                                cls_preds=[(w.detach().float(), None if b is None else b.detach().float()) for w, b in cls_preds],
+                                reg_preds=[(w.detach().float(), None if b is None else b.detach().float()) for w, b in reg_preds],
+                                out=det, strides=list(strides), use_dfl=bool(use_dfl), reg_max=int(reg_max), proj=proj, nc=nc))
+        return det

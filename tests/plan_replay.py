@@ -59,6 +59,16 @@ class OracleChain:
                 a = 1.0 if e["alpha"] is None else o.q(e["alpha"].detach().float().cpu())
                 y = o.q(y + o.q(a * self._get(e["res"])))
             return [(e["out"], y)]
+        if k in ("pw_s2", "stem_s2"):      # producer -> 3x3 stride-2 conv as one op: the producer's output is an fp16 tensor too
+            from oracle.model_oracle import Oracle
+            pe, se = e["producer"], e["s2"]
+            x = o.q(pe["x"].float().cpu()) if k == "stem_s2" else self._get(pe["x"])
+            if k == "stem_s2" and pe["x"].dtype == torch.uint8:
+                x = o.q(pe["x"].float().cpu() / 255.0)
+            fb = lambda t: None if t is None else t.detach().float().cpu()
+            m = Oracle.conv_fused(o, x, pe["w"].detach().float().cpu(), fb(pe["b"]), pe["stride"], pe["act"], None)
+            y = Oracle.conv_fused(o, m, se["w"].detach().float().cpu(), fb(se["b"]), 2, se["act"], None)
+            return [(e["out"], y)]
         if k == "conv_i8":       # int8 conv (oracle/int8_oracle.py defines the arithmetic; scales come from the plan's op log)
             from oracle.int8_oracle import int8_conv
             b = None if e["b"] is None else e["b"].detach().float().cpu()
@@ -88,20 +98,36 @@ class OracleChain:
             k = e["kind"]
             if k in ("nhwc2nchw", "absmax"):
                 continue
-            if k == "decode":
-                cls = [self._get(r) for r in e["cls"]]
-                reg = [self._get(r) for r in e["reg"]]
+            if k in ("decode", "pred_decode"):
+                if k == "pred_decode":      # the fused head tail: cls_pred / reg_pred (1x1 conv + bias, fp16 output) + decode
+                    from oracle.model_oracle import Oracle
+                    ins = e["cls_feat"] + e["reg_feat"]
+                    vals = [self._get(r) for r in ins]
+                    nl = len(e["cls_feat"])
+                    cls = [Oracle.conv_fused(self.orc, v, w, b, 1, None) for v, (w, b) in zip(vals[:nl], e["cls_preds"])]
+                    reg = [Oracle.conv_fused(self.orc, v, w, b, 1, None) for v, (w, b) in zip(vals[nl:], e["reg_preds"])]
+                else:
+                    ins = e["cls"] + e["reg"]
+                    cls = [self._get(r) for r in e["cls"]]
+                    reg = [self._get(r) for r in e["reg"]]
+                    vals = cls + reg
                 ref = self.orc.decode(cls, reg)
                 if teacher_force:
-                    for r, v in zip(e["cls"] + e["reg"], cls + reg):
+                    for r, v in zip(ins, vals):
                         self._upload(r, v)
                     plan.run_range(i, i + 1)
                     torch.cuda.synchronize()
                     hip = e["out"].float().cpu()
                     d = (hip - ref).abs()
-                    self.rows.append(dict(op=i, kind=k, desc=f"decode A={ref.shape[1]}",
-                                          err=float((d / ref.abs().clamp(min=1.0)).max()), err_abs=float(d.max()),
-                                          err_scores=float(d[..., 5:].max()), err_box_px=float(d[..., :4].max())))
+                    row = dict(op=i, kind=k, desc=f"{k} A={ref.shape[1]}",
+                               err=float((d / ref.abs().clamp(min=1.0)).max()), err_abs=float(d.max()),
+                               err_scores=float(d[..., 5:].max()), err_box_px=float(d[..., :4].max()))
+                    if k == "pred_decode":
+                        # the fused op contains the reg_pred conv: a one-ulp flip of its fp16 output (the bar of every conv op)
+                        # moves a box edge by ulp(distance) x stride - the bound of the box columns of this op
+                        dmax = [float(e["reg_max"]) if e["use_dfl"] else float(r_.abs().max()) for r_ in reg]
+                        row["box_tol_px"] = 1.5 * max(dm * 2.0 ** -10 * float(st) for dm, st in zip(dmax, e["strides"]))
+                    self.rows.append(row)
                 self.final = ref
                 continue
             if teacher_force:
@@ -147,6 +173,10 @@ def _describe(e):
         o = e["out"]
         extra = ("+post" if e["post"] is not None else "") + ("+res" if e["res"] is not None else "")
         return f"{k} {w.shape[1]}->{w.shape[0]} k{w.shape[-1]} s{e['stride']} {e['act']}{extra} out {o.B}x{o.H}x{o.W}"
+    if k in ("pw_s2", "stem_s2"):
+        pw, sw, o = e["producer"]["w"], e["s2"]["w"], e["out"]
+        return (f"{k} {pw.shape[1]}->{pw.shape[0]} k{pw.shape[-1]} {e['producer']['act']} | {sw.shape[1]}->{sw.shape[0]} k3 s2 {e['s2']['act']} "
+                f"out {o.B}x{o.H}x{o.W}")
     if k == "convt":
         return f"convT {e['w'].shape[0]}->{e['w'].shape[1]} out {e['out'].H}x{e['out'].W}"
     if k == "sppf":

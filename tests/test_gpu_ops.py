@@ -213,6 +213,93 @@ def test_stem_conv(dtype, cout, hw):
     assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
 
 
+@pytest.mark.parametrize("chans,hw,batch", [(64, (40, 40), 3), (64, (38, 54), 2), (64, (160, 160), 4),     # BiFusion1 of YOLOv6-S: 64ch (exact / ragged / many tiles per block)
+                                            (128, (40, 40), 3), (128, (22, 30), 2), (128, (80, 80), 6)])
+@pytest.mark.parametrize("acts", [("relu", "relu"), ("silu", "silu")])
+def test_fused_pw_s2_equals_two_convs(chans, hw, batch, acts):
+    """1x1 conv -> 3x3 stride-2 conv as ONE op (csrc/conv_fused.hip; BiFusion `downsample(cv2(x))`, common.py:711-716): the pair the
+    plan builder fuses, against (a) the fp32 statement rounded to fp16 at the two op boundaries and (b) the two separate ops."""
+    C_ = chans
+    x = G.rand_nhwc(batch, hw[0], hw[1], C_, seed=61, scale=2.0)
+    w1, b1 = _mk_weights(C_, C_, 1, 62)
+    w2, b2 = _mk_weights(C_, C_, 3, 63)
+    outs = []
+    for fuse in (True, False):
+        pb = PlanBuilder(G.DEV)
+        pb._fuse_s2 = fuse
+        t = pb.conv(x, w1, b1, stride=1, act=acts[0])
+        Ho, Wo = (hw[0] + 1) // 2, (hw[1] + 1) // 2
+        cat = pb.new_buffer(batch, Ho, Wo, 2 * C_)              # the consumer writes a channel slice (the BiFusion concat buffer)
+        cat.buf.zero_()
+        o = pb.conv(t, w2, b2, stride=2, act=acts[1], out=cat.slice(C_, C_))
+        plan = pb.finalize(o, autotune=False)
+        kinds = [e["kind"] for e in plan.op_log]
+        assert kinds == (["pw_s2"] if fuse else ["conv", "conv"]), kinds
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(G.nhwc_to_nchw_f32(o))
+        assert float(cat.slice(0, C_).to_nhwc_tensor().abs().max()) == 0.0, "the fused op wrote outside its channel slice"
+    mid = G.q16(G.conv_reference(G.nhwc_to_nchw_f32(x), w1, b1, 1, acts[0]))
+    ref = G.conv_reference(mid, w2, b2, 2, acts[1])
+    tol = G.op_tolerance(acts[1])
+    print("fused pw->s2 vs statement", G.max_rel(outs[0], ref), "two convs vs statement", G.max_rel(outs[1], ref), "fused vs two convs",
+          G.max_rel(outs[0], outs[1]))
+    assert G.max_rel(outs[0], ref) < tol
+    assert G.max_rel(outs[0], outs[1]) < tol
+
+
+def test_fused_pw_s2_refuses_a_later_reader_of_the_elided_tensor():
+    x = G.rand_nhwc(1, 16, 16, 64, seed=64)
+    w1, b1 = _mk_weights(64, 64, 1, 65)
+    w2, b2 = _mk_weights(64, 64, 3, 66)
+    pb = PlanBuilder(G.DEV)
+    t = pb.conv(x, w1, b1, stride=1, act="relu")
+    pb.conv(t, w2, b2, stride=2, act="relu")
+    with pytest.raises(RuntimeError, match="fused into its consumer"):
+        pb.conv(t, w2, b2, stride=1, act="relu")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.uint8])
+@pytest.mark.parametrize("cout2", [64, 32])
+@pytest.mark.parametrize("hw,batch", [((64, 128), 2), ((72, 88), 3), ((320, 512), 5)])     # exact tiles / ragged on both axes / more tiles than resident blocks
+def test_fused_stem_s2_equals_stem_plus_conv(dtype, cout2, hw, batch):
+    """Image conv (3 -> 32, 3x3 stride 2) -> 3x3 stride-2 conv as ONE op (EfficientRep stem + ERBlock_2[0], efficientrep.py:96-99)."""
+    from yolov6_amd.engine import NCHWInput
+    g = torch.Generator().manual_seed(71)
+    if dtype == torch.uint8:
+        img = torch.randint(0, 256, (batch, 3) + hw, generator=g, dtype=torch.uint8)
+        xin = (img.half() / 255).float()                        # imgs.half() / 255 (core/evaler.py:121-123)
+    else:
+        img = (torch.rand((batch, 3) + hw, generator=g) - 0.3).to(dtype)
+        xin = img.float()
+    w1, b1 = _mk_weights(32, 3, 3, 72)
+    w2, b2 = _mk_weights(cout2, 32, 3, 73)
+    outs = []
+    for fuse in (True, False):
+        pb = PlanBuilder(G.DEV)
+        pb._fuse_s2 = fuse
+        t = pb.conv(NCHWInput(img.to(G.DEV).contiguous()), w1, b1, stride=2, act="relu")
+        o = pb.conv(t, w2, b2, stride=2, act="relu")
+        plan = pb.finalize(o, autotune=False)
+        kinds = [e["kind"] for e in plan.op_log]
+        assert kinds == (["stem_s2"] if fuse else ["stem", "conv"]), kinds
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(G.nhwc_to_nchw_f32(o))
+        if fuse:        # the image is a rebindable boundary input of the fused op too
+            img2 = img.flip(0).contiguous().to(G.DEV)
+            plan.bind_inputs([img2])
+            plan.run()
+            torch.cuda.synchronize()
+            assert torch.equal(G.nhwc_to_nchw_f32(o), outs[0].flip(0)), "rebinding the image of the fused stem op"
+    mid = G.q16(G.conv_reference(xin.half().float(), w1, b1, 2, "relu"))
+    ref = G.conv_reference(mid, w2, b2, 2, "relu")
+    print("fused stem->s2 vs statement", G.max_rel(outs[0], ref), "two ops vs statement", G.max_rel(outs[1], ref), "fused vs two ops",
+          G.max_rel(outs[0], outs[1]))
+    assert G.max_rel(outs[0], ref) < TOL
+    assert G.max_rel(outs[0], outs[1]) < TOL
+
+
 def test_stem_conv_persistent_many_tiles():
     """More tiles than resident blocks: exercises the prefetch-next-tile loop of the persistent stem."""
     g = torch.Generator().manual_seed(23)
@@ -253,6 +340,49 @@ def test_layout_adapters_exact():
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), x.float().cpu())
     assert torch.equal(r.to_nhwc_tensor().cpu(), x.permute(0, 2, 3, 1).cpu())
+
+
+@pytest.mark.parametrize("use_dfl", [False, True])
+@pytest.mark.parametrize("nc,chans,sizes", [(80, (64, 128, 256), [(20, 20), (10, 10), (5, 5)]),      # YOLOv6-S head widths, ragged last blocks
+                                            (80, (32, 48, 16), [(8, 12), (4, 6), (2, 3)]),           # Cin % 32 == 16, tiny maps
+                                            (20, (64, 64, 128, 128), [(16, 16), (8, 8), (4, 4), (2, 2)])])   # four levels (P6), nc % 8 != 0
+def test_head_pred_decode_fused_equals_convs_plus_decode(use_dfl, nc, chans, sizes):
+    """The fused head tail (cls_pred + reg_pred 1x1 convs of every level + decode in one launch, csrc/head_decode.hip) against
+    the unfused ops it replaces on the same tensors: same k-step order and the same rounding points -> the same bits."""
+    B, reg_max = 3, 16
+    strides = [8.0, 16.0, 32.0, 64.0][:len(sizes)]
+    nreg = 4 * (reg_max + 1) if use_dfl else 4
+    g = torch.Generator().manual_seed(77)
+    # cls_conv / reg_conv outputs of a level live in ONE buffer (Detect._lower_cls_reg_convs): channel slices, cstride 2C
+    both = [G.rand_nhwc(B, h, w, 2 * c, seed=40 + i, scale=2.0) for i, ((h, w), c) in enumerate(zip(sizes, chans))]
+    cfeat = [b.slice(0, c) for b, c in zip(both, chans)]
+    rfeat = [b.slice(c, c) for b, c in zip(both, chans)]
+    wc = [(torch.randn((nc, c, 1, 1), generator=g) * (2.0 / c ** 0.5), torch.randn(nc, generator=g) - 2.0) for c in chans]
+    wr = [(torch.randn((nreg, c, 1, 1), generator=g) * (2.0 / c ** 0.5), torch.randn(nreg, generator=g) + 1.0) for c in chans]
+    proj = torch.linspace(0, reg_max, reg_max + 1)
+    pb = PlanBuilder(G.DEV)
+    cls = [pb.conv(x, w, b, 1, None) for x, (w, b) in zip(cfeat, wc)]
+    reg = [pb.conv(x, w, b, 1, None) for x, (w, b) in zip(rfeat, wr)]
+    ref = pb.head_decode(cls, reg, strides, use_dfl, reg_max, proj, nc)
+    pb.finalize(ref, autotune=False).run()
+    pf = PlanBuilder(G.DEV)
+    out = pf.head_pred_decode(cfeat, rfeat, wc, wr, strides, use_dfl, reg_max, proj, nc)
+    assert out is not None, "the fused kernel refused a shape it is meant for"
+    plan = pf.finalize(out, autotune=False)
+    assert plan.num_ops == 1
+    plan.run()
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    d = (out - ref).abs()
+    print("fused head tail vs convs + decode: max |diff| scores", float(d[..., 5:].max()), "boxes", float(d[..., :4].max()))
+    assert torch.equal(out[..., 4:], ref[..., 4:]), "class scores / objectness differ from the unfused ops"
+    assert torch.equal(out[..., :4], ref[..., :4]), "boxes differ from the unfused ops"
+    # a second output tensor (Model.forward alternates its results): the plan writes where it is told to
+    out2 = torch.zeros_like(out)
+    plan.rebind_output(out2)
+    plan.run()
+    torch.cuda.synchronize()
+    assert torch.equal(out2, ref)
 
 
 @pytest.mark.parametrize("use_dfl", [False, True])

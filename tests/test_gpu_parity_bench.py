@@ -58,7 +58,7 @@ def test_per_layer_teacher_forced_and_end_to_end(name, size, batch):
         assert sync < 2e-3, f"per-layer oracle chain deviates from Oracle.forward by {sync:.3e} (test harness out of sync)"
         free = []
         for i, e in enumerate(plan.op_log):
-            outs = e.get("outs") or ([e["out"]] if e["kind"] in ("conv", "stem", "convt") else [])
+            outs = e.get("outs") or ([e["out"]] if e["kind"] in ("conv", "stem", "convt", "pw_s2", "stem_s2") else [])
             for r in outs:
                 v = chain._get(r)
                 d = (chain._download(r) - v).abs()
@@ -95,7 +95,10 @@ def test_per_layer_teacher_forced_and_end_to_end(name, size, batch):
         act = "silu" if " silu" in d else ("hardswish" if "hardswish" in d else "relu")
         tol = op_tolerance(act, with_res="+res" in d)
         r["tol"] = tol
-        if r["err"] > tol:
+        if r["kind"] == "pred_decode":     # conv + decode in one op: scores at the conv's bar, boxes at one fp16 ulp of the distance x stride
+            if r["err_scores"] > 1e-3 or r["err_box_px"] > r["box_tol_px"]:
+                bad.append(r)
+        elif r["err"] > tol:
             bad.append(r)
     assert not bad, f"{name}: {len(bad)} ops above their bound teacher-forced, e.g. {bad[:3]}"
     if name == "yolov6s":

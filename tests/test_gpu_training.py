@@ -872,11 +872,19 @@ def test_checkpoint_paths_after_training_steps(tmp_path):
     sd1 = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     with torch.no_grad():
         ref1, _ = Oracle(cfg, sd1, 80, emulate_fp16=True).forward(x.float().cpu())
+        ref32, _ = Oracle(cfg, sd1, 80, emulate_fp16=False).forward(x.float().cpu())
     assert torch.isfinite(ref1).all(), "the test's own configuration overflows fp16 in eval mode"
     assert torch.isfinite(det1).all(), [int(v) for v in (~torch.isfinite(det1)).nonzero()[0]]
-    e1 = (det1.float().cpu() - ref1).abs() / ref1.abs().clamp(min=1.0)
-    print("eval after native training steps vs oracle on the new state_dict: scores", float(e1[..., 5:].max()), "all", float(e1.max()))
-    assert float(e1[..., 5:].max()) < 2e-3 and float(e1.max()) < 8e-3, (float(e1[..., 5:].max()), float(e1.max()))
+    rel = lambda a, b: (a - b).abs() / b.abs().clamp(min=1.0)
+    e1, fl = rel(det1.float().cpu(), ref32), rel(ref1, ref32)
+    # two training steps on random weights leave running statistics that do not match the activations any more: eval-mode
+    # activations grow by orders of magnitude and fp16 storage noise with them.  The scale is the reference's own fp16
+    # deviation from its fp32 result on this state_dict (the bar of tests/test_gpu_model.py).
+    print("eval after native training steps, error vs the fp32 oracle on the new state_dict: HIP scores", float(e1[..., 5:].max()), "all",
+          float(e1.max()), "| fp16-emulating oracle scores", float(fl[..., 5:].max()), "all", float(fl.max()),
+          "| largest |det|", float(ref32.abs().max()))
+    assert float(e1[..., 5:].max()) <= 2.0 * float(fl[..., 5:].max()) + 1e-3, (float(e1[..., 5:].max()), float(fl[..., 5:].max()))
+    assert float(e1.max()) <= 2.0 * float(fl.max()) + 4e-3, (float(e1.max()), float(fl.max()))
     fresh = copy.deepcopy(model)
     assert not any(k.startswith("_y6_") for m in fresh.modules() for k in m.__dict__)
     assert torch.allclose(fresh(x)[0], det1, atol=2e-3, rtol=2e-3)          # (the autotuner may pick other kernel variants)

@@ -50,6 +50,22 @@ class DecodeDesc(C.Structure):
                 ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32)]
 
 
+class PwS2Desc(C.Structure):
+    _fields_ = [("pw", ConvDesc), ("s2", ConvDesc)]
+
+
+class StemS2Desc(C.Structure):
+    _fields_ = [("stem", StemDesc), ("s2", ConvDesc)]
+
+
+class PredDecodeDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("cls_feat", Tensor * MAX_LEVELS), ("reg_feat", Tensor * MAX_LEVELS),
+                ("w_cls", C.c_void_p * MAX_LEVELS), ("w_reg", C.c_void_p * MAX_LEVELS),
+                ("b_cls", C.c_void_p * MAX_LEVELS), ("b_reg", C.c_void_p * MAX_LEVELS),
+                ("stride", C.c_float * MAX_LEVELS), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
+                ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32)]
+
+
 class NmsDesc(C.Structure):
     _fields_ = [("pred", C.c_void_p), ("B", C.c_int32), ("A", C.c_int32), ("nc", C.c_int32),
                 ("conf_thres", C.c_float), ("iou_thres", C.c_float), ("classes", C.c_void_p),
@@ -154,7 +170,8 @@ class LossGradDesc(C.Structure):
 
 WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
 TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
-             8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize"}
+             8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize",
+             17: "pred_decode", 18: "pw_s2", 19: "stem_s2"}
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
@@ -182,6 +199,12 @@ SIGNATURES = {
     "y6_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tensor), C.c_void_p]),
     "y6_nhwc_to_nchw": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_int, C.c_void_p]),
     "y6_head_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "y6_fused_pw_s2_supported": (C.c_int, [C.POINTER(PwS2Desc)]),
+    "y6_fused_pw_s2": (C.c_int, [C.POINTER(PwS2Desc), C.c_void_p]),
+    "y6_fused_stem_s2_supported": (C.c_int, [C.POINTER(StemS2Desc)]),
+    "y6_fused_stem_s2": (C.c_int, [C.POINTER(StemS2Desc), C.c_void_p]),
+    "y6_head_pred_decode_supported": (C.c_int, [C.POINTER(PredDecodeDesc)]),
+    "y6_head_pred_decode": (C.c_int, [C.POINTER(PredDecodeDesc), C.c_void_p]),
     "y6_nms_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "y6_nms": (C.c_int, [C.POINTER(NmsDesc), C.c_void_p]),
     "y6_tal_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -245,6 +268,9 @@ SIGNATURES = {
     "y6_plan_add_stem": (C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
     "y6_plan_add_sppf": (C.c_int, [C.c_void_p] + [C.POINTER(Tensor)] * 4),
     "y6_plan_add_decode": (C.c_int, [C.c_void_p, C.POINTER(DecodeDesc)]),
+    "y6_plan_add_pred_decode": (C.c_int, [C.c_void_p, C.POINTER(PredDecodeDesc)]),
+    "y6_plan_add_pw_s2": (C.c_int, [C.c_void_p, C.POINTER(PwS2Desc)]),
+    "y6_plan_add_stem_s2": (C.c_int, [C.c_void_p, C.POINTER(StemS2Desc)]),
     "y6_plan_add_nchw2nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Tensor)]),
     "y6_plan_add_nhwc2nchw": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_void_p, C.c_int]),
     "y6_plan_num_ops": (C.c_int, [C.c_void_p]),

@@ -27,6 +27,7 @@ SOURCES = {
     "conv_mfma.hip": [],
     "conv_dma.hip": [],
     "conv_misc.hip": [],
+    "conv_fused.hip": [],
     "head_decode.hip": [],
     "nms.hip": ["-ffp-contract=off"],
     "tal.hip": ["-ffp-contract=off"],
@@ -37,7 +38,7 @@ SOURCES = {
     "quant.hip": [],
     "plan.hip": [],
 }
-HEADERS = ["common.hpp", "conv_common.hpp", "plan_internal.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
+HEADERS = ["common.hpp", "conv_common.hpp", "plan_internal.hpp", "stem_piece.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
 
 
 def hipcc():

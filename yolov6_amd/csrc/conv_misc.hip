@@ -2,6 +2,7 @@
 // cross-check conv, the NCHW stem conv, ConvTranspose2d(k2,s2), SPPF pooling and the
 // NCHW<->NHWC boundary adapters.  File:line citations are into the reference tree.
 #include "common.hpp"
+#include "stem_piece.hpp"
 
 namespace {
 
@@ -306,46 +307,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TI* __restrict__ i
 constexpr int STEM4_WPC = 17;                       // 16-byte pieces per window row: cols [2*ox0-8, 2*ox0+128)
 constexpr int STEM4_PITCH = STEM4_WPC * 8 + 8;      // halves
 constexpr int STEM4_NPIECE = 3 * STEM_IH * STEM4_WPC;
-
-template <typename TI>
-struct StemPiece;
-template <>
-struct StemPiece<__half> {
-    uint4 v;
-    __device__ __forceinline__ void load(const __half* p) { v = *reinterpret_cast<const uint4*>(p); }
-    __device__ __forceinline__ void zero() { v = make_uint4(0u, 0u, 0u, 0u); }
-    __device__ __forceinline__ uint4 as_half8() const { return v; }
-};
-template <>
-struct StemPiece<float> {
-    float4 a, b;
-    __device__ __forceinline__ void load(const float* p) {
-        a = *reinterpret_cast<const float4*>(p);
-        b = *reinterpret_cast<const float4*>(p + 4);
-    }
-    __device__ __forceinline__ void zero() { a = b = make_float4(0.f, 0.f, 0.f, 0.f); }
-    __device__ __forceinline__ uint4 as_half8() const {
-        h8_t h = {(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w,
-                  (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
-        return *reinterpret_cast<const uint4*>(&h);
-    }
-};
-
-template <>
-struct StemPiece<uint8_t> {      // 8 pixels = 8 bytes; converted to the fp16 values of `imgs.half() / 255`
-    uint2 v;
-    __device__ __forceinline__ void load(const uint8_t* p) { v = *reinterpret_cast<const uint2*>(p); }
-    __device__ __forceinline__ void zero() { v = make_uint2(0u, 0u); }
-    __device__ __forceinline__ uint4 as_half8() const {
-        h8_t h;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned b = ((j < 4 ? v.x : v.y) >> (8 * (j & 3))) & 0xffu;
-            h[j] = (_Float16)((float)b / 255.f);
-        }
-        return *reinterpret_cast<const uint4*>(&h);
-    }
-};
 
 template <int ACT>
 __device__ __forceinline__ float stem_act(float v) {

@@ -50,6 +50,7 @@ struct Op {
     int gtag;
     double gflops, gbytes;
     int gout_off;   // >= 0: byte offset inside `blob` of the pointer to a caller-visible output tensor (rebindable)
+    int gin_off;    // >= 0: ... of the pointer to the caller's boundary input (the NCHW image of a fused stem op)
     alignas(16) unsigned char blob[Y6_GENERIC_BLOB];
 };
 }  // namespace
@@ -299,6 +300,7 @@ int y6_plan_push_generic(y6_plan* p, y6_generic_fn fn, const void* desc, size_t 
     op.gflops = flops;
     op.gbytes = bytes;
     op.gout_off = -1;
+    op.gin_off = -1;
     memcpy(op.blob, desc, size);
     return Y6_OK;
 }
@@ -310,18 +312,30 @@ int y6_plan_mark_output(y6_plan* p, size_t offset) {
     return Y6_OK;
 }
 
+int y6_plan_mark_input(y6_plan* p, size_t offset) {
+    Y6_REQUIRE(p && !p->ops.empty() && p->ops.back().kind == Y6_OP_GENERIC && offset + sizeof(void*) <= Y6_GENERIC_BLOB,
+               "plan_mark_input: no generic op to mark");
+    p->ops.back().gin_off = (int)offset;
+    return Y6_OK;
+}
+
+// the boundary-input pointer of an op (stem, NCHW->NHWC adapter, a fused op marked with y6_plan_mark_input), or null
+static const void** boundary_input(Op& op) {
+    if (op.kind == Y6_OP_STEM) return &op.stem.in_nchw;
+    if (op.kind == Y6_OP_NCHW2NHWC) return &op.src;
+    if (op.kind == Y6_OP_GENERIC && op.gin_off >= 0) return reinterpret_cast<const void**>(op.blob + op.gin_off);
+    return nullptr;
+}
+
 extern "C" int y6_plan_rebind(y6_plan* p, const void* old_ptr, const void* new_ptr) {
     // Point every op that reads the caller's boundary tensor `old_ptr` at `new_ptr` (same shape
     // and dtype).  Drops a captured graph: its kernel nodes baked the old address.
     Y6_REQUIRE(p && old_ptr && new_ptr, "plan_rebind: null argument");
     int n = 0;
     for (Op& op : p->ops) {
-        if (op.kind == Y6_OP_STEM && op.stem.in_nchw == old_ptr) {
-            op.stem.in_nchw = new_ptr;
-            ++n;
-        }
-        if (op.kind == Y6_OP_NCHW2NHWC && op.src == old_ptr) {
-            op.src = new_ptr;
+        const void** slot = boundary_input(op);
+        if (slot && *slot == old_ptr) {
+            *slot = new_ptr;
             ++n;
         }
     }
@@ -333,7 +347,7 @@ extern "C" int y6_plan_rebind_input(y6_plan* p, int index, const void* new_ptr) 
     Y6_REQUIRE(p && index >= 0 && new_ptr, "plan_rebind_input: bad argument");
     int k = 0;
     for (Op& op : p->ops) {
-        const void** slot = op.kind == Y6_OP_STEM ? &op.stem.in_nchw : op.kind == Y6_OP_NCHW2NHWC ? &op.src : nullptr;
+        const void** slot = boundary_input(op);
         if (!slot) continue;
         if (k++ != index) continue;
         if (*slot == new_ptr) return 0;

@@ -13,6 +13,8 @@ int y6_plan_push_generic(y6_plan* p, y6_generic_fn fn, const void* desc, size_t 
 // the op pushed last writes a caller-visible boundary tensor through the `void*` at byte `offset` of its descriptor
 // (y6_plan_rebind_output re-points it)
 int y6_plan_mark_output(y6_plan* p, size_t offset);
+// ... READS a caller boundary tensor (the NCHW image) through the `const void*` at `offset` (y6_plan_rebind_input / y6_plan_rebind)
+int y6_plan_mark_input(y6_plan* p, size_t offset);
 
 template <typename D>
 int y6_plan_push(y6_plan* p, int (*fn)(const D*, hipStream_t), const D* d, int tag, double flops, double bytes) {

@@ -199,6 +199,13 @@ class PlanBuilder:
         self.buf_ids = {}        # data_ptr of an activation buffer -> allocation index (stable between two lowerings)
         self.fp16_reads = []     # views read outside the plan (lazy feature maps): their fp16 form must exist
         self.twins = {}          # buffer index -> (int8 tensor [B,H,W,cstride], amax): int8 twins written by producers
+        # producer -> 3x3 stride-2 fusion (csrc/conv_fused.hip): a 1x1 conv / the image conv that allocated its own output is
+        # held back for one call; if the very next op is a 3x3 stride-2 conv reading exactly that tensor, the pair becomes ONE
+        # op and the intermediate tensor is never written (reads of it by any later op raise).  A/B switch: Y6_NO_FUSE_S2.
+        self._pending = None
+        self._elided = set()     # data_ptr of buffers whose producer was fused away
+        import os
+        self._fuse_s2 = not os.environ.get("Y6_NO_FUSE_S2")
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -217,7 +224,11 @@ class PlanBuilder:
 
     def keep_fp16(self, refs):
         """Declare views that are read outside the plan (Model's lazily converted feature maps)."""
-        self.fp16_reads += list(refs)
+        refs = list(refs)
+        if self._pending is not None and any(isinstance(r, TRef) and r.buf.data_ptr() == self._pending["out"].buf.data_ptr() for r in refs):
+            self._flush()
+        self._live(*refs)
+        self.fp16_reads += refs
 
     def _twin(self, ref: "TRef", amax: float) -> "TRef":
         """The int8 twin view of `ref` (allocated with the fp16 buffer's geometry on first use)."""
@@ -244,6 +255,34 @@ class PlanBuilder:
     def _ptr(t: Optional[torch.Tensor]):
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
+    # ---------------------------------------------------------------- held-back producers
+    def _flush(self):
+        """Add a held-back producer op as the plain op it is."""
+        pend, self._pending = self._pending, None
+        if pend is None:
+            return
+        if pend["kind"] == "pw":
+            _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(pend["desc"])), "plan_add_conv")
+        else:
+            _lib.check(self.lib.y6_plan_add_stem(self.h, C.byref(pend["desc"])), "plan_add_stem")
+        self.op_log.append(pend["entry"])
+
+    def _live(self, *refs):
+        for r in refs:
+            if isinstance(r, TRef) and r.buf.data_ptr() in self._elided:
+                raise RuntimeError("yolov6_amd: an op reads a tensor whose producer was fused into its consumer "
+                                   "(set Y6_NO_FUSE_S2=1 and report the graph)")
+
+    def _fuse_with_pending(self, x, K, stride, post, res):
+        """The held-back producer, if THIS conv (3x3 stride 2, plain epilogue) reads exactly its output; else None."""
+        pend = self._pending
+        if pend is None or not isinstance(x, TRef) or K != 3 or stride != 2 or post is not None or res is not None:
+            return None
+        o = pend["out"]
+        if x.buf.data_ptr() != o.buf.data_ptr() or x.coff != 0 or x.C != o.C or x.cstride != o.cstride:
+            return None
+        return pend
+
     # ---------------------------------------------------------------- inputs / outputs
     def as_nhwc(self, x) -> TRef:
         """NCHWInput -> TRef through the layout adapter kernel (TRef passes through)."""
@@ -254,6 +293,7 @@ class PlanBuilder:
         if not t.is_contiguous():
             raise RuntimeError("yolov6_amd: input must be a contiguous NCHW tensor")
         B, C_, H, W = t.shape
+        self._flush()
         out = self.new_buffer(B, H, W, C_)
         self.inputs.append(t)
         ct = out.ct()
@@ -263,6 +303,8 @@ class PlanBuilder:
         return out
 
     def to_nchw(self, x: TRef, dtype=torch.float16) -> torch.Tensor:
+        self._flush()
+        self._live(x)
         out = torch.empty((x.B, x.C, x.H, x.W), dtype=dtype, device=self.device)
         self.keep.append(out)
         ct = x.ct()
@@ -291,6 +333,10 @@ class PlanBuilder:
         Cout, Cin, K, K2 = weight.shape
         assert K == K2
         reads_image = isinstance(x, NCHWInput)      # the network's first conv stays fp16 (its input is 8-bit pixels already)
+        fuse_src = None if reads_image else self._fuse_with_pending(x, K, stride, post, res)
+        if fuse_src is None:
+            self._flush()
+        self._live(x, res)
         if reads_image:
             if K == 3 and stride == 2 and x.shape[1] <= 4 and Cout in (8, 16, 32, 48, 64) and res is None:
                 return self._stem(x, weight, bias, act, out, post)
@@ -300,10 +346,13 @@ class PlanBuilder:
         pad = K // 2
         Ho = (x.H + 2 * pad - K) // stride + 1
         Wo = (x.W + 2 * pad - K) // stride + 1
+        fresh_out = out is None                      # this call allocates the output: nobody else holds a view of it yet
         if out is None:
             out = self.new_buffer(x.B, Ho, Wo, Cout)
         assert (out.B, out.H, out.W, out.C) == (x.B, Ho, Wo, Cout), "conv output slice has the wrong shape"
         if self.quant is not None and not self._no_quant and not reads_image:
+            self._flush()
+            fuse_src = None
             idx = self.quant.next_index(dict(cin=Cin, cout=Cout, k=K, stride=stride))
             if self.quant.mode == "calibrate":
                 xt = x.ct()
@@ -330,16 +379,48 @@ class PlanBuilder:
         d.res = res.ct() if res is not None else _null_tensor()
         d.res_alpha = self._ptr(ra)
         d.ksize, d.stride, d.act, d.variant = K, stride, ACT_BY_NAME[act], self.force_variant
-        _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
         self.conv_log.append((Cin, Cout, K, stride, x.H, x.W))
-        self.op_log.append(dict(kind="conv", x=x, out=out, w=w32, b=bias, stride=stride, act=act, post=post, res=res,
-                                alpha=res_alpha))
+        entry = dict(kind="conv", x=x, out=out, w=w32, b=bias, stride=stride, act=act, post=post, res=res, alpha=res_alpha)
+        if fuse_src is not None and self._add_fused_pair(fuse_src, d, entry):
+            return out
+        self._flush()                                # (a held-back producer whose consumer the fused kernel did not take)
+        # a 1x1 conv into a tensor of its own may turn out to be the producer of a 3x3 stride-2 conv: hold it back one call
+        if (self._fuse_s2 and K == 1 and stride == 1 and fresh_out and post is None and res is None and self.quant is None
+                and self.force_variant < 0 and Cin == Cout and Cout in (64, 128)):
+            self._pending = dict(kind="pw", desc=d, entry=entry, out=out)
+            return out
+        _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
+        self.op_log.append(entry)
         return out
+
+    def _add_fused_pair(self, pend, d_s2, entry_s2) -> bool:
+        """Add `held-back producer -> this 3x3 stride-2 conv` as one fused op, if the kernel takes the pair."""
+        if pend["kind"] == "pw":
+            fd = _lib.PwS2Desc()
+            fd.pw, fd.s2 = pend["desc"], d_s2
+            if not self.lib.y6_fused_pw_s2_supported(C.byref(fd)):
+                return False
+            _lib.check(self.lib.y6_plan_add_pw_s2(self.h, C.byref(fd)), "plan_add_pw_s2")
+            kind = "pw_s2"
+        else:
+            fd = _lib.StemS2Desc()
+            fd.stem, fd.s2 = pend["desc"], d_s2
+            if not self.lib.y6_fused_stem_s2_supported(C.byref(fd)):
+                return False
+            _lib.check(self.lib.y6_plan_add_stem_s2(self.h, C.byref(fd)), "plan_add_stem_s2")
+            kind = "stem_s2"
+        self._pending = None
+        self._elided.add(pend["out"].buf.data_ptr())
+        pe = pend["entry"]
+        self.op_log.append(dict(kind=kind, x=pe["x"], mid=pend["out"], out=entry_s2["out"], producer=pe, s2=entry_s2))
+        return True
 
     def _conv_i8(self, x: TRef, weight, bias, stride, act, out: TRef, post, res, res_alpha, amax: float) -> TRef:
         """int8 conv (include/yolov6_hip.h y6_conv_i8_desc): weights quantised here per output channel, the fp16
         input quantised by the kernel with the calibrated `amax`."""
         from .quant import quantize_weight, dequant_vector
+        self._flush()
+        self._live(x, res)
         Cout, Cin, K, _ = weight.shape
         wq, s_w = quantize_weight(weight)                       # CPU: int8 OIHW, fp32 [Cout]
         wq_d = wq.to(self.device).contiguous()
@@ -395,6 +476,7 @@ class PlanBuilder:
         B, Cin, H, W = t.shape
         Cout = weight.shape[0]
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        fresh_out = out is None
         if out is None:
             out = self.new_buffer(B, Ho, Wo, Cout)
         # fp16-rounded weights, as model.half() would hold them
@@ -410,13 +492,19 @@ class PlanBuilder:
         d.post_scale = self._ptr(self._f32(post[0])) if post is not None else None
         d.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
         d.act = ACT_BY_NAME[act]
+        entry = dict(kind="stem", x=t, out=out, w=w32, b=bias, stride=2, act=act, post=post, res=None, alpha=None)
+        if self._fuse_s2 and fresh_out and post is None and self.quant is None and self.force_variant < 0 and Cin == 3 and Cout == 32:
+            self._pending = dict(kind="stem", desc=d, entry=entry, out=out)      # (conv() flushed before calling us)
+            return out
         _lib.check(self.lib.y6_plan_add_stem(self.h, C.byref(d)), "plan_add_stem")
-        self.op_log.append(dict(kind="stem", x=t, out=out, w=w32, b=bias, stride=2, act=act, post=post, res=None, alpha=None))
+        self.op_log.append(entry)
         return out
 
     def convt2x2(self, x, weight, bias, out: Optional[TRef] = None) -> TRef:
         """ConvTranspose2d(k=2, s=2): weight IOHW [Cin, Cout, 2, 2]."""
+        self._flush()
         x = self.as_nhwc(x)
+        self._live(x)
         Cin, Cout = weight.shape[0], weight.shape[1]
         assert tuple(weight.shape[2:]) == (2, 2) and x.C == Cin
         if out is None:
@@ -436,12 +524,16 @@ class PlanBuilder:
         return out
 
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
+        self._flush()
+        self._live(x)
         cts = [t.ct() for t in (x, y1, y2, y3)]
         _lib.check(self.lib.y6_plan_add_sppf(self.h, *[C.byref(c) for c in cts]), "plan_add_sppf")
         self.op_log.append(dict(kind="sppf", x=x, outs=[y1, y2, y3]))
 
     def head_decode(self, cls: List[TRef], reg: List[TRef], strides, use_dfl, reg_max, proj, nc,
                     grid_cell_offset=0.5) -> torch.Tensor:
+        self._flush()
+        self._live(*cls, *reg)
         B = cls[0].B
         A = sum(c.H * c.W for c in cls)
         out = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=self.device)
@@ -462,8 +554,64 @@ class PlanBuilder:
                                 reg_max=int(reg_max), proj=proj, nc=nc))
         return out
 
+    def _packed_1x1(self, weight):
+        """Packed MFMA image of a [Cout, Cin, 1, 1] weight (fp16-rounded, as model.half() holds it)."""
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        w16 = weight.detach().to(self.device, torch.float32).half().contiguous()
+        packed = torch.empty(self.lib.y6_packed_weight_elems(Cout, Cin, 1), dtype=torch.float16, device=self.device)
+        _lib.check(self.lib.y6_pack_conv_weight(self._ptr(w16), Y6_F16, Cout, Cin, 1, self._ptr(packed), _lib.current_stream_ptr()),
+                   "pack_conv_weight")
+        self.keep += [w16, packed]
+        return packed
+
+    def _pred_decode_desc(self, cls_feat, reg_feat, cls_preds, reg_preds, strides, use_dfl, reg_max, proj, nc, grid_cell_offset, out):
+        d = _lib.PredDecodeDesc()
+        d.n_levels = len(cls_feat)
+        for i, (c, r, (wc, bc), (wr, br)) in enumerate(zip(cls_feat, reg_feat, cls_preds, reg_preds)):
+            d.cls_feat[i], d.reg_feat[i] = c.ct(), r.ct()
+            d.w_cls[i], d.w_reg[i] = self._packed_1x1(wc).data_ptr(), self._packed_1x1(wr).data_ptr()
+            zc = bc if bc is not None else torch.zeros(wc.shape[0])
+            zr = br if br is not None else torch.zeros(wr.shape[0])
+            d.b_cls[i], d.b_reg[i] = self._f32(zc).data_ptr(), self._f32(zr).data_ptr()
+            d.stride[i] = float(strides[i])
+        d.use_dfl, d.reg_max = int(bool(use_dfl)), int(reg_max)
+        d.proj = self._ptr(self._f32(proj, fp16_round=False)) if use_dfl else None
+        d.grid_cell_offset = grid_cell_offset
+        d.out = C.c_void_p(out.data_ptr()) if out is not None else None
+        d.nc = nc
+        return d
+
+    def head_pred_decode(self, cls_feat: List[TRef], reg_feat: List[TRef], cls_preds, reg_preds, strides, use_dfl, reg_max, proj,
+                         nc, grid_cell_offset=0.5) -> Optional[torch.Tensor]:
+        """The head's tail in ONE launch (include/yolov6_hip.h y6_pred_decode_desc): cls_pred / reg_pred 1x1 convs of every
+        level + the decode.  cls_preds / reg_preds: per level (weight [Cout,Cin,1,1], bias).  Returns None when the fused
+        kernel does not take the shape (the caller then lowers convs + head_decode)."""
+        self._flush()
+        self._live(*cls_feat, *reg_feat)
+        nreg = 4 * ((int(reg_max) + 1) if use_dfl else 1)
+        ok = all(w.shape[0] == nc and tuple(w.shape[2:]) == (1, 1) and w.shape[1] == c.C for (w, _), c in zip(cls_preds, cls_feat)) and \
+            all(w.shape[0] == nreg and tuple(w.shape[2:]) == (1, 1) and w.shape[1] == r.C for (w, _), r in zip(reg_preds, reg_feat)) and \
+            all(c.C % 16 == 0 and c.C == r.C and c.cstride % 8 == 0 and c.coff % 8 == 0 and r.cstride % 8 == 0 and r.coff % 8 == 0
+                for c, r in zip(cls_feat, reg_feat)) and len(cls_feat) <= _lib.MAX_LEVELS and (nc + 5 + nreg) * 64 * 4 <= 64 * 1024
+        if not ok:
+            return None
+        B = cls_feat[0].B
+        A = sum(c.H * c.W for c in cls_feat)
+        out = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=self.device)
+        d = self._pred_decode_desc(cls_feat, reg_feat, cls_preds, reg_preds, strides, use_dfl, reg_max, proj, nc, grid_cell_offset, out)
+        if not self.lib.y6_head_pred_decode_supported(C.byref(d)):
+            return None
+        self.keep.append(out)
+        _lib.check(self.lib.y6_plan_add_pred_decode(self.h, C.byref(d)), "plan_add_pred_decode")
+        self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat), reg_feat=list(reg_feat),
+                                cls_preds=[(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in cls_preds],
+                                reg_preds=[(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in reg_preds],
+                                out=out, strides=list(strides), use_dfl=bool(use_dfl), reg_max=int(reg_max), proj=proj, nc=nc))
+        return out
+
     # ---------------------------------------------------------------- finish
     def finalize(self, outputs, autotune=True, iters=3) -> Plan:
+        self._flush()
         plan = Plan(self.h, self.keep, outputs, self.inputs)
         plan.op_log = self.op_log
         self.h = None

@@ -97,22 +97,37 @@ class Detect(HipModule):
                                       "(whole-model training graph)")
         if self.export:
             raise NotImplementedError("yolov6_amd: export mode (ONNX tracing) is out of scope of the HIP path")
-        cls_out, reg_out = [], []
-        with pb.no_quant():        # the head stays fp16 under an int8 lowering (yolov6_amd/quant.py)
-            for i in range(self.nl):
-                f = self.stems[i].lower(pb, x[i])
-                c, r = self._lower_cls_reg_convs(pb, i, f)
-                cp = self.cls_preds[i]
-                cls_out.append(pb.conv(c, cp.weight, cp.bias, stride=1, act=None))
-                rp = self.reg_preds[i]
-                reg_out.append(pb.conv(r, rp.weight, rp.bias, stride=1, act=None))
         use_dfl = self._eval_use_dfl()
         # the reference's eval branch projects with proj_conv.weight (effidehead.py:107-109), not with self.proj;
         # the bin count comes from the loaded weight, not from the constructor default
         proj = self.proj_conv.weight.detach().reshape(-1) if use_dfl else None
         reg_max = proj.numel() - 1 if use_dfl else self.reg_max
-        return pb.head_decode(cls_out, reg_out, [float(s) for s in self.stride.tolist()], use_dfl, reg_max,
-                              proj, self.nc, self.grid_cell_offset)
+        strides = [float(s) for s in self.stride.tolist()]
+        cfeat, rfeat = [], []
+        with pb.no_quant():        # the head stays fp16 under an int8 lowering (yolov6_amd/quant.py)
+            for i in range(self.nl):
+                f = self.stems[i].lower(pb, x[i])
+                c, r = self._lower_cls_reg_convs(pb, i, f)
+                cfeat.append(pb.as_nhwc(c))
+                rfeat.append(pb.as_nhwc(r))
+            # cls_pred / reg_pred of every level + the decode as ONE launch (csrc/head_decode.hip head_pred_decode_kernel):
+            # 7 launches and the [B,A,nc+4] fp16 logits' round trip through HBM less (A/B switch: Y6_HEAD_NO_FUSE)
+            fuse = getattr(pb, "head_pred_decode", None)
+            if fuse is not None and not os.environ.get("Y6_HEAD_NO_FUSE"):
+                det = fuse(cfeat, rfeat, [(m.weight, m.bias) for m in self._eval_cls_preds()],
+                           [(m.weight, m.bias) for m in self._eval_reg_preds()], strides, use_dfl, reg_max, proj, self.nc,
+                           self.grid_cell_offset)
+                if det is not None:
+                    return det
+            cls_out = [pb.conv(c, cp.weight, cp.bias, stride=1, act=None) for c, cp in zip(cfeat, self._eval_cls_preds())]
+            reg_out = [pb.conv(r, rp.weight, rp.bias, stride=1, act=None) for r, rp in zip(rfeat, self._eval_reg_preds())]
+        return pb.head_decode(cls_out, reg_out, strides, use_dfl, reg_max, proj, self.nc, self.grid_cell_offset)
+
+    def _eval_cls_preds(self):
+        return list(self.cls_preds)
+
+    def _eval_reg_preds(self):
+        return list(self.reg_preds)
 
 
 def build_effidehead_layer(channels_list, num_anchors, num_classes, reg_max=16, num_layers=3):

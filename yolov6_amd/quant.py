@@ -77,6 +77,12 @@ def _views(e):
         rd, wr = [e["x"]], list(e["outs"])
     elif k == "decode":
         rd = list(e["cls"]) + list(e["reg"])
+    elif k == "pred_decode":
+        rd = list(e["cls_feat"]) + list(e["reg_feat"])
+    elif k == "pw_s2":
+        rd, wr = [e["x"]], [e["out"]]
+    elif k == "stem_s2":
+        wr = [e["out"]]
     elif k in ("nhwc2nchw", "absmax"):
         rd = [e["x"]]
     elif k in ("stem", "nchw2nhwc"):
