@@ -173,7 +173,7 @@ int y6_stem_conv(const y6_stem_desc* d, void* stream);
  *   y6_fused_stem_s2 : s2(stem(image)), stem as y6_stem_conv.
  *     Replaces: EfficientRep.forward `self.ERBlock_2[0](self.stem(x))`  yolov6/models/efficientrep.py:96-99 (RepVGG deploy forms)
  * Rounding points are the unfused graph's (producer output rounded to fp16 before the stride-2 conv reads it).
- * Shapes taken: pw 64->64 / 128->128 into s2 of the same width; stem 3->32 into s2 32->{32,64}; no post affine, no residual.
+ * Shapes taken: pw 64->64 / 128->128 into s2 of the same width; stem 3->32 into s2 32->64; no post affine, no residual.
  * y6_fused_*_supported() says whether a pair is taken - callers fall back to the two separate ops.                    */
 typedef struct y6_pw_s2_desc {
     y6_conv_desc pw;           /* ksize 1, stride 1 */
@@ -187,6 +187,27 @@ int y6_fused_pw_s2_supported(const y6_pw_s2_desc* d);
 int y6_fused_pw_s2(const y6_pw_s2_desc* d, void* stream);
 int y6_fused_stem_s2_supported(const y6_stem_s2_desc* d);
 int y6_fused_stem_s2(const y6_stem_s2_desc* d, void* stream);
+
+/* Letterbox on the device: uint8 HWC image (cv2.imread layout, 3 channels, dense rows) -> uint8 image resized with cv2's
+ * INTER_LINEAR fixed-point arithmetic (or copied, when the size already fits) into the (new_h x new_w) window at (top, left)
+ * of an (out_h x out_w) tile filled with `pad`.  planar = 0: the tile is HWC like the source (what letterbox() returns);
+ * planar = 1: three [out_h][out_w] planes (CHW), reverse_channels = 1 additionally stores source channel c in plane 2 - c
+ * (BGR -> RGB) - the uint8 NCHW image y6_stem_conv / y6_fused_stem_s2 read (in_dtype Y6_U8, `/ 255` folded into their load).
+ * Replaces: letterbox()  yolov6/data/data_augment.py:29-58 ; Inferer.process_image (layout half)  yolov6/core/inferer.py:162-172.
+ * The host computes new_h / new_w / top / left as data_augment.py:38-56 does.  PARITY UNPINNED: the arithmetic is opencv's
+ * (requirements.txt:7, not vendored, not installed here), restated in oracle/letterbox_oracle.py.                      */
+typedef struct y6_letterbox_desc {
+    const void* src;
+    int32_t H, W;
+    void* dst;
+    int32_t out_h, out_w;
+    int32_t new_h, new_w;
+    int32_t top, left;
+    int32_t planar;
+    int32_t reverse_channels;
+    int32_t pad[3];
+} y6_letterbox_desc;
+int y6_letterbox(const y6_letterbox_desc* d, void* stream);
 
 /* Three chained MaxPool2d(5, stride 1, pad 2) (-inf padding) of `x`, written to y1,y2,y3.
  * Replaces: SPPFModule.forward  common.py:106-112 ; CSPSPPFModule.forward  :150-158

@@ -454,3 +454,69 @@ def test_int8_oracle_exact_int_conv_equals_float64_conv():
             want = F.conv2d(x.double(), w.double(), None, stride=s, padding=k // 2)
             got = exact_int_conv(x, w, s)
             assert got.dtype == torch.float64 and torch.equal(got, want), (cin, cout, k, s, worst)
+
+
+# ---------------------------------------------------------------- letterbox (row f3): host logic pinned to the reference's own function
+def _reference_letterbox_with_stub_cv2():
+    """The reference's letterbox() source (yolov6/data/data_augment.py) executed with a stand-in `cv2` module: opencv is not
+    installed here, so the two cv2 calls are served by the oracle's restatement - everything AROUND them (scale ratio, rounding
+    of the new size, `auto` stride modulus, the top / bottom / left / right split) is the reference's own code."""
+    import ast
+    import types
+    import numpy as np
+    from oracle import letterbox_oracle as LO
+    path = os.path.join(os.environ.get("Y6_REFERENCE_ROOT", "/root/reference"), "yolov6", "data", "data_augment.py")
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    src = open(path).read()
+    tree = ast.parse(src)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "letterbox")
+    cv2 = types.SimpleNamespace(INTER_LINEAR=1, BORDER_CONSTANT=0)
+    cv2.resize = lambda im, dsize, interpolation=None: LO.resize_linear_u8(im, dsize[0], dsize[1])
+
+    def copy_make_border(im, top, bottom, left, right, kind, value=None):
+        out = np.empty((im.shape[0] + top + bottom, im.shape[1] + left + right, 3), np.uint8)
+        out[...] = np.asarray(value, np.uint8)
+        out[top:top + im.shape[0], left:left + im.shape[1]] = im
+        return out
+    cv2.copyMakeBorder = copy_make_border
+    ns = {"np": np, "cv2": cv2}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns["letterbox"]
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (1080, 1920), (375, 500), (640, 640), (1280, 1280), (333, 1000), (97, 61)])
+@pytest.mark.parametrize("new_shape,auto,scaleup", [((640, 640), True, True), (640, False, True), ((1280, 1280), True, False), ([416], True, True)])
+def test_letterbox_oracle_host_logic_equals_reference(shape, new_shape, auto, scaleup):
+    import numpy as np
+    from oracle import letterbox_oracle as LO
+    ref_letterbox = _reference_letterbox_with_stub_cv2()
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, shape + (3,), dtype=np.uint8)
+    exp, r_exp, off_exp = ref_letterbox(im.copy(), new_shape, (114, 114, 114), auto, scaleup, 32)
+    got, r, off = LO.letterbox(im, new_shape, (114, 114, 114), auto, scaleup, 32)
+    assert r == r_exp and tuple(off) == tuple(off_exp)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_resize_linear_restatement_known_answers():
+    """cv2.resize(INTER_LINEAR) facts that need no cv2 to state: half-pixel centres with clamped borders ([0, 100] -> 4 wide is
+    [0, 25, 75, 100]), the identity, constant images stay constant at any scale, an exact 2 x 2 down-scale is the rounded mean
+    of each 2 x 2 block (resize.cpp routes it to INTER_AREA's fast path)."""
+    import numpy as np
+    from oracle import letterbox_oracle as LO
+    row = np.array([[[0, 0, 0], [100, 100, 100]]], np.uint8)
+    assert LO.resize_linear_u8(row, 4, 1)[0, :, 0].tolist() == [0, 25, 75, 100]
+    rng = np.random.default_rng(6)
+    im = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(LO.resize_linear_u8(im, 53, 37), im)
+    const = np.full((20, 31, 3), 177, np.uint8)
+    for w, h in ((64, 48), (9, 7), (31, 40)):
+        assert (LO.resize_linear_u8(const, w, h) == 177).all()
+    im2 = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    s = im2.astype(np.int32)
+    assert np.array_equal(LO.resize_linear_u8(im2, 30, 20), ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    # monotone ramps stay monotone and inside the source range
+    ramp = np.tile(np.arange(0, 250, 5, dtype=np.uint8)[None, :, None], (4, 1, 3))
+    out = LO.resize_linear_u8(ramp, 123, 4)[0, :, 0].astype(int)
+    assert (np.diff(out) >= 0).all() and out.min() >= 0 and out.max() <= 245

@@ -50,6 +50,12 @@ class DecodeDesc(C.Structure):
                 ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32)]
 
 
+class LetterboxDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32), ("dst", C.c_void_p), ("out_h", C.c_int32),
+                ("out_w", C.c_int32), ("new_h", C.c_int32), ("new_w", C.c_int32), ("top", C.c_int32), ("left", C.c_int32),
+                ("planar", C.c_int32), ("reverse_channels", C.c_int32), ("pad", C.c_int32 * 3)]
+
+
 class PwS2Desc(C.Structure):
     _fields_ = [("pw", ConvDesc), ("s2", ConvDesc)]
 
@@ -199,6 +205,7 @@ SIGNATURES = {
     "y6_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tensor), C.c_void_p]),
     "y6_nhwc_to_nchw": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_int, C.c_void_p]),
     "y6_head_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
+    "y6_letterbox": (C.c_int, [C.POINTER(LetterboxDesc), C.c_void_p]),
     "y6_fused_pw_s2_supported": (C.c_int, [C.POINTER(PwS2Desc)]),
     "y6_fused_pw_s2": (C.c_int, [C.POINTER(PwS2Desc), C.c_void_p]),
     "y6_fused_stem_s2_supported": (C.c_int, [C.POINTER(StemS2Desc)]),

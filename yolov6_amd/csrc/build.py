@@ -28,6 +28,7 @@ SOURCES = {
     "conv_dma.hip": [],
     "conv_misc.hip": [],
     "conv_fused.hip": [],
+    "preproc.hip": ["-ffp-contract=off"],
     "head_decode.hip": [],
     "nms.hip": ["-ffp-contract=off"],
     "tal.hip": ["-ffp-contract=off"],

@@ -34,6 +34,7 @@ struct ConvKArgs {
     int vec_ok;    // 8-byte stores legal (cstride/coff % 4 == 0)
     int vec16_ok;  // 16-byte stores legal (cstride/coff % 8 == 0, base 16-byte aligned)
     int epi_lds;   // stage the output tile through LDS and store whole NHWC rows (needs vec16_ok, Cout % 8 == 0)
+    int res_vec;   // residual readable as 8-byte pieces (res cstride/coff % 4 == 0, base 8-byte aligned)
     int nids;  // padded (tile, cout-block) id space of the 1-D grid
     unsigned long long* dbg;  // optional s_memtime trace of block 0 / wave 0 (env Y6_CONV_TRACE), 2 x 256 words
     int up, updy, updx, upH, upW, upC;  // up: 0 none, 1 one (dy,dx) sub-conv, 2 all four fused (cout block -> sub)
@@ -108,6 +109,24 @@ __device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc
         for (int r = 0; r < 16; ++r) v[r] = act_const<ACT>(acc[r] + bias[r]);
         return;
     }
+    // the residual of this lane's 16 channels (four groups of 4 consecutive couts): 8-byte loads where the view allows - the
+    // accumulating data-gradient convs of the training step (res == out) spent their epilogue on 16 two-byte loads per lane
+    float rv[16];
+    if (rrow) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = cfrag + 8 * g + 4 * kh;
+            if (a.res_vec && c0 >= 0 && c0 + 3 < cend) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(rrow + c0);
+                const __half* h = reinterpret_cast<const __half*>(&raw);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[g * 4 + j] = __half2float(h[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[g * 4 + j] = (c0 + j >= 0 && c0 + j < cend) ? __half2float(rrow[c0 + j]) : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int c = cfrag + 8 * (r >> 2) + 4 * kh + (r & 3);
@@ -115,7 +134,7 @@ __device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc
         if (c < cend) {
             if (a.pscale) x = y6_round_f16(x) * a.pscale[c] + a.pshift[c];      // QARepVGG: conv -> BN are two fp16 ops
             x = act_const<ACT>(x);
-            if (rrow) x = y6_round_f16(x) + y6_round_f16(ralpha * __half2float(rrow[c]));   // BottleRep: out + alpha*x
+            if (rrow) x = y6_round_f16(x) + y6_round_f16(ralpha * rv[r]);       // BottleRep: out + alpha*x
         } else {
             x = act_const<ACT>(x);
         }

@@ -94,29 +94,39 @@ __device__ __forceinline__ void slot_to_mid(const FusedArgs& a, int slot, int& m
     mx = ms < a.RPE ? 2 * ms : 2 * (ms - a.RPE) + 1;
 }
 
-// ---- the consumer: 3x3 stride-2 conv of the LDS-resident mid tile, one pixel fragment x CFW cout fragments per wave.
-// The (tap, k-step) sequence runs as a RUNTIME loop over groups of GK k-steps of one tap, weights double-buffered one group
-// ahead.  (Fully unrolled, hipcc hoists the 36-144 loop-invariant weight addresses out of the tile loop: 256 VGPRs + scratch.)
-template <int KSM, int CFW, int TW>
-__device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int frag, int cfg, int lane, int b, int oy0, int ox0) {
+// ---- the consumer: 3x3 stride-2 conv of the LDS-resident mid tile; a wave owns PFW pixel fragments x CFW cout fragments.
+// The (tap, k-step) sequence runs as a RUNTIME loop over groups of GK k-steps of one tap (fully unrolled, hipcc hoists the
+// 36-144 loop-invariant weight addresses out of the tile loop: 256 VGPRs + scratch).  Weight fragments come straight from the
+// packed image (L2) through a ring of three groups - two groups (an L2 round trip) ahead of the MFMAs - and every fragment
+// feeds PFW MFMAs (a 32-pixel fragment per wave would need 1 KiB of weights per MFMA: twice the vector memory path's rate).
+template <int KSM, int PFW, int CFW, int TW>
+__device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int frag0, int cf0, int lane, int b, int oy0, int ox0) {
     constexpr int GK = KSM < 4 ? KSM : 4;       // k-steps per group
     constexpr int GPT = KSM / GK;               // groups per tap
     constexpr int NG = 9 * GPT;
     constexpr int NCH = (KSM + 1) / 2;          // 32-channel chunks of the packed weight image
-    static_assert(KSM % GK == 0 && GK % 2 == 0, "k-steps come in pairs (32-channel chunks)");
+    static_assert(KSM % GK == 0 && GK % 2 == 0 && NG % 3 == 0, "k-steps come in pairs (32-channel chunks); the ring has three slots");
     const int q = fz_frag_pixel(lane & 31);
-    const int m = frag * 32 + q;
-    const int ty = m / TW, tx = m - ty * TW;
     const int kh = lane >> 5;
-    const char* base = mid + ((size_t)kh * a.PLS + (2 * ty) * a.RPS + tx) * 16;
+    int ty[PFW], tx[PFW], mm[PFW];
+    const char* base[PFW];
+#pragma unroll
+    for (int i = 0; i < PFW; ++i) {
+        mm[i] = (frag0 + i) * 32 + q;
+        ty[i] = mm[i] / TW;
+        tx[i] = mm[i] - ty[i] * TW;
+        base[i] = mid + ((size_t)kh * a.PLS + (2 * ty[i]) * a.RPS + tx[i]) * 16;
+    }
     const int plane2 = a.PLS * 32;              // bytes between k-steps (two planes)
-    const __half* wb = a.c.wpk + (size_t)(cfg * CFW) * NCH * 9 * 1024 + lane * 8;   // [cfr][chunk][tap][ks][lane][8]
-    f32x16_t acc[CFW][1];
+    const __half* wb = a.c.wpk + (size_t)cf0 * NCH * 9 * 1024 + lane * 8;   // [cfr][chunk][tap][ks][lane][8]
+    f32x16_t acc[CFW][PFW];
 #pragma unroll
     for (int cf = 0; cf < CFW; ++cf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cf][0][r] = 0.f;
-    h8_t w0[GK][CFW], w1[GK][CFW];
+        for (int i = 0; i < PFW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cf][i][r] = 0.f;
+    h8_t w0[GK][CFW], w1[GK][CFW], w2[GK][CFW];
     auto wload = [&](int g, h8_t (&w)[GK][CFW]) {
         const int t = g / GPT, kg = g - t * GPT;                       // tap, k-group (wave-uniform)
         const __half* p = wb + (size_t)(((kg * GK) >> 1) * 9 + t) * 1024;
@@ -129,42 +139,54 @@ __device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int
     auto compute = [&](int g, const h8_t (&w)[GK][CFW]) {
         const int t = g / GPT, kg = g - t * GPT;
         const int ky = (t * 11) >> 5, kx = t - ky * 3;                  // t / 3 for t < 9
-        const char* pb = base + (ky * a.RPS + (kx == 1 ? a.RPE : (kx >> 1))) * 16 + (size_t)(kg * GK) * plane2;
+        const int off = (ky * a.RPS + (kx == 1 ? a.RPE : (kx >> 1))) * 16 + (kg * GK) * plane2;
 #pragma unroll
         for (int j = 0; j < GK; ++j) {
-            const h8_t bf = *reinterpret_cast<const h8_t*>(pb + (size_t)j * plane2);
+            h8_t bf[PFW];
 #pragma unroll
-            for (int cf = 0; cf < CFW; ++cf) acc[cf][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j][cf], bf, acc[cf][0], 0, 0, 0);
+            for (int i = 0; i < PFW; ++i) bf[i] = *reinterpret_cast<const h8_t*>(base[i] + off + j * plane2);
+#pragma unroll
+            for (int cf = 0; cf < CFW; ++cf)
+#pragma unroll
+                for (int i = 0; i < PFW; ++i) acc[cf][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j][cf], bf[i], acc[cf][i], 0, 0, 0);
         }
     };
     wload(0, w0);
+    wload(1, w1);
 #pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-        if (g + 1 < NG) wload(g + 1, w1);
+    for (int g = 0; g < NG; g += 3) {
+        wload(g + 2, w2);
         compute(g, w0);
-        if (g + 2 < NG) wload(g + 2, w0);
-        if (g + 1 < NG) compute(g + 1, w1);
+        if (g + 3 < NG) wload(g + 3, w0);
+        compute(g + 1, w1);
+        if (g + 4 < NG) wload(g + 4, w1);
+        compute(g + 2, w2);
     }
-    const int oy = oy0 + ty, ox = ox0 + tx;
-    int opix[1];
-    opix[0] = (m < a.TH * TW && oy < a.c.Ho && ox < a.c.Wo) ? (b * a.c.Ho + oy) * a.c.Wo + ox : -1;
-    // bias of this lane's couts, loaded HERE (through a laundered pointer: loop-invariant loads would otherwise be hoisted out
-    // of the tile loop and hold 16 CFW registers across the producer phase)
-    const float* bp = a.c.bias;
-    asm volatile("" : "+s"(bp));
+    int opix[PFW];
+#pragma unroll
+    for (int i = 0; i < PFW; ++i) {
+        const int oy = oy0 + ty[i], ox = ox0 + tx[i];
+        opix[i] = (mm[i] < a.TH * TW && oy < a.c.Ho && ox < a.c.Wo) ? (b * a.c.Ho + oy) * a.c.Wo + ox : -1;
+    }
+    // bias of this lane's couts, loaded HERE (behind a laundered offset: loop-invariant loads would otherwise be hoisted out of
+    // the tile loop and hold 16 CFW registers across the producer phase)
+    unsigned zoff = 0;
+    asm volatile("" : "+s"(zoff));
+    const float* bp = a.c.bias ? a.c.bias + zoff : nullptr;
     BiasRegs<CFW> bz;
 #pragma unroll
     for (int cf = 0; cf < CFW; ++cf)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int c0 = (cfg * CFW + cf) * 32 + 8 * g + 4 * kh;        // Cout % 32 == 0 (host)
+            const int c0 = (cf0 + cf) * 32 + 8 * g + 4 * kh;             // Cout % 32 == 0 (host)
             const float4 t = bp ? *reinterpret_cast<const float4*>(bp + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
             bz.v[cf][g * 4 + 0] = t.x;
             bz.v[cf][g * 4 + 1] = t.y;
             bz.v[cf][g * 4 + 2] = t.z;
             bz.v[cf][g * 4 + 3] = t.w;
         }
-    conv_epilogue<CFW, 1>(a.c, acc, opix, cfg, 0, lane, bz);
+    static_assert(CFW == 1, "conv_epilogue's cout block index is the fragment index only for one fragment per wave");
+    conv_epilogue<CFW, PFW>(a.c, acc, opix, cf0, 0, lane, bz);
 }
 
 // ---- 1x1 producer + consumer.  KSI: input k-steps (Cin / 16); CM: cout fragments of the 1x1 (Cm / 32); the consumer has CM
@@ -181,10 +203,9 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
     const int cfm = wave % CM;
     constexpr int nchunk1 = (KSI + 1) / 2;
     const int nmf = a.PLS >> 5;
-    // consumer role: pixel fragment and cout-fragment group
-    const int npf = (a.TH * TW) >> 5;                  // pixel fragments of a tile (host: NW = npf * (CFT / CFW))
-    constexpr int CFW = 2 <= CFT ? 2 : 1;
-    const int cfrag_c = wave % npf, cfg_c = wave / npf;
+    // consumer role: two pixel fragments x one cout fragment (host: NW = (TH * TW / 64) * CFT)
+    const int npp = (a.TH * TW) >> 6;                  // pixel-fragment pairs of a tile
+    const int cfrag_c = 2 * (wave % npp), cf_c = wave / npp;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx_i = tile % a.tiles_x;
@@ -196,9 +217,10 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
         // ---- produce: mid = act(conv1x1(in) + b1) for the tile's (2 TH + 1) x (2 TW + 1) pixels, zeros outside the image
         // (this wave's 1x1 weight fragments and bias are re-read per tile - L2 hits - so that they do not occupy registers
         //  during the consumer phase; the laundered pointers keep hipcc from hoisting the loads out of the tile loop)
-        const __half* w1p = a.w1;
-        const float* b1p = a.b1;
-        asm volatile("" : "+s"(w1p), "+s"(b1p));
+        unsigned zoff = 0;
+        asm volatile("" : "+s"(zoff));
+        const __half* w1p = a.w1 + zoff;
+        const float* b1p = a.b1 ? a.b1 + zoff : nullptr;
         h8_t w1[KSI];
 #pragma unroll
         for (int ks = 0; ks < KSI; ++ks)
@@ -248,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
         }
         __syncthreads();
         // ---- consume
-        consume<2 * CM, CFW, TW>(a, mid, cfrag_c, cfg_c, lane, b, oy0, ox0);
+        consume<2 * CM, 2, 1, TW>(a, mid, cfrag_c, cf_c, lane, b, oy0, ox0);
         __syncthreads();   // the next tile's producer overwrites the planes
     }
 }
@@ -264,11 +286,14 @@ constexpr int FS_PLS = ((FS_MH * FS_MW + 31) / 32) * 32;       // 608 slots per 
 constexpr int FS_MID_BYTES = 4 * FS_PLS * 16;                  // 38 912
 constexpr int FS_WIN_BYTES = 3 * FS_WR * FS_PITCH * 2;         // 15 504
 
-template <typename TI, int CFT>
-__global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a) {
+constexpr int FS_WLDS_BYTES = 2 * 64 * 16 + 32 * 4;           // the image conv's two A fragments per lane + 32 biases
+
+template <typename TI>
+__global__ __launch_bounds__(256, 2) void fused_stem_s2_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* mid = smem;
     _Float16* s_in = reinterpret_cast<_Float16*>(smem + FS_MID_BYTES);
+    char* s_w = smem + FS_MID_BYTES + FS_WIN_BYTES;            // [ks][lane] x 16 B, then 32 floats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = lane >> 5;
@@ -276,7 +301,21 @@ __global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a
     constexpr int K = 27;
     const TI* img = reinterpret_cast<const TI*>(a.img);
     const size_t IHW = (size_t)a.IH * a.IW;
-    // image-conv weights: A fragments (cout = lane & 31, k = ks * 16 + kh * 8 + j, k = ci * 9 + ky * 3 + kx), bias
+    // image-conv weights as A fragments (cout = lane & 31, k = ks * 16 + kh * 8 + j, k = ci * 9 + ky * 3 + kx; k >= 27: zero) and
+    // the bias, ONCE per block into LDS: each tile reads them back with two + four ds_read_b128 (re-gathering 16 fp32 words per
+    // lane from global memory per tile cost six dependent round trips per tile - 207 us for the pair on the first visit)
+    if (tid < 128) {
+        const int l = tid & 63, ks = tid >> 6;
+        h8_t f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + (l >> 5) * 8 + j;
+            f[j] = k < K ? (_Float16)a.wst[(size_t)(l & 31) * K + k] : (_Float16)0.f;
+        }
+        *reinterpret_cast<h8_t*>(s_w + (ks * 64 + l) * 16) = f;
+    } else if (tid < 160) {
+        reinterpret_cast<float*>(s_w + 2 * 64 * 16)[tid - 128] = a.b1 ? a.b1[tid - 128] : 0.f;
+    }
     // this lane's 16 window offsets (halves): element k of the patch of mid pixel (my, mx) sits at
     // s_in[(ci * WR + 2 my + ky) * PITCH + 2 mx + 5 + kx]
     int woff[2][8];
@@ -303,19 +342,13 @@ __global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a
         pc_off[i] = (pc_ci[i] * FS_WR + pc_yy[i]) * FS_PITCH + pc_px[i] * 8;
     }
     constexpr int NMF = FS_PLS / 32;   // 19 mid fragments
-    constexpr int CFW = CFT >= 2 ? 2 : 1;
-    static_assert(CFT == CFW, "one cout-fragment group: Cout <= 64");
-
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    StemPiece<TI> pre[4];
+    auto request = [&](int tile) {     // image window of `tile` -> registers (aligned 16-byte pieces; IW % 8 == 0: a piece is wholly in or out)
         const int tx_i = tile % a.tiles_x;
         const int t2 = tile / a.tiles_x;
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
-        const int oy0 = ty_i * FS_TH, ox0 = tx_i * FS_TW;
-        const int my0 = 2 * oy0 - 1, mx0 = 2 * ox0 - 1;
-        const int iy0 = 2 * my0 - 1, cx0 = 4 * ox0 - 8;
-        // ---- image window -> LDS (aligned 16-byte pieces; IW % 8 == 0: a piece is wholly in or out)
-        StemPiece<TI> pre[4];
+        const int iy0 = 4 * ty_i * FS_TH - 3, cx0 = 4 * tx_i * FS_TW - 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int iy = iy0 + pc_yy[i], ix = cx0 + pc_px[i] * 8;
@@ -324,27 +357,29 @@ __global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a
             else
                 pre[i].zero();
         }
+    };
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) request(tile);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const int tx_i = tile % a.tiles_x;
+        const int t2 = tile / a.tiles_x;
+        const int ty_i = t2 % a.tiles_y;
+        const int b = t2 / a.tiles_y;
+        const int oy0 = ty_i * FS_TH, ox0 = tx_i * FS_TW;
+        const int my0 = 2 * oy0 - 1, mx0 = 2 * ox0 - 1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (pc_on[i]) *reinterpret_cast<uint4*>(s_in + pc_off[i]) = pre[i].as_half8();
         __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) request(tile + gridDim.x);   // in flight during the MFMAs and the stores below
         // ---- produce: mid = act(conv3x3s2(image) + b1), 32 channels = 4 planes
-        // (weights / bias re-read per tile through laundered pointers: see fused_pw_s2_kernel)
-        const float* wsp = a.wst;
-        const float* b1p = a.b1;
-        asm volatile("" : "+s"(wsp), "+s"(b1p));
         h8_t af[2];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = ks * 16 + kh * 8 + j;                      // k >= 27 (ks 1, kh 1, j >= 3): zero weight
-                af[ks][j] = k < K ? (_Float16)wsp[(size_t)(lane & 31) * K + (k < K ? k : 0)] : (_Float16)0.f;
-            }
+        af[0] = *reinterpret_cast<const h8_t*>(s_w + lane * 16);
+        af[1] = *reinterpret_cast<const h8_t*>(s_w + (64 + lane) * 16);
         float bz1[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 t = b1p ? *reinterpret_cast<const float4*>(b1p + 8 * g + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 t = *reinterpret_cast<const float4*>(s_w + 2 * 64 * 16 + (8 * g + 4 * kh) * 4);
             bz1[g * 4 + 0] = t.x;
             bz1[g * 4 + 1] = t.y;
             bz1[g * 4 + 2] = t.z;
@@ -370,10 +405,7 @@ __global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a
             for (int ks = 0; ks < 2; ++ks) {
                 h8_t bf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const _Float16 t = base[woff[ks][j]];
-                    bf[j] = (ks * 16 + kh * 8 + j) < K ? t : (_Float16)0.f;
-                }
+                for (int j = 0; j < 8; ++j) bf[j] = base[woff[ks][j]];      // (k >= 27 multiplies a zero weight)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf, acc, 0, 0, 0);
             }
             float v[16];
@@ -382,8 +414,8 @@ __global__ __launch_bounds__(256, 3) void fused_stem_s2_kernel(const FusedArgs a
             mid_store(mid, FS_PLS, 0, slot, lane, v);
         }
         __syncthreads();
-        // ---- consume: wave = output row of the tile
-        consume<2, CFW, FS_TW>(a, mid, wave, 0, lane, b, oy0, ox0);
+        // ---- consume: output rows 2 (wave & 1), 2 (wave & 1) + 1 of the tile x cout fragment (wave >> 1)
+        consume<2, 2, 1, FS_TW>(a, mid, 2 * (wave & 1), wave >> 1, lane, b, oy0, ox0);
         __syncthreads();
     }
 }
@@ -513,11 +545,11 @@ int stem_s2_ok(const y6_stem_s2_desc* d) {
     if (!esz || ((uintptr_t)st.in_nchw % (8 * esz)) != 0 || ((size_t)st.H * st.W * esz) % (8 * esz) != 0) return 0;
     const int Hm = (st.H + 2 - 3) / 2 + 1, Wm = (st.W + 2 - 3) / 2 + 1;
     if (!consumer_ok(&d->s2, st.B, Hm, Wm, 32)) return 0;
-    return d->s2.out.C == 64 || d->s2.out.C == 32;
+    return d->s2.out.C == 64;
 }
 
 int stem_s2_launch(const y6_stem_s2_desc* d, hipStream_t s) {
-    Y6_REQUIRE(stem_s2_ok(d), "fused_stem_s2: unsupported pair (3-channel image conv to 32 channels into a 3x3 stride-2 conv to 32 / 64)");
+    Y6_REQUIRE(stem_s2_ok(d), "fused_stem_s2: unsupported pair (3-channel image conv to 32 channels into a 3x3 stride-2 conv to 64)");
     FusedArgs a;
     memset(&a, 0, sizeof(a));
     const y6_stem_desc& st = d->stem;
@@ -538,21 +570,11 @@ int stem_s2_launch(const y6_stem_s2_desc* d, hipStream_t s) {
     a.RPE = FS_TW + 1;
     a.nslots = FS_MH * FS_MW;
     a.PLS = FS_PLS;
-    const size_t lds = FS_MID_BYTES + FS_WIN_BYTES;
-    static KernState kst[6];
-#define Y6_FS(TI, CFT, i) return launch_fused(fused_stem_s2_kernel<TI, CFT>, a, 256, lds, s, &kst[i])
-    const bool wide = d->s2.out.C == 64;
-    if (st.in_dtype == Y6_F16) {
-        if (wide) Y6_FS(__half, 2, 0);
-        Y6_FS(__half, 1, 1);
-    }
-    if (st.in_dtype == Y6_U8) {
-        if (wide) Y6_FS(uint8_t, 2, 2);
-        Y6_FS(uint8_t, 1, 3);
-    }
-    if (wide) Y6_FS(float, 2, 4);
-    Y6_FS(float, 1, 5);
-#undef Y6_FS
+    const size_t lds = FS_MID_BYTES + FS_WIN_BYTES + FS_WLDS_BYTES;
+    static KernState kst[3];
+    if (st.in_dtype == Y6_F16) return launch_fused(fused_stem_s2_kernel<__half>, a, 256, lds, s, &kst[0]);
+    if (st.in_dtype == Y6_U8) return launch_fused(fused_stem_s2_kernel<uint8_t>, a, 256, lds, s, &kst[1]);
+    return launch_fused(fused_stem_s2_kernel<float>, a, 256, lds, s, &kst[2]);
 }
 
 double pair_flops(double px_mid, double k1, int Cm, const y6_conv_desc& s2) {

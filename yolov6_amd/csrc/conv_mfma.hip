@@ -1226,6 +1226,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.act = d->act;
     k.vec_ok = (d->out.cstride % 4 == 0) && (d->out.coff % 4 == 0) && (((uintptr_t)d->out.data & 7) == 0);
     k.vec16_ok = (d->out.cstride % 8 == 0) && (d->out.coff % 8 == 0) && (((uintptr_t)d->out.data & 15) == 0);
+    k.res_vec = d->res.data != nullptr && (d->res.cstride % 4 == 0) && (d->res.coff % 4 == 0) && (((uintptr_t)d->res.data & 7) == 0);
     {
         static const bool no_epi_lds = getenv("Y6_CONV_NO_EPI_LDS") != nullptr;   // A/B switch for profiling
         const int cend = up == 2 ? d->out.C / 4 : d->out.C;

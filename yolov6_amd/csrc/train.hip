@@ -362,6 +362,15 @@ __global__ __launch_bounds__(256) void bnact_bwd_reduce_kernel(const BnActBwdArg
     }
 }
 
+__device__ __forceinline__ long bwd_dx_index(const BnActBwdArgs& a, int b, long p) {
+    if (a.xdil[b] != 2) return p;
+    // (b, y, x) of the logical grid -> (b, 2y, 2x) of the dilated buffer
+    const int hw = a.H * a.W;
+    const int bi = (int)(p / hw), rem = (int)(p - (long)bi * hw);
+    const int y = rem / a.W, x = rem - y * a.W;
+    return ((long)bi * a.xH[b] + 2 * y) * a.xW[b] + 2 * x;
+}
+
 // pass 2: gradients wrt every branch input (and the shortcut), 4 channels per thread (8-byte accesses: the per-channel
 // constants of 4 channels x 3 branches stay in ~50 registers).  With dz the activation gradient,
 //   dx_b = k1_b*(dz - mean(dz) - xhat_b*mean(dz*xhat_b)) = k1_b*dz + A_b*x_b + B_b,
@@ -465,6 +474,204 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs
     }
 }
 
+// ---- v2 of both passes: 8 channels per thread (16-byte accesses), the loop-invariant per-channel constants of the apply pass
+// in LDS instead of registers.  The 4-channel kernels above keep 4 waves per SIMD with 4-7 loads of 8 bytes in flight per
+// thread: 30-55 KB per CU, 2.1 TB/s measured (profiles/r03/bench_train_r03c.json: bnact_bwd 14.0 of the 57 ms step, the
+// largest single item).  Here a thread has 5-8 loads of 16 bytes in flight (reduce: two pixels) at 4-5 waves per SIMD.
+// Taken when 256 % (C / 8) == 0 and every view is 16-byte aligned (every BatchNorm of the N / S / L graphs).
+__device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
+    const __half* h = reinterpret_cast<const __half*>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __half2float(h[j]);
+}
+__device__ __forceinline__ uint4 ld16(const __half* p) { return *reinterpret_cast<const uint4*>(p); }
+
+__global__ __launch_bounds__(256, 4) void bnact_bwd_reduce8_kernel(const BnActBwdArgs a, long pix_per_block) {
+    extern __shared__ double s_acc[];   // [(1+n)*C]
+    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const int tid = threadIdx.x;
+    const int nacc = (1 + n) * C;
+    for (int i = tid; i < nacc; i += 256) s_acc[i] = 0.0;
+    __syncthreads();
+    const int R = 256 / G;                       // 256 % G == 0 (host)
+    const int g = tid % G, prow = tid / G, c0 = g * 8;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < a.f.npix ? p0 + pix_per_block : a.f.npix;
+    // fp32 partial sums of this thread's <= ~100 pixels, folded into the block's double accumulators afterwards
+    float sdz[8], sxy[3][8], salpha = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sdz[j] = sxy[0][j] = sxy[1][j] = sxy[2][j] = 0.f;
+    // scale_b and the summed shift per channel: LDS (behind the double accumulators), read where they are used
+    float* s_k = reinterpret_cast<float*>(s_acc + nacc);      // [4][C]
+    for (int ch = tid; ch < C; ch += 256) {
+        float sh = 0.f;
+        for (int b = 0; b < 3; ++b) {
+            s_k[b * C + ch] = (b < n && a.f.scale[b]) ? a.f.scale[b][ch] : 1.f;
+            if (b < n && a.f.shift[b]) sh += a.f.shift[b][ch];
+        }
+        s_k[3 * C + ch] = sh;
+    }
+    __syncthreads();
+    auto cst = [&](int k, float (&v)[8]) {
+        const float4 lo = *reinterpret_cast<const float4*>(s_k + k * C + c0), hi = *reinterpret_cast<const float4*>(s_k + k * C + c0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    const bool want_alpha = a.dalpha != nullptr;
+    for (long p = p0 + prow; p < p1; p += R) {
+        uint4 xr[3], gr, rr;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            xr[b] = ld16(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + c0);
+        }
+        gr = ld16(a.dout + p * a.dcs + a.dco + c0);
+        if (want_alpha) rr = ld16(a.f.res + p * a.f.rcs + a.f.rco + c0);
+        float z[8], go[8], dz[8];
+        cst(3, z);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            float scv[8], xb[8];
+            cst(b, scv);
+            unpack8(xr[b], xb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] += xb[j] * scv[j];
+        }
+        unpack8(gr, go);
+        if (want_alpha) {
+            float r[8];
+            unpack8(rr, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) salpha += go[j] * r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dz[j] = go[j] * act_grad(z[j], a.f.act);
+            sdz[j] += dz[j];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            float xb[8];
+            unpack8(xr[b], xb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sxy[b][j] += dz[j] * xb[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        atomicAdd(&s_acc[c0 + j], (double)sdz[j]);
+        for (int b = 0; b < n; ++b)
+            if (a.mean[b]) atomicAdd(&s_acc[(1 + b) * C + c0 + j], (double)sxy[b][j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < nacc; i += 256) atomicAdd(&a.ws[i], s_acc[i]);
+    if (want_alpha) {
+        double sa = (double)salpha;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+        if ((tid & 63) == 0) atomicAdd(&a.ws[nacc], sa);
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void bnact_bwd_apply8_kernel(const BnActBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_c[];   // [13][C]: sc_b | k1_b | A_b | B_b (b = 0..2) | sum of shifts
+    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const int tid = threadIdx.x;
+    {   // the per-channel constants of load_bwd_consts4, once per block
+        const double invN = 1.0 / (double)a.f.npix;
+        for (int ch = tid; ch < C; ch += 256) {
+            float sh = 0.f;
+            for (int b = 0; b < 3; ++b) {
+                float scv = 1.f, k1 = 1.f, A = 0.f, Bc = 0.f;
+                if (b < n) {
+                    scv = a.f.scale[b] ? a.f.scale[b][ch] : 1.f;
+                    sh += a.f.shift[b] ? a.f.shift[b][ch] : 0.f;
+                    if (a.mean[b]) {
+                        const double s0 = a.ws[ch], sb = a.ws[(1 + b) * C + ch];
+                        const float mu = a.mean[b][ch], is = a.invstd[b][ch];
+                        k1 = (a.gamma[b] ? a.gamma[b][ch] : 1.f) * is;
+                        const float m2 = (float)((sb - (double)mu * s0) * (double)is * invN);
+                        A = -k1 * m2 * is;
+                        Bc = -k1 * (float)(s0 * invN) - A * mu;
+                    } else {
+                        k1 = scv;
+                    }
+                }
+                s_c[(0 + b) * C + ch] = scv;
+                s_c[(3 + b) * C + ch] = k1;
+                s_c[(6 + b) * C + ch] = A;
+                s_c[(9 + b) * C + ch] = Bc;
+            }
+            s_c[12 * C + ch] = sh;
+        }
+    }
+    __syncthreads();
+    const float alpha = a.f.res ? (a.f.alpha ? *a.f.alpha : 1.f) : 0.f;
+    const int g = tid % G, rpb = 256 / G, c0 = g * 8;
+    auto cst = [&](int k, float (&v)[8]) {
+        const float4 lo = *reinterpret_cast<const float4*>(s_c + k * C + c0), hi = *reinterpret_cast<const float4*>(s_c + k * C + c0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    for (long p = (long)blockIdx.x * rpb + tid / G; p < a.f.npix; p += (long)gridDim.x * rpb) {
+        // every load of this pixel group first
+        uint4 xr[3], oldr[3], gr, rold;
+        long qd[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            xr[b] = ld16(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + c0);
+            if (a.dx[b]) {
+                qd[b] = bwd_dx_index(a, b, p);
+                if (a.xacc[b]) oldr[b] = ld16(a.dx[b] + qd[b] * a.xcs[b] + a.xco[b] + c0);
+            }
+        }
+        gr = ld16(a.dout + p * a.dcs + a.dco + c0);
+        if (a.dres && a.racc) rold = ld16(a.dres + p * a.rcs + a.rco + c0);
+        float z[8], go[8], dz[8], xb[3][8];
+        cst(12, z);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            float scv[8];
+            cst(b, scv);
+            unpack8(xr[b], xb[b]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] += xb[b][j] * scv[j];
+        }
+        unpack8(gr, go);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] = go[j] * act_grad(z[j], a.f.act);
+        if (a.dres) {
+            float r[8];
+            if (a.racc) unpack8(rold, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (a.racc ? r[j] : 0.f) + alpha * go[j];
+            store8(a.dres + p * a.rcs + a.rco + c0, r);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            if (!a.dx[b]) continue;
+            float k1[8], A[8], Bc[8], d[8];
+            cst(3 + b, k1);
+            cst(6 + b, A);
+            cst(9 + b, Bc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] = k1[j] * dz[j] + A[j] * xb[b][j] + Bc[j];
+            if (a.xacc[b]) {
+                float old[8];
+                unpack8(oldr[b], old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] += old[j];
+            }
+            store8(a.dx[b] + qd[b] * a.xcs[b] + a.xco[b] + c0, d);
+        }
+    }
+}
+
 __global__ void bnact_bwd_params_kernel(const BnActBwdArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int C = a.f.C;
@@ -530,17 +737,31 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     a.ws = (double*)d->workspace;
     const size_t nacc = (size_t)(1 + n) * C + 1;
     Y6_HIP(hipMemsetAsync(a.ws, 0, nacc * sizeof(double), s));
-    const int G = C / 8, R = 256 / (C / 4);
+    const int G = C / 8;
+    // v2 (8 channels per thread, 16-byte accesses): every view 16-byte aligned, a thread keeps one channel group
+    static const bool no_v2 = getenv("Y6_BNACT_BWD_V1") != nullptr;      // A/B switch
+    bool v2 = !no_v2 && C % 8 == 0 && 256 % G == 0 && (size_t)13 * C * sizeof(float) <= 64 * 1024;
+    auto al16 = [](const void* ptr, int cs, int co) { return ptr == nullptr || ((((uintptr_t)ptr) & 15) == 0 && cs % 8 == 0 && co % 8 == 0); };
+    for (int b = 0; b < n; ++b) v2 = v2 && al16(a.f.x[b], a.f.cs[b], a.f.co[b]) && al16(a.dx[b], a.xcs[b], a.xco[b]);
+    v2 = v2 && al16(a.dout, a.dcs, a.dco) && al16(a.f.res, a.f.rcs, a.f.rco) && al16(a.dres, a.rcs, a.rco);
+    const int R = v2 ? 256 / G : 256 / (C / 4);
     long ppb = (long)R * 32;
     long blocks = (a.f.npix + ppb - 1) / ppb;
     if (blocks > 2048) {
         blocks = 2048;
         ppb = (a.f.npix + blocks - 1) / blocks;
     }
-    hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double), s, a, ppb);
-    Y6_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid_for((size_t)a.f.npix * G * 2, 256, 256 * 16)), dim3(256), 0, s, a);
-    Y6_LAUNCH_CHECK();
+    if (v2) {
+        hipLaunchKernelGGL(bnact_bwd_reduce8_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double) + (size_t)4 * C * sizeof(float), s, a, ppb);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bnact_bwd_apply8_kernel, dim3(grid_for((size_t)a.f.npix * G, 256, 256 * 16)), dim3(256), (size_t)13 * C * sizeof(float), s, a);
+        Y6_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bnact_bwd_reduce_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double), s, a, ppb);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bnact_bwd_apply_kernel, dim3(grid_for((size_t)a.f.npix * G * 2, 256, 256 * 16)), dim3(256), 0, s, a);
+        Y6_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(bnact_bwd_params_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();
     return Y6_OK;

@@ -199,10 +199,12 @@ class PlanBuilder:
         self.buf_ids = {}        # data_ptr of an activation buffer -> allocation index (stable between two lowerings)
         self.fp16_reads = []     # views read outside the plan (lazy feature maps): their fp16 form must exist
         self.twins = {}          # buffer index -> (int8 tensor [B,H,W,cstride], amax): int8 twins written by producers
-        # producer -> 3x3 stride-2 fusion (csrc/conv_fused.hip): a 1x1 conv / the image conv that allocated its own output is
-        # held back for one call; if the very next op is a 3x3 stride-2 conv reading exactly that tensor, the pair becomes ONE
-        # op and the intermediate tensor is never written (reads of it by any later op raise).  A/B switch: Y6_NO_FUSE_S2.
+        # producer -> 3x3 stride-2 fusion (csrc/conv_fused.hip): a 1x1 conv / the image conv whose output the lowering declared
+        # single-use (hint_single_use(): BiFusion's cv2, the backbone's stem) is held back for one call; if the very next op is
+        # a 3x3 stride-2 conv reading exactly that tensor, the pair becomes ONE op and the intermediate tensor is never written
+        # (a read of it by any later op raises).  A/B switch: Y6_NO_FUSE_S2.
         self._pending = None
+        self._single_use = False # set by hint_single_use(): the NEXT conv's output has exactly one consumer, the op after it
         self._elided = set()     # data_ptr of buffers whose producer was fused away
         import os
         self._fuse_s2 = not os.environ.get("Y6_NO_FUSE_S2")
@@ -256,6 +258,11 @@ class PlanBuilder:
         return C.c_void_p(t.data_ptr()) if t is not None else None
 
     # ---------------------------------------------------------------- held-back producers
+    def hint_single_use(self):
+        """The output of the NEXT conv() call is read by exactly one op: the one lowered right after it.  (Only the module
+        that lowers both ops knows; the builder cannot see future readers of a tensor.)"""
+        self._single_use = True
+
     def _flush(self):
         """Add a held-back producer op as the plain op it is."""
         pend, self._pending = self._pending, None
@@ -333,13 +340,14 @@ class PlanBuilder:
         Cout, Cin, K, K2 = weight.shape
         assert K == K2
         reads_image = isinstance(x, NCHWInput)      # the network's first conv stays fp16 (its input is 8-bit pixels already)
+        single_use, self._single_use = self._single_use, False
         fuse_src = None if reads_image else self._fuse_with_pending(x, K, stride, post, res)
         if fuse_src is None:
             self._flush()
         self._live(x, res)
         if reads_image:
             if K == 3 and stride == 2 and x.shape[1] <= 4 and Cout in (8, 16, 32, 48, 64) and res is None:
-                return self._stem(x, weight, bias, act, out, post)
+                return self._stem(x, weight, bias, act, out, post, single_use)
             x = self.as_nhwc(x)
         if x.C != Cin:
             raise RuntimeError(f"yolov6_amd: conv expects {Cin} input channels, got {x.C}")
@@ -385,7 +393,7 @@ class PlanBuilder:
             return out
         self._flush()                                # (a held-back producer whose consumer the fused kernel did not take)
         # a 1x1 conv into a tensor of its own may turn out to be the producer of a 3x3 stride-2 conv: hold it back one call
-        if (self._fuse_s2 and K == 1 and stride == 1 and fresh_out and post is None and res is None and self.quant is None
+        if (self._fuse_s2 and single_use and K == 1 and stride == 1 and fresh_out and post is None and res is None and self.quant is None
                 and self.force_variant < 0 and Cin == Cout and Cout in (64, 128)):
             self._pending = dict(kind="pw", desc=d, entry=entry, out=out)
             return out
@@ -468,7 +476,7 @@ class PlanBuilder:
                                 q_in=q_in, q_out=q_out, q_out_amax=q_out_amax, has_out=has_out))
         return out
 
-    def _stem(self, x: NCHWInput, weight, bias, act, out, post) -> TRef:
+    def _stem(self, x: NCHWInput, weight, bias, act, out, post, single_use=False) -> TRef:
         t = x.t
         _lib.require_gpu_tensor(t, "input")
         if not t.is_contiguous():
@@ -493,7 +501,8 @@ class PlanBuilder:
         d.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
         d.act = ACT_BY_NAME[act]
         entry = dict(kind="stem", x=t, out=out, w=w32, b=bias, stride=2, act=act, post=post, res=None, alpha=None)
-        if self._fuse_s2 and fresh_out and post is None and self.quant is None and self.force_variant < 0 and Cin == 3 and Cout == 32:
+        if (self._fuse_s2 and single_use and fresh_out and post is None and self.quant is None and self.force_variant < 0
+                and Cin == 3 and Cout == 32):
             self._pending = dict(kind="stem", desc=d, entry=entry, out=out)      # (conv() flushed before calling us)
             return out
         _lib.check(self.lib.y6_plan_add_stem(self.h, C.byref(d)), "plan_add_stem")

@@ -727,6 +727,9 @@ class BiFusion(HipModule):
         cat = pb.new_buffer(x1.B, x1.H, x1.W, 3 * oc)
         self.upsample.lower(pb, x0, out=cat.slice(0, oc))
         self.cv1.lower(pb, x1, out=cat.slice(oc, oc))
+        hint = getattr(pb, "hint_single_use", None)
+        if hint is not None:
+            hint()            # cv2's output feeds the downsample conv only: the pair may run as one fused kernel (csrc/conv_fused.hip)
         t = self.cv2.lower(pb, x2)
         self.downsample.lower(pb, t, out=cat.slice(2 * oc, oc))
         return self.cv3.lower(pb, cat, out=out)

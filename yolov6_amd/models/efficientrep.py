@@ -39,6 +39,9 @@ class _PyramidBackbone(HipModule):
     def lower(self, pb, x, out=None):
         outs = []
         trace = getattr(pb, "trace", None)      # optional {name: activation view}, filled for tools/train_trace.py
+        hint = getattr(pb, "hint_single_use", None)
+        if hint is not None and trace is None:
+            hint()            # the stem's output feeds ERBlock_2[0] only: stem + first stride-2 block may run as one fused kernel
         x = self.stem.lower(pb, x)
         if trace is not None:
             trace["backbone.stem"] = x
