@@ -433,7 +433,8 @@ enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_W
        Y6_TOP_BIAS_GRAD = 11, Y6_TOP_FILL = 12, Y6_TOP_ADD = 13,
        Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16,
        /* fused inference ops (generic plan ops as well) */
-       Y6_TOP_PRED_DECODE = 17, Y6_TOP_PW_S2 = 18, Y6_TOP_STEM_S2 = 19 };
+       Y6_TOP_PRED_DECODE = 17, Y6_TOP_PW_S2 = 18, Y6_TOP_STEM_S2 = 19,
+       Y6_TOP_AVGPOOL3 = 20 };
 
 /* Batch statistics of a conv output + everything derived from them, on device:
  *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
@@ -608,6 +609,11 @@ int y6_subsample2(const y6_tensor* src, const y6_tensor* dst, void* stream);
 int y6_channel_sum(const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes, void* stream);
 /* dst (=|+=) a  for NHWC fp16 views of one shape (gradient fan-in of tensors with several consumers) */
 int y6_tensor_add(const y6_tensor* a, const y6_tensor* dst, int accumulate, void* stream);
+/* dst (=|+=) [src +] AvgPool2d(kernel 3, stride 1, padding 1)(src) for NHWC fp16 views of one shape: the `rbr_avg` branch of
+ * QARepVGGBlockV2's training form merged with its raw identity branch (yolov6/layers/common.py:404, :416-419:
+ * `self.rbr_dense(x) + self.rbr_1x1(x) + id_out + self.rbr_avg(x)`); the pooling is its own adjoint, so the backward of the
+ * branch is the same op applied to the gradient with accumulate = 1. */
+int y6_avgpool3(const y6_tensor* src, const y6_tensor* dst, int with_identity, int accumulate, void* stream);
 
 /* Training loss WITH gradient: y6_loss_forward's value plus d loss / d pred_scores and d loss / d pred_distri
  * (through bbox_decode's DFL projection, dist2bbox, the IoU loss, the DFL cross entropies and VarifocalLoss including
@@ -656,6 +662,7 @@ int y6_plan_add_space_to_depth2(y6_plan* p, const y6_tensor* src, const y6_tenso
 int y6_plan_add_subsample2(y6_plan* p, const y6_tensor* src, const y6_tensor* dst);
 int y6_plan_add_channel_sum(y6_plan* p, const y6_tensor* x, float* out_accum, void* workspace, size_t workspace_bytes);
 int y6_plan_add_tensor_add(y6_plan* p, const y6_tensor* a, const y6_tensor* dst, int accumulate);
+int y6_plan_add_avgpool3(y6_plan* p, const y6_tensor* src, const y6_tensor* dst, int with_identity, int accumulate);
 int y6_plan_add_fill_zero(y6_plan* p, void* ptr, size_t bytes);
 
 /* ------------------------------------------------------------------------------------ */

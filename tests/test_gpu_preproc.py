@@ -38,7 +38,7 @@ def test_letterbox_colour_and_smooth_image():
 
 def test_process_image_planes_feed_the_uint8_image_conv():
     """Inferer.process_image on the device: uint8 RGB planes == the oracle's (letterbox, HWC -> CHW, BGR -> RGB) bytes, the fp16
-    form == the reference-shaped `image.half() / 255`, and the HIP model gives the SAME detections from either."""
+    form == the reference-shaped `image.half() / 255`, and the HIP model gives the same detections from either (to the fp32 summation order of two separately tuned plans)."""
     from oracle import letterbox_oracle as LO, synth
     from yolov6_amd.configs import tiny_config
     from yolov6_amd.data.data_augment import process_image
@@ -58,4 +58,6 @@ def test_process_image_planes_feed_the_uint8_image_conv():
     det_u8 = model(planes[None].contiguous())[0].clone()
     det_f16 = model(half[None].contiguous())[0].clone()
     torch.cuda.synchronize()
-    assert torch.equal(det_u8, det_f16)
+    # (two plans, each autotuned on its own: conv variants - i.e. fp32 summation orders - may differ; the image bytes are equal)
+    err = ((det_u8 - det_f16).abs() / det_f16.abs().clamp(min=1.0)).max()
+    assert float(err) < 2e-3, float(err)

@@ -432,7 +432,7 @@ def _rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize("case,size,batch", [("tiny", 64, 2), ("tiny", 192, 4)])
+@pytest.mark.parametrize("case,size,batch", [("tiny", 64, 2), ("tiny", 192, 4), ("s_qa_tiny", 64, 2)])
 def test_training_graph_forward_backward_vs_oracle(case, size, batch):
     """Whole model, train form: head outputs, BatchNorm running statistics and EVERY parameter gradient.
 
@@ -541,13 +541,21 @@ def _block_case(kind):
         return L.BottleRep(16, 16, basic_block=L.RepVGGBlock, weight=True), [(2, 16, 8, 8)], lambda o, xs: o.bottlerep(xs[0], "m"), "repvgg"
     if kind == "bepc3":
         return L.BepC3(32, 32, n=2, block=L.RepVGGBlock), [(2, 32, 8, 8)], lambda o, xs: o.bepc3(xs[0], "m", 2), "repvgg"
+    if kind == "qarep_s1":        # first version: raw 1x1 and identity branches, BatchNorm after the sum (common.py:337-343)
+        return L.QARepVGGBlock(32, 32), [(2, 32, 12, 20)], lambda o, xs: o.block(xs[0], "m", 1), "qarepvgg"
+    if kind == "qarepv2_s1":      # + the 3x3 average-pool branch (common.py:412-419): what configs/qarepvgg/* train with
+        return L.QARepVGGBlockV2(32, 32), [(2, 32, 12, 20)], lambda o, xs: o.block(xs[0], "m", 1), "qarepvggv2"
+    if kind == "qarepv2_s2":
+        return L.QARepVGGBlockV2(16, 32, stride=2), [(2, 16, 12, 20)], lambda o, xs: o.block(xs[0], "m", 2), "qarepvggv2"
+    if kind == "qarepv2_widen":
+        return L.QARepVGGBlockV2(16, 48), [(3, 16, 9, 11)], lambda o, xs: o.block(xs[0], "m", 1), "qarepvggv2"
     if kind == "bepc3_silu":
         return L.BepC3(32, 32, n=2, block=L.ConvBNSiLU), [(2, 32, 8, 8)], lambda o, xs: o.bepc3(xs[0], "m", 2), "conv_silu"
     raise KeyError(kind)
 
 
 BLOCKS = ["repvgg_s1", "repvgg_s2", "repvgg_widen", "convbnsilu3", "convbnrelu1", "convbnrelu3s2", "repblock", "simsppf", "simcspsppf",
-          "transpose", "bifusion", "bottlerep", "bepc3", "bepc3_silu"]
+          "transpose", "bifusion", "bottlerep", "bepc3", "bepc3_silu", "qarep_s1", "qarepv2_s1", "qarepv2_s2", "qarepv2_widen"]
 
 
 @pytest.mark.parametrize("kind", BLOCKS)

@@ -95,6 +95,10 @@ class TrainChain:
             elif k == "subsample2":
                 outs.append((e["out"], self.get(e["x"])[:, :, ::2, ::2]))
                 desc = "subsample2"
+            elif k == "avgpool3":          # [x +] AvgPool2d(3, 1, 1)(x): QARepVGGBlockV2's raw identity + average-pool branches
+                xv = self.get(e["x"])
+                outs.append((e["out"], F.avg_pool2d(xv, 3, 1, 1) + (xv if e["with_identity"] else 0.0)))
+                desc = f"avgpool3{'+id' if e['with_identity'] else ''} C={xv.shape[1]} {xv.shape[2]}x{xv.shape[3]}"
             elif k == "stem":
                 x = q16(e["x"].float().cpu())
                 w = self._w16(e["weight"])
@@ -247,6 +251,17 @@ class TrainChain:
                 continue
             if k == "conv":
                 self._dgrad(i, e)
+                continue
+            if k == "avgpool3":            # backward of the branch: the same (self-adjoint) op on the gradient, maybe accumulating
+                gv = self.get(e["x"])
+                d = F.avg_pool2d(gv, 3, 1, 1) + (gv if e["with_identity"] else 0.0)
+                if e["acc"]:
+                    self.upload(e["out"], self.get(e["out"]))
+                plan.run_range(i, i + 1)
+                torch.cuda.synchronize()
+                v16 = self.put(e["out"], d, acc=bool(e["acc"]))
+                self._cmp("bwd", i, e, f"avgpool3 backward{' acc' if e['acc'] else ''}", [("dx", self.download(e["out"]), v16)], 3e-3)
+                self.upload(e["out"], v16)
                 continue
             if k == "space_to_depth2":
                 x = self.get(e["x"])

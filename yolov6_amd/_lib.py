@@ -177,7 +177,7 @@ class LossGradDesc(C.Structure):
 WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
 TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
              8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize",
-             17: "pred_decode", 18: "pw_s2", 19: "stem_s2"}
+             17: "pred_decode", 18: "pw_s2", 19: "stem_s2", 20: "avgpool3"}
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
@@ -242,6 +242,8 @@ SIGNATURES = {
     "y6_space_to_depth2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
     "y6_subsample2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
     "y6_plan_add_subsample2": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor)]),
+    "y6_avgpool3": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_int, C.c_void_p]),
+    "y6_plan_add_avgpool3": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_int]),
     "y6_channel_sum": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y6_tensor_add": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_void_p]),
     "y6_loss_forward_backward": (C.c_int, [C.POINTER(LossGradDesc), C.c_void_p]),

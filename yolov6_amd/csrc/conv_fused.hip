@@ -26,8 +26,8 @@
 //        staged as aligned 16-byte pieces (stem_mfma_v4_kernel's scheme, any of fp16 / fp32 / uint8).
 // Out-of-image producer pixels are ZERO in LDS (they are the stride-2 conv's zero padding, not relu(bias)).
 // Consumer: a wave owns one 32-pixel fragment x CFW cout fragments; weight fragments stream from the packed image (L2) through
-// a register ring D steps ahead, the pixel operand is one ds_read_b128 per (tap, k-step).  Epilogue = conv_epilogue
-// (bias, activation, 16-byte NHWC stores).  Same k order (tap-major inside 32-channel chunks ... see `consume`) is NOT the
+// a register ring, the pixel operand is one ds_read_b128 per (tap, k-step).  Epilogue: bias + activation (finish16_any), the
+// output tile staged through the (then dead) mid tile's LDS and stored as whole NHWC rows.  Same k order (tap-major inside 32-channel chunks ... see `consume`) is NOT the
 // per-tap kernels' order, so results agree with the unfused ops to fp32 summation order (<= 1 fp16 ulp), not bit for bit;
 // the rounding points (producer output fp16, consumer output fp16) are the unfused graph's.
 #include <cstddef>
@@ -60,6 +60,7 @@ struct FusedArgs {
     const float* wst;         // OIHW fp32 [Cm][3][3][3] (fp16-rounded values)
     // tiling
     int TH, tiles_x, tiles_y, ntiles;
+    int dbg;                  // timing probes (env Y6_FUSED_PROBE, WRONG RESULTS): 1 no producer arithmetic, 2 no consumer MFMA loop, 4 no output stores, 8 no input loads
     int MH, RPS, RPE, nslots, PLS;   // mid rows, slots per row (= 2 TW + 1), even columns per row (= TW + 1), MH * RPS, slots per plane (padded to 32)
 };
 
@@ -87,6 +88,28 @@ __device__ __forceinline__ void mid_store(char* mid, int PLS, int cfm, int slot,
     }
 }
 
+// producer epilogue arithmetic of one fragment: bias + activation (rounded where the reference's fp16 graph rounds: act_const),
+// zero for out-of-image pixels.  ONE wave-uniform branch per fragment: a `switch (act)` per element costs thousands of cycles
+// per fragment (conv_common.hpp finish16_any; the first version of these kernels spent 80 % of a tile there).
+template <int ACT>
+__device__ __forceinline__ void produce_act16(const f32x16_t& acc, const float (&bz)[16], bool valid, float (&v)[16]) {
+    // (computed for every lane - the operands of out-of-image lanes are real pixels, finite - then selected: a per-lane
+    //  `valid ? f(x) : 0` around SiLU / hardswish compiles to an exec-masked branch per element pair)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float t = act_const<ACT>(acc[r] + bz[r]);
+        v[r] = valid ? t : 0.f;
+    }
+}
+__device__ __forceinline__ void produce_act16_any(int act, const f32x16_t& acc, const float (&bz)[16], bool valid, float (&v)[16]) {
+    switch (act) {
+        case Y6_ACT_RELU: produce_act16<Y6_ACT_RELU>(acc, bz, valid, v); break;
+        case Y6_ACT_SILU: produce_act16<Y6_ACT_SILU>(acc, bz, valid, v); break;
+        case Y6_ACT_HARDSWISH: produce_act16<Y6_ACT_HARDSWISH>(acc, bz, valid, v); break;
+        default: produce_act16<Y6_ACT_NONE>(acc, bz, valid, v); break;
+    }
+}
+
 // slot (linear index into a mid plane) -> mid row / column, evens first
 __device__ __forceinline__ void slot_to_mid(const FusedArgs& a, int slot, int& my, int& mx) {
     my = slot / a.RPS;
@@ -99,8 +122,11 @@ __device__ __forceinline__ void slot_to_mid(const FusedArgs& a, int slot, int& m
 // 36-144 loop-invariant weight addresses out of the tile loop: 256 VGPRs + scratch).  Weight fragments come straight from the
 // packed image (L2) through a ring of three groups - two groups (an L2 round trip) ahead of the MFMAs - and every fragment
 // feeds PFW MFMAs (a 32-pixel fragment per wave would need 1 KiB of weights per MFMA: twice the vector memory path's rate).
-template <int KSM, int PFW, int CFW, int TW>
-__device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int frag0, int cf0, int lane, int b, int oy0, int ox0) {
+// RESIDENT: the wave's 9 * KSM weight fragments live in registers for the whole kernel (`wres`, loaded by the caller before the
+// tile loop; affordable for KSM = 2, the image-conv pair: 72 VGPRs) - the consumer then touches no global memory at all.
+template <int KSM, int PFW, int CFW, int TW, bool RESIDENT = false>
+__device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int frag0, int cf0, int lane, int b, int oy0, int ox0,
+                                        const h8_t* wres = nullptr) {
     constexpr int GK = KSM < 4 ? KSM : 4;       // k-steps per group
     constexpr int GPT = KSM / GK;               // groups per tap
     constexpr int NG = 9 * GPT;
@@ -151,42 +177,85 @@ __device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int
                 for (int i = 0; i < PFW; ++i) acc[cf][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[j][cf], bf[i], acc[cf][i], 0, 0, 0);
         }
     };
-    wload(0, w0);
-    wload(1, w1);
+    if (a.dbg & 2) {
+    } else if constexpr (RESIDENT) {
+        static_assert(CFW == 1, "resident weights: one cout fragment per wave");
+#pragma unroll
+        for (int u = 0; u < 9 * KSM; ++u) {
+            const int t = u / KSM, ks = u - t * KSM;
+            const int off = ((t / 3) * a.RPS + ((t % 3) == 1 ? a.RPE : ((t % 3) >> 1))) * 16 + ks * plane2;
+#pragma unroll
+            for (int i = 0; i < PFW; ++i) {
+                const h8_t bf = *reinterpret_cast<const h8_t*>(base[i] + off);
+                acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wres[u], bf, acc[0][i], 0, 0, 0);
+            }
+        }
+    } else {
+        wload(0, w0);
+        wload(1, w1);
 #pragma unroll 1
-    for (int g = 0; g < NG; g += 3) {
-        wload(g + 2, w2);
-        compute(g, w0);
-        if (g + 3 < NG) wload(g + 3, w0);
-        compute(g + 1, w1);
-        if (g + 4 < NG) wload(g + 4, w1);
-        compute(g + 2, w2);
+        for (int g = 0; g < NG; g += 3) {
+            wload(g + 2, w2);
+            compute(g, w0);
+            if (g + 3 < NG) wload(g + 3, w0);
+            compute(g + 1, w1);
+            if (g + 4 < NG) wload(g + 4, w1);
+            compute(g + 2, w2);
+        }
     }
-    int opix[PFW];
+    // ---- epilogue, staged through LDS at BLOCK level.  A wave holds 32 of a pixel's couts: stored directly, every 128-byte
+    // row of the output would be written in 16-byte pieces by 4-16 different store instructions of different waves (the
+    // stem's direct stores ran at 550 GB/s).  The mid tile is dead once every wave has issued its last MFMA: its
+    // LDS becomes the [tile pixel][Cout] fp16 image of the output tile, which leaves as whole rows, 16 bytes per lane.
+    __syncthreads();
+    unsigned zoff = 0;
+    asm volatile("" : "+s"(zoff));     // (keeps the loop-invariant bias loads inside the tile loop: they would hold 16 registers across the producer phase)
+    const float* bp = a.c.bias ? a.c.bias + zoff : nullptr;
+    const int RS = a.c.Cout * 2 + 16;  // row pitch of the staged tile (bytes)
+    char* stage = const_cast<char*>(mid);
+    static_assert(CFW == 1, "one cout fragment per wave");
+    float bz[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = bp ? *reinterpret_cast<const float4*>(bp + cf0 * 32 + 8 * g + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);   // Cout % 32 == 0 (host)
+        bz[g * 4 + 0] = t.x;
+        bz[g * 4 + 1] = t.y;
+        bz[g * 4 + 2] = t.z;
+        bz[g * 4 + 3] = t.w;
+    }
 #pragma unroll
     for (int i = 0; i < PFW; ++i) {
-        const int oy = oy0 + ty[i], ox = ox0 + tx[i];
-        opix[i] = (mm[i] < a.TH * TW && oy < a.c.Ho && ox < a.c.Wo) ? (b * a.c.Ho + oy) * a.c.Wo + ox : -1;
-    }
-    // bias of this lane's couts, loaded HERE (behind a laundered offset: loop-invariant loads would otherwise be hoisted out of
-    // the tile loop and hold 16 CFW registers across the producer phase)
-    unsigned zoff = 0;
-    asm volatile("" : "+s"(zoff));
-    const float* bp = a.c.bias ? a.c.bias + zoff : nullptr;
-    BiasRegs<CFW> bz;
+        float v[16];
+        finish16_any(a.c, acc[0][i], bz, cf0 * 32, kh, a.c.Cout, nullptr, 1.f, v);
+        unsigned pk[4][2];
 #pragma unroll
-    for (int cf = 0; cf < CFW; ++cf)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c0 = (cf0 + cf) * 32 + 8 * g + 4 * kh;             // Cout % 32 == 0 (host)
-            const float4 t = bp ? *reinterpret_cast<const float4*>(bp + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bz.v[cf][g * 4 + 0] = t.x;
-            bz.v[cf][g * 4 + 1] = t.y;
-            bz.v[cf][g * 4 + 2] = t.z;
-            bz.v[cf][g * 4 + 3] = t.w;
+            for (int h = 0; h < 2; ++h) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                h2_t t;
+                t[0] = (_Float16)v[g * 4 + h * 2];
+                t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                pk[g][h] = __builtin_bit_cast(unsigned, t);
+            }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+            *reinterpret_cast<uint4*>(stage + (size_t)mm[i] * RS + (cf0 * 32 + 16 * gp + 8 * kh) * 2) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
-    static_assert(CFW == 1, "conv_epilogue's cout block index is the fragment index only for one fragment per wave");
-    conv_epilogue<CFW, PFW>(a.c, acc, opix, cf0, 0, lane, bz);
+    }
+    __syncthreads();
+    const int ppr = a.c.Cout >> 3;                       // 16-byte pieces per output row
+    const int npc = a.TH * TW * ppr;
+    for (int qq = (int)threadIdx.x; qq < npc; qq += (int)blockDim.x) {
+        const int row = qq / ppr, pc = qq - row * ppr;
+        const int ry = row / TW, rx = row - ry * TW;
+        const int oy = oy0 + ry, ox = ox0 + rx;
+        if (oy < a.c.Ho && ox < a.c.Wo && !(a.dbg & 4))
+            *reinterpret_cast<uint4*>(a.c.out + ((size_t)(b * a.c.Ho + oy) * a.c.Wo + ox) * a.c.out_cs + a.c.out_co + pc * 8) =
+                *reinterpret_cast<const uint4*>(stage + (size_t)row * RS + pc * 16);
+    }
 }
 
 // ---- 1x1 producer + consumer.  KSI: input k-steps (Cin / 16); CM: cout fragments of the 1x1 (Cm / 32); the consumer has CM
@@ -250,6 +319,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
         h8_t x0[KSI], x1[KSI];
         bool v0 = false, v1 = false;
         int f = wave / CM;
+        if (a.dbg & 1) f = nmf;
         if (f < nmf) px_load(px_addr(f, v0), x0);
         while (f < nmf) {
             const int f1 = f + NW / CM;
@@ -260,8 +330,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
 #pragma unroll
             for (int ks = 0; ks < KSI; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ks], x0[ks], acc, 0, 0, 0);
             float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = v0 ? y6_act(acc[r] + bz1[r], a.act1) : 0.f;
+            produce_act16_any(a.act1, acc, bz1, v0, v);
             mid_store(mid, a.PLS, cfm, f * 32 + (lane & 31), lane, v);
 #pragma unroll
             for (int ks = 0; ks < KSI; ++ks) x0[ks] = x1[ks];
@@ -358,8 +427,15 @@ __global__ __launch_bounds__(256, 2) void fused_stem_s2_kernel(const FusedArgs a
                 pre[i].zero();
         }
     };
+    // the stride-2 conv's weight fragments of this wave's cout fragment (wave >> 1): 9 taps x 2 k-steps, resident
+    h8_t wres[18];
+    {
+        const __half* wb = a.c.wpk + (size_t)(wave >> 1) * 9 * 1024 + lane * 8;       // [cfr][chunk = 0][tap][ks][lane][8]
+#pragma unroll
+        for (int u = 0; u < 18; ++u) wres[u] = *reinterpret_cast<const h8_t*>(wb + (size_t)(u >> 1) * 1024 + (u & 1) * 512);
+    }
     int tile = blockIdx.x;
-    if (tile < a.ntiles) request(tile);
+    if (tile < a.ntiles && !(a.dbg & 8)) request(tile);
     for (; tile < a.ntiles; tile += gridDim.x) {
         const int tx_i = tile % a.tiles_x;
         const int t2 = tile / a.tiles_x;
@@ -371,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void fused_stem_s2_kernel(const FusedArgs a
         for (int i = 0; i < 4; ++i)
             if (pc_on[i]) *reinterpret_cast<uint4*>(s_in + pc_off[i]) = pre[i].as_half8();
         __syncthreads();
-        if (tile + (int)gridDim.x < a.ntiles) request(tile + gridDim.x);   // in flight during the MFMAs and the stores below
+        if (tile + (int)gridDim.x < a.ntiles && !(a.dbg & 8)) request(tile + gridDim.x);   // in flight during the MFMAs and the stores below
         // ---- produce: mid = act(conv3x3s2(image) + b1), 32 channels = 4 planes
         h8_t af[2];
         af[0] = *reinterpret_cast<const h8_t*>(s_w + lane * 16);
@@ -385,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void fused_stem_s2_kernel(const FusedArgs a
             bz1[g * 4 + 2] = t.z;
             bz1[g * 4 + 3] = t.w;
         }
-        for (int f = wave; f < NMF; f += 4) {
+        for (int f = wave; f < NMF && !(a.dbg & 1); f += 4) {
             const int slot = f * 32 + (lane & 31);
             int my = slot / FS_MW;
             const int ms = slot - my * FS_MW;
@@ -409,13 +485,12 @@ __global__ __launch_bounds__(256, 2) void fused_stem_s2_kernel(const FusedArgs a
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf, acc, 0, 0, 0);
             }
             float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = valid ? y6_act(acc[r] + bz1[r], a.act1) : 0.f;
+            produce_act16_any(a.act1, acc, bz1, valid, v);
             mid_store(mid, FS_PLS, 0, slot, lane, v);
         }
         __syncthreads();
         // ---- consume: output rows 2 (wave & 1), 2 (wave & 1) + 1 of the tile x cout fragment (wave >> 1)
-        consume<2, 2, 1, FS_TW>(a, mid, 2 * (wave & 1), wave >> 1, lane, b, oy0, ox0);
+        consume<2, 2, 1, FS_TW, true>(a, mid, 2 * (wave & 1), wave >> 1, lane, b, oy0, ox0, wres);
         __syncthreads();
     }
 }
@@ -434,6 +509,8 @@ int n_cu_cached() {
 int fill_consumer(const y6_conv_desc* s2, int B, int Hm, int Wm, FusedArgs* a) {
     ConvKArgs& k = a->c;
     memset(&k, 0, sizeof(k));
+    static const int probe = getenv("Y6_FUSED_PROBE") ? atoi(getenv("Y6_FUSED_PROBE")) : 0;
+    a->dbg = probe;
     k.out = (__half*)s2->out.data;
     k.wpk = (const __half*)s2->w_packed;
     k.bias = s2->bias;

@@ -1386,6 +1386,61 @@ int tensor_add_launch(const TwoT* d, hipStream_t s) {
     return Y6_OK;
 }
 
+// dst (=|+=) [src +] AvgPool2d(3, stride 1, pad 1, count_include_pad)(src): the `rbr_avg` branch of QARepVGGBlockV2 (reference
+// yolov6/layers/common.py:404, :416-419) merged with the block's raw identity branch (flag bit 1).  The pooling is symmetric,
+// so its backward is the same op on the gradient (flag bit 0: accumulate into dst).  fp32 sum of the nine fp16 taps / 9.
+__global__ __launch_bounds__(256) void avgpool3_kernel(const __half* __restrict__ src, int scs, int sco, __half* __restrict__ dst, int dcs,
+                                                       int dco, int B, int H, int W, int C, int acc, int with_id) {
+    const int G = C >> 3;
+    const size_t total = (size_t)B * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        size_t t = i / G;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        float sum[8], ctr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] = ctr[j] = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+                float v[8];
+                load8(src + ((size_t)(b * H + yy) * W + xx) * scs + sco + g * 8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[j] += v[j];
+                if (dy == 0 && dx == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ctr[j] = v[j];
+                }
+            }
+        __half* q = dst + ((size_t)(b * H + y) * W + x) * dcs + dco + g * 8;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = sum[j] / 9.f + (with_id ? ctr[j] : 0.f);
+        if (acc) {
+            float old[8];
+            load8(q, old);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += old[j];
+        }
+        store8(q, o);
+    }
+}
+int avgpool3_launch(const TwoT* d, hipStream_t s) {
+    const y6_tensor &a = d->a, &o = d->b;
+    Y6_REQUIRE(view_ok(a) && view_ok(o) && same_shape(a, o), "avgpool3: bad views");
+    Y6_REQUIRE(a.data != o.data, "avgpool3: in-place pooling is not defined");
+    hipLaunchKernelGGL(avgpool3_kernel, dim3(grid_for((size_t)a.B * a.H * a.W * (a.C / 8), 256, 256 * 16)), dim3(256), 0, s, (const __half*)a.data,
+                       a.cstride, a.coff, (__half*)o.data, o.cstride, o.coff, a.B, a.H, a.W, a.C, d->flag & 1, (d->flag >> 1) & 1);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 struct ChanSum {
     y6_tensor x;
     float* out;
@@ -1711,6 +1766,17 @@ extern "C" int y6_plan_add_tensor_add(y6_plan* p, const y6_tensor* a, const y6_t
     Y6_REQUIRE(p && a && dst, "plan_add: null argument");
     TwoT t{*a, *dst, accumulate};
     return y6_plan_push(p, tensor_add_launch, &t, Y6_TOP_ADD, 0.0, nhwc_bytes(*a) * (accumulate ? 3 : 2));
+}
+extern "C" int y6_avgpool3(const y6_tensor* src, const y6_tensor* dst, int with_identity, int accumulate, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(src && dst, "avgpool3: null argument");
+    TwoT t{*src, *dst, (accumulate ? 1 : 0) | (with_identity ? 2 : 0)};
+    return avgpool3_launch(&t, (hipStream_t)stream);
+}
+extern "C" int y6_plan_add_avgpool3(y6_plan* p, const y6_tensor* src, const y6_tensor* dst, int with_identity, int accumulate) {
+    Y6_REQUIRE(p && src && dst, "plan_add_avgpool3: null argument");
+    TwoT t{*src, *dst, (accumulate ? 1 : 0) | (with_identity ? 2 : 0)};
+    return y6_plan_push(p, avgpool3_launch, &t, Y6_TOP_AVGPOOL3, 0.0, nhwc_bytes(*src) * (accumulate ? 3 : 2));
 }
 extern "C" int y6_plan_add_fill_zero(y6_plan* p, void* ptr, size_t bytes) {
     Y6_REQUIRE(p && ptr, "plan_add: null argument");

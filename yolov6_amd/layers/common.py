@@ -556,7 +556,22 @@ class QARepVGGBlock(RepVGGBlock):
         return kernel, b3
 
     def _lower_train(self, pb, x, out, res, res_alpha):
-        raise NotImplementedError("yolov6_amd: QARepVGG training form (avg-pool / raw branches) is not on the HIP path yet")
+        """Training form (common.py:337-343 first version, :412-419 V2):
+            ReLU(bn(bn3(conv3x3(x)) + conv1x1(x) [+ x [+ AvgPool3x3(x)]]))       batch statistics in both BatchNorms.
+        The raw (un-normalised) 1x1 / identity / average-pool branches enter the branch sum with scale 1; identity and
+        average pool are one tensor (`pb.avgpool3`).  Two branch-sum passes: the inner sum has no activation, the outer one is
+        the block's BatchNorm + ReLU."""
+        if hasattr(self, "rbr_reparam"):
+            raise NotImplementedError("yolov6_amd: a deployed QARepVGG block cannot be trained (no branches left)")
+        s = self.rbr_dense.conv.stride[0]
+        y3 = pb.conv(x, self.rbr_dense.conv.weight, s)
+        y1 = pb.conv(x, self.rbr_1x1.weight, s)
+        branches = [(y3, pb.bn(y3, self.rbr_dense.bn)), (y1, None)]
+        if self.rbr_identity is not None:
+            xr = pb.as_nhwc(x)
+            branches.append((pb.avgpool3(xr, True) if getattr(self, "rbr_avg", None) is not None else xr, None))
+        z = pb.bnact(branches, None)
+        return pb.bnact([(z, pb.bn(z, self.bn))], "relu", out=out, res=res, alpha=res_alpha)
 
     def _post_affine(self):
         # the deploy form keeps self.bn after the conv (:338-339, :390-392)

@@ -344,6 +344,25 @@ class TrainBuilder:
         self.tape.append(lambda: self._bnact_backward(d, branches, out, res, alpha))
         return out
 
+    def avgpool3(self, x: TRef, with_identity: bool) -> TRef:
+        """[x +] AvgPool2d(3, 1, 1)(x): the raw identity + average-pool branches of QARepVGGBlockV2's training form
+        (common.py:416-419) as one tensor.  The pooling is its own adjoint: the backward is the same op on the gradient."""
+        out = self.new_buffer(x.B, x.H, x.W, x.C)
+        ca, cb = x.ct(), out.ct()
+        self._f(self.lib.y6_plan_add_avgpool3(self.fwd, C.byref(ca), C.byref(cb), int(with_identity), 0), "plan_add_avgpool3", x=x, out=out,
+                with_identity=bool(with_identity))
+
+        def bwd():
+            gout = self.grad(out)
+            self.grad_ready(gout)
+            gx = self.grad(x)
+            acc = self.grad_mode(gx)
+            ga, gb = gout.ct(), gx.ct()
+            self._b(self.lib.y6_plan_add_avgpool3(self.bwd, C.byref(ga), C.byref(gb), int(with_identity), acc), "plan_add_avgpool3", x=gout, out=gx,
+                    with_identity=bool(with_identity), acc=int(acc))
+        self.tape.append(bwd)
+        return out
+
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
         cts = [t.ct() for t in (x, y1, y2, y3)]
         self._f(self.lib.y6_plan_add_sppf(self.fwd, *[C.byref(c) for c in cts]), "plan_add_sppf", x=x, outs=[y1, y2, y3])
