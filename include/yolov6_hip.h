@@ -388,11 +388,44 @@ typedef struct y6_loss_desc {
     int32_t box_mode;              /* 0: pred_distri are (l,t,r,b) distances / DFL logits (loss.py:194-198);
                                       1: (dx, dy, w, h) around the anchor point, the anchor-based branch of loss_fuseab.py:75-76
                                          (`pred_distri[..., :2] += anchor_points_s; xywh2xyxy`) - gradient only, use_dfl must be 0 */
+    int32_t norm_mode;             /* 0: loss.py's normalisation (terms / target_scores_sum when that is > 1, :168-169, :238-261);
+                                      1: the self-distillation losses' (class term when it is > 0, box terms unless it is exactly 0:
+                                         loss_distill.py:178-183, :283-330 and loss_distill_ns.py likewise) */
 } y6_loss_desc;
 int y6_bbox_decode(const float* pred_distri, const float* anchor_points_s, int B, int A, int use_dfl, int reg_max,
                    float* pred_bboxes, void* stream);
 size_t y6_loss_workspace_bytes(void);
 int y6_loss_forward(const y6_loss_desc* d, void* stream);
+
+/* Self-distillation terms of loss_distill.py / loss_distill_ns.py, as sums the host scales:
+ *   acc[0] = sum over ALL anchors of KL(softmax(scores_t / T) || softmax(scores_s / T))      distill_loss_cls :210-221
+ *   acc[1] = sum over positive anchors x 4 sides of the same KL over the reg_max + 1 DFL bins   distill_loss_dfl :349-359
+ *   acc[2] = sum of the positives' weights (target_scores.sum(-1)),  acc[3] = number of positives
+ * (the class "logits" are the post-sigmoid scores of the two heads, as the reference passes them).  y6_distill_backward ADDS
+ *   coef[0] * d acc[0] / d scores_s  to dscores  and  coef[1] * d acc[1] / d distri_s  to ddistri
+ * (coef: two device floats the host derives from acc - T^2, loss weights, the cosine weight decay, the mean over positives,
+ * the incoming gradient - without a host sync).  distri_s / distri_t NULL: class term only.
+ * y6_distill_cw: channel-wise feature distillation :222-246 for one level: s_feat / t_feat dense [rows = N*C][hw] fp32; forward
+ * (acc given): acc[0] += sum over rows of KL(softmax_hw(t / T) || softmax_hw(s / T)); backward (coef, d_s_feat given):
+ * d_s_feat = coef[0] * d acc / d s_feat. */
+typedef struct y6_distill_desc {
+    const float* scores_s;
+    const float* scores_t;
+    const float* distri_s;
+    const float* distri_t;
+    const uint8_t* fg_mask;
+    const float* target_scores;
+    int32_t BA, C, reg_max;
+    float temperature;
+    double* acc;
+    const float* coef;
+    float* dscores;
+    float* ddistri;
+} y6_distill_desc;
+int y6_distill_forward(const y6_distill_desc* d, void* stream);
+int y6_distill_backward(const y6_distill_desc* d, void* stream);
+int y6_distill_cw(const float* s_feat, const float* t_feat, int rows, int hw, float temperature, double* acc, const float* coef,
+                  float* d_s_feat, void* stream);
 
 /* ------------------------------------------------------------------------------------ */
 /* BatchNorm2d in TRAINING mode (batch statistics), forward only - the primitives the training-form forward needs

@@ -246,8 +246,7 @@ class Oracle:
             while e * 2 < n:
                 e *= 2
             n_list = [0, e, n]
-        w, b = self.conv_module_wb(p + ".cv1")
-        y = self.conv_fused(x, w, b, 1, act)
+        y = self.conv_module(x, p + ".cv1", act)
         c = y.shape[1] // len(n_list)
         ys = list(y.split(c, 1))
         all_y = [ys[0]]
@@ -255,8 +254,12 @@ class Oracle:
             all_y.append(ys[mi + 1])
             for j in range(steps):
                 all_y.append(self.bottlerep3(all_y[-1], f"{p}.m.{mi}.{j}"))
-        w2, b2 = self.conv_module_wb(p + ".cv2")
-        return self.conv_fused(torch.cat(all_y, 1), w2, b2, 1, act)
+        return self.conv_module(torch.cat(all_y, 1), p + ".cv2", act)
+
+    def conv_module(self, x, p, act, stride=1):
+        """A bare ConvModule at prefix p (conv -> BatchNorm -> activation, common.py:26-54), eval form: BN folded."""
+        w, b = self.conv_module_wb(p)
+        return self.conv_fused(x, w, b, stride, act)
 
     def stage(self, x, p, n):
         if self.a.csp and self.a.mbla:
@@ -495,6 +498,15 @@ class TrainOracle(Oracle):
             return self.convbn(x, p, "relu" if mode == "conv_relu" else "silu", stride)
         return self.repvgg_train_form(x, p, stride)
 
+    def conv_module(self, x, p, act, stride=1):
+        """A bare ConvModule in training mode (common.py:45-49): conv -> BatchNorm on batch statistics -> activation."""
+        sd = self.sd
+        w = sd[p + ".conv.weight"]
+        y = self.c2d(x, w, sd.get(p + ".conv.bias"), stride=stride, padding=w.shape[-1] // 2)
+        if p + ".bn.weight" in sd:
+            y = self.bn(y, p + ".bn")
+        return self.r16(self.act(y, act))
+
     def head_train(self, feats):
         sd = self.sd
         xs, cls_l, reg_l = [], [], []
@@ -531,6 +543,30 @@ class TrainOracle(Oracle):
             caf.append(torch.sigmoid(self.c2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])).flatten(2).permute(0, 2, 1))
             raf.append(self.c2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"]).flatten(2).permute(0, 2, 1))
         return xs, torch.cat(cab, 1), torch.cat(rab, 1), torch.cat(caf, 1), torch.cat(raf, 1)
+
+    def head_train_distill_ns(self, feats):
+        """Detect training branch of the N / S self-distillation head (heads/effidehead_distill_ns.py:80-103): a third output,
+        plain (l, t, r, b) distances from `reg_preds`, next to the DFL logits of `reg_preds_dist`.
+        -> stems, cls_scores [B,A,nc], reg_distri [B,A,4*(reg_max+1)], reg_lrtb [B,A,4]"""
+        sd = self.sd
+        xs, cls_l, dist_l, lrtb_l = [], [], [], []
+        for i, x in enumerate(feats):
+            f = self.convbn(x, f"detect.stems.{i}", "silu")
+            c = self.convbn(f, f"detect.cls_convs.{i}", "silu")
+            r = self.convbn(f, f"detect.reg_convs.{i}", "silu")
+            co = self.c2d(c, sd[f"detect.cls_preds.{i}.weight"], sd[f"detect.cls_preds.{i}.bias"])
+            do = self.c2d(r, sd[f"detect.reg_preds_dist.{i}.weight"], sd[f"detect.reg_preds_dist.{i}.bias"])
+            lo = self.c2d(r, sd[f"detect.reg_preds.{i}.weight"], sd[f"detect.reg_preds.{i}.bias"])
+            xs.append(f)
+            cls_l.append(torch.sigmoid(co).flatten(2).permute(0, 2, 1))
+            dist_l.append(do.flatten(2).permute(0, 2, 1))
+            lrtb_l.append(lo.flatten(2).permute(0, 2, 1))
+        return xs, torch.cat(cls_l, 1), torch.cat(dist_l, 1), torch.cat(lrtb_l, 1)
+
+    def forward_train_distill_ns(self, x):
+        self.new_stats = {}
+        feats = self.neck(self.backbone(x.float()))
+        return self.head_train_distill_ns(list(feats)), feats
 
     def forward_train_fuseab(self, x, anchors_init):
         self.new_stats = {}

@@ -458,6 +458,35 @@ def gen_distill_ns():
     print(f"model_tiny_distill_ns: det {tuple(det.shape)} keys {len(model.state_dict())}")
 
 
+DISTILL_NS_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "detect.reg_convs.1.block.conv.weight", "detect.reg_preds.0.weight",
+                          "detect.reg_preds.2.bias", "detect.reg_preds_dist.1.weight", "detect.reg_preds_dist.0.bias", "detect.cls_preds.2.bias"]
+
+
+def gen_distill_ns_train():
+    """Model(..., distill_ns=True) in TRAINING mode (heads/effidehead_distill_ns.py:80-103): the three head outputs - class scores,
+    DFL logits, plain (l, t, r, b) distances - and reference parameter gradients of a scalar of all three."""
+    from yolov6.models.yolo import Model
+    cfile, over, size, batch, nc = MODEL_CASES["tiny"]
+    cfg = ref_config(cfile, over)
+    torch.manual_seed(0)
+    model = Model(cfg, channels=3, num_classes=nc, distill_ns=True)
+    sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd)
+    model.train()
+    x = synth.synth_images(max(batch, 2), size, seed=21)
+    (xs, cls_scores, reg_distri, reg_lrtb), featmaps = model(x)
+    scalar = (cls_scores * cls_scores).sum() + reg_distri.square().mean() + reg_lrtb.square().mean()
+    model.zero_grad()
+    scalar.backward()
+    params = dict(model.named_parameters())
+    out = dict(cls_scores=cls_scores.detach().numpy(), reg_distri=reg_distri.detach().numpy(), reg_lrtb=reg_lrtb.detach().numpy(),
+               scalar=np.float64(float(scalar)))
+    for q in DISTILL_NS_GRAD_PROBES:
+        out["grad:" + q] = params[q].grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "distill_ns_train_tiny.npz"), **out)
+    print(f"distill_ns_train_tiny: cls {tuple(cls_scores.shape)} distri {tuple(reg_distri.shape)} lrtb {tuple(reg_lrtb.shape)} scalar {float(scalar):.4f}")
+
+
 FUSEAB_GRAD_PROBES = ["backbone.stem.rbr_dense.conv.weight", "neck.Rep_p3.conv1.rbr_1x1.bn.weight", "detect.cls_convs.1.block.conv.weight",
                       "detect.cls_preds_ab.0.weight", "detect.reg_preds_ab.1.bias", "detect.reg_preds_ab.2.weight", "detect.cls_preds.2.bias"]
 LOSSAB_CASES = {
@@ -524,6 +553,8 @@ if __name__ == "__main__":
     if "distill_ns" in which:
         gen_distill_ns()
         gen_loss_distill_ns()
+    if "distill_ns_train" in which or "distill_ns" in which:
+        gen_distill_ns_train()
     if "fuseab_eval" in which or "fuseab" in which:
         gen_fuseab_eval()
     if "models" in which:

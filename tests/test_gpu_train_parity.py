@@ -26,7 +26,11 @@ def _rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-def test_training_step_per_op_teacher_forced_yolov6s_640():
+@pytest.mark.parametrize("name,size,B", [("yolov6s", 640, 8), ("s_qa_tiny", 64, 2), ("s_mbla_tiny", 64, 2)])
+def test_training_step_per_op_teacher_forced(name, size, B):
+    """yolov6s 640 b8: BASELINE configs[2]'s plan.  s_qa_tiny / s_mbla_tiny (golden cases of tests/golden): the QARepVGGBlockV2
+    training form (raw 1x1 / identity / average-pool branches, BatchNorm after the sum) and the MBLABlock training graph
+    (BatchNorm statistics as channel slices) - every op teacher-forced, no free-running comparison of a chaotic network."""
     import bench
     from oracle.model_oracle import TrainOracle
     from tests.train_replay import TrainChain
@@ -34,17 +38,26 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
     from yolov6_amd.models.losses.loss import ComputeLoss
     from yolov6_amd.models.yolo import build_model
     from yolov6_amd.utils import synth
-    B, size, S = 8, 640, 8192.0
-    cfg = get_config("yolov6s")
-    model = build_model(cfg, 80, "cpu")
-    sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    S, nc = 8192.0, 80
+    if name == "yolov6s":
+        cfg = get_config("yolov6s")
+        model = build_model(cfg, 80, "cpu")
+        sd = synth.synth_state_dict(model.state_dict(), seed=0)
+    else:
+        from tests.helpers import case_config, synth_sd_from_keys
+        cfg, meta = case_config(name)
+        nc = meta["num_classes"]
+        model = build_model(cfg, nc, "cpu")
+        sd = synth_sd_from_keys(meta["train"])
     model.load_state_dict(sd)
     sd = {k: v.clone() for k, v in sd.items()}
     model = model.to(DEV).train()
     x = synth.synth_images(B, size, seed=0).half()
-    targets = bench.synth_targets(B, seed=0).to(DEV)
+    targets = bench.synth_targets(B, seed=0)
+    targets[:, 1] = targets[:, 1] % nc
+    targets = targets.to(DEV)
     h = cfg.model.head
-    crit = ComputeLoss(num_classes=80, ori_img_size=size, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    crit = ComputeLoss(num_classes=nc, ori_img_size=size, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
     # ---- the step as bench.py --mode train runs it (free running), autotuned plans
     xd = x.to(DEV)
     (feats, scores, distri), _ = model(xd)
@@ -71,14 +84,14 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
         chain.forward()
     # the teacher IS the fp16-activation oracle (same statement, batch statistics stored in fp32 on both sides)
     with torch.no_grad():
-        (xs_o, cls_o, reg_o), _ = TrainOracle(cfg, sd, 80, amp_fp16=True).forward_train(x.float())
+        (xs_o, cls_o, reg_o), _ = TrainOracle(cfg, sd, nc, amp_fp16=True).forward_train(x.float())
     tie = dict(scores=float((chain.scores - cls_o).abs().max()), distri=_rel_l2(chain.distri, reg_o))
     # ... up to the fp16 noise floor of this 90-conv, batch-statistics network on random weights: two statements that round
     # at the same places but evaluate BatchNorm in a different fp32 order ((x - mean) / sqrt(var + eps) * g + b vs x * scale +
     # shift) flip fp16 roundings, and every flip is re-amplified by the following normalisations.  The floor is measured the
     # same way: the same oracle with and without fp16 activations.
     with torch.no_grad():
-        (_, cls_32, reg_32), _ = TrainOracle(cfg, sd, 80, amp_fp16=False).forward_train(x.float())
+        (_, cls_32, reg_32), _ = TrainOracle(cfg, sd, nc, amp_fp16=False).forward_train(x.float())
     floor = dict(scores=float((cls_o - cls_32).abs().max()), distri=_rel_l2(reg_o, reg_32))
     tie["floor_amp_vs_fp32"] = floor
     chain.backward(dscores, ddistri)
@@ -102,7 +115,7 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
         d["n"] += 1
         if r["err"] >= d["worst"]:
             d["worst"], d["worst_desc"] = r["err"], r["desc"]
-    summary = dict(model="yolov6s", size=size, batch=B, loss=float(loss), loss_scale=S, fwd_ops=len(graph.fwd_log), bwd_ops=len(graph.bwd_log),
+    summary = dict(model=name, size=size, batch=B, loss=float(loss), loss_scale=S, fwd_ops=len(graph.fwd_log), bwd_ops=len(graph.bwd_log),
                    rows=len(rows), teacher_vs_train_oracle_amp=tie, per_kind=by_kind,
                    free_running_head=dict(scores_max=float((free_scores - chain.scores).abs().max()), distri_rel_l2=_rel_l2(free_distri, chain.distri)),
                    free_running_param_grads=dict(n=len(vals), median=float(np.median(vals)), p90=float(np.quantile(vals, 0.9)), worst=float(vals.max()),
@@ -110,9 +123,11 @@ def test_training_step_per_op_teacher_forced_yolov6s_640():
     summary["relu_ties_excluded"] = int(sum(r.get("relu_ties_excluded", 0) for r in rows))
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, f"train_parity_yolov6s_{size}_b{B}.json"), "w") as f:
+    with open(os.path.join(out_dir, f"train_parity_{name}_{size}_b{B}.json"), "w") as f:
         json.dump(dict(summary=summary, rows=rows, variants=variants, free_running_param_grads=e2e), f, indent=1)
     print(json.dumps(summary))
     bad = [r for r in rows if r["err"] > r["tol"]]
     assert not bad, f"{len(bad)} of {len(rows)} ops above their bound teacher-forced, e.g. {bad[:4]}"
-    assert tie["scores"] <= 1.5 * floor["scores"] + 5e-3 and tie["distri"] <= 1.5 * floor["distri"] + 5e-3, tie
+    # (QARepVGGBlockV2: the HIP graph stores x + AvgPool(x) and the inner branch sum as fp16 tensors, two rounding points the
+    #  oracle's AMP statement does not have - the teacher follows the graph)
+    assert tie["scores"] <= 2.5 * floor["scores"] + 5e-3 and tie["distri"] <= 2.5 * floor["distri"] + 5e-3, tie

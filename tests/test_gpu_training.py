@@ -432,7 +432,7 @@ def _rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-30))
 
 
-@pytest.mark.parametrize("case,size,batch", [("tiny", 64, 2), ("tiny", 192, 4), ("s_qa_tiny", 64, 2)])
+@pytest.mark.parametrize("case,size,batch", [("tiny", 64, 2), ("tiny", 192, 4)])
 def test_training_graph_forward_backward_vs_oracle(case, size, batch):
     """Whole model, train form: head outputs, BatchNorm running statistics and EVERY parameter gradient.
 
@@ -549,13 +549,20 @@ def _block_case(kind):
         return L.QARepVGGBlockV2(16, 32, stride=2), [(2, 16, 12, 20)], lambda o, xs: o.block(xs[0], "m", 2), "qarepvggv2"
     if kind == "qarepv2_widen":
         return L.QARepVGGBlockV2(16, 48), [(3, 16, 9, 11)], lambda o, xs: o.block(xs[0], "m", 1), "qarepvggv2"
+    if kind == "bottlerep3":
+        return L.BottleRep3(16, 16, basic_block=L.RepVGGBlock, weight=True), [(2, 16, 8, 8)], lambda o, xs: o.bottlerep3(xs[0], "m"), "repvgg"
+    if kind == "mbla":            # three branches: n = 4 -> n_list [0, 1, 2] (common.py:653-692)
+        return L.MBLABlock(32, 32, n=4, block=L.RepVGGBlock), [(2, 32, 8, 8)], lambda o, xs: o.mbla(xs[0], "m", 4), "repvgg"
+    if kind == "mbla_silu":       # two branches, ConvBNSiLU body (the yolov6*_mbla configs)
+        return L.MBLABlock(32, 64, n=2, block=L.ConvBNSiLU), [(2, 32, 8, 8)], lambda o, xs: o.mbla(xs[0], "m", 2), "conv_silu"
     if kind == "bepc3_silu":
         return L.BepC3(32, 32, n=2, block=L.ConvBNSiLU), [(2, 32, 8, 8)], lambda o, xs: o.bepc3(xs[0], "m", 2), "conv_silu"
     raise KeyError(kind)
 
 
 BLOCKS = ["repvgg_s1", "repvgg_s2", "repvgg_widen", "convbnsilu3", "convbnrelu1", "convbnrelu3s2", "repblock", "simsppf", "simcspsppf",
-          "transpose", "bifusion", "bottlerep", "bepc3", "bepc3_silu", "qarep_s1", "qarepv2_s1", "qarepv2_s2", "qarepv2_widen"]
+          "transpose", "bifusion", "bottlerep", "bepc3", "bepc3_silu", "qarep_s1", "qarepv2_s1", "qarepv2_s2", "qarepv2_widen",
+          "bottlerep3", "mbla", "mbla_silu"]
 
 
 @pytest.mark.parametrize("kind", BLOCKS)
@@ -756,6 +763,76 @@ def test_fuseab_training_graph_vs_oracle():
     assert not bad, f"{len(bad)} gradients above twice the fp16 floor, e.g. {bad[:4]}"
     ab = [k for k in g32 if "_ab" in k]
     assert len(ab) == 12 and all(float(named[k].grad.abs().max()) > 0 for k in ab)
+
+
+def test_distill_ns_training_graph_vs_oracle():
+    """Model(distill_ns=True) in training mode on the HIP path (heads/effidehead_distill_ns.py:80-103): the three head outputs and
+    every parameter gradient against TrainOracle.forward_train_distill_ns (pinned to the reference's training-mode golden on the
+    CPU), at the fp16 noise floor; then one self-distillation step: loss_distill_ns.ComputeLoss with a teacher's outputs drives
+    the native backward plan."""
+    from oracle import synth
+    from oracle.model_oracle import TrainOracle
+    from tests.helpers import case_config, synth_sd_from_keys
+    from yolov6_amd.models.losses.loss_distill_ns import ComputeLoss
+    from yolov6_amd.models.yolo import build_model
+    with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+        meta = json.load(f)
+    cfg, _ = case_config("tiny")
+    nc = meta["num_classes"]
+    sd = synth_sd_from_keys(meta["train"])
+    x = synth.synth_images(4, 192, seed=21)
+    xh = x.half().float()
+
+    def run(amp):
+        params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+        orc = TrainOracle(cfg, sd, nc, amp_fp16=amp)
+        orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+        (xs, c, d, l), _ = orc.forward_train_distill_ns(xh)
+        ((c * c).sum() + d.square().mean() + l.square().mean()).backward()
+        return [t.detach() for t in (c, d, l)], {k: p.grad.detach() for k, p in params.items() if p.grad is not None}
+    o32, g32 = run(False)
+    o16, g16 = run(True)
+    model = build_model(cfg, nc, "cpu", distill_ns=True)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    (stems, c, d, l), _ = model(x.to(DEV).half())
+    S = 256.0
+    (((c * c).sum() + d.square().mean() + l.square().mean()) * S).backward()
+    torch.cuda.synchronize()
+    for name, got, r32, r16 in zip(("cls_scores", "reg_distri", "reg_lrtb"), (c, d, l), o32, o16):
+        e, fl = _rel_l2(got.detach().cpu(), r32), _rel_l2(r16, r32)
+        assert e <= 2 * fl + 2e-3, f"{name}: HIP {e:.3e} vs fp16 noise floor {fl:.3e}"
+    named = dict(model.named_parameters())
+    bad = []
+    for k, ref in g32.items():
+        if k == "detect.proj" or k.startswith("detect.proj_conv") or float(ref.norm()) == 0.0:
+            continue
+        fl = _rel_l2(g16[k], ref)
+        if fl > 1.0:
+            continue
+        e = _rel_l2(named[k].grad.detach().float().cpu() / S, ref)
+        if e > 2 * fl + 2e-3:
+            bad.append((k, e, fl))
+    assert not bad, f"{len(bad)} gradients above twice the fp16 floor, e.g. {bad[:4]}"
+    both = [k for k in g32 if "reg_preds" in k]
+    assert len(both) == 12 and all(float(named[k].grad.abs().max()) > 0 for k in both)       # reg_preds AND reg_preds_dist, 3 levels x (w, b)
+    # ---- one self-distillation step (core/engine.py:153-160): the teacher's outputs are plain tensors
+    h = cfg.model.head
+    crit = ComputeLoss(num_classes=nc, ori_img_size=192, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type)
+    arena = c._y6_graph.arena
+    arena.zero_grad()
+    xs_in = x.to(DEV).half()
+    with torch.no_grad():
+        t_out, t_feats = model(xs_in)
+        t_out = tuple(t.clone() if isinstance(t, torch.Tensor) else t for t in t_out)
+    outs, s_feats = model(xs_in.flip(0).contiguous())
+    targets = _seam_targets(8)
+    targets[:, 1] = targets[:, 1] % nc
+    loss, items = crit(outs, t_out, s_feats, t_feats, targets, 5, 100, 20.0, 1, 192, 192)
+    (loss * 64.0).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and items.shape == (4,) and torch.isfinite(arena.grad).all()
+    assert float(named["detect.reg_preds.0.weight"].grad.abs().max()) > 0 and float(named["backbone.stem.rbr_dense.conv.weight"].grad.abs().max()) > 0
 
 
 # ------------------------------------------------------------------ the reference trainer's step on the HIP model (seam)

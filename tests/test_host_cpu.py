@@ -288,8 +288,9 @@ def test_distill_ns_head_state_dict_abi_and_eval_oracle():
         det, _ = Oracle(ocfg, sd, meta["num_classes"]).forward(x, train_form=True)
     g = np.load(os.path.join(GOLDEN, "model_tiny_distill_ns.npz"))["det_train"]
     assert float(np.abs(det.numpy() - g).max() / max(1.0, float(np.abs(g).max()))) < 1e-4
-    with pytest.raises(NotImplementedError):
-        m.detect.lower_train(None, None)
+    # the training branch exists on the HIP path now (tests/test_gpu_training.py::test_distill_ns_training_graph_vs_oracle): it
+    # returns three head outputs - class scores, DFL logits, plain distances - from the SAME reg_conv features
+    assert callable(m.detect.lower_train) and len(m.detect.reg_preds_dist) == len(m.detect.reg_preds) == 3
 
 
 WIRING_CASES = CASES + ["tiny_distill_ns", "tiny_fuseab_eval"]

@@ -520,3 +520,29 @@ def test_resize_linear_restatement_known_answers():
     ramp = np.tile(np.arange(0, 250, 5, dtype=np.uint8)[None, :, None], (4, 1, 3))
     out = LO.resize_linear_u8(ramp, 123, 4)[0, :, 0].astype(int)
     assert (np.diff(out) >= 0).all() and out.min() >= 0 and out.max() <= 245
+
+
+def test_distill_ns_train_oracle_matches_reference_golden():
+    """TrainOracle.head_train_distill_ns vs the unmodified reference Model(distill_ns=True) in training mode: the three head outputs
+    (class scores, DFL logits, plain distances) and seven reference parameter gradients."""
+    from oracle.model_oracle import TrainOracle
+    with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(GOLDEN, "distill_ns_train_tiny.npz"))
+    cfg, _ = case_config("tiny")
+    sd = synth_sd_from_keys(meta["train"])
+    params = {k: v.clone().float().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    orc = TrainOracle(cfg, sd, meta["num_classes"])
+    orc.sd = {k: (params[k] if k in params else v.float()) for k, v in sd.items()}
+    x = synth.synth_images(max(meta["batch"], 2), meta["size"], seed=21)
+    (xs, cls_s, dist, lrtb), _ = orc.forward_train_distill_ns(x)
+    for name, t in (("cls_scores", cls_s), ("reg_distri", dist), ("reg_lrtb", lrtb)):
+        np.testing.assert_allclose(t.detach().numpy(), g[name], rtol=2e-4, atol=1e-4, err_msg=name)
+    scalar = (cls_s * cls_s).sum() + dist.square().mean() + lrtb.square().mean()
+    scalar.backward()
+    np.testing.assert_allclose(float(scalar), float(g["scalar"]), rtol=1e-5)
+    for k in g.files:
+        if k.startswith("grad:"):
+            ref = g[k]
+            got = params[k[5:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 2e-3 * max(np.abs(ref).max(), 1e-6), k

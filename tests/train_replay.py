@@ -125,6 +125,7 @@ class TrainChain:
                 shift = beta - mean * scale
                 ref = dict(scale=scale.float(), shift=shift.float(), mean=mean.float(), invstd=invstd.float())
                 self.stats[id(st)] = ref
+                self.stats[id(bn)] = ref           # channel slices of these statistics (BnStats.slice: MBLABlock's cv1) look them up by module
                 rm0, rv0 = bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()
                 plan.run_range(i, i + 1)
                 torch.cuda.synchronize()
@@ -142,8 +143,9 @@ class TrainChain:
                 for t, st in e["branches"]:
                     xb = self.get(t)
                     if st is not None:
-                        s_ = self.stats[id(st)]
-                        xb = xb * s_["scale"].view(1, -1, 1, 1) + s_["shift"].view(1, -1, 1, 1)
+                        s_ = self.stats.get(id(st)) or self.stats[id(st.module)]
+                        c0 = getattr(st, "c0", 0)
+                        xb = xb * s_["scale"][c0:c0 + xb.shape[1]].view(1, -1, 1, 1) + s_["shift"][c0:c0 + xb.shape[1]].view(1, -1, 1, 1)
                     z = z + xb
                 o = ACT[e["act"]](z)
                 if e["res"] is not None:
@@ -195,7 +197,9 @@ class TrainChain:
         pairs = []
         for name, p, ref in items:
             pairs.append((name, self._grad_view(p).detach().cpu().float(), ref.float()))
-            self.param_grads[id(p)] = ref.float()
+            prev = self.param_grads.get(id(p))
+            # several ops may each own a channel slice of one parameter's gradient (BatchNorm of MBLABlock's cv1): their sum
+            self.param_grads[id(p)] = ref.float() if (prev is None or not getattr(self, "_partial_bn", False)) else prev + ref.float()
         self._cmp(phase, i, e, desc, pairs, tol)
 
     def backward(self, dscores, ddistri):
@@ -297,9 +301,10 @@ class TrainChain:
             leaves.append(xb)
             if st is not None:
                 bn = st.module
-                w = bn.weight.detach().float().cpu().requires_grad_(True) if bn.weight is not None else None
-                b = bn.bias.detach().float().cpu().requires_grad_(True) if bn.bias is not None else None
-                params.append((bn, w, b))
+                c0, nch = getattr(st, "c0", 0), xb.shape[1]          # a channel slice of a wider BatchNorm (MBLABlock's cv1)
+                w = bn.weight.detach().float().cpu()[c0:c0 + nch].clone().requires_grad_(True) if bn.weight is not None else None
+                b = bn.bias.detach().float().cpu()[c0:c0 + nch].clone().requires_grad_(True) if bn.bias is not None else None
+                params.append((bn, w, b, c0, nch))
                 yb = F.batch_norm(xb, None, None, w, b, True, 0.0, bn.eps)
             else:
                 params.append(None)
@@ -318,7 +323,7 @@ class TrainChain:
         wanted = list(leaves)
         for pr in params:
             if pr is not None:
-                wanted += [t for t in pr[1:] if t is not None]
+                wanted += [t for t in pr[1:3] if t is not None]
         if res_leaf is not None:
             wanted.append(res_leaf)
         if alpha_leaf is not None:
@@ -326,16 +331,22 @@ class TrainChain:
         grads = dict(zip(map(id, wanted), torch.autograd.grad(o, wanted, dout)))
         # zero the parameter-gradient slots this op accumulates into
         items = []
+        def widen(g_, full, c0, nch):      # the op accumulates into channels [c0, c0 + nch) of the parameter's gradient only
+            if nch == full.numel():
+                return g_
+            r = torch.zeros(full.numel())
+            r[c0:c0 + nch] = g_
+            return r
         for pr in params:
             if pr is None:
                 continue
-            bn, w, b = pr
+            bn, w, b, c0, nch = pr
             if w is not None:
                 self._grad_view(bn.weight).zero_()
-                items.append(("dgamma", bn.weight, grads[id(w)]))
+                items.append(("dgamma", bn.weight, widen(grads[id(w)], bn.weight, c0, nch)))
             if b is not None:
                 self._grad_view(bn.bias).zero_()
-                items.append(("dbeta", bn.bias, grads[id(b)]))
+                items.append(("dbeta", bn.bias, widen(grads[id(b)], bn.bias, c0, nch)))
         if alpha_leaf is not None:
             self._grad_view(e["alpha"]).zero_()
             items.append(("dalpha", e["alpha"], grads[id(alpha_leaf)]))
@@ -374,7 +385,9 @@ class TrainChain:
         desc = f"bnact_bwd x{len(leaves)} {e['act']} C={o_.C} {o_.H}x{o_.W}"
         self._cmp("bwd", i, e, desc, pairs, 3e-3, extra=dict(relu_ties_excluded=n_ties))
         if items:
+            self._partial_bn = any(pr is not None and pr[4] != pr[0].weight.numel() for pr in params)
             self._check_param("bwd", i, e, desc + " params", items, 3e-3)
+            self._partial_bn = False
 
     def _dy_compact(self, e):
         dy = self.get(e["dy"]) if "dy" in e else self.get(e["x"])

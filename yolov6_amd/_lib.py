@@ -105,7 +105,14 @@ class LossDesc(C.Structure):
                 ("target_bboxes", C.c_void_p), ("target_scores", C.c_void_p), ("fg_mask", C.c_void_p),
                 ("B", C.c_int32), ("A", C.c_int32), ("C", C.c_int32), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
                 ("iou_type", C.c_int32), ("w_class", C.c_float), ("w_iou", C.c_float), ("w_dfl", C.c_float),
-                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("box_mode", C.c_int32)]
+                ("out", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("box_mode", C.c_int32),
+                ("norm_mode", C.c_int32)]
+
+
+class DistillDesc(C.Structure):
+    _fields_ = [("scores_s", C.c_void_p), ("scores_t", C.c_void_p), ("distri_s", C.c_void_p), ("distri_t", C.c_void_p),
+                ("fg_mask", C.c_void_p), ("target_scores", C.c_void_p), ("BA", C.c_int32), ("C", C.c_int32), ("reg_max", C.c_int32),
+                ("temperature", C.c_float), ("acc", C.c_void_p), ("coef", C.c_void_p), ("dscores", C.c_void_p), ("ddistri", C.c_void_p)]
 
 
 class BnApplyDesc(C.Structure):
@@ -221,6 +228,9 @@ SIGNATURES = {
     "y6_bbox_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_loss_workspace_bytes": (C.c_size_t, []),
     "y6_loss_forward": (C.c_int, [C.POINTER(LossDesc), C.c_void_p]),
+    "y6_distill_forward": (C.c_int, [C.POINTER(DistillDesc), C.c_void_p]),
+    "y6_distill_backward": (C.c_int, [C.POINTER(DistillDesc), C.c_void_p]),
+    "y6_distill_cw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_bn_stats_workspace_bytes": (C.c_size_t, [C.c_int]),
     "y6_bn_stats": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "y6_bn_apply": (C.c_int, [C.POINTER(BnApplyDesc), C.c_void_p]),

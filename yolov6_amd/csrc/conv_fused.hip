@@ -246,10 +246,10 @@ __device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int
         }
     }
     __syncthreads();
-    const int ppr = a.c.Cout >> 3;                       // 16-byte pieces per output row
-    const int npc = a.TH * TW * ppr;
+    const int lpr = 31 - __builtin_clz(a.c.Cout >> 3);    // log2 of the 16-byte pieces per output row (Cout in {64, 128})
+    const int npc = (a.TH * TW) << lpr;
     for (int qq = (int)threadIdx.x; qq < npc; qq += (int)blockDim.x) {
-        const int row = qq / ppr, pc = qq - row * ppr;
+        const int row = qq >> lpr, pc = qq - (row << lpr);
         const int ry = row / TW, rx = row - ry * TW;
         const int oy = oy0 + ry, ox = ox0 + rx;
         if (oy < a.c.Ho && ox < a.c.Wo && !(a.dbg & 4))
@@ -258,18 +258,24 @@ __device__ __forceinline__ void consume(const FusedArgs& a, const char* mid, int
     }
 }
 
-// ---- 1x1 producer + consumer.  KSI: input k-steps (Cin / 16); CM: cout fragments of the 1x1 (Cm / 32); the consumer has CM
-// k-step pairs (Cm / 16 = 2 CM k-steps) and CFT cout fragments; NW waves; tile TH (runtime) x TW.
-template <int KSI, int CM, int CFT, int TW, int NW>
+// ---- 1x1 producer + consumer.  KSI: input k-steps (Cin / 16); CM: cout fragments of the 1x1 (Cm / 32), of which a wave computes
+// PCM per pixel fragment (PCM = CM: every wave owns whole pixel fragments - each input piece is loaded once per block; PCM < CM:
+// CM / PCM waves share a pixel fragment, each with its own cout fragments - what fits the registers at Cm = 128); the consumer has
+// 2 CM k-steps and CFT cout fragments; NW waves; tile TH (runtime) x TW.
+// The input pieces of a pixel fragment are requested TWO fragments ahead (a ring of three register sets): with one fragment
+// ahead the producer ran at HBM latency per fragment - 38 of the 67 us of the 64-channel pair (tools/fused_bench.py probes).
+template <int KSI, int CM, int CFT, int TW, int NW, int PCM>
 __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char mid[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = lane >> 5;
     const int Hm = a.c.H, Wm = a.c.W;
-    // producer role of this wave: one cout fragment of the 1x1, every (NW / CM)-th mid fragment
-    static_assert(NW % CM == 0, "waves per 1x1 cout fragment");
-    const int cfm = wave % CM;
+    static_assert(CM % PCM == 0 && NW % (CM / PCM) == 0, "waves per 1x1 cout-fragment group");
+    constexpr int NGRP = CM / PCM;                     // wave groups along the 1x1's couts
+    const int cfm0 = (wave % NGRP) * PCM;              // first cout fragment of this wave
+    const int fstart = wave / NGRP;
+    constexpr int FS = NW / NGRP;                      // pixel-fragment stride of a wave
     constexpr int nchunk1 = (KSI + 1) / 2;
     const int nmf = a.PLS >> 5;
     // consumer role: two pixel fragments x one cout fragment (host: NW = (TH * TW / 64) * CFT)
@@ -285,57 +291,67 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_pw_s2_kernel(const FusedArgs
         const int my0 = 2 * oy0 - 1, mx0 = 2 * ox0 - 1;
         // ---- produce: mid = act(conv1x1(in) + b1) for the tile's (2 TH + 1) x (2 TW + 1) pixels, zeros outside the image
         // (this wave's 1x1 weight fragments and bias are re-read per tile - L2 hits - so that they do not occupy registers
-        //  during the consumer phase; the laundered pointers keep hipcc from hoisting the loads out of the tile loop)
+        //  during the consumer phase; the laundered offset keeps hipcc from hoisting the loads out of the tile loop)
         unsigned zoff = 0;
         asm volatile("" : "+s"(zoff));
         const __half* w1p = a.w1 + zoff;
         const float* b1p = a.b1 ? a.b1 + zoff : nullptr;
-        h8_t w1[KSI];
+        h8_t w1[PCM][KSI];
+        float bz1[PCM][16];
 #pragma unroll
-        for (int ks = 0; ks < KSI; ++ks)
-            w1[ks] = *reinterpret_cast<const h8_t*>(w1p + ((size_t)(cfm * nchunk1 + (ks >> 1)) * 2 + (ks & 1)) * 512 + lane * 8);
-        float bz1[16];
+        for (int c = 0; c < PCM; ++c) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 t = b1p ? *reinterpret_cast<const float4*>(b1p + cfm * 32 + 8 * g + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bz1[g * 4 + 0] = t.x;
-            bz1[g * 4 + 1] = t.y;
-            bz1[g * 4 + 2] = t.z;
-            bz1[g * 4 + 3] = t.w;
+            for (int ks = 0; ks < KSI; ++ks)
+                w1[c][ks] = *reinterpret_cast<const h8_t*>(w1p + ((size_t)((cfm0 + c) * nchunk1 + (ks >> 1)) * 2 + (ks & 1)) * 512 + lane * 8);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 t = b1p ? *reinterpret_cast<const float4*>(b1p + (cfm0 + c) * 32 + 8 * g + 4 * kh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bz1[c][g * 4 + 0] = t.x;
+                bz1[c][g * 4 + 1] = t.y;
+                bz1[c][g * 4 + 2] = t.z;
+                bz1[c][g * 4 + 3] = t.w;
+            }
         }
-        auto px_addr = [&](int f, bool& valid) -> const __half* {
+        auto issue = [&](int f, h8_t (&x)[KSI], bool& valid) {
             const int slot = f * 32 + (lane & 31);
             int my, mx;
             slot_to_mid(a, slot, my, mx);
             const int gy = my0 + my, gx = mx0 + mx;
             valid = slot < a.nslots && (unsigned)gy < (unsigned)Hm && (unsigned)gx < (unsigned)Wm;
             const size_t pix = valid ? ((size_t)b * Hm + gy) * Wm + gx : (size_t)b * Hm * Wm;   // invalid lanes read a real pixel and drop it
-            return a.in + pix * a.in_cs + a.in_co + kh * 8;
-        };
-        auto px_load = [&](const __half* p, h8_t (&x)[KSI]) {
+            const __half* p = a.in + pix * a.in_cs + a.in_co + kh * 8;
 #pragma unroll
             for (int ks = 0; ks < KSI; ++ks) x[ks] = *reinterpret_cast<const h8_t*>(p + ks * 16);
         };
-        h8_t x0[KSI], x1[KSI];
-        bool v0 = false, v1 = false;
-        int f = wave / CM;
-        if (a.dbg & 1) f = nmf;
-        if (f < nmf) px_load(px_addr(f, v0), x0);
-        while (f < nmf) {
-            const int f1 = f + NW / CM;
-            if (f1 < nmf) px_load(px_addr(f1, v1), x1);       // in flight during this fragment's MFMAs and LDS stores
-            f32x16_t acc;
+        auto work = [&](int f, const h8_t (&x)[KSI], bool valid) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int c = 0; c < PCM; ++c) {
+                f32x16_t acc;
 #pragma unroll
-            for (int ks = 0; ks < KSI; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[ks], x0[ks], acc, 0, 0, 0);
-            float v[16];
-            produce_act16_any(a.act1, acc, bz1, v0, v);
-            mid_store(mid, a.PLS, cfm, f * 32 + (lane & 31), lane, v);
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KSI; ++ks) x0[ks] = x1[ks];
-            v0 = v1;
-            f = f1;
+                for (int ks = 0; ks < KSI; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[c][ks], x[ks], acc, 0, 0, 0);
+                float v[16];
+                produce_act16_any(a.act1, acc, bz1[c], valid, v);
+                mid_store(mid, a.PLS, cfm0 + c, f * 32 + (lane & 31), lane, v);
+            }
+        };
+        h8_t x0[KSI], x1[KSI], x2[KSI];
+        bool v0 = false, v1 = false, v2 = false;
+        int f = (a.dbg & 1) ? nmf : fstart;
+        if (f < nmf) issue(f, x0, v0);
+        if (f + FS < nmf) issue(f + FS, x1, v1);
+        for (; f < nmf; f += 3 * FS) {
+            if (f + 2 * FS < nmf) issue(f + 2 * FS, x2, v2);
+            work(f, x0, v0);
+            if (f + FS < nmf) {
+                if (f + 3 * FS < nmf) issue(f + 3 * FS, x0, v0);
+                work(f + FS, x1, v1);
+            }
+            if (f + 2 * FS < nmf) {
+                if (f + 4 * FS < nmf) issue(f + 4 * FS, x1, v1);
+                work(f + 2 * FS, x2, v2);
+            }
         }
         __syncthreads();
         // ---- consume
@@ -611,8 +627,8 @@ int pw_s2_launch(const y6_pw_s2_desc* d, hipStream_t s) {
     a.PLS = y6_cdiv(a.nslots, 32) * 32;
     const size_t lds = (size_t)(pw.out.C / 8) * a.PLS * 16;
     static KernState st64, st128;
-    if (cfg.ksi == 4) return launch_fused(fused_pw_s2_kernel<4, 2, 2, 16, 4>, a, 256, lds, s, &st64);
-    return launch_fused(fused_pw_s2_kernel<8, 4, 4, 16, 4>, a, 256, lds, s, &st128);
+    if (cfg.ksi == 4) return launch_fused(fused_pw_s2_kernel<4, 2, 2, 16, 4, 2>, a, 256, lds, s, &st64);
+    return launch_fused(fused_pw_s2_kernel<8, 4, 4, 16, 4, 1>, a, 256, lds, s, &st128);
 }
 
 int stem_s2_ok(const y6_stem_s2_desc* d) {

@@ -1108,8 +1108,9 @@ __global__ __launch_bounds__(256) void head_unpack_kernel(const HeadArgs a) {
 }
 
 int fill_head_args(const y6_head_pack_desc* d, HeadArgs* a, bool backward) {
-    Y6_REQUIRE(d && d->n_levels >= 1 && d->n_levels <= 4 && d->scores, "head_pack: bad descriptor");
-    Y6_REQUIRE(backward ? (d->dscores && d->ddistri) : (d->distri != nullptr), "head_pack: null buffer");
+    // nc == 0: a regression-only pack (the plain-distance output of the distillation head, effidehead_distill_ns.py:95-101)
+    Y6_REQUIRE(d && d->n_levels >= 1 && d->n_levels <= 4 && (d->scores || d->nc == 0), "head_pack: bad descriptor");
+    Y6_REQUIRE(backward ? ((d->dscores || d->nc == 0) && d->ddistri) : (d->distri != nullptr), "head_pack: null buffer");
     memset(a, 0, sizeof(*a));
     a->n_levels = d->n_levels;
     a->nc = d->nc;
@@ -1117,8 +1118,8 @@ int fill_head_args(const y6_head_pack_desc* d, HeadArgs* a, bool backward) {
     int A = 0;
     for (int l = 0; l < d->n_levels; ++l) {
         const y6_tensor &c = d->cls[l], &r = d->reg[l];
-        Y6_REQUIRE(c.data && r.data && c.C == d->nc && r.C == d->nreg, "head_pack: level %d channels", l);
-        Y6_REQUIRE(c.B == r.B && c.H == r.H && c.W == r.W && c.B == d->cls[0].B, "head_pack: level %d shape mismatch", l);
+        Y6_REQUIRE(r.data && r.C == d->nreg && (d->nc == 0 || (c.data && c.C == d->nc)), "head_pack: level %d channels", l);
+        Y6_REQUIRE(r.B == d->reg[0].B && (d->nc == 0 || (c.B == r.B && c.H == r.H && c.W == r.W)), "head_pack: level %d shape mismatch", l);
         a->cls[l] = (const __half*)c.data;
         a->reg[l] = (const __half*)r.data;
         a->dcls[l] = (__half*)c.data;
@@ -1127,12 +1128,12 @@ int fill_head_args(const y6_head_pack_desc* d, HeadArgs* a, bool backward) {
         a->cco[l] = c.coff;
         a->rcs[l] = r.cstride;
         a->rco[l] = r.coff;
-        a->hw[l] = c.H * c.W;
+        a->hw[l] = r.H * r.W;
         a->a0[l] = A;
-        A += c.H * c.W;
+        A += r.H * r.W;
     }
     a->a0[d->n_levels] = A;
-    a->B = d->cls[0].B;
+    a->B = d->reg[0].B;
     a->A = A;
     a->scores = d->scores;
     a->distri = d->distri;

@@ -698,14 +698,31 @@ class MBLABlock(HipModule):
         self.split_num = tuple([self.c] * branch_num)
 
     def lower(self, pb, x, out=None):
-        if getattr(pb, "is_train", False):
-            raise NotImplementedError("yolov6_amd: the training graph of MBLABlock is not on the HIP path yet")
         x = pb.as_nhwc(x)
         c = self.c
         if c % 8:
             raise NotImplementedError(f"yolov6_amd: MBLABlock branches of {c} channels (channel slices need a multiple of 8)")
         total = self.cv2.conv.in_channels
         cat = pb.new_buffer(x.B, x.H, x.W, total)
+        if getattr(pb, "is_train", False):
+            # training form (common.py:45-49 for cv1 / cv2): cv1 is ONE conv with ONE BatchNorm over its branch_num * c
+            # channels; BatchNorm + activation are per channel, so each branch's slice of the normalised result is written
+            # straight into its slot of the buffer cv2 reads (statistics and d-gamma / d-beta as channel slices)
+            if not hasattr(self.cv1, "bn") or self.cv1.conv.bias is not None:
+                raise NotImplementedError("yolov6_amd: training needs the un-fused ConvModule (conv without bias + BatchNorm)")
+            y = pb.conv(x, self.cv1.conv.weight, 1)
+            st = pb.bn(y, self.cv1.bn)
+            act = self.cv1._activation_name()
+            pb.bnact([(y.slice(0, c), st.slice(0, c))], act, out=cat.slice(0, c))
+            off = c
+            for bi, seq in enumerate(self.m):
+                prev = pb.bnact([(y.slice((bi + 1) * c, c), st.slice((bi + 1) * c, c))], act, out=cat.slice(off, c))
+                off += c
+                for blk in seq:
+                    prev = blk.lower(pb, prev, out=cat.slice(off, c))
+                    off += c
+            assert off == total
+            return self.cv2.lower(pb, cat, out=out)
         w, b = self.cv1.fused_weight_bias()
         act = self.cv1._activation_name()
 

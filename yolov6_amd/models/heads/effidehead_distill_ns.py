@@ -54,8 +54,24 @@ class Detect(_Detect):
         return False                     # :116-133: boxes come from reg_preds (l, t, r, b), no bin projection
 
     def lower_train(self, tb, x):
-        raise NotImplementedError("yolov6_amd: the training branch of the distillation head (cls, DFL bins and plain distances, "
-                                  "effidehead_distill_ns.py:81-103) is not on the HIP path yet")
+        """Training branch (effidehead_distill_ns.py:81-103): per level stem -> {cls conv, cls_pred}, {reg conv, reg_preds_dist AND
+        reg_preds}; sigmoid on the class logits; levels flattened and concatenated to cls_scores [B,A,nc], reg_distri
+        [B,A,4*(reg_max+1)] and reg_lrtb [B,A,4] (the fourth output loss_distill_ns.py consumes)."""
+        stems, cls_out, dist_out, lrtb_out = [], [], [], []
+        for i in range(self.nl):
+            f = self.stems[i].lower(tb, x[i])
+            stems.append(f)
+            c = self.cls_convs[i].lower(tb, f)
+            r = self.reg_convs[i].lower(tb, f)
+            cp, dp, rp = self.cls_preds[i], self.reg_preds_dist[i], self.reg_preds[i]
+            cls_out.append(tb.conv(c, cp.weight, 1, bias=cp.bias))
+            dist_out.append(tb.conv(r, dp.weight, 1, bias=dp.bias))
+            lrtb_out.append(tb.conv(r, rp.weight, 1, bias=rp.bias))
+            tb.trace.update({f"detect.stem{i}": f, f"detect.cls_conv{i}": c, f"detect.reg_conv{i}": r,
+                             f"detect.cls_logit{i}": cls_out[-1], f"detect.reg_raw{i}": dist_out[-1], f"detect.reg_lrtb{i}": lrtb_out[-1]})
+        scores, distri = tb.head_pack(cls_out, dist_out, self.nc, self.reg_preds_dist[0].out_channels)
+        _, lrtb = tb.head_pack(None, lrtb_out, 0, self.reg_preds[0].out_channels)
+        return stems, (scores, distri, lrtb)
 
 
 def build_effidehead_layer(channels_list, num_anchors, num_classes, reg_max=16):

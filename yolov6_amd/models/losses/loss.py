@@ -100,22 +100,48 @@ class ComputeLoss:
         out[:, :, 1:5] = torch.stack([x1, y1, x1 + box[..., 2], y1 + box[..., 3]], -1)
         return out
 
-    def bbox_decode(self, anchor_points, pred_dist):
+    def bbox_decode(self, anchor_points, pred_dist, use_dfl=None):
         lib = _lib.load()
+        use_dfl = self.use_dfl if use_dfl is None else use_dfl
         pred_dist = pred_dist.detach().float().contiguous()
         _lib.require_gpu_tensor(pred_dist, "pred_dist")
         B, A = pred_dist.shape[:2]
         pts = anchor_points.float().contiguous()
         out = torch.empty((B, A, 4), dtype=torch.float32, device=pred_dist.device)
         _lib.check(lib.y6_bbox_decode(C.c_void_p(pred_dist.data_ptr()), C.c_void_p(pts.data_ptr()), B, A,
-                                      int(self.use_dfl), int(self.reg_max), C.c_void_p(out.data_ptr()),
+                                      int(use_dfl), int(self.reg_max if use_dfl else 0), C.c_void_p(out.data_ptr()),
                                       _lib.current_stream_ptr()), "bbox_decode")
         return out
 
     # ------------------------------------------------------------------ the call
     def __call__(self, outputs, targets, epoch_num, step_num, batch_height, batch_width):
-        lib = _lib.load()
         feats, pred_scores, pred_distri = outputs
+        t = self._forward_terms(feats, pred_scores, pred_distri, targets, epoch_num, batch_height, batch_width)
+        d, res = t["desc"], t["out"].float()
+        ps_in, pd_in = outputs[1], outputs[2]
+        if torch.is_grad_enabled() and (ps_in.requires_grad or pd_in.requires_grad):
+            graph = getattr(ps_in, "_y6_graph", None)
+            dscores = graph.grad_buffer_of(ps_in) if graph is not None else None     # the native backward plan reads these directly
+            ddistri = graph.grad_buffer_of(pd_in) if graph is not None else None
+            if dscores is None or ddistri is None:
+                dscores, ddistri = torch.empty_like(t["pred_scores"]), torch.empty_like(t["pred_distri"])
+            g = _lib.LossGradDesc()
+            g.fwd = d
+            g.dpred_scores, g.dpred_distri = C.c_void_p(dscores.data_ptr()), C.c_void_p(ddistri.data_ptr())
+            holder = dict(desc=g, dscores=dscores, ddistri=ddistri, loss=res[0], keep=t["keep"])
+            return _LossFn.apply(ps_in, pd_in, holder), res[1:4].detach()
+        return res[0], res[1:4].detach()
+
+    def _forward_terms(self, feats, pred_scores, pred_distri, targets, epoch_num, batch_height, batch_width, norm_mode=0,
+                       warmup=True, use_dfl=None, weights=None, assigned=None):
+        """Everything of __call__ up to and including y6_loss_forward: anchors, target packing, box decode, label assignment,
+        the loss terms.  -> dict(desc, out [6] f64 device, the tensors the descriptor points at).  `norm_mode` / `warmup` /
+        `use_dfl` / `weights` / `assigned` (the (labels, boxes, scores, fg) of an earlier call: no second assignment) let the
+        self-distillation losses (loss_distill.py, loss_distill_ns.py) re-use it for their detection terms and for the extra IoU
+        term of the plain-distance branch."""
+        lib = _lib.load()
+        use_dfl = self.use_dfl if use_dfl is None else use_dfl
+        weights = self.loss_weight if weights is None else weights
         _lib.require_gpu_tensor(pred_scores, "pred_scores")
         dev = pred_scores.device
         # only the spatial sizes of `feats` matter (loss.py:63-69); lazily converted training-graph features are not touched
@@ -146,8 +172,10 @@ class ComputeLoss:
             x1y1 = cxy - pred_distri[..., 2:] * 0.5
             pred_bboxes = torch.cat([x1y1, x1y1 + pred_distri[..., 2:]], -1).contiguous()
         else:
-            pred_bboxes = self.bbox_decode(anchor_points_s, pred_distri)
-        if epoch_num < self.warmup_epoch:
+            pred_bboxes = self.bbox_decode(anchor_points_s, pred_distri, use_dfl)
+        if assigned is not None:
+            target_labels, target_bboxes, target_scores, fg_mask = assigned
+        elif warmup and epoch_num < self.warmup_epoch:
             target_labels, target_bboxes, target_scores, fg_mask = self.warmup_assigner(
                 anchors, n_anchors_list, gt_labels, gt_bboxes, mask_gt, pred_bboxes * stride_tensor)
         else:
@@ -171,24 +199,14 @@ class ComputeLoss:
                         ("out", out), ("workspace", ws)):
             setattr(d, name, C.c_void_p(t.data_ptr()))
         d.B, d.A, d.C = B, A, Cn
-        d.use_dfl, d.reg_max, d.iou_type = int(self.use_dfl), int(self.reg_max), _lib.IOU_TYPES[self.iou_type]
-        d.w_class, d.w_iou, d.w_dfl = (float(self.loss_weight[k]) for k in ("class", "iou", "dfl"))
+        d.use_dfl, d.reg_max, d.iou_type = int(use_dfl), int(self.reg_max if use_dfl else 0), _lib.IOU_TYPES[self.iou_type]
+        d.w_class, d.w_iou, d.w_dfl = (float(weights[k]) for k in ("class", "iou", "dfl"))
         d.workspace_bytes = ws.numel()
         d.box_mode = self.box_mode
+        d.norm_mode = int(norm_mode)
         _lib.check(lib.y6_loss_forward(C.byref(d), _lib.current_stream_ptr()), "loss_forward")
-        res = out.float()
-        ps_in, pd_in = outputs[1], outputs[2]
-        if torch.is_grad_enabled() and (ps_in.requires_grad or pd_in.requires_grad):
-            graph = getattr(ps_in, "_y6_graph", None)
-            dscores = graph.grad_buffer_of(ps_in) if graph is not None else None     # the native backward plan reads these directly
-            ddistri = graph.grad_buffer_of(pd_in) if graph is not None else None
-            if dscores is None or ddistri is None:
-                dscores, ddistri = torch.empty_like(pred_scores), torch.empty_like(pred_distri)
-            g = _lib.LossGradDesc()
-            g.fwd = d
-            g.dpred_scores, g.dpred_distri = C.c_void_p(dscores.data_ptr()), C.c_void_p(ddistri.data_ptr())
-            keep = (pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_flat, target_labels, target_bboxes,
-                    target_scores, fg_u8, out, ws)
-            holder = dict(desc=g, dscores=dscores, ddistri=ddistri, loss=res[0], keep=keep)
-            return _LossFn.apply(ps_in, pd_in, holder), res[1:4].detach()
-        return res[0], res[1:4].detach()
+        keep = (pred_scores, pred_distri, pred_bboxes, anchor_points_s, stride_flat, target_labels, target_bboxes,
+                target_scores, fg_u8, out, ws)
+        return dict(desc=d, out=out, keep=keep, pred_scores=pred_scores, pred_distri=pred_distri, pred_bboxes=pred_bboxes,
+                    anchor_points_s=anchor_points_s, target_scores=target_scores, fg=fg_u8, B=B, A=A, C=Cn,
+                    assigned=(target_labels, target_bboxes, target_scores, fg_u8))

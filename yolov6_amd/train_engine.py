@@ -96,6 +96,13 @@ class BnStats:
     shift: torch.Tensor
     mean: torch.Tensor
     invstd: torch.Tensor
+    c0: int = 0               # first channel of the BatchNorm these vectors belong to (channel slices: MBLABlock's cv1)
+
+    def slice(self, c0: int, n: int) -> "BnStats":
+        """The statistics of channels [c0, c0 + n): views of the same vectors (BatchNorm is per channel)."""
+        assert c0 % 4 == 0 and n % 4 == 0, "16-byte aligned statistic slices"
+        return BnStats(self.module, self.scale[c0:c0 + n], self.shift[c0:c0 + n], self.mean[c0:c0 + n], self.invstd[c0:c0 + n],
+                       self.c0 + c0)
 
 
 @dataclass
@@ -382,41 +389,50 @@ class TrainBuilder:
         self.tape.append(lambda: self._convt_backward(x, out, weight, bias))
         return out
 
-    def head_pack(self, cls: List[TRef], reg: List[TRef], nc: int, nreg: int):
-        B = cls[0].B
-        A = sum(c.H * c.W for c in cls)
-        self.scores = torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
-        self.distri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
-        self.dscores = torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
-        self.ddistri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
+    def head_pack(self, cls: Optional[List[TRef]], reg: List[TRef], nc: int, nreg: int):
+        """Detect's training branch tail: per level sigmoid(cls) and reg, flattened and concatenated -> scores [B,A,nc], distri
+        [B,A,nreg] (fp32).  cls None / nc 0: a regression-only pack (the plain-distance output of the distillation head)."""
+        only_reg = cls is None
+        B = reg[0].B
+        A = sum(r.H * r.W for r in reg)
+        scores = None if only_reg else torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
+        dscores = None if only_reg else torch.zeros((B, A, nc), dtype=torch.float32, device=self.device)
+        distri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
+        ddistri = torch.zeros((B, A, nreg), dtype=torch.float32, device=self.device)
+        self.keep += [t for t in (scores, dscores, distri, ddistri) if t is not None]
+        if not only_reg:
+            self.scores, self.distri, self.dscores, self.ddistri = scores, distri, dscores, ddistri
         d = _lib.HeadPackDesc()
-        d.n_levels = len(cls)
-        for i, (c, r) in enumerate(zip(cls, reg)):
-            d.cls[i], d.reg[i] = c.ct(), r.ct()
-        d.scores, d.distri = _ptr(self.scores), _ptr(self.distri)
-        d.nc, d.nreg = nc, nreg
-        self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack", cls=list(cls), reg=list(reg), scores=self.scores,
-                distri=self.distri)
-        self.head_outputs += [(self.scores, self.dscores), (self.distri, self.ddistri)]
+        d.n_levels = len(reg)
+        for i, r in enumerate(reg):
+            d.reg[i] = r.ct()
+            if not only_reg:
+                d.cls[i] = cls[i].ct()
+        d.scores, d.distri = _ptr(scores), _ptr(distri)
+        d.nc, d.nreg = (0 if only_reg else nc), nreg
+        self._f(self.lib.y6_plan_add_head_pack(self.fwd, C.byref(d)), "plan_add_head_pack", cls=[] if only_reg else list(cls), reg=list(reg),
+                scores=scores, distri=distri)
+        self.head_outputs += ([] if only_reg else [(scores, dscores)]) + [(distri, ddistri)]
+        cls_l = [] if only_reg else list(cls)
 
         def bwd():
             g = _lib.HeadPackDesc()
-            g.n_levels = len(cls)
-            for i, (c, r) in enumerate(zip(cls, reg)):
-                for t, slot in ((c, g.cls), (r, g.reg)):
+            g.n_levels = len(reg)
+            for i in range(len(reg)):
+                for t, slot in ([(cls_l[i], g.cls)] if cls_l else []) + [(reg[i], g.reg)]:
                     rec = t._conv
                     cp = _rup(t.C, 8)                       # conv inputs need 8-channel views: pad channels stay zero
                     buf = self.new_buffer(t.B, t.H, t.W, cp, zero=True)
                     rec.dy, rec.dy_dil, rec.cpad = buf, 1, cp
                     slot[i] = TRef(buf.buf, t.B, t.H, t.W, t.C, cp, 0).ct()
-            g.scores = _ptr(self.scores)
-            g.dscores, g.ddistri = _ptr(self.dscores), _ptr(self.ddistri)
-            g.nc, g.nreg = nc, nreg
+            g.scores = _ptr(scores)
+            g.dscores, g.ddistri = _ptr(dscores), _ptr(ddistri)
+            g.nc, g.nreg = (0 if only_reg else nc), nreg
             self._b(self.lib.y6_plan_add_head_unpack_backward(self.bwd, C.byref(g)), "plan_add_head_unpack_backward",
-                    dcls=[c._conv.dy for c in cls], dreg=[r._conv.dy for r in reg], nc=[c.C for c in cls], nreg=[r.C for r in reg],
-                    scores=self.scores, dscores=self.dscores, ddistri=self.ddistri)
+                    dcls=[c._conv.dy for c in cls_l], dreg=[r._conv.dy for r in reg], nc=[c.C for c in cls_l], nreg=[r.C for r in reg],
+                    scores=scores, dscores=dscores, ddistri=ddistri)
         self.tape.append(bwd)
-        return self.scores, self.distri
+        return scores, distri
 
     def head_pack_ab(self, cls: List[TRef], reg: List[TRef], nc: int, na: int, anchors_init: torch.Tensor):
         """Anchor-based auxiliary branch of the fuse_ab head (effidehead_fuseab.py:110-124)."""
@@ -470,11 +486,11 @@ class TrainBuilder:
                 g.mean[i], g.invstd[i] = st.mean.data_ptr(), st.invstd.data_ptr()
                 bn = st.module
                 if bn.weight is not None:
-                    g.gamma[i] = self.arena.data_ptr(bn.weight).value
-                    g.dgamma[i] = self.arena.grad_ptr(bn.weight).value
+                    g.gamma[i] = self.arena.data_ptr(bn.weight).value + 4 * st.c0
+                    g.dgamma[i] = self.arena.grad_ptr(bn.weight).value + 4 * st.c0
                     finals.append(bn.weight)
                 if bn.bias is not None:
-                    g.dbeta[i] = self.arena.grad_ptr(bn.bias).value
+                    g.dbeta[i] = self.arena.grad_ptr(bn.bias).value + 4 * st.c0
                     finals.append(bn.bias)
             rec = getattr(t, "_conv", None)
             if rec is not None:                      # a conv output: its gradient lives in a private buffer

@@ -47,7 +47,7 @@ def synth_tensor(key, shape, dtype, seed=0):
         v = r.normal(0.0, gain / np.sqrt(fan_in), size=shape)
     elif leaf == "weight" and ".rbr_identity." in key:   # identity-branch BatchNorm gamma
         v = r.uniform(0.2, 0.5, size=shape)
-    elif leaf == "weight" and key.rsplit(".", 2)[-2] == "bn" and key.rsplit(".", 3)[-3] not in ("block", "rbr_dense", "rbr_1x1"):
+    elif leaf == "weight" and key.split(".")[-2:-1] == ["bn"] and (key.split(".")[-3:-2] or [""])[0] not in ("block", "rbr_dense", "rbr_1x1"):
         v = r.uniform(0.25, 0.55, size=shape)            # QARepVGG post-BN gamma (raw identity adds variance)
     elif leaf == "weight":  # BatchNorm gamma
         v = r.uniform(0.5, 1.5, size=shape)
