@@ -824,7 +824,8 @@ def test_distill_ns_training_graph_vs_oracle():
     xs_in = x.to(DEV).half()
     with torch.no_grad():
         t_out, t_feats = model(xs_in)
-        t_out = tuple(t.clone() if isinstance(t, torch.Tensor) else t for t in t_out)
+        # a teacher is an ordinary model: (feats, cls_scores, reg_distri) - loss_distill_ns.py:76 takes t_outputs[-2], [-1]
+        t_out = tuple(t.clone() if isinstance(t, torch.Tensor) else t for t in t_out[:3])
     outs, s_feats = model(xs_in.flip(0).contiguous())
     targets = _seam_targets(8)
     targets[:, 1] = targets[:, 1] % nc
@@ -833,6 +834,38 @@ def test_distill_ns_training_graph_vs_oracle():
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and items.shape == (4,) and torch.isfinite(arena.grad).all()
     assert float(named["detect.reg_preds.0.weight"].grad.abs().max()) > 0 and float(named["backbone.stem.rbr_dense.conv.weight"].grad.abs().max()) > 0
+    # ---- channel-wise feature distillation through the graph's gradient inlets: with the head's gradients zeroed, the backbone
+    # still receives the feature term's gradient, and it equals autograd's through the same neck maps
+    g_plain = arena.grad.clone()
+    model2 = build_model(cfg, nc, "cpu", distill_ns=True)
+    model2.load_state_dict(sd)
+    model2.distill_feat = True
+    model2 = model2.to(DEV).train()
+    crit_f = ComputeLoss(num_classes=nc, ori_img_size=192, warmup_epoch=0, use_dfl=h.use_dfl, reg_max=h.reg_max, iou_type=h.iou_type,
+                         distill_feat=True)
+    outs2, s_feats2 = model2(xs_in.flip(0).contiguous())
+    graph2 = outs2[1]._y6_graph
+    assert graph2.feat_inlets is not None and len(graph2.feat_inlets) == 3
+    graph2.arena.zero_grad()
+    t_feats_t = [f.float() * 0.5 + 0.1 for f in s_feats2]                      # a "teacher" with different maps
+    loss_f, items_f = crit_f(outs2, t_out, s_feats2, t_feats_t, targets, 5, 100, 20.0, 1, 192, 192)
+    (loss_f * 64.0).backward()
+    torch.cuda.synchronize()
+    assert float(items_f[3]) > 0 and torch.isfinite(graph2.arena.grad).all()
+    # the inlets hold 64 x d (w_cwd decay d_cw) / d feature map: compare with autograd of the same statement on the same maps
+    import math
+    decay = ((1 - math.cos(5 * math.pi / 100)) / 2) * (0.01 - 1) + 1
+    for inlet, sfm, tfm in zip(graph2.feat_inlets, s_feats2, t_feats_t):
+        sl = sfm.float().clone().requires_grad_(True)
+        N_, C_, H_, W_ = sl.shape
+        ref = torch.nn.functional.kl_div(torch.log_softmax(sl.view(N_, C_, -1), 2), torch.log_softmax(tfm.view(N_, C_, -1), 2), reduction="sum",
+                                         log_target=True) / (N_ * C_)
+        (ref * 10.0 * decay * 64.0).backward()
+        got = inlet.to_nhwc_tensor().permute(0, 3, 1, 2).float()
+        den = float(sl.grad.abs().max())
+        assert float((got - sl.grad).abs().max()) <= 2e-3 * den + 1e-6, "gradient inlet of a neck map"
+    dd = (graph2.arena.grad - g_plain).abs().max()
+    assert float(dd) > 0
 
 
 # ------------------------------------------------------------------ the reference trainer's step on the HIP model (seam)

@@ -15,7 +15,8 @@ The sums come from kernels; the handful of scalar operations that combine them r
 `loss.backward()` writes d loss / d pred_scores and d loss / d pred_distri into the training graph's head-gradient buffers
 like loss.py's mirror does.  The teacher's outputs are plain tensors (the reference computes them under torch.no_grad(),
 core/engine.py:153-156).  Channel-wise feature distillation returns its gradient through autograd when the student feature
-maps are autograd leaves; feature maps that come out of the native training graph have no gradient inlet yet (NotImplementedError).
+maps are autograd leaves; for the feature maps of the native training graph it is written into the graph's gradient inlets
+(`model.distill_feat = True` before the first training forward: train_engine.TrainBuilder.grad_inlet).
 """
 import ctypes as C
 import math
@@ -55,12 +56,15 @@ class _DistillFn(torch.autograd.Function):
         d.coef = C.c_void_p(coef.data_ptr())
         d.dscores, d.ddistri = C.c_void_p(h["dscores"].data_ptr()), C.c_void_p(h["ddistri"].data_ptr())
         _lib.check(lib.y6_distill_backward(C.byref(d), stream), "distill_backward")      # adds the distillation terms
-        for (sf, tf, rows, hw, k) in h["cw"]:
+        for i, (sf, tf, rows, hw, k) in enumerate(h["cw"]):
             ck = (k * gs).float().contiguous()
             dsf = torch.empty_like(sf)
             _lib.check(lib.y6_distill_cw(C.c_void_p(sf.data_ptr()), C.c_void_p(tf.data_ptr()), rows, hw, 1.0, None,
                                          C.c_void_p(ck.data_ptr()), C.c_void_p(dsf.data_ptr()), stream), "distill_cw")
-            grads.append(dsf)
+            if h.get("inlets") is not None:          # the native training graph: its backward plan starts from these buffers
+                h["inlets"][i].to_nhwc_tensor().copy_(dsf.permute(0, 2, 3, 1))
+            else:
+                grads.append(dsf)
         h["keep_bwd"] = (gs, coef)
         out = [None] + [gr.to(dt) for gr, dt in zip(grads, ctx.dtypes)]
         return tuple(out + [None] * (1 + len(ctx.dtypes) - len(out)))
@@ -90,6 +94,9 @@ class ComputeLoss(_ComputeLoss):
             feats, pred_scores, pred_distri = outputs
             pred_lrtb = None
         t_pred_scores, t_pred_distri = t_outputs[-2], t_outputs[-1]
+        if tuple(t_pred_scores.shape) != tuple(pred_scores.shape) or (self.use_dfl and tuple(t_pred_distri.shape) != tuple(pred_distri.shape)):
+            raise RuntimeError(f"yolov6_amd: teacher outputs {tuple(t_pred_scores.shape)} / {tuple(t_pred_distri.shape)} do not match the "
+                               f"student's {tuple(pred_scores.shape)} / {tuple(pred_distri.shape)} (t_outputs = (feats, cls_scores, reg_distri))")
         w = self.loss_weight
         t = self._forward_terms(feats, pred_scores, pred_distri, targets, epoch_num, batch_height, batch_width, norm_mode=1,
                                 warmup=self.use_warmup)
@@ -146,9 +153,13 @@ class ComputeLoss(_ComputeLoss):
         items = torch.stack([iou_w, dfl_all, cls_all, cw_w]).float().detach()
         leaves = [outputs[1], outputs[2]] + ([pred_lrtb] if pred_lrtb is not None else [])
         feat_leaves = [sf for sf in s_featmaps if isinstance(sf, torch.Tensor) and sf.requires_grad] if self.distill_feat else []
+        inlets = None
         if self.distill_feat and not feat_leaves and torch.is_grad_enabled() and any(x.requires_grad for x in leaves):
-            raise NotImplementedError("yolov6_amd: the native training graph has no gradient inlet for its neck feature maps yet: "
-                                      "channel-wise feature distillation (distill_feat=True) cannot be back-propagated")
+            fg_ = getattr(s_featmaps, "_y6_graph", None)
+            inlets = getattr(fg_, "feat_inlets", None)
+            if inlets is None:
+                raise NotImplementedError("yolov6_amd: channel-wise feature distillation needs gradient inlets on the neck feature maps: "
+                                          "set `model.distill_feat = True` before the model's first training forward")
         if not (torch.is_grad_enabled() and any(x.requires_grad for x in leaves + feat_leaves)):
             return loss, items
         ps_in, pd_in = outputs[1], outputs[2]
@@ -164,7 +175,7 @@ class ComputeLoss(_ComputeLoss):
                       # d loss / d acc[0], d loss / d acc[1] (device scalars; the incoming gradient is multiplied in at backward time)
                       coef=torch.stack([torch.full((), float(w['class']) * dwc * decay * T2, dtype=torch.float64, device=dev),
                                         float(w['dfl']) * dwd * decay * per_sum]),
-                      cw=cw_items if feat_leaves else [])
+                      cw=cw_items if (feat_leaves or inlets is not None) else [], inlets=inlets)
         if t2 is not None:
             dlrtb = gb(pred_lrtb)
             if dlrtb is None:

@@ -370,6 +370,21 @@ class TrainBuilder:
         self.tape.append(bwd)
         return out
 
+    def grad_inlet(self, t: TRef) -> TRef:
+        """An external gradient source for activation `t` (the neck feature maps under channel-wise feature distillation,
+        loss_distill.py:222-246): returns a zero-initialised NHWC fp16 buffer; the backward plan STARTS by copying it into the
+        gradient of `t` (call this after every forward consumer of `t` has been lowered), so whoever fills it before
+        `loss.backward()` reaches the native plan adds that gradient."""
+        ext = self.new_buffer(t.B, t.H, t.W, t.C, zero=True)
+
+        def bwd():
+            gx = self.grad(t)
+            acc = self.grad_mode(gx)
+            ca, cb = ext.ct(), gx.ct()
+            self._b(self.lib.y6_plan_add_tensor_add(self.bwd, C.byref(ca), C.byref(cb), acc), "plan_add_tensor_add", x=ext, out=gx, acc=int(acc))
+        self.tape.append(bwd)
+        return ext
+
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
         cts = [t.ct() for t in (x, y1, y2, y3)]
         self._f(self.lib.y6_plan_add_sppf(self.fwd, *[C.byref(c) for c in cts]), "plan_add_sppf", x=x, outs=[y1, y2, y3])
@@ -726,6 +741,9 @@ class TrainGraph:
         self.input = torch.empty_like(x, memory_format=torch.contiguous_format).copy_(x)
         tb = TrainBuilder(x.device, arena)
         stems, necks, heads = model.lower_train(tb, NCHWInput(self.input))
+        # channel-wise feature distillation (`model.distill_feat = True` before the first training forward): gradient inlets
+        # on the neck feature maps, filled by loss_distill.ComputeLoss
+        self.feat_inlets = [tb.grad_inlet(r) for r in necks] if getattr(model, "distill_feat", False) else None
         self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
         self.tb = tb
         self.stem_refs, self.neck_refs = stems, necks
@@ -887,4 +905,6 @@ def train_forward(model, x):
     for t in outs:
         t._y6_graph = g                      # lets ComputeLoss write its gradients straight into the graph's buffers
     # base head: (feats, cls_scores, reg_distri); fuse_ab head: (feats, cls_ab, reg_ab, cls_af, reg_af) - effidehead_fuseab.py:139
-    return [(_LazyNCHW(g.stem_refs, x.dtype),) + tuple(outs), _LazyNCHW(g.neck_refs, x.dtype)]
+    necks = _LazyNCHW(g.neck_refs, x.dtype)
+    necks._y6_graph = g                      # channel-wise feature distillation finds the graph's gradient inlets here
+    return [(_LazyNCHW(g.stem_refs, x.dtype),) + tuple(outs), necks]
