@@ -487,6 +487,8 @@ typedef struct y6_bn_train_desc {
     float* invstd;
     void* workspace;               /* y6_bn_stats_workspace_bytes(C) */
     size_t workspace_bytes;
+    int32_t workspace_clean;       /* nonzero: the workspace is all-zero on entry (allocated zeroed, used by these calls only - they
+                                      leave it zeroed); no memset launch.  0: a memset is issued first. */
 } y6_bn_train_desc;
 int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream);
 
@@ -529,6 +531,7 @@ typedef struct y6_bnact_bwd_desc {
     float* dalpha;                 /* += ; NULL: skip */
     void* workspace;               /* y6_bnact_bwd_workspace_bytes(C) */
     size_t workspace_bytes;
+    int32_t workspace_clean;       /* as in y6_bn_train_desc: all-zero on entry, left all-zero */
 } y6_bnact_bwd_desc;
 size_t y6_bnact_bwd_workspace_bytes(int C);
 int y6_bnact_backward(const y6_bnact_bwd_desc* d, void* stream);

@@ -124,7 +124,7 @@ class BnTrainDesc(C.Structure):
     _fields_ = [("x", Tensor), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("workspace_clean", C.c_int32)]
 
 
 class BnActDesc(C.Structure):
@@ -136,7 +136,7 @@ class BnActBwdDesc(C.Structure):
     _fields_ = [("fwd", BnActDesc), ("mean", C.c_void_p * 3), ("invstd", C.c_void_p * 3), ("gamma", C.c_void_p * 3),
                 ("dout", Tensor), ("dx", Tensor * 3), ("dx_dil", C.c_int32 * 3), ("dx_acc", C.c_int32 * 3),
                 ("dgamma", C.c_void_p * 3), ("dbeta", C.c_void_p * 3), ("dres", Tensor), ("dres_acc", C.c_int32),
-                ("dalpha", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("dalpha", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("workspace_clean", C.c_int32)]
 
 
 class WgradTDesc(C.Structure):

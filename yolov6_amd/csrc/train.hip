@@ -51,6 +51,27 @@ __device__ __forceinline__ void loadf8(const float* p, float (&v)[8], float dflt
 }
 
 // ------------------------------------------------------------------ batch statistics (forward)
+// The constants of one channel from its sums (torch.nn.BatchNorm2d training semantics).
+__device__ __forceinline__ void bn_finalize_channel(int c, double sum, double sumsq, double n, const y6_bn_train_desc& d) {
+    const double m = sum / n;
+    double v = sumsq / n - m * m;
+    v = v > 0.0 ? v : 0.0;
+    const float mean = (float)m, var = (float)v;
+    const float invstd = 1.f / sqrtf(var + d.eps);
+    const float g = d.gamma ? d.gamma[c] : 1.f, b = d.beta ? d.beta[c] : 0.f;
+    const float scale = g * invstd;
+    d.scale[c] = scale;
+    d.shift[c] = b - mean * scale;
+    d.mean[c] = mean;
+    d.invstd[c] = invstd;
+    if (d.running_mean) {
+        const float mo = d.momentum;
+        const float unb = (float)(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+        d.running_mean[c] = (1.f - mo) * d.running_mean[c] + mo * mean;
+        d.running_var[c] = (1.f - mo) * d.running_var[c] + mo * unb;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_sum_kernel(const __half* __restrict__ x, int cs, int co, long npix, int G,
                                                      long pix_per_block, double* __restrict__ ws, int C) {
     extern __shared__ double s_acc[];   // [2*C]
@@ -100,27 +121,18 @@ __global__ __launch_bounds__(256) void bn_sum_kernel(const __half* __restrict__ 
     for (int i = tid; i < 2 * C; i += 256) atomicAdd(&ws[i], s_acc[i]);
 }
 
-__global__ void bn_train_finalize_kernel(const double* __restrict__ ws, int C, double n, const y6_bn_train_desc d) {
+// Turns the sums into the BatchNorm constants and leaves the workspace zeroed again: a caller whose workspace starts zeroed
+// (`workspace_clean`) never needs a memset launch (profiles/r03/rocprofv3_kernel_stats_train_r03c.csv: 279 of them per training
+// step, ~4.6 us each).  Folding this kernel into the last block of the sums (device-scope ticket + __threadfence) was measured
+// and lost: the agent-scope release / acquire is an L2 write-back + invalidate per block on gfx950 (bn_stats 4.07 -> 5.88 ms,
+// bnact_bwd 8.94 -> 10.33 ms per step, profiles/r03/bench_train_r03l_{old,new}.json).
+__global__ void bn_train_finalize_kernel(double* __restrict__ ws, int C, double n, const y6_bn_train_desc d) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && d.num_batches_tracked) *d.num_batches_tracked += 1;
     if (c >= C) return;
-    const double m = ws[c] / n;
-    double v = ws[C + c] / n - m * m;
-    v = v > 0.0 ? v : 0.0;
-    const float mean = (float)m, var = (float)v;
-    const float invstd = 1.f / sqrtf(var + d.eps);
-    const float g = d.gamma ? d.gamma[c] : 1.f, b = d.beta ? d.beta[c] : 0.f;
-    const float scale = g * invstd;
-    d.scale[c] = scale;
-    d.shift[c] = b - mean * scale;
-    d.mean[c] = mean;
-    d.invstd[c] = invstd;
-    if (d.running_mean) {
-        const float mo = d.momentum;
-        const float unb = (float)(v * (n / (n > 1.0 ? n - 1.0 : 1.0)));
-        d.running_mean[c] = (1.f - mo) * d.running_mean[c] + mo * mean;
-        d.running_var[c] = (1.f - mo) * d.running_var[c] + mo * unb;
-    }
+    bn_finalize_channel(c, ws[c], ws[C + c], n, d);
+    ws[c] = 0.0;
+    ws[C + c] = 0.0;
 }
 
 int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
@@ -128,11 +140,13 @@ int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
     Y6_REQUIRE(view_ok(d->x), "bn_train_stats: the view must be fp16 NHWC with 8-channel alignment");
     const int C = d->x.C, G = C / 8;
     Y6_REQUIRE(C <= 2048, "bn_train_stats: at most 2048 channels");
-    Y6_REQUIRE(d->workspace_bytes >= (size_t)2 * C * sizeof(double), "bn_train_stats: workspace too small");
+    Y6_REQUIRE(d->workspace_bytes >= y6_bn_stats_workspace_bytes(C), "bn_train_stats: workspace too small");
     const long npix = (long)d->x.B * d->x.H * d->x.W;
     Y6_REQUIRE(npix > 0, "bn_train_stats: empty tensor");
     double* ws = (double*)d->workspace;
-    Y6_HIP(hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), s));
+    // the workspace must be all-zero when the sums start; the finalize kernel leaves it so.  A caller that allocated it zeroed
+    // and uses it for nothing else says so (workspace_clean) and the memset launch is dropped.
+    if (!d->workspace_clean) Y6_HIP(hipMemsetAsync(ws, 0, y6_bn_stats_workspace_bytes(C), s));
     const int R = 256 / G;
     long ppb = (long)R * 64;
     long blocks = (npix + ppb - 1) / ppb;
@@ -479,6 +493,12 @@ __global__ __launch_bounds__(256) void bnact_bwd_apply_kernel(const BnActBwdArgs
 // thread: 30-55 KB per CU, 2.1 TB/s measured (profiles/r03/bench_train_r03c.json: bnact_bwd 14.0 of the 57 ms step, the
 // largest single item).  Here a thread has 5-8 loads of 16 bytes in flight (reduce: two pixels) at 4-5 waves per SIMD.
 // Taken when 256 % (C / 8) == 0 and every view is 16-byte aligned (every BatchNorm of the N / S / L graphs).
+// dgamma / dbeta of branch b, channel c, from the finished sums
+__device__ __forceinline__ void bwd_param_grads(const BnActBwdArgs& a, int b, int c, double s0, double sb) {
+    if (a.dgamma[b]) a.dgamma[b][c] += (float)((sb - (double)a.mean[b][c] * s0) * (double)a.invstd[b][c]);
+    if (a.dbeta[b]) a.dbeta[b][c] += (float)s0;
+}
+
 __device__ __forceinline__ void unpack8(const uint4& raw, float (&v)[8]) {
     const __half* h = reinterpret_cast<const __half*>(&raw);
 #pragma unroll
@@ -672,17 +692,22 @@ __global__ __launch_bounds__(256, 4) void bnact_bwd_apply8_kernel(const BnActBwd
     }
 }
 
+// runs after the apply pass: parameter gradients, then the workspace is zeroed for the next launch on it (see
+// bn_train_finalize_kernel)
 __global__ void bnact_bwd_params_kernel(const BnActBwdArgs a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     const int C = a.f.C;
-    if (c == 0 && a.dalpha) *a.dalpha += (float)a.ws[(1 + a.f.n) * C];
-    if (c >= C) return;
-    for (int b = 0; b < a.f.n; ++b) {
-        if (!a.mean[b]) continue;
-        const double s0 = a.ws[c], sb = a.ws[(1 + b) * C + c];
-        if (a.dgamma[b]) a.dgamma[b][c] += (float)((sb - (double)a.mean[b][c] * s0) * (double)a.invstd[b][c]);
-        if (a.dbeta[b]) a.dbeta[b][c] += (float)s0;
+    if (c == 0) {
+        if (a.dalpha) *a.dalpha += (float)a.ws[(1 + a.f.n) * C];
+        a.ws[(1 + a.f.n) * C] = 0.0;
     }
+    if (c >= C) return;
+    const double s0 = a.ws[c];
+    for (int b = 0; b < a.f.n; ++b) {
+        if (a.mean[b]) bwd_param_grads(a, b, c, s0, a.ws[(1 + b) * C + c]);
+        a.ws[(1 + b) * C + c] = 0.0;
+    }
+    a.ws[c] = 0.0;
 }
 
 int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
@@ -736,7 +761,7 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     a.dalpha = (a.f.res && d->dalpha) ? d->dalpha : nullptr;
     a.ws = (double*)d->workspace;
     const size_t nacc = (size_t)(1 + n) * C + 1;
-    Y6_HIP(hipMemsetAsync(a.ws, 0, nacc * sizeof(double), s));
+    if (!d->workspace_clean) Y6_HIP(hipMemsetAsync(a.ws, 0, nacc * sizeof(double), s));
     const int G = C / 8;
     // v2 (8 channels per thread, 16-byte accesses): every view 16-byte aligned, a thread keeps one channel group
     static const bool no_v2 = getenv("Y6_BNACT_BWD_V1") != nullptr;      // A/B switch

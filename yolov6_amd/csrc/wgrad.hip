@@ -22,6 +22,8 @@
 //    slice of the (image, row) range;
 //    each slice stores its partial tile to a workspace and a small second kernel sums the slices into the OIHW
 //    gradient array (+=; zeroed once per step by the caller) - deterministic, no atomics.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "plan_internal.hpp"
 
@@ -330,7 +332,9 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     const int T = d->mode == Y6_WG_1X1 ? 1 : (d->mode == Y6_WG_CONVT ? 4 : 9);
     const long total_rows = (long)d->B * d->rows;
     const long tiles = (long)a.mtiles * a.ntiles * ng;
-    long nsplit = (8192 + tiles - 1) / tiles;        // ~8 waves per SIMD of work items over the chip (4 resident)
+    // ~8 waves per SIMD of work items over the chip (4 resident); 4096 / 16384 items measured the same step time
+    // (profiles/r03/bench_train_r03l_items{4k,16k}.json)
+    long nsplit = (8192 + tiles - 1) / tiles;
     // ... but a slice should hold >= ~256 MFMAs (its fixed costs: pointer set-up, first-load latency per row, the partial tile)
     const long mfma_per_row = (long)(d->Q / 16) * (T / ng);
     const long max_by_work = (total_rows * mfma_per_row + 255) / 256;

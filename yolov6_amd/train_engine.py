@@ -16,6 +16,7 @@ Per conv the backward emits (see yolov6_amd/csrc/wgrad.hip, train.hip):
                       output gradient, which the BatchNorm backward writes directly in dilated form)
     weight gradient   channel-major transposes of x and dy + the tap-table MFMA GEMM, fp32 atomics into the arena
 """
+import os
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -149,6 +150,9 @@ class TrainBuilder:
         # per-op replay of tests/train_replay.py walks these (test infrastructure only; nothing in the step reads them)
         self.fwd_log: List[dict] = []
         self.bwd_log: List[dict] = []
+        self.convs: List[ConvRec] = []     # every conv of the forward (the backward shares wgrad operand planes between them)
+        self.planes = {}                   # (view key, sy, sx, oy, ox, R, Q, C) -> transposed copy already in the backward plan
+        self.share_planes = os.environ.get("Y6_NO_SHARED_PLANES") is None
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -275,6 +279,7 @@ class TrainBuilder:
             self._conv_op(self.fwd, x, y, packed, K, stride, bias_ptr=bptr, log=dict(role="fwd", weight=weight, bias=bias))
         rec = ConvRec(x, y, weight, bias, K, stride)
         y._conv = rec
+        self.convs.append(rec)
         self.tape.append(lambda: self._conv_backward(rec))
         return y
 
@@ -327,6 +332,7 @@ class TrainBuilder:
         d.eps = float(bn.eps)
         d.scale, d.shift, d.mean, d.invstd = (_ptr(t) for t in (st.scale, st.shift, st.mean, st.invstd))
         d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
+        d.workspace_clean = 1          # bytes_() hands out zeroed memory and nothing else touches it: one launch per BatchNorm
         self._f(self.lib.y6_plan_add_bn_train_stats(self.fwd, C.byref(d)), "plan_add_bn_train_stats", x=y, bn=bn, stats=st)
         return st
 
@@ -541,12 +547,20 @@ class TrainBuilder:
                 finals.append(alpha)
         ws = self.bytes_(int(self.lib.y6_bnact_bwd_workspace_bytes(out.C)))
         g.workspace, g.workspace_bytes = _ptr(ws), ws.numel()
+        g.workspace_clean = 1
         self._b(self.lib.y6_plan_add_bnact_backward(self.bwd, C.byref(g)), "plan_add_bnact_backward", branches=list(branches),
                 act=[k for k, v in ACT_BY_NAME.items() if v == fwd_desc.act][0], out=out, res=res, alpha=alpha, dout=gout, dx=dx_log, dres=dres_log)
         self.bwd_marks.append((self.n_bwd_ops, finals))
 
     def _transpose(self, view: Optional[TRef], sy, sx, oy, ox, R, Q, Cn, B, nchw_t=None) -> torch.Tensor:
-        """Channel-major sampling dst[c][b][r][q] = src(b, r*sy+oy, q*sx+ox, c) into a private fp16 buffer."""
+        """Channel-major sampling dst[c][b][r][q] = src(b, r*sy+oy, q*sx+ox, c) into a private fp16 buffer.  A plane that an
+        earlier conv of the backward already made of the same view (RepVGG's 3x3 and 1x1 branch read one x; the head's cls and
+        reg convs one stem output) is handed out again: activations do not change during the backward."""
+        key = None
+        if nchw_t is None and self.share_planes:
+            key = (view.buf.data_ptr(), view.B, view.H, view.W, view.C, view.cstride, view.coff, sy, sx, oy, ox, R, Q, Cn)
+            if key in self.planes:
+                return self.planes[key]
         dst = torch.empty(Cn * B * R * Q, dtype=torch.float16, device=self.device)
         self.keep.append(dst)
         d = _lib.WgradTDesc()
@@ -560,7 +574,22 @@ class TrainBuilder:
         d.sy, d.sx, d.oy, d.ox, d.R, d.Q = sy, sx, oy, ox, R, Q
         d.dst = dst.data_ptr()
         self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose", aux=True)
+        if key is not None:
+            self.planes[key] = dst
         return dst
+
+    def _reads_same(self, rec: ConvRec, k: int, stride: int) -> bool:
+        """Does another conv (k, stride) of the forward read exactly the view rec.x?"""
+        x = rec.x
+        if isinstance(x, NCHWInput):
+            return False
+        for o in self.convs:
+            if o is rec or o.k != k or o.stride != stride or isinstance(o.x, NCHWInput):
+                continue
+            ox = o.x
+            if (ox.buf.data_ptr(), ox.B, ox.H, ox.W, ox.C, ox.cstride, ox.coff) == (x.buf.data_ptr(), x.B, x.H, x.W, x.C, x.cstride, x.coff):
+                return True
+        return False
 
     def _wgrad(self, mode, a, planes, M, N, B, Q, rows, T, out_ptr, flops, a_ch=None, b_ch=None, log=None):
         w = _lib.WgradDesc()
@@ -602,7 +631,11 @@ class TrainBuilder:
             planes = [(p, Ho + 2, ky) for ky in range(3)]
         elif s == 1 and K == 1:
             mode = _lib.WG_1X1
-            planes = [(self._transpose(xv, 1, 1, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
+            if self.share_planes and self._reads_same(rec, 3, 1):
+                # a 3x3 stride-1 conv reads the same view: its plane (one zero row above and below) serves with a row offset
+                planes = [(self._transpose(xv, 1, 1, -1, 0, Ho + 2, Q, Cin, B, xt), Ho + 2, 1)]
+            else:
+                planes = [(self._transpose(xv, 1, 1, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
         elif s == 2 and K == 3:
             mode = _lib.WG_3X3S2
             pe = [self._transpose(xv, 2, 2, 0, cp, Ho, Q, Cin, B, xt) for cp in (0, 1)]          # even rows  x[2r][2q+cp]
