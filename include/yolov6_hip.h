@@ -572,6 +572,26 @@ typedef struct y6_wgrad_desc {
 } y6_wgrad_desc;
 int y6_wgrad(const y6_wgrad_desc* d, void* stream);
 
+/* The same weight gradient for 3x3 stride-1 (pad 1) and 1x1 stride-1 convs read STRAIGHT from the NHWC tensors - no
+ * y6_wgrad_transpose copies: rows arrive in LDS by DMA and leave it through gfx950's transposing LDS read
+ * (ds_read_b64_tr_b16) as the MFMA's pixel-major operands.
+ *   out[m*sm + n*sn + t*st] += sum_{b,y,x} dy(b,y,x,m) * x(b, y+ky-1, x+kx-1, n),  t = ky*3 + kx   (1x1: t = 0, no offsets)
+ * dy may be wider than M (8-channel padded prediction-conv gradients): channels M.. of the view must then be zero.
+ * y6_wgrad_nhwc_supported: 1 when the shapes fit (W <= 208 for 3x3, <= 320 for 1x1; 8-channel aligned fp16 views). */
+typedef struct y6_wgrad_nhwc_desc {
+    int32_t ksize;                 /* 3 or 1 */
+    y6_tensor dy;                  /* [B, H, W, >= M] */
+    y6_tensor x;                   /* [B, H, W, >= N] */
+    int32_t M, N;
+    float* out;
+    int32_t sm, sn, st;
+    double flops;
+    void* workspace;               /* as y6_wgrad_desc */
+    size_t workspace_bytes;
+} y6_wgrad_nhwc_desc;
+int y6_wgrad_nhwc_supported(const y6_wgrad_nhwc_desc* d);
+int y6_wgrad_nhwc(const y6_wgrad_nhwc_desc* d, void* stream);
+
 /* Per-step weight preparation: every packed fp16 MFMA weight image the step's convs read is rebuilt from the fp32
  * master parameters by ONE launch over a device job table.
  *   kind 0: forward conv    dst = pack(W[Cout][Cin][K][K])
@@ -688,6 +708,7 @@ int y6_plan_add_bnact_forward(y6_plan* p, const y6_bnact_desc* d);
 int y6_plan_add_bnact_backward(y6_plan* p, const y6_bnact_bwd_desc* d);
 int y6_plan_add_wgrad_transpose(y6_plan* p, const y6_wgrad_t_desc* d);
 int y6_plan_add_wgrad(y6_plan* p, const y6_wgrad_desc* d);
+int y6_plan_add_wgrad_nhwc(y6_plan* p, const y6_wgrad_nhwc_desc* d);
 int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d);
 int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
 int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);

@@ -121,6 +121,57 @@ def test_wgrad_3x3_s1_and_1x1(cin, cout, B, H, W):
     assert float((got1 - ref1).abs().max()) <= 1e-3 * float(ref1.abs().max())
 
 
+def _wgrad_nhwc(ksize, dyv: TRef, xv: TRef, M, N):
+    lib = _lib.load()
+    T = ksize * ksize
+    out = torch.zeros(M * N * T, dtype=torch.float32, device=DEV)
+    w = _lib.WgradNhwcDesc()
+    w.ksize, w.dy, w.x, w.M, w.N = ksize, dyv.ct(), xv.ct(), M, N
+    w.out = out.data_ptr()
+    w.sm, w.sn, w.st = N * T, T, 1
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    w.workspace, w.workspace_bytes = ws.data_ptr(), ws.numel()
+    assert lib.y6_wgrad_nhwc_supported(C.byref(w)) == 1
+    _lib.check(lib.y6_wgrad_nhwc(C.byref(w), _stream()), "wgrad_nhwc")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("cin,cout,B,H,W", [(16, 24, 3, 13, 17), (64, 64, 2, 20, 20), (40, 80, 2, 9, 33), (128, 32, 1, 40, 40),
+                                            (64, 64, 3, 37, 160), (256, 128, 5, 20, 20), (32, 96, 2, 7, 80), (64, 68, 2, 11, 40)])
+def test_wgrad_nhwc_3x3_s1_and_1x1(cin, cout, B, H, W):
+    """The NHWC-fed weight gradient (LDS-DMA rows + ds_read_b64_tr_b16, csrc/wgrad.hip) against torch's conv2d_weight: ragged
+    widths (pad columns must read as zeros), several images per slice (the x row ring crosses image borders), channel counts
+    that are not multiples of the 32-channel chunk / the 64-channel block tile, and - last case - an 8-channel padded dy view
+    (68 -> 72, zero pad channels) as the prediction convs' gradients are stored."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = (torch.rand((B, cin, H, W), generator=g) - 0.5).half().float()
+    dy = (torch.rand((B, cout, H, W), generator=g) - 0.5).half().float()
+    cpad = _rup(cout, 8)
+    dyp = torch.zeros((B, cpad, H, W))
+    dyp[:, :cout] = dy
+    # both operands as channel slices of wider buffers (concat slots): cstride > C, coff > 0
+    xbuf = torch.full((B, H, W, cin + 16), float("nan"), dtype=torch.float16, device=DEV)
+    xbuf[..., 8:8 + cin] = x.permute(0, 2, 3, 1).to(DEV).half()
+    xv = TRef(xbuf, B, H, W, cin, cin + 16, 8)
+    dbuf = torch.full((B, H, W, cpad + 8), float("nan"), dtype=torch.float16, device=DEV)
+    dbuf[..., :cpad] = dyp.permute(0, 2, 3, 1).to(DEV).half()
+    dyv = TRef(dbuf, B, H, W, cpad, cpad + 8, 0)
+    got3 = _wgrad_nhwc(3, dyv, xv, cout, cin).view(cout, cin, 3, 3)
+    ref3 = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, stride=1, padding=1)
+    err3 = float((got3 - ref3).abs().max()) / float(ref3.abs().max())
+    got1 = _wgrad_nhwc(1, dyv, xv, cout, cin).view(cout, cin, 1, 1)
+    ref1 = torch.nn.grad.conv2d_weight(x, (cout, cin, 1, 1), dy, stride=1, padding=0)
+    err1 = float((got1 - ref1).abs().max()) / float(ref1.abs().max())
+    print(f"wgrad_nhwc {cin}->{cout} b{B} {H}x{W}: 3x3 {err3:.2e}  1x1 {err1:.2e}")
+    if err3 > 1e-3:      # which taps are off (transpose / shift errors show as whole taps)
+        per_tap = (got3 - ref3).abs().amax(dim=(0, 1)) / float(ref3.abs().max())
+        print("per-tap error:", per_tap)
+    assert err3 <= 1e-3 and err1 <= 1e-3
+    # deterministic: slices are summed in a fixed order
+    assert torch.equal(_wgrad_nhwc(3, dyv, xv, cout, cin), got3.reshape(-1))
+
+
 @pytest.mark.parametrize("cin,cout,B,H,W", [(16, 32, 2, 12, 20), (32, 64, 3, 16, 16), (3, 16, 2, 24, 40)])
 def test_wgrad_stride2(cin, cout, B, H, W):
     g = torch.Generator().manual_seed(7 + cin)

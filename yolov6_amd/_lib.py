@@ -152,6 +152,12 @@ class WgradDesc(C.Structure):
                 ("flops", C.c_double), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class WgradNhwcDesc(C.Structure):
+    _fields_ = [("ksize", C.c_int32), ("dy", Tensor), ("x", Tensor), ("M", C.c_int32), ("N", C.c_int32), ("out", C.c_void_p),
+                ("sm", C.c_int32), ("sn", C.c_int32), ("st", C.c_int32), ("flops", C.c_double), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
 class PackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("K", C.c_int32), ("first", C.c_uint64)]
@@ -240,6 +246,8 @@ SIGNATURES = {
     "y6_bnact_backward": (C.c_int, [C.POINTER(BnActBwdDesc), C.c_void_p]),
     "y6_wgrad_transpose": (C.c_int, [C.POINTER(WgradTDesc), C.c_void_p]),
     "y6_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "y6_wgrad_nhwc": (C.c_int, [C.POINTER(WgradNhwcDesc), C.c_void_p]),
+    "y6_wgrad_nhwc_supported": (C.c_int, [C.POINTER(WgradNhwcDesc)]),
     "y6_pack_job_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "y6_pack_weights_batched": (C.c_int, [C.POINTER(PackBatchDesc), C.c_void_p]),
     "y6_sppf_pool_backward": (C.c_int, [C.POINTER(SppfBwdDesc), C.c_void_p]),
@@ -269,6 +277,7 @@ SIGNATURES = {
     "y6_plan_add_bnact_backward": (C.c_int, [C.c_void_p, C.POINTER(BnActBwdDesc)]),
     "y6_plan_add_wgrad_transpose": (C.c_int, [C.c_void_p, C.POINTER(WgradTDesc)]),
     "y6_plan_add_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradDesc)]),
+    "y6_plan_add_wgrad_nhwc": (C.c_int, [C.c_void_p, C.POINTER(WgradNhwcDesc)]),
     "y6_plan_add_pack_batch": (C.c_int, [C.c_void_p, C.POINTER(PackBatchDesc)]),
     "y6_plan_add_sppf_backward": (C.c_int, [C.c_void_p, C.POINTER(SppfBwdDesc)]),
     "y6_plan_add_head_pack": (C.c_int, [C.c_void_p, C.POINTER(HeadPackDesc)]),

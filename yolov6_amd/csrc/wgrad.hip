@@ -268,6 +268,219 @@ __global__ __launch_bounds__(256, kWavesPerSimd<MODE>) void wgrad_kernel(const W
         }
 }
 
+// =====================================================================================================================
+// NHWC-fed form (3x3 stride 1 and 1x1 stride 1 - 9.6 of the 13 ms the weight gradients of a YOLOv6-S step take): no transposed
+// copies.  The run-major planes above exist because an MFMA operand wants 8 consecutive PIXELS of one channel per lane
+// while NHWC keeps channels contiguous; gfx950's ds_read_b64_tr_b16 does that transpose on the way out of LDS (a 16-lane
+// group reads a [4 pixels][16 channels] block and every lane receives one channel's four pixels).  So:
+//  * a block (4 waves) owns one 64 x 64 (cout, cin) tile x one slice of the (image, row) range and walks its rows; the dy row
+//    and the x rows y-1 / y / y+1 arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction) straight from the NHWC
+//    tensors as [32-channel chunk][pixel][32 channels] images (64-byte pixel pitch: the 4 x 64 bytes a 32-lane half reads
+//    per transpose-read are contiguous, no bank conflicts); x rows live in a ring of four (each is fetched ONCE per slice and
+//    serves three output rows), dy rows in a ring of two; the next row's requests are in flight while the current row is
+//    multiplied - one barrier per row; padding rows / columns beyond W / channels beyond the view are zero-filled by the
+//    buffer descriptor's range check;
+//  * two transpose-reads give a lane exactly the 16-byte run (8 consecutive pixels of one channel) the plane-fed kernel loads,
+//    so the register side is unchanged: k order "lanes 0-31 first half of the row, 32-63 second half", +-1 column taps by
+//    v_alignbit from the previous / next run, row-end masks;
+//  * a wave owns one 32 x 32 tile and ALL taps (nine accumulator tiles): one dy operand and three x operands per k-step feed
+//    nine MFMAs (the plane-fed kernel: two operands from L1 / L2 per three MFMAs).
+struct WgLArgs {
+    const __half* a;
+    const __half* x;
+    unsigned a_bytes, x_bytes;     // extents of the two buffers (descriptor range check)
+    int a_cs, a_co, a_C;           // dy view: pixel pitch, channel offset (halves), readable channels (multiple of 8, >= M)
+    int x_cs, x_co, x_C;
+    int B, H, W, Q;
+    int M, N;
+    int mt2, nt2, nsplit, rows_per;
+    float* ws;
+};
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobL = 0xf0000000u;   // voffset of a piece that must read zeros (tensors stay below 3.5 GiB)
+
+__device__ __forceinline__ i32x4_t make_rsrc_l(const void* base, unsigned bytes) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = (int)(unsigned)(p & 0xffffffffu);
+    r[1] = (int)(unsigned)((p >> 32) & 0xffffu);   // stride 0: raw buffer, byte offsets, range check against num_records
+    r[2] = (int)bytes;
+    r[3] = 0x00020000;
+    return r;
+}
+// one LDS-DMA piece (see conv_dma.hip): lane i writes 16 B to lds_dst + 16*i from rsrc.base + voff(lane); out of range -> zeros
+__device__ __forceinline__ void dma16_l(const i32x4_t& rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_l(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+// 8 consecutive pixels of one channel: two transpose-reads 256 bytes (4 pixels) apart
+__device__ __forceinline__ u32x4 tr_run(const char* p) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 256));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    u32x4 r;
+    r[0] = l2[0], r[1] = l2[1], r[2] = h2[0], r[3] = h2[1];
+    return r;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgLArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = KS * KS;
+    constexpr int XS = KS == 3 ? 4 : 2;                 // x ring slots
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = lane >> 5, l31 = lane & 31;
+    // XCD-aware placement as above: the tiles of one slice share an XCD (its rows come from HBM once)
+    const int tg = a.mt2 * a.nt2;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int slot = bi % tg, ks = (bi / tg) * 8 + xcd;
+    if (ks >= a.nsplit) return;
+    const int n2 = slot % a.nt2, m2 = slot / a.nt2;
+    const int mtl = wave & 1, ntl = wave >> 1;
+    const bool active = (m2 * 64 + mtl * 32 < a.M) && (n2 * 64 + ntl * 32 < a.N);
+    const long total_rows = (long)a.B * a.H;
+    const long r0 = (long)ks * a.rows_per;
+    long r1 = r0 + a.rows_per;
+    if (r1 > total_rows) r1 = total_rows;
+    const int Qr = a.Q >> 3, Qh = Qr >> 1;
+    const int rowb = a.Q * 64;                           // bytes of one 32-channel chunk row
+    const int slotb = 2 * rowb;
+    char* const ldsA = smem;                             // 2 slots
+    char* const ldsX = smem + 2 * slotb;                 // XS slots
+    const i32x4_t rsA = make_rsrc_l(a.a, a.a_bytes), rsX = make_rsrc_l(a.x, a.x_bytes);
+
+    // one NHWC row (64 channels from ch0) -> the two chunk images of a slot; grow < 0: a zero row
+    auto issue_row = [&](const i32x4_t& rs, int cs, int co, int Cv, int ch0, long grow, unsigned lds_base) {
+        const int ni = a.Q >> 4;                         // 1 KiB instructions per chunk row
+        for (int j = wave; j < 2 * ni; j += 4) {
+            const int c = j >= ni ? 1 : 0, i = j - c * ni;
+            if (ch0 + c * 32 >= Cv && grow >= 0) continue;       // a chunk nobody reads (its waves are inactive)
+            const int pix = i * 16 + (lane >> 2);
+            const int ch = ch0 + c * 32 + (lane & 3) * 8;
+            const bool ok = grow >= 0 && pix < a.W && ch + 8 <= Cv;
+            const unsigned voff = ok ? (unsigned)((((unsigned long long)grow * a.W + pix) * cs + co + ch) * 2ull) : kOobL;
+            dma16_l(rs, voff, lds_base + (unsigned)(c * rowb + i * 1024));
+        }
+    };
+    auto xrow_issue = [&](long p) {                      // p: padded row index (image stride H + 2) for 3x3, row index for 1x1
+        long grow = p;
+        if (KS == 3) {
+            const long bp = p / (a.H + 2);
+            const int yy = (int)(p - bp * (a.H + 2)) - 1;
+            grow = (yy >= 0 && yy < a.H) ? bp * a.H + yy : -1;
+        }
+        issue_row(rsX, a.x_cs, a.x_co, a.x_C, n2 * 64, grow, lds_addr_l(ldsX) + (unsigned)(p & (XS - 1)) * (unsigned)slotb);
+    };
+    auto arow_issue = [&](long gr) { issue_row(rsA, a.a_cs, a.a_co, a.a_C, m2 * 64, gr, lds_addr_l(ldsA) + (unsigned)(gr & 1) * (unsigned)slotb); };
+    auto sync_all = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    f32x16_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    // lane part of a transpose-read address: pixel (lane&15)>>2 of the group's four, channels 4*(lane&3) + 16*((lane>>4)&1) of
+    // the chunk, and this half's first run
+    const int lane_off = ((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2 + half * Qh * 512;
+    const int run_lo = half ? -1 : 0;                    // first / last run this half may read, relative to its first run
+    const int run_hi = half ? Qh - 1 : Qr - 1;
+    const unsigned mlo = half ? 0xffffffffu : 0u, mhi = half ? 0u : 0xffffffffu;   // validity of run -1 / run Qh for this lane
+
+    long xfront = -1, afront = r0 - 1;
+    for (long gr = r0; gr < r1; ++gr) {
+        const long bimg = gr / a.H;
+        const long plo = KS == 3 ? bimg * (a.H + 2) + (gr - bimg * a.H) : gr;
+        const long phi = plo + KS - 1;
+        sync_all();                                      // the row requested one iteration ago has landed; everyone left row gr-1
+        if (xfront < phi || afront < gr) {               // first row of the slice, first row of an image
+            if (xfront < plo - 1) xfront = plo - 1;
+            while (xfront < phi) xrow_issue(++xfront);
+            if (afront < gr) {
+                arow_issue(gr);
+                afront = gr;
+            }
+            sync_all();
+        }
+        if (gr + 1 < r1) {                               // next row: its dy row and the one x row it adds
+            arow_issue(gr + 1);
+            afront = gr + 1;
+            xrow_issue(phi + 1);
+            xfront = phi + 1;
+        }
+        // (waves without a tile of their own - M or N of 32 - multiply whatever their chunk images hold and drop the result:
+        // straight-line code below, no accumulator copies at control-flow joins)
+        const char* ab = ldsA + (gr & 1) * slotb + mtl * rowb + lane_off;
+        if constexpr (KS == 3) {
+            const char* xb[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) xb[r] = ldsX + ((plo + r) & 3) * slotb + ntl * rowb + lane_off;
+            u32x4 P[3], Cc[3], Nx[3], Ac, An;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                P[r] = tr_run(xb[r] + run_lo * 512);
+                Cc[r] = tr_run(xb[r]);
+                P[r][3] &= mlo;                          // k = 0: only element 7 of the previous run is used
+            }
+            Ac = tr_run(ab);
+            for (int k = 0; k < Qh; ++k) {
+                const int kn = k + 1 > run_hi ? run_hi : k + 1;
+                const int ka = k + 1 < Qh ? k + 1 : k;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) Nx[r] = tr_run(xb[r] + kn * 512);
+                An = tr_run(ab + ka * 512);
+                const h8_t af = as_h8(Ac);
+                const unsigned mnext = k == Qh - 1 ? mhi : 0xffffffffu;   // k = Qh - 1: only element 0 of the next run is used
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(shift_m1(P[r], Cc[r])), acc[r * 3 + 0], 0, 0, 0);
+                    acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(Cc[r]), acc[r * 3 + 1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    u32x4 nx = Nx[r];
+                    nx[0] &= mnext;
+                    acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(shift_p1(Cc[r], nx)), acc[r * 3 + 2], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    P[r] = Cc[r];
+                    Cc[r] = Nx[r];
+                }
+                Ac = An;
+            }
+        } else {
+            const char* xb = ldsX + (gr & 1) * slotb + ntl * rowb + lane_off;
+            u32x4 Ac = tr_run(ab), Bc = tr_run(xb);
+            for (int k = 0; k < Qh; ++k) {
+                const int ka = k + 1 < Qh ? k + 1 : k;
+                const u32x4 An = tr_run(ab + ka * 512), Bn = tr_run(xb + ka * 512);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(Ac), as_h8(Bc), acc[0], 0, 0, 0);
+                Ac = An;
+                Bc = Bn;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no request may outlive the block's LDS allocation
+    if (!active) return;
+    const int n_out = n2 * 64 + ntl * 32 + l31;
+    if (n_out >= a.N) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m_out = m2 * 64 + mtl * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (m_out < a.M) a.ws[(((size_t)ks * NT + t) * a.M + m_out) * a.N + n_out] = acc[t][q];
+        }
+}
+
 // Two-level, deterministic sum of the slice partials (a single level - one thread walking all `nsplit` slices of an element -
 // is a serial chain of strided loads: 0.77 ms for the 683 slices of the 64->64 @160x160 layers):
 //   level 1: chunk c of kRedChunk slices -> ws2[c][t][m][n]              (grid: elements x chunks)
@@ -372,6 +585,85 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     return Y6_OK;
 }
 
+size_t wgrad_nhwc_lds_bytes(int ksize, int Q) { return (size_t)(2 + (ksize == 3 ? 4 : 2)) * 2 * Q * 64; }
+
+bool wgrad_nhwc_view_ok(const y6_tensor& t) {
+    return t.data && t.C % 8 == 0 && t.cstride % 8 == 0 && t.coff % 8 == 0 && (((uintptr_t)t.data) & 15) == 0 &&
+           (size_t)t.B * t.H * t.W * t.cstride * 2 < 0xf0000000ull;
+}
+
+const char* wgrad_nhwc_unsupported(const y6_wgrad_nhwc_desc* d) {
+    if (!d || !d->out) return "null argument";
+    if (d->ksize != 1 && d->ksize != 3) return "ksize must be 1 or 3 (stride 1)";
+    if (!wgrad_nhwc_view_ok(d->dy) || !wgrad_nhwc_view_ok(d->x)) return "views must be fp16 NHWC, 8-channel / 16-byte aligned, below 3.75 GiB";
+    if (d->dy.B != d->x.B || d->dy.H != d->x.H || d->dy.W != d->x.W || d->x.B < 1 || d->x.H < 1 || d->x.W < 1) return "dy and x must have one spatial shape";
+    if (d->M < 1 || d->N < 1 || d->dy.C < d->M || d->x.C < d->N) return "views narrower than M / N";
+    const int Q = (d->x.W + 15) / 16 * 16;
+    if (wgrad_nhwc_lds_bytes(d->ksize, Q) > 160 * 1024) return "row too wide for the LDS row ring";
+    return nullptr;
+}
+
+int wgrad_nhwc_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
+    const char* why = wgrad_nhwc_unsupported(d);
+    Y6_REQUIRE(why == nullptr, "wgrad_nhwc: %s", why ? why : "");
+    WgLArgs a;
+    memset(&a, 0, sizeof(a));
+    a.a = (const __half*)d->dy.data;
+    a.x = (const __half*)d->x.data;
+    a.a_bytes = (unsigned)((size_t)d->dy.B * d->dy.H * d->dy.W * d->dy.cstride * 2);
+    a.x_bytes = (unsigned)((size_t)d->x.B * d->x.H * d->x.W * d->x.cstride * 2);
+    a.a_cs = d->dy.cstride, a.a_co = d->dy.coff, a.a_C = d->dy.C;
+    a.x_cs = d->x.cstride, a.x_co = d->x.coff, a.x_C = d->x.C;
+    a.B = d->x.B, a.H = d->x.H, a.W = d->x.W;
+    a.Q = (a.W + 15) / 16 * 16;
+    a.M = d->M, a.N = d->N;
+    a.mt2 = y6_cdiv(d->M, 64);
+    a.nt2 = y6_cdiv(d->N, 64);
+    const int T = d->ksize * d->ksize;
+    const long total_rows = (long)a.B * a.H;
+    const long tiles = (long)a.mt2 * a.nt2;
+    // one block per CU (the row ring fills the LDS): three rounds of blocks over the chip, slices of >= 4 rows (a slice pays
+    // for two extra x rows and one exposed round trip)
+    long nsplit = (768 + tiles - 1) / tiles;
+    if (nsplit > total_rows / 4) nsplit = total_rows / 4;
+    if (nsplit < 1) nsplit = 1;
+    const size_t per = (size_t)T * d->M * d->N;
+    Y6_REQUIRE(d->workspace && d->workspace_bytes >= 2 * per * sizeof(float), "wgrad_nhwc: workspace missing or too small");
+    long max_by_ws = (long)(d->workspace_bytes / (per * sizeof(float)));
+    max_by_ws = max_by_ws * kRedChunk / (kRedChunk + 1) - 1;
+    if (max_by_ws < 1) max_by_ws = 1;
+    if (nsplit > max_by_ws) nsplit = max_by_ws;
+    a.rows_per = (int)((total_rows + nsplit - 1) / nsplit);
+    a.nsplit = (int)((total_rows + a.rows_per - 1) / a.rows_per);
+    a.ws = (float*)d->workspace;
+    const size_t lds = wgrad_nhwc_lds_bytes(d->ksize, a.Q);
+    const unsigned grid = (unsigned)(8 * ((a.nsplit + 7) / 8) * tiles);
+    static bool big3 = false, big1 = false;
+    if (d->ksize == 3) {
+        if (!big3) {
+            Y6_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            big3 = true;
+        }
+        hipLaunchKernelGGL(wgrad_lds_kernel<3>, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        if (!big1) {
+            Y6_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            big1 = true;
+        }
+        hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+    }
+    Y6_LAUNCH_CHECK();
+    unsigned rg = (unsigned)((per + 255) / 256);
+    if (rg > 4096) rg = 4096;
+    const int nchunk = (a.nsplit + kRedChunk - 1) / kRedChunk;
+    float* ws2 = a.ws + (size_t)a.nsplit * per;
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(rg, (unsigned)nchunk), dim3(256), 0, s, a.ws, a.nsplit, per, ws2);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(rg), dim3(256), 0, s, ws2, nchunk, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
 }  // namespace
 
 extern "C" int y6_wgrad(const y6_wgrad_desc* d, void* stream) {
@@ -384,4 +676,19 @@ extern "C" int y6_plan_add_wgrad(y6_plan* p, const y6_wgrad_desc* d) {
     const double ns = d->mode == Y6_WG_3X3S1 ? 3 : d->mode == Y6_WG_1X1 ? 1 : d->mode == Y6_WG_3X3S2 ? 6 : 4;
     const double bytes = 2.0 * d->B * d->rows * d->Q * ((double)d->M + ns / 3.0 * d->N);
     return y6_plan_push(p, wgrad_launch, d, Y6_TOP_WGRAD, d->flops, bytes);
+}
+
+extern "C" int y6_wgrad_nhwc_supported(const y6_wgrad_nhwc_desc* d) { return wgrad_nhwc_unsupported(d) == nullptr ? 1 : 0; }
+
+extern "C" int y6_wgrad_nhwc(const y6_wgrad_nhwc_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return wgrad_nhwc_launch(d, (hipStream_t)stream);
+}
+
+extern "C" int y6_plan_add_wgrad_nhwc(y6_plan* p, const y6_wgrad_nhwc_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add: null argument");
+    const char* why = wgrad_nhwc_unsupported(d);
+    Y6_REQUIRE(why == nullptr, "wgrad_nhwc: %s", why ? why : "");
+    const double bytes = 2.0 * d->x.B * d->x.H * d->x.W * ((double)d->M + d->N);
+    return y6_plan_push(p, wgrad_nhwc_launch, d, Y6_TOP_WGRAD, d->flops, bytes);
 }

@@ -153,6 +153,7 @@ class TrainBuilder:
         self.convs: List[ConvRec] = []     # every conv of the forward (the backward shares wgrad operand planes between them)
         self.planes = {}                   # (view key, sy, sx, oy, ox, R, Q, C) -> transposed copy already in the backward plan
         self.share_planes = os.environ.get("Y6_NO_SHARED_PLANES") is None
+        self.wgrad_nhwc = os.environ.get("Y6_WGRAD_PLANES") is None     # A/B: weight gradients of stride-1 convs from NHWC (LDS transpose reads)
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -624,6 +625,22 @@ class TrainBuilder:
         xv = None if is_stem else x
         # A operand: dy, channel-major (a dilated gradient is sampled back with stride 2)
         dyv = TRef(dy.buf, dy.B, dy.H, dy.W, rec.cpad or dy.C, dy.cstride, dy.coff)
+        flops = 2.0 * Cout * Cin * K * K * B * Ho * Wo
+        wlog = dict(weight=rec.weight, x=(xt if is_stem else xv), dy=dyv, dil=rec.dy_dil, k=K, stride=s, cout=Cout)
+        if s == 1 and not is_stem and rec.dy_dil == 1 and self.wgrad_nhwc:
+            # stride-1 convs: the weight gradient reads x and dy as they lie (NHWC) - no transposed copies
+            w = _lib.WgradNhwcDesc()
+            w.ksize, w.dy, w.x, w.M, w.N = K, dyv.ct(), xv.ct(), Cout, Cin
+            w.out = self.arena.grad_ptr(rec.weight)
+            w.sm, w.sn, w.st = Cin * K * K, K * K, 1
+            w.flops = flops
+            w.workspace, w.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
+            if self.lib.y6_wgrad_nhwc_supported(C.byref(w)):
+                self._b(self.lib.y6_plan_add_wgrad_nhwc(self.bwd, C.byref(w)), "plan_add_wgrad", mode=(_lib.WG_3X3S1 if K == 3 else _lib.WG_1X1),
+                        nhwc=True, **wlog)
+                self.bwd_flops += flops
+                self._conv_backward_rest(rec, dyv, is_stem)
+                return
         a = self._transpose(dyv, rec.dy_dil, rec.dy_dil, 0, 0, Ho, Q, dyv.C, B)
         if s == 1 and K == 3:
             mode = _lib.WG_3X3S1
@@ -647,9 +664,13 @@ class TrainBuilder:
         else:                      # 1x1 stride 2: x[2y, 2x]
             mode = _lib.WG_1X1
             planes = [(self._transpose(xv, 2, 2, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
-        self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight),
-                    2.0 * Cout * Cin * K * K * B * Ho * Wo, a_ch=dyv.C, b_ch=Cin,
-                    log=dict(weight=rec.weight, x=(xt if is_stem else xv), dy=dyv, dil=rec.dy_dil, k=K, stride=s, cout=Cout))
+        self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight), flops, a_ch=dyv.C, b_ch=Cin, log=wlog)
+        self._conv_backward_rest(rec, dyv, is_stem)
+
+    def _conv_backward_rest(self, rec: ConvRec, dyv: TRef, is_stem: bool):
+        """Bias gradient and data gradient of one conv (after its weight gradient)."""
+        x, y, K, s, dy = rec.x, rec.y, rec.k, rec.stride, rec.dy
+        Cout, Cin = rec.weight.shape[0], rec.weight.shape[1]
         finals = [rec.weight]
         if rec.bias is not None:
             ws = self.bytes_(16 * _rup(max(y.C, 1), 8))
