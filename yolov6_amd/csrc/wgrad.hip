@@ -295,6 +295,8 @@ struct WgLArgs {
     int M, N;
     int mt2, nt2, nsplit, rows_per;
     float* ws;
+    int da, dx;                    // rows the dy / x requests run ahead of the MFMAs (1 or 2, by LDS capacity)
+    int dbg;                       // timing probes only
 };
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -330,55 +332,116 @@ __device__ __forceinline__ u32x4 tr_run(const char* p) {
     return r;
 }
 
+// wait until at most n of this wave's vector-memory operations are in flight (they complete in order: the older rows have landed)
+__device__ __forceinline__ void wait_vm(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 template <int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgLArgs a) {
+__global__ __launch_bounds__(512, 2) void wgrad_lds_kernel(const WgLArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = KS * KS;
-    constexpr int XS = KS == 3 ? 4 : 2;                 // x ring slots
+    constexpr int NWV = 8;                               // waves per block: four tiles x two halves of a row's k-steps
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int half = lane >> 5, l31 = lane & 31;
-    // XCD-aware placement as above: the tiles of one slice share an XCD (its rows come from HBM once)
+    // XCD-aware placement: work items (slice, tile) in slice-major order, an eighth of the list per XCD (block b runs on XCD
+    // b % 8) - the tiles of one slice land on one XCD wherever a slice has at least that many tiles' worth of neighbours, and
+    // every XCD gets the same number of blocks also when there are fewer than eight slices (512 x 512 @ 20 x 20: 64 tiles x 4)
     const int tg = a.mt2 * a.nt2;
+    const int nwork = a.nsplit * tg, per_xcd = (nwork + 7) >> 3;
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-    const int slot = bi % tg, ks = (bi / tg) * 8 + xcd;
-    if (ks >= a.nsplit) return;
+    const int item = xcd * per_xcd + bi;
+    if (bi >= per_xcd || item >= nwork) return;
+    const int ks = item / tg, slot = item - ks * tg;
     const int n2 = slot % a.nt2, m2 = slot / a.nt2;
-    const int mtl = wave & 1, ntl = wave >> 1;
+    const int mtl = wave & 1, ntl = (wave >> 1) & 1, kpart = wave >> 2;
     const bool active = (m2 * 64 + mtl * 32 < a.M) && (n2 * 64 + ntl * 32 < a.N);
-    const long total_rows = (long)a.B * a.H;
-    const long r0 = (long)ks * a.rows_per;
-    long r1 = r0 + a.rows_per;
-    if (r1 > total_rows) r1 = total_rows;
+    const int total_rows = a.B * a.H;
+    const int r0 = ks * a.rows_per;
+    const int r1 = r0 + a.rows_per < total_rows ? r0 + a.rows_per : total_rows;
     const int Qr = a.Q >> 3, Qh = Qr >> 1;
+    const int kper = (Qh + 1) >> 1;                      // k-steps of a row this wave multiplies: [k0, k1)
+    const int k0 = kpart * kper, k1 = k0 + kper < Qh ? k0 + kper : Qh;
     const int rowb = a.Q * 64;                           // bytes of one 32-channel chunk row
     const int slotb = 2 * rowb;
-    char* const ldsA = smem;                             // 2 slots
-    char* const ldsX = smem + 2 * slotb;                 // XS slots
+    // row rings: dy rows da rows ahead (da + 1 slots), x rows dx ahead (dx + 3 slots for the 3x3's three rows, dx + 1 for 1x1)
+    const int AS = a.da + 1, XS = a.dx + (KS == 3 ? 3 : 1);
+    char* const ldsA = smem;
+    char* const ldsX = smem + AS * slotb;
     const i32x4_t rsA = make_rsrc_l(a.a, a.a_bytes), rsX = make_rsrc_l(a.x, a.x_bytes);
+    const bool no_mfma = (a.dbg & 2) != 0;              // timing probe (tools/wgrad_bench.py): requests and barriers only
 
-    // one NHWC row (64 channels from ch0) -> the two chunk images of a slot; grow < 0: a zero row
-    auto issue_row = [&](const i32x4_t& rs, int cs, int co, int Cv, int ch0, long grow, unsigned lds_base) {
+    // one NHWC row (64 channels from ch0) -> the two chunk images of a slot; grow < 0: a zero row.  Returns this wave's requests.
+    auto issue_row = [&](const i32x4_t& rs, int cs, int co, int Cv, int ch0, int grow, unsigned lds_base) -> int {
         const int ni = a.Q >> 4;                         // 1 KiB instructions per chunk row
-        for (int j = wave; j < 2 * ni; j += 4) {
+        int n = 0;
+        for (int j = wave; j < 2 * ni; j += NWV) {
             const int c = j >= ni ? 1 : 0, i = j - c * ni;
-            if (ch0 + c * 32 >= Cv && grow >= 0) continue;       // a chunk nobody reads (its waves are inactive)
+            if (ch0 + c * 32 >= Cv) continue;            // a chunk nobody reads (its waves are inactive)
             const int pix = i * 16 + (lane >> 2);
             const int ch = ch0 + c * 32 + (lane & 3) * 8;
             const bool ok = grow >= 0 && pix < a.W && ch + 8 <= Cv;
             const unsigned voff = ok ? (unsigned)((((unsigned long long)grow * a.W + pix) * cs + co + ch) * 2ull) : kOobL;
             dma16_l(rs, voff, lds_base + (unsigned)(c * rowb + i * 1024));
+            ++n;
         }
+        return n;
     };
-    auto xrow_issue = [&](long p) {                      // p: padded row index (image stride H + 2) for 3x3, row index for 1x1
-        long grow = p;
+    // x rows are addressed by a PADDED row index (3x3: image stride H + 2 - one zero row above and below every image; 1x1: the
+    // row itself); output row (b, y) multiplies padded rows b*(H+2) + y .. + KS - 1.  All ring slots, image / row counters advance
+    // incrementally: a 32-bit division is ~150 cycles and ten of them per row cost more than the MFMAs of a 40 x 40 row.
+    const int y_first = (int)((unsigned)r0 % (unsigned)a.H), b_first = (int)((unsigned)r0 / (unsigned)a.H);
+    int y = y_first;                                     // row of gr inside its image
+    int plo = KS == 3 ? b_first * (a.H + 2) + y_first : r0;
+    auto pad_ahead = [&](int j) -> int {                 // padded top row of output row gr + j
+        if (KS != 3) return plo + j;
+        int yy = y + j, add = 0;
+        while (yy >= a.H) {
+            yy -= a.H;
+            add += 2;
+        }
+        return plo + j + add;
+    };
+    // request frontier of x: padded row xfront = (image fb, padded row fyy of it), ring slot sxf
+    int xfront = plo - 1, fb = b_first, fyy = y_first - 1, sxf, sx_lo;
+    if (KS == 3) {
+        if (fyy < 0) {
+            fyy = a.H + 1;
+            --fb;
+        }
+    }
+    sx_lo = (int)((unsigned)plo % (unsigned)XS);
+    sxf = sx_lo == 0 ? XS - 1 : sx_lo - 1;
+    auto xrow_issue_next = [&]() -> int {                // requests padded row ++xfront
+        ++xfront;
+        if (++sxf == XS) sxf = 0;
+        int grow = xfront;
         if (KS == 3) {
-            const long bp = p / (a.H + 2);
-            const int yy = (int)(p - bp * (a.H + 2)) - 1;
-            grow = (yy >= 0 && yy < a.H) ? bp * a.H + yy : -1;
+            if (++fyy == a.H + 2) {
+                fyy = 0;
+                ++fb;
+            }
+            grow = (fyy >= 1 && fyy <= a.H) ? fb * a.H + fyy - 1 : -1;
         }
-        issue_row(rsX, a.x_cs, a.x_co, a.x_C, n2 * 64, grow, lds_addr_l(ldsX) + (unsigned)(p & (XS - 1)) * (unsigned)slotb);
+        return issue_row(rsX, a.x_cs, a.x_co, a.x_C, n2 * 64, grow, lds_addr_l(ldsX) + (unsigned)sxf * (unsigned)slotb);
     };
-    auto arow_issue = [&](long gr) { issue_row(rsA, a.a_cs, a.a_co, a.a_C, m2 * 64, gr, lds_addr_l(ldsA) + (unsigned)(gr & 1) * (unsigned)slotb); };
+    int afront = r0 - 1, sa = (int)((unsigned)r0 % (unsigned)AS), saf = sa == 0 ? AS - 1 : sa - 1;
+    auto arow_issue_next = [&]() -> int {                // requests dy row ++afront
+        ++afront;
+        if (++saf == AS) saf = 0;
+        return issue_row(rsA, a.a_cs, a.a_co, a.a_C, m2 * 64, afront, lds_addr_l(ldsA) + (unsigned)saf * (unsigned)slotb);
+    };
     auto sync_all = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     f32x16_t acc[NT];
@@ -393,49 +456,76 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgLArgs a) {
     const int run_lo = half ? -1 : 0;                    // first / last run this half may read, relative to its first run
     const int run_hi = half ? Qh - 1 : Qr - 1;
     const unsigned mlo = half ? 0xffffffffu : 0u, mhi = half ? 0u : 0xffffffffu;   // validity of run -1 / run Qh for this lane
+    const int kprev = k0 - 1 < run_lo ? run_lo : k0 - 1;
+    const unsigned mfirst = k0 == 0 ? mlo : 0xffffffffu;
 
-    long xfront = -1, afront = r0 - 1;
-    for (long gr = r0; gr < r1; ++gr) {
-        const long bimg = gr / a.H;
-        const long plo = KS == 3 ? bimg * (a.H + 2) + (gr - bimg * a.H) : gr;
-        const long phi = plo + KS - 1;
-        sync_all();                                      // the row requested one iteration ago has landed; everyone left row gr-1
+    int allow = 0;                                       // requests of this wave that may still be in flight at the next row's start
+    for (int gr = r0; gr < r1; ++gr) {
+        const int phi = plo + KS - 1;
+        wait_vm(allow);                                  // row gr's images have landed (younger rows may still be in flight) ...
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... for every wave, and everyone left row gr-1
         if (xfront < phi || afront < gr) {               // first row of the slice, first row of an image
-            if (xfront < plo - 1) xfront = plo - 1;
-            while (xfront < phi) xrow_issue(++xfront);
-            if (afront < gr) {
-                arow_issue(gr);
-                afront = gr;
-            }
+            while (xfront < phi) xrow_issue_next();
+            if (afront < gr) arow_issue_next();
             sync_all();
         }
-        if (gr + 1 < r1) {                               // next row: its dy row and the one x row it adds
-            arow_issue(gr + 1);
-            afront = gr + 1;
-            xrow_issue(phi + 1);
-            xfront = phi + 1;
+        // requests for the rows ahead.  Slots: the ring holds dy rows gr .. gr+da and padded x rows plo .. plo+XS-1.
+        {
+            int issued = 0;
+            bool younger = true;                         // none of them is needed by row gr+1
+            const int alast = gr + a.da < r1 - 1 ? gr + a.da : r1 - 1;
+            while (afront < alast) {
+                issued += arow_issue_next();
+                younger = younger && afront > gr + 1;
+            }
+            const int jlast = gr + a.dx < r1 - 1 ? a.dx : r1 - 1 - gr;
+            int xlast = pad_ahead(jlast) + KS - 1;
+            if (xlast > plo + XS - 1) xlast = plo + XS - 1;
+            const int pnext = gr + 1 < r1 ? pad_ahead(1) + KS - 1 : -1;
+            while (xfront < xlast) {
+                issued += xrow_issue_next();
+                younger = younger && xfront > pnext;
+            }
+            allow = younger ? issued : 0;
         }
+        // this row's slots, then the counters move on to row gr + 1
+        const int sa_now = sa, sx_now = sx_lo;
+        {
+            if (++sa == AS) sa = 0;
+            int d = 1;
+            if (++y == a.H) {
+                y = 0;
+                if (KS == 3) d = 3;
+            }
+            plo += d;
+            sx_lo += d;
+            while (sx_lo >= XS) sx_lo -= XS;
+        }
+        if (no_mfma) continue;
         // (waves without a tile of their own - M or N of 32 - multiply whatever their chunk images hold and drop the result:
         // straight-line code below, no accumulator copies at control-flow joins)
-        const char* ab = ldsA + (gr & 1) * slotb + mtl * rowb + lane_off;
+        const char* ab = ldsA + sa_now * slotb + mtl * rowb + lane_off;
         if constexpr (KS == 3) {
             const char* xb[3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) xb[r] = ldsX + ((plo + r) & 3) * slotb + ntl * rowb + lane_off;
-            u32x4 P[3], Cc[3], Nx[3], Ac, An;
+            for (int r = 0; r < 3; ++r) xb[r] = ldsX + (sx_now + r < XS ? sx_now + r : sx_now + r - XS) * slotb + ntl * rowb + lane_off;
+            // three run sets rotate through the roles (previous, current, next): the loop is unrolled by hand over the rotation
+            // so that no set is ever copied; the dy operand alternates between two registers the same way
+            u32x4 R0[3], R1[3], R2[3], A0, A1;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                P[r] = tr_run(xb[r] + run_lo * 512);
-                Cc[r] = tr_run(xb[r]);
-                P[r][3] &= mlo;                          // k = 0: only element 7 of the previous run is used
+                R0[r] = tr_run(xb[r] + kprev * 512);
+                R1[r] = tr_run(xb[r] + k0 * 512);
+                R0[r][3] &= mfirst;                      // k = 0: only element 7 of the previous run is used
             }
-            Ac = tr_run(ab);
-            for (int k = 0; k < Qh; ++k) {
+            A0 = tr_run(ab + k0 * 512);
+            auto step = [&](const u32x4 (&P)[3], const u32x4 (&Cc)[3], u32x4 (&Nx)[3], const u32x4& Ac, u32x4& An, int k) {
                 const int kn = k + 1 > run_hi ? run_hi : k + 1;
-                const int ka = k + 1 < Qh ? k + 1 : k;
+                const int ka = k + 1 < k1 ? k + 1 : k;
 #pragma unroll
                 for (int r = 0; r < 3; ++r) Nx[r] = tr_run(xb[r] + kn * 512);
                 An = tr_run(ab + ka * 512);
+                __builtin_amdgcn_sched_barrier(0);       // the reads of step k+1 go out BEFORE the MFMAs of step k
                 const h8_t af = as_h8(Ac);
                 const unsigned mnext = k == Qh - 1 ? mhi : 0xffffffffu;   // k = Qh - 1: only element 0 of the next run is used
 #pragma unroll
@@ -443,41 +533,58 @@ __global__ __launch_bounds__(256, 2) void wgrad_lds_kernel(const WgLArgs a) {
                     acc[r * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(shift_m1(P[r], Cc[r])), acc[r * 3 + 0], 0, 0, 0);
                     acc[r * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(Cc[r]), acc[r * 3 + 1], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);       // six MFMAs that do not need the new runs cover the LDS latency
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     u32x4 nx = Nx[r];
                     nx[0] &= mnext;
                     acc[r * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(shift_p1(Cc[r], nx)), acc[r * 3 + 2], 0, 0, 0);
                 }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    P[r] = Cc[r];
-                    Cc[r] = Nx[r];
-                }
-                Ac = An;
+            };
+            for (int k = k0; k < k1; k += 6) {           // 6 = lcm of the two rotations
+                step(R0, R1, R2, A0, A1, k);
+                if (k + 1 < k1) step(R1, R2, R0, A1, A0, k + 1);
+                if (k + 2 < k1) step(R2, R0, R1, A0, A1, k + 2);
+                if (k + 3 < k1) step(R0, R1, R2, A1, A0, k + 3);
+                if (k + 4 < k1) step(R1, R2, R0, A0, A1, k + 4);
+                if (k + 5 < k1) step(R2, R0, R1, A1, A0, k + 5);
             }
         } else {
-            const char* xb = ldsX + (gr & 1) * slotb + ntl * rowb + lane_off;
-            u32x4 Ac = tr_run(ab), Bc = tr_run(xb);
-            for (int k = 0; k < Qh; ++k) {
-                const int ka = k + 1 < Qh ? k + 1 : k;
-                const u32x4 An = tr_run(ab + ka * 512), Bn = tr_run(xb + ka * 512);
+            const char* xb = ldsX + sx_now * slotb + ntl * rowb + lane_off;
+            u32x4 A0 = tr_run(ab + k0 * 512), B0 = tr_run(xb + k0 * 512), A1, B1;
+            auto step = [&](const u32x4& Ac, const u32x4& Bc, u32x4& An, u32x4& Bn, int k) {
+                const int ka = k + 1 < k1 ? k + 1 : k;
+                An = tr_run(ab + ka * 512);
+                Bn = tr_run(xb + ka * 512);
+                __builtin_amdgcn_sched_barrier(0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(Ac), as_h8(Bc), acc[0], 0, 0, 0);
-                Ac = An;
-                Bc = Bn;
+            };
+            for (int k = k0; k < k1; k += 2) {
+                step(A0, B0, A1, B1, k);
+                if (k + 1 < k1) step(A1, B1, A0, B0, k + 1);
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no request may outlive the block's LDS allocation
-    if (!active) return;
+    // the two halves of the k range meet in LDS (the row rings are dead): waves 4-7 park their tiles, waves 0-3 add them to
+    // their own and write ONE partial tile set per slice (fixed order: deterministic)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // no request or read may outlive the rings
+    float* park = reinterpret_cast<float*>(smem) + (size_t)(wave & 3) * NT * 16 * 64;
+    if (kpart == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) park[(t * 16 + q) * 64 + lane] = acc[t][q];
+    }
+    __syncthreads();
+    if (kpart == 1 || !active) return;
     const int n_out = n2 * 64 + ntl * 32 + l31;
-    if (n_out >= a.N) return;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
+            const float v = acc[t][q] + park[(t * 16 + q) * 64 + lane];
             const int m_out = m2 * 64 + mtl * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
-            if (m_out < a.M) a.ws[(((size_t)ks * NT + t) * a.M + m_out) * a.N + n_out] = acc[t][q];
+            if (m_out < a.M && n_out < a.N) a.ws[(((size_t)ks * NT + t) * a.M + m_out) * a.N + n_out] = v;
         }
 }
 
@@ -585,7 +692,7 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
     return Y6_OK;
 }
 
-size_t wgrad_nhwc_lds_bytes(int ksize, int Q) { return (size_t)(2 + (ksize == 3 ? 4 : 2)) * 2 * Q * 64; }
+size_t wgrad_nhwc_lds_bytes(int ksize, int Q, int da, int dx) { return (size_t)(da + 1 + dx + (ksize == 3 ? 3 : 1)) * 2 * Q * 64; }
 
 bool wgrad_nhwc_view_ok(const y6_tensor& t) {
     return t.data && t.C % 8 == 0 && t.cstride % 8 == 0 && t.coff % 8 == 0 && (((uintptr_t)t.data) & 15) == 0 &&
@@ -599,7 +706,7 @@ const char* wgrad_nhwc_unsupported(const y6_wgrad_nhwc_desc* d) {
     if (d->dy.B != d->x.B || d->dy.H != d->x.H || d->dy.W != d->x.W || d->x.B < 1 || d->x.H < 1 || d->x.W < 1) return "dy and x must have one spatial shape";
     if (d->M < 1 || d->N < 1 || d->dy.C < d->M || d->x.C < d->N) return "views narrower than M / N";
     const int Q = (d->x.W + 15) / 16 * 16;
-    if (wgrad_nhwc_lds_bytes(d->ksize, Q) > 160 * 1024) return "row too wide for the LDS row ring";
+    if (wgrad_nhwc_lds_bytes(d->ksize, Q, 1, 1) > 160 * 1024) return "row too wide for the LDS row ring";
     return nullptr;
 }
 
@@ -622,9 +729,9 @@ int wgrad_nhwc_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
     const int T = d->ksize * d->ksize;
     const long total_rows = (long)a.B * a.H;
     const long tiles = (long)a.mt2 * a.nt2;
-    // one block per CU (the row ring fills the LDS): three rounds of blocks over the chip, slices of >= 4 rows (a slice pays
-    // for two extra x rows and one exposed round trip)
-    long nsplit = (768 + tiles - 1) / tiles;
+    // one block per CU, one round: every slice costs two partial tiles (the k halves) that the reduction reads again
+    // (three rounds: 216 MB of partials per 3x3 64 -> 64 launch, more time than its MFMAs - profiles/r03/r03n_wgrad_bench.json)
+    long nsplit = 256 / tiles;
     if (nsplit > total_rows / 4) nsplit = total_rows / 4;
     if (nsplit < 1) nsplit = 1;
     const size_t per = (size_t)T * d->M * d->N;
@@ -636,28 +743,37 @@ int wgrad_nhwc_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
     a.rows_per = (int)((total_rows + nsplit - 1) / nsplit);
     a.nsplit = (int)((total_rows + a.rows_per - 1) / a.rows_per);
     a.ws = (float*)d->workspace;
-    const size_t lds = wgrad_nhwc_lds_bytes(d->ksize, a.Q);
-    const unsigned grid = (unsigned)(8 * ((a.nsplit + 7) / 8) * tiles);
+    static const bool probing = getenv("Y6_WGRAD_PROBE") != nullptr;
+    a.dbg = probing && getenv("Y6_WGRAD_DBG") ? atoi(getenv("Y6_WGRAD_DBG")) : 0;
+    // requests run two rows ahead where the LDS holds the deeper rings (one row of requests in flight per CU: 3.4 TB/s)
+    a.da = a.dx = 1;
+    if (wgrad_nhwc_lds_bytes(d->ksize, a.Q, 2, 2) < 160 * 1024) a.da = a.dx = 2;
+    else if (wgrad_nhwc_lds_bytes(d->ksize, a.Q, 2, 1) < 160 * 1024) a.da = 2;
+    size_t lds = wgrad_nhwc_lds_bytes(d->ksize, a.Q, a.da, a.dx);
+    const size_t park = (size_t)4 * T * 16 * 64 * sizeof(float);      // where the two k halves of the four tiles meet
+    if (lds < park) lds = park;
+    const unsigned grid = (unsigned)(8 * (((long)a.nsplit * tiles + 7) / 8));
     static bool big3 = false, big1 = false;
     if (d->ksize == 3) {
         if (!big3) {
             Y6_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             big3 = true;
         }
-        hipLaunchKernelGGL(wgrad_lds_kernel<3>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(wgrad_lds_kernel<3>, dim3(grid), dim3(512), lds, s, a);
     } else {
         if (!big1) {
             Y6_HIP(hipFuncSetAttribute((const void*)wgrad_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             big1 = true;
         }
-        hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(wgrad_lds_kernel<1>, dim3(grid), dim3(512), lds, s, a);
     }
     Y6_LAUNCH_CHECK();
     unsigned rg = (unsigned)((per + 255) / 256);
     if (rg > 4096) rg = 4096;
-    const int nchunk = (a.nsplit + kRedChunk - 1) / kRedChunk;
-    float* ws2 = a.ws + (size_t)a.nsplit * per;
-    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(rg, (unsigned)nchunk), dim3(256), 0, s, a.ws, a.nsplit, per, ws2);
+    const int nparts = a.nsplit;
+    const int nchunk = (nparts + kRedChunk - 1) / kRedChunk;
+    float* ws2 = a.ws + (size_t)nparts * per;
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(rg, (unsigned)nchunk), dim3(256), 0, s, a.ws, nparts, per, ws2);
     Y6_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3(rg), dim3(256), 0, s, ws2, nchunk, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
     Y6_LAUNCH_CHECK();

@@ -154,6 +154,8 @@ class TrainBuilder:
         self.planes = {}                   # (view key, sy, sx, oy, ox, R, Q, C) -> transposed copy already in the backward plan
         self.share_planes = os.environ.get("Y6_NO_SHARED_PLANES") is None
         self.wgrad_nhwc = os.environ.get("Y6_WGRAD_PLANES") is None     # A/B: weight gradients of stride-1 convs from NHWC (LDS transpose reads)
+        self.wgrad_nhwc_minw3 = int(os.environ.get("Y6_WGRAD_NHWC_MINW3", "64"))   # narrower 3x3 maps keep the plane-fed kernel
+        self.wgrad_nhwc_minw1 = int(os.environ.get("Y6_WGRAD_NHWC_MINW1", "64"))
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -627,7 +629,7 @@ class TrainBuilder:
         dyv = TRef(dy.buf, dy.B, dy.H, dy.W, rec.cpad or dy.C, dy.cstride, dy.coff)
         flops = 2.0 * Cout * Cin * K * K * B * Ho * Wo
         wlog = dict(weight=rec.weight, x=(xt if is_stem else xv), dy=dyv, dil=rec.dy_dil, k=K, stride=s, cout=Cout)
-        if s == 1 and not is_stem and rec.dy_dil == 1 and self.wgrad_nhwc:
+        if s == 1 and not is_stem and rec.dy_dil == 1 and self.wgrad_nhwc and Wo >= (self.wgrad_nhwc_minw3 if K == 3 else self.wgrad_nhwc_minw1):
             # stride-1 convs: the weight gradient reads x and dy as they lie (NHWC) - no transposed copies
             w = _lib.WgradNhwcDesc()
             w.ksize, w.dy, w.x, w.M, w.N = K, dyv.ct(), xv.ct(), Cout, Cin
