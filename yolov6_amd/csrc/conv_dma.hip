@@ -90,6 +90,12 @@ constexpr bool kProbeNoEpilogue = kDmaProbe == 2 || kDmaProbe == 7 || kDmaProbe 
 #define Y6_DMA_PLANAR16 1
 #endif
 
+// Pixel-major 16-channel-chunk image only: the 9 x PF swizzled fragment addresses of a lane are kernel invariants - keep them in
+// registers (one v_add per fragment read, as the planar image needs) instead of four VALU instructions per read.
+#ifndef Y6_DMA_PIX16_HOIST
+#define Y6_DMA_PIX16_HOIST 1
+#endif
+
 constexpr unsigned kOob = 0xf0000000u;   // voffset of a piece that must read zeros / a store that must be dropped (tensors stay below 3.5 GiB)
 
 // lane (0..31) -> pixel of the fragment it holds (see the header comment)
@@ -151,7 +157,7 @@ __device__ __forceinline__ void wait_vm_barrier(int n) {
 //     (tools/dma_model.py).
 template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1, bool WRES = false>
 __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKArgs a) {
-    static_assert(ST == 1 || (HC == 16 && Y6_DMA_PLANAR16 != 0), "stride 2 is built on the planar 16-channel-chunk image");
+    static_assert(ST == 1 || HC == 16, "stride 2 is built on the planar 16-channel-chunk image");
     static_assert(!WRES || (!I8 && ST == 1 && STG == 2), "resident weights: fp16, stride 1, two halo stages");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename AccT<I8>::type acc_t;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     constexpr int KS = HC / 16;                                   // MFMA k-steps per chunk and tap
     constexpr int SPP = HC / 8;                                   // 16-byte pieces per halo pixel and chunk
     constexpr int JB = HC == 16 ? 1 : 2;                          // bits of the piece index
-    constexpr bool PLANAR = HC == 16 && Y6_DMA_PLANAR16 != 0;     // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
+    constexpr bool PLANAR = HC == 16 && (Y6_DMA_PLANAR16 != 0 || ST == 2);    // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
     constexpr int WP = CF * NT * KS;                              // weight pieces (1 KiB) per chunk
     constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32, ST>::value * SPP + 63) / 64;
     constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
@@ -332,6 +338,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
         const int ty = mm / a.TW, tx = mm - ty * a.TW;
         pixoff[pf] = PLANAR ? ((lane >> 5) * PLs + ty * ST * RP + tx) * 16 : (ty * RP + tx);   // pixel-major: the pixel's linear index
         ptytx[pf] = m < npx ? ((ty << 16) | tx) : -1;
+    }
+    constexpr bool HOIST = !PLANAR && HC == 16 && Y6_DMA_PIX16_HOIST != 0;
+    int tapaddr[HOIST ? NT : 1][PF];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) {
+                const int p = pixoff[pf] + (t / 3) * RP + (t % 3);
+                tapaddr[t][pf] = p * (SPP * 16) + ((((lane >> 5) ^ (p >> (4 - JB))) & (SPP - 1)) << 4);
+            }
     }
     auto setup_pix = [&](int item) {
         int tile;
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             for (int pf = 0; pf < PF; ++pf) {
                 plc[pf] = pixoff[pf];
                 // opaque per chunk: otherwise hipcc hoists the 9 x PF swizzled tap addresses out of the chunk loop and spills
-                if (!PLANAR) asm volatile("" : "+v"(plc[pf]));
+                if (!PLANAR && !HOIST) asm volatile("" : "+v"(plc[pf]));
             }
             auto ldfrag = [&](int u, int buf) {
                 const int t = u / KS, ks = u - t * KS;
@@ -586,6 +603,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                     const int tapoff = ((t / 3) * RP + (ST == 1 ? (t % 3) : ((t % 3) == 1 ? ((a.HWd + 1) >> 1) : ((t % 3) >> 1)))) * 16;
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixoff[pf] + tapoff);
+                } else if constexpr (HOIST) {
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) fb[buf][pf] = *reinterpret_cast<const i32x4_t*>(Ab + tapaddr[t][pf]);
                 } else {
 #pragma unroll
                     for (int pf = 0; pf < PF; ++pf) {
