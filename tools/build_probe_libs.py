@@ -36,11 +36,14 @@ def one_dma(n):
     return lib
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "--dma-pixmajor":   # A/B: 16-channel-chunk kernels with the pixel-major swizzled halo image (default build: planar)
+if len(sys.argv) > 1 and sys.argv[1] in ("--dma-pixmajor", "--dma-planar"):
+    # A/B of the halo image of the fp16 stride-1 16-channel-chunk kernels: pixel-major swizzled (the default build since round 3)
+    # against the two-plane image (the default of rounds 1-2)
+    planar = sys.argv[1] == "--dma-planar"
     oth = [o for o in glob.glob(os.path.join(B.OBJ_DIR, "*.o")) if not os.path.basename(o).startswith("conv_dma.")]
-    obj = os.path.join(out, "conv_dma_pixmajor.o")
-    lib = os.path.join(out, "libyolov6_hip_dmapixmajor.so")
-    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_dma.hip"] + ["-DY6_DMA_PLANAR16=0", "-c", os.path.join(B.HERE, "conv_dma.hip"), "-o", obj],
+    obj = os.path.join(out, "conv_dma_layout.o")
+    lib = os.path.join(out, "libyolov6_hip_dmaplanar.so" if planar else "libyolov6_hip_dmapixmajor.so")
+    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_dma.hip"] + ["-DY6_DMA_PLANAR16=" + ("1" if planar else "0"), "-c", os.path.join(B.HERE, "conv_dma.hip"), "-o", obj],
                    check=True, capture_output=True)
     subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + sorted(oth), check=True)
     os.remove(obj)

@@ -81,17 +81,19 @@ __device__ __forceinline__ ConvKArgs reload_args() {
 constexpr int kDmaProbe = Y6_DMA_PROBE;
 constexpr bool kProbeNoEpilogue = kDmaProbe == 2 || kDmaProbe == 7 || kDmaProbe == 8;
 
-// Halo image of the 16-channel-chunk kernels: 1 = two planes (channels 0-7 / 8-15), one cache line per lane of a request but
-// fragment addresses that are a constant offset per tap; 0 = pixel-major with the piece index XOR bit 3 of the pixel index
-// (two lanes of a request per pixel, four VALU instructions per fragment address).  Same-box A/B (tools/gpu_ab_layout.sh,
-// profiles/r02/ab_layout_ablayout1.txt): planar 1.85 ms for the 35 launches, pixel-major 1.92-2.01 ms - the address
-// arithmetic costs more than the request rate gains at this chunk size.  (The 32-channel-chunk kernels are pixel-major.)
+// Halo image of the fp16 stride-1 16-channel-chunk kernels: 0 (default since round 3) = pixel-major, [halo pixel][2 pieces of 16 B] with
+// the piece index XOR bit 3 of the pixel index on the SOURCE side - two lanes of a request read one pixel, so a request touches
+// 32 cache lines instead of 64, and the halo requests are what the fill costs; 1 = two planes (channels 0-7 /
+// 8-15), one cache line per lane of a request, fragment addresses a constant offset per tap.  History: round 2 measured the
+// pixel-major image 4-8 % SLOWER (profiles/r02/ab_layout_ablayout1.txt) - its fragment addresses were recomputed per read, four
+// VALU instructions each; with the 9 x PF addresses of a lane kept in registers (Y6_DMA_PIX16_HOIST: they are kernel invariants;
+// one v_add per fragment read, as the planar image needs) it is 1.3-1.4 % FASTER over the whole step, same box, alternating runs
+// (profiles/r03/bench_infer_r03r_{planar,pixmajor}{1,2}.json; the tuner then prefers dma_c1p2 where it took dma_c2p1).
+// The stride-2 form and the int8 kernels stay planar (the even/odd column split of stride 2 is a property of the planar rows;
+// the int8 8-wave form has no registers to spare).  (The 32-channel-chunk kernels are pixel-major by construction.)
 #ifndef Y6_DMA_PLANAR16
-#define Y6_DMA_PLANAR16 1
+#define Y6_DMA_PLANAR16 0
 #endif
-
-// Pixel-major 16-channel-chunk image only: the 9 x PF swizzled fragment addresses of a lane are kernel invariants - keep them in
-// registers (one v_add per fragment read, as the planar image needs) instead of four VALU instructions per read.
 #ifndef Y6_DMA_PIX16_HOIST
 #define Y6_DMA_PIX16_HOIST 1
 #endif
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     constexpr int KS = HC / 16;                                   // MFMA k-steps per chunk and tap
     constexpr int SPP = HC / 8;                                   // 16-byte pieces per halo pixel and chunk
     constexpr int JB = HC == 16 ? 1 : 2;                          // bits of the piece index
-    constexpr bool PLANAR = HC == 16 && (Y6_DMA_PLANAR16 != 0 || ST == 2);    // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
+    constexpr bool PLANAR = HC == 16 && (Y6_DMA_PLANAR16 != 0 || ST == 2 || I8);    // else pixel-major [halo pixel][SPP pieces], piece index XOR bits (4-JB).. of the pixel index
     constexpr int WP = CF * NT * KS;                              // weight pieces (1 KiB) per chunk
     constexpr int MAXNHP = (DmaHaloCap<NW * PF * 32, ST>::value * SPP + 63) / 64;
     constexpr int ES = I8 ? 1 : 2;                                // bytes per input element
