@@ -234,9 +234,24 @@ def _bn_stats(ref: TRef, gamma, beta, rm, rv, eps=1e-3, mom=0.03):
 @pytest.mark.parametrize("act,with_res,dil", [("relu", False, 1), ("silu", False, 1), ("relu", True, 1), ("relu", False, 2), (None, False, 1)])
 def test_bnact_forward_backward_vs_autograd(act, with_res, dil):
     """ReLU(bn(y3) + bn(y1) + bn_id(x)) [+ alpha*res] with batch statistics, and every gradient of it."""
+    _run_bnact_case(act, with_res, dil, (3, 24, 6, 10))
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 40, 40), (2, 128, 33, 20)])
+def test_bnact_sums_many_blocks_reproducible(shape):
+    """The 8-channels-per-thread kernels at sizes where the per-channel sums span many blocks (block partials + ordered
+    second-level sums, no atomics): every output equals autograd, and two runs agree bit for bit."""
+    a = _run_bnact_case("relu", True, 1, shape)
+    b = _run_bnact_case("relu", True, 1, shape)
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x, y), f"output {i} differs between two runs"
+
+
+def _run_bnact_case(act, with_res, dil, shape):
     lib = _lib.load()
     g = torch.Generator().manual_seed(11)
-    B, Cn, H, W = 3, 24, 6, 10
+    B, Cn, H, W = shape
     ys = [(torch.randn((B, Cn, H, W), generator=g) * s).half().float() for s in (1.0, 0.5, 2.0)]
     res = torch.randn((B, Cn, H, W), generator=g).half().float()
     gam = [torch.rand(Cn, generator=g) + 0.5 for _ in range(3)]
@@ -330,6 +345,8 @@ def test_bnact_forward_backward_vs_autograd(act, with_res, dil):
     if with_res:
         assert float((_back(dres) - rv_.grad).abs().max()) < 3e-3 * float(rv_.grad.abs().max())
         assert abs(float(dal) - float(av.grad)) < 2e-3 * abs(float(av.grad))
+    outs = [t.cpu() for st in stats for t in st] + [t.cpu() for t in rmd + rvd + dgd + dbd] + [_back(t) for t in dxs] + [_back(out), dal.cpu()]
+    return outs
 
 
 def test_sppf_pool_backward_first_max_semantics():

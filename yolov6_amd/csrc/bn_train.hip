@@ -102,7 +102,8 @@ bool view_ok(const y6_tensor& t) {
 
 }  // namespace
 
-extern "C" size_t y6_bn_stats_workspace_bytes(int C) { return (size_t)2 * C * sizeof(double); }
+// [2C] final sums (the atomic path of y6_bn_stats) followed by [kBnPartBlocks][2C] block partials (y6_bn_train_stats, train.hip)
+extern "C" size_t y6_bn_stats_workspace_bytes(int C) { return (size_t)2 * C * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
 
 extern "C" int y6_bn_stats(const y6_tensor* x, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream) {
     Y6_CLEAR_STALE_ERROR();

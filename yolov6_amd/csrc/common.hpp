@@ -42,6 +42,9 @@ void y6_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int y6_cdiv(int a, int b) { return (a + b - 1) / b; }
+// BatchNorm statistics / backward sums (train.hip): at most this many blocks, each leaving its per-channel partial sums in the
+// workspace; a second kernel adds them in a fixed order (y6_bn_stats_workspace_bytes / y6_bnact_bwd_workspace_bytes size for it)
+constexpr int kBnPartBlocks = 1024;
 static inline size_t y6_tensor_elems(const y6_tensor& t) { return (size_t)t.B * t.H * t.W * t.cstride; }
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));

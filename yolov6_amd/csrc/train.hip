@@ -121,7 +121,98 @@ __global__ __launch_bounds__(256) void bn_sum_kernel(const __half* __restrict__ 
     for (int i = tid; i < 2 * C; i += 256) atomicAdd(&ws[i], s_acc[i]);
 }
 
-// Turns the sums into the BatchNorm constants and leaves the workspace zeroed again: a caller whose workspace starts zeroed
+// The same sums without atomics: every block stores its 2C partial sums, the finalize kernel adds the blocks' partials in a
+// fixed order (16 interleaved sub-sums per value, then those in order) - deterministic, and no workspace has to start zeroed.
+// Why: with the one-kernel-plus-atomics form a BatchNorm statistics launch cost 19 us + bytes / 4.5 TB/s
+// (profiles/r03/bench_train_ops_r03q.json: 13 MB tensors 19.6 us, 52 MB 24.9 us) - the floor is the serial loop of a thread over
+// its 64 pixel rows (16 rounds of four loads), which could not be shortened while every extra block meant 2C more same-address
+// double atomics.  Partials make blocks cheap: a thread walks 16 rows (4 rounds).
+__global__ __launch_bounds__(256) void bn_sum_part_kernel(const __half* __restrict__ x, int cs, int co, long npix, int G,
+                                                          long pix_per_block, double* __restrict__ part, int C) {
+    extern __shared__ double s_rows[];   // [R][2][8][G]: the sums of pixel-row thread r, value k, channel g*8 + j at ((r*2 + k)*8 + j)*G + g
+    const int tid = threadIdx.x;
+    const int R = 256 / G;
+    if (tid < R * G) {
+        const int g = tid % G, prow = tid / G;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+        double s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
+        long p = p0 + prow;
+        for (; p + 3 * (long)R < p1; p += 4 * (long)R) {
+            float v0[8], v1[8], v2[8], v3[8];
+            load8(x + p * cs + co + g * 8, v0);
+            load8(x + (p + R) * cs + co + g * 8, v1);
+            load8(x + (p + 2 * (long)R) * cs + co + g * 8, v2);
+            load8(x + (p + 3 * (long)R) * cs + co + g * 8, v3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)((v0[j] + v1[j]) + (v2[j] + v3[j]));
+                q[j] += (double)v0[j] * (double)v0[j] + (double)v1[j] * (double)v1[j] + (double)v2[j] * (double)v2[j] +
+                        (double)v3[j] * (double)v3[j];
+            }
+        }
+        for (; p < p1; p += R) {
+            float v[8];
+            load8(x + p * cs + co + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)v[j];
+                q[j] += (double)v[j] * (double)v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s_rows[((prow * 2 + 0) * 8 + j) * G + g] = s[j];
+            s_rows[((prow * 2 + 1) * 8 + j) * G + g] = q[j];
+        }
+    }
+    __syncthreads();
+    // the R pixel-row threads of a channel are added in row order (no atomics anywhere: the statistics are reproducible)
+    double* dst = part + (size_t)blockIdx.x * (size_t)(2 * C);
+    for (int i = tid; i < 2 * C; i += 256) {   // i = (k*8 + j)*G + g
+        const int g = i % G, kj = i / G;
+        double tot = 0.0;
+        for (int r = 0; r < R; ++r) tot += s_rows[(size_t)r * 2 * C + i];
+        dst[(kj >> 3) * C + g * 8 + (kj & 7)] = tot;
+    }
+}
+
+// sum over the blocks' partials of value v (stride `nvals` doubles between blocks): 16 interleaved sub-sums (one per 32-lane
+// row of the block, four independent loads in flight), combined in row order.  512 threads; red: [16][33] doubles.
+__device__ __forceinline__ double part_subsum(const double* __restrict__ p, size_t stride, int nblocks, int prt) {
+    double s = 0.0;
+    int b = prt;
+    for (; b + 48 < nblocks; b += 64) {
+        const double a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + 16) * stride], a2 = p[(size_t)(b + 32) * stride],
+                     a3 = p[(size_t)(b + 48) * stride];
+        s += (a0 + a1) + (a2 + a3);
+    }
+    for (; b < nblocks; b += 16) s += p[(size_t)b * stride];
+    return s;
+}
+
+// block = 16 channels x {sum, sum of squares}
+__global__ __launch_bounds__(512) void bn_train_finalize_part_kernel(const double* __restrict__ part, int nblocks, int C, double n,
+                                                                    const y6_bn_train_desc d) {
+    __shared__ double red[16][33];
+    const int t = threadIdx.x, vi = t & 31, prt = t >> 5;
+    const int k = vi >> 4, c = blockIdx.x * 16 + (vi & 15);
+    red[prt][vi] = c < C ? part_subsum(part + (size_t)k * C + c, (size_t)2 * C, nblocks, prt) : 0.0;
+    __syncthreads();
+    if (t < 32) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][t];
+        red[0][t] = tot;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0 && d.num_batches_tracked) *d.num_batches_tracked += 1;
+    if (t < 16 && blockIdx.x * 16 + t < C) bn_finalize_channel(blockIdx.x * 16 + t, red[0][t], red[0][16 + t], n, d);
+}
+
+// The atomic form (A/B: Y6_BN_ATOMICS=1): turns the sums into the BatchNorm constants and leaves the workspace zeroed again: a caller whose workspace starts zeroed
 // (`workspace_clean`) never needs a memset launch (profiles/r03/rocprofv3_kernel_stats_train_r03c.csv: 279 of them per training
 // step, ~4.6 us each).  Folding this kernel into the last block of the sums (device-scope ticket + __threadfence) was measured
 // and lost: the agent-scope release / acquire is an L2 write-back + invalidate per block on gfx950 (bn_stats 4.07 -> 5.88 ms,
@@ -135,6 +226,11 @@ __global__ void bn_train_finalize_kernel(double* __restrict__ ws, int C, double 
     ws[C + c] = 0.0;
 }
 
+static bool bn_use_atomics() {
+    static const bool v = getenv("Y6_BN_ATOMICS") != nullptr;
+    return v;
+}
+
 int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
     Y6_REQUIRE(d && d->scale && d->shift && d->mean && d->invstd && d->workspace, "bn_train_stats: null argument");
     Y6_REQUIRE(view_ok(d->x), "bn_train_stats: the view must be fp16 NHWC with 8-channel alignment");
@@ -144,10 +240,27 @@ int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
     const long npix = (long)d->x.B * d->x.H * d->x.W;
     Y6_REQUIRE(npix > 0, "bn_train_stats: empty tensor");
     double* ws = (double*)d->workspace;
+    const int R = 256 / G;
+    if (!bn_use_atomics()) {
+        long ppb = (long)R * 16;
+        long blocks = (npix + ppb - 1) / ppb;
+        if (blocks > kBnPartBlocks) {
+            blocks = kBnPartBlocks;
+            ppb = (npix + blocks - 1) / blocks;
+            blocks = (npix + ppb - 1) / ppb;
+        }
+        double* part = ws + (size_t)2 * C;
+        hipLaunchKernelGGL(bn_sum_part_kernel, dim3((unsigned)blocks), dim3(256), (size_t)R * 2 * C * sizeof(double), s,
+                           (const __half*)d->x.data, d->x.cstride, d->x.coff, npix, G, ppb, part, C);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_train_finalize_part_kernel, dim3((unsigned)((C + 15) / 16)), dim3(512), 0, s, (const double*)part, (int)blocks,
+                           C, (double)npix, *d);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
     // the workspace must be all-zero when the sums start; the finalize kernel leaves it so.  A caller that allocated it zeroed
     // and uses it for nothing else says so (workspace_clean) and the memset launch is dropped.
-    if (!d->workspace_clean) Y6_HIP(hipMemsetAsync(ws, 0, y6_bn_stats_workspace_bytes(C), s));
-    const int R = 256 / G;
+    if (!d->workspace_clean) Y6_HIP(hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), s));
     long ppb = (long)R * 64;
     long blocks = (npix + ppb - 1) / ppb;
     if (blocks > 2048) {
@@ -288,6 +401,8 @@ struct BnActBwdArgs {
     float* dalpha;
     double* ws;       // [ (1 + n) * C + 1 ] : sum dz | sum dz*xhat_b ... | sum dout*res
     int H, W;
+    double* part;     // atomic-free form: [blocks][(1 + n) * C + 1] block partials of the same sums
+    int nparts;
 };
 
 __device__ __forceinline__ void load4(const __half* p, float (&v)[4]) {
@@ -595,6 +710,139 @@ __global__ __launch_bounds__(256, 4) void bnact_bwd_reduce8_kernel(const BnActBw
     }
 }
 
+__global__ __launch_bounds__(256, 4) void bnact_bwd_reduce8_part_kernel(const BnActBwdArgs a, long pix_per_block) {
+    // atomic-free form of the kernel above: the R pixel-row threads of a channel leave their fp32 sums in LDS and are added in row
+    // order (double), the block's sums go to its slot of a.part; bnact_bwd_sums_kernel adds the blocks
+    extern __shared__ float s_rowf[];   // [R][1+n][8][G] | scale_b, summed shift [4][C]
+    const int C = a.f.C, G = C >> 3, n = a.f.n;
+    const int tid = threadIdx.x;
+    const int nacc = (1 + n) * C;
+    const int R = 256 / G;                       // 256 % G == 0 (host)
+    const int g = tid % G, prow = tid / G, c0 = g * 8;
+    const long p0 = (long)blockIdx.x * pix_per_block;
+    const long p1 = p0 + pix_per_block < a.f.npix ? p0 + pix_per_block : a.f.npix;
+    // fp32 partial sums of this thread's <= ~100 pixels, folded into the block's double accumulators afterwards
+    float sdz[8], sxy[3][8], salpha = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sdz[j] = sxy[0][j] = sxy[1][j] = sxy[2][j] = 0.f;
+    // scale_b and the summed shift per channel: LDS (behind the double accumulators), read where they are used
+    float* s_k = s_rowf + (size_t)R * nacc;                   // [4][C]
+    for (int ch = tid; ch < C; ch += 256) {
+        float sh = 0.f;
+        for (int b = 0; b < 3; ++b) {
+            s_k[b * C + ch] = (b < n && a.f.scale[b]) ? a.f.scale[b][ch] : 1.f;
+            if (b < n && a.f.shift[b]) sh += a.f.shift[b][ch];
+        }
+        s_k[3 * C + ch] = sh;
+    }
+    __syncthreads();
+    auto cst = [&](int k, float (&v)[8]) {
+        const float4 lo = *reinterpret_cast<const float4*>(s_k + k * C + c0), hi = *reinterpret_cast<const float4*>(s_k + k * C + c0 + 4);
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+        v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
+    const bool want_alpha = a.dalpha != nullptr;
+    for (long p = p0 + prow; p < p1; p += R) {
+        uint4 xr[3], gr, rr;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            xr[b] = ld16(a.f.x[b] + p * a.f.cs[b] + a.f.co[b] + c0);
+        }
+        gr = ld16(a.dout + p * a.dcs + a.dco + c0);
+        if (want_alpha) rr = ld16(a.f.res + p * a.f.rcs + a.f.rco + c0);
+        float z[8], go[8], dz[8];
+        cst(3, z);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            float scv[8], xb[8];
+            cst(b, scv);
+            unpack8(xr[b], xb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) z[j] += xb[j] * scv[j];
+        }
+        unpack8(gr, go);
+        if (want_alpha) {
+            float r[8];
+            unpack8(rr, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) salpha += go[j] * r[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dz[j] = go[j] * act_grad(z[j], a.f.act);
+            sdz[j] += dz[j];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (b >= n) break;
+            float xb[8];
+            unpack8(xr[b], xb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sxy[b][j] += dz[j] * xb[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s_rowf[((prow * (1 + n) + 0) * 8 + j) * G + g] = sdz[j];
+        for (int b = 0; b < n; ++b) s_rowf[((prow * (1 + n) + 1 + b) * 8 + j) * G + g] = a.mean[b] ? sxy[b][j] : 0.f;
+    }
+    __shared__ double s_al[4];
+    {
+        double sa = want_alpha ? (double)salpha : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sa += __shfl_xor(sa, o, 64);
+        if ((tid & 63) == 0) s_al[tid >> 6] = sa;
+    }
+    __syncthreads();
+    double* dst = a.part + (size_t)blockIdx.x * (size_t)(nacc + 1);
+    for (int i = tid; i < nacc; i += 256) {      // i = (k*8 + j)*G + g
+        const int gg = i % G, kj = i / G;
+        double tot = 0.0;
+        for (int r = 0; r < R; ++r) tot += (double)s_rowf[(size_t)r * nacc + i];
+        dst[(kj >> 3) * C + gg * 8 + (kj & 7)] = tot;
+    }
+    if (tid == 0) dst[nacc] = (s_al[0] + s_al[1]) + (s_al[2] + s_al[3]);
+}
+
+// Adds the blocks' partials (fixed order), leaves the totals in a.ws for the apply pass and forms dgamma / dbeta / dalpha.
+// block = 8 channels x (1 + n) sums; 512 threads = 16 interleaved sub-sums per value
+__global__ __launch_bounds__(512) void bnact_bwd_sums_kernel(const BnActBwdArgs a) {
+    __shared__ double red[16][33];
+    __shared__ double al[512];
+    const int C = a.f.C, n = a.f.n, nacc = (1 + n) * C;
+    const int t = threadIdx.x, vi = t & 31, prt = t >> 5;
+    const int k = vi >> 3, c = blockIdx.x * 8 + (vi & 7);
+    const bool live = k <= n && c < C;
+    red[prt][vi] = live ? part_subsum(a.part + (size_t)k * C + c, (size_t)(nacc + 1), a.nparts, prt) : 0.0;
+    __syncthreads();
+    if (t < 32) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][t];
+        red[0][t] = tot;
+        if (live) a.ws[k * C + c] = tot;
+    }
+    __syncthreads();
+    if (t < 8 && blockIdx.x * 8 + t < C) {
+        const int ch = blockIdx.x * 8 + t;
+        for (int b = 0; b < n; ++b)
+            if (a.mean[b]) bwd_param_grads(a, b, ch, red[0][t], red[0][(1 + b) * 8 + t]);
+    }
+    if (blockIdx.x == 0 && a.dalpha) {           // sum dout*res: one value per block partial
+        double sa = 0.0;
+        for (int b = t; b < a.nparts; b += 512) sa += a.part[(size_t)b * (size_t)(nacc + 1) + nacc];
+        al[t] = sa;
+        __syncthreads();
+        for (int w = 256; w > 0; w >>= 1) {
+            if (t < w) al[t] += al[t + w];
+            __syncthreads();
+        }
+        if (t == 0) *a.dalpha += (float)al[0];
+    }
+}
+
 __global__ __launch_bounds__(256, 4) void bnact_bwd_apply8_kernel(const BnActBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_c[];   // [13][C]: sc_b | k1_b | A_b | B_b (b = 0..2) | sum of shifts
     const int C = a.f.C, G = C >> 3, n = a.f.n;
@@ -775,6 +1023,26 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     if (blocks > 2048) {
         blocks = 2048;
         ppb = (a.f.npix + blocks - 1) / blocks;
+    }
+    if (v2 && !bn_use_atomics()) {
+        // atomic-free form: short per-thread loops (8 pixel rows), block partials, ordered sums (see bn_sum_part_kernel)
+        ppb = (long)R * 8;
+        blocks = (a.f.npix + ppb - 1) / ppb;
+        if (blocks > kBnPartBlocks) {
+            blocks = kBnPartBlocks;
+            ppb = (a.f.npix + blocks - 1) / blocks;
+            blocks = (a.f.npix + ppb - 1) / ppb;
+        }
+        a.part = a.ws + nacc;
+        a.nparts = (int)blocks;
+        hipLaunchKernelGGL(bnact_bwd_reduce8_part_kernel, dim3((unsigned)blocks), dim3(256),
+                           (size_t)R * (1 + n) * C * sizeof(float) + (size_t)4 * C * sizeof(float), s, a, ppb);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bnact_bwd_sums_kernel, dim3((unsigned)((C + 7) / 8)), dim3(512), 0, s, a);
+        Y6_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bnact_bwd_apply8_kernel, dim3(grid_for((size_t)a.f.npix * G, 256, 256 * 16)), dim3(256), (size_t)13 * C * sizeof(float), s, a);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
     }
     if (v2) {
         hipLaunchKernelGGL(bnact_bwd_reduce8_kernel, dim3((unsigned)blocks), dim3(256), (size_t)(1 + n) * C * sizeof(double) + (size_t)4 * C * sizeof(float), s, a, ppb);
@@ -1605,7 +1873,8 @@ __global__ void scaler_update_kernel(float* scale, int32_t* found_inf, int32_t* 
 }  // namespace
 
 // ====================================================================== C ABI
-extern "C" size_t y6_bnact_bwd_workspace_bytes(int C) { return ((size_t)4 * C + 1) * sizeof(double); }
+// [4C + 1] totals followed by [kBnPartBlocks][4C + 1] block partials
+extern "C" size_t y6_bnact_bwd_workspace_bytes(int C) { return ((size_t)4 * C + 1) * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
 
 extern "C" int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
