@@ -763,6 +763,12 @@ int y6_plan_rebind_output(y6_plan* p, const void* old_ptr, void* new_ptr);
 int y6_plan_run(y6_plan* p, void* stream);
 /* Eager launch of ops [first, last) only (teacher-forced per-layer parity tests, partial re-runs). */
 int y6_plan_run_range(y6_plan* p, void* stream, int first, int last);
+/* Marks the op added last as SIDE-STREAM work for eager runs (y6_plan_run / y6_plan_run_range with Y6_SIDE_STREAM=1 in the
+ * environment): it is ordered behind every op before it in plan order, nothing on the main stream waits for it before the end of
+ * the run / range, where the side stream is joined.  The caller guarantees that no later op of the run writes what it reads or
+ * touches what it writes (the training graph marks weight-gradient work: it feeds only the optimizer step - the reference's
+ * autograd engine orders `conv2d_backward`'s weight and input gradients the same way, yolov6/core/engine.py:161-166). */
+int y6_plan_mark_side(y6_plan* p);
 /* Live per-op timing: reserve `slots` runs worth of hipEvents, run eagerly with an event between
  * consecutive ops (on `stream`), then - after the caller synchronised - read the per-op sums. */
 int y6_plan_timing_begin(y6_plan* p, int slots);

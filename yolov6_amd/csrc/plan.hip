@@ -62,6 +62,11 @@ struct y6_plan {
     std::vector<hipEvent_t> events;  // timing slots: (ops+1) events per slot
     int slots = 0;
     int slots_used = 0;
+    // side stream (y6_plan_mark_side): ops nobody on the main stream waits for before the end of a run
+    std::vector<char> side;          // per op (shorter than ops: the rest are main-stream ops)
+    hipStream_t side_stream = nullptr;
+    std::vector<hipEvent_t> sync_ev; // ring of fork / join events
+    size_t sync_pos = 0;
 };
 
 static int run_op(const Op& op, hipStream_t s) {
@@ -126,7 +131,90 @@ extern "C" void y6_plan_destroy(y6_plan* p) {
     if (!p) return;
     drop_graph(p);
     drop_events(p);
+    for (hipEvent_t e : p->sync_ev) (void)hipEventDestroy(e);
+    if (p->side_stream) (void)hipStreamDestroy(p->side_stream);
     delete p;
+}
+
+// The op added last runs on the plan's SIDE stream in eager runs (y6_plan_run / y6_plan_run_range; timed runs and captured
+// graphs stay on one stream).  Contract, kept by the caller (train_engine.py marks weight-gradient work: operand transposes,
+// weight-gradient GEMMs, bias sums): a side op may read anything ops BEFORE it in plan order wrote; nothing it reads is
+// written by a later op; nothing it writes is read or written by a main-stream op of the same run.  The executor forks the
+// side stream off the main stream in front of a side op whenever main-stream ops were enqueued since the last fork, and
+// joins it back at the end of the run / range - so for every caller the main stream still orders everything.
+// Why: the backward pass of a conv net is one dependent chain (data gradients, BatchNorm backward) plus weight-gradient work
+// that hangs off it and feeds only the optimizer; on one stream the two alternate and the small weight-gradient launches
+// (1x1 convs, narrow maps: 45-130 TFLOP/s, 20 us operand transposes) run alone on a 256-CU chip.
+extern "C" int y6_plan_mark_side(y6_plan* p) {
+    Y6_REQUIRE(p && !p->ops.empty(), "plan_mark_side: no op to mark");
+    p->side.resize(p->ops.size(), 0);
+    p->side.back() = 1;
+    return Y6_OK;
+}
+
+static bool side_stream_enabled() {
+    static const bool v = [] {
+        const char* e = getenv("Y6_SIDE_STREAM");
+        return e ? atoi(e) != 0 : false;
+    }();
+    return v;
+}
+
+static int next_sync_event(y6_plan* p, hipEvent_t* out) {
+    constexpr size_t kRing = 512;    // an event is re-recorded only after 511 younger ones: its waits are long enqueued
+    if (p->sync_ev.size() < kRing) {
+        hipEvent_t e;
+        Y6_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->sync_ev.push_back(e);
+        *out = e;
+        return Y6_OK;
+    }
+    *out = p->sync_ev[p->sync_pos];
+    p->sync_pos = (p->sync_pos + 1) % kRing;
+    return Y6_OK;
+}
+
+static int run_ops(y6_plan* p, hipStream_t s, size_t first, size_t last) {
+    bool any_side = false;
+    if (side_stream_enabled())
+        for (size_t i = first; i < last && i < p->side.size(); ++i) any_side = any_side || p->side[i];
+    if (!any_side) {
+        for (size_t i = first; i < last; ++i) {
+            int rc = run_op(p->ops[i], s);
+            if (rc) return rc;
+        }
+        return Y6_OK;
+    }
+    if (!p->side_stream) Y6_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+    bool main_ahead = true, side_used = false;   // main_ahead: the main stream holds work the side stream has not been ordered behind
+    for (size_t i = first; i < last; ++i) {
+        const bool on_side = i < p->side.size() && p->side[i];
+        if (on_side) {
+            if (main_ahead) {
+                hipEvent_t e;
+                int rc = next_sync_event(p, &e);
+                if (rc) return rc;
+                Y6_HIP(hipEventRecord(e, s));
+                Y6_HIP(hipStreamWaitEvent(p->side_stream, e, 0));
+                main_ahead = false;
+            }
+            int rc = run_op(p->ops[i], p->side_stream);
+            if (rc) return rc;
+            side_used = true;
+        } else {
+            int rc = run_op(p->ops[i], s);
+            if (rc) return rc;
+            main_ahead = true;
+        }
+    }
+    if (side_used) {
+        hipEvent_t e;
+        int rc = next_sync_event(p, &e);
+        if (rc) return rc;
+        Y6_HIP(hipEventRecord(e, p->side_stream));
+        Y6_HIP(hipStreamWaitEvent(s, e, 0));
+    }
+    return Y6_OK;
 }
 
 extern "C" int y6_plan_timing_begin(y6_plan* p, int slots) {
@@ -394,21 +482,12 @@ extern "C" int y6_plan_run(y6_plan* p, void* stream) {
         Y6_HIP(hipGraphLaunch(p->exec, s));
         return Y6_OK;
     }
-    for (size_t i = 0; i < p->ops.size(); ++i) {
-        int rc = run_op(p->ops[i], s);
-        if (rc) return rc;
-    }
-    return Y6_OK;
+    return run_ops(p, s, 0, p->ops.size());
 }
 
 extern "C" int y6_plan_run_range(y6_plan* p, void* stream, int first, int last) {
     Y6_REQUIRE(p && first >= 0 && first <= last && last <= (int)p->ops.size(), "plan_run_range: bad range");
-    hipStream_t s = (hipStream_t)stream;
-    for (int i = first; i < last; ++i) {
-        int rc = run_op(p->ops[i], s);
-        if (rc) return rc;
-    }
-    return Y6_OK;
+    return run_ops(p, (hipStream_t)stream, (size_t)first, (size_t)last);
 }
 
 // ---- data dependences between ops (for the multi-stream capture) -------------------------------------

@@ -224,8 +224,16 @@ class TrainBuilder:
         self.n_fwd_ops += 1
         self.fwd_log.append(dict(kind=what.replace("plan_add_", ""), **log))
 
+    # weight-gradient work: ordered behind everything before it, feeds only the optimizer step -> the plan's side stream
+    # (include/yolov6_hip.h y6_plan_mark_side).  Their inputs are complete when they are emitted (grad_ready asserts it for
+    # gradients; activations and operand planes do not change during the backward), every buffer of the graph is its own
+    # allocation, and the workspaces they share (wgrad_ws) are shared among side ops only.
+    _SIDE_OPS = ("plan_add_wgrad_transpose", "plan_add_wgrad", "plan_add_channel_sum")
+
     def _b(self, rc, what, **log):
         _lib.check(rc, what)
+        if what in self._SIDE_OPS:
+            _lib.check(self.lib.y6_plan_mark_side(self.bwd), "plan_mark_side")
         self.n_bwd_ops += 1
         self.bwd_log.append(dict(kind=what.replace("plan_add_", ""), **log))
 
