@@ -244,7 +244,7 @@ def train_main(args):
     scaler = LossScaler(device)
     ema = ArenaEMA(model, arena) if rank == 0 else None
     reducer = GradReducer(arena, graph.bwd_marks, graph.n_bwd_ops, rep, chunks=4)
-    if world > 1:
+    if rep.dist is not None:         # N > 1 (or a one-rank group forced by Y6_FORCE_DIST=1: the same code path on one GPU)
         reducer.install(model)
     losses = []
 

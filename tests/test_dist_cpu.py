@@ -108,6 +108,35 @@ print("RESULT " + json.dumps(dict(rank=r.rank, err=err, calls=calls, segments=re
 r.close()
 '''
 
+def test_forced_one_rank_group(monkeypatch):
+    """Y6_FORCE_DIST=1: a one-rank job brings the process group up (gloo here, RCCL on a GPU box) and runs the barrier / MAX
+    reduce / gradient all-reduce code of an N-rank launch - the path `tools/gpu_visit_r03t.sh` exercises on one MI355X."""
+    import torch
+    from yolov6_amd.parallel import GradReducer, Replicas
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("Y6_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29571")
+    r = Replicas(backend="gloo")
+    try:
+        assert r.world == 1 and r.dist is not None and r.dist.is_initialized()
+        r.barrier()
+        assert r.max_over_ranks(2.5) == 2.5
+
+        class _Arena:
+            pass
+        a = _Arena()
+        p = torch.nn.Parameter(torch.zeros(8))
+        a.params, a.offsets, a.numel, a.grad = [p], [0], 8, torch.arange(8, dtype=torch.float32)
+        red = GradReducer(a, [(1, [p])], 1, r, chunks=1, average=True)
+        red.reduce_range(0, 8)
+        assert torch.equal(a.grad, torch.arange(8, dtype=torch.float32))     # sum over one rank, / 1
+    finally:
+        r.close()
+    assert r.dist is None
+
+
 
 def test_two_rank_gloo_gradient_exchange_equals_concatenated_batch():
     """DDP semantics of the training step (engine.py:455-468) on the arena: per-rank shard gradients, chunked all-reduce

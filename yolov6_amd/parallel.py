@@ -24,7 +24,9 @@ class Replicas:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
         self.dist = None
-        if self.world > 1:
+        # Y6_FORCE_DIST=1: bring the process group up for a one-rank job too, so that a 1-GPU box runs the very code an
+        # 8-GPU launch runs (RCCL communicator, barriers, the MAX reduce, the chunked gradient all-reduce)
+        if self.world > 1 or os.environ.get("Y6_FORCE_DIST", "0") == "1":
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")   # container hostnames may not resolve
             os.environ.setdefault("MASTER_PORT", "29533")
