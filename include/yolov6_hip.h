@@ -427,25 +427,6 @@ int y6_distill_backward(const y6_distill_desc* d, void* stream);
 int y6_distill_cw(const float* s_feat, const float* t_feat, int rows, int hw, float temperature, double* acc, const float* coef,
                   float* d_s_feat, void* stream);
 
-/* ------------------------------------------------------------------------------------ */
-/* BatchNorm2d in TRAINING mode (batch statistics), forward only - the primitives the training-form forward needs
- * around the conv kernels:
- *   y6_bn_stats  per-channel mean / biased variance over B*H*W of an NHWC fp16 view: the statistics
- *                F.batch_norm(training=True) uses in every ConvModule (yolov6/layers/common.py:26-54) and every
- *                RepVGG branch (:250-255, :341-347).  workspace: y6_bn_stats_workspace_bytes(C).
- *   y6_bn_apply  out = act( sum_b x_b * scale_b[c] + shift_b[c] ), 1..3 branches: the RepVGG train-form sum
- *                ReLU(bn(conv3x3) + bn(conv1x1) + bn_id(x)) (:250-255) in one pass.  scale/shift: [C] fp32.     */
-typedef struct y6_bn_apply_desc {
-    int32_t n;
-    y6_tensor x[3];
-    const float* scale[3];
-    const float* shift[3];
-    y6_tensor out;
-    int32_t act;               /* Y6_ACT_* */
-} y6_bn_apply_desc;
-size_t y6_bn_stats_workspace_bytes(int C);
-int y6_bn_stats(const y6_tensor* x, float* mean, float* var, void* workspace, size_t workspace_bytes, void* stream);
-int y6_bn_apply(const y6_bn_apply_desc* d, void* stream);
 
 typedef struct y6_plan y6_plan;
 
@@ -490,6 +471,7 @@ typedef struct y6_bn_train_desc {
     int32_t workspace_clean;       /* nonzero: the workspace is all-zero on entry (allocated zeroed, used by these calls only - they
                                       leave it zeroed); no memset launch.  0: a memset is issued first. */
 } y6_bn_train_desc;
+size_t y6_bn_stats_workspace_bytes(int C);
 int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream);
 
 /* out = act( sum_b ( x_b * scale_b[c] + shift_b[c] ) ) [+ alpha * res]   (1..3 branches; NULL scale = 1, NULL shift = 0)

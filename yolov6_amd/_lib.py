@@ -115,11 +115,6 @@ class DistillDesc(C.Structure):
                 ("temperature", C.c_float), ("acc", C.c_void_p), ("coef", C.c_void_p), ("dscores", C.c_void_p), ("ddistri", C.c_void_p)]
 
 
-class BnApplyDesc(C.Structure):
-    _fields_ = [("n", C.c_int32), ("x", Tensor * 3), ("scale", C.c_void_p * 3), ("shift", C.c_void_p * 3),
-                ("out", Tensor), ("act", C.c_int32)]
-
-
 class BnTrainDesc(C.Structure):
     _fields_ = [("x", Tensor), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
                 ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("momentum", C.c_float), ("eps", C.c_float),
@@ -238,8 +233,6 @@ SIGNATURES = {
     "y6_distill_backward": (C.c_int, [C.POINTER(DistillDesc), C.c_void_p]),
     "y6_distill_cw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_bn_stats_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "y6_bn_stats": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "y6_bn_apply": (C.c_int, [C.POINTER(BnApplyDesc), C.c_void_p]),
     "y6_bn_train_stats": (C.c_int, [C.POINTER(BnTrainDesc), C.c_void_p]),
     "y6_bnact_forward": (C.c_int, [C.POINTER(BnActDesc), C.c_void_p]),
     "y6_bnact_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),

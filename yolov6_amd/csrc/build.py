@@ -33,7 +33,6 @@ SOURCES = {
     "nms.hip": ["-ffp-contract=off"],
     "tal.hip": ["-ffp-contract=off"],
     "loss.hip": ["-ffp-contract=off"],
-    "bn_train.hip": [],
     "train.hip": [],
     "wgrad.hip": [],
     "quant.hip": [],

@@ -1873,6 +1873,9 @@ __global__ void scaler_update_kernel(float* scale, int32_t* found_inf, int32_t* 
 }  // namespace
 
 // ====================================================================== C ABI
+// [2C] totals (the atomic form, Y6_BN_ATOMICS=1) followed by [kBnPartBlocks][2C] block partials
+extern "C" size_t y6_bn_stats_workspace_bytes(int C) { return (size_t)2 * C * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
+
 // [4C + 1] totals followed by [kBnPartBlocks][4C + 1] block partials
 extern "C" size_t y6_bnact_bwd_workspace_bytes(int C) { return ((size_t)4 * C + 1) * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
 
