@@ -527,6 +527,8 @@ def main():
                                    "sync per step)" + ("; two-deep pipeline over batches: the NMS of batch k on a second HIP stream beside "
                                                        "the forward of batch k+1 (two result tensors in turn), both streams drained "
                                                        "inside the timed region" if side else "") +
+                                   ("; the forward's ops off its critical path (neck laterals, SPPF bypass, early head levels) run on "
+                                    "the plan's second HIP stream, ordered by events" if getattr(plan, "sched", None) else "") +
                                    "; the reference-signature API step is reported under dropin_api",
                        "global_batch": world * args.batch, "parallelism": f"replicas x{world} (no collective)",
                        "weights": "random (oracle/synth.py), cls bias calibrated to ~2% candidates"},
@@ -548,6 +550,12 @@ def main():
             "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1), "stream": args.nms_stream},
             "dropin_api": dropin,
             "self_check": {"nms_equals_oracle_images": verified},
+            # two-stream schedule of the un-instrumented steps (yolov6_amd/schedule.py; the event-sampled steps run in plan
+            # order on one stream, so the per-kernel times above are kernels running alone)
+            "schedule": (None if not getattr(plan, "sched", None) else
+                         {"policy": plan.sched["policy"], "margin": plan.sched["margin"], "side_ops": len(plan.sched["side_ops"]),
+                          "event_edges": len(plan.sched["edges"]),
+                          "side_share_of_op_time": round(plan.sched["side_cost"] / max(plan.sched["total_cost"], 1e-9), 4)}),
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cfg, sd_train, shift)

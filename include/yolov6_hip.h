@@ -745,12 +745,21 @@ int y6_plan_rebind_output(y6_plan* p, const void* old_ptr, void* new_ptr);
 int y6_plan_run(y6_plan* p, void* stream);
 /* Eager launch of ops [first, last) only (teacher-forced per-layer parity tests, partial re-runs). */
 int y6_plan_run_range(y6_plan* p, void* stream, int first, int last);
-/* Marks the op added last as SIDE-STREAM work for eager runs (y6_plan_run / y6_plan_run_range with Y6_SIDE_STREAM=1 in the
- * environment): it is ordered behind every op before it in plan order, nothing on the main stream waits for it before the end of
+/* Marks the op added last as SIDE-STREAM work for eager runs (y6_plan_run / y6_plan_run_range; Y6_SIDE_STREAM=0 in the
+ * environment keeps everything on one stream): it is ordered behind every op before it in plan order, nothing on the main stream waits for it before the end of
  * the run / range, where the side stream is joined.  The caller guarantees that no later op of the run writes what it reads or
  * touches what it writes (the training graph marks weight-gradient work: it feeds only the optimizer step - the reference's
  * autograd engine orders `conv2d_backward`'s weight and input gradients the same way, yolov6/core/engine.py:161-166). */
 int y6_plan_mark_side(y6_plan* p);
+/* Two-stream schedule of whole-plan eager runs (y6_plan_run only; ranges, timed runs and captured graphs keep plan order on one
+ * stream).  order[n]: the ops in the order they are enqueued (a permutation); stream[n], by op index: 0 = the caller's stream,
+ * 1 = the plan's side stream; edges[2 * nedges]: (src, dst) pairs on different streams, src enqueued before dst: dst waits for
+ * an event recorded behind src.  A run forks the side stream off the caller's stream first and joins it back last.  The caller
+ * (yolov6_amd/schedule.py: the ops off the critical path of the forward - BiFusion's lateral convs yolov6/layers/common.py:
+ * 695-718, the CSP-SPPF bypass :135-158, the head levels that finish early yolov6/models/effidehead.py:93-139 - as early as
+ * their inputs allow) guarantees that every data dependence between ops on different streams is covered by an edge.
+ * n = 0 drops the schedule. */
+int y6_plan_set_schedule(y6_plan* p, const int32_t* order, const int32_t* stream, int n, const int32_t* edges, int nedges);
 /* Live per-op timing: reserve `slots` runs worth of hipEvents, run eagerly with an event between
  * consecutive ops (on `stream`), then - after the caller synchronised - read the per-op sums. */
 int y6_plan_timing_begin(y6_plan* p, int slots);

@@ -173,6 +173,39 @@ def test_multistream_graph_matches_eager(case, monkeypatch):
         assert torch.equal(o, eager)
 
 
+@pytest.mark.parametrize("policy", ["asap", "alap"])
+@pytest.mark.parametrize("case", ["tiny", "s", "l6_tiny", "m_tiny"])
+def test_two_stream_schedule_matches_one_stream(case, policy):
+    """Plan.schedule() (yolov6_amd/schedule.py + y6_plan_set_schedule): the ops off the critical path run on the plan's side stream,
+    ordered by events.  The same kernels on the same data: every result - detections and the neck feature maps - must be
+    bit-identical to the one-stream run, also when runs are enqueued back to back on alternating inputs (a run's side
+    stream must not overtake the previous run's readers, nor the next run's writers this run's)."""
+    cfg, meta, sd, m = _build(case, deploy=True)
+    xs = [synth.synth_images(meta["batch"], meta["size"], seed=20 + i).to(DEV).half() for i in range(3)]
+    plan = m.compile(xs[0])
+    want = []
+    for x in xs:
+        plan = m.compile(x)
+        want.append(plan.run().clone())
+    torch.cuda.synchronize()
+    info = plan.schedule(policy=policy)
+    assert info is not None and info["side_ops"] and len(info["order"]) == plan.num_ops
+    assert 0.0 < info["side_cost"] < 0.5 * info["total_cost"]
+    got = []
+    for rep in range(4):
+        for x in xs:
+            plan = m.compile(x)             # same plan, input rebound
+            got.append(plan.run().clone())
+    torch.cuda.synchronize()
+    for i, g in enumerate(got):
+        assert torch.equal(g, want[i % len(xs)]), f"{case}/{policy}: scheduled run {i} differs from the one-stream run"
+    det, feats = m(xs[1])                   # the reference-signature API over the scheduled plan (lazy feature maps read after the join)
+    torch.cuda.synchronize()
+    assert torch.equal(det, want[1])
+    plan.clear_schedule()
+    assert torch.equal(m.compile(xs[2]).run(), want[2])
+
+
 def test_single_block_in_train_mode_is_refused_not_faked():
     """Batch-statistics BatchNorm runs through the whole-model training graph (tests/test_gpu_training.py); a lone block
     in .train() mode has no standalone forward and must say so instead of silently using running statistics."""

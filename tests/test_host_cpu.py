@@ -356,6 +356,91 @@ def test_lowering_wiring_matches_reference_golden(case):
     assert sync == 0.0, f"{case}: lowered op chain vs Oracle.forward {sync:.3e}"
 
 
+@pytest.mark.parametrize("case", WIRING_CASES)
+def test_two_stream_schedule_enforces_every_dependence(case):
+    """yolov6_amd/schedule.py on the lowering graph of every model family (CPU mock of the plan builder): the ops off the
+    critical path go to the side stream, the enqueue order is topological, and stream FIFO + the cross-stream event edges
+    cover every RAW / WAR / WAW dependence between the ops' tensor views (checked by an independent closure walk)."""
+    import json
+    from tests.helpers import GOLDEN, synth_sd_from_keys
+    from tests.mock_plan import MockBuilder
+    from yolov6_amd import schedule as S
+    from yolov6_amd.configs import tiny_config
+    from yolov6_amd.engine import NCHWInput
+    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+    special = case in ("tiny_distill_ns", "tiny_fuseab_eval")
+    if special:
+        with open(os.path.join(GOLDEN, "keys_tiny_distill_ns.json" if case == "tiny_distill_ns" else "keys_tiny_fuseab.json")) as f:
+            meta = json.load(f)
+        m = build_model(tiny_config(), meta["num_classes"], "cpu", distill_ns=case == "tiny_distill_ns",
+                        fuse_ab=case == "tiny_fuseab_eval").eval()
+    else:
+        cfg, meta = case_config(case)
+        m = build_model(cfg, meta["num_classes"], "cpu").eval()
+    m.load_state_dict(synth_sd_from_keys(meta["train"]))
+    switch_to_deploy(fuse_model(m))
+    pb = MockBuilder()
+    with torch.no_grad():
+        m.lower(pb, NCHWInput(synth.synth_images(1, meta["size"], seed=1)))
+    acc = [S.op_access(e) for e in pb.op_log]
+    assert all(a is not None for a in acc)
+    deps = S.dependences(acc)
+    n = len(deps)
+    # a conv reads what the op before it in its chain wrote; the decode waits for every head level
+    # (the mock logs the image conv as an adapter op + a stem op reading the image itself: ops 0 / 1 have no producer)
+    assert all(deps[j] for j in range(2, n)) and len(deps[-1]) >= len(m.detect.stems)
+    # costs as the device would see them: proportional to the MACs of a conv, a floor for everything else
+    cost = []
+    for e in pb.op_log:
+        if e["kind"] in ("conv", "stem"):
+            co, ci, k, _ = e["w"].shape
+            cost.append(5.0 + co * ci * k * k * e["out"].H * e["out"].W * 1e-6)
+        else:
+            cost.append(5.0)
+    res = S.build_schedule(deps, cost)
+    assert res is not None, "every YOLOv6 family has lateral / head branches off the critical path"
+    order, stream, edges = res
+    S.check_schedule(deps, order, stream, edges)
+    pos = {op: i for i, op in enumerate(order)}
+    side = [i for i in range(n) if stream[i]]
+    main = [i for i in range(n) if not stream[i]]
+    assert [i for i in order if not stream[i]] == main, "main-stream ops keep plan order"
+    assert stream[0] == 0 and stream[n - 1] == 0 and 2 <= len(side) < n // 2
+    # hoisting: some side op is enqueued EARLIER than its plan position (it overlaps the chain instead of following it)
+    assert any(pos[i] < i for i in side)
+    # every edge crosses streams, and nothing waits for a later op
+    assert all(stream[a] != stream[b] and pos[a] < pos[b] for a, b in edges)
+    # uniform costs (what a build without a device profile would use) must give a valid schedule too
+    r2 = S.build_schedule(deps, None)
+    if r2 is not None:
+        S.check_schedule(deps, *r2)
+
+
+def test_two_stream_schedule_random_dags():
+    """Property check of schedule.build_schedule on random dependence graphs: valid for every graph, and a broken schedule (an
+    edge removed) is caught by check_schedule."""
+    import random
+    from yolov6_amd import schedule as S
+    rng = random.Random(7)
+    caught = 0
+    for trial in range(300):
+        n = rng.randint(2, 40)
+        deps = [sorted(set(rng.sample(range(j), min(j, rng.randint(0, 3))))) if j else [] for j in range(n)]
+        cost = [rng.uniform(1.0, 50.0) for _ in range(n)]
+        res = S.build_schedule(deps, cost)
+        if res is None:
+            continue
+        order, stream, edges = res
+        S.check_schedule(deps, order, stream, edges)
+        if edges:
+            cut = edges[:-1] if trial % 2 else edges[1:]
+            try:
+                S.check_schedule(deps, order, stream, cut)
+            except AssertionError:
+                caught += 1
+    assert caught > 50       # (an edge is only dropped by build_schedule when another wait already implies it: most cuts break)
+
+
 def test_native_state_never_pickled_or_deepcopied():
     """after a train-mode forward the model's __dict__ holds `_y6_train_graphs` / `_y6_arena` /
     `_y6_backward_hook` (ctypes handles inside); the reference's epoch-end path `deepcopy(model).half()` + torch.save must not

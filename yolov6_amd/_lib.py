@@ -302,6 +302,7 @@ SIGNATURES = {
     "y6_plan_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y6_plan_run_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "y6_plan_mark_side": (C.c_int, [C.c_void_p]),
+    "y6_plan_set_schedule": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int]),
     "y6_plan_capture": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y6_plan_timing_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "y6_plan_run_timed": (C.c_int, [C.c_void_p, C.c_void_p]),

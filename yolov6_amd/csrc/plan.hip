@@ -67,6 +67,11 @@ struct y6_plan {
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> sync_ev; // ring of fork / join events
     size_t sync_pos = 0;
+    // two-stream schedule of whole-plan eager runs (y6_plan_set_schedule): enqueue order, stream per op, event waits
+    std::vector<int32_t> sched_order, sched_stream;
+    std::vector<std::vector<int32_t>> sched_waits;   // per op: ops of the OTHER stream it waits for
+    std::vector<char> sched_records;                 // per op: somebody waits for it -> an event is recorded behind it
+    std::vector<hipEvent_t> sched_ev;                // per op: that event, in the run being enqueued
 };
 
 static int run_op(const Op& op, hipStream_t s) {
@@ -155,7 +160,7 @@ extern "C" int y6_plan_mark_side(y6_plan* p) {
 static bool side_stream_enabled() {
     static const bool v = [] {
         const char* e = getenv("Y6_SIDE_STREAM");
-        return e ? atoi(e) != 0 : false;
+        return e ? atoi(e) != 0 : true;   // on since r03t: 45.5 -> 41.8 ms per training step, same box (profiles/r03/bench_train_r03t_{one1,side1}.json)
     }();
     return v;
 }
@@ -214,6 +219,74 @@ static int run_ops(y6_plan* p, hipStream_t s, size_t first, size_t last) {
         Y6_HIP(hipEventRecord(e, p->side_stream));
         Y6_HIP(hipStreamWaitEvent(s, e, 0));
     }
+    return Y6_OK;
+}
+
+// ---- two-stream schedule (inference plans; yolov6_amd/schedule.py decides it from the ops' tensor views) ----------------
+// order[n]: a permutation of the ops = the order they are enqueued in; stream[n] (by op index): 0 = the caller's stream,
+// 1 = the plan's side stream; edges[2 * nedges]: (src, dst) pairs on DIFFERENT streams with src enqueued before dst - dst waits
+// for an event recorded right behind src.  Every run forks the side stream off the caller's stream first and joins it back
+// last, so for the caller (and for the previous / next run of the same plan) the main stream still orders everything.
+// n = 0 drops the schedule.  Only y6_plan_run uses it; ranges, timed runs and captured graphs keep plan order on one stream.
+extern "C" int y6_plan_set_schedule(y6_plan* p, const int32_t* order, const int32_t* stream, int n, const int32_t* edges, int nedges) {
+    Y6_REQUIRE(p, "plan_set_schedule: null plan");
+    p->sched_order.clear();
+    p->sched_stream.clear();
+    p->sched_waits.clear();
+    p->sched_records.clear();
+    if (n == 0) return Y6_OK;
+    Y6_REQUIRE(order && stream && n == (int)p->ops.size() && nedges >= 0 && (edges || nedges == 0), "plan_set_schedule: bad arguments");
+    std::vector<int> pos((size_t)n, -1);
+    for (int i = 0; i < n; ++i) {
+        Y6_REQUIRE(order[i] >= 0 && order[i] < n && pos[order[i]] < 0, "plan_set_schedule: order is not a permutation of the ops");
+        Y6_REQUIRE(stream[i] == 0 || stream[i] == 1, "plan_set_schedule: stream must be 0 or 1");
+        pos[order[i]] = i;
+    }
+    std::vector<std::vector<int32_t>> waits((size_t)n);
+    std::vector<char> records((size_t)n, 0);
+    for (int e = 0; e < nedges; ++e) {
+        const int a = edges[2 * e], b = edges[2 * e + 1];
+        Y6_REQUIRE(a >= 0 && a < n && b >= 0 && b < n && pos[a] < pos[b] && stream[a] != stream[b],
+                   "plan_set_schedule: edge %d (%d -> %d) must point forward in the enqueue order, across streams", e, a, b);
+        waits[b].push_back(a);
+        records[a] = 1;
+    }
+    p->sched_order.assign(order, order + n);
+    p->sched_stream.assign(stream, stream + n);
+    p->sched_waits.swap(waits);
+    p->sched_records.swap(records);
+    return Y6_OK;
+}
+
+static int run_scheduled(y6_plan* p, hipStream_t s) {
+    const size_t n = p->ops.size();
+    if (!p->side_stream) Y6_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+    hipEvent_t e;
+    int rc = next_sync_event(p, &e);   // fork: the side stream runs behind everything the caller has enqueued so far
+    if (rc) return rc;
+    Y6_HIP(hipEventRecord(e, s));
+    Y6_HIP(hipStreamWaitEvent(p->side_stream, e, 0));
+    p->sched_ev.assign(n, nullptr);
+    for (size_t q = 0; q < n; ++q) {
+        const int i = p->sched_order[q];
+        hipStream_t st = p->sched_stream[i] ? p->side_stream : s;
+        for (int w : p->sched_waits[i]) {
+            Y6_REQUIRE(p->sched_ev[w] != nullptr, "plan_run: scheduled op %d waits for op %d, which has not been enqueued", i, w);
+            Y6_HIP(hipStreamWaitEvent(st, p->sched_ev[w], 0));
+        }
+        rc = run_op(p->ops[i], st);
+        if (rc) return rc;
+        if (p->sched_records[i]) {
+            rc = next_sync_event(p, &e);
+            if (rc) return rc;
+            Y6_HIP(hipEventRecord(e, st));
+            p->sched_ev[i] = e;
+        }
+    }
+    rc = next_sync_event(p, &e);       // join
+    if (rc) return rc;
+    Y6_HIP(hipEventRecord(e, p->side_stream));
+    Y6_HIP(hipStreamWaitEvent(s, e, 0));
     return Y6_OK;
 }
 
@@ -482,6 +555,7 @@ extern "C" int y6_plan_run(y6_plan* p, void* stream) {
         Y6_HIP(hipGraphLaunch(p->exec, s));
         return Y6_OK;
     }
+    if (p->sched_order.size() == p->ops.size() && !p->ops.empty()) return run_scheduled(p, s);
     return run_ops(p, s, 0, p->ops.size());
 }
 

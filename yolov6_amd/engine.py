@@ -122,6 +122,44 @@ class Plan:
         _lib.check(self._lib.y6_plan_capture(self._h, _lib.current_stream_ptr()), "plan_capture")
         self.captured = True
 
+    def schedule(self, costs=None, profile_iters: int = 3, policy=None, margin=None):
+        """Two-stream schedule of run() (yolov6_amd/schedule.py): ops off the critical path of the forward go to the plan's
+        side stream, each as early as its inputs allow.  `costs`: per-op times (any unit); default: the ops timed one by one
+        on this device.  Returns a summary dict, or None when the plan has nothing to overlap / holds ops without view
+        information (int8 twins, calibration): run() then stays on one stream."""
+        from . import schedule as S
+        log = getattr(self, "op_log", None)
+        n = self.num_ops
+        if not log or len(log) != n:
+            return None
+        acc = [S.op_access(e) for e in log]
+        if any(a is None for a in acc):
+            return None
+        deps = S.dependences(acc)
+        if costs is None:
+            costs = [r["ms"] for r in self.profile(profile_iters)]
+        import os
+        policy = policy or os.environ.get("Y6_SCHED_POLICY", "alap")
+        margin = float(margin if margin is not None else os.environ.get("Y6_SCHED_MARGIN", "2.0"))
+        res = S.build_schedule(deps, costs, policy=policy, margin=margin)
+        if res is None:
+            return None
+        order, stream, edges = res
+        S.check_schedule(deps, order, stream, edges)
+        co = (C.c_int32 * n)(*order)
+        cs = (C.c_int32 * n)(*stream)
+        flat = [v for e in edges for v in e]
+        ce = (C.c_int32 * max(1, len(flat)))(*flat)
+        _lib.check(self._lib.y6_plan_set_schedule(self._h, co, cs, n, ce, len(edges)), "plan_set_schedule")
+        self.sched = dict(policy=policy, margin=margin, order=list(order), stream=list(stream), edges=list(edges), costs=list(costs),
+                          side_ops=[i for i in range(n) if stream[i]], side_cost=sum(costs[i] for i in range(n) if stream[i]),
+                          total_cost=sum(costs))
+        return self.sched
+
+    def clear_schedule(self):
+        _lib.check(self._lib.y6_plan_set_schedule(self._h, None, None, 0, None, 0), "plan_set_schedule")
+        self.sched = None
+
     def timing_begin(self, slots: int):
         _lib.check(self._lib.y6_plan_timing_begin(self._h, slots), "plan_timing_begin")
 
@@ -626,4 +664,7 @@ class PlanBuilder:
         self.h = None
         if autotune and self.force_variant < 0:
             plan.autotune(iters)
+        import os
+        if os.environ.get("Y6_SCHED_STREAMS", "1") == "2" and self.quant is None:   # off until measured (tools/gpu_visit_r03u.sh)
+            plan.schedule()
         return plan
