@@ -665,6 +665,8 @@ class PlanBuilder:
         if autotune and self.force_variant < 0:
             plan.autotune(iters)
         import os
-        if os.environ.get("Y6_SCHED_STREAMS", "1") == "2" and self.quant is None:   # off until measured (tools/gpu_visit_r03u.sh)
+        # two-stream schedule of run(): on since r03u (+2.0 % img/s same box, alternating runs, bit-identical results:
+        # profiles/r03/bench_infer_r03u_*.json); Y6_SCHED_STREAMS=1 keeps every op on the caller's stream
+        if os.environ.get("Y6_SCHED_STREAMS", "2") == "2" and self.quant is None:
             plan.schedule()
         return plan
