@@ -633,6 +633,50 @@ BLOCKS = ["repvgg_s1", "repvgg_s2", "repvgg_widen", "convbnsilu3", "convbnrelu1"
           "bottlerep3", "mbla", "mbla_silu"]
 
 
+@pytest.mark.parametrize("case,policy", [("tiny", "asap"), ("tiny", "alap"), ("s_qa_tiny", "asap"), ("s_mbla_tiny", "asap"), ("m_tiny", "asap")])
+def test_training_forward_two_stream_schedule_bit_identical(case, policy):
+    """The training-form forward with its branch ops on the plan's side stream (train_engine.schedule_forward, Y6_TRAIN_FWD_STREAMS=2):
+    same kernels, same data - head outputs, stem feature maps, every BatchNorm's running statistics and every parameter
+    gradient of the step equal the one-stream run bit for bit (the sums of these kernels are order-fixed, so equality is the bar)."""
+    import copy
+    from oracle import synth
+    from yolov6_amd import schedule as Sch
+    cfg, meta, sd, model = _tiny_train_model(case)
+    x = synth.synth_images(2, 64, seed=31).to(DEV).half()
+    runs = {}
+    for mode in ("one", "two"):
+        m = copy.deepcopy(model).to(DEV).train()
+        m(x)                                                       # builds the graph (and takes one step of running statistics)
+        graph = next(iter(m.__dict__["_y6_train_graphs"].values()))
+        if mode == "two":
+            info = graph.fwd_plan.schedule(costs=Sch.train_costs(graph.fwd_log), accesses=[Sch.train_op_access(e) for e in graph.fwd_log],
+                                           policy=policy)
+            assert info is not None and len(info["side_ops"]) > graph.fwd_plan.num_ops // 5
+        else:
+            graph.fwd_plan.clear_schedule()
+        outs = []
+        for step in range(3):
+            for p in m.parameters():
+                p.grad = None
+            (stems, scores, distri), _ = m(x)
+            ((scores * scores).sum() * 64.0 + distri.square().mean() * 64.0).backward()
+            outs.append((scores.detach().clone(), distri.detach().clone()))
+        torch.cuda.synchronize()
+        runs[mode] = (outs, [t.clone() for t in stems], {k: v.clone() for k, v in m.state_dict().items()},
+                      {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    (o1, f1, s1, g1), (o2, f2, s2, g2) = runs["one"], runs["two"]
+    for (a, b), (c, d) in zip(o1, o2):
+        assert torch.equal(a, c) and torch.equal(b, d), f"{case}/{policy}: head outputs differ"
+    for a, b in zip(f1, f2):
+        assert torch.equal(a, b)
+    assert s1.keys() == s2.keys() and g1.keys() == g2.keys() and len(g1) > 20
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), f"{case}/{policy}: {k} differs after three steps"
+    for k in g1:      # (the backward plan is the same in both runs; equal forward activations -> equal gradients up to the order of any atomic sums)
+        den = float(g1[k].float().abs().max()) + 1e-12
+        assert float((g1[k].float() - g2[k].float()).abs().max()) <= 1e-5 * den, f"{case}/{policy}: gradient of {k} differs"
+
+
 @pytest.mark.parametrize("kind", BLOCKS)
 def test_block_training_graph_vs_autograd(kind):
     from oracle import synth

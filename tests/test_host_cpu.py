@@ -416,6 +416,43 @@ def test_two_stream_schedule_enforces_every_dependence(case):
         S.check_schedule(deps, *r2)
 
 
+@pytest.mark.parametrize("case,flags", [("tiny", {}), ("s_qa_tiny", {}), ("s_mbla_tiny", {}), ("tiny", {"fuse_ab": True}),
+                                        ("tiny", {"distill_ns": True}), ("m_tiny", {})])
+def test_training_forward_schedule_enforces_every_dependence(case, flags):
+    """The training-form forward (train_engine.TrainBuilder lowers it without a GPU: plans only record launches) under
+    schedule.train_op_access / build_schedule: every RepVGG block's 1x1 branch leaves the chain, BatchNorm statistics are
+    ordered in front of the branch sum that reads them, running statistics are written by one op each, and stream FIFO + the
+    event edges cover every dependence."""
+    from yolov6_amd import schedule as S
+    from yolov6_amd.engine import NCHWInput
+    from yolov6_amd.train_engine import ParamArena, TrainBuilder
+    cfg, meta = case_config(case)
+    m = build_model(cfg, meta["num_classes"], "cpu", **flags).train()
+    x = synth.synth_images(2, 64, seed=1)
+    tb = TrainBuilder(x.device, ParamArena(m, x.device))
+    m.lower_train(tb, NCHWInput(x))
+    log = tb.fwd_log
+    acc = [S.train_op_access(e) for e in log]
+    assert all(a is not None for a in acc), sorted({e["kind"] for e, a in zip(log, acc) if a is None})
+    deps = S.dependences(acc)
+    kinds = [e["kind"] for e in log]
+    for j, e in enumerate(log):
+        if e["kind"] == "bnact_forward":     # the branch sum waits for the statistics op of every normalised branch
+            stats_ops = [i for i in deps[j] if kinds[i] == "bn_train_stats"]
+            assert len(stats_ops) == sum(1 for _, st in e["branches"] if st is not None)
+        if e["kind"] == "bn_train_stats":    # ... which waits for the op(s) that wrote the tensor it reduces - and for nothing else
+            assert deps[j] and all(kinds[i] in ("conv", "stem", "bnact_forward", "nchw2nhwc", "subsample2", "convt", "avgpool3", "sppf")
+                                   for i in deps[j])       # (more than one producer: statistics over a concat buffer)
+    for policy in ("asap", "alap"):
+        res = S.build_schedule(deps, S.train_costs(log), policy=policy)
+        assert res is not None
+        order, stream, edges = res
+        S.check_schedule(deps, order, stream, edges)
+        side = [i for i in range(len(log)) if stream[i]]
+        assert any(kinds[i] == "conv" and log[i]["k"] == 1 for i in side) and any(kinds[i] == "bn_train_stats" for i in side)
+        assert stream[0] == 0 and kinds[-1] in ("head_pack", "head_ab_pack") and len(side) > len(log) // 5
+
+
 def test_two_stream_schedule_random_dags():
     """Property check of schedule.build_schedule on random dependence graphs: valid for every graph, and a broken schedule (an
     edge removed) is caught by check_schedule."""

@@ -122,18 +122,20 @@ class Plan:
         _lib.check(self._lib.y6_plan_capture(self._h, _lib.current_stream_ptr()), "plan_capture")
         self.captured = True
 
-    def schedule(self, costs=None, profile_iters: int = 3, policy=None, margin=None):
+    def schedule(self, costs=None, profile_iters: int = 3, policy=None, margin=None, accesses=None):
         """Two-stream schedule of run() (yolov6_amd/schedule.py): ops off the critical path of the forward go to the plan's
         side stream, each as early as its inputs allow.  `costs`: per-op times (any unit); default: the ops timed one by one
         on this device.  Returns a summary dict, or None when the plan has nothing to overlap / holds ops without view
         information (int8 twins, calibration): run() then stays on one stream."""
         from . import schedule as S
-        log = getattr(self, "op_log", None)
         n = self.num_ops
-        if not log or len(log) != n:
-            return None
-        acc = [S.op_access(e) for e in log]
-        if any(a is None for a in acc):
+        if accesses is None:
+            log = getattr(self, "op_log", None)
+            if not log or len(log) != n:
+                return None
+            accesses = [S.op_access(e) for e in log]
+        acc = list(accesses)
+        if len(acc) != n or any(a is None for a in acc):
             return None
         deps = S.dependences(acc)
         if costs is None:

@@ -13,18 +13,24 @@ over the lowering graph of every model family and checks that the schedule enfor
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
-Span = Tuple[int, int, int]          # (buffer address, first channel, one past the last channel)
+Span = Tuple[int, int, int, int]     # (first byte, one past the last byte of the allocation piece, first channel, one past the last)
 WHOLE = 1 << 30
+
+
+def _bytes_of(t) -> Tuple[int, int]:
+    lo = int(t.data_ptr())
+    return lo, lo + max(int(t.numel()) * int(t.element_size()), 1)
 
 
 def _span(v) -> Optional[Span]:
     if v is None:
         return None
-    if hasattr(v, "buf") and hasattr(v, "coff"):           # engine.TRef (or the CPU mock's view)
-        base = v.buf.data_ptr() if hasattr(v.buf, "data_ptr") else id(v.buf)
-        return (int(base), int(v.coff), int(v.coff) + int(v.C))
-    if hasattr(v, "data_ptr"):                             # a caller tensor: the whole allocation
-        return (int(v.data_ptr()), 0, WHOLE)
+    if hasattr(v, "buf") and hasattr(v, "coff"):           # engine.TRef: channels [coff, coff + C) of an NHWC buffer
+        lo, hi = _bytes_of(v.buf)
+        return (lo, hi, int(v.coff), int(v.coff) + int(v.C))
+    if hasattr(v, "data_ptr"):                             # a plain tensor (or a contiguous slice of one): its bytes
+        lo, hi = _bytes_of(v)
+        return (lo, hi, 0, WHOLE)
     raise TypeError(f"schedule: no span for {type(v)}")
 
 
@@ -51,8 +57,70 @@ def op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
     return [_span(v) for v in rd], [_span(v) for v in wr]
 
 
+def train_op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
+    """(reads, writes) of one entry of train_engine.TrainBuilder.fwd_log (the training-form forward: conv -> batch-statistics
+    BatchNorm -> branch sum + activation, reference yolov6/layers/common.py:44-49, :250-255).  Parameters (views of the flat
+    arena) are only read by the forward and are left out; a BatchNorm's running statistics are written by its statistics op."""
+    k = entry.get("kind")
+    rd, wr = [], []
+    if k in ("nchw2nhwc", "subsample2", "stem", "avgpool3", "convt"):
+        rd.append(entry["x"])
+        wr.append(entry["out"])
+    elif k == "conv":
+        if entry.get("acc"):
+            return None                                    # an accumulating conv reads a tensor the log does not name
+        rd.append(entry["x"])
+        wr.append(entry["out"])
+    elif k == "bn_train_stats":
+        st, bn = entry["stats"], entry["bn"]
+        rd.append(entry["x"])
+        wr += [st.scale, st.shift, st.mean, st.invstd]
+        if getattr(bn, "track_running_stats", False) and getattr(bn, "running_mean", None) is not None:
+            wr += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    elif k == "bnact_forward":
+        for t, st in entry["branches"]:
+            rd.append(t)
+            if st is not None:
+                rd += [st.scale, st.shift]
+        if entry.get("res") is not None:
+            rd.append(entry["res"])
+        wr.append(entry["out"])
+    elif k == "sppf":
+        rd.append(entry["x"])
+        wr += list(entry["outs"])
+    elif k in ("head_pack", "head_ab_pack"):
+        rd += list(entry["cls"]) + list(entry["reg"])
+        wr += [t for t in (entry.get("scores"), entry.get("distri")) if t is not None]
+    else:
+        return None
+    return [_span(v) for v in rd], [_span(v) for v in wr]
+
+
+def train_costs(log: Sequence[dict]) -> List[float]:
+    """Rough per-op times (microseconds) of a training-form forward from its shapes - enough to tell the chain from the
+    branches (a device profile would re-run the statistics ops, which update running statistics).  Convs at 500 TFLOP/s,
+    everything at 2.5 TB/s of the bytes its views cover, 6 us per launch."""
+    out = []
+    for e in log:
+        acc = train_op_access(e)
+        by = 0.0
+        if acc is not None:
+            for lo, hi, c0, c1 in acc[0] + acc[1]:
+                by += (hi - lo)
+        fl = 0.0
+        if e.get("kind") == "conv":
+            o, x, k = e["out"], e["x"], int(e.get("k", 1))
+            fl = 2.0 * o.B * o.H * o.W * o.C * x.C * k * k
+        out.append(6.0 + by / 2.5e6 + fl / 5.0e8)
+    return out
+
+
 def _overlap(a: Span, b: Span) -> bool:
-    return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+    if not (a[0] < b[1] and b[0] < a[1]):
+        return False
+    if a[0] == b[0] and a[1] == b[1]:                       # two views of one buffer: by channel slice
+        return a[2] < b[3] and b[2] < a[3]
+    return True                                            # different pieces that share bytes (a slice of a vector, ...)
 
 
 def dependences(acc: Sequence[Tuple[List[Span], List[Span]]]) -> List[List[int]]:

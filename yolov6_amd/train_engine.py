@@ -791,6 +791,18 @@ class _LazyNCHW(list):
         return super().__getitem__(i)
 
 
+def schedule_forward(plan, fwd_log):
+    """Two-stream schedule of a training-form forward plan (yolov6_amd/schedule.py): a RepVGG block's 1x1 / identity branches
+    (their convs and BatchNorm statistics passes, reference yolov6/layers/common.py:250-255) are independent of its 3x3 branch
+    until the branch sum, BepC3's two 1x1 inputs of each other (:634-650) - on one stream they queue behind each other.
+    Opt-in (Y6_TRAIN_FWD_STREAMS=2) until measured.  Returns the schedule summary or None."""
+    if os.environ.get("Y6_TRAIN_FWD_STREAMS", "1") != "2" or plan.num_ops != len(fwd_log):
+        return None
+    from . import schedule as S
+    return plan.schedule(costs=S.train_costs(fwd_log), accesses=[S.train_op_access(e) for e in fwd_log],
+                         policy=os.environ.get("Y6_TRAIN_FWD_POLICY", "asap"))
+
+
 class TrainGraph:
     """Forward + backward native plans of one model for one input shape."""
 
@@ -809,6 +821,7 @@ class TrainGraph:
         # on the neck feature maps, filled by loss_distill.ComputeLoss
         self.feat_inlets = [tb.grad_inlet(r) for r in necks] if getattr(model, "distill_feat", False) else None
         self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
+        self.fwd_sched = schedule_forward(self.fwd_plan, tb.fwd_log)
         self.tb = tb
         self.stem_refs, self.neck_refs = stems, necks
         # head outputs in the order the model returns them, each with the buffer the backward plan reads its gradient from
@@ -872,6 +885,7 @@ class ModuleTrainGraph:
             tb.grad_mode(g)                   # written by the caller (set_output_grads) before the backward plan runs
             self.dout_refs.append(g)
         self.pack_plan, self.fwd_plan, self.bwd_plan = tb.finalize()
+        self.fwd_sched = schedule_forward(self.fwd_plan, tb.fwd_log)
         self.tb = tb
 
     def forward(self):
