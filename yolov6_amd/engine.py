@@ -138,6 +138,8 @@ class Plan:
         if len(acc) != n or any(a is None for a in acc):
             return None
         deps = S.dependences(acc)
+        if S.is_chain(deps):             # (single-op and straight-line plans: nothing to overlap, nothing to time)
+            return None
         if costs is None:
             costs = [r["ms"] for r in self.profile(profile_iters)]
         import os

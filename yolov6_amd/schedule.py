@@ -138,6 +138,17 @@ def dependences(acc: Sequence[Tuple[List[Span], List[Span]]]) -> List[List[int]]
     return deps
 
 
+def is_chain(deps: List[List[int]]) -> bool:
+    """No op has two producers or two consumers: nothing can overlap, whatever the costs."""
+    users = [0] * len(deps)
+    for d in deps:
+        if len(d) > 1:
+            return False
+        for i in d:
+            users[i] += 1
+    return all(u <= 1 for u in users)
+
+
 def build_schedule(deps: List[List[int]], cost: Optional[Sequence[float]] = None, min_side_cost: float = 0.0,
                    policy: str = "asap", margin: float = 2.0):
     """-> (order, stream, edges) or None when nothing is off the critical path.
