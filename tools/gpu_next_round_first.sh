@@ -1,31 +1,46 @@
 #!/usr/bin/env bash
-# First GPU visit of the round after round 2 (one box, ~12 min):
-#   1. the probes / tests of everything written after round 2's last visit (model families, dma8_c4p1) - reported, not fatal
-#   2. fill pricing: LDS-DMA requests + barriers only, all / halo only / weights only (probe builds 2 / 7 / 8), four layers
-#   3. same-box A/B of the candidate set: default / + dma8_c4p1 (33) / + resident-weight forms (34, 35) / + dma_c2p4 (36) / + stride-2 dma8s2_c4p1 (37) / + all five
-# Before the visit, in the build container:  python tools/build_probe_libs.py --dma 2 7 8   (tools/_build/ travels with the snapshot)
+# First GPU visit of the round after round 3 (one box, about 4 minutes of box time):
+#   1. the K-resident 1x1 kernel (kres1x1_c2 / kres1x1_c1, csrc/conv_mfma.hip; written after round 3's last GPU visit, selectable
+#      only with Y6_ENABLE_CANDIDATES=1): parity on its own shapes, then its time against every other 1x1 kernel on the layers it
+#      was written for (the CSP-SPPF / neck 1x1s of YOLOv6-S at b32: 14-30 us each today)
+#   2. same-box A/B of the headline with / without it in the autotuner's candidate set, one-stream and scheduled
+#   3. the training-forward schedule once more (r03v: no gain; the `alap` run ended on a different loss - if that repeats, find
+#      the undeclared dependence before anybody turns it on)
+# Outcome -> DESIGN.md 6 / 9; if (1) is green and (2) gains: drop the Y6_ENABLE_CANDIDATES gate in y6_conv_mfma_supports and add
+# the test shapes of tests/test_gpu_ops.py (behind the same variable today) to CONV_SHAPES.
 set -u
-OUT=gpurun_out/${1:-next1}; mkdir -p "$OUT"; export TMPDIR=/tmp
-for n in 2 7 8; do
-  [ -f tools/_build/libyolov6_hip_dmaprobe$n.so ] || { echo "probe lib $n missing: building on the box"; python tools/build_probe_libs.py --dma $n > "$OUT/build_probe_$n.log" 2>&1; }
-done
-timeout 900 python -m pytest tests/test_gpu_families.py -q -m gpu -rxX -p no:cacheprovider > "$OUT/pytest_families.log" 2>&1
-tail -8 "$OUT/pytest_families.log"
-L="64,64,3,1,160,160,32 64,64,3,1,80,80,32 64,128,3,1,80,80,32 128,128,3,1,80,80,32 256,256,3,1,40,40,32 512,512,3,1,20,20,32 128,128,3,1,40,40,32"
-( echo base; timeout 300 python tools/conv_bench.py --layers $L --variants 25 26 28 33 34 35 36 --iters 20 ) > "$OUT/probe_base.log" 2>&1
-( echo "base s2"; timeout 300 python tools/conv_bench.py --layers 64,128,3,2,160,160,32 128,256,3,2,80,80,32 256,512,3,2,40,40,32 128,128,3,2,40,40,32 --variants 2 3 31 32 37 --iters 20 ) > "$OUT/probe_base_s2.log" 2>&1
-for n in 2 7 8; do
-  ( echo probe $n; Y6_LIB_PATH=tools/_build/libyolov6_hip_dmaprobe$n.so timeout 300 python tools/conv_bench.py --layers $L --variants 25 26 --iters 20 ) > "$OUT/probe_$n.log" 2>&1
-done
-grep -h "probe\|base\|ms" "$OUT"/probe_*.log | grep -v amdgpu
-BASE="7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30"
-for cfg in default:$BASE,33,34,35,36,37 all:$BASE; do
-  name=${cfg%%:*}; ex=${cfg#*:}
-  Y6_AUTOTUNE_EXCLUDE="$ex" Y6_AUTOTUNE_LOG="$OUT/autotune_$name.log" timeout 600 python bench.py --steps 200 --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/ops_$name.json" > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+OUT=gpurun_out/${1:-r04a}; mkdir -p "$OUT"
+T0=$(date +%s); lap() { echo "-- $1 done at +$(( $(date +%s) - T0 )) s"; }
+Y6_ENABLE_CANDIDATES=1 timeout 200 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k conv_all_variants > "$OUT/pytest_kres.log" 2>&1
+echo "pytest kres rc=$?"; tail -4 "$OUT/pytest_kres.log" | cut -c1-300; grep -E "variant kres|Error|FAILED" "$OUT/pytest_kres.log" | head -8 | cut -c1-300; lap "kres parity"
+# variants: 1-6 per-tap, 22/23 streaming, 38/39 K-resident
+L="512,256,1,1,20,20,32 256,256,1,1,20,20,32 1024,256,1,1,20,20,32 512,512,1,1,20,20,32 512,128,1,1,20,20,32 384,128,1,1,40,40,32 256,64,1,1,40,40,32 192,64,1,1,80,80,32 128,128,1,1,40,40,32"
+Y6_ENABLE_CANDIDATES=1 timeout 200 python tools/conv_bench.py --layers $L --variants 1 2 3 4 5 6 22 23 38 39 --iters 20 --out "$OUT/conv_bench_1x1.json" > "$OUT/conv_bench_1x1.log" 2>&1
+grep -v amdgpu "$OUT/conv_bench_1x1.log" | tail -60 | cut -c1-200; lap "1x1 layer table"
+run() {  # name, env...
+  local name=$1; shift
+  env "$@" timeout 90 python bench.py --no-cpu-baseline --dropin-steps 0 --profile-out "$OUT/ops_$name.json" > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"
   python - <<PY
 import json
-d=json.load(open("$OUT/bench_$name.json")); r=json.load(open("$OUT/ops_$name.json"))["rows"]
-print("$name", d["value"], d["ms_per_step"], "3x3s1", round(d["breakdown"]["conv3x3s1"]["ms"],3))
-print("   ", " ".join(f"{x['op']}:{x['variant']}:{x['ms']*1e3:.0f}" for x in r if x["ksize"] == 3))
+try:
+    d=json.load(open("$OUT/bench_$name.json")); r=json.load(open("$OUT/ops_$name.json"))["rows"]
+    print("$name", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["forward"]["ms"], {k: round(v["ms"], 3) for k, v in d["breakdown"].items()}, d.get("schedule"))
+    print("   1x1:", " ".join(f"{x['op']}:{x['variant']}:{x['ms']*1e3:.0f}" for x in r if x["kind"] == "conv" and x["ksize"] == 1))
+except Exception as e: print("no result", e)
 PY
+}
+run base1
+run kres1 Y6_ENABLE_CANDIDATES=1
+run base2
+run kres2 Y6_ENABLE_CANDIDATES=1
+run base_1stream Y6_SCHED_STREAMS=1
+run kres_1stream Y6_SCHED_STREAMS=1 Y6_ENABLE_CANDIDATES=1
+lap "headline A/B"
+for n in one asap alap one2 alap2; do
+  case $n in one*) E="Y6_TRAIN_FWD_STREAMS=1";; asap*) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=asap";; *) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=alap";; esac
+  env $E timeout 120 python bench.py --mode train > "$OUT/bench_train_$n.json" 2> "$OUT/bench_train_$n.err"
+  python -c "import json; d=json.load(open('$OUT/bench_train_$n.json')); print('train $n', d['value'], d['ms_per_step'], d['loss'])" 2>/dev/null || echo "train $n: no result"
 done
+lap "training forward schedule"
+echo done
