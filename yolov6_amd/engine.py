@@ -145,11 +145,16 @@ class Plan:
         import os
         policy = policy or os.environ.get("Y6_SCHED_POLICY", "alap")
         margin = float(margin if margin is not None else os.environ.get("Y6_SCHED_MARGIN", "2.0"))
-        res = S.build_schedule(deps, costs, policy=policy, margin=margin)
-        if res is None:
+        try:
+            res = S.build_schedule(deps, costs, policy=policy, margin=margin)
+            if res is None:
+                return None
+            order, stream, edges = res
+            S.check_schedule(deps, order, stream, edges)    # independent re-statement of what the executor guarantees
+        except AssertionError as e:                          # an optimisation must not take the model down: one stream, loudly
+            import warnings
+            warnings.warn(f"yolov6_amd: two-stream schedule rejected ({e}); the plan runs on one stream")
             return None
-        order, stream, edges = res
-        S.check_schedule(deps, order, stream, edges)
         co = (C.c_int32 * n)(*order)
         cs = (C.c_int32 * n)(*stream)
         flat = [v for e in edges for v in e]
