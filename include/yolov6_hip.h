@@ -40,6 +40,9 @@ enum { Y6_ACT_NONE = 0, Y6_ACT_RELU = 1, Y6_ACT_SILU = 2, Y6_ACT_HARDSWISH = 3 }
 enum { Y6_F16 = 0, Y6_F32 = 1, Y6_U8 = 2 /* stem input only: uint8 pixels, read as imgs.half()/255 (core/evaler.py:121-123) */ };
 
 int y6_abi_version(void);
+/* sizeof of a public struct of this header by its name ("y6_conv_desc", ...), 0 if unknown: a hand-written mirror of these
+ * structs (ctypes, cgo, JNI) checks itself against it when it loads the library. */
+size_t y6_abi_sizeof(const char* name);
 const char* y6_last_error(void);
 /* number of CUs / arch name of the current device ("gfx950"); fails if no HIP device */
 int y6_device_info(int* n_cu, char* arch, size_t arch_len);

@@ -480,6 +480,21 @@ def test_two_stream_schedule_random_dags():
     assert caught > 50       # (an edge is only dropped by build_schedule when another wait already implies it: most cuts break)
 
 
+def test_every_public_struct_has_a_size_checked_mirror(hip_lib):
+    """include/yolov6_hip.h <-> yolov6_amd/_lib.py: every `typedef struct {...} y6_*;` of the header has a ctypes mirror, and each
+    mirror's size equals the C compiler's (y6_abi_sizeof; _lib.load() refuses to return a library whose layouts differ)."""
+    import ctypes as C
+    import re
+    from yolov6_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "include", "yolov6_hip.h")) as f:
+        names = re.findall(r"^\} (y6_[a-z0-9_]+);", f.read(), re.M)
+    assert len(names) >= 27 and sorted(names) == sorted(_lib.STRUCTS)
+    for n, t in _lib.STRUCTS.items():
+        assert int(hip_lib.y6_abi_sizeof(n.encode())) == C.sizeof(t) > 0, n
+    assert int(hip_lib.y6_abi_sizeof(b"y6_no_such_struct")) == 0
+
+
 def test_native_state_never_pickled_or_deepcopied():
     """after a train-mode forward the model's __dict__ holds `_y6_train_graphs` / `_y6_arena` /
     `_y6_backward_hook` (ctypes handles inside); the reference's epoch-end path `deepcopy(model).half()` + torch.save must not

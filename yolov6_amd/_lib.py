@@ -189,9 +189,21 @@ TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose"
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
+# public struct of include/yolov6_hip.h -> its ctypes mirror above (load() checks every size against y6_abi_sizeof)
+STRUCTS = {
+    "y6_tensor": Tensor, "y6_conv_desc": ConvDesc, "y6_conv_i8_desc": ConvI8Desc, "y6_convt_desc": ConvTDesc, "y6_stem_desc": StemDesc,
+    "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
+    "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
+    "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
+    "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc,
+    "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_head_pack_desc": HeadPackDesc,
+    "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
+}
+
 # symbol -> (restype, argtypes); also the list the CPU test checks the .so exports against
 SIGNATURES = {
     "y6_abi_version": (C.c_int, []),
+    "y6_abi_sizeof": (C.c_size_t, [C.c_char_p]),
     "y6_last_error": (C.c_char_p, []),
     "y6_device_info": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "y6_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -335,6 +347,11 @@ def load():
         fn.argtypes = args
     if lib.y6_abi_version() != 1:
         raise RuntimeError("yolov6_amd: libyolov6_hip.so ABI version mismatch - rebuild")
+    bad = [(n, C.sizeof(t), int(lib.y6_abi_sizeof(n.encode()))) for n, t in STRUCTS.items()
+           if C.sizeof(t) != int(lib.y6_abi_sizeof(n.encode()))]
+    if bad:      # a descriptor field added on one side only: kernels would read past (or short of) what Python filled in
+        raise RuntimeError("yolov6_amd: struct layout differs between yolov6_amd/_lib.py and libyolov6_hip.so (name, ctypes, C): "
+                           f"{bad} - rebuild the library / update the mirror")
     _lib = lib
     return lib
 

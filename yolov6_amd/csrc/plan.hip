@@ -3,6 +3,7 @@
 // autotuning and a per-op hipEvent profile.  This is what sits behind Model.forward
 // (reference yolov6/models/yolo.py:33-41) instead of ~200 aten dispatches.
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,44 @@ void y6_set_error(const char* fmt, ...) {
 
 extern "C" const char* y6_last_error(void) { return g_err; }
 extern "C" int y6_abi_version(void) { return Y6_ABI_VERSION; }
+
+// sizeof of a public struct of include/yolov6_hip.h by name (0: unknown).  A binding in another language mirrors these structs
+// by hand (yolov6_amd/_lib.py does, with ctypes): it checks its mirrors against this table when it loads the library, so a field
+// added on one side only is a load-time error instead of a kernel reading past a descriptor.
+extern "C" size_t y6_abi_sizeof(const char* name) {
+    static const struct { const char* n; size_t s; } kTab[] = {
+        {"y6_tensor", sizeof(y6_tensor)},
+        {"y6_conv_desc", sizeof(y6_conv_desc)},
+        {"y6_conv_i8_desc", sizeof(y6_conv_i8_desc)},
+        {"y6_convt_desc", sizeof(y6_convt_desc)},
+        {"y6_stem_desc", sizeof(y6_stem_desc)},
+        {"y6_pw_s2_desc", sizeof(y6_pw_s2_desc)},
+        {"y6_stem_s2_desc", sizeof(y6_stem_s2_desc)},
+        {"y6_letterbox_desc", sizeof(y6_letterbox_desc)},
+        {"y6_decode_desc", sizeof(y6_decode_desc)},
+        {"y6_pred_decode_desc", sizeof(y6_pred_decode_desc)},
+        {"y6_nms_desc", sizeof(y6_nms_desc)},
+        {"y6_tal_desc", sizeof(y6_tal_desc)},
+        {"y6_atss_desc", sizeof(y6_atss_desc)},
+        {"y6_loss_desc", sizeof(y6_loss_desc)},
+        {"y6_distill_desc", sizeof(y6_distill_desc)},
+        {"y6_bn_train_desc", sizeof(y6_bn_train_desc)},
+        {"y6_bnact_desc", sizeof(y6_bnact_desc)},
+        {"y6_bnact_bwd_desc", sizeof(y6_bnact_bwd_desc)},
+        {"y6_wgrad_t_desc", sizeof(y6_wgrad_t_desc)},
+        {"y6_wgrad_desc", sizeof(y6_wgrad_desc)},
+        {"y6_wgrad_nhwc_desc", sizeof(y6_wgrad_nhwc_desc)},
+        {"y6_pack_job", sizeof(y6_pack_job)},
+        {"y6_pack_batch_desc", sizeof(y6_pack_batch_desc)},
+        {"y6_sppf_bwd_desc", sizeof(y6_sppf_bwd_desc)},
+        {"y6_head_pack_desc", sizeof(y6_head_pack_desc)},
+        {"y6_head_ab_desc", sizeof(y6_head_ab_desc)},
+        {"y6_loss_grad_desc", sizeof(y6_loss_grad_desc)}};
+    if (!name) return 0;
+    for (const auto& e : kTab)
+        if (strcmp(e.n, name) == 0) return e.s;
+    return 0;
+}
 
 extern "C" int y6_device_info(int* n_cu, char* arch, size_t arch_len) {
     int dev = 0;
