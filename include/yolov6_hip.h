@@ -267,6 +267,9 @@ typedef struct y6_pred_decode_desc {
     float grid_cell_offset;
     float* out;                /* [B, A, 5+nc] fp32 */
     int32_t nc;
+    int32_t first_anchor;      /* with total_anchors > 0: row (inside an image) of `out` where this call's first level starts, */
+    int32_t total_anchors;     /* and the rows per image of `out` - a call may then cover a SUBSET of the head's levels (one call per
+                                  level lets a level be decoded as soon as its convs are done).  0 / 0: the call covers `out`. */
 } y6_pred_decode_desc;
 int y6_head_pred_decode_supported(const y6_pred_decode_desc* d);   /* 1 if the fused kernel takes this shape */
 int y6_head_pred_decode(const y6_pred_decode_desc* d, void* stream);

@@ -4,7 +4,8 @@
 #      only with Y6_ENABLE_CANDIDATES=1): parity on its own shapes, then its time against every other 1x1 kernel on the layers it
 #      was written for (the CSP-SPPF / neck 1x1s of YOLOv6-S at b32: 14-30 us each today)
 #      + the packed-maximum form of the SPPF pool kernel (same switch; 27.7 us per launch today, VALU-bound on unpacked fp16 compares)
-#   2. same-box A/B of the headline with / without it in the autotuner's candidate set, one-stream and scheduled
+#      + one head-tail op per level instead of one for all (token `levels`): levels 0 / 1 decode beside the neck's small-map stretch
+#   2. same-box A/B of the headline with each candidate alone and all together, one-stream and scheduled
 #   3. the training-forward schedule once more (r03v: no gain; the `alap` run ended on a different loss - if that repeats, find
 #      the undeclared dependence before anybody turns it on)
 # Outcome -> DESIGN.md 6 / 9; if (1) is green and (2) gains: drop the Y6_ENABLE_CANDIDATES gate in y6_conv_mfma_supports and add
@@ -13,14 +14,17 @@ set -u
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/${1:-r04a}; mkdir -p "$OUT"
 T0=$(date +%s); lap() { echo "-- $1 done at +$(( $(date +%s) - T0 )) s"; }
-Y6_ENABLE_CANDIDATES=1 timeout 200 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k conv_all_variants > "$OUT/pytest_kres.log" 2>&1
+Y6_ENABLE_CANDIDATES=kres timeout 200 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k conv_all_variants > "$OUT/pytest_kres.log" 2>&1
 echo "pytest kres rc=$?"; tail -4 "$OUT/pytest_kres.log" | cut -c1-300; grep -E "variant kres|Error|FAILED" "$OUT/pytest_kres.log" | head -8 | cut -c1-300; lap "kres parity"
 # the packed-maximum form of the SPPF pool kernel (same switch): bit-exact pool tests, then the model tests that run a whole SPPF
-Y6_ENABLE_CANDIDATES=1 timeout 200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k "sppf or pool or model_vs_oracle" > "$OUT/pytest_sppf_pk.log" 2>&1
+Y6_ENABLE_CANDIDATES=sppf timeout 200 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k "sppf or pool or model_vs_oracle" > "$OUT/pytest_sppf_pk.log" 2>&1
 echo "pytest sppf (packed max) rc=$?"; tail -3 "$OUT/pytest_sppf_pk.log" | cut -c1-300; lap "sppf parity"
+# one head-tail op per level (y6_pred_decode_desc.first_anchor / total_anchors; the schedule then decodes levels 0 / 1 early)
+Y6_ENABLE_CANDIDATES=levels timeout 200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k "model_vs_oracle or two_stream or rebind or full_resolution or dropin" > "$OUT/pytest_levels.log" 2>&1
+echo "pytest per-level head tail rc=$?"; tail -3 "$OUT/pytest_levels.log" | cut -c1-300; lap "levels parity"
 # variants: 1-6 per-tap, 22/23 streaming, 38/39 K-resident
 L="512,256,1,1,20,20,32 256,256,1,1,20,20,32 1024,256,1,1,20,20,32 512,512,1,1,20,20,32 512,128,1,1,20,20,32 384,128,1,1,40,40,32 256,64,1,1,40,40,32 192,64,1,1,80,80,32 128,128,1,1,40,40,32"
-Y6_ENABLE_CANDIDATES=1 timeout 200 python tools/conv_bench.py --layers $L --variants 1 2 3 4 5 6 22 23 38 39 --iters 20 --out "$OUT/conv_bench_1x1.json" > "$OUT/conv_bench_1x1.log" 2>&1
+Y6_ENABLE_CANDIDATES=kres timeout 200 python tools/conv_bench.py --layers $L --variants 1 2 3 4 5 6 22 23 38 39 --iters 20 --out "$OUT/conv_bench_1x1.json" > "$OUT/conv_bench_1x1.log" 2>&1
 grep -v amdgpu "$OUT/conv_bench_1x1.log" | tail -60 | cut -c1-200; lap "1x1 layer table"
 run() {  # name, env...
   local name=$1; shift
@@ -35,11 +39,14 @@ except Exception as e: print("no result", e)
 PY
 }
 run base1
-run kres1 Y6_ENABLE_CANDIDATES=1
+run kres1 Y6_ENABLE_CANDIDATES=kres
+run sppf1 Y6_ENABLE_CANDIDATES=sppf
+run levels1 Y6_ENABLE_CANDIDATES=levels
+run all1 Y6_ENABLE_CANDIDATES=all
 run base2
-run kres2 Y6_ENABLE_CANDIDATES=1
+run all2 Y6_ENABLE_CANDIDATES=all
 run base_1stream Y6_SCHED_STREAMS=1
-run kres_1stream Y6_SCHED_STREAMS=1 Y6_ENABLE_CANDIDATES=1
+run all_1stream Y6_SCHED_STREAMS=1 Y6_ENABLE_CANDIDATES=all
 lap "headline A/B"
 for n in one asap alap one2 alap2; do
   case $n in one*) E="Y6_TRAIN_FWD_STREAMS=1";; asap*) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=asap";; *) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=alap";; esac

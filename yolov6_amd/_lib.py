@@ -69,7 +69,8 @@ class PredDecodeDesc(C.Structure):
                 ("w_cls", C.c_void_p * MAX_LEVELS), ("w_reg", C.c_void_p * MAX_LEVELS),
                 ("b_cls", C.c_void_p * MAX_LEVELS), ("b_reg", C.c_void_p * MAX_LEVELS),
                 ("stride", C.c_float * MAX_LEVELS), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
-                ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32)]
+                ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32),
+                ("first_anchor", C.c_int32), ("total_anchors", C.c_int32)]
 
 
 class NmsDesc(C.Structure):
@@ -354,6 +355,13 @@ def load():
                            f"{bad} - rebuild the library / update the mirror")
     _lib = lib
     return lib
+
+
+def candidate_enabled(token: str) -> bool:
+    """Y6_ENABLE_CANDIDATES: "1" / "all" enables every kernel or lowering that has not been on a device yet, a comma list the
+    named ones (csrc/common.hpp y6_candidate_enabled reads the same variable)."""
+    e = os.environ.get("Y6_ENABLE_CANDIDATES", "")
+    return e in ("1", "all") or token in [t.strip() for t in e.split(",") if t.strip()]
 
 
 def check(rc, what=""):

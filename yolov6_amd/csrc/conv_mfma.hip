@@ -1711,7 +1711,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist == 5) {   // K-resident 1x1: whole 16-channel k-steps, the block's weight fragments within 64 KiB of LDS
-        static const bool enabled = getenv("Y6_ENABLE_CANDIDATES") != nullptr;   // not measured on a device yet
+        static const bool enabled = y6_candidate_enabled("kres");   // not measured on a device yet
         if (!enabled || ks != 1 || st != 1 || d->w_packed == nullptr) return 0;
         if (d->in.C % 16 || d->in.C < 64 || kres_lds(vc.cf, d->in.C) > 64 * 1024) return 0;
         if (d->in.cstride % 8 || d->in.coff % 8 || ((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;

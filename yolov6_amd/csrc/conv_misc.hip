@@ -861,7 +861,7 @@ extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_te
                    "sppf_pool: output %d shape/alignment mismatch", i);
     const size_t lds = (size_t)x->H * x->W * 16 * 2;
     Y6_REQUIRE(lds <= 160 * 1024, "sppf_pool: plane %dx%d too large for LDS", x->H, x->W);
-    static const bool packed_max = getenv("Y6_ENABLE_CANDIDATES") != nullptr;
+    static const bool packed_max = y6_candidate_enabled("sppf");
     auto kern = packed_max ? sppf_pool_kernel<true> : sppf_pool_kernel<false>;
     if (lds > 64 * 1024)
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

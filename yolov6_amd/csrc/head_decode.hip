@@ -380,6 +380,11 @@ extern "C" int y6_head_pred_decode_supported(const y6_pred_decode_desc* d) {
         if (c.cstride % 8 || c.coff % 8 || r.cstride % 8 || r.coff % 8 || ((uintptr_t)c.data & 15) || ((uintptr_t)r.data & 15)) return 0;
         if (((uintptr_t)d->w_cls[l] & 15) || ((uintptr_t)d->w_reg[l] & 15)) return 0;
     }
+    if (d->total_anchors != 0 || d->first_anchor != 0) {   // a subset of the levels, written into a larger tensor
+        long A = 0;
+        for (int l = 0; l < d->n_levels; ++l) A += (long)d->cls_feat[l].H * d->cls_feat[l].W;
+        if (d->first_anchor < 0 || d->total_anchors <= 0 || d->first_anchor + A > d->total_anchors) return 0;
+    }
     return ((uintptr_t)d->out & 15) == 0;
 }
 
@@ -406,13 +411,13 @@ static int pred_decode_launch(const y6_pred_decode_desc* d, hipStream_t stream) 
         a.C[l] = c.C;
         a.H[l] = c.H;
         a.W[l] = c.W;
-        a.astart[l] = A;
+        a.astart[l] = d->first_anchor + A;
         a.bstart[l] = nb;
         a.stride[l] = d->stride[l];
         A += c.H * c.W;
         nb += (c.H * c.W + PD_TA - 1) / PD_TA;
     }
-    a.astart[d->n_levels] = A;
+    a.astart[d->n_levels] = d->first_anchor + A;
     a.bstart[d->n_levels] = nb;
     a.use_dfl = d->use_dfl;
     a.reg_max = d->reg_max;
@@ -421,7 +426,7 @@ static int pred_decode_launch(const y6_pred_decode_desc* d, hipStream_t stream) 
     a.cell_offset = d->grid_cell_offset;
     a.out = d->out;
     a.B = d->cls_feat[0].B;
-    a.A = A;
+    a.A = d->total_anchors > 0 ? d->total_anchors : A;
     a.nc = d->nc;
     a.ncf_c = (d->nc + 31) / 32;
     a.ncf_r = (a.nreg + 31) / 32;

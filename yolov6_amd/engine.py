@@ -620,7 +620,8 @@ class PlanBuilder:
         self.keep += [w16, packed]
         return packed
 
-    def _pred_decode_desc(self, cls_feat, reg_feat, cls_preds, reg_preds, strides, use_dfl, reg_max, proj, nc, grid_cell_offset, out):
+    def _pred_decode_desc(self, cls_feat, reg_feat, cls_preds, reg_preds, strides, use_dfl, reg_max, proj, nc, grid_cell_offset, out,
+                          first_anchor=0, total_anchors=0):
         d = _lib.PredDecodeDesc()
         d.n_levels = len(cls_feat)
         for i, (c, r, (wc, bc), (wr, br)) in enumerate(zip(cls_feat, reg_feat, cls_preds, reg_preds)):
@@ -635,6 +636,7 @@ class PlanBuilder:
         d.grid_cell_offset = grid_cell_offset
         d.out = C.c_void_p(out.data_ptr()) if out is not None else None
         d.nc = nc
+        d.first_anchor, d.total_anchors = int(first_anchor), int(total_anchors)
         return d
 
     def head_pred_decode(self, cls_feat: List[TRef], reg_feat: List[TRef], cls_preds, reg_preds, strides, use_dfl, reg_max, proj,
@@ -658,10 +660,27 @@ class PlanBuilder:
         if not self.lib.y6_head_pred_decode_supported(C.byref(d)):
             return None
         self.keep.append(out)
+        cpu = lambda ps: [(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in ps]   # noqa: E731
+        if _lib.candidate_enabled("levels") and len(cls_feat) > 1:
+            # candidate (written after round 3's last GPU visit): one head-tail op per level, each writing its rows of `out`
+            # (y6_pred_decode_desc.first_anchor / total_anchors) - the two-stream schedule can then decode a level as soon as its
+            # convs are done, beside the neck's small-map stretch, instead of all 8 400 anchors at the very end (69 us, HBM-bound)
+            first = 0
+            for i in range(len(cls_feat)):
+                di = self._pred_decode_desc(cls_feat[i:i + 1], reg_feat[i:i + 1], cls_preds[i:i + 1], reg_preds[i:i + 1], strides[i:i + 1],
+                                            use_dfl, reg_max, proj, nc, grid_cell_offset, out, first_anchor=first, total_anchors=A)
+                if not self.lib.y6_head_pred_decode_supported(C.byref(di)):
+                    raise RuntimeError("yolov6_amd: per-level head tail refused a level the fused kernel took")
+                _lib.check(self.lib.y6_plan_add_pred_decode(self.h, C.byref(di)), "plan_add_pred_decode")
+                self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat[i:i + 1]), reg_feat=list(reg_feat[i:i + 1]),
+                                        cls_preds=cpu(cls_preds[i:i + 1]), reg_preds=cpu(reg_preds[i:i + 1]), out=out,
+                                        strides=list(strides[i:i + 1]), use_dfl=bool(use_dfl), reg_max=int(reg_max), proj=proj, nc=nc,
+                                        first_anchor=first, total_anchors=A))
+                first += cls_feat[i].H * cls_feat[i].W
+            return out
         _lib.check(self.lib.y6_plan_add_pred_decode(self.h, C.byref(d)), "plan_add_pred_decode")
         self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat), reg_feat=list(reg_feat),
-                                cls_preds=[(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in cls_preds],
-                                reg_preds=[(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in reg_preds],
+                                cls_preds=cpu(cls_preds), reg_preds=cpu(reg_preds),
                                 out=out, strides=list(strides), use_dfl=bool(use_dfl), reg_max=int(reg_max), proj=proj, nc=nc))
         return out
 
