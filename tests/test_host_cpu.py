@@ -453,6 +453,22 @@ def test_training_forward_schedule_enforces_every_dependence(case, flags):
         assert stream[0] == 0 and kinds[-1] in ("head_pack", "head_ab_pack") and len(side) > len(log) // 5
 
 
+def test_schedule_access_lists_follow_int8_twins():
+    """An int8 conv may read its producer's int8 twin instead of the fp16 view and write a twin for its consumers: the
+    schedule's dependence analysis must see both buffers (engine.PlanBuilder._conv_i8 logs them as q_in / q_out)."""
+    from yolov6_amd import schedule as S
+    from yolov6_amd.engine import TRef
+    f16 = [torch.zeros(1, 4, 4, 16, dtype=torch.float16) for _ in range(3)]
+    i8 = [torch.zeros(1, 4, 4, 16, dtype=torch.int8) for _ in range(3)]
+    ref = lambda t: TRef(t, 1, 4, 4, 16, 16, 0)   # noqa: E731
+    log = [dict(kind="conv_i8", x=ref(f16[0]), out=ref(f16[1]), q_in=None, q_out=ref(i8[1]), res=None, has_out=False),
+           dict(kind="conv_i8", x=ref(f16[1]), out=ref(f16[2]), q_in=ref(i8[1]), q_out=None, res=None, has_out=True),
+           dict(kind="conv_i8", x=ref(f16[0]), out=ref(f16[1]), q_in=None, q_out=ref(i8[1]), res=None, has_out=True)]
+    deps = S.dependences([S.op_access(e) for e in log])
+    assert deps == [[], [0], [0, 1]]            # RAW through the twin; WAW + WAR of the rewrite
+    assert S.op_access(dict(kind="absmax", x=ref(f16[0]), index=0)) is None
+
+
 def test_two_stream_schedule_random_dags():
     """Property check of schedule.build_schedule on random dependence graphs: valid for every graph, and a broken schedule (an
     edge removed) is caught by check_schedule."""

@@ -48,6 +48,15 @@ run all2 Y6_ENABLE_CANDIDATES=all
 run base_1stream Y6_SCHED_STREAMS=1
 run all_1stream Y6_SCHED_STREAMS=1 Y6_ENABLE_CANDIDATES=all
 lap "headline A/B"
+# int8 plan (configs[4]) under the two-stream schedule (twin-aware access lists, token `i8sched`): parity first
+Y6_ENABLE_CANDIDATES=i8sched timeout 200 python -m pytest tests/test_gpu_int8.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider > "$OUT/pytest_int8_sched.log" 2>&1
+echo "pytest int8 (scheduled) rc=$?"; tail -3 "$OUT/pytest_int8_sched.log" | cut -c1-300
+for n in i8_one i8_sched i8_one2 i8_sched2; do
+  case $n in *sched*) E="Y6_ENABLE_CANDIDATES=i8sched";; *) E="Y6_DUMMY=1";; esac
+  env $E timeout 120 python bench.py --model yolov6s_qa --int8 --no-cpu-baseline --dropin-steps 0 > "$OUT/bench_$n.json" 2> "$OUT/bench_$n.err"
+  python -c "import json; d=json.load(open('$OUT/bench_$n.json')); print('$n', d['value'], d['ms_per_step'], d['self_check'], d.get('schedule'))" 2>/dev/null || echo "$n: no result"
+done
+lap "int8 schedule"
 for n in one asap alap one2 alap2; do
   case $n in one*) E="Y6_TRAIN_FWD_STREAMS=1";; asap*) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=asap";; *) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=alap";; esac
   env $E timeout 120 python bench.py --mode train > "$OUT/bench_train_$n.json" 2> "$OUT/bench_train_$n.err"

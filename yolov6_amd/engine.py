@@ -695,6 +695,8 @@ class PlanBuilder:
         import os
         # two-stream schedule of run(): on since r03u (+2.0 % img/s same box, alternating runs, bit-identical results:
         # profiles/r03/bench_infer_r03u_*.json); Y6_SCHED_STREAMS=1 keeps every op on the caller's stream
-        if os.environ.get("Y6_SCHED_STREAMS", "2") == "2" and self.quant is None:
+        # (int8 plans: the twin-aware access lists exist but have not been on a device - candidate token `i8sched`)
+        if os.environ.get("Y6_SCHED_STREAMS", "2") == "2" and (
+                self.quant is None or (self.quant.mode == "int8" and _lib.candidate_enabled("i8sched"))):
             plan.schedule()
         return plan

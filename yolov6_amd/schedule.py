@@ -43,6 +43,15 @@ def op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
         if entry.get("res") is not None:
             rd.append(entry["res"])
         wr.append(entry["out"])                            # (the `mid` tensor of a fused pair is never written)
+    elif k == "conv_i8":                                   # int8 conv: reads the fp16 view or the producer's int8 twin of it,
+        rd.append(entry["x"])                              # writes the fp16 view and / or the int8 twin for ITS consumers
+        if entry.get("q_in") is not None:
+            rd.append(entry["q_in"])
+        if entry.get("res") is not None:
+            rd.append(entry["res"])
+        wr.append(entry["out"])                            # (kept even when the fp16 store is dropped: conservative)
+        if entry.get("q_out") is not None:
+            wr.append(entry["q_out"])
     elif k == "sppf":
         rd.append(entry["x"])
         wr += list(entry["outs"])
@@ -53,7 +62,7 @@ def op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
         rd += list(entry["cls_feat"]) + list(entry["reg_feat"])
         wr.append(entry["out"])
     else:
-        return None                                        # int8 twins, calibration slots, training ops: not scheduled
+        return None                                        # calibration slots, training ops: not scheduled
     return [_span(v) for v in rd], [_span(v) for v in wr]
 
 
