@@ -5,6 +5,8 @@
 #      was written for (the CSP-SPPF / neck 1x1s of YOLOv6-S at b32: 14-30 us each today)
 #      + the packed-maximum form of the SPPF pool kernel (same switch; 27.7 us per launch today, VALU-bound on unpacked fp16 compares)
 #      + one head-tail op per level instead of one for all (token `levels`): levels 0 / 1 decode beside the neck's small-map stretch
+#      + small-map convs lowered as two ops over the batch halves (token `split`): the 21 layers with at most one work item per CU
+#        become two independent chains the schedule runs side by side (the targeted form of the micro-batch A/B of r03r: +2.7 %)
 #   2. same-box A/B of the headline with each candidate alone and all together, one-stream and scheduled
 #   3. the training-forward schedule once more (r03v: no gain; the `alap` run ended on a different loss - if that repeats, find
 #      the undeclared dependence before anybody turns it on)
@@ -22,6 +24,9 @@ echo "pytest sppf (packed max) rc=$?"; tail -3 "$OUT/pytest_sppf_pk.log" | cut -
 # one head-tail op per level (y6_pred_decode_desc.first_anchor / total_anchors; the schedule then decodes levels 0 / 1 early)
 Y6_ENABLE_CANDIDATES=levels timeout 200 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k "model_vs_oracle or two_stream or rebind or full_resolution or dropin" > "$OUT/pytest_levels.log" 2>&1
 echo "pytest per-level head tail rc=$?"; tail -3 "$OUT/pytest_levels.log" | cut -c1-300; lap "levels parity"
+# small-map convs lowered per batch half (token `split`): two independent chains through the 20x20 / 40x40 stretches
+Y6_ENABLE_CANDIDATES=split timeout 250 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py tests/test_gpu_parity_bench.py -m gpu -q --tb=short --timeout 200 -p no:cacheprovider > "$OUT/pytest_split.log" 2>&1
+echo "pytest batch-half lowering rc=$?"; tail -3 "$OUT/pytest_split.log" | cut -c1-300; lap "split parity"
 # variants: 1-6 per-tap, 22/23 streaming, 38/39 K-resident
 L="512,256,1,1,20,20,32 256,256,1,1,20,20,32 1024,256,1,1,20,20,32 512,512,1,1,20,20,32 512,128,1,1,20,20,32 384,128,1,1,40,40,32 256,64,1,1,40,40,32 192,64,1,1,80,80,32 128,128,1,1,40,40,32"
 Y6_ENABLE_CANDIDATES=kres timeout 200 python tools/conv_bench.py --layers $L --variants 1 2 3 4 5 6 22 23 38 39 --iters 20 --out "$OUT/conv_bench_1x1.json" > "$OUT/conv_bench_1x1.log" 2>&1
@@ -42,6 +47,9 @@ run base1
 run kres1 Y6_ENABLE_CANDIDATES=kres
 run sppf1 Y6_ENABLE_CANDIDATES=sppf
 run levels1 Y6_ENABLE_CANDIDATES=levels
+run split1 Y6_ENABLE_CANDIDATES=split
+run split400 Y6_ENABLE_CANDIDATES=split Y6_SPLIT_MAX_HW=400
+run split_levels Y6_ENABLE_CANDIDATES=split,levels
 run all1 Y6_ENABLE_CANDIDATES=all
 run base2
 run all2 Y6_ENABLE_CANDIDATES=all

@@ -255,6 +255,11 @@ class PlanBuilder:
         self._elided = set()     # data_ptr of buffers whose producer was fused away
         import os
         self._fuse_s2 = not os.environ.get("Y6_NO_FUSE_S2")
+        # candidate (token `split`, written after round 3's last GPU visit): convs on small maps are lowered as TWO ops over the two
+        # halves of the batch.  A 20x20 / 40x40 layer has at most one work item per CU and costs 25-30 us whatever its FLOPs (DESIGN.md
+        # 9.1); the halves of consecutive layers form two independent chains, and the two-stream schedule runs them side by side.
+        self._split = _lib.candidate_enabled("split")
+        self._split_max_hw = int(os.environ.get("Y6_SPLIT_MAX_HW", "1600"))
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -444,9 +449,32 @@ class PlanBuilder:
                 and self.force_variant < 0 and Cin == Cout and Cout in (64, 128)):
             self._pending = dict(kind="pw", desc=d, entry=entry, out=out)
             return out
+        halves = self._batch_halves(x, out, res)
+        if halves is not None:
+            for xh, oh, rh in halves:
+                dh = _lib.ConvDesc.from_buffer_copy(d)
+                dh.inp, dh.out = xh.ct(), oh.ct()
+                dh.res = rh.ct() if rh is not None else _null_tensor()
+                _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(dh)), "plan_add_conv")
+                self.op_log.append(dict(entry, x=xh, out=oh, res=rh))
+            return out
         _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
         self.op_log.append(entry)
         return out
+
+    def _batch_halves(self, x: TRef, out: TRef, res: Optional[TRef]):
+        """[(x, out, res) views of images [0, B/2) and [B/2, B)] if this conv is lowered per batch half, else None."""
+        if not self._split or self.quant is not None or self.force_variant >= 0:
+            return None
+        if x.B < 4 or x.B % 2 or out.H * out.W > self._split_max_hw or x.H * x.W > 4 * self._split_max_hw:
+            return None
+
+        def half(t, i):
+            if t is None:
+                return None
+            hb = t.B // 2
+            return TRef(t.buf.view(t.B, t.H, t.W, t.cstride)[i * hb:(i + 1) * hb], hb, t.H, t.W, t.C, t.cstride, t.coff)
+        return [(half(x, i), half(out, i), half(res, i)) for i in range(2)]
 
     def _add_fused_pair(self, pend, d_s2, entry_s2) -> bool:
         """Add `held-back producer -> this 3x3 stride-2 conv` as one fused op, if the kernel takes the pair."""
