@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# First GPU visit of the round after round 3 (one box, about 4 minutes of box time):
+# First GPU visit of the round after round 3 (one box, 8-9 minutes of box time):
 #   1. the K-resident 1x1 kernel (kres1x1_c2 / kres1x1_c1, csrc/conv_mfma.hip; written after round 3's last GPU visit, selectable
 #      only with Y6_ENABLE_CANDIDATES=1): parity on its own shapes, then its time against every other 1x1 kernel on the layers it
 #      was written for (the CSP-SPPF / neck 1x1s of YOLOv6-S at b32: 14-30 us each today)
