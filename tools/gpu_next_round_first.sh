@@ -27,6 +27,11 @@ echo "pytest per-level head tail rc=$?"; tail -3 "$OUT/pytest_levels.log" | cut 
 # small-map convs lowered per batch half (token `split`): two independent chains through the 20x20 / 40x40 stretches
 Y6_ENABLE_CANDIDATES=split timeout 250 python -m pytest tests/test_gpu_model.py tests/test_gpu_dropin.py tests/test_gpu_parity_bench.py -m gpu -q --tb=short --timeout 200 -p no:cacheprovider > "$OUT/pytest_split.log" 2>&1
 echo "pytest batch-half lowering rc=$?"; tail -3 "$OUT/pytest_split.log" | cut -c1-300; lap "split parity"
+# the three-stage form of dma8_c4p1 (variant 40, token `stg3`): the dma parity tests, then its time against the two-stage form on its layers
+Y6_ENABLE_CANDIDATES=stg3 timeout 200 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short --timeout 150 -p no:cacheprovider -k "dma or conv_all_variants" > "$OUT/pytest_stg3.log" 2>&1
+echo "pytest stg3 rc=$?"; tail -3 "$OUT/pytest_stg3.log" | cut -c1-300
+Y6_ENABLE_CANDIDATES=stg3 timeout 150 python tools/conv_bench.py --layers 128,128,3,1,80,80,32 256,256,3,1,40,40,32 512,512,3,1,20,20,32 128,128,3,1,40,40,32 256,256,3,1,20,20,32 --variants 26 33 40 --iters 20 --out "$OUT/conv_bench_stg3.json" > "$OUT/conv_bench_stg3.log" 2>&1
+grep -v amdgpu "$OUT/conv_bench_stg3.log" | tail -16 | cut -c1-200; lap "stg3"
 # variants: 1-6 per-tap, 22/23 streaming, 38/39 K-resident
 L="512,256,1,1,20,20,32 256,256,1,1,20,20,32 1024,256,1,1,20,20,32 512,512,1,1,20,20,32 512,128,1,1,20,20,32 384,128,1,1,40,40,32 256,64,1,1,40,40,32 192,64,1,1,80,80,32 128,128,1,1,40,40,32"
 Y6_ENABLE_CANDIDATES=kres timeout 200 python tools/conv_bench.py --layers $L --variants 1 2 3 4 5 6 22 23 38 39 --iters 20 --out "$OUT/conv_bench_1x1.json" > "$OUT/conv_bench_1x1.log" 2>&1
@@ -47,6 +52,7 @@ run base1
 run kres1 Y6_ENABLE_CANDIDATES=kres
 run sppf1 Y6_ENABLE_CANDIDATES=sppf
 run levels1 Y6_ENABLE_CANDIDATES=levels
+run stg3 Y6_ENABLE_CANDIDATES=stg3
 run split1 Y6_ENABLE_CANDIDATES=split
 run split400 Y6_ENABLE_CANDIDATES=split Y6_SPLIT_MAX_HW=400
 run split_levels Y6_ENABLE_CANDIDATES=split,levels

@@ -40,6 +40,7 @@ def functions(path):
                 out[cur], cur, buf = buf, None, []
             else:
                 t = re.sub(r"\.Lfunc_\w+", "", re.sub(r"\.LBB\d+_", ".LBB_", re.sub(r";.*", "", line).strip()))
+                t = re.sub(r"\.Lpost_getpc\d+", ".Lpost_getpc", t)      # (long-branch labels are numbered per file)
                 if t:
                     buf.append(t)
     return out

@@ -1250,7 +1250,12 @@ const VariantCfg kVariants[] = {
     // per MFMA, so twice the couts per halo is where the stride-2 form can gain (it only won on the first layer)
     {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2},
     // persist == 5: the K-resident 1x1 kernel (small maps, many input channels; Y6_ENABLE_CANDIDATES=1 until measured)
-    {2, 1, 5, "kres1x1_c2"}, {1, 1, 5, "kres1x1_c1"}};
+    {2, 1, 5, "kres1x1_c2"}, {1, 1, 5, "kres1x1_c1"},
+    // dma8_c4p1 with THREE LDS stages (141 KB of its one block per CU): the pieces of chunk c+2 are requested while chunk c is
+    // multiplied and the wait in front of the chunk barrier is a counted vmcnt.  Round 2 measured a third stage on the 4-wave forms
+    // (-10 %: it cost them a resident block); this form has one block per CU either way, and its eight waves are the ones that wait
+    // together at the barrier (1 000 of 6 400 cycles per chunk).  Candidate token `stg3`.
+    {4, 1, 4, "dma8_c4p1s3", 8, 1, 3}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1721,6 +1726,10 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
         if (st != vc.cs || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here; vc.cs the stride)
+        if (vc.depth == 3) {
+            static const bool stg3 = y6_candidate_enabled("stg3");   // not measured on a device yet
+            if (!stg3) return 0;
+        }
         if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (vc.wres && d->in.C > 64) return 0;   // 9 x Cin x 64 couts of fp16 must fit beside two halo stages
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
@@ -1781,7 +1790,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 23: return launch_stream1x1_cfg<2>(L, s);
         case 38: return launch_kres1x1<2>(L, s);
         case 39: return launch_kres1x1<1>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 40:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
     }
