@@ -73,7 +73,8 @@ done
 lap "int8 schedule"
 for n in one asap alap one2 alap2; do
   case $n in one*) E="Y6_TRAIN_FWD_STREAMS=1";; asap*) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=asap";; *) E="Y6_TRAIN_FWD_STREAMS=2 Y6_TRAIN_FWD_POLICY=alap";; esac
-  env $E timeout 120 python bench.py --mode train > "$OUT/bench_train_$n.json" 2> "$OUT/bench_train_$n.err"
+  # one tuning cache for all five runs: identical kernel choices, so any difference in the losses is the schedule's
+  env $E Y6_AUTOTUNE_CACHE="$PWD/$OUT/autotune_train.cache" timeout 120 python bench.py --mode train > "$OUT/bench_train_$n.json" 2> "$OUT/bench_train_$n.err"
   python -c "import json; d=json.load(open('$OUT/bench_train_$n.json')); print('train $n', d['value'], d['ms_per_step'], d['loss'])" 2>/dev/null || echo "train $n: no result"
 done
 lap "training forward schedule"
