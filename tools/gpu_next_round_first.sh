@@ -55,6 +55,8 @@ run levels1 Y6_ENABLE_CANDIDATES=levels
 run stg3 Y6_ENABLE_CANDIDATES=stg3
 run split1 Y6_ENABLE_CANDIDATES=split
 run split400 Y6_ENABLE_CANDIDATES=split Y6_SPLIT_MAX_HW=400
+run split6400 Y6_ENABLE_CANDIDATES=split Y6_SPLIT_MAX_HW=6400      # + the 80x80 layers: their last partial round (3.1 -> 4) fills with the other half's blocks
+run split25600 Y6_ENABLE_CANDIDATES=split Y6_SPLIT_MAX_HW=25600    # every conv: micro-batching inside one plan
 run split_levels Y6_ENABLE_CANDIDATES=split,levels
 run all1 Y6_ENABLE_CANDIDATES=all
 run base2
