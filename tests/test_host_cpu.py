@@ -498,6 +498,43 @@ def test_schedule_runs_the_two_batch_halves_of_a_small_map_chain_side_by_side():
     assert pos[side[0]] <= pos[1] + 2                                # the side chain starts with the main chain, not after it
 
 
+@pytest.mark.parametrize("case", ["s", "l6_tiny", "m_tiny"])
+def test_batch_half_lowering_reproduces_the_reference_and_schedules_as_two_chains(case):
+    """Candidate lowering `split` on the CPU mock: every conv of a small map as two ops over views of the two batch halves
+    (engine.batch_halves - the same function the real builder uses).  The model output still equals the reference golden, and the
+    schedule built from that op log runs one half's chain on the side stream."""
+    from tests.helpers import case_golden, rel_err, synth_sd_from_keys
+    from tests.mock_plan import MockBuilder
+    from yolov6_amd import schedule as S
+    from yolov6_amd.engine import NCHWInput
+    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
+    cfg, meta = case_config(case)
+    m = build_model(cfg, meta["num_classes"], "cpu").eval()
+    m.load_state_dict(synth_sd_from_keys(meta["train"]))
+    m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
+    switch_to_deploy(fuse_model(m))
+    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
+    reps = 1 if (x.shape[0] >= 4 and x.shape[0] % 2 == 0) else (4 if x.shape[0] % 2 else max(2, 4 // x.shape[0]))
+    x4 = torch.cat([x] * reps, 0)                                             # the lowering needs an even batch of at least four
+    assert x4.shape[0] >= 4 and x4.shape[0] % 2 == 0
+    plain, split = MockBuilder(), MockBuilder(split_max_hw=10 ** 9)
+    with torch.no_grad():
+        d0 = m.lower(plain, NCHWInput(x4))
+        d1 = m.lower(split, NCHWInput(x4))
+    assert torch.equal(d0, d1), "batch halves change per-image results"
+    assert rel_err(d1[:x.shape[0]].numpy(), case_golden(case)["det_deploy"]) < 2e-4
+    n0 = sum(e["kind"] == "conv" for e in plain.op_log)
+    n1 = sum(e["kind"] == "conv" for e in split.op_log)
+    assert n1 == 2 * n0
+    acc = [S.op_access(e) for e in split.op_log]
+    deps = S.dependences(acc)
+    cost = [10.0 if e["kind"] == "conv" else 3.0 for e in split.op_log]
+    order, stream, edges = S.build_schedule(deps, cost, policy="alap")
+    S.check_schedule(deps, order, stream, edges)
+    side = [i for i in range(len(cost)) if stream[i]]
+    assert len(side) >= n0 // 2                                               # most of one half's convs run beside the other's
+
+
 def test_two_stream_schedule_random_dags():
     """Property check of schedule.build_schedule on random dependence graphs: valid for every graph, and a broken schedule (an
     edge removed) is caught by check_schedule."""

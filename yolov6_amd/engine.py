@@ -57,6 +57,21 @@ def _dtype_tag(t: torch.Tensor) -> int:
     raise RuntimeError(f"yolov6_amd: unsupported dtype {t.dtype} (fp16 / fp32, uint8 images at the stem)")
 
 
+def batch_halves(x: "TRef", out: "TRef", res: Optional["TRef"], max_hw: int):
+    """[(x, out, res) views of images [0, B/2) and [B/2, B)] for a conv that is lowered per batch half (candidate lowering
+    `split`: maps of at most `max_hw` output pixels, an even batch of at least four images), else None.  Pure view arithmetic:
+    the CPU mock of the plan builder (tests/mock_plan.py) lowers with the same function."""
+    if x.B < 4 or x.B % 2 or out.H * out.W > max_hw or x.H * x.W > 4 * max_hw:
+        return None
+
+    def half(t, i):
+        if t is None:
+            return None
+        hb = t.B // 2
+        return TRef(t.buf.view(t.B, t.H, t.W, t.cstride)[i * hb:(i + 1) * hb], hb, t.H, t.W, t.C, t.cstride, t.coff)
+    return [(half(x, i), half(out, i), half(res, i)) for i in range(2)]
+
+
 def _null_tensor() -> _lib.Tensor:
     return _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
 
@@ -466,15 +481,7 @@ class PlanBuilder:
         """[(x, out, res) views of images [0, B/2) and [B/2, B)] if this conv is lowered per batch half, else None."""
         if not self._split or self.quant is not None or self.force_variant >= 0:
             return None
-        if x.B < 4 or x.B % 2 or out.H * out.W > self._split_max_hw or x.H * x.W > 4 * self._split_max_hw:
-            return None
-
-        def half(t, i):
-            if t is None:
-                return None
-            hb = t.B // 2
-            return TRef(t.buf.view(t.B, t.H, t.W, t.cstride)[i * hb:(i + 1) * hb], hb, t.H, t.W, t.C, t.cstride, t.coff)
-        return [(half(x, i), half(out, i), half(res, i)) for i in range(2)]
+        return batch_halves(x, out, res, self._split_max_hw)
 
     def _add_fused_pair(self, pend, d_s2, entry_s2) -> bool:
         """Add `held-back producer -> this 3x3 stride-2 conv` as one fused op, if the kernel takes the pair."""
