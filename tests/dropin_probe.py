@@ -112,6 +112,20 @@ def load(ref_root, path):
     rep["fuse_model_is_ours"] = tu.fuse_model.__module__
     rep["time_sync_is_reference"] = tu.time_sync.__module__
     rep["checkpoint_is_ours"] = ck.__name__
+    # the four ComputeLoss classes core/engine.py:24-27 imports (its module body also needs cv2 / tensorboard / the data
+    # loaders, which are outside the hot path: import the four names the way that file does)
+    from yolov6.models.losses.loss import ComputeLoss as CL
+    from yolov6.models.losses.loss_fuseab import ComputeLoss as CL_ab
+    from yolov6.models.losses.loss_distill import ComputeLoss as CL_distill
+    from yolov6.models.losses.loss_distill_ns import ComputeLoss as CL_distill_ns
+    rep["loss_modules"] = [c.__module__ for c in (CL, CL_ab, CL_distill, CL_distill_ns)]
+    try:                                                 # and through the trainer module itself when its imports resolve
+        sys.modules.setdefault("torch.utils.tensorboard", types.ModuleType("torch.utils.tensorboard")).__dict__.setdefault("SummaryWriter", object)
+        import yolov6.core.engine as eng
+        rep["engine_loss_modules"] = [getattr(eng, n).__module__ for n in
+                                      ("ComputeLoss", "ComputeLoss_ab", "ComputeLoss_distill", "ComputeLoss_distill_ns")]
+    except Exception as e:                               # noqa: BLE001 - reported, the test decides
+        rep["engine_import_error"] = f"{type(e).__name__}: {e}"
     rep["backfilled"] = [n for n in ("RealVGGBlock", "LinearAddBlock", "Lite_EffiBlockS1", "MBLABlock") if hasattr(lc, n)]
     # the reference's Evaler.init_model, on CPU (no warm-up forward there): load_checkpoint -> fuse -> switch_to_deploy
     ev = Evaler.__new__(Evaler)

@@ -41,3 +41,10 @@ def test_reference_callers_run_on_the_overlay(tmp_path):
     assert rep["backend_model_type"] == "Model" and rep["backend_stride"] == 32
     assert rep["deploy_keys_equal"] and rep["deploy_max_diff"] < 1e-5
     assert rep["config_type"] == "YOLOv6s"
+    # every loss the reference trainer constructs (core/engine.py:24-27, :309-313) is this package's
+    assert rep["loss_modules"] == ["yolov6_amd.models.losses.loss", "yolov6_amd.models.losses.loss_fuseab",
+                                   "yolov6_amd.models.losses.loss_distill", "yolov6_amd.models.losses.loss_distill_ns"]
+    if "engine_loss_modules" in rep:
+        assert rep["engine_loss_modules"] == rep["loss_modules"]
+    else:                                                # the trainer module needs packages this image lacks: say which
+        print("yolov6.core.engine not importable here:", rep["engine_import_error"])

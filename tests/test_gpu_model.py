@@ -114,9 +114,10 @@ def test_train_form_eval_equals_deploy(case):
 
 
 def test_rebind_and_repeat():
-    """Model.forward hands out its detections without a copy (yolov6_amd/models/yolo.py: `output_buffers` result tensors per
-    plan, the decode op re-pointed per call): two consecutive results are independent tensors, the third call re-uses the
-    first one's memory (the documented contract), `output_buffers = 0` restores clone-per-call."""
+    """Model.forward hands out its detections without a copy (yolov6_amd/models/yolo.py `_ResultRing`: `output_buffers` result
+    tensors per plan, the decode op re-pointed per call).  A result is never overwritten while the caller holds it (the
+    reference returns independent tensors, yolo.py:37-47); once dropped, its memory is written again; `output_buffers = 0`
+    restores clone-per-call."""
     cfg, meta, sd, m = _build("tiny", deploy=True)
     x1 = synth.synth_images(2, 64, seed=5).to(DEV).half()
     x2 = synth.synth_images(2, 64, seed=6).to(DEV).half()
@@ -130,11 +131,24 @@ def test_rebind_and_repeat():
     c2 = a2.clone()
     a3, _ = m(x1.clone())
     assert torch.equal(a3, c1)           # deterministic, and the plan followed the new input pointer
-    assert torch.equal(a2, c2)
-    assert a3.data_ptr() == a1.data_ptr()
-    m.output_buffers = 3
-    r = [m(x)[0] for x in (x1, x2, x1)]
-    assert len({t.data_ptr() for t in r}) == 3 and torch.equal(r[0], c1) and torch.equal(r[1], c2)
+    assert torch.equal(a2, c2) and torch.equal(a1, c1)
+    assert a3.data_ptr() not in (a1.data_ptr(), a2.data_ptr())     # both earlier results are still held: neither is re-used
+    held = [m(x)[0] for x in (x1, x2, x1, x2, x1)]                  # results collected over several batches (TTA, deferred NMS)
+    torch.cuda.synchronize()
+    assert len({t.data_ptr() for t in held}) == 5
+    assert all(torch.equal(t, c) for t, c in zip(held, (c1, c2, c1, c2, c1)))
+    view = m(x2)[0][:, :10]              # only a view survives: its base must not be written either
+    for _ in range(4):
+        m(x1)
+    torch.cuda.synchronize()
+    assert torch.equal(view, c2[:, :10])
+    del a1, a2, a3, held, view
+    ptrs = set()
+    for _ in range(6):                   # the usual caller drops the result: two tensors alternate, nothing is allocated
+        t = m(x1)[0]
+        ptrs.add(t.data_ptr())
+        del t
+    assert len(ptrs) == 2
     m.output_buffers = 0
     b1, _ = m(x1)
     b2, _ = m(x2)

@@ -610,3 +610,37 @@ def test_native_state_never_pickled_or_deepcopied():
     # ... until something moves the parameters
     m.half()
     assert "_y6_arena" not in m.__dict__ and "_y6_train_graphs" not in m.__dict__
+
+
+def test_result_ring_never_overwrites_a_held_result():
+    """`Model.forward` hands out its detections without a copy (`_ResultRing`, models/yolo.py): the reference returns an
+    independent tensor per call (yolo.py:37-47), so a result - or a view of one - that the caller still holds must never
+    be the next run's output; results the caller dropped are written again (no allocation in the steady state)."""
+    from yolov6_amd.models.yolo import _ResultRing
+
+    class FakePlan:
+        def __init__(self):
+            self.outputs = torch.zeros(3)
+
+        def rebind_output(self, t):
+            self.outputs = t
+
+    plan = FakePlan()
+    ring = _ResultRing(plan.outputs, 2)
+
+    def call():
+        plan.rebind_output(ring.next(plan.outputs))
+        return plan.outputs
+
+    held = [call() for _ in range(5)]                   # TTA / results collected over several batches
+    assert len({id(t) for t in held}) == 5
+    view = call()[0:1]
+    later = [call() for _ in range(4)]
+    assert all(t is not view._base for t in later)      # a view keeps its base out of the rotation
+    del held, view, later
+    ids = set()
+    for _ in range(8):
+        t = call()
+        ids.add(id(t))
+        del t
+    assert len(ids) == 2                                # dropped results: the two slots alternate

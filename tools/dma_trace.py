@@ -24,7 +24,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = buf.cpu().view(256, 2).tolist()
 tags = {1: "kernel start", 2: "prologue done", 9: "chunk top (after prev taps/epilogue)", 10: "barrier passed", 11: "taps issued", 19: "chunk loop done",
-        20: "epilogue issued", 21: "args reloaded + output pixels", 22: "cout fragment 0 stored", 23: "cout fragment 1 stored"}
+        20: "epilogue issued", 21: "args reloaded + output pixels", 22: "cout fragment 0 stored", 23: "last item's epilogue units issued (kernel end)"}
 prev = t[0][0]
 acc = {}
 for ts, tag in t:

@@ -688,11 +688,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
                 if (do_item(yes_t{}, acc0, acc1)) {
 #pragma unroll
                     for (int u = 0; u < NUNIT; ++u) fast_unit(acc0, u);
+                    DT(23);
                     break;
                 }
                 if (do_item(yes_t{}, acc1, acc0)) {
 #pragma unroll
                     for (int u = 0; u < NUNIT; ++u) fast_unit(acc1, u);
+                    DT(23);
                     break;
                 }
             }

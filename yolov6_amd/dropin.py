@@ -11,7 +11,7 @@ distillation models - keeps loading from the reference checkout):
     yolov6.layers.common            -> yolov6_amd.layers.common      (+ the reference's other block classes, untouched,
                                                                       so `from yolov6.layers.common import *` stays complete)
     yolov6.models.{yolo,efficientrep,reppan,effidehead}              -> yolov6_amd.models.*
-    yolov6.models.losses.{loss,loss_fuseab}, yolov6.models.heads.{effidehead_fuseab,effidehead_distill_ns} -> yolov6_amd.models.*
+    yolov6.models.losses.{loss,loss_fuseab,loss_distill,loss_distill_ns}, yolov6.models.heads.{effidehead_fuseab,effidehead_distill_ns} -> yolov6_amd.models.*
     yolov6.assigners[.tal_assigner/.atss_assigner/.anchor_generator] -> yolov6_amd.assigners.*
     yolov6.utils.nms                -> yolov6_amd.utils.nms          (the reference's imports cv2 + torchvision at the top)
     yolov6.utils.checkpoint         -> yolov6_amd.utils.checkpoint   (same functions; torch>=2.6-safe un-pickling)
@@ -38,6 +38,8 @@ REPLACED = {
     "models.effidehead": "models.effidehead",
     "models.losses.loss": "models.losses.loss",
     "models.losses.loss_fuseab": "models.losses.loss_fuseab",
+    "models.losses.loss_distill": "models.losses.loss_distill",          # core/engine.py:26, used :309-313 (--distill)
+    "models.losses.loss_distill_ns": "models.losses.loss_distill_ns",    # core/engine.py:27 (n / s models: distill_ns head)
     "models.heads.effidehead_fuseab": "models.heads.effidehead_fuseab",
     "models.heads.effidehead_distill_ns": "models.heads.effidehead_distill_ns",
     "assigners": "assigners",

@@ -3,6 +3,7 @@ build_model :136-138).  `Model.forward(x)` keeps the reference contract
 `[detections[B,A,5+nc] fp32, featmaps]` but runs as one native plan of HIP kernels.
 """
 import math
+import sys
 import weakref
 
 import torch
@@ -43,12 +44,42 @@ class _LazyFeatmaps(list):
         return super().__getitem__(i)
 
 
+class _ResultRing:
+    """Result tensors of one plan, handed out WITHOUT a copy and never overwritten while somebody still holds them.
+
+    The reference returns an independent tensor per call (yolo.py:37-47: a fresh `torch.cat`).  Here the decode op writes into
+    one of `n` tensors of this ring, re-pointed per call (`Plan.rebind_output`).  A slot is written again only when nothing
+    but the ring references its tensor: CPython's reference count of the tensor object covers the caller's own name, list
+    entries and every view made from it (a view keeps its base alive through `_base`).  A slot that is still held is given
+    away - the ring allocates a fresh tensor for that position (no copy, no clone; the caching allocator makes it one pointer
+    bump) - so 3-pass TTA, results collected over several batches and consumers on other streams (which must hold a reference
+    while their kernels run, as with any caching-allocator tensor) all see the reference's semantics.  The usual caller
+    (evaler.py:128-132, inferer.py:61-63: straight into non_max_suppression, result dropped) never triggers an allocation."""
+
+    def __init__(self, like, n):
+        self.slots = [torch.empty_like(like) for _ in range(n)]
+        self.pos = 0
+        probe = [torch.empty(0)]
+        self._base = self._refs(probe, 0)        # references to a tensor that only its list holds, counted the same way
+
+    @staticmethod
+    def _refs(lst, i):
+        return sys.getrefcount(lst[i])
+
+    def next(self, held_by_plan=None):
+        """The tensor the next run writes.  `held_by_plan`: the plan's current output (its own reference is not a caller's)."""
+        self.pos = (self.pos + 1) % len(self.slots)
+        extra = 1 if held_by_plan is self.slots[self.pos] else 0
+        if self._refs(self.slots, self.pos) > self._base + extra:
+            self.slots[self.pos] = torch.empty_like(self.slots[self.pos])     # the caller keeps the old one
+        return self.slots[self.pos]
+
+
 class Model(HipModule):
     export = False
-    # Eval results are handed out WITHOUT a copy: the decode kernel alternates between this many output tensors per plan, so
-    # a returned `det` stays valid until `output_buffers` further eval calls of this model have been made (the reference's
-    # callers - evaler.py:128-132, inferer.py:61-63 - pass it straight to non_max_suppression).  0: clone every result
-    # (the reference's independent-tensor semantics at +91 MB of traffic per b32 call).
+    # Eval results are handed out WITHOUT a copy and stay valid for as long as the caller holds them (`_ResultRing`): the
+    # decode kernel alternates between this many output tensors per plan, re-using one only after the caller has dropped it.
+    # 0: clone every result (+91 MB of traffic per b32 call).
     output_buffers = 2
 
     def __init__(self, config, channels=3, num_classes=None, fuse_ab=False, distill_ns=False):
@@ -86,12 +117,9 @@ class Model(HipModule):
         nbuf = int(self.output_buffers)
         if nbuf >= 2:
             ring = getattr(plan, "_det_ring", None)
-            if ring is None or len(ring) != nbuf:
-                first = plan.outputs
-                ring = plan._det_ring = [first] + [torch.empty_like(first) for _ in range(nbuf - 1)]
-                plan._det_pos = 0
-            plan._det_pos = (plan._det_pos + 1) % nbuf
-            plan.rebind_output(ring[plan._det_pos])
+            if ring is None or len(ring.slots) != nbuf:
+                ring = plan._det_ring = _ResultRing(plan.outputs, nbuf)
+            plan.rebind_output(ring.next(plan.outputs))
         det = plan.run()
         feats = _LazyFeatmaps(self._featrefs, x.dtype)
         self.__dict__["_last_featmaps"] = weakref.ref(feats)
