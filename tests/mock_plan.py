@@ -20,8 +20,7 @@ def _act(y, kind):
 class MockBuilder:
     is_train = False
 
-    def __init__(self, split_max_hw=0):
-        self.split_max_hw = split_max_hw     # > 0: convs on small maps are lowered per batch half (engine.batch_halves)
+    def __init__(self):
         self.device = torch.device("cpu")
         self.quant = None
         self.force_variant = -1
@@ -81,18 +80,6 @@ class MockBuilder:
         w = weight.detach().float()
         Cout, Cin, K, _ = w.shape
         assert x.C == Cin
-        if self.split_max_hw and image is None:
-            from yolov6_amd.engine import batch_halves
-            Ho, Wo = (x.H + 2 * (K // 2) - K) // stride + 1, (x.W + 2 * (K // 2) - K) // stride + 1
-            full = out if out is not None else self.new_buffer(x.B, Ho, Wo, Cout)
-            hv = batch_halves(x, full, res, self.split_max_hw)
-            if hv is not None:
-                keep, self.split_max_hw = self.split_max_hw, 0
-                for xh, oh, rh in hv:                    # two ops on views of the same buffers
-                    self.conv(xh, weight, bias, stride, act, oh, post, rh, res_alpha)
-                self.split_max_hw = keep
-                return full
-            out = full
         y = F.conv2d(self._read(x), w, None if bias is None else bias.detach().float(), stride=stride, padding=K // 2)
         if post is not None:
             y = y * post[0].detach().float().view(1, -1, 1, 1) + post[1].detach().float().view(1, -1, 1, 1)

@@ -33,11 +33,6 @@ CONV_SHAPES = [
 ]
 if os.environ.get("Y6_TEST_UNSEEN") == "1":   # isolated probe of not-yet-measured variants: a stride-2 layer with more work items than blocks
     CONV_SHAPES.append((64, 128, 3, 2, 192, 192, 12))
-if os.environ.get("Y6_ENABLE_CANDIDATES", "") in ("1", "all") or "kres" in os.environ.get("Y6_ENABLE_CANDIDATES", ""):    # the K-resident 1x1 kernel (kres1x1_*, written after round 3's last GPU visit): one / two / three
-    # passes over the input channels, padded passes, ragged cout blocks and pixel counts, more fragments than waves
-    CONV_SHAPES += [(512, 256, 1, 1, 20, 20, 4), (1024, 256, 1, 1, 20, 20, 3), (384, 96, 1, 1, 13, 17, 2), (768, 128, 1, 1, 10, 14, 3),
-                    (128, 64, 1, 1, 40, 40, 2), (512, 512, 1, 1, 40, 40, 32), (192, 64, 1, 1, 9, 7, 1)]
-
 
 def _mk_weights(Cout, Cin, k, seed):
     g = torch.Generator().manual_seed(seed)

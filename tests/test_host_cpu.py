@@ -469,72 +469,6 @@ def test_schedule_access_lists_follow_int8_twins():
     assert S.op_access(dict(kind="absmax", x=ref(f16[0]), index=0)) is None
 
 
-def test_schedule_runs_the_two_batch_halves_of_a_small_map_chain_side_by_side():
-    """Candidate lowering `split` (engine.PlanBuilder._batch_halves): every conv of a small-map stretch becomes two ops over the
-    two halves of the batch.  Views of different halves share no bytes, so the halves of consecutive layers are two independent
-    chains; the schedule keeps one on the main stream and runs the other beside it, joined where an op reads whole tensors."""
-    from yolov6_amd import schedule as S
-    from yolov6_amd.engine import TRef
-    B, H, W, Cn, L = 8, 4, 4, 16, 5
-    bufs = [torch.zeros(B, H, W, Cn, dtype=torch.float16) for _ in range(L + 1)]
-    full = lambda t: TRef(t, B, H, W, Cn, Cn, 0)                                        # noqa: E731
-    half = lambda t, i: TRef(t.view(B, H, W, Cn)[i * 4:(i + 1) * 4], 4, H, W, Cn, Cn, 0)   # noqa: E731
-    log = [dict(kind="conv", x=full(torch.zeros(B, H, W, Cn, dtype=torch.float16)), out=full(bufs[0]), res=None)]   # unsplit producer
-    for l in range(L):
-        for i in range(2):
-            log.append(dict(kind="conv", x=half(bufs[l], i), out=half(bufs[l + 1], i), res=None))
-    log.append(dict(kind="decode", cls=[full(bufs[L])], reg=[full(bufs[L])], out=torch.zeros(B, 16, 8)))           # reads whole tensors
-    deps = S.dependences([S.op_access(e) for e in log])
-    assert deps[1] == [0] and deps[2] == [0]                      # both halves wait for the unsplit producer
-    for l in range(1, L):
-        assert deps[1 + 2 * l] == [1 + 2 * (l - 1)] and deps[2 + 2 * l] == [2 + 2 * (l - 1)]   # ... then only for their own half
-    assert deps[-1] == [2 * L - 1, 2 * L]                          # the join reads both
-    order, stream, edges = S.build_schedule(deps, [1.0] + [10.0] * (2 * L) + [1.0], policy="alap")
-    S.check_schedule(deps, order, stream, edges)
-    side = [i for i in range(len(log)) if stream[i]]
-    assert len(side) == L and all((i - 1) % 2 == (side[0] - 1) % 2 for i in side)          # exactly one of the two chains
-    assert len(edges) == 2                                           # fork after the producer, join in front of the reader
-    pos = {op: k for k, op in enumerate(order)}
-    assert pos[side[0]] <= pos[1] + 2                                # the side chain starts with the main chain, not after it
-
-
-@pytest.mark.parametrize("case", ["s", "l6_tiny", "m_tiny"])
-def test_batch_half_lowering_reproduces_the_reference_and_schedules_as_two_chains(case):
-    """Candidate lowering `split` on the CPU mock: every conv of a small map as two ops over views of the two batch halves
-    (engine.batch_halves - the same function the real builder uses).  The model output still equals the reference golden, and the
-    schedule built from that op log runs one half's chain on the side stream."""
-    from tests.helpers import case_golden, rel_err, synth_sd_from_keys
-    from tests.mock_plan import MockBuilder
-    from yolov6_amd import schedule as S
-    from yolov6_amd.engine import NCHWInput
-    from yolov6_amd.utils.torch_utils import fuse_model, switch_to_deploy
-    cfg, meta = case_config(case)
-    m = build_model(cfg, meta["num_classes"], "cpu").eval()
-    m.load_state_dict(synth_sd_from_keys(meta["train"]))
-    m.detect.proj_conv.weight.data = m.detect.proj.view(1, -1, 1, 1).clone()
-    switch_to_deploy(fuse_model(m))
-    x = synth.synth_images(meta["batch"], meta["size"], seed=1)
-    reps = 1 if (x.shape[0] >= 4 and x.shape[0] % 2 == 0) else (4 if x.shape[0] % 2 else max(2, 4 // x.shape[0]))
-    x4 = torch.cat([x] * reps, 0)                                             # the lowering needs an even batch of at least four
-    assert x4.shape[0] >= 4 and x4.shape[0] % 2 == 0
-    plain, split = MockBuilder(), MockBuilder(split_max_hw=10 ** 9)
-    with torch.no_grad():
-        d0 = m.lower(plain, NCHWInput(x4))
-        d1 = m.lower(split, NCHWInput(x4))
-    assert torch.equal(d0, d1), "batch halves change per-image results"
-    assert rel_err(d1[:x.shape[0]].numpy(), case_golden(case)["det_deploy"]) < 2e-4
-    n0 = sum(e["kind"] == "conv" for e in plain.op_log)
-    n1 = sum(e["kind"] == "conv" for e in split.op_log)
-    assert n1 == 2 * n0
-    acc = [S.op_access(e) for e in split.op_log]
-    deps = S.dependences(acc)
-    cost = [10.0 if e["kind"] == "conv" else 3.0 for e in split.op_log]
-    order, stream, edges = S.build_schedule(deps, cost, policy="alap")
-    S.check_schedule(deps, order, stream, edges)
-    side = [i for i in range(len(cost)) if stream[i]]
-    assert len(side) >= n0 // 2                                               # most of one half's convs run beside the other's
-
-
 def test_two_stream_schedule_random_dags():
     """Property check of schedule.build_schedule on random dependence graphs: valid for every graph, and a broken schedule (an
     edge removed) is caught by check_schedule."""

@@ -789,7 +789,6 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
             if (cf == 4 && pf == 1 && nw == 8) return launch_dma<4, 1, 8, 2, 2, 1, 16, false>(L, s);
             if (cf == 2 && pf == 4 && nw == 4) return launch_dma<2, 4, 4, 2, 2, 1, 16, false>(L, s);
         }
-        if (hc == 16 && stg == 3 && il == 1 && cf == 4 && pf == 1 && nw == 8) return launch_dma<4, 1, 8, 2, 3, 1, 16, false>(L, s);   // candidate `stg3`
         if (hc == 32 && stg == 2 && il == 1) {
             if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 32, false>(L, s);
         }

@@ -1128,98 +1128,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 1x1 conv, K-resident form - for the small maps (20x20 / 40x40 at b32: 12 800 / 51 200 pixels) with many input channels.
-// There the per-tap kernel above is a latency chain: it stages the pixel operand ONE 32-channel chunk ahead through registers,
-// so a 512-channel layer is 16 dependent global-load round trips with four MFMAs of work behind each, and with 1-2 blocks per
-// CU nothing hides them (CSP-SPPF's cv1: 3.4 GFLOP in 22.8 us, profiles/r03/bench_infer_ops_r03t.json).  The
-// streaming kernel above stops at Cin 256 (its weights live in registers).  Here
-//   * the weights of the block's cout fragments (CF x Cin/16 fragments of 1 KiB, at most 64 KiB) arrive in LDS by ONE burst
-//     of LDS-DMA requests and stay there for every pixel fragment the block processes;
-//   * a wave loads ALL k-steps of its 32-pixel fragment (up to 32 x 16 B per lane = 512 channels; more channels: a second
-//     pass over the same accumulators) with back-to-back global loads - one round trip, not sixteen;
-//   * no barrier after the first one; blocks are persistent over pixel fragments, cout blocks of a fragment share an XCD.
-// Written after round 3's last GPU visit: selectable only with Y6_ENABLE_CANDIDATES=1 (y6_conv_mfma_supports) until it has
-// been through tests/test_gpu_ops.py on a device (tools/gpu_next_round_first.sh).
-// ---------------------------------------------------------------------------------------------
-template <int CF, int KSP>   // KSP: k-steps (of 16 channels) per pass; Cin is padded to whole passes with zero weight fragments
-__global__ __launch_bounds__(256, 2) void conv1x1_kres_kernel(const ConvKArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [cf][padded k-step][lane][16 B]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    const int cb = (b >> 3) % a.ncb;
-    const int j = (b / (8 * a.ncb)) * 8 + (b & 7);
-    const int nstream = (gridDim.x / a.ncb) * 4;
-    const int npix = a.W;                                         // flattened B*H*W (build_launch)
-    const int nfrag = (npix + 31) >> 5;
-    const int nks = a.Cin >> 4;                                   // k-steps in all (Cin is a multiple of 16)
-    const int npass = (nks + KSP - 1) / KSP;
-    const int nksp = npass * KSP;
-
-    for (int q = wave; q < CF * nksp; q += 4) {                   // weight fragments -> LDS (zeros for the padding k-steps)
-        const int cf = q / nksp, ks = q - cf * nksp;
-        if (ks < nks) {
-            const __half* src = a.wpk + ((((size_t)(cb * CF + cf) * a.nchunk + (ks >> 1)) * 2 + (ks & 1)) * 64 + lane) * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, 0, 0);
-        } else {
-            *reinterpret_cast<uint4*>(smem + q * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-    BiasRegs<CF> bzall;
-    load_bias<CF>(a, cb, 0, lane, bzall);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave's pieces have landed
-
-    const char* wl = smem + lane * 16;
-    for (int f = j * 4 + wave; f < nfrag; f += nstream) {
-        int px = f * 32 + (lane & 31);
-        const int opix[1] = {px < npix ? px : -1};
-        px = px < npix ? px : npix - 1;                            // clamped rows are computed and dropped by the epilogue
-        const __half* p = a.in + (size_t)px * a.in_cs + a.in_co + (lane >> 5) * 8;
-        f32x16_t acc[CF][1];
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[cf][0][q] = 0.f;
-        for (int pass = 0; pass < npass; ++pass) {
-            const int k0 = pass * KSP;
-            h8_t r[KSP];
-#pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) {                     // a padding k-step re-reads k-step 0 (its weights are zero)
-                const int kk = __builtin_amdgcn_readfirstlane(k0 + ks < nks ? k0 + ks : 0);
-                r[ks] = *reinterpret_cast<const h8_t*>(p + kk * 16);
-            }
-            // every load of the pass is in flight before the first MFMA waits for one (hipcc otherwise sinks each load down to
-            // its use to save registers: load - wait - MFMA, the latency chain this kernel exists to avoid)
-            __builtin_amdgcn_sched_barrier(0);
-            const char* wp = wl + (size_t)k0 * 1024;
-            h8_t wv[2][CF];                                        // weight fragments one k-step ahead of the MFMAs
-#pragma unroll
-            for (int cf = 0; cf < CF; ++cf) wv[0][cf] = *reinterpret_cast<const h8_t*>(wp + (size_t)cf * nksp * 1024);
-#pragma unroll
-            for (int ks = 0; ks < KSP; ++ks) {
-                if (ks + 1 < KSP) {
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf)
-                        wv[(ks + 1) & 1][cf] = *reinterpret_cast<const h8_t*>(wp + ((size_t)cf * nksp + ks + 1) * 1024);
-                }
-#pragma unroll
-                for (int cf = 0; cf < CF; ++cf)
-                    acc[cf][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[ks & 1][cf], r[ks], acc[cf][0], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf) {
-            BiasRegs<1> bz;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) bz.v[0][q] = bzall.v[cf][q];
-            conv_epilogue<1, 1>(a, *reinterpret_cast<const f32x16_t(*)[1][1]>(&acc[cf]), opix, cb * CF + cf, 0, lane, bz);
-        }
-    }
-}
-
 // index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
 // 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
 const VariantCfg kVariants[] = {
@@ -1248,14 +1156,7 @@ const VariantCfg kVariants[] = {
     {2, 4, 4, "dma_c2p4", 4},
     // stride 2, 128 couts x 256 output pixels on eight waves: a stride-2 block stages four times the halo of a stride-1 one
     // per MFMA, so twice the couts per halo is where the stride-2 form can gain (it only won on the first layer)
-    {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2},
-    // persist == 5: the K-resident 1x1 kernel (small maps, many input channels; Y6_ENABLE_CANDIDATES=1 until measured)
-    {2, 1, 5, "kres1x1_c2"}, {1, 1, 5, "kres1x1_c1"},
-    // dma8_c4p1 with THREE LDS stages (141 KB of its one block per CU): the pieces of chunk c+2 are requested while chunk c is
-    // multiplied and the wait in front of the chunk barrier is a counted vmcnt.  Round 2 measured a third stage on the 4-wave forms
-    // (-10 %: it cost them a resident block); this form has one block per CU either way, and its eight waves are the ones that wait
-    // together at the barrier (1 000 of 6 400 cycles per chunk).  Candidate token `stg3`.
-    {4, 1, 4, "dma8_c4p1s3", 8, 1, 3}};
+    {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1507,44 +1408,6 @@ int launch_stream1x1_cfg(const Launch& L, hipStream_t s) {
     return Y6_EUNSUPPORTED;
 }
 
-// k-steps per pass of the K-resident 1x1 kernel: 16 when that wastes less of the last pass than 32 would
-inline int kres_ksp(int Cin) {
-    const int nks = Cin / 16, tail = nks % 32;
-    return (tail >= 1 && tail <= 16) ? 16 : 32;
-}
-inline size_t kres_lds(int cf, int Cin) {
-    const int ksp = kres_ksp(Cin);
-    return (size_t)cf * y6_cdiv(Cin / 16, ksp) * ksp * 1024;
-}
-
-template <int CF, int KSP>
-int launch_kres1x1_k(const Launch& L, hipStream_t s) {
-    auto kern = conv1x1_kres_kernel<CF, KSP>;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        Y6_HIP(hipGetDevice(&dev));
-        Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    const size_t lds = kres_lds(CF, L.k.Cin);
-    Y6_REQUIRE(lds <= 64 * 1024, "conv1x1_kres: %zu bytes of weight fragments per block", lds);
-    const int ncb = L.k.ncb;
-    const int nfrag = (L.k.W + 31) / 32;
-    const int unit = 8 * ncb;                                   // blocks come in groups of 8 (one per XCD) per cout block
-    int groups = (n_cu * 2) / unit;                             // two resident blocks per CU (64 KiB of LDS, 256 registers)
-    const int need = y6_cdiv(y6_cdiv(nfrag, 4), 8);             // groups that still get at least one fragment per wave
-    if (groups > need) groups = need;
-    if (groups < 1) groups = 1;
-    hipLaunchKernelGGL(kern, dim3(groups * unit), dim3(256), lds, s, L.k);
-    Y6_LAUNCH_CHECK();
-    return Y6_OK;
-}
-
-template <int CF>
-int launch_kres1x1(const Launch& L, hipStream_t s) {
-    return kres_ksp(L.k.Cin) == 16 ? launch_kres1x1_k<CF, 16>(L, s) : launch_kres1x1_k<CF, 32>(L, s);
-}
-
 template <int CF, int PF>
 int launch_persist_cfg(const Launch& L, int st, hipStream_t s) {
     if (st == 1) return launch_persist<CF, PF, 1>(L, s);
@@ -1715,21 +1578,9 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
-    if (vc.persist == 5) {   // K-resident 1x1: whole 16-channel k-steps, the block's weight fragments within 64 KiB of LDS
-        static const bool enabled = y6_candidate_enabled("kres");   // not measured on a device yet
-        if (!enabled || ks != 1 || st != 1 || d->w_packed == nullptr) return 0;
-        if (d->in.C % 16 || d->in.C < 64 || kres_lds(vc.cf, d->in.C) > 64 * 1024) return 0;
-        if (d->in.cstride % 8 || d->in.coff % 8 || ((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
-        if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
-        return vc.cf <= y6_cdiv(d->out.C, 32);
-    }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
         if (st != vc.cs || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here; vc.cs the stride)
-        if (vc.depth == 3) {
-            static const bool stg3 = y6_candidate_enabled("stg3");   // not measured on a device yet
-            if (!stg3) return 0;
-        }
         if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (vc.wres && d->in.C > 64) return 0;   // 9 x Cin x 64 couts of fp16 must fit beside two halo stages
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
@@ -1788,9 +1639,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 38: return launch_kres1x1<2>(L, s);
-        case 39: return launch_kres1x1<1>(L, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 40:
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
     }

@@ -489,25 +489,15 @@ __global__ __launch_bounds__(256) void stem_mfma_v4_kernel(const TI* __restrict_
 // ------------------------------------------------------------------ SPPF: 3 chained 5x5 s1 p2 max pools
 // One block = one image x 8 channels; the HxW plane lives in LDS; each pool is a
 // separable row-max / column-max pass with -inf padding (nn.MaxPool2d semantics).
-// PK: the eight-channel maximum as four v_pk_max_f16 (plus the canonicalising self-maxima hipcc adds) instead of eight
-// compare / select pairs on unpacked halves - the kernel is VALU-bound on those (64 v_cmp_gt_f16 + 69 v_cndmask + 96 shifts /
-// permutes + 68 s_nop in its four tap loops; 27.7 us per launch for 26 MB, profiles/r03/rocprofv3_kernel_stats_infer_r03t.csv).
-// Same values for finite inputs (the maximum is exact; a +0 / -0 tie may resolve to the other zero, NaNs are not propagated by
-// either form).  Written after round 3's last GPU visit: used only with Y6_ENABLE_CANDIDATES=1 until the bit-exact pool tests have
-// run it on a device (tools/gpu_next_round_first.sh).
-template <bool PK>
+// (Round 4, r04a: a packed-maximum form - four v_pk_max_f16 per eight channels - measured 32 -> 31 us: the kernel is bound by its
+// 16-byte-per-pixel global accesses, not by the compares; removed.)
 __device__ __forceinline__ h8_t hmax8(const h8_t& v, const h8_t& m) {
-    if constexpr (PK) {
-        return __builtin_elementwise_max(v, m);
-    } else {
-        h8_t r = m;
+    h8_t r = m;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = v[j] > m[j] ? v[j] : m[j];
-        return r;
-    }
+    for (int j = 0; j < 8; ++j) r[j] = v[j] > m[j] ? v[j] : m[j];
+    return r;
 }
 
-template <bool PK>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const __half* __restrict__ x, int x_cs, int x_co,
                                                         __half* __restrict__ y1, int y1_cs, int y1_co,
                                                         __half* __restrict__ y2, int y2_cs, int y2_co,
@@ -532,7 +522,7 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const __half* __restrict
             for (int d = -2; d <= 2; ++d) {
                 const int x2 = xx + d;
                 if (d == 0 || x2 < 0 || x2 >= W) continue;
-                m = hmax8<PK>(cur[yy * W + x2], m);
+                m = hmax8(cur[yy * W + x2], m);
             }
             tmp[p] = m;
         }
@@ -543,7 +533,7 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const __half* __restrict
             for (int d = -2; d <= 2; ++d) {
                 const int y2i = yy + d;
                 if (d == 0 || y2i < 0 || y2i >= H) continue;
-                m = hmax8<PK>(tmp[y2i * W + xx], m);
+                m = hmax8(tmp[y2i * W + xx], m);
             }
             *reinterpret_cast<h8_t*>(outs[pass] + (pbase + p) * ocs[pass] + oco[pass] + cg * 8) = m;
             // safe to overwrite cur[p]: the column pass reads tmp only
@@ -861,8 +851,7 @@ extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_te
                    "sppf_pool: output %d shape/alignment mismatch", i);
     const size_t lds = (size_t)x->H * x->W * 16 * 2;
     Y6_REQUIRE(lds <= 160 * 1024, "sppf_pool: plane %dx%d too large for LDS", x->H, x->W);
-    static const bool packed_max = y6_candidate_enabled("sppf");
-    auto kern = packed_max ? sppf_pool_kernel<true> : sppf_pool_kernel<false>;
+    auto kern = sppf_pool_kernel;
     if (lds > 64 * 1024)
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int C8 = x->C / 8;

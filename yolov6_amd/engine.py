@@ -57,21 +57,6 @@ def _dtype_tag(t: torch.Tensor) -> int:
     raise RuntimeError(f"yolov6_amd: unsupported dtype {t.dtype} (fp16 / fp32, uint8 images at the stem)")
 
 
-def batch_halves(x: "TRef", out: "TRef", res: Optional["TRef"], max_hw: int):
-    """[(x, out, res) views of images [0, B/2) and [B/2, B)] for a conv that is lowered per batch half (candidate lowering
-    `split`: maps of at most `max_hw` output pixels, an even batch of at least four images), else None.  Pure view arithmetic:
-    the CPU mock of the plan builder (tests/mock_plan.py) lowers with the same function."""
-    if x.B < 4 or x.B % 2 or out.H * out.W > max_hw or x.H * x.W > 4 * max_hw:
-        return None
-
-    def half(t, i):
-        if t is None:
-            return None
-        hb = t.B // 2
-        return TRef(t.buf.view(t.B, t.H, t.W, t.cstride)[i * hb:(i + 1) * hb], hb, t.H, t.W, t.C, t.cstride, t.coff)
-    return [(half(x, i), half(out, i), half(res, i)) for i in range(2)]
-
-
 def _null_tensor() -> _lib.Tensor:
     return _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
 
@@ -270,11 +255,6 @@ class PlanBuilder:
         self._elided = set()     # data_ptr of buffers whose producer was fused away
         import os
         self._fuse_s2 = not os.environ.get("Y6_NO_FUSE_S2")
-        # candidate (token `split`, written after round 3's last GPU visit): convs on small maps are lowered as TWO ops over the two
-        # halves of the batch.  A 20x20 / 40x40 layer has at most one work item per CU and costs 25-30 us whatever its FLOPs (DESIGN.md
-        # 9.1); the halves of consecutive layers form two independent chains, and the two-stream schedule runs them side by side.
-        self._split = _lib.candidate_enabled("split")
-        self._split_max_hw = int(os.environ.get("Y6_SPLIT_MAX_HW", "1600"))
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -464,24 +444,9 @@ class PlanBuilder:
                 and self.force_variant < 0 and Cin == Cout and Cout in (64, 128)):
             self._pending = dict(kind="pw", desc=d, entry=entry, out=out)
             return out
-        halves = self._batch_halves(x, out, res)
-        if halves is not None:
-            for xh, oh, rh in halves:
-                dh = _lib.ConvDesc.from_buffer_copy(d)
-                dh.inp, dh.out = xh.ct(), oh.ct()
-                dh.res = rh.ct() if rh is not None else _null_tensor()
-                _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(dh)), "plan_add_conv")
-                self.op_log.append(dict(entry, x=xh, out=oh, res=rh))
-            return out
         _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
         self.op_log.append(entry)
         return out
-
-    def _batch_halves(self, x: TRef, out: TRef, res: Optional[TRef]):
-        """[(x, out, res) views of images [0, B/2) and [B/2, B)] if this conv is lowered per batch half, else None."""
-        if not self._split or self.quant is not None or self.force_variant >= 0:
-            return None
-        return batch_halves(x, out, res, self._split_max_hw)
 
     def _add_fused_pair(self, pend, d_s2, entry_s2) -> bool:
         """Add `held-back producer -> this 3x3 stride-2 conv` as one fused op, if the kernel takes the pair."""
@@ -696,23 +661,6 @@ class PlanBuilder:
             return None
         self.keep.append(out)
         cpu = lambda ps: [(w.detach().float().cpu(), None if b is None else b.detach().float().cpu()) for w, b in ps]   # noqa: E731
-        if _lib.candidate_enabled("levels") and len(cls_feat) > 1:
-            # candidate (written after round 3's last GPU visit): one head-tail op per level, each writing its rows of `out`
-            # (y6_pred_decode_desc.first_anchor / total_anchors) - the two-stream schedule can then decode a level as soon as its
-            # convs are done, beside the neck's small-map stretch, instead of all 8 400 anchors at the very end (69 us, HBM-bound)
-            first = 0
-            for i in range(len(cls_feat)):
-                di = self._pred_decode_desc(cls_feat[i:i + 1], reg_feat[i:i + 1], cls_preds[i:i + 1], reg_preds[i:i + 1], strides[i:i + 1],
-                                            use_dfl, reg_max, proj, nc, grid_cell_offset, out, first_anchor=first, total_anchors=A)
-                if not self.lib.y6_head_pred_decode_supported(C.byref(di)):
-                    raise RuntimeError("yolov6_amd: per-level head tail refused a level the fused kernel took")
-                _lib.check(self.lib.y6_plan_add_pred_decode(self.h, C.byref(di)), "plan_add_pred_decode")
-                self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat[i:i + 1]), reg_feat=list(reg_feat[i:i + 1]),
-                                        cls_preds=cpu(cls_preds[i:i + 1]), reg_preds=cpu(reg_preds[i:i + 1]), out=out,
-                                        strides=list(strides[i:i + 1]), use_dfl=bool(use_dfl), reg_max=int(reg_max), proj=proj, nc=nc,
-                                        first_anchor=first, total_anchors=A))
-                first += cls_feat[i].H * cls_feat[i].W
-            return out
         _lib.check(self.lib.y6_plan_add_pred_decode(self.h, C.byref(d)), "plan_add_pred_decode")
         self.op_log.append(dict(kind="pred_decode", cls_feat=list(cls_feat), reg_feat=list(reg_feat),
                                 cls_preds=cpu(cls_preds), reg_preds=cpu(reg_preds),
@@ -730,8 +678,7 @@ class PlanBuilder:
         import os
         # two-stream schedule of run(): on since r03u (+2.0 % img/s same box, alternating runs, bit-identical results:
         # profiles/r03/bench_infer_r03u_*.json); Y6_SCHED_STREAMS=1 keeps every op on the caller's stream
-        # (int8 plans: the twin-aware access lists exist but have not been on a device - candidate token `i8sched`)
-        if os.environ.get("Y6_SCHED_STREAMS", "2") == "2" and (
-                self.quant is None or (self.quant.mode == "int8" and _lib.candidate_enabled("i8sched"))):
+        # (int8 plans too since r04a: twin-aware access lists, 12 259 -> 12 405 img/s same box, int8 GPU tests green with it on)
+        if os.environ.get("Y6_SCHED_STREAMS", "2") == "2" and (self.quant is None or self.quant.mode == "int8"):
             plan.schedule()
         return plan
