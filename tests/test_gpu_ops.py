@@ -118,6 +118,58 @@ def test_conv_dma_fast_epilogue_with_post_affine():
             assert err < 2.01 * 2.0 ** -10, f"{n}/{act}: {err:.3e}"   # two fp16 roundings (conv output, affine output)
 
 
+def test_conv_wreg_variants():
+    """The register-fed 3x3 kernels (csrc/conv_wreg.hip: weight fragments global -> VGPR, halo in 32-channel LDS stages): several
+    items per block (stage ping-pong and weight ring across items), one / two / eight stages per item, one / two cout blocks,
+    tile overhang on both axes, the 64-cout form; then the epilogue modes (SiLU, kept post-affine, BottleRep residual) and a
+    view with a channel offset on both sides."""
+    names = G.variant_names()
+    wreg = [v for v, n in enumerate(names) if n.startswith("wreg")]
+    if not wreg or not any(G.supports(G.rand_nhwc(1, 8, 8, 32, seed=1), torch.zeros(128, 32, 3, 3), 1, v) for v in wreg):
+        pytest.skip("wreg variants are not enabled in this build / environment")
+    shapes = [(64, 128, 80, 80, 6), (32, 128, 80, 80, 20), (128, 64, 36, 52, 4), (32, 256, 21, 19, 9), (256, 256, 20, 20, 8),
+              (64, 64, 50, 70, 5), (128, 128, 40, 40, 33)]
+    for (Cin, Cout, H, W, B) in shapes:
+        x = G.rand_nhwc(B, H, W, Cin, seed=41)
+        w, b = _mk_weights(Cout, Cin, 3, 42)
+        ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, 1, "relu")
+        ran = 0
+        for v in wreg:
+            if not G.supports(x, w, 1, v):
+                continue
+            o, _ = G.run_conv(x, w, b, 1, "relu", v)
+            err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+            assert err < TOL, f"{names[v]}: max rel err {err:.3e} on {(Cin, Cout, H, W, B)}"
+            ran += 1
+        assert ran >= 2, (Cin, Cout, ran)
+    # epilogue modes
+    B, H, W, Cin, Cout = 5, 40, 40, 64, 128
+    x = G.rand_nhwc(B, H, W, Cin, seed=43)
+    w, b = _mk_weights(Cout, Cin, 3, 44)
+    g = torch.Generator().manual_seed(45)
+    post = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1)
+    for act, pst in (("silu", None), ("relu", post), (None, post)):
+        ref = G.conv_reference(G.nhwc_to_nchw_f32(x), w, b, 1, act, pst)
+        for v in wreg:
+            if G.supports(x, w, 1, v):
+                o, _ = G.run_conv(x, w, b, 1, act, v, post=pst)
+                err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
+                assert err < 2.01 * 2.0 ** -10, f"{names[v]}/{act}/{pst is not None}: {err:.3e}"
+    # channel-sliced views: input channels [32, 96) of a 128-channel buffer, output channels [128, 256) of a 384-channel buffer
+    big = G.rand_nhwc(B, H, W, 128, seed=46)
+    xin = TRef(big.buf, B, H, W, 64, 128, 32)
+    outbuf = torch.zeros((B, H, W, 384), dtype=torch.float16, device=G.DEV)
+    oview = TRef(outbuf, B, H, W, Cout, 384, 128)
+    ref = G.conv_reference(G.nhwc_to_nchw_f32(xin), w, b, 1, "relu")
+    for v in wreg:
+        if G.supports(xin, w, 1, v):
+            outbuf.zero_()
+            G.run_conv(xin, w, b, 1, "relu", v, out=oview)
+            err = G.max_rel(G.nhwc_to_nchw_f32(oview), ref)
+            assert err < TOL, f"{names[v]} on channel-sliced views: {err:.3e}"
+            assert float(outbuf[..., :128].abs().max()) == 0.0 and float(outbuf[..., 256:].abs().max()) == 0.0   # nothing outside the view
+
+
 def test_conv_mfma_layout_is_not_transposed():
     """Asymmetric weights: output channel c copies input channel (c+1)%C of the centre tap only."""
     C_, H, W = 64, 16, 16

@@ -1,0 +1,11 @@
+#!/usr/bin/env bash
+# Round 4, visit b: first run of the register-fed 3x3 kernels (csrc/conv_wreg.hip): parity, then the layer table against the LDS-DMA forms
+set -u
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 Y6_ENABLE_CANDIDATES=wreg
+OUT=gpurun_out/${1:-r04b}; mkdir -p "$OUT"
+timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short --timeout 300 -p no:cacheprovider -k "wreg or conv_all_variants or tap_geometry or not_transposed" > "$OUT/pytest_wreg.log" 2>&1
+echo "pytest wreg rc=$?"; tail -15 "$OUT/pytest_wreg.log" | cut -c1-400
+L="64,64,3,1,160,160,32 128,128,3,1,80,80,32 256,256,3,1,40,40,32 512,512,3,1,20,20,32 128,128,3,1,40,40,32 256,256,3,1,20,20,32 64,64,3,1,80,80,32 128,64,3,1,80,80,32 256,128,3,1,40,40,32 512,256,3,1,20,20,32"
+timeout 300 python tools/conv_bench.py --layers $L --variants 25 26 33 38 39 40 41 42 --iters 20 --out "$OUT/conv_bench_wreg.json" > "$OUT/conv_bench_wreg.log" 2>&1
+grep -v amdgpu "$OUT/conv_bench_wreg.log" | tail -80 | cut -c1-200
+echo done

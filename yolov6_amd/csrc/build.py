@@ -26,6 +26,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 SOURCES = {
     "conv_mfma.hip": [],
     "conv_dma.hip": [],
+    "conv_wreg.hip": [],
     "conv_misc.hip": [],
     "conv_fused.hip": [],
     "preproc.hip": ["-ffp-contract=off"],

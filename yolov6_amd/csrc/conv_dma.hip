@@ -31,44 +31,6 @@
 
 namespace {
 
-__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long long p = (unsigned long long)(uintptr_t)base;
-    i32x4_t r;
-    r[0] = (int)(unsigned)(p & 0xffffffffu);
-    r[1] = (int)(unsigned)((p >> 32) & 0xffffu);   // stride 0: raw buffer, byte offsets, range check against num_records
-    r[2] = (int)bytes;
-    r[3] = 0x00020000;
-    return r;
-}
-
-// one LDS-DMA piece: lane i writes 16 B to lds_dst + 16*i from rsrc.base + voff(lane) + soff; out of range -> zeros.
-// Issued from inline asm (hipcc neither counts it nor fences later ds_reads against it; completion = the kernel's own
-// vmcnt(0) + barrier).  M0 is saved/restored inside the statement (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void dma16(const i32x4_t& rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
-        : "memory");   // (both are wave-uniform by construction; under register pressure hipcc may still carry them in VGPRs)
-}
-
-// The argument block again, loaded where it is used.  The epilogue reads two dozen fields of ConvKArgs; taken from the
-// by-value kernel parameter they are loaded at kernel entry and stay live across the chunk loop (200+ spilled SGPRs,
-// v_readlane traffic inside the loop).  Re-reading the kernarg segment through a laundered pointer gives the epilogue
-// its own short-lived copies (scalar loads, once per work item).
-__device__ __forceinline__ ConvKArgs reload_args() {
-    unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(v));
-    const __attribute__((address_space(4))) unsigned* src = reinterpret_cast<const __attribute__((address_space(4))) unsigned*>(v);
-    static_assert(sizeof(ConvKArgs) % 4 == 0, "ConvKArgs is copied dword by dword");
-    ConvKArgs r;
-    unsigned* dst = reinterpret_cast<unsigned*>(&r);
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(ConvKArgs) / 4; ++i) dst[i] = src[i];   // scalar loads of the fields the caller uses
-    return r;
-}
-
 // Ceiling probes / trace (tools/build_probe_libs.py --dma; WRONG RESULTS for n >= 2, timing only), compile-time:
 //   1 = s_memtime trace of block 0 / thread 0 into a.dbg (tools/dma_trace.py); 2 = no epilogue; 3 = no MFMAs;
 //   4 = no LDS-DMA requests after the prologue; 5 = fragment reads of tap 0 only (MFMAs on stale operands);
@@ -97,13 +59,6 @@ constexpr bool kProbeNoEpilogue = kDmaProbe == 2 || kDmaProbe == 7 || kDmaProbe 
 #ifndef Y6_DMA_PIX16_HOIST
 #define Y6_DMA_PIX16_HOIST 1
 #endif
-
-constexpr unsigned kOob = 0xf0000000u;   // voffset of a piece that must read zeros / a store that must be dropped (tensors stay below 3.5 GiB)
-
-// lane (0..31) -> pixel of the fragment it holds (see the header comment)
-__device__ __forceinline__ int frag_pixel(int l) {
-    return l < 4 ? l : (l < 12 ? l + 12 : (l < 16 ? l - 8 : (l < 20 ? l + 8 : (l < 28 ? l - 12 : l))));
-}
 
 template <int BP, int ST = 1>
 struct DmaHaloCap {   // halo pixels per plane for BP output pixels (stride 2: (2 TH + 1) x (2 TW + 1) input pixels)

@@ -1156,7 +1156,12 @@ const VariantCfg kVariants[] = {
     {2, 4, 4, "dma_c2p4", 4},
     // stride 2, 128 couts x 256 output pixels on eight waves: a stride-2 block stages four times the halo of a stride-1 one
     // per MFMA, so twice the couts per halo is where the stride-2 form can gain (it only won on the first layer)
-    {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2}};
+    {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2},
+    // persist == 6: weights through registers, halo in 32-channel LDS stages (conv_wreg.hip).  cf = waves along the couts (32 each),
+    // pf = pixel fragments per wave, nw = waves per block (nw / cf pixel groups): 128 couts x pf * 32 pixels on four waves, two
+    // blocks per CU; 64 couts x 2 * pf * 32 pixels for the 64-channel layers.  The tile (TH x TW <= the block's pixel slots) is
+    // chosen for whole rounds of the persistent walk (choose_tile_wreg).
+    {4, 8, 6, "wreg_p8", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {2, 8, 6, "wreg2_p8", 4}, {2, 7, 6, "wreg2_p7", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1202,6 +1207,48 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
 }
 
 
+// conv_wreg.hip: halo row pitch for a tile width (a read group that wraps to the next tile row must continue at a pixel index
+// that is consecutive modulo 16), 1 KiB requests per stage image, and the tile itself
+int wreg_row_pitch(int TW) { return TW % 16 == 0 ? TW + 2 : TW + 16; }
+int wreg_pieces(int TH, int TW) { return y6_cdiv(5 * (TH + 2) * wreg_row_pitch(TW), 64); }
+// TH x TW <= bp pixel slots: fewest rounds of the persistent walk (items / resident blocks, rounded up) first - a block's time is
+// its pixel SLOTS, so a tile that divides the map with a few idle slots beats a full tile that leaves a partial last round -
+// then the fewest items (less padding inside the rounds), then the smallest stage image
+void choose_tile_wreg(int B, int Ho, int Wo, int ncb, int bp, int max_pieces, int slots, int* pTH, int* pTW) {
+    long best_rounds = -1, best_items = 0;
+    int best_halo = 0, bTH = 1, bTW = 1;
+    for (int TW = 1; TW <= (Wo < bp ? Wo : bp); ++TW) {
+        int TH = bp / TW;
+        if (TH > Ho) TH = Ho;
+        while (TH >= 1 && wreg_pieces(TH, TW) > max_pieces) --TH;
+        if (TH < 1) continue;
+        // (a smaller TH with the same row count per map never hurts the rounds: take the smallest that keeps the tile count)
+        const int ty = y6_cdiv(Ho, TH);
+        TH = y6_cdiv(Ho, ty);
+        const long items = (long)B * ty * y6_cdiv(Wo, TW) * ncb;
+        const long rounds = (items + slots - 1) / slots;
+        const int halo = wreg_pieces(TH, TW);
+        if (best_rounds < 0 || rounds < best_rounds || (rounds == best_rounds && (items < best_items || (items == best_items && halo < best_halo)))) {
+            best_rounds = rounds;
+            best_items = items;
+            best_halo = halo;
+            bTH = TH;
+            bTW = TW;
+        }
+    }
+    *pTH = bTH;
+    *pTW = bTW;
+}
+
+int device_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx, Launch* L) {
     const VariantCfg& vc = kVariants[variant];
     const int ks = d->ksize, st = d->stride;
@@ -1238,7 +1285,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.upH = d->in.H;
     k.upW = d->in.W;
     k.upC = up == 2 ? d->out.C / 4 : d->out.C;
-    const int bp = 32 * vc.nw * vc.pf;
+    const int bp = vc.persist == 6 ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
     if (ks == 1) {
         // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row
         const long npix = (long)d->in.B * d->in.H * d->in.W;
@@ -1256,7 +1303,10 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.Ho = d->out.H;
         k.Wo = d->out.W;
         const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp, vc.cs) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
-        choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
+        if (vc.persist == 6)   // two 4-wave blocks per CU
+            choose_tile_wreg(k.B, k.Ho, k.Wo, y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf), bp, y6_conv_wreg_max_pieces(vc.nw), 2 * device_cus(), &k.TH, &k.TW);
+        else
+            choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
     }
     k.tiles_x = y6_cdiv(k.Wo, k.TW);
     k.tiles_y = y6_cdiv(k.Ho, k.TH);
@@ -1273,7 +1323,12 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
     L->grid = k.nids;
-    if (vc.persist == 4) {
+    if (vc.persist == 6) {
+        k.dma_rp = wreg_row_pitch(k.TW);
+        k.dma_pls = k.HH * k.dma_rp;
+        k.dma_nhp = wreg_pieces(k.TH, k.TW);
+        L->lds = 2 * (size_t)k.dma_nhp * 1024 + 1024;   // two stage images + the dummy request target
+    } else if (vc.persist == 4) {
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
         k.dma_nhp = y6_cdiv((vc.hc / 8) * k.dma_pls, 64);
@@ -1579,6 +1634,14 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist && ks != 3) return 0;
+    if (vc.persist == 6) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
+        static const bool enabled = y6_candidate_enabled("wreg");   // until its parity tests have run on a device
+        if (!enabled || st != 1 || d->w_packed == nullptr) return 0;
+        if (d->in.C % 32 || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
+        if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
+        if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;
+        return 1;
+    }
     if (vc.persist == 4) {   // LDS-DMA kernels: whole 16-channel chunks, 16-byte pieces straight from the tensor
         if (st != vc.cs || d->w_packed == nullptr) return 0;   // (vc.st is the issue mode here; vc.cs the stride)
         if (d->in.C % vc.hc || d->in.cstride % 8 || d->in.coff % 8) return 0;
@@ -1639,6 +1702,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
+        case 38: case 39: case 40: case 41: case 42:
+            return y6_conv_wreg_launch(&L, kVariants[variant].pf, kVariants[variant].cf, kVariants[variant].nw / kVariants[variant].cf, s);
         case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
