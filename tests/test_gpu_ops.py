@@ -170,6 +170,36 @@ def test_conv_wreg_variants():
             assert float(outbuf[..., :128].abs().max()) == 0.0 and float(outbuf[..., 256:].abs().max()) == 0.0   # nothing outside the view
 
 
+def test_conv_wreg_bits_do_not_depend_on_what_else_runs():
+    """The register-fed kernels order their own loads by hand (`s_waitcnt vmcnt(N)`): the same launch must give the same bits
+    every time, also beside a bandwidth-hungry kernel on a second stream.  (LDS-DMA requests and loads into VGPRs do not retire
+    in order with respect to each other on gfx950: the first version of the kernel counted the halo burst into its waits, passed
+    every parity test on an idle chip and failed 299 of 300 runs of this test - profiles/r04/wreg_stress_r04h.log.)  The LDS-DMA
+    kernels (one vmcnt(0) per chunk) run the same gauntlet."""
+    names = G.variant_names()
+    todo = [v for v, n in enumerate(names) if n.startswith("wreg") or n in ("dma_c2p2", "dma8_c4p1")]
+    side = torch.cuda.Stream()
+    big = torch.empty(256 << 20, dtype=torch.uint8, device=G.DEV)
+    for (Cin, Cout, H, W, B) in [(128, 128, 80, 80, 32), (256, 256, 20, 20, 32)]:
+        x = G.rand_nhwc(B, H, W, Cin, seed=51)
+        x.buf.clamp_(min=0)
+        w, b = _mk_weights(Cout, Cin, 3, 52)
+        ref = G.conv_reference(G.nhwc_to_nchw_f32(TRef(x.buf[:2].contiguous(), 2, H, W, Cin, Cin, 0)), w, b, 1, "relu")
+        for v in todo:
+            if not G.supports(x, w, 1, v):
+                continue
+            o, plan = G.run_conv(x, w, b, 1, "relu", v)
+            first = o.to_nhwc_tensor().clone()
+            assert G.max_rel(first[:2].float().cpu().permute(0, 3, 1, 2), ref) < TOL, names[v]
+            for it in range(60):
+                o.buf.fill_(7.0)
+                with torch.cuda.stream(side):
+                    big.add_(1)
+                plan.run()
+                torch.cuda.synchronize()
+                assert torch.equal(o.to_nhwc_tensor(), first), f"{names[v]} on {(Cin, Cout, H, W, B)}: run {it} differs from the first"
+
+
 def test_conv_mfma_layout_is_not_transposed():
     """Asymmetric weights: output channel c copies input channel (c+1)%C of the centre tap only."""
     C_, H, W = 64, 16, 16

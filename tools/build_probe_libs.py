@@ -50,6 +50,25 @@ if len(sys.argv) > 1 and sys.argv[1] in ("--dma-pixmajor", "--dma-planar"):
     print("built", lib)
     sys.exit(0)
 
+def one_wreg(n):
+    """conv_wreg.hip rebuilt with -DY6_WREG_PROBE=n -> tools/_build/libyolov6_hip_wregprobe<n>.so"""
+    oth = [o for o in glob.glob(os.path.join(B.OBJ_DIR, "*.o")) if not os.path.basename(o).startswith("conv_wreg.")]
+    obj = os.path.join(out, f"conv_wreg_probe{n}.o")
+    lib = os.path.join(out, f"libyolov6_hip_wregprobe{n}.so")
+    subprocess.run([cc] + B.COMMON + B.SOURCES["conv_wreg.hip"] + [f"-DY6_WREG_PROBE={n}", "-c",
+                    os.path.join(B.HERE, "conv_wreg.hip"), "-o", obj], check=True, capture_output=True)
+    subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + sorted(oth), check=True)
+    os.remove(obj)
+    return lib
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--wreg":
+    probes = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 5, 6, 7]
+    with cf.ThreadPoolExecutor(max_workers=min(len(probes), 8)) as ex:
+        for lib in ex.map(one_wreg, probes):
+            print("built", lib)
+    sys.exit(0)
+
 if len(sys.argv) > 1 and sys.argv[1] == "--dma":
     probes = [int(a) for a in sys.argv[2:]] or [1, 2, 3, 4, 5, 6]
     with cf.ThreadPoolExecutor(max_workers=len(probes)) as ex:

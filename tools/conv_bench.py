@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--variants", nargs="*", type=int, default=None)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--data", default="rand", choices=["rand", "relu", "zeros"],
+                    help="input activations: N(0,1), the same clamped at 0 (half zeros, as behind a ReLU), all zeros - the chip clocks to its power budget")
     a = ap.parse_args()
     lib = _lib.load()
     names = [lib.y6_conv_variant_name(i).decode() for i in range(lib.y6_conv_variants())]
@@ -32,6 +34,10 @@ def main():
     for spec in a.layers:
         cin, cout, k, s, H, W, B = (int(v) for v in spec.split(","))
         x = torch.randn((B, H, W, cin), device=dev).half()
+        if a.data == "relu":
+            x = x.clamp(min=0)
+        elif a.data == "zeros":
+            x = x * 0
         w = torch.randn((cout, cin, k, k)) / (cin * k * k) ** 0.5
         b = torch.randn((cout,)) * 0.1
         xr = TRef(x, B, H, W, cin, cin, 0)
@@ -49,7 +55,7 @@ def main():
                 raise
             ms = plan.profile(a.iters)[0]["ms"]
             fl = 2.0 * B * (H // s) * (W // s) * cout * cin * k * k
-            row = dict(layer=spec, variant=names[v], ms=round(ms, 5), tflops=round(fl / ms / 1e9, 1))
+            row = dict(layer=spec, variant=names[v], ms=round(ms, 5), tflops=round(fl / ms / 1e9, 1), data=a.data)
             res.append(row)
             print(json.dumps(row), flush=True)
     if a.out:

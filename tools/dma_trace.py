@@ -15,6 +15,10 @@ spec, vname = sys.argv[1], sys.argv[2]
 variant = names.index(vname)
 cin, cout, k, s, H, W, B = (int(v) for v in spec.split(","))
 x = torch.randn((B, H, W, cin), device="cuda:0").half()
+if os.environ.get("Y6_TRACE_DATA") == "relu":
+    x = x.clamp(min=0)
+if os.environ.get("Y6_TRACE_DATA") == "zeros":
+    x = x * 0
 w = torch.randn((cout, cin, k, k)) / (cin * k * k) ** 0.5
 pb = PlanBuilder("cuda:0"); pb.force_variant = variant
 pb.conv(TRef(x, B, H, W, cin, cin, 0), w, torch.zeros(cout), stride=s, act="relu")
@@ -23,8 +27,19 @@ for _ in range(3):
     plan.run()
 torch.cuda.synchronize()
 t = buf.cpu().view(256, 2).tolist()
-tags = {1: "kernel start", 2: "prologue done", 9: "chunk top (after prev taps/epilogue)", 10: "barrier passed", 11: "taps issued", 19: "chunk loop done",
+if vname.startswith("wreg"):   # conv_wreg.hip (python tools/build_probe_libs.py --wreg 1)
+    tags = {1: "kernel start", 2: "prologue done", 9: "stage top", 10: "barrier passed", 11: "next stage's halo requested", 12: "18 units issued",
+            20: "epilogue: args, output pixels, bias", 21: "epilogue: fragments stored", 22: "last loads landed (kernel end)"}
+else:
+  tags = {1: "kernel start", 2: "prologue done", 9: "chunk top (after prev taps/epilogue)", 10: "barrier passed", 11: "taps issued", 19: "chunk loop done",
         20: "epilogue issued", 21: "args reloaded + output pixels", 22: "cout fragment 0 stored", 23: "last item's epilogue units issued (kernel end)"}
+real = [ts for ts, tag in t if tag in (90, 91)]
+t = [e for e in t if e[1] not in (90, 91)]
+if len(real) == 2:
+    cyc = [ts for ts, tag in t if tag in (1, 22)]
+    if len(cyc) == 2:
+        us = (real[1] - real[0]) / 100.0
+        print(f"block 0 lived {cyc[1] - cyc[0]} shader cycles in {us:.2f} us (100 MHz counter): {(cyc[1] - cyc[0]) / us / 1e3:.3f} GHz")
 prev = t[0][0]
 acc = {}
 for ts, tag in t:

@@ -49,6 +49,8 @@ struct ConvKArgs {
     int* acc_out;                   // optional raw int32 accumulators [pixel][Cout] (parity tests)
     // LDS-DMA kernels (conv_dma.hip) only: halo row pitch (slots of 16 B), slots per plane, 1 KiB pieces of the two planes
     int dma_rp, dma_pls, dma_nhp;
+    // conv_wreg.hip only: 1.0f / halo row pitch, 1.0f / tile width (div_small)
+    float inv_rp, inv_tw;
 };
 
 // LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it

@@ -1209,7 +1209,14 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
 
 // conv_wreg.hip: halo row pitch for a tile width (a read group that wraps to the next tile row must continue at a pixel index
 // that is consecutive modulo 16), 1 KiB requests per stage image, and the tile itself
-int wreg_row_pitch(int TW) { return TW % 16 == 0 ? TW + 2 : TW + 16; }
+// (Y6_WREG_PITCH=conflictfree: TW + 16 for widths that are not multiples of 16 - a read group that wraps to the next tile row then
+// continues at a pixel index consecutive modulo 16 and never conflicts.  Default: the dense pitch TW + 2 - a wrapping group has two
+// 2-way conflicts, one extra LDS cycle on some reads, but the stage image is 25-40 % smaller and the halo REQUESTS are what the
+// stage top costs: 470 cycles each with ten per wave in flight, profiles/r04/v0_trace_wreg_*.txt)
+int wreg_row_pitch(int TW) {
+    static const bool conflict_free = getenv("Y6_WREG_PITCH") && strcmp(getenv("Y6_WREG_PITCH"), "conflictfree") == 0;
+    return (TW % 16 == 0 || !conflict_free) ? TW + 2 : TW + 16;
+}
 int wreg_pieces(int TH, int TW) { return y6_cdiv(5 * (TH + 2) * wreg_row_pitch(TW), 64); }
 // TH x TW <= bp pixel slots: fewest rounds of the persistent walk (items / resident blocks, rounded up) first - a block's time is
 // its pixel SLOTS, so a tile that divides the map with a few idle slots beats a full tile that leaves a partial last round -
@@ -1327,7 +1334,9 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dma_rp = wreg_row_pitch(k.TW);
         k.dma_pls = k.HH * k.dma_rp;
         k.dma_nhp = wreg_pieces(k.TH, k.TW);
-        L->lds = 2 * (size_t)k.dma_nhp * 1024 + 1024;   // two stage images + the dummy request target
+        k.inv_rp = 1.0f / (float)k.dma_rp;
+        k.inv_tw = 1.0f / (float)k.TW;
+        L->lds = 2 * (size_t)k.dma_nhp * 1024 + 3 * (size_t)vc.cf * 32 * 4;   // two stage images + bias / post scale / post shift of the block's couts
     } else if (vc.persist == 4) {
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
@@ -1635,8 +1644,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 6) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
-        static const bool enabled = y6_candidate_enabled("wreg");   // until its parity tests have run on a device
-        if (!enabled || st != 1 || d->w_packed == nullptr) return 0;
+        if (st != 1 || d->w_packed == nullptr) return 0;
         if (d->in.C % 32 || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
         if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;

@@ -23,9 +23,14 @@
 //     continues at p + 17 - consecutive modulo 16 - so ANY tile width is conflict-free.  That frees the tile shape: the host
 //     picks TH x TW so that tiles divide the map and the item count fills whole rounds (10x20 / 5x40 tiles of 200 pixels =
 //     7 fragments on the 80x80 / 40x40 / 20x20 maps of YOLOv6 at batch 32: 1 024 / 512 items for 512 resident blocks);
-//   * vector-memory ordering is hand-counted: every VMEM instruction of the main loop is inline asm (weight loads, LDS-DMA),
-//     issued in a fixed pattern (a burst of kMaxP halo requests per stage - dummies beyond the image - then one weight load
-//     per unit), so `s_waitcnt vmcnt(N)` in front of a unit's MFMAs names exactly the loads that may stay in flight.
+//   * vector-memory ordering: every VMEM instruction of the main loop is inline asm (weight loads, LDS-DMA).  LDS-DMA requests
+//     and loads into VGPRs do NOT retire in order with respect to each other on gfx950: a first version counted the halo burst
+//     into `s_waitcnt vmcnt(N)` (N = younger weight loads + the burst's requests) and passed every parity test on an idle chip,
+//     but beside a bandwidth-hungry kernel on a second stream 299 of 300 runs came out wrong (tools/wreg_stress.py,
+//     profiles/r04/wreg_stress_r04h.log).  So: a stage top waits for EVERYTHING this wave has in flight (vmcnt(0): its halo
+//     requests of this stage, issued a whole stage ago, and the weight fragments of the first kRing - 1 units) before the
+//     barrier; a counted wait (vmcnt(kRing - 1)) appears only where the awaited load AND all younger ones it counts are
+//     weight loads into VGPRs - which do retire in order among themselves; requests in flight only make it stricter.
 // The epilogue is conv_common.hpp's (bias, post-affine, activation, residual, ragged stores), run at the end of an item while
 // the SIMD's other wave (the CU's second block) keeps the matrix pipe busy.
 #include "common.hpp"
@@ -34,7 +39,7 @@
 namespace {
 
 constexpr int kPix = 80;     // LDS bytes per halo pixel: 32 channels (64 B) + one 16-byte pad slot
-constexpr int kMaxP = 10;    // halo requests (1 KiB each) per wave and stage - always issued, so that vmcnt arithmetic is static
+constexpr int kMaxP = 8;     // at most this many halo requests (1 KiB each) per wave and stage
 constexpr int kRing = 6;     // weight fragments in flight per wave (divides the 18 units of a stage)
 constexpr int kUnits = 18;   // (tap, k-step) units per 32-channel stage
 
@@ -47,6 +52,31 @@ template <int N>
 __device__ __forceinline__ void wait_frag(i32x4_t& frag) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
 }
+// the same with a wave-uniform run-time count (kRing - 1 + the wave's halo requests per stage)
+__device__ __forceinline__ void wait_frag_n(i32x4_t& frag, int n) {
+    switch (n) {
+        case 5: wait_frag<5>(frag); break;
+        case 6: wait_frag<6>(frag); break;
+        case 7: wait_frag<7>(frag); break;
+        case 8: wait_frag<8>(frag); break;
+        case 9: wait_frag<9>(frag); break;
+        case 10: wait_frag<10>(frag); break;
+        case 11: wait_frag<11>(frag); break;
+        case 12: wait_frag<12>(frag); break;
+        default: wait_frag<13>(frag); break;
+    }
+}
+// n / d for small non-negative n (below 2^16) with the host's 1.0f / d: exact - (n + 0.5) / d is at least 0.5 / d away from an integer
+__device__ __forceinline__ int div_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+// Ceiling probes / trace (tools/build_probe_libs.py --wreg n; WRONG RESULTS for n >= 2, timing only), compile-time:
+//   1 = s_memtime trace of block 0 / thread 0 into a.dbg (tools/dma_trace.py --wreg); 2 = no weight loads after the prologue (the
+//   waits stay); 3 = no fragment reads after a stage's first unit; 4 = no halo requests after the prologue; 5 = no epilogue;
+//   6 = no MFMAs; 7 = no stage barrier; 9 (WRONG under load, see the header) = the first version's counted waits across the halo burst
+#ifndef Y6_WREG_PROBE
+#define Y6_WREG_PROBE 0
+#endif
+constexpr int kWregProbe = Y6_WREG_PROBE;
 
 template <int PF, int WC, int WP>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
@@ -54,7 +84,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     constexpr int NW = WC * WP;
     constexpr int R = kRing;
     static_assert(kUnits % R == 0, "ring slots are compile-time indices");
-    static_assert(R - 1 + kMaxP <= 63, "vmcnt is a 6-bit counter");
+    static_assert(R - 1 + kMaxP == 13 && R - 1 == 5, "wait_frag_n's cases");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,7 +93,6 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     const int RP = a.dma_rp, NHP = a.dma_nhp;
     const unsigned stage_bytes = (unsigned)NHP * 1024u;
     const unsigned smem_base = lds_addr(smem);
-    const unsigned dummy_dst = smem_base + 2u * stage_bytes;   // 1 KiB nobody reads
     const int nsc = a.Cin >> 5;
     const int nids = a.nids;
     const int gstride = gridDim.x;
@@ -98,32 +127,49 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         if (t >= a.ntiles) id = next_valid(id);
     }
     if (id >= nids) return;
+    int dbg_n = 0;
+    const bool tracing = kWregProbe == 1 && a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+#define DT(tag)                                                              \
+    do {                                                                     \
+        if (kWregProbe == 1 && tracing && dbg_n < 256) {                     \
+            a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                 \
+            a.dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                \
+            ++dbg_n;                                                         \
+        }                                                                    \
+    } while (0)
+    DT(1);
+    if (kWregProbe == 1 && tracing) {   // the constant 100 MHz counter beside the shader clock: the kernel's effective frequency
+        a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[2 * dbg_n + 1] = 90;
+        ++dbg_n;
+    }
     {
         int t;
         decode(id, t, cb);   // the grid stride is a multiple of 8 * ncb: every item of this block has this cout block
     }
 
-    // ---- this wave's halo requests: slot s = 64 * P + lane of the stage image -> (halo row, halo column, piece), fixed for the
-    //      whole kernel (the divisions happen once); per item only the tile origin changes
-    unsigned hinfo[kMaxP];
-#pragma unroll
-    for (int i = 0; i < kMaxP; ++i) {
-        const int P = wave + NW * i;
-        const int s = P * 64 + lane;
-        const int p = s / 5, j = s - 5 * p;
-        const int hy = p / RP, hx = p - hy * RP;
-        const bool v = (P < NHP) && (j < 4) && (hx < a.HWd) && (hy < a.HH);
-        hinfo[i] = v ? (unsigned)((hy << 16) | (hx << 3) | j) : 0xffffffffu;
-    }
-    // requests of one stage: the item's tile origin (iy0, ix0, byte offset of its pixel (0, 0)), the stage's channel offset
-    auto issue_halo = [&](bool real, int iy0, int ix0, unsigned base, unsigned soff, unsigned dst0) {
+    // ---- this wave's halo requests: slot s = 64 * P + lane of the stage image (P = wave + NW * i < NHP) is piece j of halo pixel
+    //      p = s / 5 (j = 4: the pad slot).  Their byte offsets into the input view are the same for every stage of an item (the
+    //      stage's channels are the scalar offset): computed once per item.
+    const int npw = NHP > wave ? (NHP - wave + NW - 1) / NW : 0;
+    unsigned hvoff[kMaxP];
+    bool in_loop = false;
+    auto setup_halo = [&](int iy0, int ix0, unsigned base) {
 #pragma unroll
         for (int i = 0; i < kMaxP; ++i) {
-            const int P = wave + NW * i;
-            const int hy = (int)(hinfo[i] >> 16), hx = (int)((hinfo[i] & 0xffffu) >> 3), j = (int)(hinfo[i] & 7u);
-            const bool v = real && (hinfo[i] != 0xffffffffu) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
-            const unsigned voff = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * 2) + (unsigned)(j * 16) : kOob;
-            dma16(rsA, voff, soff, (real && P < NHP) ? dst0 + (unsigned)P * 1024u : dummy_dst);
+            int s = (wave + NW * i) * 64 + lane;
+            asm volatile("" : "+v"(s));   // opaque: otherwise hipcc hoists (row, column, piece) of every request out of the item loop and spills them
+            const int p = s / 5, j = s - 5 * p;
+            const int hy = div_small(p, a.inv_rp), hx = p - hy * RP;
+            const bool v = (i < npw) && (j < 4) && (hy < a.HH) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
+            hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * 2) + (unsigned)(j * 16) : kOob;
+        }
+    };
+    // requests of one stage (always npw of them: the counted waits below rely on it; behind the last stage they ask for nothing)
+    auto issue_halo = [&](bool real, unsigned soff, unsigned dst0) {
+#pragma unroll
+        for (int i = 0; i < kMaxP; ++i) {
+            if (i < npw && (kWregProbe != 4 || !in_loop)) dma16(rsA, real ? hvoff[i] : kOob, soff, dst0 + (unsigned)(wave + NW * i) * 1024u);
         }
     };
     auto tile_origin = [&](int item, int& iy0, int& ix0, unsigned& base) {
@@ -147,7 +193,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         const int m = wp * (PF * 32) + pf * 32 + fq;
         const int npx = a.TH * a.TW;
         const int mm = m < npx ? m : npx - 1;
-        const int ty = mm / a.TW, tx = mm - ty * a.TW;
+        const int ty = div_small(mm, a.inv_tw), tx = mm - ty * a.TW;
         pixaddr[pf] = (unsigned)((ty * RP + tx) * kPix + (lane >> 5) * 16);
     }
     auto out_pix = [&](const ConvKArgs& ea, int item, int (&opix)[PF]) {
@@ -160,9 +206,10 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         const int oy0 = ty_i * ea.TH, ox0 = tx_i * ea.TW;
         const int base = (b * ea.Ho + oy0) * ea.Wo + ox0;
 #pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {   // (the divisions again, once per item: eight registers the main loop does not carry)
-            const int m = wp * (PF * 32) + pf * 32 + fq;
-            const int ty = m / ea.TW, tx = m - ty * ea.TW;
+        for (int pf = 0; pf < PF; ++pf) {   // (recomputed per item - opaque, or hipcc hoists and spills them: registers the main loop does not carry)
+            int m = wp * (PF * 32) + pf * 32 + fq;
+            asm volatile("" : "+v"(m));
+            const int ty = div_small(m, ea.inv_tw), tx = m - ty * ea.TW;
             const bool v = m < ea.TH * ea.TW && (oy0 + ty < ea.Ho) && (ox0 + tx < ea.Wo);
             opix[pf] = v ? base + ty * ea.Wo + tx : -1;
         }
@@ -181,6 +228,63 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
 
+    // ---- fast epilogue (conv + bias (+ QARepVGG post-affine) + activation, no residual, into a 16-byte aligned fp16 view - every
+    //      3x3 of the deploy graphs but the BottleRep shortcut convs): per-channel vectors of the block's couts in LDS (the cout
+    //      block is the same for all its items: written once, visible behind the first stage barrier), stores through a buffer
+    //      descriptor with 32-bit byte offsets.  Anything else takes conv_common.hpp's general epilogue.
+    float* ldsVec = reinterpret_cast<float*>(smem + 2u * stage_bytes);   // [bias | post scale | post shift][WC * 32]
+    const bool has_post = a.pscale != nullptr;
+    const bool fast = a.res == nullptr && a.up == 0 && a.out != nullptr && a.vec16_ok && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
+    const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
+    const bool smooth_act = a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH;
+    const __amdgpu_buffer_rsrc_t rsO =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
+    auto fast_unit = [&](const f32x16_t& accv, unsigned obyte, const float (&bias16)[16]) {
+        const int kh = lane >> 5;
+        const float* lb = ldsVec + wc * 32;
+        float v[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float x[4] = {accv[g * 4 + 0] + bias16[g * 4 + 0], accv[g * 4 + 1] + bias16[g * 4 + 1], accv[g * 4 + 2] + bias16[g * 4 + 2],
+                          accv[g * 4 + 3] + bias16[g * 4 + 3]};
+            if (has_post) {   // QARepVGG: conv -> BatchNorm are two fp16 ops (finish16 in conv_common.hpp)
+                const float4 ps = *reinterpret_cast<const float4*>(lb + WC * 32 + 8 * g + 4 * kh);
+                const float4 pt = *reinterpret_cast<const float4*>(lb + 2 * WC * 32 + 8 * g + 4 * kh);
+                x[0] = y6_round_f16(x[0]) * ps.x + pt.x;
+                x[1] = y6_round_f16(x[1]) * ps.y + pt.y;
+                x[2] = y6_round_f16(x[2]) * ps.z + pt.z;
+                x[3] = y6_round_f16(x[3]) * ps.w + pt.w;
+            }
+            if (smooth_act) {   // one wave-uniform branch per group, the arithmetic of act_const<>
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[g * 4 + j] = a.act == Y6_ACT_SILU ? act_const<Y6_ACT_SILU>(x[j]) : act_const<Y6_ACT_HARDSWISH>(x[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
+            }
+        }
+        unsigned pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                h2_t t;
+                t[0] = (_Float16)v[g * 4 + h * 2];
+                t[1] = (_Float16)v[g * 4 + h * 2 + 1];
+                pk[g][h] = __builtin_bit_cast(unsigned, t);
+            }
+        const unsigned ocol = (unsigned)((cb * WC + wc) * 32 + 8 * kh);
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {   // pair groups across the two half-waves: one 16-byte store per lane and pair
+            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyte + (ocol + (unsigned)(16 * gp)) * 2u), 0, 0);
+        }
+    };
+
     // prologue: the first stage of the first item, the first R - 1 weight fragments
     int n_item = id;          // item whose stage is requested next
     int n_sc = 0;
@@ -188,42 +292,58 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         int iy0, ix0;
         unsigned base;
         tile_origin(n_item, iy0, ix0, base);
-        issue_halo(true, iy0, ix0, base, 0u, smem_base);
+        setup_halo(iy0, ix0, base);
+        issue_halo(true, 0u, smem_base);
     }
 #pragma unroll
     for (int u = 0; u < R - 1; ++u) load_frag(wr[u], rsW, lane16, woff_cur + (unsigned)(u * 1024));
+    // the per-channel vectors of the block's couts (behind the first requests: their latency is the prologue's anyway)
+    if (tid < WC * 32) {
+        const int c = cb * WC * 32 + tid;
+        ldsVec[tid] = a.bias != nullptr ? a.bias[c] : 0.f;
+        ldsVec[WC * 32 + tid] = has_post ? a.pscale[c] : 1.f;
+        ldsVec[2 * WC * 32 + tid] = has_post ? a.pshift[c] : 0.f;
+    }
 
     const unsigned rp_bytes = (unsigned)(RP * kPix);
     int sc = 0, stage = 0;
+    in_loop = true;
+    DT(2);
     while (true) {
-        // ---- stage top.  Inside an item the requests of this stage were issued a whole stage ago and are older than every
-        // weight load still in flight: the counted waits of the previous stage's units already covered them.  At an item's
-        // first stage the epilogue's stores may be outstanding (loads and stores retire out of order with respect to each
-        // other): wait for everything.
-        if (sc == 0) {
+        DT(9);
+        // ---- stage top.  First the bookkeeping of the NEXT stage's requests (the next item's first stage behind this item's
+        // last; a new item: its tile origin and the byte offsets of this wave's requests) - VALU / SALU work that overlaps the
+        // landing of the youngest weight fragment.  Then everything this wave has in flight - its halo requests of THIS stage
+        // (issued a whole stage ago), the weight fragments of the first R - 1 units (the youngest one unit ago), an epilogue's
+        // stores - and the barrier.  Then the requests, into the half everybody has finished reading.
+        bool real = true;
+        if (n_sc + 1 < nsc) {
+            ++n_sc;
+        } else {
+            const int n = next_valid(n_item);
+            if (n >= nids) {
+                real = false;
+            } else {
+                n_item = n;
+                n_sc = 0;
+            }
+        }
+        if (real && n_sc == 0) {
+            int iy0, ix0;
+            unsigned base;
+            tile_origin(n_item, iy0, ix0, base);
+            setup_halo(iy0, ix0, base);
+        }
+        if (kWregProbe == 7) {
+            if (sc == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else if (sc == 0 || kWregProbe != 9) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // requests of the NEXT stage (the next item's first one behind this item's last) into the other half
-        {
-            bool real = true;
-            if (n_sc + 1 < nsc) {
-                ++n_sc;
-            } else {
-                const int n = next_valid(n_item);
-                if (n >= nids) {
-                    real = false;
-                } else {
-                    n_item = n;
-                    n_sc = 0;
-                }
-            }
-            int iy0 = 0, ix0 = 0;
-            unsigned base = 0;
-            if (real) tile_origin(n_item, iy0, ix0, base);
-            issue_halo(real, iy0, ix0, base, (unsigned)n_sc * 64u, smem_base + (stage ? 0u : stage_bytes));
-        }
+        DT(10);
+        issue_halo(real, (unsigned)n_sc * 64u, smem_base + (stage ? 0u : stage_bytes));
+        DT(11);
         const char* Ab = smem + (stage ? stage_bytes : 0u);
         i32x4_t fb[PF];
 #pragma unroll
@@ -233,41 +353,70 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             {   // the fragment R - 1 units ahead, into the slot unit u - 1 just released
                 const int up = u + R - 1;
                 const unsigned so = up < kUnits ? woff_cur + (unsigned)(up * 1024) : woff_next + (unsigned)((up - kUnits) * 1024);
-                load_frag(wr[up % R], rsW, lane16, so);
+                if (kWregProbe != 2) load_frag(wr[up % R], rsW, lane16, so);
             }
             // in flight behind this unit's fragment: the R - 1 younger fragments, and - for the fragments requested before this
             // stage's top - the halo burst
-            if (u < R - 1) {
-                wait_frag<R - 1 + kMaxP>(wr[u % R]);
-            } else {
+            if (u < R - 1) {   // landed at the stage top (tie the value to this point: no instruction)
+                if (kWregProbe == 9)
+                    wait_frag_n(wr[u % R], R - 1 + npw);
+                else
+                    asm volatile("" : "+v"(wr[u % R]));
+            } else {           // requested in this stage, behind the burst: only weight loads are younger
                 wait_frag<R - 1>(wr[u % R]);
             }
             const int un = u + 1;
             const unsigned offn = (unsigned)((un >> 1) / 3) * rp_bytes + (unsigned)((((un >> 1) % 3) * kPix) + (un & 1) * 32);
 #pragma unroll
             for (int pf = 0; pf < PF; ++pf) {
-                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[pf]), acc[pf], 0, 0, 0);
-                if (u + 1 < kUnits) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf] + offn);
+                if (kWregProbe != 6)
+                    acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[pf]), acc[pf], 0, 0, 0);
+                if (u + 1 < kUnits && kWregProbe != 3) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf] + offn);
             }
         }
+        DT(12);
         // ---- next stage
         stage ^= 1;
         ++sc;
         woff_cur = woff_next;
         if (sc == nsc) {
             // the item is complete: bias (+ post-affine) + activation (+ residual) -> fp16 NHWC
-            const ConvKArgs ea = reload_args();
-            int opix[PF];
-            out_pix(ea, id, opix);
-            BiasRegs<1> bz;
-            load_bias<1>(ea, cb * WC + wc, 0, lane, bz);
+            if (fast) {
+                int opix[PF];
+                out_pix(a, id, opix);
+                float bias16[16];   // the wave's 32 couts are the same for all its fragments: one read per item
 #pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                const int op1[1] = {opix[pf]};
-                conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&acc[pf]), op1, cb * WC + wc, 0, lane, bz);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bz = *reinterpret_cast<const float4*>(ldsVec + wc * 32 + 8 * g + 4 * (lane >> 5));
+                    bias16[g * 4 + 0] = bz.x;
+                    bias16[g * 4 + 1] = bz.y;
+                    bias16[g * 4 + 2] = bz.z;
+                    bias16[g * 4 + 3] = bz.w;
+                }
+                DT(20);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+                for (int pf = 0; pf < PF; ++pf) {
+                    const unsigned ob = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;   // overhang: dropped by the range check
+                    if (kWregProbe != 5) fast_unit(acc[pf], ob, bias16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+                }
+            } else {
+                const ConvKArgs ea = reload_args();
+                int opix[PF];
+                out_pix(ea, id, opix);
+                BiasRegs<1> bz;
+                load_bias<1>(ea, cb * WC + wc, 0, lane, bz);
+                DT(20);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) {
+                    const int op1[1] = {opix[pf]};
+                    if (kWregProbe != 5) conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&acc[pf]), op1, cb * WC + wc, 0, lane, bz);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+                }
             }
+            DT(21);
             const int nid = next_valid(id);
             if (nid >= nids) break;
             id = nid;
@@ -277,6 +426,13 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     }
     // the fragments requested past the end and the dummy requests of the last stage land before the wave ends
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DT(22);
+    if (kWregProbe == 1 && tracing && dbg_n < 256) {
+        a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memrealtime();
+        a.dbg[2 * dbg_n + 1] = 91;
+        ++dbg_n;
+    }
+#undef DT
 }
 
 template <int PF, int WC, int WP>
