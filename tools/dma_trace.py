@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-buf = torch.zeros(512, dtype=torch.int64, device="cuda:0")
+buf = torch.zeros(4096, dtype=torch.int64, device="cuda:0")
 os.environ["Y6_CONV_TRACE"] = str(buf.data_ptr())
 from yolov6_amd import _lib
 from yolov6_amd.engine import PlanBuilder, TRef
@@ -26,7 +26,23 @@ plan = pb.finalize(None, autotune=False)
 for _ in range(3):
     plan.run()
 torch.cuda.synchronize()
-t = buf.cpu().view(256, 2).tolist()
+import time
+buf.zero_(); torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+ev[0].record(); plan.run(); ev[1].record(); torch.cuda.synchronize()
+print(f"one launch between two events: {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us")
+allb = buf.cpu()
+t = allb[:512].view(256, 2).tolist()
+blk = allb[1024:3072].view(1024, 2)
+blk = blk[blk[:, 0] > 0]
+if blk.shape[0]:
+    t0 = int(blk[:, 0].min())
+    st, en = (blk[:, 0] - t0).float() / 100.0, (blk[:, 1] - t0).float() / 100.0
+    life = en - st
+    q = lambda v, f: float(v.sort().values[int(f * (len(v) - 1))])
+    print(f"{blk.shape[0]} blocks (us on the 100 MHz counter): start min/median/max {q(st, 0):.2f}/{q(st, .5):.2f}/{q(st, 1):.2f}, end min/median/max {q(en, 0):.2f}/{q(en, .5):.2f}/{q(en, 1):.2f}, "
+          f"lifetime min/median/max {q(life, 0):.2f}/{q(life, .5):.2f}/{q(life, 1):.2f}")
+    print("   end-time histogram (us):", torch.histc(en, bins=10, min=float(en.min()), max=float(en.max())).int().tolist(), f"from {float(en.min()):.1f} to {float(en.max()):.1f}")
 if vname.startswith("wreg"):   # conv_wreg.hip (python tools/build_probe_libs.py --wreg 1)
     tags = {1: "kernel start", 2: "prologue done", 9: "stage top", 10: "barrier passed", 11: "next stage's halo requested", 12: "18 units issued",
             20: "epilogue: args, output pixels, bias", 21: "epilogue: fragments stored", 22: "last loads landed (kernel end)"}
