@@ -112,6 +112,5 @@ int y6_conv_dma_launch(const void* launch_record, int cf, int pf, int nw, int st
 int y6_conv_dma_halo_cap(int block_pixels, int stride);
 int y6_conv_wreg_launch(const void* launch_record, int pf, int cout_waves, int pixel_waves, hipStream_t s);   // conv_wreg.hip
 int y6_conv_wreg_max_pieces(int waves);
-int y6_conv_wregpp_launch(const void* launch_record, int pf, int cout_waves, hipStream_t s);                     // conv_wreg.hip (ping-pong form)
 double y6_conv_flops(const y6_conv_desc* d);
 double y6_conv_bytes(const y6_conv_desc* d);

@@ -1161,10 +1161,7 @@ const VariantCfg kVariants[] = {
     // pf = pixel fragments per wave, nw = waves per block (nw / cf pixel groups): 128 couts x pf * 32 pixels on four waves, two
     // blocks per CU; 64 couts x 2 * pf * 32 pixels for the 64-channel layers.  The tile (TH x TW <= the block's pixel slots) is
     // chosen for whole rounds of the persistent walk (choose_tile_wreg).
-    {4, 8, 6, "wreg_p8", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {2, 8, 6, "wreg2_p8", 4}, {2, 7, 6, "wreg2_p7", 4},
-    // persist == 7: the same data path as ONE 8-wave block per CU whose two 4-wave groups alternate matrix and request / epilogue
-    // phases between block barriers (conv_wreg.hip, conv3x3_wregpp_kernel); pf pixel fragments per wave, a group's tile = pf * 32 slots
-    {4, 6, 7, "wregpp_p6", 8}, {4, 5, 7, "wregpp_p5", 8}, {4, 4, 7, "wregpp_p4", 8}};
+    {4, 8, 6, "wreg_p8", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {2, 8, 6, "wreg2_p8", 4}, {2, 7, 6, "wreg2_p7", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1295,7 +1292,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.upH = d->in.H;
     k.upW = d->in.W;
     k.upC = up == 2 ? d->out.C / 4 : d->out.C;
-    const int bp = vc.persist == 7 ? 32 * vc.pf : vc.persist == 6 ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
+    const int bp = vc.persist == 6 ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
     if (ks == 1) {
         // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row
         const long npix = (long)d->in.B * d->in.H * d->in.W;
@@ -1313,8 +1310,8 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.Ho = d->out.H;
         k.Wo = d->out.W;
         const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp, vc.cs) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
-        if (vc.persist == 6 || vc.persist == 7)   // two 4-wave blocks (groups of one block) per CU
-            choose_tile_wreg(k.B, k.Ho, k.Wo, y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf), bp, y6_conv_wreg_max_pieces(vc.persist == 7 ? vc.cf : vc.nw), 2 * device_cus(), &k.TH, &k.TW);
+        if (vc.persist == 6)   // two 4-wave blocks per CU
+            choose_tile_wreg(k.B, k.Ho, k.Wo, y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf), bp, y6_conv_wreg_max_pieces(vc.nw), 2 * device_cus(), &k.TH, &k.TW);
         else
             choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
     }
@@ -1333,14 +1330,17 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.dbg = (unsigned long long*)(uintptr_t)strtoull(tr, nullptr, 10);
     }
     L->grid = k.nids;
-    if (vc.persist == 6 || vc.persist == 7) {
+    if (vc.persist == 6) {
         k.dma_rp = wreg_row_pitch(k.TW);
         k.dma_pls = k.HH * k.dma_rp;
         k.dma_nhp = wreg_pieces(k.TH, k.TW);
         k.inv_rp = 1.0f / (float)k.dma_rp;
         k.inv_tw = 1.0f / (float)k.TW;
+        {
+            static const int prio = getenv("Y6_WREG_PRIO") ? atoi(getenv("Y6_WREG_PRIO")) : 0;   // A/B switch (unmeasured: off)
+            k.prio_mode = prio;
+        }
         L->lds = 2 * (size_t)k.dma_nhp * 1024 + 3 * (size_t)vc.cf * 32 * 4;   // two stage images + bias / post scale / post shift of the block's couts
-        if (vc.persist == 7) L->lds *= 2;                                      // per group
     } else if (vc.persist == 4) {
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
@@ -1647,7 +1647,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist && ks != 3) return 0;
-    if (vc.persist == 6 || vc.persist == 7) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
+    if (vc.persist == 6) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
         if (st != 1 || d->w_packed == nullptr) return 0;
         if (d->in.C % 32 || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
@@ -1714,8 +1714,6 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 43: case 44: case 45:
-            return y6_conv_wregpp_launch(&L, kVariants[variant].pf, kVariants[variant].cf, s);
         case 38: case 39: case 40: case 41: case 42:
             return y6_conv_wreg_launch(&L, kVariants[variant].pf, kVariants[variant].cf, kVariants[variant].nw / kVariants[variant].cf, s);
         case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:

@@ -188,17 +188,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)a.in_co) * 2u;
     };
 
-    // ---- this lane's pixels: position in the tile (fixed for the whole kernel), LDS offset of the tap (0, 0) read
-    const int fq = frag_pixel(lane & 31);
-    unsigned pixaddr[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const int m = wp * (PF * 32) + pf * 32 + fq;
-        const int npx = a.TH * a.TW;
-        const int mm = m < npx ? m : npx - 1;
-        const int ty = div_small(mm, a.inv_tw), tx = mm - ty * a.TW;
-        pixaddr[pf] = (unsigned)((ty * RP + tx) * kPix + (lane >> 5) * 16);
-    }
+    const int fq = frag_pixel(lane & 31);   // fragment pixel this lane holds
     auto out_pix = [&](const ConvKArgs& ea, int item, int (&opix)[PF]) {
         int tile = item;
         if (ea.ncb != 1) tile = ((item >> 3) / ea.ncb) * 8 + (item & 7);
@@ -309,8 +299,20 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         ldsVec[2 * WC * 32 + tid] = has_post ? a.pshift[c] : 0.f;
     }
 
+    __builtin_amdgcn_sched_barrier(0);   // the requests above leave first; the arithmetic below fills their latency
+    // this lane's pixels: LDS offset of the tap (0, 0) read (fixed for the whole kernel)
+    unsigned pixaddr[PF];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int m = wp * (PF * 32) + pf * 32 + fq;
+        const int npx = a.TH * a.TW;
+        const int mm = m < npx ? m : npx - 1;
+        const int ty = div_small(mm, a.inv_tw), tx = mm - ty * a.TW;
+        pixaddr[pf] = (unsigned)((ty * RP + tx) * kPix + (lane >> 5) * 16);
+    }
+
     const unsigned rp_bytes = (unsigned)(RP * kPix);
-    int sc = 0, stage = 0;
+    int sc = 0, stage = 0, gstage = 0;
     in_loop = true;
     DT(2);
     while (true) {
@@ -346,6 +348,20 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         DT(10);
+        // The two blocks of a CU put one wave each on every SIMD, and the hardware arbitrates their issue by age: the older block's
+        // waves win the matrix pipe whenever both want it, finish first (45 us of a 58 us launch, profiles/r04/block_times_r04j.txt)
+        // and leave the younger block to run alone with nothing beside its request / epilogue phases.  A priority that falls from
+        // stage to stage (3, 2, 1, 0, 3, ...) gives a block that lags by a stage the higher priority three times out of four: the
+        // lag stays within a stage or so, both blocks finish together, and their matrix phases tend to interleave.
+        if (a.prio_mode == 1) {
+            switch (gstage & 3) {
+                case 0: __builtin_amdgcn_s_setprio(3); break;
+                case 1: __builtin_amdgcn_s_setprio(2); break;
+                case 2: __builtin_amdgcn_s_setprio(1); break;
+                default: __builtin_amdgcn_s_setprio(0); break;
+            }
+        }
+        ++gstage;
         issue_halo(real, (unsigned)n_sc * 64u, smem_base + (stage ? 0u : stage_bytes));
         DT(11);
         const char* Ab = smem + (stage ? stage_bytes : 0u);
@@ -440,366 +456,11 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 #undef DT
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Ping-pong form.  The kernel above runs two independent 4-wave blocks per CU; each SIMD hosts one wave of each, and the hardware
-// arbitrates their instruction issue by age: the older block's waves win the matrix pipe whenever both want it, finish first
-// (45 us of a 58 us launch on 256 -> 256 @ 40x40, profiles/r04/block_times_r04j.txt) and leave the younger block to run alone, one
-// wave per SIMD, with nothing to cover its request / epilogue / stage-top phases: 63 % matrix-pipe use over the CU's busy time
-// although the two-wave steady state reaches 93-97 %.  Here ONE 8-wave block holds two GROUPS of WC waves (group = the old block:
-// its own items, its own two halo stage images), and the block barrier makes their phases alternate by construction:
-//
-//      group 0:  | MFMA stage s      | epilogue? + requests for stage s+2 + wait | MFMA stage s+1     | ...
-//      group 1:  | requests + wait   | MFMA stage s                              | epilogue? + ...    | ...
-//                ^ barrier           ^ barrier                                   ^ barrier
-//
-// A SIMD always has exactly one wave in its matrix phase (a lone wave issues 126 MFMAs in 4 000-4 500 cycles: tools/dma_trace.py
-// on the first version), the other wave's non-matrix work sits beside it, nobody runs ahead, and both groups finish together.
-// Everything a group has in flight (halo requests, the first R - 1 weight fragments of its next stage) is awaited at the END
-// of its non-matrix phase - a whole matrix phase of the other group after it was requested.
-// GENERAL: the instantiation with conv_common.hpp's general epilogue (residual, ragged stores) instead of the fast one - two
-// kernels, chosen by the host, because both epilogues in one body push the register allocator over 256 and a spilled weight-ring
-// register is a wrong result (hipcc does not know the asm load is still in flight): tests/test_host_cpu.py checks the spill count.
-template <int PF, int WC, bool GENERAL>
-__global__ __launch_bounds__(WC * 2 * 64, 2) void conv3x3_wregpp_kernel(const ConvKArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int R = kRing;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave / WC, wc = wave % WC;
-    const int gtid = tid - grp * (WC * 64);
-    const int RP = a.dma_rp, NHP = a.dma_nhp;
-    const unsigned stage_bytes = (unsigned)NHP * 1024u;
-    const unsigned smem_base = lds_addr(smem) + (unsigned)grp * 2u * stage_bytes;   // this group's two stage images
-    char* const smem_g = smem + (size_t)grp * 2u * stage_bytes;
-    const int nsc = a.Cin >> 5;
-    const int nids = a.nids;
-    const int gstride = 2 * gridDim.x;                      // the groups of all blocks walk the id space like 2 * grid blocks
-    const int ics = a.in_cs;
-    const i32x4_t rsA = make_rsrc(a.in, (unsigned)((size_t)a.B * a.H * a.W * ics * 2));
-    const i32x4_t rsW = make_rsrc(a.wpk, 0xfffffe00u);
-
-    auto decode = [&](int id, int& tile, int& cb) {
-        if (a.ncb == 1) {
-            tile = id;
-            cb = 0;
-        } else {
-            const int lo = id & 7, r = id >> 3;
-            cb = r % a.ncb;
-            tile = (r / a.ncb) * 8 + lo;
-        }
-    };
-    auto first_valid = [&](int id) {
-        for (; id < nids; id += gstride) {
-            int t, c;
-            decode(id, t, c);
-            if (t < a.ntiles) break;
-        }
-        return id;
-    };
-    auto next_valid = [&](int id) { return first_valid(id + gstride); };
-    // virtual block index: consecutive ids share an XCD-friendly residue as before (block b -> ids 2b, 2b + 1 would put a tile's
-    // cout blocks on different XCDs): group g of block b is virtual block b + g * gridDim
-    const int vb = blockIdx.x + grp * gridDim.x;
-    // steps (stages) of both groups: the barriers are the block's, the longer group sets the trip count
-    int steps_mine = 0, steps_max = 0;
-    {
-        for (int g = 0; g < 2; ++g) {
-            int n = 0;
-            for (int i = first_valid(blockIdx.x + g * gridDim.x); i < nids; i = next_valid(i)) ++n;
-            if (g == grp) steps_mine = n * nsc;
-            steps_max = n * nsc > steps_max ? n * nsc : steps_max;
-        }
-    }
-    int id = first_valid(vb);
-    int cb = 0;
-    if (id < nids) {
-        int t;
-        decode(id, t, cb);   // (the virtual grid stride is a multiple of 8 * ncb: one cout block per group)
-    }
-
-    const int npw = NHP > wc ? (NHP - wc + WC - 1) / WC : 0;
-    // (the requests' byte offsets are recomputed for every stage: this group's request phase runs beside the other group's matrix
-    // phase and has cycles to spare - registers are what the matrix phase lacks)
-    int h_iy0 = 0, h_ix0 = 0;
-    unsigned h_base = 0;
-    auto setup_halo = [&](int iy0, int ix0, unsigned base) {
-        h_iy0 = iy0;
-        h_ix0 = ix0;
-        h_base = base;
-    };
-    auto issue_halo = [&](unsigned soff, unsigned dst0) {
-#pragma unroll
-        for (int i = 0; i < kMaxP; ++i) {
-            if (i < npw) {
-                int l = lane;
-                asm volatile("" : "+v"(l));   // opaque BEFORE the sum: hipcc otherwise keeps the eight sums live across the whole loop
-                const int s = (wc + WC * i) * 64 + l;
-                const int p = s / 5, j = s - 5 * p;
-                const int hy = div_small(p, a.inv_rp), hx = p - hy * RP;
-                const bool v = (j < 4) && (hy < a.HH) && ((unsigned)(h_iy0 + hy) < (unsigned)a.H) && ((unsigned)(h_ix0 + hx) < (unsigned)a.W);
-                const unsigned voff = v ? h_base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * 2) + (unsigned)(j * 16) : kOob;
-                dma16(rsA, voff, soff, dst0 + (unsigned)(wc + WC * i) * 1024u);
-                __builtin_amdgcn_sched_barrier(0);   // one request's arithmetic at a time (registers)
-            }
-        }
-    };
-    auto tile_origin = [&](int item, int& iy0, int& ix0, unsigned& base) {
-        int tile, c;
-        decode(item, tile, c);
-        const int tx_i = tile % a.tiles_x;
-        const int t2 = tile / a.tiles_x;
-        const int ty_i = t2 % a.tiles_y;
-        const int b = t2 / a.tiles_y;
-        iy0 = ty_i * a.TH - 1;
-        ix0 = tx_i * a.TW - 1;
-        base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)a.in_co) * 2u;
-    };
-    const int fq = frag_pixel(lane & 31);
-    unsigned pixaddr[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf) {
-        const int m = pf * 32 + fq;
-        const int npx = a.TH * a.TW;
-        const int mm = m < npx ? m : npx - 1;
-        const int ty = div_small(mm, a.inv_tw), tx = mm - ty * a.TW;
-        pixaddr[pf] = (unsigned)((ty * RP + tx) * kPix + (lane >> 5) * 16);
-    }
-    auto out_pix = [&](int item, int (&opix)[PF]) {
-        int tile = item;
-        if (a.ncb != 1) tile = ((item >> 3) / a.ncb) * 8 + (item & 7);
-        const int tx_i = tile % a.tiles_x;
-        const int t2 = tile / a.tiles_x;
-        const int ty_i = t2 % a.tiles_y;
-        const int b = t2 / a.tiles_y;
-        const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
-        const int base = (b * a.Ho + oy0) * a.Wo + ox0;
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {
-            int m = pf * 32 + fq;
-            asm volatile("" : "+v"(m));
-            const int ty = div_small(m, a.inv_tw), tx = m - ty * a.TW;
-            const bool v = m < a.TH * a.TW && (oy0 + ty < a.Ho) && (ox0 + tx < a.Wo);
-            opix[pf] = v ? base + ty * a.Wo + tx : -1;
-        }
-    };
-
-    const unsigned wbase = (unsigned)((cb * WC + wc) * nsc) * (unsigned)(kUnits * 1024);
-    const unsigned lane16 = (unsigned)lane * 16u;
-    unsigned woff_cur = wbase;
-    unsigned woff_next = nsc > 1 ? wbase + kUnits * 1024 : wbase;
-    i32x4_t wr[R];
-    f32x16_t acc[PF];
-#pragma unroll
-    for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
-
-    float* ldsVec = reinterpret_cast<float*>(smem + 4u * stage_bytes) + grp * 3 * WC * 32;   // [bias | post scale | post shift][WC * 32] per group
-    const bool has_post = a.pscale != nullptr;
-    const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
-    const bool smooth_act = a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH;
-    const __amdgpu_buffer_rsrc_t rsO =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
-    auto fast_unit = [&](const f32x16_t& accv, unsigned obyte, const float (&bias16)[16]) {
-        const int kh = lane >> 5;
-        const float* lb = ldsVec + wc * 32;
-        float v[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float x[4] = {accv[g * 4 + 0] + bias16[g * 4 + 0], accv[g * 4 + 1] + bias16[g * 4 + 1], accv[g * 4 + 2] + bias16[g * 4 + 2],
-                          accv[g * 4 + 3] + bias16[g * 4 + 3]};
-            if (has_post) {
-                const float4 ps = *reinterpret_cast<const float4*>(lb + WC * 32 + 8 * g + 4 * kh);
-                const float4 pt = *reinterpret_cast<const float4*>(lb + 2 * WC * 32 + 8 * g + 4 * kh);
-                x[0] = y6_round_f16(x[0]) * ps.x + pt.x;
-                x[1] = y6_round_f16(x[1]) * ps.y + pt.y;
-                x[2] = y6_round_f16(x[2]) * ps.z + pt.z;
-                x[3] = y6_round_f16(x[3]) * ps.w + pt.w;
-            }
-            if (smooth_act) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[g * 4 + j] = a.act == Y6_ACT_SILU ? act_const<Y6_ACT_SILU>(x[j]) : act_const<Y6_ACT_HARDSWISH>(x[j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
-            }
-        }
-        unsigned pk[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                h2_t t;
-                t[0] = (_Float16)v[g * 4 + h * 2];
-                t[1] = (_Float16)v[g * 4 + h * 2 + 1];
-                pk[g][h] = __builtin_bit_cast(unsigned, t);
-            }
-        const unsigned ocol = (unsigned)((cb * WC + wc) * 32 + 8 * kh);
-#pragma unroll
-        for (int gp = 0; gp < 2; ++gp) {
-            auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyte + (ocol + (unsigned)(16 * gp)) * 2u), 0, 0);
-        }
-    };
-
-    // ---- prologue: both stage images of the first item (stage 0, and stage 1 - the next item's first one when an item is a single
-    //      stage), the first R - 1 weight fragments, the per-channel vectors; everything landed before the first barrier
-    int n_item = id, n_sc = 0;      // (item, stage) whose halo is requested next
-    bool n_real = id < nids;
-    auto advance_request = [&]() {  // -> the (item, stage) behind the one requested last; recomputes the offsets at an item's first stage
-        if (!n_real) return;
-        if (n_sc + 1 < nsc) {
-            ++n_sc;
-            return;
-        }
-        const int n = next_valid(n_item);
-        if (n >= nids) {
-            n_real = false;
-            return;
-        }
-        n_item = n;
-        n_sc = 0;
-        int iy0, ix0;
-        unsigned base;
-        tile_origin(n_item, iy0, ix0, base);
-        setup_halo(iy0, ix0, base);
-    };
-    if (n_real) {
-        int iy0, ix0;
-        unsigned base;
-        tile_origin(n_item, iy0, ix0, base);
-        setup_halo(iy0, ix0, base);
-        issue_halo(0u, smem_base);
-        advance_request();
-        if (n_real) issue_halo((unsigned)n_sc * 64u, smem_base + stage_bytes);
-#pragma unroll
-        for (int u = 0; u < R - 1; ++u) load_frag(wr[u], rsW, lane16, woff_cur + (unsigned)(u * 1024));
-        if (gtid < WC * 32) {
-            const int c = cb * WC * 32 + gtid;
-            ldsVec[gtid] = a.bias != nullptr ? a.bias[c] : 0.f;
-            ldsVec[WC * 32 + gtid] = has_post ? a.pscale[c] : 1.f;
-            ldsVec[2 * WC * 32 + gtid] = has_post ? a.pshift[c] : 0.f;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-
-    const unsigned rp_bytes = (unsigned)(RP * kPix);
-    int sc = 0, stage = 0, step = 0;
-    // one matrix phase: the 18 units of stage `sc` of item `id` on stage image `stage`
-    auto matrix_phase = [&]() __attribute__((always_inline)) {
-        const char* Ab = smem_g + (stage ? stage_bytes : 0u);
-        i32x4_t fb[PF];
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf]);
-#pragma unroll
-        for (int u = 0; u < kUnits; ++u) {
-            {
-                const int up = u + R - 1;
-                const unsigned so = up < kUnits ? woff_cur + (unsigned)(up * 1024) : woff_next + (unsigned)((up - kUnits) * 1024);
-                load_frag(wr[up % R], rsW, lane16, so);
-            }
-            if (u < R - 1)
-                asm volatile("" : "+v"(wr[u % R]));     // landed before the barrier in front of this phase
-            else
-                wait_frag<R - 1>(wr[u % R]);             // requested in this phase: only weight loads are younger
-            const int un = u + 1;
-            const unsigned offn = (unsigned)((un >> 1) / 3) * rp_bytes + (unsigned)((((un >> 1) % 3) * kPix) + (un & 1) * 32);
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[pf]), acc[pf], 0, 0, 0);
-                if (u + 1 < kUnits) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf] + offn);
-                // one fragment read behind each MFMA, PF - 1 MFMAs ahead of its use (hipcc otherwise batches a unit's reads behind
-                // its sixth MFMA: a lone wave then waits an LDS round trip per unit with nobody to cover it)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (u + 1 < kUnits) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-    };
-    // the phase behind it: the stage image just read is free (every wave of the group is past the barrier); finish the item if
-    // this was its last stage; request the stage after next into the freed image; wait for everything in flight
-    auto other_phase = [&]() __attribute__((always_inline)) {
-        const unsigned freed = smem_base + (stage ? stage_bytes : 0u);
-        stage ^= 1;
-        ++sc;
-        woff_cur = woff_next;
-        if (sc == nsc) {
-            if constexpr (!GENERAL) {
-                float bias16[16];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bz = *reinterpret_cast<const float4*>(ldsVec + wc * 32 + 8 * g + 4 * (lane >> 5));
-                    bias16[g * 4 + 0] = bz.x;
-                    bias16[g * 4 + 1] = bz.y;
-                    bias16[g * 4 + 2] = bz.z;
-                    bias16[g * 4 + 3] = bz.w;
-                }
-                int tile = id;
-                if (a.ncb != 1) tile = ((id >> 3) / a.ncb) * 8 + (id & 7);
-                const int tx_i = tile % a.tiles_x;
-                const int t2 = tile / a.tiles_x;
-                const int ty_i = t2 % a.tiles_y;
-                const int bimg = t2 / a.tiles_y;
-                const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
-                const int obase = (bimg * a.Ho + oy0) * a.Wo + ox0;
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf) {   // one fragment at a time (the barrier keeps hipcc from interleaving them: registers)
-                    int q = fq;
-                    asm volatile("" : "+v"(q));
-                    const int m = pf * 32 + q;
-                    const int ty = div_small(m, a.inv_tw), tx = m - ty * a.TW;
-                    const bool v = m < a.TH * a.TW && (oy0 + ty < a.Ho) && (ox0 + tx < a.Wo);
-                    const unsigned ob = v ? ((unsigned)(obase + ty * a.Wo + tx) * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;
-                    fast_unit(acc[pf], ob, bias16);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                const ConvKArgs ea = reload_args();
-                int opix[PF];
-                out_pix(id, opix);
-                BiasRegs<1> bz;
-                load_bias<1>(ea, cb * WC + wc, 0, lane, bz);
-#pragma unroll
-                for (int pf = 0; pf < PF; ++pf) {
-                    const int op1[1] = {opix[pf]};
-                    conv_epilogue<1, 1>(ea, *reinterpret_cast<const f32x16_t(*)[1][1]>(&acc[pf]), op1, cb * WC + wc, 0, lane, bz);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
-                }
-            }
-            id = next_valid(id);
-            sc = 0;
-        }
-        woff_next = (sc + 1 < nsc) ? woff_cur + kUnits * 1024 : wbase;
-        advance_request();
-        if (n_real) issue_halo((unsigned)n_sc * 64u, freed);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-
-    // half-steps: group g has the matrix pipe in half-steps h with h % 2 == g and does its request / epilogue phase in the next one
-    // (one copy of each phase in the code: two inlined copies per group cost hundreds of spilled registers)
-    bool pending = false;   // a matrix phase of this group has not had its request / epilogue phase yet
-    for (int h = 0; h < 2 * steps_max + 1; ++h) {
-        if ((h & 1) == grp) {
-            if (step < steps_mine) {
-                matrix_phase();
-                ++step;
-                pending = true;
-            }
-        } else if (pending) {
-            other_phase();
-            pending = false;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+// (Round 4, r04k: a ping-pong form - ONE 8-wave block whose two 4-wave groups strictly alternate matrix phases and request /
+// epilogue phases between block barriers, the structure of the tuned attention kernels - was built, passed parity and the stress
+// test, and ran 13 % SLOWER than the two free-running blocks above on the same tiles (profiles/r04/conv_bench_pingpong_r04k.json):
+// a lone wave per SIMD issues MFMAs at 89 % of the pipe's rate, and every phase lasts as long as the longer of the two partners.
+// Removed; git history has it.)
 
 template <int PF, int WC, int WP>
 int launch_wreg(const Launch& L, hipStream_t s) {
@@ -833,55 +494,9 @@ int launch_wreg(const Launch& L, hipStream_t s) {
     return Y6_OK;
 }
 
-template <int PF, int WC, bool GENERAL>
-int launch_wregpp_k(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_wregpp_kernel<PF, WC, GENERAL>;
-    static bool big_lds_enabled = false;
-    if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds_enabled = true;
-    }
-    Y6_REQUIRE(L.lds <= 160 * 1024, "conv_wregpp: tile needs %zu bytes of LDS", L.lds);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        Y6_HIP(hipGetDevice(&dev));
-        Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
-    int grid = n_cu;              // one 8-wave block per CU; its two groups walk the ids like 2 * grid blocks
-    const int gq = 8 * L.k.ncb;   // both grid and 2 * grid strides keep (id >> 3) % ncb - the cout block - fixed per group
-    grid -= grid % gq;
-    if (grid < gq) grid = gq;
-    const int need = (L.grid + 1) / 2;
-    if (grid > need) grid = ((need + gq - 1) / gq) * gq;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WC * 2 * 64), L.lds, s, L.k);
-    Y6_LAUNCH_CHECK();
-    return Y6_OK;
-}
-
-template <int PF, int WC>
-int launch_wregpp(const Launch& L, hipStream_t s) {
-    const ConvKArgs& a = L.k;   // the fast epilogue's preconditions (the kernel's own `fast` in the two-block form)
-    const bool fast = a.res == nullptr && a.up == 0 && a.out != nullptr && a.vec16_ok && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
-    return fast ? launch_wregpp_k<PF, WC, false>(L, s) : launch_wregpp_k<PF, WC, true>(L, s);
-}
-
 }  // namespace
 
 int y6_conv_wreg_max_pieces(int nw) { return kMaxP * nw; }
-
-int y6_conv_wregpp_launch(const void* Lp, int pf, int wc, hipStream_t s) {
-    const Launch& L = *static_cast<const Launch*>(Lp);
-    if (wc == 4) {
-        switch (pf) {
-            case 6: return launch_wregpp<6, 4>(L, s);
-            case 5: return launch_wregpp<5, 4>(L, s);
-            case 4: return launch_wregpp<4, 4>(L, s);
-        }
-    }
-    y6_set_error("conv_wregpp: no instantiation pf %d, %d cout waves", pf, wc);
-    return Y6_EUNSUPPORTED;
-}
 
 // L points at conv_mfma.hip's launch record (conv_common.hpp)
 int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, hipStream_t s) {
