@@ -578,3 +578,54 @@ def test_result_ring_never_overwrites_a_held_result():
         ids.add(id(t))
         del t
     assert len(ids) == 2                                # dropped results: the two slots alternate
+
+
+def _device_kernel_notes(lib_path):
+    """(kernel name -> metadata dict) of every gfx950 code object embedded in the shared library (llvm-readelf --notes)."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    blob = open(lib_path, "rb").read()
+    out = {}
+    pos = blob.find(b"\x7fELF", 1)
+    while pos >= 0:
+        e_shoff, = struct.unpack_from("<Q", blob, pos + 0x28)
+        e_shentsize, e_shnum = struct.unpack_from("<HH", blob, pos + 0x3A)
+        e_machine, = struct.unpack_from("<H", blob, pos + 0x12)
+        size = e_shoff + e_shentsize * e_shnum
+        if e_machine == 224 and size > 0:   # EM_AMDGPU
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(blob[pos:pos + size])
+                f.flush()
+                txt = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+            cur = None
+            for line in txt.splitlines():
+                m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)$", line)
+                if not m:
+                    continue
+                k, v = m.group(1), m.group(2).strip()
+                if k == "name" and v.startswith("_Z"):
+                    cur = out.setdefault(v, {})
+                elif cur is not None and k in ("vgpr_spill_count", "sgpr_spill_count", "vgpr_count", "private_segment_fixed_size"):
+                    cur[k] = int(v)
+        pos = blob.find(b"\x7fELF", pos + 4)
+    return out
+
+
+def test_wreg_kernels_keep_their_asm_loaded_registers():
+    """conv_wreg.hip loads weight and pixel fragments by inline asm and awaits them by hand-counted s_waitcnt: hipcc does not know
+    those registers are still in flight, so a spilled one (scratch store of a value that has not landed) is a WRONG RESULT, not a
+    slowdown.  Every instantiation in the shipped library must be free of VGPR spills and scratch."""
+    import os
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        import pytest
+        pytest.skip("llvm-readelf not present")
+    from yolov6_amd import _lib
+    notes = _device_kernel_notes(_lib.LIB_PATH)
+    wreg = {k: v for k, v in notes.items() if "conv3x3_wreg_kernel" in k}
+    assert len(wreg) >= 4, sorted(notes)[:5]
+    for name, meta in wreg.items():
+        assert meta.get("vgpr_spill_count", -1) == 0, (name, meta)
+        assert meta.get("private_segment_fixed_size", -1) == 0, (name, meta)

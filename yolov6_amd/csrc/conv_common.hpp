@@ -51,7 +51,7 @@ struct ConvKArgs {
     int dma_rp, dma_pls, dma_nhp;
     // conv_wreg.hip only: 1.0f / halo row pitch, 1.0f / tile width (div_small)
     float inv_rp, inv_tw;
-    int prio_mode;   // 1: wave priority falls from stage to stage (keeps the two blocks of a CU within a stage of each other)
+    int prio_mode;   // conv_wreg.hip: bit 0 = matrix-phase priority falls from stage to stage, bit 1 = non-matrix phases at priority 3
 };
 
 // LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it

@@ -1161,7 +1161,7 @@ const VariantCfg kVariants[] = {
     // pf = pixel fragments per wave, nw = waves per block (nw / cf pixel groups): 128 couts x pf * 32 pixels on four waves, two
     // blocks per CU; 64 couts x 2 * pf * 32 pixels for the 64-channel layers.  The tile (TH x TW <= the block's pixel slots) is
     // chosen for whole rounds of the persistent walk (choose_tile_wreg).
-    {4, 8, 6, "wreg_p8", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {2, 8, 6, "wreg2_p8", 4}, {2, 7, 6, "wreg2_p7", 4}};
+    {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4}, {2, 7, 6, "wreg2_p7", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {

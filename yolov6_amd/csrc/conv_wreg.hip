@@ -35,6 +35,7 @@
 // the SIMD's other wave (the CU's second block) keeps the matrix pipe busy.
 #include "common.hpp"
 #include "conv_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -66,12 +67,30 @@ __device__ __forceinline__ void wait_frag_n(i32x4_t& frag, int n) {
         default: wait_frag<13>(frag); break;
     }
 }
+// one pixel fragment out of LDS, asynchronously (pair with wait_lds): lane i gets the 16 B at addr(lane) + IMM
+template <int IMM>
+__device__ __forceinline__ void lds_read16(i32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
+}
+// the fragment has landed once at most N younger LDS reads are in flight (LDS returns in order; anything else counted by lgkmcnt
+// only makes the wait stricter)
+template <int N>
+__device__ __forceinline__ void wait_lds(i32x4_t& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 // n / d for small non-negative n (below 2^16) with the host's 1.0f / d: exact - (n + 0.5) / d is at least 0.5 / d away from an integer
 __device__ __forceinline__ int div_small(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
 // Ceiling probes / trace (tools/build_probe_libs.py --wreg n; WRONG RESULTS for n >= 2, timing only), compile-time:
 //   1 = s_memtime trace of block 0 / thread 0 into a.dbg (tools/dma_trace.py --wreg); 2 = no weight loads after the prologue (the
-//   waits stay); 3 = no fragment reads after a stage's first unit; 4 = no halo requests after the prologue; 5 = no epilogue;
+//   waits stay); 4 = no halo requests after the prologue; 5 = no epilogue;
 //   6 = no MFMAs; 7 = no stage barrier; 9 (WRONG under load, see the header) = the first version's counted waits across the halo burst
 #ifndef Y6_WREG_PROBE
 #define Y6_WREG_PROBE 0
@@ -127,6 +146,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         if (t >= a.ntiles) id = next_valid(id);
     }
     if (id >= nids) return;
+    if (a.prio_mode & 2) __builtin_amdgcn_s_setprio(3);
     int dbg_n = 0;
     const bool tracing = kWregProbe == 1 && a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
 #define DT(tag)                                                              \
@@ -277,6 +297,9 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
             __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyte + (ocol + (unsigned)(16 * gp)) * 2u), 0, 0);
         }
+        // (r04n: the same stores as 64-byte runs - each fragment transposed through a per-wave LDS scratch so that four adjacent
+        // lanes hold one pixel's 64 B - took 22.9 k cycles per item instead of 12.9 k: the end-of-launch store burst, 26 MB from
+        // every block at once, is bound by the fabric's write bandwidth (7 us at 3.7 TB/s), not by the request count.  Removed.)
     };
 
     // prologue: the first stage of the first item, the first R - 1 weight fragments
@@ -348,53 +371,72 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         DT(10);
+        issue_halo(real, (unsigned)n_sc * 64u, smem_base + (stage ? 0u : stage_bytes));
         // The two blocks of a CU put one wave each on every SIMD, and the hardware arbitrates their issue by age: the older block's
-        // waves win the matrix pipe whenever both want it, finish first (45 us of a 58 us launch, profiles/r04/block_times_r04j.txt)
-        // and leave the younger block to run alone with nothing beside its request / epilogue phases.  A priority that falls from
-        // stage to stage (3, 2, 1, 0, 3, ...) gives a block that lags by a stage the higher priority three times out of four: the
-        // lag stays within a stage or so, both blocks finish together, and their matrix phases tend to interleave.
-        if (a.prio_mode == 1) {
-            switch (gstage & 3) {
-                case 0: __builtin_amdgcn_s_setprio(3); break;
-                case 1: __builtin_amdgcn_s_setprio(2); break;
-                case 2: __builtin_amdgcn_s_setprio(1); break;
+        // waves win the matrix pipe whenever both want it, finish first and leave the younger block to run alone with nothing beside
+        // its request / epilogue phases.  Wave priority as a counter-measure (a.prio_mode, A/B switch Y6_WREG_PRIO):
+        //   bit 0: the matrix phase's priority falls from stage to stage (2, 1, 0, 2, ...): a block that lags by a stage has the
+        //          higher priority two times out of three, so the lag stays within a stage or so and both finish together;
+        //   bit 1: the non-matrix phases (stage top, requests, epilogue) run at priority 3: a wave between two matrix phases gets
+        //          every issue slot it can use and is back at the matrix pipe sooner; the partner's MFMAs need one slot in 32.
+        if (a.prio_mode & 1) {
+            switch (gstage % 3) {
+                case 0: __builtin_amdgcn_s_setprio(2); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
                 default: __builtin_amdgcn_s_setprio(0); break;
             }
+        } else if (a.prio_mode & 2) {
+            __builtin_amdgcn_s_setprio(0);
         }
         ++gstage;
-        issue_halo(real, (unsigned)n_sc * 64u, smem_base + (stage ? 0u : stage_bytes));
         DT(11);
-        const char* Ab = smem + (stage ? stage_bytes : 0u);
-        i32x4_t fb[PF];
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf]);   // unit 0: tap (0, 0), k-step 0
-#pragma unroll
-        for (int u = 0; u < kUnits; ++u) {
-            {   // the fragment R - 1 units ahead, into the slot unit u - 1 just released
-                const int up = u + R - 1;
-                const unsigned so = up < kUnits ? woff_cur + (unsigned)(up * 1024) : woff_next + (unsigned)((up - kUnits) * 1024);
-                if (kWregProbe != 2) load_frag(wr[up % R], rsW, lane16, so);
+        // ---- the stage's 18 x PF fragment products.  The pixel fragments come out of LDS by inline asm with hand-counted lgkmcnt
+        // (frag_ring below): fragment i + G is requested right behind the MFMA of fragment i, so G - 1 = PF - 1 reads are in flight behind
+        // the one an MFMA waits for (a ring of two units, G = 2 PF, measured 1-2 % slower: r04m).  (hipcc's own counting forces lgkmcnt(0) in front of the first MFMA of every unit - the kernel
+        // contains FLAT instructions in its general epilogue, and with a FLAT access "pending" forever (it never sees a vmcnt wait:
+        // those are asm too) it may not assume in-order return - and it clusters the reads behind the MFMAs: every unit started
+        // with a full LDS round trip.)
+        const unsigned Aoff = smem_base + (stage ? stage_bytes : 0u);
+        constexpr int G = PF, TOTAL = kUnits * PF;
+        i32x4_t fb[G];
+        auto frag_read = [&](auto ic) {   // request fragment i = (unit, pf) of this stage into its ring slot
+            constexpr int i = decltype(ic)::value;
+            constexpr int u = i / PF, pf = i % PF, tap = u >> 1;
+            const unsigned addr = Aoff + pixaddr[pf] + (unsigned)(tap / 3) * rp_bytes;
+            lds_read16<(tap % 3) * kPix + (u & 1) * 32>(fb[i % G], addr);
+        };
+        static_for<0, G>(frag_read);
+        static_for<0, TOTAL>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int u = i / PF, pf = i % PF;
+            if constexpr (pf == 0) {
+                {   // the weight fragment R - 1 units ahead, into the slot unit u - 1 just released
+                    constexpr int up = u + R - 1;
+                    const unsigned so = up < kUnits ? woff_cur + (unsigned)(up * 1024) : woff_next + (unsigned)((up - kUnits) * 1024);
+                    if (kWregProbe != 2) load_frag(wr[up % R], rsW, lane16, so);
+                }
+                // in flight behind this unit's fragment: the R - 1 younger fragments, and - for the fragments requested before this
+                // stage's top - the halo burst
+                if constexpr (u < R - 1) {   // landed at the stage top (tie the value to this point: no instruction)
+                    if (kWregProbe == 9)
+                        wait_frag_n(wr[u % R], R - 1 + npw);
+                    else
+                        asm volatile("" : "+v"(wr[u % R]));
+                } else {                     // requested in this stage, behind the burst: only weight loads are younger
+                    wait_frag<R - 1>(wr[u % R]);
+                }
             }
-            // in flight behind this unit's fragment: the R - 1 younger fragments, and - for the fragments requested before this
-            // stage's top - the halo burst
-            if (u < R - 1) {   // landed at the stage top (tie the value to this point: no instruction)
-                if (kWregProbe == 9)
-                    wait_frag_n(wr[u % R], R - 1 + npw);
-                else
-                    asm volatile("" : "+v"(wr[u % R]));
-            } else {           // requested in this stage, behind the burst: only weight loads are younger
-                wait_frag<R - 1>(wr[u % R]);
+            wait_lds<(TOTAL - 1 - i < G - 1 ? TOTAL - 1 - i : G - 1)>(fb[i % G]);
+            if (kWregProbe != 6)
+                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[i % G]), acc[pf], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i + G < TOTAL) {
+                frag_read(std::integral_constant<int, i + G>{});
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const int un = u + 1;
-            const unsigned offn = (unsigned)((un >> 1) / 3) * rp_bytes + (unsigned)((((un >> 1) % 3) * kPix) + (un & 1) * 32);
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf) {
-                if (kWregProbe != 6)
-                    acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[pf]), acc[pf], 0, 0, 0);
-                if (u + 1 < kUnits && kWregProbe != 3) fb[pf] = *reinterpret_cast<const i32x4_t*>(Ab + pixaddr[pf] + offn);
-            }
-        }
+        });
         DT(12);
+        if (a.prio_mode & 2) __builtin_amdgcn_s_setprio(3);
         // ---- next stage
         stage ^= 1;
         ++sc;
@@ -503,14 +545,14 @@ int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, hipStream_t s) 
     const Launch& L = *static_cast<const Launch*>(Lp);
     if (wc == 4 && wpx == 1) {
         switch (pf) {
-            case 8: return launch_wreg<8, 4, 1>(L, s);
             case 7: return launch_wreg<7, 4, 1>(L, s);
+            case 6: return launch_wreg<6, 4, 1>(L, s);
+            case 5: return launch_wreg<5, 4, 1>(L, s);
             case 4: return launch_wreg<4, 4, 1>(L, s);
         }
     }
     if (wc == 2 && wpx == 2) {
         switch (pf) {
-            case 8: return launch_wreg<8, 2, 2>(L, s);
             case 7: return launch_wreg<7, 2, 2>(L, s);
         }
     }

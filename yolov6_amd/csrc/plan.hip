@@ -876,9 +876,9 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // layers, 35 dmarw8_c2p2 (tap images resident in LDS) wins the 64-channel layers in isolation: candidates (+1.9 % img/s
     // with all three allowed).  34 dmar8_c2p2 and 36 dma_c2p4 lost on every layer: selectable, never default.
     // 38-42, round 4 (conv_wreg.hip, profiles/r04/conv_bench_wreg_v3_r04e.json): 39 wreg_p7 / 40 wreg_p4 take the 128-cout-block
-    // layers from the LDS-DMA forms (+6...12 % on the 60-GFLOP layers in isolation); 38 wreg_p8 (16x16 tiles: the rounds do not fill)
-    // and the 64-cout forms 41 / 42 lose: selectable, not default.
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,34,36,38,41,42";
+    // layers from the LDS-DMA forms (+6...12 % on the 60-GFLOP layers in isolation); 38 wreg_p6 / 41 wreg_p5 (tiles of 192 / 160 pixel slots) are
+    // candidates since r04n; the 64-cout form 42 loses: selectable, not default.
+    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,34,36,42";
     {
         for (const char* c = ex; *c;) {
             char* end = nullptr;
