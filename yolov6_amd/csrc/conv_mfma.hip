@@ -1161,7 +1161,10 @@ const VariantCfg kVariants[] = {
     // pf = pixel fragments per wave, nw = waves per block (nw / cf pixel groups): 128 couts x pf * 32 pixels on four waves, two
     // blocks per CU; 64 couts x 2 * pf * 32 pixels for the 64-channel layers.  The tile (TH x TW <= the block's pixel slots) is
     // chosen for whole rounds of the persistent walk (choose_tile_wreg).
-    {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4}, {2, 7, 6, "wreg2_p7", 4}};
+    {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4}, {2, 7, 6, "wreg2_p7", 4},
+    // the same kernel for stride 2 (cs = 2): a halo row is stored as [even columns | odd columns], the tap offsets stay immediates;
+    // the halo of a tile is four times its pixels, so the tiles are small (96 / 128 pixel slots)
+    {4, 3, 6, "wregs2_p3", 4, 1, 2, 16, 2}, {4, 4, 6, "wregs2_p4", 4, 1, 2, 16, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 int halo_cap(int ks, int st, int pf) {
@@ -1213,28 +1216,31 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
 // continues at a pixel index consecutive modulo 16 and never conflicts.  Default: the dense pitch TW + 2 - a wrapping group has two
 // 2-way conflicts, one extra LDS cycle on some reads, but the stage image is 25-40 % smaller and the halo REQUESTS are what the
 // stage top costs: 470 cycles each with ten per wave in flight, profiles/r04/v0_trace_wreg_*.txt)
-int wreg_row_pitch(int TW) {
+int wreg_row_pitch(int TW, int st) {
+    if (st == 2) return 2 * TW + 2;   // TW + 1 even columns, TW odd ones, one pad slot
     static const bool conflict_free = getenv("Y6_WREG_PITCH") && strcmp(getenv("Y6_WREG_PITCH"), "conflictfree") == 0;
     return (TW % 16 == 0 || !conflict_free) ? TW + 2 : TW + 16;
 }
-int wreg_pieces(int TH, int TW) { return y6_cdiv(5 * (TH + 2) * wreg_row_pitch(TW), 64); }
+int wreg_pieces(int TH, int TW, int st) { return y6_cdiv(5 * ((TH - 1) * st + 3) * wreg_row_pitch(TW, st), 64); }
 // TH x TW <= bp pixel slots: fewest rounds of the persistent walk (items / resident blocks, rounded up) first - a block's time is
 // its pixel SLOTS, so a tile that divides the map with a few idle slots beats a full tile that leaves a partial last round -
 // then the fewest items (less padding inside the rounds), then the smallest stage image
-void choose_tile_wreg(int B, int Ho, int Wo, int ncb, int bp, int max_pieces, int slots, int* pTH, int* pTW) {
+void choose_tile_wreg(int B, int Ho, int Wo, int ncb, int bp, int max_pieces, int slots, int st, int* pTH, int* pTW) {
     long best_rounds = -1, best_items = 0;
     int best_halo = 0, bTH = 1, bTW = 1;
     for (int TW = 1; TW <= (Wo < bp ? Wo : bp); ++TW) {
         int TH = bp / TW;
         if (TH > Ho) TH = Ho;
-        while (TH >= 1 && wreg_pieces(TH, TW) > max_pieces) --TH;
+        while (TH >= 1 && wreg_pieces(TH, TW, st) > max_pieces) --TH;
         if (TH < 1) continue;
         // (a smaller TH with the same row count per map never hurts the rounds: take the smallest that keeps the tile count)
         const int ty = y6_cdiv(Ho, TH);
         TH = y6_cdiv(Ho, ty);
         const long items = (long)B * ty * y6_cdiv(Wo, TW) * ncb;
-        const long rounds = (items + slots - 1) / slots;
-        const int halo = wreg_pieces(TH, TW);
+        const int halo = wreg_pieces(TH, TW, st);
+        // two blocks per CU need both stage images of both blocks in 160 KiB: a bigger image halves the resident blocks
+        const int sl = (2 * halo * 1024 + 2048 > 80 * 1024) ? slots / 2 : slots;
+        const long rounds = (items + sl - 1) / sl * (sl == slots ? 1 : 2);   // (a round of half the blocks counts double)
         if (best_rounds < 0 || rounds < best_rounds || (rounds == best_rounds && (items < best_items || (items == best_items && halo < best_halo)))) {
             best_rounds = rounds;
             best_items = items;
@@ -1311,7 +1317,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         k.Wo = d->out.W;
         const int cap = vc.persist == 4 ? y6_conv_dma_halo_cap(bp, vc.cs) : vc.persist == 2 ? (st == 2 ? 1161 : (bp <= 128 ? 208 : (bp <= 256 ? 352 : (bp <= 512 ? 660 : 1190)))) : halo_cap(ks, st, vc.pf);
         if (vc.persist == 6)   // two 4-wave blocks per CU
-            choose_tile_wreg(k.B, k.Ho, k.Wo, y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf), bp, y6_conv_wreg_max_pieces(vc.nw), 2 * device_cus(), &k.TH, &k.TW);
+            choose_tile_wreg(k.B, k.Ho, k.Wo, y6_cdiv(y6_cdiv(k.Cout, 32), vc.cf), bp, y6_conv_wreg_max_pieces(vc.nw, st), 2 * device_cus(), st, &k.TH, &k.TW);
         else
             choose_tile(k.Ho, k.Wo, ks, st, bp, cap, &k.TH, &k.TW, vc.persist == 4 ? 16 : 0);
     }
@@ -1331,9 +1337,9 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     }
     L->grid = k.nids;
     if (vc.persist == 6) {
-        k.dma_rp = wreg_row_pitch(k.TW);
+        k.dma_rp = wreg_row_pitch(k.TW, st);
         k.dma_pls = k.HH * k.dma_rp;
-        k.dma_nhp = wreg_pieces(k.TH, k.TW);
+        k.dma_nhp = wreg_pieces(k.TH, k.TW, st);
         k.inv_rp = 1.0f / (float)k.dma_rp;
         k.inv_tw = 1.0f / (float)k.TW;
         {
@@ -1635,7 +1641,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     const VariantCfg& vc = kVariants[variant];
     const int ks = d->ksize, st = d->stride;
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
-    if (st == 2 && vc.pf != 1) return 0;
+    if (st == 2 && vc.pf != 1 && vc.persist != 6) return 0;
     if (vc.persist == 3) {   // streaming 1x1: Cin = 16 * {4, 8, 16} exactly, weights in registers
         if (ks != 1 || st != 1 || d->w_packed == nullptr) return 0;
         const int ksn = d->in.C / 16;
@@ -1648,7 +1654,7 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 6) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
-        if (st != 1 || d->w_packed == nullptr) return 0;
+        if (st != vc.cs || d->w_packed == nullptr) return 0;
         if (d->in.C % 32 || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
         if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;
@@ -1714,8 +1720,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
         case 22: return launch_stream1x1_cfg<1>(L, s);
         case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 38: case 39: case 40: case 41: case 42:
-            return y6_conv_wreg_launch(&L, kVariants[variant].pf, kVariants[variant].cf, kVariants[variant].nw / kVariants[variant].cf, s);
+        case 38: case 39: case 40: case 41: case 42: case 43: case 44:
+            return y6_conv_wreg_launch(&L, kVariants[variant].pf, kVariants[variant].cf, kVariants[variant].nw / kVariants[variant].cf, kVariants[variant].cs, s);
         case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
             return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
                                       kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);

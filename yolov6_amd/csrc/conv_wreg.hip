@@ -40,7 +40,8 @@
 namespace {
 
 constexpr int kPix = 80;     // LDS bytes per halo pixel: 32 channels (64 B) + one 16-byte pad slot
-constexpr int kMaxP = 8;     // at most this many halo requests (1 KiB each) per wave and stage
+constexpr int kMaxP1 = 8;    // at most this many halo requests (1 KiB each) per wave and stage, stride 1
+constexpr int kMaxP2 = 12;   // ... stride 2 (the halo of a tile is four times its pixels)
 constexpr int kRing = 6;     // weight fragments in flight per wave (divides the 18 units of a stage)
 constexpr int kUnits = 18;   // (tap, k-step) units per 32-channel stage
 
@@ -97,13 +98,14 @@ __device__ __forceinline__ int div_small(int n, float inv) { return (int)(((floa
 #endif
 constexpr int kWregProbe = Y6_WREG_PROBE;
 
-template <int PF, int WC, int WP>
+template <int PF, int WC, int WP, int ST>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
+    constexpr int kMaxP = ST == 2 ? kMaxP2 : kMaxP1;   // halo requests per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WC * WP;
     constexpr int R = kRing;
     static_assert(kUnits % R == 0, "ring slots are compile-time indices");
-    static_assert(R - 1 + kMaxP == 13 && R - 1 == 5, "wait_frag_n's cases");
+    static_assert(R - 1 + kMaxP1 == 13 && R - 1 == 5, "wait_frag_n's cases");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -183,8 +185,11 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             asm volatile("" : "+v"(l));   // opaque: otherwise hipcc hoists (row, column, piece) of every request out of the item loop and spills them
             const int s = (wave + NW * i) * 64 + l;
             const int p = s / 5, j = s - 5 * p;
-            const int hy = div_small(p, a.inv_rp), hx = p - hy * RP;
-            const bool v = (i < npw) && (j < 4) && (hy < a.HH) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
+            const int hy = div_small(p, a.inv_rp), hc = p - hy * RP;
+            // stride 2: a halo row is stored as [even columns (TW + 1) | odd columns (TW)], so that the 16 lanes of a read group -
+            // consecutive output pixels, input columns two apart - still read 16 consecutive pixel slots
+            const int hx = ST == 1 ? hc : (hc <= a.TW ? 2 * hc : 2 * (hc - a.TW - 1) + 1);
+            const bool v = (i < npw) && (j < 4) && (hy < a.HH) && (ST == 1 || hc <= 2 * a.TW) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
             hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * 2) + (unsigned)(j * 16) : kOob;
         }
     };
@@ -202,8 +207,8 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         const int t2 = tile / a.tiles_x;
         const int ty_i = t2 % a.tiles_y;
         const int b = t2 / a.tiles_y;
-        iy0 = ty_i * a.TH - 1;
-        ix0 = tx_i * a.TW - 1;
+        iy0 = ty_i * a.TH * ST - 1;
+        ix0 = tx_i * a.TW * ST - 1;
         // modulo 2^32 (tensors up to 3.5 GiB): the origin may lie one row / column outside the image
         base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)a.in_co) * 2u;
     };
@@ -331,10 +336,11 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         const int npx = a.TH * a.TW;
         const int mm = m < npx ? m : npx - 1;
         const int ty = div_small(mm, a.inv_tw), tx = mm - ty * a.TW;
-        pixaddr[pf] = (unsigned)((ty * RP + tx) * kPix + (lane >> 5) * 16);
+        pixaddr[pf] = (unsigned)((ST * ty * RP + tx) * kPix + (lane >> 5) * 16);
     }
 
     const unsigned rp_bytes = (unsigned)(RP * kPix);
+    const unsigned odd_bytes = (unsigned)((a.TW + 1) * kPix);   // stride 2: first odd-column slot of a halo row
     int sc = 0, stage = 0, gstage = 0;
     in_loop = true;
     DT(2);
@@ -402,8 +408,13 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         auto frag_read = [&](auto ic) {   // request fragment i = (unit, pf) of this stage into its ring slot
             constexpr int i = decltype(ic)::value;
             constexpr int u = i / PF, pf = i % PF, tap = u >> 1;
-            const unsigned addr = Aoff + pixaddr[pf] + (unsigned)(tap / 3) * rp_bytes;
-            lds_read16<(tap % 3) * kPix + (u & 1) * 32>(fb[i % G], addr);
+            if constexpr (ST == 1) {
+                const unsigned addr = Aoff + pixaddr[pf] + (unsigned)(tap / 3) * rp_bytes;
+                lds_read16<(tap % 3) * kPix + (u & 1) * 32>(fb[i % G], addr);
+            } else {   // input column 2 tx + dx: dx = 0 / 2 are even-plane slots tx / tx + 1, dx = 1 is odd-plane slot tx
+                const unsigned addr = Aoff + pixaddr[pf] + (unsigned)(tap / 3) * rp_bytes + ((tap % 3) == 1 ? odd_bytes : 0u);
+                lds_read16<((tap % 3) == 2 ? kPix : 0) + (u & 1) * 32>(fb[i % G], addr);
+            }
         };
         static_for<0, G>(frag_read);
         static_for<0, TOTAL>([&](auto ic) {
@@ -504,9 +515,9 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 // a lone wave per SIMD issues MFMAs at 89 % of the pipe's rate, and every phase lasts as long as the longer of the two partners.
 // Removed; git history has it.)
 
-template <int PF, int WC, int WP>
+template <int PF, int WC, int WP, int ST>
 int launch_wreg(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_wreg_kernel<PF, WC, WP>;
+    auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -538,24 +549,30 @@ int launch_wreg(const Launch& L, hipStream_t s) {
 
 }  // namespace
 
-int y6_conv_wreg_max_pieces(int nw) { return kMaxP * nw; }
+int y6_conv_wreg_max_pieces(int nw, int stride) { return (stride == 2 ? kMaxP2 : kMaxP1) * nw; }
 
 // L points at conv_mfma.hip's launch record (conv_common.hpp)
-int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, hipStream_t s) {
+int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, hipStream_t s) {
     const Launch& L = *static_cast<const Launch*>(Lp);
-    if (wc == 4 && wpx == 1) {
+    if (stride == 2 && wc == 4 && wpx == 1) {
         switch (pf) {
-            case 7: return launch_wreg<7, 4, 1>(L, s);
-            case 6: return launch_wreg<6, 4, 1>(L, s);
-            case 5: return launch_wreg<5, 4, 1>(L, s);
-            case 4: return launch_wreg<4, 4, 1>(L, s);
+            case 4: return launch_wreg<4, 4, 1, 2>(L, s);
+            case 3: return launch_wreg<3, 4, 1, 2>(L, s);
         }
     }
-    if (wc == 2 && wpx == 2) {
+    if (stride == 1 && wc == 4 && wpx == 1) {
         switch (pf) {
-            case 7: return launch_wreg<7, 2, 2>(L, s);
+            case 7: return launch_wreg<7, 4, 1, 1>(L, s);
+            case 6: return launch_wreg<6, 4, 1, 1>(L, s);
+            case 5: return launch_wreg<5, 4, 1, 1>(L, s);
+            case 4: return launch_wreg<4, 4, 1, 1>(L, s);
         }
     }
-    y6_set_error("conv_wreg: no instantiation pf %d, %d x %d waves", pf, wc, wpx);
+    if (stride == 1 && wc == 2 && wpx == 2) {
+        switch (pf) {
+            case 7: return launch_wreg<7, 2, 2, 1>(L, s);
+        }
+    }
+    y6_set_error("conv_wreg: no instantiation pf %d, %d x %d waves, stride %d", pf, wc, wpx, stride);
     return Y6_EUNSUPPORTED;
 }
