@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--dropin-steps", type=int, default=50, help="extra (separately timed) steps through the reference-"
                     "signature API: model(x) + non_max_suppression(); 0 disables")
     ap.add_argument("--no-verify", action="store_true", help="skip the NMS-vs-oracle self check (outside the timed region)")
+    ap.add_argument("--no-fuse-candidates", action="store_true",
+                    help="A/B: NMS selects its candidates itself (re-reads the prediction tensor) instead of the decode launch doing it")
     ap.add_argument("--nms-stream", choices=("same", "side"), default=os.environ.get("Y6_BENCH_NMS_STREAM", "same"),
                     help="same: forward and NMS of a batch back to back on one stream; side: the NMS of batch k runs on a second "
                          "HIP stream while the forward of batch k+1 runs on the first (two result tensors, alternating)")
@@ -377,10 +379,15 @@ def main():
         cal = [_synth.synth_images(8, args.size, seed=100 + i).to(device).half() for i in range(4)]
         quant.quantize(model, quant.calibrate(model, cal))
     plan = model.compile(x, autotune=not args.no_autotune)
+    # the fused head tail selects the NMS candidates of its rows while they are in LDS (Plan.attach_nms: y6_nms's own first stage,
+    # same thresholds); y6_nms then starts at the sort.  Not with --nms-stream side: one candidate workspace per plan.
+    cand = None
+    if args.nms_stream != "side" and not args.no_fuse_candidates:
+        cand = plan.attach_nms(CONF, None, True)
 
     def step(timed=False):
         det = plan.run_timed() if timed else plan.run()
-        return nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
+        return nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
 
     for _ in range(args.warmup):
         step()
@@ -413,11 +420,11 @@ def main():
             plan.rebind_output(ring[slot])
         det = plan.run_timed() if timed else plan.run()
         if not side:
-            return det, nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
+            return det, nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
         fwd_done[slot].record(fwd_stream)
         with torch.cuda.stream(nms_stream):
             nms_stream.wait_event(fwd_done[slot])
-            out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
+            out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
             nms_done[slot] = torch.cuda.Event()
             nms_done[slot].record(nms_stream)
         return det, out
@@ -444,14 +451,14 @@ def main():
                 with torch.cuda.stream(nms_stream):
                     nms_stream.wait_event(fwd_done[slot])
                     nms_ev[k][0].record()
-                    out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
+                    out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
                     nms_ev[k][1].record()
                     nms_done[slot] = torch.cuda.Event()
                     nms_done[slot].record(nms_stream)
             else:
                 det = plan.run_timed()
                 nms_ev[k][0].record()
-                out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET)
+                out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
                 nms_ev[k][1].record()
             k += 1
         else:
@@ -547,7 +554,8 @@ def main():
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0,
                               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0}
                           for k, v in sorted(by_class.items())},
-            "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1), "stream": args.nms_stream},
+            "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1), "stream": args.nms_stream,
+                    "candidates_from": "decode launch (y6_nms_sink)" if cand is not None else "nms first stage"},
             "dropin_api": dropin,
             "self_check": {"nms_equals_oracle_images": verified},
             # two-stream schedule of the un-instrumented steps (yolov6_amd/schedule.py; the event-sampled steps run in plan

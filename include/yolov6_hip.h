@@ -252,6 +252,20 @@ int y6_head_decode(const y6_decode_desc* d, void* stream);
  * Replaces: Detect.forward eval branch  yolov6/models/effidehead.py:93-139 from cls_preds / reg_preds on.
  * cls_feat[l] / reg_feat[l]: views [B,Hl,Wl,Cl] (Cl % 16 == 0, 16-byte aligned); w_*: y6_pack_conv_weight images of the
  * [nc,Cl,1,1] / [4*(reg_max+1),Cl,1,1] weights; b_*: fp32 biases (fp16-rounded values).                          */
+/* Candidate sink of the fused head tail: with `workspace` set (a y6_nms workspace for the same B, A, nc, multi_label), the decode
+ * launch also selects the NMS candidates of its rows (nms.py:48, :69-84, the arithmetic of y6_nms's first stage - same device
+ * function) while they sit in LDS and appends their keys to the workspace; y6_nms called with candidates_ready = 1 and the SAME
+ * conf_thres / classes / multi_label then starts at the sort and never reads the [B, A, 5 + nc] tensor for the selection
+ * (91 MB for YOLOv6-S 640^2 b32).  The tensor itself is still written: it is Detect.forward's result.                        */
+typedef struct y6_nms_sink {
+    void* workspace;           /* NULL: no sink */
+    size_t workspace_bytes;
+    float conf_thres;
+    const int32_t* classes;    /* optional device list of kept classes */
+    int32_t n_classes;
+    int32_t multi_label;
+} y6_nms_sink;
+
 typedef struct y6_pred_decode_desc {
     int32_t n_levels;
     y6_tensor cls_feat[Y6_MAX_LEVELS];
@@ -270,6 +284,7 @@ typedef struct y6_pred_decode_desc {
     int32_t first_anchor;      /* with total_anchors > 0: row (inside an image) of `out` where this call's first level starts, */
     int32_t total_anchors;     /* and the rows per image of `out` - a call may then cover a SUBSET of the head's levels (one call per
                                   level lets a level be decoded as soon as its convs are done).  0 / 0: the call covers `out`. */
+    y6_nms_sink cand;          /* optional (workspace NULL: off); needs first_anchor / total_anchors = 0 / 0 */
 } y6_pred_decode_desc;
 int y6_head_pred_decode_supported(const y6_pred_decode_desc* d);   /* 1 if the fused kernel takes this shape */
 int y6_head_pred_decode(const y6_pred_decode_desc* d, void* stream);
@@ -301,6 +316,8 @@ typedef struct y6_nms_desc {
     int32_t* out_count;
     void* workspace;
     size_t workspace_bytes;
+    int32_t candidates_ready;  /* 1: the workspace already holds this call's candidates (y6_nms_sink of the decode launch that
+                                  produced `pred`, same conf_thres / classes / multi_label): start at the sort */
 } y6_nms_desc;
 size_t y6_nms_workspace_bytes(int B, int A, int nc, int multi_label);
 int y6_nms(const y6_nms_desc* d, void* stream);
@@ -730,6 +747,10 @@ int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);
 int y6_plan_add_pw_s2(y6_plan* p, const y6_pw_s2_desc* d);       /* generic op, tag Y6_TOP_PW_S2 */
 int y6_plan_add_stem_s2(y6_plan* p, const y6_stem_s2_desc* d);   /* generic op, tag Y6_TOP_STEM_S2; its image pointer is a rebindable input */
 int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d);   /* generic op, tag Y6_TOP_PRED_DECODE; its `out` is rebindable */
+/* Attach (sink->workspace set) or detach (NULL workspace) the candidate sink of the plan's fused head-tail op(s).  Returns the
+ * number of ops changed (0: the plan has no such op, or the op cannot serve this sink - the caller keeps y6_nms's own first
+ * stage), negative on error. */
+int y6_plan_set_nms_sink(y6_plan* p, const y6_nms_sink* sink);
 int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
 int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);
 int y6_plan_num_ops(const y6_plan* p);

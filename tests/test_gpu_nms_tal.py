@@ -63,6 +63,13 @@ def test_nms_edge_cases():
     # (d) more than 16384 candidates (global-memory sort path) and more than max_nms
     t = synth.synth_predictions(2, 8400, 80, seed=5, frac=0.05)
     _check_vs_oracle(t, conf_thres=0.03, iou_thres=0.65, multi_label=True, max_det=300)
+    # (f) objectness above 1 (not a sigmoid's): cls <= conf < cls * obj is then possible, and the row flag of nms.py:48 (max cls > conf)
+    #     is no longer implied by the candidate - the selection's fast form must hand such blocks to the general one
+    u = synth.synth_predictions(3, 700, 12, seed=6, frac=0.2)
+    u[..., 4] = u[..., 4] * 1.8
+    u[..., 5:] = u[..., 5:] * 0.7
+    _check_vs_oracle(u, conf_thres=0.2, iou_thres=0.5, multi_label=True, max_det=300)
+    _check_vs_oracle(u, conf_thres=0.2, iou_thres=0.5, multi_label=False, max_det=300)
     # (e) threshold asserts are the reference's (nms.py:50-51)
     with pytest.raises(AssertionError):
         non_max_suppression(s.to(DEV), conf_thres=1.5)

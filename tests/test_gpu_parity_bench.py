@@ -122,3 +122,39 @@ def test_bench_step_nms_equals_oracle_nms():
     dets, index, count = nms_raw(det, bench.CONF, bench.IOU, multi_label=True, max_det=bench.MAX_DET)
     torch.cuda.synchronize()
     bench.verify_nms(det, dets, index, count, images=range(0, 32, 4))
+
+
+def test_decode_launch_candidates_equal_nms_first_stage():
+    """Plan.attach_nms (include/yolov6_hip.h y6_nms_sink): the fused head tail selects the NMS candidates of its rows while they
+    are in LDS.  The detections, flat indices and counts must equal - bit for bit - those of y6_nms selecting them itself from
+    the prediction tensor, for multi-label / best-class / a class filter, on repeated runs (the per-image key lists are re-zeroed
+    by every decode launch), and the full-size case must equal the oracle."""
+    from yolov6_amd.utils.nms import nms_raw
+    import bench
+    cfg, sd, model, x = _bench_setup("yolov6s", 640, 32)
+    plan = model.compile(x, autotune=False)
+    for kw in (dict(conf_thres=bench.CONF, multi_label=True, classes=None), dict(conf_thres=0.25, multi_label=False, classes=None),
+               dict(conf_thres=0.1, multi_label=True, classes=[0, 3, 17, 79])):
+        plan.attach_nms(None)
+        det = plan.run()
+        ref = nms_raw(det, kw["conf_thres"], bench.IOU, classes=kw["classes"], multi_label=kw["multi_label"], max_det=bench.MAX_DET)
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in ref]
+        tok = plan.attach_nms(kw["conf_thres"], kw["classes"], kw["multi_label"])
+        assert tok is not None, "the YOLOv6-S plan has a fused head tail: the sink must attach"
+        for rep in range(3):
+            det2 = plan.run()
+            got = nms_raw(det2, kw["conf_thres"], bench.IOU, classes=kw["classes"], multi_label=kw["multi_label"], max_det=bench.MAX_DET,
+                          candidates=tok)
+            torch.cuda.synchronize()
+            assert torch.equal(det2, det)
+            for a, b, nm in zip(got, ref, ("dets", "index", "count")):
+                assert torch.equal(a, b), f"{nm} differ with candidates from the decode launch ({kw}, run {rep})"
+        assert int(ref[2].sum()) > 0 or kw["classes"] is not None or not kw["multi_label"]
+        with pytest.raises(RuntimeError):   # other thresholds than the sink's: refused, not silently wrong
+            nms_raw(det2, kw["conf_thres"] + 0.01, bench.IOU, classes=kw["classes"], multi_label=kw["multi_label"], candidates=tok)
+    tok = plan.attach_nms(bench.CONF, None, True)
+    det = plan.run()
+    dets, index, count = nms_raw(det, bench.CONF, bench.IOU, multi_label=True, max_det=bench.MAX_DET, candidates=tok)
+    torch.cuda.synchronize()
+    bench.verify_nms(det, dets, index, count, images=(0, 13, 31))

@@ -64,13 +64,18 @@ class StemS2Desc(C.Structure):
     _fields_ = [("stem", StemDesc), ("s2", ConvDesc)]
 
 
+class NmsSink(C.Structure):
+    _fields_ = [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("conf_thres", C.c_float),
+                ("classes", C.c_void_p), ("n_classes", C.c_int32), ("multi_label", C.c_int32)]
+
+
 class PredDecodeDesc(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("cls_feat", Tensor * MAX_LEVELS), ("reg_feat", Tensor * MAX_LEVELS),
                 ("w_cls", C.c_void_p * MAX_LEVELS), ("w_reg", C.c_void_p * MAX_LEVELS),
                 ("b_cls", C.c_void_p * MAX_LEVELS), ("b_reg", C.c_void_p * MAX_LEVELS),
                 ("stride", C.c_float * MAX_LEVELS), ("use_dfl", C.c_int32), ("reg_max", C.c_int32),
                 ("proj", C.c_void_p), ("grid_cell_offset", C.c_float), ("out", C.c_void_p), ("nc", C.c_int32),
-                ("first_anchor", C.c_int32), ("total_anchors", C.c_int32)]
+                ("first_anchor", C.c_int32), ("total_anchors", C.c_int32), ("cand", NmsSink)]
 
 
 class NmsDesc(C.Structure):
@@ -79,7 +84,7 @@ class NmsDesc(C.Structure):
                 ("n_classes", C.c_int32), ("agnostic", C.c_int32), ("multi_label", C.c_int32),
                 ("max_det", C.c_int32), ("max_nms", C.c_int32), ("max_wh", C.c_float), ("out_dets", C.c_void_p),
                 ("out_index", C.c_void_p), ("out_count", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("workspace_bytes", C.c_size_t), ("candidates_ready", C.c_int32)]
 
 
 class TalDesc(C.Structure):
@@ -194,7 +199,7 @@ IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 STRUCTS = {
     "y6_tensor": Tensor, "y6_conv_desc": ConvDesc, "y6_conv_i8_desc": ConvI8Desc, "y6_convt_desc": ConvTDesc, "y6_stem_desc": StemDesc,
     "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
-    "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
+    "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
     "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc,
     "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_head_pack_desc": HeadPackDesc,
@@ -303,6 +308,7 @@ SIGNATURES = {
     "y6_plan_add_sppf": (C.c_int, [C.c_void_p] + [C.POINTER(Tensor)] * 4),
     "y6_plan_add_decode": (C.c_int, [C.c_void_p, C.POINTER(DecodeDesc)]),
     "y6_plan_add_pred_decode": (C.c_int, [C.c_void_p, C.POINTER(PredDecodeDesc)]),
+    "y6_plan_set_nms_sink": (C.c_int, [C.c_void_p, C.POINTER(NmsSink)]),
     "y6_plan_add_pw_s2": (C.c_int, [C.c_void_p, C.POINTER(PwS2Desc)]),
     "y6_plan_add_stem_s2": (C.c_int, [C.c_void_p, C.POINTER(StemS2Desc)]),
     "y6_plan_add_nchw2nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Tensor)]),

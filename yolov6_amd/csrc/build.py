@@ -39,7 +39,7 @@ SOURCES = {
     "quant.hip": [],
     "plan.hip": [],
 }
-HEADERS = ["common.hpp", "conv_common.hpp", "plan_internal.hpp", "stem_piece.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
+HEADERS = ["common.hpp", "conv_common.hpp", "plan_internal.hpp", "stem_piece.hpp", "nms_cand.hpp", os.path.join(ROOT, "include", "yolov6_hip.h")]
 
 
 def hipcc():

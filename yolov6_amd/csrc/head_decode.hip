@@ -9,6 +9,7 @@
 #include <cstddef>
 
 #include "common.hpp"
+#include "nms_cand.hpp"
 #include "plan_internal.hpp"
 
 namespace {
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void head_decode_tiled_kernel(const DecodeArgs
 // The k-step order of the accumulation is the unfused kernels' (one chain, ascending input channel), so the result is
 // bit-identical to conv -> conv -> decode.
 constexpr int PD_TA = 64;
+static_assert(PD_TA <= y6cand::kCandRows, "one lane of a wave per row in y6cand::emit_candidates");
 
 struct PredDecodeArgs {
     int n_levels;
@@ -191,6 +193,13 @@ struct PredDecodeArgs {
     float* out;
     int B, A, nc;
     int ncf_c, ncf_r;                      // cout fragments (32 channels) of cls_pred / reg_pred
+    // candidate sink (y6_nms_sink): key lists [B][cand_cap] and their lengths, or cand_keys == nullptr
+    unsigned long long* cand_keys;
+    size_t cand_cap;
+    int* cand_counts;
+    float cand_conf;
+    const int* cand_classes;
+    int cand_nclasses, cand_ml;
 };
 
 __device__ __forceinline__ float side_dist_lds(const PredDecodeArgs& a, const float* r, int side) {
@@ -207,7 +216,8 @@ __device__ __forceinline__ float side_dist_lds(const PredDecodeArgs& a, const fl
 }
 
 __global__ __launch_bounds__(256) void head_pred_decode_kernel(const PredDecodeArgs a, int blocks_per_image) {
-    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [PD_TA][no] output rows, then [PD_TA][nreg] reg values
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [PD_TA][no] output rows, then [PD_TA][nreg] reg values, then PD_TA row flags
+    __shared__ int s_cnt, s_base, s_gen;
     const int no = a.nc + 5;
     float* s_reg = s_rows + PD_TA * no;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -294,6 +304,21 @@ __global__ __launch_bounds__(256) void head_pred_decode_kernel(const PredDecodeA
         r[4] = 1.f;
     }
     __syncthreads();
+    // The NMS candidates of these rows, while they are here (nms_cand.hpp: y6_nms's own first stage).  The selection is LDS work
+    // and runs BEFORE the row stores; one thread reserves the block's slice of the image's key list, the row stores leave behind
+    // that atomic, and its result is only awaited where the keys are written (a wave's memory results return in order: anything
+    // that waits behind the 21 KB of row stores of a block pays their acknowledgement, r04q).
+    const bool sink = a.cand_keys != nullptr;
+    const y6cand::lds_f32* lrows = (const y6cand::lds_f32*)s_rows;
+    y6cand::CandSel2 cs;
+    cs.fast = 0;
+    int cand_total = 0, cand_base = 0;
+    if (sink) {
+        cs = y6cand::cand_select(lrows, (y6cand::lds_i32*)reinterpret_cast<int*>(s_reg + PD_TA * a.nreg), na, no, a.nc, a.cand_conf, a.cand_classes,
+                                 a.cand_nclasses, a.cand_ml, (y6cand::lds_i32*)&s_cnt, (y6cand::lds_i32*)&s_gen);
+        cand_total = *(y6cand::lds_i32*)&s_cnt;
+        if (tid == 0 && cand_total > 0) cand_base = atomicAdd(a.cand_counts + b * y6cand::kCountStride, cand_total);
+    }
     const size_t obase = ((size_t)b * a.A + a.astart[l] + a0) * no;
     const int nfl = na * no;
     if ((obase & 3) == 0) {
@@ -303,6 +328,11 @@ __global__ __launch_bounds__(256) void head_pred_decode_kernel(const PredDecodeA
         for (int i = (nv << 2) + tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
     } else {
         for (int i = tid; i < nfl; i += 256) a.out[obase + i] = s_rows[i];
+    }
+    if (sink && cand_total > 0) {
+        if (tid == 0) *(y6cand::lds_i32*)&s_base = cand_base;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // LDS only: nobody waits for row stores here
+        y6cand::cand_publish(lrows, na, no, a.nc, a.astart[l] + a0, a.cand_ml, cs, a.cand_keys + (size_t)b * a.cand_cap + *(y6cand::lds_i32*)&s_base);
     }
 }
 
@@ -371,7 +401,7 @@ extern "C" int y6_head_decode(const y6_decode_desc* d, void* stream) {
 extern "C" int y6_head_pred_decode_supported(const y6_pred_decode_desc* d) {
     if (!d || d->n_levels < 1 || d->n_levels > Y6_MAX_LEVELS || !d->out) return 0;
     const int nreg = 4 * (d->use_dfl ? d->reg_max + 1 : 1);
-    const size_t lds = (size_t)PD_TA * (d->nc + 5 + nreg) * sizeof(float);
+    const size_t lds = (size_t)PD_TA * (d->nc + 5 + nreg) * sizeof(float) + PD_TA * sizeof(int);
     if (lds > 64 * 1024) return 0;
     for (int l = 0; l < d->n_levels; ++l) {
         const y6_tensor &c = d->cls_feat[l], &r = d->reg_feat[l];
@@ -384,6 +414,14 @@ extern "C" int y6_head_pred_decode_supported(const y6_pred_decode_desc* d) {
         long A = 0;
         for (int l = 0; l < d->n_levels; ++l) A += (long)d->cls_feat[l].H * d->cls_feat[l].W;
         if (d->first_anchor < 0 || d->total_anchors <= 0 || d->first_anchor + A > d->total_anchors) return 0;
+    }
+    if (d->cand.workspace != nullptr) {   // candidate sink: the whole tensor in one call, the rows of a block within the selection's task budget
+        if (d->total_anchors != 0 || d->first_anchor != 0) return 0;
+        if ((long)PD_TA * d->nc > 64 * 256) return 0;   // y6cand::emit_candidates: a 64-bit pass mask per thread
+        long A = 0;
+        for (int l = 0; l < d->n_levels; ++l) A += (long)d->cls_feat[l].H * d->cls_feat[l].W;
+        if (d->cand.workspace_bytes < y6_nms_workspace_bytes(d->cls_feat[0].B, (int)A, d->nc, d->cand.multi_label)) return 0;
+        if ((size_t)A * d->nc >= 0xFFFFFFFFull) return 0;
     }
     return ((uintptr_t)d->out & 15) == 0;
 }
@@ -430,7 +468,17 @@ static int pred_decode_launch(const y6_pred_decode_desc* d, hipStream_t stream) 
     a.nc = d->nc;
     a.ncf_c = (d->nc + 31) / 32;
     a.ncf_r = (a.nreg + 31) / 32;
-    const size_t lds = (size_t)PD_TA * (d->nc + 5 + a.nreg) * sizeof(float);
+    if (d->cand.workspace != nullptr) {
+        int rc = y6_nms_workspace_views(d->cand.workspace, d->cand.workspace_bytes, a.B, a.A, a.nc, d->cand.multi_label, &a.cand_keys, &a.cand_cap,
+                                        &a.cand_counts);
+        if (rc) return rc;
+        a.cand_conf = d->cand.conf_thres;
+        a.cand_classes = d->cand.classes;
+        a.cand_nclasses = d->cand.n_classes;
+        a.cand_ml = d->cand.multi_label && d->nc > 1;
+        Y6_HIP(hipMemsetAsync(a.cand_counts, 0, (size_t)a.B * y6cand::kCountStride * sizeof(int), stream));
+    }
+    const size_t lds = (size_t)PD_TA * (d->nc + 5 + a.nreg) * sizeof(float) + PD_TA * sizeof(int);
     hipLaunchKernelGGL(head_pred_decode_kernel, dim3((unsigned)(a.B * nb)), dim3(256), lds, stream, a, nb);
     Y6_LAUNCH_CHECK();
     return Y6_OK;

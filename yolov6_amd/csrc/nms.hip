@@ -20,17 +20,11 @@
 //   matrix (= the sequential greedy order), until max_det (:97-98) boxes are kept.
 // Compile with -ffp-contract=off: index parity needs the reference's unfused fp32 arithmetic.
 #include "common.hpp"
+#include "nms_cand.hpp"
 
 namespace {
 
 typedef unsigned long long u64;
-
-__device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classes) {
-    if (!classes) return true;
-    for (int k = 0; k < n_classes; ++k)
-        if (classes[k] == j) return true;
-    return false;
-}
 
 // One block = `rpb` consecutive anchor rows of ONE image (blockIdx interleaves images so that
 // concurrently running blocks append to different per-image counters).  The rows are one contiguous run
@@ -41,8 +35,9 @@ __device__ __forceinline__ bool class_ok(int j, const int* classes, int n_classe
 // image's key list and the keys go straight to it.  LDS holds only the rows (22 KiB for 80 classes), so
 // seven blocks per CU keep ~150 KiB of loads in flight.
 // History: v1 one global atomic per row (same-address atomics serialise at ~12 ns: 4.3 ms per call);
-// v2 wave per row with shuffles and a 40 KiB LDS key stage (0.17 ms); this version 0.04 ms.
-constexpr int kCandTasks = 4;   // (row, 8-class) tasks per thread
+// v2 wave per row with shuffles and a 40 KiB LDS key stage (0.17 ms); v3 a thread per (row, 8 classes) 0.05 ms - LDS reads
+// with a stride of eight words, 8-way bank conflicts; v4 (nms_cand.hpp, shared with the decode launch): a thread per class score in
+// (row, class) order - conflict-free.
 
 __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __restrict__ pred, int B, int A, int nc,
                                                              float conf_thres, const int* __restrict__ classes,
@@ -50,7 +45,7 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
                                                              u64* __restrict__ keys, size_t cap,
                                                              int* __restrict__ counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_cnt, s_base;
+    __shared__ int s_cnt, s_base, s_gen;
     const int tid = threadIdx.x;
     const int b = blockIdx.x % B, chunk = blockIdx.x / B;
     const int no = nc + 5;
@@ -70,97 +65,15 @@ __global__ __launch_bounds__(256) void nms_candidates_kernel(const float* __rest
             for (int i = tid; i < nfl; i += 256) rows[i] = src[i];
         }
     }
-    if (tid == 0) s_cnt = 0;
-    for (int r = tid; r < nrows; r += 256) rowflag[r] = 0;
     __syncthreads();
-    const int npc = (nc + 7) >> 3;
-    const int ntask = nrows * npc;   // <= 256 * kCandTasks by the launcher's choice of rpb
-#pragma unroll
-    for (int m = 0; m < kCandTasks; ++m) {
-        const int idx = tid + m * 256;
-        if (idx >= ntask) break;
-        const int r = idx / npc, j0 = (idx - r * npc) << 3;
-        const float* row = rows + r * no;
-        if (!(row[4] > conf_thres)) continue;
-        bool any = false;
-        for (int j = j0; j < j0 + 8 && j < nc; ++j) any = any || (row[5 + j] > conf_thres);
-        if (any) rowflag[r] = 1;   // benign race: every writer stores 1
-    }
-    __syncthreads();
-    unsigned passm[kCandTasks];
-    int off[kCandTasks];
-    if (multi_label) {
-#pragma unroll
-        for (int m = 0; m < kCandTasks; ++m) {
-            passm[m] = 0u;
-            off[m] = 0;
-            const int idx = tid + m * 256;
-            if (idx >= ntask) continue;
-            const int r = idx / npc, j0 = (idx - r * npc) << 3;
-            if (!rowflag[r]) continue;
-            const float* row = rows + r * no;
-            const float obj = row[4];
-            unsigned pm = 0u;
-            for (int j = j0; j < j0 + 8 && j < nc; ++j)
-                if ((row[5 + j] * obj > conf_thres) && class_ok(j, classes, n_classes)) pm |= 1u << (j - j0);
-            passm[m] = pm;
-            if (pm) off[m] = atomicAdd(&s_cnt, __popc(pm));
-        }
-    } else {
-        // best class per row: max conf, first (lowest) class index on ties (torch.max semantics, nms.py:79);
-        // task slot 0 of thread r carries row r (rpb <= 256); passm holds class+1
-#pragma unroll
-        for (int m = 0; m < kCandTasks; ++m) {
-            passm[m] = 0u;
-            off[m] = 0;
-        }
-        if (tid < nrows && rowflag[tid]) {
-            const float* row = rows + tid * no;
-            const float obj = row[4];
-            float bc = -INFINITY;
-            int bj = 0;
-            for (int j = 0; j < nc; ++j) {
-                const float c = row[5 + j] * obj;
-                if (c > bc) {
-                    bc = c;
-                    bj = j;
-                }
-            }
-            if (bc > conf_thres && class_ok(bj, classes, n_classes)) {
-                passm[0] = (unsigned)bj + 1u;
-                off[0] = atomicAdd(&s_cnt, 1);
-            }
-        }
-    }
-    __syncthreads();
+    const y6cand::lds_f32* lrows = (const y6cand::lds_f32*)rows;
+    const y6cand::CandSel2 cs = y6cand::cand_select(lrows, (y6cand::lds_i32*)rowflag, nrows, no, nc, conf_thres, classes, n_classes, multi_label,
+                                                    (y6cand::lds_i32*)&s_cnt, (y6cand::lds_i32*)&s_gen);
     const int total = s_cnt;
     if (total == 0) return;
-    if (tid == 0) s_base = atomicAdd(&counts[b], total);
+    if (tid == 0) s_base = atomicAdd(&counts[b * y6cand::kCountStride], total);
     __syncthreads();
-    u64* kb = keys + (size_t)b * cap + s_base;
-    if (multi_label) {
-#pragma unroll
-        for (int m = 0; m < kCandTasks; ++m) {
-            unsigned pm = passm[m];
-            if (!pm) continue;
-            const int idx = tid + m * 256;
-            const int r = idx / npc, j0 = (idx - r * npc) << 3;
-            const float* row = rows + r * no;
-            const float obj = row[4];
-            int pos = off[m];
-            while (pm) {
-                const int j = j0 + __ffs((int)pm) - 1;
-                pm &= pm - 1u;
-                const unsigned flat = (unsigned)(a0 + r) * (unsigned)nc + (unsigned)j;
-                kb[pos++] = ((u64)__float_as_uint(row[5 + j] * obj) << 32) | (u64)(0xFFFFFFFFu - flat);
-            }
-        }
-    } else if (passm[0]) {
-        const int bj = (int)passm[0] - 1;
-        const float* row = rows + tid * no;
-        const unsigned flat = (unsigned)(a0 + tid) * (unsigned)nc + (unsigned)bj;
-        kb[off[0]] = ((u64)__float_as_uint(row[5 + bj] * row[4]) << 32) | (u64)(0xFFFFFFFFu - flat);
-    }
+    y6cand::cand_publish(lrows, nrows, no, nc, a0, multi_label, cs, keys + (size_t)b * cap + s_base);
 }
 
 // descending bitonic sort of P (power of two) keys held in LDS by the whole block.
@@ -274,22 +187,68 @@ __device__ __forceinline__ bool nms_suppresses(const float4 bi, const float4 bj,
 //                           (the cap of nms.py:90-91).
 constexpr int kChunk = 2048;
 
+// v2 (r04r): the chunk lives in REGISTERS - thread t holds keys 8 t .. 8 t + 7.  Of the 66 compare-exchange steps of a 2048-key
+// bitonic network 30 have distance < 8 (inside a thread), 33 have distance 8 .. 256 (a lane xor of 1 .. 32: wave shuffles) and only
+// 3 cross waves (through LDS).  The first version kept the keys in LDS and paid two dependent LDS round trips plus a wait for every
+// one of the 4 exchanges a lane made per step: 50 us per launch, one block per CU with nothing to hide behind.
+__device__ __forceinline__ void cmpx(u64& a, u64& b, bool desc) {   // a at the lower position: descending puts the larger there
+    const bool sw = desc ? (a < b) : (a > b);
+    const u64 t = a;
+    a = sw ? b : a;
+    b = sw ? t : b;
+}
+
 __global__ __launch_bounds__(256) void nms_chunk_sort_kernel(u64* __restrict__ keys, size_t cap,
                                                              const int* __restrict__ counts, int chunks_per_image) {
     __shared__ __attribute__((aligned(16))) u64 lk[kChunk];
+    static_assert(kChunk == 2048, "8 keys per thread, 256 threads");
+    const int tid = threadIdx.x;
     // the grid holds `chunks_per_image` blocks per image (a few); a block walks the image's chunks with that stride
     const int b = blockIdx.x / chunks_per_image;
-    const int n = counts[b];
+    const int n = counts[b * y6cand::kCountStride];
     for (int c = blockIdx.x - b * chunks_per_image; c * kChunk < n; c += chunks_per_image) {
         const int c0 = c * kChunk;
         u64* gk = keys + (size_t)b * cap + c0;
         const int m = min(kChunk, n - c0);
-        int P = 128;
-        while (P < m) P <<= 1;
-        for (int i = threadIdx.x; i < P; i += 256) lk[i] = i < m ? gk[i] : 0ull;   // real keys are never 0
-        __syncthreads();
-        bitonic_desc_lds(lk, P);
-        for (int i = threadIdx.x; i < m; i += 256) gk[i] = lk[i];
+        u64 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = (tid * 8 + r < m) ? gk[tid * 8 + r] : 0ull;   // real keys are never 0: the padding sorts last
+#pragma unroll
+        for (int k = 2; k <= kChunk; k <<= 1) {
+            // direction of this thread's keys in the merges of size k: for k < 8 it depends on the register index
+            const bool desc_t = ((tid * 8) & k) == 0;
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j < 8) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        if ((r & j) == 0) cmpx(v[r], v[r | j], k < 8 ? ((r & k) == 0) : desc_t);
+                } else {
+                    const bool lower = ((tid * 8) & j) == 0;
+                    const bool take_max = lower == desc_t;
+                    if (j < 512) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const u64 o = __shfl_xor(v[r], j >> 3, 64);
+                            v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                        }
+                    } else {
+                        __syncthreads();   // (the previous cross-wave step's reads)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) lk[tid * 8 + r] = v[r];
+                        __syncthreads();
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const u64 o = lk[((tid * 8) ^ j) + r];
+                            v[r] = take_max ? (o > v[r] ? o : v[r]) : (o < v[r] ? o : v[r]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (tid * 8 + r < m) gk[tid * 8 + r] = v[r];
         __syncthreads();
     }
 }
@@ -303,7 +262,7 @@ __global__ __launch_bounds__(256) void nms_merge_rank_kernel(const u64* __restri
     __shared__ __attribute__((aligned(16))) u64 run[2][kChunk];
     constexpr int KPT = kChunk / 256;   // keys per thread
     const int b = blockIdx.x / chunks_per_image;
-    const int n = counts[b];
+    const int n = counts[b * y6cand::kCountStride];
     const int tid = threadIdx.x;
     const u64* gk = keys + (size_t)b * cap;
     const int nchunks = (n + kChunk - 1) / kChunk;
@@ -406,7 +365,7 @@ __global__ __launch_bounds__(1024) void nms_sweep_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int T = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
-    int n = counts[b];
+    int n = counts[b * y6cand::kCountStride];
     // the outputs need no pre-fill by the caller: rows past the kept count are written here (zeros / -1)
     auto pad_outputs = [&](int from) {
         for (int i = from * 6 + tid; i < max_det * 6; i += T) out_dets[(size_t)b * max_det * 6 + i] = 0.f;
@@ -705,11 +664,20 @@ NmsWs nms_ws_layout(int B, int A, int nc, int multi_label, int max_nms) {
     w.off_keys = 0;
     w.off_boxes = align256(w.off_keys + (size_t)B * w.cap * sizeof(u64));
     w.off_counts = align256(w.off_boxes + (size_t)B * max_nms * sizeof(float4));
-    w.total = align256(w.off_counts + (size_t)B * sizeof(int));
+    w.total = align256(w.off_counts + (size_t)B * y6cand::kCountStride * sizeof(int));
     return w;
 }
 
 }  // namespace
+
+int y6_nms_workspace_views(void* workspace, size_t bytes, int B, int A, int nc, int multi_label, unsigned long long** keys, size_t* cap, int** counts) {
+    const NmsWs w = nms_ws_layout(B, A, nc, multi_label && nc > 1, 30000);
+    Y6_REQUIRE(workspace && bytes >= w.total, "nms workspace too small (%zu < %zu)", bytes, w.total);
+    *keys = (u64*)((char*)workspace + w.off_keys);
+    *cap = w.cap;
+    *counts = (int*)((char*)workspace + w.off_counts);
+    return Y6_OK;
+}
 
 extern "C" size_t y6_nms_workspace_bytes(int B, int A, int nc, int multi_label) {
     return nms_ws_layout(B, A, nc, multi_label, 30000).total;
@@ -735,18 +703,20 @@ extern "C" int y6_nms(const y6_nms_desc* d, void* stream) {
     int* counts = (int*)(ws + w.off_counts);
     static const int stop0 = getenv("Y6_NMS_STOP_AFTER") ? atoi(getenv("Y6_NMS_STOP_AFTER")) : 99;
     if (stop0 < 1) return Y6_OK;   // host-side cost of a call only
-    Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * sizeof(int), s));
-    // rows per block: up to 64, bounded by kCandTasks (row, 8-class) tasks per thread
-    const int npc = (d->nc + 7) / 8;
-    int rpb = (256 * kCandTasks) / npc;
-    rpb = rpb > 64 ? 64 : (rpb < 1 ? 1 : rpb);
-    Y6_REQUIRE(npc <= 256 * kCandTasks, "nms: %d classes exceed the candidate kernel's task budget", d->nc);
+    if (!d->candidates_ready) {
+    Y6_HIP(hipMemsetAsync(counts, 0, (size_t)d->B * y6cand::kCountStride * sizeof(int), s));
+    // rows per block: up to 64 (y6cand::kCandRows), bounded by the 64 KiB row image
+    int rpb = (int)((64 * 1024) / ((size_t)(d->nc + 5) * sizeof(float) + sizeof(int)));
+    rpb = rpb > y6cand::kCandRows ? y6cand::kCandRows : rpb;
+    if ((long)rpb * d->nc > 64 * 256) rpb = (64 * 256) / d->nc;   // a 64-bit pass mask per thread
+    Y6_REQUIRE(rpb >= 1, "nms: %d classes do not fit the LDS row image", d->nc);
     const size_t stage_bytes = (size_t)rpb * (d->nc + 5) * sizeof(float) + (size_t)rpb * sizeof(int);   // row image + row flags
     Y6_REQUIRE(stage_bytes <= 64 * 1024, "nms: %d classes do not fit the LDS row image", d->nc);
     const unsigned blocks = (unsigned)d->B * (unsigned)((d->A + rpb - 1) / rpb);
     hipLaunchKernelGGL(nms_candidates_kernel, dim3(blocks), dim3(256), stage_bytes, s, d->pred, d->B, d->A, d->nc,
                        d->conf_thres, d->classes, d->n_classes, ml, rpb, keys, w.cap, counts);
     Y6_LAUNCH_CHECK();
+    }
     static const int stop_after = getenv("Y6_NMS_STOP_AFTER") ? atoi(getenv("Y6_NMS_STOP_AFTER")) : 99;   // stage timing (tools/nms_bench.py)
     if (stop_after < 2) return Y6_OK;
     // sort: chunks, then rank-merge into the (otherwise unused) box area of the workspace

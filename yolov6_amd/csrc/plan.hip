@@ -37,6 +37,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
         {"y6_letterbox_desc", sizeof(y6_letterbox_desc)},
         {"y6_decode_desc", sizeof(y6_decode_desc)},
         {"y6_pred_decode_desc", sizeof(y6_pred_decode_desc)},
+        {"y6_nms_sink", sizeof(y6_nms_sink)},
         {"y6_nms_desc", sizeof(y6_nms_desc)},
         {"y6_tal_desc", sizeof(y6_tal_desc)},
         {"y6_atss_desc", sizeof(y6_atss_desc)},
@@ -510,6 +511,22 @@ int y6_plan_mark_output(y6_plan* p, size_t offset) {
                "plan_mark_output: no generic op to mark");
     p->ops.back().gout_off = (int)offset;
     return Y6_OK;
+}
+
+extern "C" int y6_plan_set_nms_sink(y6_plan* p, const y6_nms_sink* sink) {
+    Y6_REQUIRE(p && sink, "plan_set_nms_sink: null argument");
+    int changed = 0;
+    for (Op& op : p->ops) {
+        if (op.kind != Y6_OP_GENERIC || op.gtag != Y6_TOP_PRED_DECODE) continue;
+        y6_pred_decode_desc d;
+        memcpy(&d, op.blob, sizeof(d));
+        d.cand = *sink;
+        if (sink->workspace != nullptr && !y6_head_pred_decode_supported(&d)) continue;   // this op keeps running without a sink
+        memcpy(op.blob, &d, sizeof(d));
+        ++changed;
+    }
+    if (changed) drop_graph(p);
+    return changed;
 }
 
 int y6_plan_mark_input(y6_plan* p, size_t offset) {

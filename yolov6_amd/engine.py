@@ -110,6 +110,43 @@ class Plan:
         _lib.check(self._lib.y6_plan_run(self._h, _lib.current_stream_ptr()), "plan_run")
         return self.outputs
 
+    def attach_nms(self, conf_thres=0.25, classes=None, multi_label=False):
+        """Let the plan's fused head tail select the NMS candidates of its rows while they sit in LDS (include/yolov6_hip.h
+        y6_nms_sink: the arithmetic of y6_nms's own first stage, reference yolov6/utils/nms.py:48, :69-84).  Returns a
+        token to pass to utils.nms.nms_raw(..., candidates=token) with the SAME conf_thres / classes / multi_label - that call
+        then starts at the sort and does not re-read the prediction tensor for the selection - or None when the plan has no
+        fused head tail that can serve it (the caller just keeps calling nms_raw without the token).  attach_nms(None)
+        detaches."""
+        sink = _lib.NmsSink()
+        if conf_thres is None:
+            n = self._lib.y6_plan_set_nms_sink(self._h, C.byref(sink))
+            self._nms_token = None
+            return None
+        out = self.outputs[0] if isinstance(self.outputs, (tuple, list)) else self.outputs
+        if not isinstance(out, torch.Tensor) or out.dim() != 3:
+            return None
+        B, A, no = out.shape
+        nc = no - 5
+        ml = bool(multi_label) and nc > 1
+        nbytes = self._lib.y6_nms_workspace_bytes(B, A, nc, int(ml))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
+        cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=out.device) if classes is not None else None
+        sink.workspace, sink.workspace_bytes = C.c_void_p(ws.data_ptr()), nbytes
+        sink.conf_thres = float(conf_thres)
+        sink.classes = C.c_void_p(cls_t.data_ptr()) if cls_t is not None else None
+        sink.n_classes = int(cls_t.numel()) if cls_t is not None else 0
+        sink.multi_label = int(ml)
+        n = self._lib.y6_plan_set_nms_sink(self._h, C.byref(sink))
+        if n < 0:
+            _lib.check(n, "plan_set_nms_sink")
+        if n == 0:
+            self._nms_token = None
+            return None
+        self.captured = False
+        self._nms_token = dict(workspace=ws, classes_t=cls_t, conf_thres=float(conf_thres), multi_label=ml,
+                               classes=None if classes is None else tuple(int(c) for c in classes), shape=(B, A, no), plan=self)
+        return self._nms_token
+
     def run_range(self, first: int, last: int):
         """Eager launch of ops [first, last) only (per-layer parity tests)."""
         _lib.check(self._lib.y6_plan_run_range(self._h, _lib.current_stream_ptr(), first, last), "plan_run_range")

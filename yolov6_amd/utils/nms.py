@@ -23,9 +23,12 @@ def _workspace(device, nbytes):
     return ws
 
 
-def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300,
+            candidates=None):
     """Device-side result without host synchronisation:
-    (dets [B,max_det,6] f32, index [B,max_det] i32 (anchor*nc+cls), count [B] i32)."""
+    (dets [B,max_det,6] f32, index [B,max_det] i32 (anchor*nc+cls), count [B] i32).
+    candidates: the token of engine.Plan.attach_nms() when `prediction` is that plan's output of its LAST run on this stream -
+    the candidates were selected by the decode launch, with the same thresholds (checked here)."""
     lib = _lib.load()
     _lib.require_gpu_tensor(prediction, "prediction")
     # the reference asserts the thresholds (nms.py:50-51)
@@ -44,10 +47,17 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     index = torch.empty((B, max_det), dtype=torch.int32, device=dev)
     count = torch.empty((B,), dtype=torch.int32, device=dev)
     nbytes = lib.y6_nms_workspace_bytes(B, A, nc, int(ml))
-    ws = _workspace(dev, nbytes)
     cls_t = None
-    if classes is not None:
-        cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
+    if candidates is not None:
+        want = (float(conf_thres), ml, None if classes is None else tuple(int(c) for c in classes), (B, A, no))
+        have = (candidates["conf_thres"], candidates["multi_label"], candidates["classes"], candidates["shape"])
+        if want != have:
+            raise RuntimeError(f"yolov6_amd: nms_raw(candidates=...) with other thresholds / shape than attach_nms(): {want} vs {have}")
+        ws, cls_t = candidates["workspace"], candidates["classes_t"]
+    else:
+        ws = _workspace(dev, nbytes)
+        if classes is not None:
+            cls_t = torch.as_tensor(list(classes), dtype=torch.int32, device=dev)
     d = _lib.NmsDesc()
     d.pred = C.c_void_p(pred.data_ptr())
     d.B, d.A, d.nc = B, A, nc
@@ -58,6 +68,7 @@ def nms_raw(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=
     d.max_det, d.max_nms, d.max_wh = int(max_det), 30000, 4096.0
     d.out_dets, d.out_index, d.out_count = (C.c_void_p(t.data_ptr()) for t in (dets, index, count))
     d.workspace, d.workspace_bytes = C.c_void_p(ws.data_ptr()), ws.numel()
+    d.candidates_ready = 1 if candidates is not None else 0
     _lib.check(lib.y6_nms(C.byref(d), _lib.current_stream_ptr()), "nms")
     return dets, index, count
 
