@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="images in the CPU-baseline sample")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
     ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--train-autotune", action="store_true",
+                    help="--mode train: choose the conv kernel variants by timing (per process: not reproducible) instead of from the layer shapes")
     ap.add_argument("--event-every", type=int, default=4, help="record per-kernel hipEvents on every N-th timed step")
     ap.add_argument("--dropin-steps", type=int, default=50, help="extra (separately timed) steps through the reference-"
                     "signature API: model(x) + non_max_suppression(); 0 disables")
@@ -239,7 +241,9 @@ def train_main(args):
     out, _ = model(x)                               # builds the forward / backward plans and the parameter arena
     graph = next(iter(model.__dict__["_y6_train_graphs"].values()))
     arena = graph.arena
-    if not args.no_autotune:
+    # Kernel variants of the training plans: by default a function of the layer shapes (the same in every process and on every
+    # rank: two runs give the same bits); --train-autotune picks them by timing in this process, as inference does.
+    if args.train_autotune and not args.no_autotune:
         graph.fwd_plan.autotune(2)
         graph.bwd_plan.autotune(2)
     opt = FusedSGD(model, arena, lr=0.01 / 64 * args.batch, momentum=0.937, weight_decay=5e-4)
@@ -347,7 +351,11 @@ def train_main(args):
                               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0}
                           for k, v in sorted(cls.items())},
             "loss": {"first": round(float(losses[0]), 4) if losses else None, "last": round(float(last), 4),
-                     "loss_scale": float(scaler.scale)},
+                     "loss_scale": float(scaler.scale),
+                     # exact bits of the warm-up losses and the last one: two runs of a shape-derived variant table must agree
+                     "bits": [float(v).hex() for v in losses] + [float(last).hex()]},
+            "variants": {"chosen_by": "timing (this process)" if (args.train_autotune and not args.no_autotune) else "layer shape",
+                         "fwd_hash": graph.fwd_plan.variant_hash(), "bwd_hash": graph.bwd_plan.variant_hash()},
             "memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
         }
         if args.profile_out:

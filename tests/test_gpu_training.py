@@ -1139,3 +1139,26 @@ def test_checkpoint_paths_after_training_steps(tmp_path):
     assert all(p.data_ptr() == g2.arena.data.data_ptr() + 4 * g2.arena.offset_of(p) for p in g2.arena.params)
     torch.cuda.synchronize()
     assert torch.isfinite(s2).all()
+
+
+def test_two_fresh_processes_train_to_the_same_bits():
+    """Reproducibility of the training path (reference yolov6/core/engine.py:142-176 runs the same step on every rank): two
+    fresh processes, the same seeds, ten steps of YOLOv6-N 192^2 b4 - forward, TAL, loss, backward, SGD, loss scale.  With the
+    kernel variants derived from the layer shapes (the default of the training plans; an autotuned plan picks by timing, per
+    process) and no order-dependent float atomics on the path (SPPF pool backward: 25 conflict-free rounds), every loss must
+    agree bit for bit and the variant tables must hash the same."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "train", "--model", "yolov6n", "--size", "192",
+                            "--batch", "4", "--steps", "4", "--warmup", "6"], capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    a, b = runs
+    assert a["variants"]["chosen_by"] == "layer shape"
+    assert a["variants"] == b["variants"], (a["variants"], b["variants"])
+    assert len(a["loss"]["bits"]) == 7
+    assert a["loss"]["bits"] == b["loss"]["bits"], (a["loss"]["bits"], b["loss"]["bits"])

@@ -2,6 +2,7 @@
 // cross-check conv, the NCHW stem conv, ConvTranspose2d(k2,s2), SPPF pooling and the
 // NCHW<->NHWC boundary adapters.  File:line citations are into the reference tree.
 #include "common.hpp"
+#include <cstring>
 #include "stem_piece.hpp"
 
 namespace {
@@ -650,12 +651,30 @@ static int check_conv_desc(const y6_conv_desc* d) {
     return Y6_OK;
 }
 
-// default variant when a plan was not autotuned
+// Variant of a plan that was not autotuned: a function of the layer's shape only, so that two processes (two ranks of a
+// training job, two runs of a regression test) run the same kernels and produce the same bits - an autotuned plan picks by
+// timing, and timing is per process (the run-to-run differences of the training loss were this).
+static int variant_by_name(const char* name) {
+    static int n = y6_conv_variants();
+    for (int v = 1; v < n; ++v)
+        if (strcmp(y6_conv_variant_name(v), name) == 0) return v;
+    return -1;
+}
 static int default_variant(const y6_conv_desc* d) {
+    const long px = (long)d->out.B * d->out.H * d->out.W;
+    if (d->ksize == 3) {
+        // round 4 (profiles/r04): the register-fed kernels win wherever they apply (Cin % 32 == 0, Cout % 128 == 0): 7 pixel
+        // fragments per wave when the 200-pixel items fill the 512 resident blocks, else 4; stride 2: 3 / 4 fragments
+        static const int p7 = variant_by_name("wreg_p7"), p4 = variant_by_name("wreg_p4"), s2p3 = variant_by_name("wregs2_p3");
+        const long items200 = (px + 199) / 200 * ((d->out.C + 127) / 128);
+        const int first = d->stride == 1 ? (items200 >= 512 ? p7 : p4) : s2p3;
+        if (first > 0 && y6_conv_variant_supports(d, first)) return first;
+        if (d->stride == 1 && p4 > 0 && y6_conv_variant_supports(d, p4)) return p4;
+    }
     // measured (profiles/r02 autotune logs): the LDS-DMA kernels win 3x3 stride 1 - 256-pixel blocks (variant 25) when
     // there are at least two of them per CU slot, else 128-pixel blocks (26); then round 1's pipelined kernel (10-12 are
     // skipped by `supports` for 1x1); elsewhere high-occupancy small tiles win
-    const long items256 = ((long)d->out.B * d->out.H * d->out.W + 255) / 256 * ((d->out.C + 63) / 64);
+    const long items256 = (px + 255) / 256 * ((d->out.C + 63) / 64);
     const int dma_a = items256 >= 512 ? 25 : 26, dma_b = items256 >= 512 ? 26 : 25;
     const int prefs_s1[] = {dma_a, dma_b, 10, 11, 12, 2, 1, 5, 4, 3, 6, 0};
     const int prefs_s2[] = {2, 1, 3, 0};

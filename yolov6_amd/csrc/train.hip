@@ -1234,33 +1234,45 @@ int pack_batch_launch(const y6_pack_batch_desc* d, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ SPPF pools backward
-// block = (image, 8-channel group); planes in LDS; three scatter passes with LDS float atomics.
+// block = (image, 8-channel group); planes in LDS; three scatter passes.
+// Deterministic: two outputs can send their gradient to the same input only if their 5x5 windows overlap, i.e. if they are less
+// than 5 apart in y and in x.  The outputs are visited in 25 rounds by (y mod 5, x mod 5): inside a round no two outputs share a
+// window, so the adds need no atomics, and an input receives its contributions round by round - in the same order on every run.
+// (Until r04 this was a scatter with LDS float atomics: the order of the adds, and with it the last bits of d x, depended on
+// how the waves of the block happened to be scheduled.)
 __device__ __forceinline__ void pool_scatter(const float* __restrict__ in, const float* __restrict__ gout, float* __restrict__ gin,
                                              int H, int W, int tid, int nthr) {
     // in/gout/gin: [H*W][8] in LDS; gin += scatter(gout) to the first maximum of each 5x5 window of `in`
-    const int HW = H * W;
-    for (int i = tid; i < HW * 8; i += nthr) {
-        const int p = i >> 3, c = i & 7;
-        const int y = p / W, x = p - y * W;
-        float best = -INFINITY;
-        int arg = p;
-        bool found = false;
-        for (int dy = -2; dy <= 2; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= H) continue;
-            for (int dx = -2; dx <= 2; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= W) continue;
-                const float v = in[(yy * W + xx) * 8 + c];
-                if (!found || v > best) {
-                    best = v;
-                    arg = yy * W + xx;
-                    found = true;
+    const int ny = (H + 4) / 5, nx = (W + 4) / 5;
+    for (int round = 0; round < 25; ++round) {
+        const int cy = round / 5, cx = round - cy * 5;
+        for (int i = tid; i < ny * nx * 8; i += nthr) {
+            const int c = i & 7, q = i >> 3;
+            const int y = (q / nx) * 5 + cy, x = (q % nx) * 5 + cx;
+            if (y >= H || x >= W) continue;
+            const int p = y * W + x;
+            const float g = gout[p * 8 + c];
+            if (g == 0.f) continue;
+            float best = -INFINITY;
+            int arg = p;
+            bool found = false;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= W) continue;
+                    const float v = in[(yy * W + xx) * 8 + c];
+                    if (!found || v > best) {
+                        best = v;
+                        arg = yy * W + xx;
+                        found = true;
+                    }
                 }
             }
+            gin[arg * 8 + c] += g;
         }
-        const float g = gout[i];
-        if (g != 0.f) atomicAdd(&gin[arg * 8 + c], g);
+        __syncthreads();
     }
 }
 

@@ -238,6 +238,23 @@ class Plan:
     def num_ops(self) -> int:
         return self._lib.y6_plan_num_ops(self._h)
 
+    def variant_table(self):
+        """[(op index, conv kernel variant name)] of the plan's conv ops: what an autotuned plan chose by timing, what a plan
+        that was not autotuned derives from the layer shapes (csrc/conv_misc.hip default_variant: the same in every process)."""
+        out = []
+        for i in range(self.num_ops):
+            kind, var, ks, st = (C.c_int32() for _ in range(4))
+            fl, by = C.c_double(), C.c_double()
+            _lib.check(self._lib.y6_plan_op_info(self._h, i, C.byref(kind), C.byref(var), C.byref(ks), C.byref(st),
+                                                 C.byref(fl), C.byref(by)), "plan_op_info")
+            if kind.value == 1:
+                out.append((i, self._lib.y6_conv_variant_name(var.value).decode() if var.value >= 0 else "shape-derived"))
+        return out
+
+    def variant_hash(self) -> str:
+        import hashlib
+        return hashlib.sha256(repr(self.variant_table()).encode()).hexdigest()[:16]
+
     def profile(self, iters: int = 5):
         n = self.num_ops
         ms = (C.c_float * n)()
