@@ -77,7 +77,7 @@ def spawn_ranks(args):
     (RCCL process group over xGMI; 127.0.0.1 rendezvous).  Returns the child's exit code."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    n_dev = args.gpus if os.environ.get("Y6_BENCH_MOCK") == "1" else torch.cuda.device_count()
     if args.gpus > n_dev:
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} device(s) are visible", file=sys.stderr)
         return 2
@@ -366,8 +366,56 @@ def train_main(args):
     rep.close()
 
 
+def mock_main(args):
+    """Y6_BENCH_MOCK=1: the N-rank launch path of this file on CPU ranks over gloo, with a stand-in step (a small module's
+    gradient through parallel.GradReducer's chunked all-reduce) in place of the HIP plans - tests/test_dist_cpu.py launches
+    `bench.py --mode train --gpus 2` this way: self-spawn under torch.distributed.run, rendezvous on 127.0.0.1, barriers, MAX over
+    ranks, one JSON line from rank 0 LAST on stdout.  Not a benchmark: `data` says so."""
+    from yolov6_amd.parallel import GradReducer, Replicas
+    from yolov6_amd.train_engine import ParamArena
+    rep = Replicas(backend="gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+    arena = ParamArena(net, "cpu")
+    marks = [(i + 1, [p]) for i, p in enumerate(arena.params)]
+    x = torch.randn(args.batch or 8, 16, generator=torch.Generator().manual_seed(rep.rank))
+
+    class Graph:
+        bwd_marks, n_bwd_ops = marks, len(arena.params)
+
+        def backward(self, grads, first=0, last=None):
+            if first == 0:
+                arena.zero_grad()
+                net(x).square().mean().backward()
+    Graph.arena = arena
+    red = GradReducer(arena, marks, len(arena.params), rep, chunks=2, average=True)
+    g = Graph()
+    for _ in range(args.warmup):
+        red.run_backward(g, None)
+    rep.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        red.run_backward(g, None)
+    rep.barrier()
+    elapsed = rep.max_over_ranks(time.perf_counter() - t0)
+    gsum = float(arena.grad.abs().sum())
+    if rep.rank == 0:
+        b = args.batch or 8
+        print("bench.py mock launch: not a measurement", flush=True)
+        print(json.dumps({"metric": "mock steps/sec", "value": round(rep.throughput(b, args.steps, elapsed), 2), "unit": "images/sec",
+                          "n_gpus": rep.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "mock (Y6_BENCH_MOCK=1)",
+                          "config": {"workload": "launch-path stand-in", "global_batch": rep.world * b, "parallelism": f"dp{rep.world}"},
+                          "grad_abs_sum": gsum}), flush=True)
+    rep.close()
+
+
 def main():
     args = parse()
+    if os.environ.get("Y6_BENCH_MOCK") == "1":
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            sys.exit(spawn_ranks(args))
+        return mock_main(args)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the hot path has no CPU fallback)"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))

@@ -751,6 +751,9 @@ int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d);   /* gene
  * number of ops changed (0: the plan has no such op, or the op cannot serve this sink - the caller keeps y6_nms's own first
  * stage), negative on error. */
 int y6_plan_set_nms_sink(y6_plan* p, const y6_nms_sink* sink);
+/* Side-stream ops (y6_plan_mark_side) enqueued since the plan's side stream last joined the caller's stream: 0 after every
+ * y6_plan_run / y6_plan_run_range (they join before they return). */
+int y6_plan_side_pending(const y6_plan* p);
 int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
 int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);
 int y6_plan_num_ops(const y6_plan* p);

@@ -253,3 +253,139 @@ def test_two_rank_gloo_training_seam(mode):
         assert res["local_vs_global"] > 1e-3, res          # the shards really differ: an un-reduced gradient would fail below
         assert max(res["errs"]) < 1e-6, res
         assert res["views"], res
+
+
+def test_bench_train_two_ranks_self_spawn_on_gloo(tmp_path):
+    """`python bench.py --mode train --gpus 2` as the driver will launch it on an 8-GPU node, minus the GPUs (Y6_BENCH_MOCK=1:
+    CPU ranks over gloo, a stand-in step through parallel.GradReducer): the file re-executes itself under torch.distributed.run
+    with a free port on 127.0.0.1, both ranks meet, rank 0 prints ONE JSON line and it is the LAST line of stdout (a banner
+    precedes it), n_gpus = 2, the global batch doubles, the gradient is the all-reduced one.  Two launches at once must not
+    collide on the rendezvous port."""
+    env = dict(os.environ, Y6_BENCH_MOCK="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "5", "--warmup", "2", "--batch", "8"]
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)) for _ in range(2)]
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err[-3000:]
+        outs.append(out)
+    one = subprocess.run([c if c != "2" else "1" for c in cmd], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert one.returncode == 0, one.stderr[-3000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for out in outs:
+        lines = [l for l in out.strip().splitlines() if l.strip()]
+        assert sum(1 for l in lines if l.startswith("{")) == 1, lines          # one JSON line (rank 0 only)
+        r = json.loads(lines[-1])                                              # ... and it is the last line
+        assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2
+        assert r["config"]["global_batch"] == 2 * r1["config"]["global_batch"] == 16
+        assert r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+        assert r["grad_abs_sum"] != pytest.approx(r1["grad_abs_sum"], rel=1e-9)   # the average over two different shards
+
+
+PENDING_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import torch
+from yolov6_amd.parallel import GradReducer, Replicas
+from yolov6_amd.train_engine import ParamArena
+r = Replicas(backend="gloo")
+net = torch.nn.Linear(4, 4)
+arena = ParamArena(net, "cpu")
+marks = [(i + 1, [p]) for i, p in enumerate(arena.params)]
+class Plan:
+    pending = 0
+    def side_pending(self):
+        return self.pending
+class Graph:
+    bwd_marks, n_bwd_ops, bwd_plan = marks, len(arena.params), Plan()
+    def backward(self, grads, first=0, last=None):
+        if first == 0:
+            arena.zero_grad()
+            net(torch.ones(2, 4)).sum().backward()
+Graph.arena = arena
+red = GradReducer(arena, marks, len(arena.params), r, chunks=2, average=True)
+g = Graph()
+red.run_backward(g, None)                       # joined side stream: fine
+ok_first = True
+Graph.bwd_plan.pending = 3                      # a plan that returned with side-stream work the launch stream is not ordered behind
+try:
+    red.run_backward(g, None)
+    refused = False
+except RuntimeError as e:
+    refused = "side stream" in str(e)
+print("RESULT " + json.dumps(dict(rank=r.rank, ok_first=ok_first, refused=refused)), flush=True)
+r.close()
+"""
+
+
+def test_two_rank_gloo_reducer_refuses_an_unjoined_side_stream():
+    """parallel.GradReducer hands a gradient chunk to the all-reduce behind an event recorded on the launch stream; the backward
+    plan writes weight gradients on its side stream.  The plan joins before it returns (csrc/plan.hip run_ops,
+    y6_plan_side_pending == 0); the reducer asserts it - a plan that did not would let the all-reduce read half-written
+    gradients.  Both ranks refuse (nobody is left waiting in a collective)."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", PENDING_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert res["ok_first"] and res["refused"], res
+
+
+BUFFER_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import torch, torch.nn as nn
+from torch.nn.parallel import DistributedDataParallel as DDP
+from yolov6_amd.parallel import Replicas
+from yolov6_amd.train_engine import ParamArena
+torch.manual_seed(0)
+torch.set_num_threads(1)
+r = Replicas(backend="gloo")
+net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU())
+arena = ParamArena(net, "cpu")                     # parameters become views of the flat arena; buffers stay what they are
+bn = net[1]
+ptrs0 = (bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr())
+seen = []
+net.register_forward_pre_hook(lambda m, a: seen.append(bn.running_mean.clone()))
+ddp = DDP(net)                                     # broadcast_buffers=True: rank 0's buffers are written INTO every rank's, in place
+g = torch.Generator().manual_seed(10 + r.rank)
+for it in range(3):
+    x = torch.randn(4, 3, 8, 8, generator=g) + r.rank     # different statistics per rank
+    ddp(x).sum().backward()
+ptrs1 = (bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr())
+# what rank 0 had at the start of forward k is what every rank sees at the start of forward k
+mine = torch.stack(seen)
+ref = mine.clone()
+r.dist.broadcast(ref, src=0)
+params_are_views = all(p.data_ptr() == arena.data.data_ptr() + 4 * arena.offset_of(p) for p in net.parameters())
+print("RESULT " + json.dumps(dict(rank=r.rank, same_storage=ptrs0 == ptrs1, follows_rank0=bool(torch.equal(mine, ref)),
+                                  moved=float((mine[-1] - mine[0]).abs().max()), params_are_views=params_are_views)), flush=True)
+r.close()
+"""
+
+
+def test_two_rank_gloo_ddp_buffer_broadcast_lands_in_the_storage_the_plans_hold():
+    """BatchNorm running statistics under a torch-DDP wrapper (reference core/engine.py:463-466 wraps the model; DDP broadcasts
+    rank 0's buffers into every rank's at each forward).  The native statistics op holds the ADDRESS of running_mean / running_var
+    (the training graph is built once): the broadcast must be an in-place write into that storage, and after it every rank
+    must see rank 0's statistics.  (The native GradReducer path does not broadcast: statistics stay per rank and rank 0's are the
+    ones a checkpoint keeps - the same end state as DDP's.)"""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", BUFFER_WORKER % ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out
+        res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+        assert res["same_storage"] and res["follows_rank0"] and res["params_are_views"], res
+        assert res["moved"] > 1e-4, res

@@ -629,3 +629,39 @@ def test_wreg_kernels_keep_their_asm_loaded_registers():
     for name, meta in wreg.items():
         assert meta.get("vgpr_spill_count", -1) == 0, (name, meta)
         assert meta.get("private_segment_fixed_size", -1) == 0, (name, meta)
+
+
+@pytest.mark.parametrize("case,flags", [("tiny", {}), ("s_qa_tiny", {}), ("s_mbla_tiny", {}), ("tiny", {"fuse_ab": True}), ("m_tiny", {})])
+def test_backward_side_stream_contract_holds_on_every_training_graph(case, flags):
+    """The backward plan runs its weight-gradient work (operand transposes, weight-gradient GEMMs, bias sums) on a side stream
+    that is only ordered behind EARLIER ops and joins at the end of a run (csrc/plan.hip y6_plan_mark_side).  For every side op
+    and every later main-stream op: the main op must not write what the side op reads nor touch what it writes
+    (schedule.side_conflicts over TrainBuilder.bwd_log: gradient buffers, operand planes, workspaces, arena gradient slices).
+    Every backward op kind must have an access list - an unknown kind would silently escape the check."""
+    from yolov6_amd import schedule as S
+    from yolov6_amd.engine import NCHWInput
+    from yolov6_amd.train_engine import ParamArena, TrainBuilder
+    cfg, meta = case_config(case)
+    m = build_model(cfg, meta["num_classes"], "cpu", **flags).train()
+    x = synth.synth_images(2, 64, seed=1)
+    arena = ParamArena(m, x.device)
+    tb = TrainBuilder(x.device, arena)
+    m.lower_train(tb, NCHWInput(x))
+    tb.finalize()
+    log = tb.bwd_log
+    assert len(log) > 50 and any(e["side"] for e in log) and any(not e["side"] for e in log)
+    unknown = sorted({e["kind"] for e in log if S.train_bwd_access(e, arena) is None})
+    assert not unknown, unknown
+    assert S.side_conflicts(log, arena) == []
+    # the checker does see a violation: a main-stream op that overwrites the gradient a pending transpose / GEMM still reads,
+    # and one that works in place on what it wrote
+    i = next(k for k, e in enumerate(log) if e["kind"] == "wgrad_transpose" and hasattr(e["src"], "buf"))
+    rogue = dict(kind="tensor_add", side=False, x=log[i]["src"], out=log[i]["src"], acc=0)
+    bad = S.side_conflicts(log[:i + 1] + [rogue], arena)
+    assert bad and bad[0][0] == i and bad[0][2] == "writes an input"
+    j = next(k for k, e in enumerate(log) if e["kind"] == "wgrad")
+    from yolov6_amd.engine import TRef
+    g = arena.grad
+    rogue2 = dict(kind="channel_sum", side=False, x=log[i]["src"], param=log[j]["weight"], ws=torch.zeros(16, dtype=torch.uint8))
+    bad2 = S.side_conflicts(log[:j + 1] + [rogue2], arena)
+    assert any(b[0] == j and b[2] == "touches an output" for b in bad2), bad2

@@ -309,6 +309,7 @@ SIGNATURES = {
     "y6_plan_add_decode": (C.c_int, [C.c_void_p, C.POINTER(DecodeDesc)]),
     "y6_plan_add_pred_decode": (C.c_int, [C.c_void_p, C.POINTER(PredDecodeDesc)]),
     "y6_plan_set_nms_sink": (C.c_int, [C.c_void_p, C.POINTER(NmsSink)]),
+    "y6_plan_side_pending": (C.c_int, [C.c_void_p]),
     "y6_plan_add_pw_s2": (C.c_int, [C.c_void_p, C.POINTER(PwS2Desc)]),
     "y6_plan_add_stem_s2": (C.c_int, [C.c_void_p, C.POINTER(StemS2Desc)]),
     "y6_plan_add_nchw2nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Tensor)]),

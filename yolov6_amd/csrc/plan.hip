@@ -104,6 +104,7 @@ struct y6_plan {
     int slots_used = 0;
     // side stream (y6_plan_mark_side): ops nobody on the main stream waits for before the end of a run
     std::vector<char> side;          // per op (shorter than ops: the rest are main-stream ops)
+    int side_pending = 0;            // side-stream ops enqueued since the side stream last joined the caller's stream
     hipStream_t side_stream = nullptr;
     std::vector<hipEvent_t> sync_ev; // ring of fork / join events
     size_t sync_pos = 0;
@@ -246,6 +247,7 @@ static int run_ops(y6_plan* p, hipStream_t s, size_t first, size_t last) {
             int rc = run_op(p->ops[i], p->side_stream);
             if (rc) return rc;
             side_used = true;
+            ++p->side_pending;
         } else {
             int rc = run_op(p->ops[i], s);
             if (rc) return rc;
@@ -258,9 +260,15 @@ static int run_ops(y6_plan* p, hipStream_t s, size_t first, size_t last) {
         if (rc) return rc;
         Y6_HIP(hipEventRecord(e, p->side_stream));
         Y6_HIP(hipStreamWaitEvent(s, e, 0));
+        p->side_pending = 0;
     }
     return Y6_OK;
 }
+
+// Side-stream ops enqueued by eager runs that the caller's stream has not been ordered behind yet: 0 after every y6_plan_run /
+// y6_plan_run_range returns (they join before returning).  parallel.GradReducer asserts it before it records the event an
+// all-reduce of the finished gradient chunk waits for.
+extern "C" int y6_plan_side_pending(const y6_plan* p) { return p ? p->side_pending : 0; }
 
 // ---- two-stream schedule (inference plans; yolov6_amd/schedule.py decides it from the ops' tensor views) ----------------
 // order[n]: a permutation of the ops = the order they are enqueued in; stream[n] (by op index): 0 = the caller's stream,
@@ -290,6 +298,12 @@ extern "C" int y6_plan_set_schedule(y6_plan* p, const int32_t* order, const int3
                    "plan_set_schedule: edge %d (%d -> %d) must point forward in the enqueue order, across streams", e, a, b);
         waits[b].push_back(a);
         records[a] = 1;
+    }
+    {   // the events of one run come out of a 512-entry ring (next_sync_event): fork + join + one per recording op must fit,
+        // or an event would be re-recorded while a later op of the same run still has to wait for its first recording
+        int nrec = 0;
+        for (char r : records) nrec += r;
+        Y6_REQUIRE(nrec + 2 <= 510, "plan_set_schedule: %d cross-stream events in one run exceed the event ring", nrec);
     }
     p->sched_order.assign(order, order + n);
     p->sched_stream.assign(stream, stream + n);

@@ -238,6 +238,10 @@ class Plan:
     def num_ops(self) -> int:
         return self._lib.y6_plan_num_ops(self._h)
 
+    def side_pending(self) -> int:
+        """Side-stream ops the current stream has not been ordered behind (0 after every run / run_range)."""
+        return int(self._lib.y6_plan_side_pending(self._h))
+
     def variant_table(self):
         """[(op index, conv kernel variant name)] of the plan's conv ops: what an autotuned plan chose by timing, what a plan
         that was not autotuned derives from the layer shapes (csrc/conv_misc.hip default_variant: the same in every process)."""

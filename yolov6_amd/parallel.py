@@ -148,6 +148,12 @@ class GradReducer:
                 graph.backward(grads if first == 0 else None, first=first, last=last)
             if self.rep.dist is None:
                 continue
+            # the chunk's all-reduce waits for an event recorded on the launch stream: everything that writes the chunk - also
+            # the weight-gradient ops the backward plan runs on its side stream - must have been ordered into that stream
+            pending = getattr(getattr(graph, "bwd_plan", None), "side_pending", None)
+            if pending is not None and pending():
+                raise RuntimeError("yolov6_amd: the backward plan's side stream has not joined the launch stream: the gradient "
+                                   "chunk would be all-reduced before its weight gradients are written")
             if cuda:
                 ev = torch.cuda.Event()
                 ev.record()

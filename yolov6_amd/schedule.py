@@ -105,6 +105,95 @@ def train_op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
     return [_span(v) for v in rd], [_span(v) for v in wr]
 
 
+def _grad_span(arena, p) -> Span:
+    lo = int(arena.grad.data_ptr()) + 4 * int(arena.offset_of(p))
+    return (lo, lo + 4 * int(p.numel()), 0, WHOLE)
+
+
+def train_bwd_access(entry: dict, arena) -> Optional[Tuple[List[Span], List[Span]]]:
+    """(reads, writes) of one entry of train_engine.TrainBuilder.bwd_log: gradient buffers, operand planes, workspaces and the
+    slices of the flat gradient arena the op writes.  Forward activations, saved statistics and (packed) weights are read-only
+    during the backward and are left out of the reads of MAIN-stream ops; for side ops (weight-gradient work) every read is
+    listed - that is what a later main-stream op must not overwrite."""
+    k = entry.get("kind")
+    rd, wr = [], []
+    if k == "conv":                                   # data gradient (dgrad / convt_dgrad): x = dy view, out = dx
+        rd.append(_span(entry["x"]))
+        wr.append(_span(entry["out"]))
+        if entry.get("acc"):
+            rd.append(_span(entry["out"]))
+    elif k == "wgrad_transpose":
+        rd.append(_span(entry["src"]))
+        wr.append(_span(entry["dst"]))
+    elif k == "wgrad":
+        if entry.get("nhwc"):
+            rd += [_span(entry["x"]), _span(entry["dy"])]
+        else:
+            rd += [_span(entry["a"])] + [_span(t) for t in entry["planes"]]
+        wr.append(_grad_span(arena, entry["weight"]))
+        wr.append(_span(entry["ws"]))
+    elif k == "channel_sum":
+        rd.append(_span(entry["x"]))
+        wr += [_grad_span(arena, entry["param"]), _span(entry["ws"])]
+    elif k == "bnact_backward":
+        rd.append(_span(entry["dout"]))
+        for t, dil, acc in entry["dx"]:
+            wr.append(_span(t))
+            if acc:
+                rd.append(_span(t))
+        if entry.get("dres") is not None:
+            t, acc = entry["dres"]
+            wr.append(_span(t))
+            if acc:
+                rd.append(_span(t))
+        for t, st in entry["branches"]:
+            if st is not None:
+                bn = st.module
+                for p in (bn.weight, bn.bias):
+                    if p is not None:
+                        wr.append(_grad_span(arena, p))      # (a channel slice of it: the whole parameter is the safe superset)
+        if entry.get("alpha") is not None:
+            wr.append(_grad_span(arena, entry["alpha"]))
+    elif k in ("avgpool3", "tensor_add", "space_to_depth2"):
+        rd.append(_span(entry["x"]))
+        wr.append(_span(entry["out"]))
+        if entry.get("acc"):
+            rd.append(_span(entry["out"]))
+    elif k in ("head_unpack_backward", "head_ab_unpack_backward"):
+        rd += [_span(entry[n]) for n in ("dscores", "ddistri") if entry.get(n) is not None]
+        wr += [_span(t) for t in list(entry.get("dcls", [])) + list(entry.get("dreg", []))]
+    elif k == "sppf_backward":
+        rd += [_span(t) for t in entry["dys"]] + [_span(entry["dx"])]
+        wr.append(_span(entry["dx"]))
+    else:
+        return None
+    return [v for v in rd if v is not None], [v for v in wr if v is not None]
+
+
+def side_conflicts(log: Sequence[dict], arena, only_last: bool = False):
+    """The contract of the backward plan's side stream (csrc/plan.hip y6_plan_mark_side; train_engine marks weight-gradient
+    work): ops are enqueued in plan order, a side op is ordered behind every EARLIER op (fork event) and the side stream joins
+    the main stream only at the end of a run / range.  So for a side op i and a LATER main-stream op j nothing orders j behind
+    i: j must not write what i reads, and must not read or write what i writes.  (Side ops among themselves are one stream.)
+    Returns [(i, j, what)] - empty when the contract holds.  only_last: check only the log's last op as j (build-time use)."""
+    acc = [train_bwd_access(e, arena) for e in log]
+    out = []
+    js = [len(log) - 1] if only_last else range(len(log))
+    for j in js:
+        if log[j].get("side") or acc[j] is None:
+            continue
+        rj, wj = acc[j]
+        for i in range(j):
+            if not log[i].get("side") or acc[i] is None:
+                continue
+            ri, wi = acc[i]
+            if any(_overlap(w, r) for w in wj for r in ri):
+                out.append((i, j, "writes an input"))
+            elif any(_overlap(w, w2) for w in wj for w2 in wi) or any(_overlap(r, w2) for r in rj for w2 in wi):
+                out.append((i, j, "touches an output"))
+    return out
+
+
 def train_costs(log: Sequence[dict]) -> List[float]:
     """Rough per-op times (microseconds) of a training-form forward from its shapes - enough to tell the chain from the
     branches (a device profile would re-run the statistics ops, which update running statistics).  Convs at 500 TFLOP/s,

@@ -235,7 +235,18 @@ class TrainBuilder:
         if what in self._SIDE_OPS:
             _lib.check(self.lib.y6_plan_mark_side(self.bwd), "plan_mark_side")
         self.n_bwd_ops += 1
-        self.bwd_log.append(dict(kind=what.replace("plan_add_", ""), **log))
+        entry = dict(kind=what.replace("plan_add_", ""), side=what in self._SIDE_OPS, **log)
+        self.bwd_log.append(entry)
+        # the side-stream contract, checked as the plan is built (schedule.side_conflicts: a main-stream op must not write what an
+        # earlier side op reads, nor touch what it writes): a future in-place backward op or a reused buffer fails HERE, not as a
+        # race under load.  Ops whose access list this file does not know are skipped (tests/test_host_cpu.py requires all known).
+        if not entry["side"]:
+            from . import schedule as _S
+            bad = _S.side_conflicts(self.bwd_log, self.arena, only_last=True)
+            if bad:
+                i, j, why = bad[0]
+                raise RuntimeError(f"yolov6_amd: backward op {j} ({self.bwd_log[j]['kind']}) {why} of side-stream op {i} "
+                                   f"({self.bwd_log[i]['kind']}): the weight-gradient side stream contract is broken")
 
     def _add_pack(self, src_ptr, kind, Cout, Cin, K):
         n = int(self.lib.y6_pack_job_elems(kind, Cout, Cin, K))
@@ -584,7 +595,8 @@ class TrainBuilder:
             d.nchw, d.src_dtype = 0, Y6_F16
         d.sy, d.sx, d.oy, d.ox, d.R, d.Q = sy, sx, oy, ox, R, Q
         d.dst = dst.data_ptr()
-        self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose", aux=True)
+        self._b(self.lib.y6_plan_add_wgrad_transpose(self.bwd, C.byref(d)), "plan_add_wgrad_transpose", aux=True,
+                src=(nchw_t if nchw_t is not None else view), dst=dst)
         if key is not None:
             self.planes[key] = dst
         return dst
@@ -616,7 +628,8 @@ class TrainBuilder:
         w.sm, w.sn, w.st = N * T, T, 1
         w.flops = flops
         w.workspace, w.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
-        self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad", mode=mode, **(log or {}))
+        self._b(self.lib.y6_plan_add_wgrad(self.bwd, C.byref(w)), "plan_add_wgrad", mode=mode, a=a, planes=[t for t, _, _ in planes],
+                ws=self.wgrad_ws, **(log or {}))
         self.bwd_flops += flops
 
     def _conv_backward(self, rec: ConvRec):
@@ -647,7 +660,7 @@ class TrainBuilder:
             w.workspace, w.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
             if self.lib.y6_wgrad_nhwc_supported(C.byref(w)):
                 self._b(self.lib.y6_plan_add_wgrad_nhwc(self.bwd, C.byref(w)), "plan_add_wgrad", mode=(_lib.WG_3X3S1 if K == 3 else _lib.WG_1X1),
-                        nhwc=True, **wlog)
+                        nhwc=True, ws=self.wgrad_ws, **wlog)
                 self.bwd_flops += flops
                 self._conv_backward_rest(rec, dyv, is_stem)
                 return
@@ -686,7 +699,7 @@ class TrainBuilder:
             ws = self.bytes_(16 * _rup(max(y.C, 1), 8))
             ct = TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff).ct()
             self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(rec.bias), _ptr(ws), ws.numel()),
-                    "plan_add_channel_sum", x=TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff), param=rec.bias)
+                    "plan_add_channel_sum", x=TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff), param=rec.bias, ws=ws)
             finals.append(rec.bias)
         # data gradient: the forward conv kernel on the flipped / transposed weights, stride 1 over the (dilated) dy
         if not is_stem:
@@ -719,7 +732,7 @@ class TrainBuilder:
         ws = self.bytes_(16 * _rup(Cout, 8))
         ct = gout.ct()
         self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(bias), _ptr(ws), ws.numel()),
-                "plan_add_channel_sum", x=gout, param=bias)
+                "plan_add_channel_sum", x=gout, param=bias, ws=ws)
         a = self._transpose(x, 1, 1, 0, 0, H, Q, Cin, B)
         planes = [(self._transpose(gout, 2, 2, sub >> 1, sub & 1, H, Q, Cout, B), H, 0) for sub in range(4)]
         self._wgrad(_lib.WG_CONVT, a, planes, Cin, Cout, B, Q, H, 4, self.arena.grad_ptr(weight), 2.0 * Cin * Cout * 4 * B * H * W,
