@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--int8", action="store_true", help="BASELINE configs[4]: int8 plan (use with --model yolov6s_qa): max-"
                     "calibration on 4 synthetic batches, backbone + neck convs on the int8 MFMA kernels, head fp16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=32, help="images in the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU-baseline sample (1 warm-up + 3 timed passes of forward + NMS + TAL)")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--train-autotune", action="store_true",
@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--dropin-steps", type=int, default=50, help="extra (separately timed) steps through the reference-"
                     "signature API: model(x) + non_max_suppression(); 0 disables")
     ap.add_argument("--no-verify", action="store_true", help="skip the NMS-vs-oracle self check (outside the timed region)")
+    ap.add_argument("--no-train-sub", action="store_true", help="skip the ten training steps reported under `train` next to the headline")
+    ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the reported value is the median window")
     ap.add_argument("--no-fuse-candidates", action="store_true",
                     help="A/B: NMS selects its candidates itself (re-reads the prediction tensor) instead of the decode launch doing it")
     ap.add_argument("--nms-stream", choices=("same", "side"), default=os.environ.get("Y6_BENCH_NMS_STREAM", "same"),
@@ -177,8 +179,12 @@ def classify(row):
 
 
 def cpu_baseline(args, cfg, sd_train, shift):
-    """Oracle port of the same workload on the host cores: deploy-form fp32 forward + numpy NMS."""
-    from oracle import nms_oracle, synth
+    """Oracle port of the same workload on the host cores (one warm-up + three timed passes, the three parts of
+    the path timed separately, min and median): deploy-form fp32 forward and numpy NMS of `--cpu-batch` images, and the numpy
+    task-aligned assigner on a training-sized problem (the same number of images, 8400 anchors, 80 classes, up to 40 boxes)."""
+    import statistics
+    import numpy as np
+    from oracle import nms_oracle, synth, tal_oracle
     from oracle.model_oracle import Oracle, deploy_state_dict
     threads = torch.get_num_threads()
     sd = deploy_state_dict(cfg, sd_train, 80)
@@ -186,17 +192,35 @@ def cpu_baseline(args, cfg, sd_train, shift):
         if "cls_preds" in k and k.endswith(".bias"):
             sd[k] = sd[k] + shift
     orc = Oracle(cfg, sd, 80)
-    x = synth.synth_images(args.cpu_batch, args.size, seed=0)
+    n = args.cpu_batch
+    x = synth.synth_images(n, args.size, seed=0)
+    fs, st = [(args.size // s, args.size // s) for s in (8, 16, 32)], [8, 16, 32]
+    g = np.random.default_rng(0)
+    tal_in = synth.synth_tal_inputs(n, fs, st, 80, 40, seed=9, n_valid=[int(v) for v in g.integers(1, 41, n)], img=args.size)
+    tal_np = [tal_in[k].numpy() for k in ("pd_scores", "pd_bboxes", "anc_points", "gt_labels", "gt_bboxes", "mask_gt")]
+    fwd, nms, tal = [], [], []
     with torch.no_grad():
-        orc.forward(x[:1])                      # warm
-        t0 = time.perf_counter()
-        det, _ = orc.forward(x)
-        t1 = time.perf_counter()
-        nms_oracle.non_max_suppression(det.numpy(), CONF, IOU, multi_label=True, max_det=MAX_DET)
-        t2 = time.perf_counter()
-    return dict(value=round(args.cpu_batch / (t2 - t0), 3), unit="images/sec", cores=threads, kind="port",
-                sample=f"{args.cpu_batch} images {args.size}x{args.size}, fp32 torch-CPU oracle forward "
-                       f"({t1 - t0:.2f} s) + numpy NMS ({t2 - t1:.2f} s), 1 pass",
+        for rep in range(4):                        # pass 0 warms caches / thread pools and is not counted
+            t0 = time.perf_counter()
+            det, _ = orc.forward(x)
+            t1 = time.perf_counter()
+            nms_oracle.non_max_suppression(det.numpy(), CONF, IOU, multi_label=True, max_det=MAX_DET)
+            t2 = time.perf_counter()
+            tal_oracle.assign(*tal_np, topk=13, num_classes=80)
+            t3 = time.perf_counter()
+            if rep:
+                fwd.append(t1 - t0)
+                nms.append(t2 - t1)
+                tal.append(t3 - t2)
+    step = [a + b for a, b in zip(fwd, nms)]        # the bench's step: forward + NMS
+    med = statistics.median
+    return dict(value=round(n / med(step), 3), unit="images/sec", cores=threads, kind="port",
+                value_best=round(n / min(step), 3),
+                forward_s={"min": round(min(fwd), 3), "median": round(med(fwd), 3)},
+                nms_s={"min": round(min(nms), 3), "median": round(med(nms), 3)},
+                tal_s={"min": round(min(tal), 3), "median": round(med(tal), 3), "images": n, "anchors": 8400, "max_boxes": 40},
+                sample=f"{n} images {args.size}x{args.size}: fp32 torch-CPU oracle forward + numpy NMS (value = images / median "
+                       f"(forward + NMS)), numpy task-aligned assigner on {n} images; 1 warm-up + 3 timed passes",
                 torch=torch.__version__)
 
 
@@ -410,6 +434,24 @@ def mock_main(args):
     rep.close()
 
 
+def train_sub_bench():
+    """BASELINE configs[2] beside the headline (N = 1 only): ten timed steps of `--mode train` (YOLOv6-S 640^2 b64) in a child
+    process, summarised - so that the run the driver times also carries a training-step figure.  Never fails the headline."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "10", "--warmup", "3"],
+                           capture_output=True, text=True, timeout=420)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-400:]}
+        d = json.loads(line[-1])
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                "ms_per_step": d["ms_per_step"], "mfma_frac": d["roofline"]["frac"], "hbm_frac": d["roofline_hbm"]["frac"],
+                "loss_first": d["loss"]["first"], "loss_last": d["loss"]["last"], "variants": d["variants"], "memory_gb": d["memory_gb"]}
+    except Exception as e:      # noqa: BLE001 - a reported sub-bench, not the headline
+        return {"error": repr(e)[:400]}
+
+
 def main():
     args = parse()
     if os.environ.get("Y6_BENCH_MOCK") == "1":
@@ -453,8 +495,9 @@ def main():
     # step would tax the headline number by 6 %.  All K steps run the same kernels on the same stream.
     ev_every = max(1, args.event_every)
     sampled = [i for i in range(args.steps) if i % ev_every == 0]
-    plan.timing_begin(len(sampled))
-    nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in sampled]
+    n_win = max(1, args.windows)
+    plan.timing_begin(n_win * len(sampled))
+    nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_win * len(sampled))]
 
     # --nms-stream side: a two-deep software pipeline over batches.  The forward plan writes its [B,A,85] result into two
     # tensors in turn (Plan.rebind_output); the NMS of batch k is enqueued on a second stream behind an event recorded after
@@ -491,37 +534,43 @@ def main():
         torch.cuda.synchronize()
         nms_done = [None for _ in ring]
 
-    rep.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # Three windows (--windows) of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and reduced
+    # with MAX over the ranks; `value` comes from the median window, the others are reported as the spread (a 0.05 s region on
+    # a power-managed chip moves by several per cent from one window to the next).
     k = 0
-    for i in range(args.steps):
-        if i % ev_every == 0:
-            if side:
-                slot = i % len(ring)
-                if nms_done[slot] is not None:
-                    fwd_stream.wait_event(nms_done[slot])
-                plan.rebind_output(ring[slot])
-                det = plan.run_timed()
-                fwd_done[slot].record(fwd_stream)
-                with torch.cuda.stream(nms_stream):
-                    nms_stream.wait_event(fwd_done[slot])
+    elapsed_w = []
+    for w in range(n_win):
+        rep.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if i % ev_every == 0:
+                if side:
+                    slot = i % len(ring)
+                    if nms_done[slot] is not None:
+                        fwd_stream.wait_event(nms_done[slot])
+                    plan.rebind_output(ring[slot])
+                    det = plan.run_timed()
+                    fwd_done[slot].record(fwd_stream)
+                    with torch.cuda.stream(nms_stream):
+                        nms_stream.wait_event(fwd_done[slot])
+                        nms_ev[k][0].record()
+                        out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
+                        nms_ev[k][1].record()
+                        nms_done[slot] = torch.cuda.Event()
+                        nms_done[slot].record(nms_stream)
+                else:
+                    det = plan.run_timed()
                     nms_ev[k][0].record()
                     out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
                     nms_ev[k][1].record()
-                    nms_done[slot] = torch.cuda.Event()
-                    nms_done[slot].record(nms_stream)
+                k += 1
             else:
-                det = plan.run_timed()
-                nms_ev[k][0].record()
-                out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
-                nms_ev[k][1].record()
-            k += 1
-        else:
-            det, out = pipelined_step(i, False)
-    torch.cuda.synchronize()          # drains both streams
-    rep.barrier()
-    elapsed = rep.max_over_ranks(time.perf_counter() - t0)
+                det, out = pipelined_step(i, False)
+        torch.cuda.synchronize()          # drains both streams
+        rep.barrier()
+        elapsed_w.append(rep.max_over_ranks(time.perf_counter() - t0))
+    elapsed = sorted(elapsed_w)[len(elapsed_w) // 2]
 
     rows = plan.timing_read()
     nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / len(nms_ev)
@@ -582,6 +631,8 @@ def main():
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "windows": {"n": n_win, "ms_per_step": [round(e / args.steps * 1e3, 4) for e in elapsed_w], "value_from": "median window",
+                        "spread_pct": round((max(elapsed_w) - min(elapsed_w)) / elapsed * 100.0, 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 (backbone + neck convs; image conv, convT, head, decode fp16)" if args.int8 else "f16", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.size}x{args.size} b{args.batch}/GPU {'int8' if args.int8 else 'fp16'} inference: "
@@ -596,7 +647,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"replicas x{world} (no collective)",
                        "weights": "random (oracle/synth.py), cls bias calibrated to ~2% candidates"},
             "roofline": {"bound": "mfma", "kernel": ("int8 convs 3x3 / 3x3 s2 / 1x1 (conv3x3_dma_kernel<int8> conv_dma.hip, conv_i8_kernel conv_mfma.hip), all launches" if args.int8 else
-                                                     "3x3 stride-1 conv+bias+act (LDS-DMA kernels conv_dma.hip / conv_mfma.hip); variants chosen per layer: "
+                                                     "3x3 stride-1 conv+bias+act (register-fed kernels conv_wreg.hip, LDS-DMA kernels conv_dma.hip); variants chosen per layer: "
                                                      + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items()))),
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TOP/s" if args.int8 else "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -623,6 +674,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args, cfg, sd_train, shift)
+        if world == 1 and headline and not args.no_train_sub:
+            res["train"] = train_sub_bench()
         if args.profile_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
             with open(args.profile_out, "w") as f:
