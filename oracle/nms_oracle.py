@@ -12,6 +12,11 @@ returned in descending-score order.  The same greedy / strict-">" form appears i
 deploy/TensorRT/yolov6.cpp:122-155.  PARITY UNPINNED for this one call: the reference holds
 no test vectors for it; everything around the call is pinned by running the
 reference's own nms.py with this function injected (tests/golden/gen_golden.py).
+CORROBORATED since round 4: oracle/build_ref.py compiles that in-tree C++ statement
+(`nms_sorted_bboxes` + `intersection_area`, cut out of the reference file where it lies) into
+oracle/_ref/libref_nms.so, and tests/test_oracle_ref.py checks that it and `nms()` keep the same
+boxes on random, clustered and exactly-at-threshold inputs - a second implementation of the
+rule written by the reference's authors, not the torchvision kernel itself.
 
 Tie rule (upstream leaves it unspecified): equal scores keep their original order.
 """
