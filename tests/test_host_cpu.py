@@ -665,3 +665,34 @@ def test_backward_side_stream_contract_holds_on_every_training_graph(case, flags
     rogue2 = dict(kind="channel_sum", side=False, x=log[i]["src"], param=log[j]["weight"], ws=torch.zeros(16, dtype=torch.uint8))
     bad2 = S.side_conflicts(log[:j + 1] + [rogue2], arena)
     assert any(b[0] == j and b[2] == "touches an output" for b in bad2), bad2
+
+
+def test_histogram_calibration_rules():
+    """yolov6_amd.quant.HistogramCalibrator: the reference's PTQ recipe (tools/qat/qat_utils.py:12-58, histogram / entropy,
+    configs/repopt/yolov6s_opt_qat.py:63-69) on known distributions: the histogram grows by whole bins of the first batch's
+    width, percentile 100 is the range, a long thin tail is clipped by all three rules (below the abs-max) and a uniform
+    distribution is not (entropy / mse keep ~ the whole range), the rules are ordered sensibly."""
+    from yolov6_amd import quant as Q
+    g = torch.Generator().manual_seed(0)
+    c = Q.HistogramCalibrator()
+    a = torch.randn(200000, generator=g)
+    c.collect(a)
+    w = c.edges[1] - c.edges[0]
+    assert len(c.hist) == 2048 and abs(c.hist.sum() - 200000) < 1
+    b = torch.cat([torch.randn(200000, generator=g), torch.tensor([37.5, -41.0])])     # two far outliers in the second batch
+    c.collect(b)
+    assert len(c.hist) > 2048 and abs((c.edges[1] - c.edges[0]) - w) < 1e-12 and c.edges[-1] >= 41.0
+    assert abs(c.hist.sum() - 400002) < 1
+    amax = float(torch.cat([a, b]).abs().max())
+    p100 = c.compute_amax("percentile", 100.0)
+    p9999 = c.compute_amax("percentile", 99.99)
+    ent = c.compute_amax("entropy")
+    mse = c.compute_amax("mse")
+    assert p100 >= amax - w and 3.0 < p9999 < 5.0          # 99.99 % of |N(0,1)| lies below 3.9
+    # (mse weighs the two outliers' squared clipping error against 400 000 values' rounding noise: it lands between the two)
+    assert 2.0 < ent < 8.0 and ent < amax / 4 and ent < mse < amax - 5.0
+    u = Q.HistogramCalibrator()
+    u.collect(torch.rand(400000, generator=g) * 6.0)
+    assert u.compute_amax("entropy") > 5.0 and u.compute_amax("mse") > 5.0 and u.compute_amax("percentile", 99.99) > 5.9
+    with pytest.raises(ValueError):
+        c.compute_amax("median")

@@ -6,7 +6,8 @@ skipped - configs/repopt/yolov6s_opt_qat.py:70-76).  None of that arithmetic is 
 on the HIP int8 kernels (include/yolov6_hip.h `y6_conv_i8_desc` holds the exact quantisation rule):
 
     model = build_model(cfg, nc, device).eval().half();  fuse_model(model);  switch_to_deploy ...
-    table = yolov6_amd.quant.calibrate(model, [batch0, batch1, ...])     # PTQ: max-calibration, on the device
+    table = yolov6_amd.quant.calibrate(model, [batch0, batch1, ...])     # PTQ: max-calibration, on the device; or the reference's
+                                                                         # recipe: method="histogram", histogram_amax_method="entropy"
     yolov6_amd.quant.quantize(model, table)                              # later forwards run the int8 plan
     yolov6_amd.quant.dequantize(model)                                   # back to fp16
 
@@ -150,12 +151,124 @@ def dequant_vector(amax, s_w):
     return ((a16 / 127.0) * s_w.float()).contiguous()
 
 
-def calibrate(model, batches):
-    """Max-calibration on the device: runs the fp16 plan of `model` over `batches` (NCHW image tensors on the GPU) with an
-    abs-max reduction (`y6_absmax`) over the input of every quantisable conv.  Returns the table (one float per conv, in
-    lowering order) to hand to `quantize`."""
+class HistogramCalibrator:
+    """|x| histogram of one activation tensor over the calibration batches and the three ways the reference's PTQ recipe turns
+    it into a clipping value (tools/qat/qat_utils.py:12-58 `collect_stats` / `compute_amax`, configs/repopt/yolov6s_opt_qat.py:
+    63-69: calib_method 'histogram', histogram_amax_method 'entropy' | 'percentile' | 'mse', percentile 99.99, 4 batches).
+    The arithmetic is `pytorch_quantization.calib.HistogramCalibrator`'s (NVIDIA's library, an un-vendored dependency of the
+    reference - requirements of tools/qat; not installed here): restated from its published source, PARITY UNPINNED.
+      collect:    2048 bins over [0, max] of the first batch; a later batch with a larger maximum appends bins of the SAME width.
+      percentile: the bin edge where the cumulative histogram reaches p %.
+      mse:        amax = the bin centre (from bin 128 on) whose 8-bit fake quantisation of all centres has the least
+                  count-weighted squared error.
+      entropy:    TensorRT's rule - for every candidate i >= 128: P = the first i bins with the outliers folded into the last,
+                  Q = P merged into 128 levels and spread back over its non-empty bins; amax = the edge of the LAST i that
+                  minimises KL(P || Q)."""
+
+    def __init__(self, num_bins=2048):
+        self.num_bins = int(num_bins)
+        self.hist = None      # float64 numpy
+        self.edges = None
+
+    def collect(self, x: torch.Tensor):
+        import numpy as np
+        x = x.detach().float().abs().flatten()
+        x_max = float(x.max())
+        if self.hist is None:
+            hi = x_max if x_max > 0 else 1.0
+            h = torch.histc(x, bins=self.num_bins, min=0.0, max=hi)
+            self.hist = h.double().cpu().numpy()
+            self.edges = np.linspace(0.0, hi, self.num_bins + 1)
+            return
+        if x_max > self.edges[-1]:
+            width = self.edges[1] - self.edges[0]
+            extra = int(np.ceil((x_max - self.edges[-1]) / width))
+            self.edges = np.concatenate([self.edges, self.edges[-1] + width * np.arange(1, extra + 1)])
+            self.hist = np.concatenate([self.hist, np.zeros(extra)])
+        h = torch.histc(x, bins=len(self.edges) - 1, min=0.0, max=float(self.edges[-1]))
+        self.hist = self.hist + h.double().cpu().numpy()
+
+    def compute_amax(self, method="entropy", percentile=99.99, num_bits=8, stride=1, start_bin=128):
+        if self.hist is None:
+            raise RuntimeError("yolov6_amd.quant: HistogramCalibrator.compute_amax before collect")
+        if method == "percentile":
+            return amax_percentile(self.hist, self.edges, percentile)
+        if method == "mse":
+            return amax_mse(self.hist, self.edges, num_bits, stride, start_bin)
+        if method == "entropy":
+            return amax_entropy(self.hist, self.edges, num_bits, stride, start_bin)
+        raise ValueError(f"yolov6_amd.quant: unknown histogram_amax_method {method!r} (entropy | percentile | mse)")
+
+
+def amax_percentile(hist, edges, percentile):
+    import numpy as np
+    if not 0 <= percentile <= 100:
+        raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
+    cdf = np.cumsum(hist / hist.sum())
+    idx = int(np.searchsorted(cdf, percentile / 100.0))
+    return float(edges[min(idx, len(edges) - 1)])
+
+
+def amax_mse(hist, edges, num_bits=8, stride=1, start_bin=128):
+    import numpy as np
+    centers = (edges[1:] + edges[:-1]) / 2.0
+    bound = float((1 << (num_bits - 1)) - 1)
+    best, best_i = None, None
+    for i in range(start_bin, len(centers), stride):
+        amax = centers[i]
+        scale = bound / amax
+        q = np.clip(np.round(centers * scale), -bound, bound) / scale      # fake_tensor_quant of the bin centres
+        mse = float((((q - centers) ** 2) * hist).mean())
+        if best is None or mse < best:
+            best, best_i = mse, i
+    return float(centers[best_i if best_i is not None else len(centers) - 1])
+
+
+def amax_entropy(hist, edges, num_bits=8, stride=1, start_bin=128):
+    import numpy as np
+    bins = np.array(hist, dtype=np.float64)
+    bins[0] = bins[1]
+    nlev = 1 << (num_bits - 1)                      # 128 magnitudes + sign
+    n = len(bins)
+    if n <= start_bin:
+        return float(edges[-1])
+    tail = np.concatenate([np.cumsum(bins[::-1])[::-1], [0.0]])      # tail[i] = sum(bins[i:])
+    best, best_i = None, None
+    for i in range(start_bin, n + 1, stride):
+        p = bins[:i].copy()
+        nz = p != 0
+        level = np.minimum((np.arange(i) * nlev) // i, nlev - 1)     # np.digitize(range(i), linspace(0, i, nlev + 1)) - 1
+        cnt = np.bincount(level[nz], weights=p[nz], minlength=nlev)
+        num = np.bincount(level[nz], minlength=nlev)
+        q = np.zeros(i)
+        q[nz] = (cnt / np.maximum(num, 1))[level[nz]]
+        p[i - 1] += tail[i]
+        ps, qs = p.sum(), q.sum()
+        if ps == 0 or qs == 0:
+            continue
+        p /= ps
+        q /= qs
+        m = p > 0
+        if np.any(q[m] == 0):
+            kl = np.inf
+        else:
+            kl = float(np.sum(p[m] * np.log(p[m] / q[m])))         # scipy.stats.entropy(p, q)
+        if best is None or kl <= best:                               # ties: the LAST minimum (len - 1 - argmin(reversed))
+            best, best_i = kl, i
+    return float(edges[best_i if best_i is not None else n])
+
+
+def calibrate(model, batches, method="max", histogram_amax_method="entropy", percentile=99.99):
+    """Activation scales of every quantisable conv, in lowering order - the table to hand to `quantize`.
+    method "max": abs-max reductions (`y6_absmax`) inserted into the fp16 plan, on the device (the reference's `MaxCalibrator`).
+    method "histogram": the reference's PTQ recipe (configs/repopt/yolov6s_opt_qat.py:63-69): the fp16 plan runs over
+    `batches` (NCHW image tensors on the GPU), the |x| histogram of every quantisable conv's input is collected on the device
+    (HistogramCalibrator) and turned into amax by `histogram_amax_method` ('entropy' - the recipe's choice - 'percentile' with
+    `percentile`, or 'mse')."""
     if model.training:
         raise RuntimeError("yolov6_amd.quant: calibrate a deploy-form model in .eval() mode")
+    if method not in ("max", "histogram"):
+        raise ValueError(f"yolov6_amd.quant: calib_method {method!r} (max | histogram)")
     batches = list(batches)
     if not batches:
         raise ValueError("yolov6_amd.quant: no calibration batches")
@@ -164,11 +277,22 @@ def calibrate(model, batches):
     model.__dict__["_y6_quant"] = st
     model.invalidate_plans()
     try:
+        calibs = {}
         for x in batches:
             plan = model.compile(x, autotune=False)
             plan.run()
+            if method == "histogram":
+                torch.cuda.synchronize()
+                # every activation of an inference plan is its own allocation: the conv inputs are still there after the run
+                for e in plan.op_log:
+                    if e.get("kind") == "absmax":
+                        calibs.setdefault(e["index"], HistogramCalibrator()).collect(e["x"].to_nhwc_tensor())
         torch.cuda.synchronize()
         table = st.read()
+        if method == "histogram":
+            if sorted(calibs) != list(range(len(table))):
+                raise RuntimeError("yolov6_amd.quant: the calibration plan does not expose every quantisable conv's input")
+            table = [calibs[i].compute_amax(histogram_amax_method, percentile) for i in range(len(table))]
     finally:
         if prev is None:
             model.__dict__.pop("_y6_quant", None)
