@@ -304,7 +304,9 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         }
         // (r04n: the same stores as 64-byte runs - each fragment transposed through a per-wave LDS scratch so that four adjacent
         // lanes hold one pixel's 64 B - took 22.9 k cycles per item instead of 12.9 k: the end-of-launch store burst, 26 MB from
-        // every block at once, is bound by the fabric's write bandwidth (7 us at 3.7 TB/s), not by the request count.  Removed.)
+        // every block at once, is bound by the fabric's write bandwidth (7 us at 3.7 TB/s), not by the request count.  Removed.
+        // r04w: cache-policy bits on these stores - sc1 / sc0 sc1 / nt sc1 (write-through) lose 5-7 % of the class, nt is level with the
+        // default write-back policy (profiles/r04/bench_r04w_st*.json).  Default kept.)
     };
 
     // prologue: the first stage of the first item, the first R - 1 weight fragments
