@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--train-autotune", action="store_true",
                     help="--mode train: choose the conv kernel variants by timing (per process: not reproducible) instead of from the layer shapes")
-    ap.add_argument("--event-every", type=int, default=4, help="record per-kernel hipEvents on every N-th timed step")
+    ap.add_argument("--event-every", type=int, default=16, help="record per-kernel hipEvents on every N-th timed step")
+    ap.add_argument("--inflight", type=int, default=2, help="steps in flight: step i runs on HIP stream i %% N with its own plan (1 = one at a time)")
     ap.add_argument("--dropin-steps", type=int, default=50, help="extra (separately timed) steps through the reference-"
                     "signature API: model(x) + non_max_suppression(); 0 disables")
     ap.add_argument("--no-verify", action="store_true", help="skip the NMS-vs-oracle self check (outside the timed region)")
@@ -63,9 +64,6 @@ def parse():
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the reported value is the median window")
     ap.add_argument("--no-fuse-candidates", action="store_true",
                     help="A/B: NMS selects its candidates itself (re-reads the prediction tensor) instead of the decode launch doing it")
-    ap.add_argument("--nms-stream", choices=("same", "side"), default=os.environ.get("Y6_BENCH_NMS_STREAM", "same"),
-                    help="same: forward and NMS of a batch back to back on one stream; side: the NMS of batch k runs on a second "
-                         "HIP stream while the forward of batch k+1 runs on the first (two result tensors, alternating)")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 64 if a.mode == "train" else 32
@@ -477,100 +475,104 @@ def main():
         cal = [_synth.synth_images(8, args.size, seed=100 + i).to(device).half() for i in range(4)]
         quant.quantize(model, quant.calibrate(model, cal))
     plan = model.compile(x, autotune=not args.no_autotune)
+    # --inflight N (default 2): N steps in flight.  Step i runs on HIP stream i % N with its own plan - its own activation buffers
+    # and NMS workspace, the same weights - so the launch ramps of one step (every kernel's prologue fetch, store burst and tail:
+    # ~10 us of a 26 us small-map launch) overlap the other step's kernels.  Every step is still one full forward +
+    # NMS of one b32 batch, the K steps of a window are all inside its barrier + synchronize bracket; `sequential` in the line
+    # is the same loop with one step at a time.
+    import copy
+    n_fly = max(1, args.inflight)
+    plans = [plan]
+    for _ in range(1, n_fly):
+        m2 = copy.deepcopy(model)           # (HipModule.__getstate__ leaves native plans behind: the copy compiles its own)
+        plans.append(m2.compile(x, autotune=not args.no_autotune))
     # the fused head tail selects the NMS candidates of its rows while they are in LDS (Plan.attach_nms: y6_nms's own first stage,
-    # same thresholds); y6_nms then starts at the sort.  Not with --nms-stream side: one candidate workspace per plan.
-    cand = None
-    if args.nms_stream != "side" and not args.no_fuse_candidates:
-        cand = plan.attach_nms(CONF, None, True)
+    # same thresholds); y6_nms then starts at the sort.
+    cands = [None if args.no_fuse_candidates else p.attach_nms(CONF, None, True) for p in plans]
+    cand = cands[0]
 
-    def step(timed=False):
-        det = plan.run_timed() if timed else plan.run()
-        return nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
+    def pick_streams(n):
+        """n streams that really run side by side: HIP streams share a few hardware queues, and two streams on one queue do not
+        overlap.  Candidates are timed pairwise on a few steps; the first is kept, each further one is the best partner found."""
+        pool = [torch.cuda.Stream() for _ in range(max(n, 6 if n > 1 else 1))]
+        if n == 1:
+            return pool[:1]
+        def trial(ss):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(12):
+                with torch.cuda.stream(ss[i % len(ss)]):
+                    d = plans[i % len(ss)].run()
+                    nms_raw(d, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[i % len(ss)])
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        chosen = [pool[0]]
+        for _ in range(1, n):
+            rest = [q for q in pool if q not in chosen]
+            for q in rest:
+                trial(chosen + [q])                              # warm
+            best = min(rest, key=lambda q: min(trial(chosen + [q]) for _ in range(2)))
+            chosen.append(best)
+        return chosen
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    # Per-kernel hipEvents are recorded live inside the timed region, on every `--event-every`-th step (default 4):
-    # 75 event packets per pass cost 0.21 ms of a 3.2 ms step (tools/graph_ab.py, r13), so instrumenting every
-    # step would tax the headline number by 6 %.  All K steps run the same kernels on the same stream.
+    # Per-kernel hipEvents are recorded live inside the timed region, on every `--event-every`-th step (default 16), on plan 0:
+    # 75 event packets per pass cost 0.21 ms of a step (tools/graph_ab.py, r13).  A sampled step runs ALONE (the other streams
+    # wait for it and it waits for them), in plan order on one stream: `roofline.achieved` is the kernel by itself.
     ev_every = max(1, args.event_every)
+    if ev_every % n_fly:
+        ev_every += n_fly - ev_every % n_fly                       # sampled steps fall on plan 0
     sampled = [i for i in range(args.steps) if i % ev_every == 0]
     n_win = max(1, args.windows)
     plan.timing_begin(n_win * len(sampled))
     nms_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_win * len(sampled))]
+    state = {"k": 0, "det": None, "out": None}
 
-    # --nms-stream side: a two-deep software pipeline over batches.  The forward plan writes its [B,A,85] result into two
-    # tensors in turn (Plan.rebind_output); the NMS of batch k is enqueued on a second stream behind an event recorded after
-    # forward k, and forward k+2 (the next writer of that tensor) waits for the event recorded after NMS k.  Every batch
-    # still gets its full forward + NMS inside the timed region (both streams are drained before the clock stops); only
-    # the one-block-per-image NMS sweep no longer leaves the other CUs idle.
-    side = args.nms_stream == "side"
-    fwd_stream = torch.cuda.current_stream()
-    nms_stream = torch.cuda.Stream() if side else fwd_stream
-    ring = [plan.outputs, torch.empty_like(plan.outputs)] if side else [plan.outputs]
-    fwd_done = [torch.cuda.Event() for _ in ring]
-    nms_done = [None for _ in ring]
-
-    def pipelined_step(i, timed):
-        slot = i % len(ring)
-        if side:
-            if nms_done[slot] is not None:
-                fwd_stream.wait_event(nms_done[slot])      # the NMS that still reads this result tensor (two batches ago)
-            plan.rebind_output(ring[slot])
-        det = plan.run_timed() if timed else plan.run()
-        if not side:
-            return det, nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
-        fwd_done[slot].record(fwd_stream)
-        with torch.cuda.stream(nms_stream):
-            nms_stream.wait_event(fwd_done[slot])
-            out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
-            nms_done[slot] = torch.cuda.Event()
-            nms_done[slot].record(nms_stream)
-        return det, out
-
-    if side:
-        for i in range(4):
-            pipelined_step(i, False)
-        torch.cuda.synchronize()
-        nms_done = [None for _ in ring]
-
-    # Three windows (--windows) of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and reduced
-    # with MAX over the ranks; `value` comes from the median window, the others are reported as the spread (a 0.05 s region on
-    # a power-managed chip moves by several per cent from one window to the next).
-    k = 0
-    elapsed_w = []
-    for w in range(n_win):
+    def run_window(streams, sample):
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over the ranks."""
+        n = len(streams)
+        done = [None] * n
         rep.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            if i % ev_every == 0:
-                if side:
-                    slot = i % len(ring)
-                    if nms_done[slot] is not None:
-                        fwd_stream.wait_event(nms_done[slot])
-                    plan.rebind_output(ring[slot])
-                    det = plan.run_timed()
-                    fwd_done[slot].record(fwd_stream)
-                    with torch.cuda.stream(nms_stream):
-                        nms_stream.wait_event(fwd_done[slot])
-                        nms_ev[k][0].record()
-                        out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
-                        nms_ev[k][1].record()
-                        nms_done[slot] = torch.cuda.Event()
-                        nms_done[slot].record(nms_stream)
+            j = i % n
+            st = streams[j]
+            timed = sample and i % ev_every == 0
+            with torch.cuda.stream(st):
+                if timed:
+                    for e in done:
+                        if e is not None:
+                            st.wait_event(e)
+                    det = plans[0].run_timed()
+                    nms_ev[state["k"]][0].record()
+                    out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[0])
+                    nms_ev[state["k"]][1].record()
+                    state["k"] += 1
                 else:
-                    det = plan.run_timed()
-                    nms_ev[k][0].record()
-                    out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cand)
-                    nms_ev[k][1].record()
-                k += 1
-            else:
-                det, out = pipelined_step(i, False)
-        torch.cuda.synchronize()          # drains both streams
+                    if sample and (i - 1) % ev_every == 0 and n > 1 and done[(i - 1) % n] is not None:
+                        st.wait_event(done[(i - 1) % n])       # the sampled step before this one runs alone
+                    det = plans[j].run()
+                    out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[j])
+                done[j] = torch.cuda.Event()
+                done[j].record(st)
+        torch.cuda.synchronize()          # drains every stream
         rep.barrier()
-        elapsed_w.append(rep.max_over_ranks(time.perf_counter() - t0))
+        state["det"], state["out"] = det, out
+        return rep.max_over_ranks(time.perf_counter() - t0)
+
+    streams = pick_streams(n_fly)
+    for i in range(max(args.warmup, n_fly)):
+        with torch.cuda.stream(streams[i % n_fly]):
+            d = plans[i % n_fly].run()
+            nms_raw(d, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[i % n_fly])
+    torch.cuda.synchronize()
+    # Three windows (--windows) of EXACTLY K steps each; `value` comes from the median window, the others are reported as the
+    # spread (a short region on a power-managed chip moves by several per cent from one window to the next).
+    elapsed_w = [run_window(streams, True) for _ in range(n_win)]
     elapsed = sorted(elapsed_w)[len(elapsed_w) // 2]
+    det, out = state["det"], state["out"]
+    # the same K steps one at a time (one stream, one plan, no event sampling): what a caller that waits for every result gets
+    seq_elapsed = run_window(streams[:1], False) if n_fly > 1 else None
 
     rows = plan.timing_read()
     nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / len(nms_ev)
@@ -631,6 +633,11 @@ def main():
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "inflight": n_fly,
+            "sequential": (None if seq_elapsed is None else
+                           {"value": round(rep.throughput(args.batch, args.steps, seq_elapsed), 2), "unit": "images/sec",
+                            "ms_per_step": round(seq_elapsed / args.steps * 1e3, 4),
+                            "what": "the same K steps one at a time: one stream, one plan, each step enqueued behind the previous one"}),
             "windows": {"n": n_win, "ms_per_step": [round(e / args.steps * 1e3, 4) for e in elapsed_w], "value_from": "median window",
                         "spread_pct": round((max(elapsed_w) - min(elapsed_w)) / elapsed * 100.0, 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -638,9 +645,9 @@ def main():
             "config": {"workload": f"{args.model} {args.size}x{args.size} b{args.batch}/GPU {'int8' if args.int8 else 'fp16'} inference: "
                                    "forward (deploy form) + NMS conf 0.03 / IoU 0.65 / multi-label / max_det 300; timed through the "
                                    "plan API (model.compile(x) once, then plan.run() + nms_raw() per step: no output clone, no host "
-                                   "sync per step)" + ("; two-deep pipeline over batches: the NMS of batch k on a second HIP stream beside "
-                                                       "the forward of batch k+1 (two result tensors in turn), both streams drained "
-                                                       "inside the timed region" if side else "") +
+                                   "sync per step)" + (f"; {n_fly} steps in flight: step i on HIP stream i % {n_fly} with its own plan (own activation "
+                                                       "buffers and NMS workspace, the same weights), every stream drained inside the timed "
+                                                       "region; one step at a time: see `sequential`" if n_fly > 1 else "") +
                                    ("; the forward's ops off its critical path (neck laterals, SPPF bypass, early head levels) run on "
                                     "the plan's second HIP stream, ordered by events" if getattr(plan, "sched", None) else "") +
                                    "; the reference-signature API step is reported under dropin_api",
@@ -661,7 +668,7 @@ def main():
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0,
                               "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0}
                           for k, v in sorted(by_class.items())},
-            "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1), "stream": args.nms_stream,
+            "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1),
                     "candidates_from": "decode launch (y6_nms_sink)" if cand is not None else "nms first stage"},
             "dropin_api": dropin,
             "self_check": {"nms_equals_oracle_images": verified},
