@@ -491,29 +491,15 @@ def main():
     cands = [None if args.no_fuse_candidates else p.attach_nms(CONF, None, True) for p in plans]
     cand = cands[0]
 
-    def pick_streams(n):
-        """n streams that really run side by side: HIP streams share a few hardware queues, and two streams on one queue do not
-        overlap.  Candidates are timed pairwise on a few steps; the first is kept, each further one is the best partner found."""
-        pool = [torch.cuda.Stream() for _ in range(max(n, 6 if n > 1 else 1))]
-        if n == 1:
-            return pool[:1]
-        def trial(ss):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for i in range(12):
-                with torch.cuda.stream(ss[i % len(ss)]):
-                    d = plans[i % len(ss)].run()
-                    nms_raw(d, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[i % len(ss)])
-            torch.cuda.synchronize()
-            return time.perf_counter() - t
-        chosen = [pool[0]]
-        for _ in range(1, n):
-            rest = [q for q in pool if q not in chosen]
-            for q in rest:
-                trial(chosen + [q])                              # warm
-            best = min(rest, key=lambda q: min(trial(chosen + [q]) for _ in range(2)))
-            chosen.append(best)
-        return chosen
+    def stream_trial(ss):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(12):
+            with torch.cuda.stream(ss[i % len(ss)]):
+                d = plans[i % len(ss)].run()
+                nms_raw(d, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[i % len(ss)])
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
 
     # Per-kernel hipEvents are recorded live inside the timed region, on every `--event-every`-th step (default 16), on plan 0:
     # 75 event packets per pass cost 0.21 ms of a step (tools/graph_ab.py, r13).  A sampled step runs ALONE (the other streams
@@ -560,7 +546,8 @@ def main():
         state["det"], state["out"] = det, out
         return rep.max_over_ranks(time.perf_counter() - t0)
 
-    streams = pick_streams(n_fly)
+    from yolov6_amd.pipeline import pick_streams   # (two streams on one hardware queue do not overlap: pairs are timed)
+    streams = pick_streams(n_fly, stream_trial)
     for i in range(max(args.warmup, n_fly)):
         with torch.cuda.stream(streams[i % n_fly]):
             d = plans[i % n_fly].run()

@@ -1,0 +1,100 @@
+"""Throughput inference with N batches in flight.
+
+A forward pass is ~60 dependent kernel launches, and every launch has ramps - the first fetch of every block at once, the store
+burst at the end, the tail while the last blocks finish - during which most of the chip idles (~10 us of a 26 us
+small-map launch).  Consecutive layers cannot overlap them (data dependence); consecutive BATCHES can: `InflightRunner` keeps N
+plans of the same model (own activation buffers and NMS workspace, the same weights) on N HIP streams and hands batch i to plan
+i % N.  Measured on one MI355X, YOLOv6-S 640^2 b32 fp16 forward + NMS: 13 961 -> 15 730 img/s with N = 2 (bench.py, r04y).
+
+The reference's eval loop (yolov6/core/evaler.py:98-120: `outputs = model(imgs)`; `non_max_suppression(outputs, ...)`; convert to
+COCO json) is one batch at a time because the host consumes every result before the next forward; a caller that can defer the
+host side by one batch gets the overlap:
+
+    run = InflightRunner(model, example_batch, depth=2, conf_thres=0.03, iou_thres=0.65, multi_label=True)
+    pending = None
+    for imgs in loader:
+        ticket = run.submit(imgs)            # enqueues forward + NMS of this batch, returns at once
+        if pending is not None:
+            dets, counts = pending.result()  # waits for the PREVIOUS batch only
+            ...
+        pending = ticket
+"""
+import copy
+import time
+
+import torch
+
+from .utils.nms import nms_raw
+
+
+class Ticket:
+    def __init__(self, det, dets, index, count, event):
+        self.det, self.dets, self.index, self.count, self._event = det, dets, index, count, event
+
+    def result(self):
+        """Per-image detection lists as `non_max_suppression` returns them (one host synchronisation on this batch's event)."""
+        self._event.synchronize()
+        counts = self.count.tolist()
+        return [self.dets[i, :n] for i, n in enumerate(counts)], counts
+
+
+class InflightRunner:
+    def __init__(self, model, example, depth=2, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                 max_det=300, autotune=True):
+        if depth < 1:
+            raise ValueError("yolov6_amd.pipeline: depth >= 1")
+        self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, multi_label=multi_label,
+                       max_det=max_det)
+        self.models = [model] + [copy.deepcopy(model) for _ in range(depth - 1)]   # HipModule.__getstate__: copies compile their own plans
+        self.plans = [m.compile(example, autotune=autotune) for m in self.models]
+        self.inputs = [example] + [torch.empty_like(example) for _ in range(depth - 1)]
+        for p, x in zip(self.plans[1:], self.inputs[1:]):
+            p.bind_inputs([x])
+        self.tokens = [p.attach_nms(conf_thres, classes, multi_label) for p in self.plans]
+        self.streams = pick_streams(depth, self._trial)
+        self.done = [None] * depth
+        self.i = 0
+
+    def _trial(self, streams):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(12):
+            j = i % len(streams)
+            with torch.cuda.stream(streams[j]):
+                det = self.plans[j].run()
+                nms_raw(det, candidates=self.tokens[j], **self.kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def submit(self, x: torch.Tensor) -> Ticket:
+        """Enqueue forward + NMS of one batch (same shape / dtype as the example).  The slot's previous batch must have been
+        consumed (`Ticket.result()`) or be older than `depth` submissions: its tensors are overwritten."""
+        j = self.i % len(self.plans)
+        self.i += 1
+        st = self.streams[j]
+        st.wait_stream(torch.cuda.current_stream())          # x was produced on the caller's stream
+        with torch.cuda.stream(st):
+            if x.data_ptr() != self.inputs[j].data_ptr():
+                self.inputs[j].copy_(x, non_blocking=True)
+            det = self.plans[j].run()
+            dets, index, count = nms_raw(det, candidates=self.tokens[j], **self.kw)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self.done[j] = ev
+        return Ticket(det, dets, index, count, ev)
+
+
+def pick_streams(n, trial):
+    """n HIP streams that really run side by side.  HIP streams share a few hardware queues, and two streams on one queue do not
+    overlap: candidates are timed (trial(streams) -> seconds for a few steps round-robin over them); the first is kept, each
+    further one is the best partner found."""
+    pool = [torch.cuda.Stream() for _ in range(max(n, 6 if n > 1 else 1))]
+    if n == 1:
+        return pool[:1]
+    chosen = [pool[0]]
+    for _ in range(1, n):
+        rest = [q for q in pool if q not in chosen]
+        for q in rest:
+            trial(chosen + [q])                              # warm
+        chosen.append(min(rest, key=lambda q: min(trial(chosen + [q]) for _ in range(2))))
+    return chosen
