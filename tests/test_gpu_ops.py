@@ -121,7 +121,7 @@ def test_conv_dma_fast_epilogue_with_post_affine():
 def test_conv_wreg_variants():
     """The register-fed 3x3 kernels (csrc/conv_wreg.hip: weight fragments global -> VGPR, halo in 32-channel LDS stages): several
     items per block (stage ping-pong and weight ring across items), one / two / eight stages per item, one / two cout blocks,
-    tile overhang on both axes, the 64-cout form; then the epilogue modes (SiLU, kept post-affine, BottleRep residual) and a
+    tile overhang on both axes; then the epilogue modes (SiLU, kept post-affine, BottleRep residual) and a
     view with a channel offset on both sides."""
     names = G.variant_names()
     wreg = [v for v, n in enumerate(names) if n.startswith("wreg") and not n.startswith("wregs2")]
@@ -141,7 +141,7 @@ def test_conv_wreg_variants():
             err = G.max_rel(G.nhwc_to_nchw_f32(o), ref)
             assert err < TOL, f"{names[v]}: max rel err {err:.3e} on {(Cin, Cout, H, W, B)}"
             ran += 1
-        assert ran >= (2 if Cout % 128 == 0 else 1), (Cin, Cout, ran)
+        assert ran >= (2 if Cout % 128 == 0 else 0), (Cin, Cout, ran)   # (64-cout layers have no register-fed form: the LDS-DMA kernels keep them)
     # epilogue modes
     B, H, W, Cin, Cout = 5, 40, 40, 64, 128
     x = G.rand_nhwc(B, H, W, Cin, seed=43)

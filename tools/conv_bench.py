@@ -21,7 +21,7 @@ from yolov6_amd.engine import PlanBuilder, TRef  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", nargs="+", default=["256,256,3,1,40,40,32"])
-    ap.add_argument("--variants", nargs="*", type=int, default=None)
+    ap.add_argument("--variants", nargs="*", default=None, help="variant names (wreg_p7 ...) or indices")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--data", default="rand", choices=["rand", "relu", "zeros"],
@@ -41,7 +41,8 @@ def main():
         w = torch.randn((cout, cin, k, k)) / (cin * k * k) ** 0.5
         b = torch.randn((cout,)) * 0.1
         xr = TRef(x, B, H, W, cin, cin, 0)
-        for v in (a.variants if a.variants else range(1, len(names))):
+        chosen = [names.index(v) if v in names else int(v) for v in a.variants] if a.variants else range(1, len(names))
+        for v in chosen:
             pb = PlanBuilder(dev)
             pb.force_variant = v
             try:

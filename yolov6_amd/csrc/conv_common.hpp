@@ -452,6 +452,7 @@ struct VariantCfg {
     int hc = 16;     // dma kernels: input channels per chunk
     int cs = 1;      // dma kernels: the conv stride they are built for
     int wres = 0;    // dma kernels: 1 = the block's tap images stay in LDS for all its work items (Cin <= 64)
+    int i8only = 0;  // a tile geometry only the int8 path uses (y6_conv_i8): never offered to fp16 convs
 };
 
 struct Launch {

@@ -715,10 +715,7 @@ template <bool I8>
 int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int hc, int stride, int wres, hipStream_t s) {
     if (wres) {
         if constexpr (!I8) {
-            if (stride == 1 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) {
-                if (hc == 16) return launch_dma<2, 2, 8, 2, 2, 1, 16, false, 1, true>(L, s);
-                if (hc == 32) return launch_dma<2, 2, 8, 2, 2, 1, 32, false, 1, true>(L, s);
-            }
+            if (stride == 1 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8 && hc == 32) return launch_dma<2, 2, 8, 2, 2, 1, 32, false, 1, true>(L, s);
         }
         y6_set_error("conv_dma: no resident-weight instantiation c%dp%d x %d waves, %d-channel chunks", cf, pf, nw, hc);
         return Y6_EUNSUPPORTED;
@@ -732,22 +729,16 @@ int launch_dma_cfg(const Launch& L, int cf, int pf, int nw, int stg, int il, int
         y6_set_error("conv_dma: no stride-2 instantiation c%dp%d x %d waves", cf, pf, nw);
         return Y6_EUNSUPPORTED;
     }
-    if (hc == 16 && stg == 2 && il == 1) {
-        if (cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, 16, I8>(L, s);
-        if (cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, 16, I8>(L, s);
-    }
-    if (hc == 32 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, I8>(L, s);
-    if constexpr (!I8) {
+    if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 4) return launch_dma<2, 2, 4, 2, 2, 1, 16, I8>(L, s);
+    if constexpr (I8) {   // the 8-wave 512-pixel geometries: int8 only since round 4
+        if (hc == 16 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 4, 2, 1, 16, true>(L, s);
+        if (hc == 32 && stg == 2 && il == 1 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 1, 32, true>(L, s);
+    } else {
         if (hc == 16 && stg == 2 && il == 1) {
             if (cf == 2 && pf == 1 && nw == 4) return launch_dma<2, 1, 4, 3, 2, 1, 16, false>(L, s);
             if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 16, false>(L, s);
             if (cf == 4 && pf == 1 && nw == 8) return launch_dma<4, 1, 8, 2, 2, 1, 16, false>(L, s);
-            if (cf == 2 && pf == 4 && nw == 4) return launch_dma<2, 4, 4, 2, 2, 1, 16, false>(L, s);
         }
-        if (hc == 32 && stg == 2 && il == 1) {
-            if (cf == 1 && pf == 2 && nw == 4) return launch_dma<1, 2, 4, 2, 2, 1, 32, false>(L, s);
-        }
-        if (hc == 32 && stg == 2 && il == 3 && cf == 2 && pf == 2 && nw == 8) return launch_dma<2, 2, 8, 2, 2, 3, 32, false>(L, s);
     }
     y6_set_error("conv_dma: no instantiation c%dp%d x %d waves, %d stages, il %d, %d-channel chunks", cf, pf, nw, stg, il, hc);
     return Y6_EUNSUPPORTED;

@@ -417,266 +417,6 @@ __global__ __launch_bounds__(256, (CF * PF <= 4 ? 2 : 1)) void conv_i8_kernel(co
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// Persistent, chunk-granular variant (3x3 only).  What the r03-r08 counters and the s_memtime trace
-// (tools/conv_trace.py; numbers in DESIGN.md §6) showed for the per-tap kernel above and the first persistent cuts:
-//   * per-tap barriers + in-order vmcnt waits parked the waves ~50 % of the time;
-//   * every 1 KiB LDS-DMA piece costs 100-185 cycles of ISSUE time in the wave that issues it
-//     (nine pieces + the halo loads = ~2500 cycles per chunk against 2304 cycles of MFMA);
-//   * a per-element `switch(act)` epilogue cost ~4000 cycles per fragment.
-// Here
-//   * a block walks a strided list of (tile, cout-block) items;
-//   * the unit of staging is a 32-channel CHUNK: its halo AND all nine tap weight images are fetched
-//     with plain 16-byte global loads into registers one whole chunk ahead (across item boundaries
-//     too) - hipcc tracks them, no manual vmcnt - and written to LDS at the chunk boundary;
-//     the weight image of (cout fragment, chunk) is 18 KiB CONTIGUOUS in the packed weights, so the
-//     staging is a straight copy into the LDS layout [cf][tap][ks][lane][16 B];
-//   * inside a chunk there is NO barrier: 18 k-steps of ds_read + MFMA the compiler pipelines;
-//   * two barriers per chunk: "everyone done reading" -> LDS writes -> "published".
-template <int CF, int PF, int ST>
-__global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvKArgs a) {   // 2 waves/SIMD: <= 256 VGPR+AGPR
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KS = 3, NT = 9;
-    constexpr int WQ = CF * NT * 2 * 64;         // 16-byte units of one chunk's weight image (CF x 18 KiB)
-    constexpr int NWR = (WQ + 255) / 256;        // ... per thread
-    constexpr int MAXHP = HaloCap<KS, ST, PF>::value;
-    constexpr int NP = (MAXHP * 4 + 255) / 256;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    char* ldsA = smem;
-    char* ldsW = smem + a.ldsA_bytes;
-    const int nids = a.nids;
-    const int gstride = gridDim.x;
-
-    auto decode = [&](int id, int& tile, int& cb) {
-        if (a.ncb == 1) {
-            tile = id;
-            cb = 0;
-        } else {
-            const int lo = id & 7, r = id >> 3;
-            cb = r % a.ncb;
-            tile = (r / a.ncb) * 8 + lo;
-        }
-    };
-    auto next_valid = [&](int id) {
-        for (id += gstride; id < nids; id += gstride) {
-            int t, c;
-            decode(id, t, c);
-            if (t < a.ntiles) break;
-        }
-        return id;
-    };
-
-    int id = blockIdx.x;
-    {
-        int t, c;
-        decode(id, t, c);
-        if (t >= a.ntiles) id = next_valid(id);
-    }
-    if (id >= nids) return;
-
-    const int npieces = a.HH * a.HWd * 4;
-    int goff[NP];
-    auto setup_goff = [&](int item) {
-        int tile, cbx;
-        decode(item, tile, cbx);
-        const int tx_i = tile % a.tiles_x;
-        const int t2 = tile / a.tiles_x;
-        const int ty_i = t2 % a.tiles_y;
-        const int b = t2 / a.tiles_y;
-        const int iy0 = ty_i * a.TH * ST - 1, ix0 = tx_i * a.TW * ST - 1;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
-            int g = -2;
-            if (idx < npieces) {
-                const int hp = idx >> 2, q = idx & 3;
-                const int hy = hp / a.HWd, hx = hp - hy * a.HWd;
-                const int iy = iy0 + hy, ix = ix0 + hx;
-                const bool v = (iy >= 0) && (iy < a.H) && (ix >= 0) && (ix < a.W);
-                g = v ? (((b * a.H + iy) * a.W + ix) * a.in_cs + a.in_co + q * 8) : -1;
-            }
-            goff[i] = g;
-        }
-    };
-    int pixoff[PF], opix[PF], cb = 0;
-    auto setup_pix = [&](int item) {
-        int tile;
-        decode(item, tile, cb);
-        const int tx_i = tile % a.tiles_x;
-        const int t2 = tile / a.tiles_x;
-        const int ty_i = t2 % a.tiles_y;
-        const int b = t2 / a.tiles_y;
-        const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
-#pragma unroll
-        for (int pf = 0; pf < PF; ++pf) {
-            const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
-            const int npx = a.TH * a.TW;
-            bool v = m < npx;
-            const int mm = v ? m : npx - 1;
-            const int ty = mm / a.TW, tx = mm - ty * a.TW;
-            const int oy = oy0 + ty, ox = ox0 + tx;
-            v = v && (oy < a.Ho) && (ox < a.Wo);
-            pixoff[pf] = ((ty * ST) * a.HWd + tx * ST) * PIXB + (lane >> 5) * 16;
-            opix[pf] = v ? (b * a.Ho + oy) * a.Wo + ox : -1;
-        }
-    };
-    auto load_A = [&](int chunk, uint4 (&regs)[NP]) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            const int q = (tid + i * 256) & 3;
-            if (goff[i] >= 0 && (chunk * 32 + q * 8) < a.Cin)
-                v = *reinterpret_cast<const uint4*>(a.in + goff[i] + chunk * 32);
-            regs[i] = v;
-        }
-    };
-    auto store_A = [&](const uint4 (&regs)[NP]) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < npieces) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = regs[i];
-        }
-    };
-    // weights of (item, chunk): CF contiguous 18 KiB blocks -> registers (16 B per thread per step)
-    auto load_W = [&](int item, int chunk, uint4 (&regs)[NWR]) {
-        int wt, wcb;
-        decode(item, wt, wcb);
-#pragma unroll
-        for (int j = 0; j < NWR; ++j) {
-            const int q = tid + j * 256;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (q < WQ) {
-                const int cf = q / (NT * 2 * 64), r = q - cf * (NT * 2 * 64);
-                const size_t cfg = (size_t)wcb * CF + cf;
-                v = *reinterpret_cast<const uint4*>(a.wpk + ((cfg * a.nchunk + chunk) * (NT * 2 * 64) + r) * 8);
-            }
-            regs[j] = v;
-        }
-    };
-    auto store_W = [&](const uint4 (&regs)[NWR]) {
-#pragma unroll
-        for (int j = 0; j < NWR; ++j) {
-            const int q = tid + j * 256;
-            if (q < WQ) *reinterpret_cast<uint4*>(ldsW + q * 16) = regs[j];
-        }
-    };
-
-    // optional s_memtime trace of block 0 / thread 0 (tools/conv_trace.py, env Y6_CONV_TRACE)
-    int dbg_n = 0;
-    const bool tracing = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
-#define Y6_TRACE(tag)                                                        \
-    do {                                                                     \
-        if (tracing && dbg_n < 256) {                                        \
-            a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                 \
-            a.dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                \
-            ++dbg_n;                                                         \
-        }                                                                    \
-    } while (0)
-    Y6_TRACE(1);
-    setup_goff(id);
-    setup_pix(id);
-    uint4 areg[NP];
-    uint4 wreg[NWR];
-    load_A(0, areg);
-    load_W(id, 0, wreg);
-    store_A(areg);
-    store_W(wreg);
-    __syncthreads();
-    Y6_TRACE(2);
-
-    int item_parity = 0;
-    while (true) {
-        f32x16_t acc[CF][PF];
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-            for (int pf = 0; pf < PF; ++pf)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cf][pf][r] = 0.f;
-        // bias of this item's couts -> LDS (double-buffered by item parity); holding 16*CF floats in
-        // registers across the chunk loop tipped the kernel into spilling
-        float* lbias = reinterpret_cast<float*>(ldsW + WQ * 16) + (item_parity ? CF * 32 : 0);
-        if (tid < CF * 32) {
-            const int c = cb * CF * 32 + tid;
-            lbias[tid] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
-        }
-        const int nid = next_valid(id);
-        for (int chunk = 0; chunk < a.nchunk; ++chunk) {
-            const bool last = (chunk + 1) == a.nchunk;
-            const bool have_next = !last || nid < nids;
-            if (have_next) {  // request everything the NEXT chunk needs, a whole chunk of MFMAs ahead
-                if (last) setup_goff(nid);           // the current item's table is dead from here
-                load_A(last ? 0 : chunk + 1, areg);
-                load_W(last ? nid : id, last ? 0 : chunk + 1, wreg);
-            }
-            Y6_TRACE(10);   // prefetch issued
-            // Two-stage software pipeline over the nine taps: the fragments of tap t+1 are requested from
-            // LDS BEFORE tap t's MFMAs are issued, so the reads complete in the shadow of the matrix pipe.
-            // sched_barrier(0) keeps hipcc from hoisting further ahead (it otherwise pre-loads the whole
-            // chunk and spills: 377 registers without).
-            const char* wb = ldsW + lane * 16;
-            h8_t fa[2][2][CF], fb[2][2][PF];
-            auto ldfrag = [&](int t, int buf) {
-                const int tapoff = ((t / KS) * a.HWd + (t % KS)) * PIXB;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf)
-                        fa[buf][ks][cf] = *reinterpret_cast<const h8_t*>(wb + ((cf * NT + t) * 2 + ks) * 1024);
-#pragma unroll
-                    for (int pf = 0; pf < PF; ++pf)
-                        fb[buf][ks][pf] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + tapoff + ks * 32);
-                }
-            };
-            ldfrag(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT) ldfrag(t + 1, (t + 1) & 1);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-                        for (int pf = 0; pf < PF; ++pf)
-                            acc[cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[t & 1][ks][cf], fb[t & 1][ks][pf],
-                                                                                 acc[cf][pf], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            Y6_TRACE(11);   // 18 k-steps of ds_read + MFMA issued
-            if (have_next) {
-                __syncthreads();   // everyone is done reading this chunk's halo and weights
-                Y6_TRACE(14);
-                store_A(areg);
-                store_W(wreg);
-                __syncthreads();   // next chunk published
-                Y6_TRACE(15);
-            }
-        }
-        if (a.nchunk == 1 && nid >= nids) __syncthreads();   // no chunk barrier has published lbias yet
-        BiasRegs<CF> bz;
-#pragma unroll
-        for (int cf = 0; cf < CF; ++cf)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 t = *reinterpret_cast<const float4*>(lbias + cf * 32 + 8 * g + 4 * (lane >> 5));
-                bz.v[cf][g * 4 + 0] = t.x;
-                bz.v[cf][g * 4 + 1] = t.y;
-                bz.v[cf][g * 4 + 2] = t.z;
-                bz.v[cf][g * 4 + 3] = t.w;
-            }
-        conv_epilogue<CF, PF>(a, acc, opix, cb, 0, lane, bz);
-        Y6_TRACE(20);       // epilogue issued
-        if (nid >= nids) break;
-        id = nid;
-        item_parity ^= 1;
-        setup_pix(id);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // v3: pipelined persistent kernel (3x3 stride 1).  tools/mfma_ceiling.hip shows what LDS-fed MFMA loops
 // sustain on this box (1.4-1.9 PFLOP/s); the s_memtime traces of the kernels above show where they lose
@@ -706,6 +446,16 @@ template <int BP>
 struct PipeHaloCap {   // halo pixels (3x3 stride 1) of the largest tile shape offered for BP output pixels
     static constexpr int value = BP <= 128 ? 208 : (BP <= 256 ? 352 : (BP <= 512 ? 660 : 1190));
 };
+
+// s_memtime trace of block 0 / thread 0 (tools/conv_trace.py, env Y6_CONV_TRACE): the kernel declares `tracing` and `dbg_n`
+#define Y6_TRACE(tag)                                                        \
+    do {                                                                     \
+        if (tracing && dbg_n < 256) {                                        \
+            a.dbg[2 * dbg_n] = __builtin_amdgcn_s_memtime();                 \
+            a.dbg[2 * dbg_n + 1] = (unsigned long long)(tag);                \
+            ++dbg_n;                                                         \
+        }                                                                    \
+    } while (0)
 
 // NW waves per block: 4 (two blocks per CU) or 8 (one block per CU, twice the pixels sharing one weight image)
 // ST = 2 (stride-2 3x3): the halo is stored with its even and odd columns de-interleaved -
@@ -1128,44 +878,40 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
     }
 }
 
-// index 0 is the naive kernel (conv_misc.hip); 1-6 one block per (tile, cout block), barrier per tap;
-// 7-9 persistent chunk-granular; 10-14 persistent, pipelined fill (3x3 stride 1 only)
+// The kernel forms a conv op can run on (index = the `variant` of y6_conv_desc; NAMES are the stable handle: autotune caches,
+// the default candidate set and the tools use them).  Round 4 retired the forms no committed autotune log picked since round 2
+// (the chunk-granular persistent kernel pers_*, the 8-wave / 3-stage / 4-fragment pipe forms, dma8_c2p2, the 32-channel-chunk
+// dmaw* forms, dmar8_c2p2, dma_c2p4, the 64-cout register-fed form): git history has them.
+//   naive                      conv_misc.hip, cross-check only
+//   mfma_c{1,2,4}p{1,2}        one block per (tile, cout block), barrier per tap: 1x1, 3x3 stride 2, convT scatter, odd shapes
+//   pipe_c2p2 / c2p1 / c1p2    round 1's persistent 3x3 stride-1 kernel (residual / ragged-channel / narrow layers: the
+//                              data-gradient convs of the first stages have 32 couts)
+//   stream1x1_c1 / _c2         streaming 1x1 (Cin 64 / 128 / 256)
+//   dma_c2p2 / c2p1 / c1p2, dma8_c4p1, dmarw8_c2p2 (resident weights, Cin <= 64), dmas2_c2p1 / dma8s2_c2p1 / dma8s2_c4p1
+//                              LDS-DMA fed 3x3 kernels (conv_dma.hip); depth = LDS stages, hc = channels per chunk, cs = stride
+//   wreg_p{4,5,6,7}, wregs2_p{3,4}   weights through registers, halo in 32-channel LDS stages (conv_wreg.hip), stride 1 / 2:
+//                              cf = waves along the couts (32 each), pf = pixel fragments per wave, two 4-wave blocks per CU
 const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
-    {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"}, {1, 1, 1, "pers_c1p1"},
-    {2, 1, 1, "pers_c2p1"}, {1, 2, 1, "pers_c1p2"},   // c2p2 / c4p1 spill under the 2-waves/SIMD register bound
-    {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"}, {4, 2, 2, "pipe_c4p2"}, {4, 1, 2, "pipe_c4p1"},
-    {4, 2, 2, "pipe8_c4p2", 8}, {2, 4, 2, "pipe8_c2p4", 8}, {2, 2, 2, "pipe8_c2p2", 8},
-    {2, 1, 2, "pipe8s2_c2p1", 8, 2}, {1, 1, 2, "pipe8s2_c1p1", 8, 2}, {2, 2, 2, "pipe3_c2p2", 4, 1, 3}, {2, 1, 2, "pipe3_c2p1", 4, 1, 3},
-    {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"},    // persist == 3: the streaming 1x1 kernel
-    // persist == 4: LDS-DMA fed 3x3 stride-1 kernels (conv_dma.hip)
-    // (depth = LDS stages; st = 1: requests interleaved with the MFMAs, 0: issued in a burst after the barrier)
-    {2, 2, 4, "dma8_c2p2", 8}, {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4},
-    // hc = 32: 32-channel chunks, four lanes of a request per pixel (16 cache lines per request instead of 64)
-    {2, 2, 4, "dmaw8_c2p2", 8, 1, 2, 32}, {1, 2, 4, "dmaw_c1p2", 4, 1, 2, 32}, {2, 2, 4, "dmaw8f_c2p2", 8, 3, 2, 32},   // f: three requests per unit (front-loaded)
-    // cs = 2: stride-2 forms (parity-split halo rows): 128 output pixels x 64 couts, two blocks per CU / 256 pixels, one block
+    {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"},
+    {2, 2, 2, "pipe_c2p2"}, {2, 1, 2, "pipe_c2p1"}, {1, 2, 2, "pipe_c1p2"},
+    {1, 1, 3, "stream1x1_c1"}, {2, 1, 3, "stream1x1_c2"},
+    {2, 2, 4, "dma_c2p2", 4}, {2, 1, 4, "dma_c2p1", 4}, {1, 2, 4, "dma_c1p2", 4},
     {2, 1, 4, "dmas2_c2p1", 4, 1, 2, 16, 2}, {2, 1, 4, "dma8s2_c2p1", 8, 1, 2, 16, 2},
-    // 128 couts x 256 pixels on eight waves: the halo requests of a chunk feed twice the MFMAs of dma_c2p2 (DESIGN.md 6b.7;
-    // written after round 2's last GPU visit - not in the default candidate set until it has been measured)
     {4, 1, 4, "dma8_c4p1", 8},
-    // wres = 1: resident weights (layers of at most 64 input channels), 512 pixels x 64 couts on eight waves, one block per CU;
-    // 16-channel chunks (planar halo) / 32-channel chunks (pixel-major halo).  Also written after the last GPU visit.
-    {2, 2, 4, "dmar8_c2p2", 8, 1, 2, 16, 1, 1}, {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1},
-    // 64 couts x 512 pixels on four waves (two blocks per CU): the tap images of a chunk feed twice the MFMAs of dma_c2p2
-    // (39 KB per 288 MFMAs instead of 29 KB per 144); eight accumulator fragments per wave, so the epilogue is not deferred
-    {2, 4, 4, "dma_c2p4", 4},
-    // stride 2, 128 couts x 256 output pixels on eight waves: a stride-2 block stages four times the halo of a stride-1 one
-    // per MFMA, so twice the couts per halo is where the stride-2 form can gain (it only won on the first layer)
+    {2, 2, 4, "dmarw8_c2p2", 8, 1, 2, 32, 1, 1},
     {4, 1, 4, "dma8s2_c4p1", 8, 1, 2, 16, 2},
-    // persist == 6: weights through registers, halo in 32-channel LDS stages (conv_wreg.hip).  cf = waves along the couts (32 each),
-    // pf = pixel fragments per wave, nw = waves per block (nw / cf pixel groups): 128 couts x pf * 32 pixels on four waves, two
-    // blocks per CU; 64 couts x 2 * pf * 32 pixels for the 64-channel layers.  The tile (TH x TW <= the block's pixel slots) is
-    // chosen for whole rounds of the persistent walk (choose_tile_wreg).
-    {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4}, {2, 7, 6, "wreg2_p7", 4},
-    // the same kernel for stride 2 (cs = 2): a halo row is stored as [even columns | odd columns], the tap offsets stay immediates;
-    // the halo of a tile is four times its pixels, so the tiles are small (96 / 128 pixel slots)
+    // tile geometries of the int8 LDS-DMA kernels (y6_conv_i8 variants 7 / 9; variant 8 shares dma_c2p2's): 512 pixels x 64 couts on
+    // eight waves with 16- / 32-channel chunks.  Their fp16 forms lost everywhere and are no longer built.
+    {2, 2, 4, "i8_dma8_c2p2", 8, 1, 2, 16, 1, 0, 1}, {2, 2, 4, "i8_dmaw8_c2p2", 8, 1, 2, 32, 1, 0, 1},
+    {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4},
     {4, 3, 6, "wregs2_p3", 4, 1, 2, 16, 2}, {4, 4, 6, "wregs2_p4", 4, 1, 2, 16, 2}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+static int variant_index(const char* name) {
+    for (int i = 0; i < kNumVariants; ++i)
+        if (strcmp(kVariants[i].name, name) == 0) return i;
+    return -1;
+}
 
 int halo_cap(int ks, int st, int pf) {
     if (ks == 1) return pf * 128;
@@ -1356,8 +1102,6 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
                          : vc.depth * (size_t)(k.dma_nhp + wp) * 1024 + 8 * vc.cf * 32 * 4;   // stages of (halo + tap images), per-channel vectors [2 parities][bias | post scale | post shift | dequant]
     } else if (vc.persist == 2)
         L->lds = 2 * (size_t)k.ldsA_bytes + 2 * (size_t)9 * vc.cf * 1024 + 2 * vc.cf * 32 * 4 + 16;   // two buffers of halo + nine 16-channel tap images, bias x2, dump slot
-    else if (vc.persist)
-        L->lds = (size_t)k.ldsA_bytes + (size_t)9 * vc.cf * 2 * 1024 + 2 * vc.cf * 32 * 4;   // one chunk of nine tap images + bias x2
     else
         L->lds = (size_t)k.ldsA_bytes + 3 * (size_t)vc.cf * 2 * 1024;      // 3-slot ring of tap images
     if (k.epi_lds) {
@@ -1379,38 +1123,6 @@ int launch_one(const Launch& L, hipStream_t s) {
     }
     Y6_REQUIRE(L.lds <= 128 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
     hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, KS, ST>), dim3(L.grid), dim3(256), L.lds, s, L.k);
-    Y6_LAUNCH_CHECK();
-    return Y6_OK;
-}
-
-template <int CF, int PF, int ST>
-int launch_persist(const Launch& L, hipStream_t s) {
-    auto kern = conv_mfma_persist_kernel<CF, PF, ST>;
-    static bool big_lds_enabled = false;
-    if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        big_lds_enabled = true;
-    }
-    Y6_REQUIRE(L.lds <= 128 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
-    // resident blocks per CU for this LDS footprint (cached per footprint)
-    static size_t cached_lds = 0;
-    static int cached_bpc = 0, n_cu = 0;
-    if (cached_lds != L.lds) {
-        int bpc = 0;
-        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, 256, L.lds));
-        if (n_cu == 0) {
-            int dev = 0;
-            Y6_HIP(hipGetDevice(&dev));
-            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        cached_bpc = bpc < 1 ? 1 : bpc;
-        cached_lds = L.lds;
-    }
-    int grid = n_cu * cached_bpc;
-    grid -= grid % 8;                 // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple
-    if (grid < 8) grid = 8;
-    if (grid > L.grid) grid = L.grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), L.lds, s, L.k);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -1479,14 +1191,6 @@ int launch_stream1x1_cfg(const Launch& L, hipStream_t s) {
             break;
     }
     y6_set_error("conv1x1_stream: unsupported Cin %d", L.k.Cin);
-    return Y6_EUNSUPPORTED;
-}
-
-template <int CF, int PF>
-int launch_persist_cfg(const Launch& L, int st, hipStream_t s) {
-    if (st == 1) return launch_persist<CF, PF, 1>(L, s);
-    if constexpr (PF == 1) return launch_persist<CF, 1, 2>(L, s);
-    y6_set_error("conv_mfma: stride-2 needs a pf=1 variant");
     return Y6_EUNSUPPORTED;
 }
 
@@ -1599,7 +1303,8 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         Y6_REQUIRE(d.ksize == 3 && d.stride == 1 && has_qin && q->q_in.C % 32 == 0, "conv_i8: the LDS-DMA variants need k3 s1, an int8 input view and Cin %% 32 == 0");
     Y6_REQUIRE(dma || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
     Launch L;
-    const int kv = dma ? (variant == 7 ? 24 : (variant == 8 ? 25 : 28)) : variant;   // kVariants row that sizes the tile
+    static const int kv7 = variant_index("i8_dma8_c2p2"), kv8 = variant_index("dma_c2p2"), kv9 = variant_index("i8_dmaw8_c2p2");
+    const int kv = dma ? (variant == 7 ? kv7 : (variant == 8 ? kv8 : kv9)) : variant;   // kVariants row that sizes the tile
     if (variant == 9) Y6_REQUIRE(q->q_in.C % 64 == 0, "conv_i8: variant 9 needs Cin %% 64 == 0");
     int rc = build_launch(&d, kv, 0, 0, 0, &L);
     if (rc) return rc;
@@ -1639,6 +1344,7 @@ extern "C" const char* y6_conv_variant_name(int i) {
 int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     if (variant < 1 || variant >= kNumVariants) return 0;
     const VariantCfg& vc = kVariants[variant];
+    if (vc.i8only) return 0;
     const int ks = d->ksize, st = d->stride;
     if (!((ks == 1 && st == 1) || (ks == 3 && (st == 1 || st == 2)))) return 0;
     if (st == 2 && vc.pf != 1 && vc.persist != 6) return 0;
@@ -1668,7 +1374,6 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;   // byte offsets + the range-check sentinel
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
-    if (vc.persist == 1 && vc.cf == 2 && st == 2) return 0;   // that instantiation spills
     if (vc.persist == 2 && st != vc.st) return 0;
     if (vc.persist == 2 && vc.depth == 3 && (y6_cdiv(d->in.C, 16) & 1)) return 0;   // two chunks per loop trip
     if (d->w_packed == nullptr) return 0;
@@ -1696,35 +1401,27 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
     Launch L;
     int rc = build_launch(d, variant, up, updy, updx, &L);
     if (rc) return rc;
-    switch (variant) {
-        case 1: return launch_cfg<1, 1>(L, d->ksize, d->stride, s);
-        case 2: return launch_cfg<2, 1>(L, d->ksize, d->stride, s);
-        case 3: return launch_cfg<4, 1>(L, d->ksize, d->stride, s);
-        case 4: return launch_cfg<1, 2>(L, d->ksize, d->stride, s);
-        case 5: return launch_cfg<2, 2>(L, d->ksize, d->stride, s);
-        case 6: return launch_cfg<4, 2>(L, d->ksize, d->stride, s);
-        case 7: return launch_persist_cfg<1, 1>(L, d->stride, s);
-        case 8: return launch_persist_cfg<2, 1>(L, d->stride, s);
-        case 9: return launch_persist_cfg<1, 2>(L, d->stride, s);
-        case 10: return launch_pipe<2, 2, 2>(L, s);
-        case 11: return launch_pipe<2, 1, 2>(L, s);
-        case 12: return launch_pipe<1, 2, 2>(L, s);
-        case 13: return launch_pipe<4, 2, 1>(L, s);
-        case 14: return launch_pipe<4, 1, 1>(L, s);
-        case 15: return launch_pipe<4, 2, 2, 8>(L, s);
-        case 16: return launch_pipe<2, 4, 2, 8>(L, s);
-        case 17: return launch_pipe<2, 2, 2, 8>(L, s);
-        case 18: return launch_pipe<2, 1, 2, 8, 2>(L, s);
-        case 19: return launch_pipe<1, 1, 2, 8, 2>(L, s);
-        case 20: return launch_pipe<2, 2, 2, 4, 1, 3>(L, s);
-        case 21: return launch_pipe<2, 1, 2, 4, 1, 3>(L, s);
-        case 22: return launch_stream1x1_cfg<1>(L, s);
-        case 23: return launch_stream1x1_cfg<2>(L, s);
-        case 38: case 39: case 40: case 41: case 42: case 43: case 44:
-            return y6_conv_wreg_launch(&L, kVariants[variant].pf, kVariants[variant].cf, kVariants[variant].nw / kVariants[variant].cf, kVariants[variant].cs, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37:
-            return y6_conv_dma_launch(&L, kVariants[variant].cf, kVariants[variant].pf, kVariants[variant].nw, kVariants[variant].depth,
-                                      kVariants[variant].st, kVariants[variant].hc, kVariants[variant].cs, 0, kVariants[variant].wres, s);
+    const VariantCfg& vc = kVariants[variant];
+    switch (vc.persist) {
+        case 0:
+            if (vc.cf == 1 && vc.pf == 1) return launch_cfg<1, 1>(L, d->ksize, d->stride, s);
+            if (vc.cf == 2 && vc.pf == 1) return launch_cfg<2, 1>(L, d->ksize, d->stride, s);
+            if (vc.cf == 4 && vc.pf == 1) return launch_cfg<4, 1>(L, d->ksize, d->stride, s);
+            if (vc.cf == 1 && vc.pf == 2) return launch_cfg<1, 2>(L, d->ksize, d->stride, s);
+            if (vc.cf == 2 && vc.pf == 2) return launch_cfg<2, 2>(L, d->ksize, d->stride, s);
+            if (vc.cf == 4 && vc.pf == 2) return launch_cfg<4, 2>(L, d->ksize, d->stride, s);
+            break;
+        case 2:
+            if (vc.cf == 2 && vc.pf == 2) return launch_pipe<2, 2, 2>(L, s);
+            if (vc.cf == 2 && vc.pf == 1) return launch_pipe<2, 1, 2>(L, s);
+            if (vc.cf == 1 && vc.pf == 2) return launch_pipe<1, 2, 2>(L, s);
+            break;
+        case 3:
+            return vc.cf == 1 ? launch_stream1x1_cfg<1>(L, s) : launch_stream1x1_cfg<2>(L, s);
+        case 4:
+            return y6_conv_dma_launch(&L, vc.cf, vc.pf, vc.nw, vc.depth, vc.st, vc.hc, vc.cs, 0, vc.wres, s);
+        case 6:
+            return y6_conv_wreg_launch(&L, vc.pf, vc.cf, vc.nw / vc.cf, vc.cs, s);
     }
     return Y6_EINVAL;
 }

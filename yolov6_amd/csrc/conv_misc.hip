@@ -671,17 +671,20 @@ static int default_variant(const y6_conv_desc* d) {
         if (first > 0 && y6_conv_variant_supports(d, first)) return first;
         if (d->stride == 1 && p4 > 0 && y6_conv_variant_supports(d, p4)) return p4;
     }
-    // measured (profiles/r02 autotune logs): the LDS-DMA kernels win 3x3 stride 1 - 256-pixel blocks (variant 25) when
-    // there are at least two of them per CU slot, else 128-pixel blocks (26); then round 1's pipelined kernel (10-12 are
-    // skipped by `supports` for 1x1); elsewhere high-occupancy small tiles win
+    // then (profiles/r02 autotune logs) the LDS-DMA kernels on 3x3 stride 1 - 256-pixel blocks when there are at least two of
+    // them per CU slot, else 128-pixel blocks - then round 1's pipelined kernel; elsewhere high-occupancy small tiles win
     const long items256 = (px + 255) / 256 * ((d->out.C + 63) / 64);
-    const int dma_a = items256 >= 512 ? 25 : 26, dma_b = items256 >= 512 ? 26 : 25;
-    const int prefs_s1[] = {dma_a, dma_b, 10, 11, 12, 2, 1, 5, 4, 3, 6, 0};
-    const int prefs_s2[] = {2, 1, 3, 0};
+    static const int dma22 = variant_by_name("dma_c2p2"), dma21 = variant_by_name("dma_c2p1"), pipe22 = variant_by_name("pipe_c2p2"),
+                     pipe21 = variant_by_name("pipe_c2p1"), pipe12 = variant_by_name("pipe_c1p2"), c2p1 = variant_by_name("mfma_c2p1"), c1p1 = variant_by_name("mfma_c1p1"),
+                     c2p2 = variant_by_name("mfma_c2p2"), c1p2 = variant_by_name("mfma_c1p2"), c4p1 = variant_by_name("mfma_c4p1"),
+                     c4p2 = variant_by_name("mfma_c4p2");
+    const int dma_a = items256 >= 512 ? dma22 : dma21, dma_b = items256 >= 512 ? dma21 : dma22;
+    const int prefs_s1[] = {dma_a, dma_b, pipe22, pipe21, pipe12, c2p1, c1p1, c2p2, c1p2, c4p1, c4p2, 0};
+    const int prefs_s2[] = {c2p1, c1p1, c4p1, 0};
     const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
     const int n = d->stride == 1 ? 12 : 4;
     for (int i = 0; i < n; ++i)
-        if (y6_conv_variant_supports(d, prefs[i])) return prefs[i];
+        if (prefs[i] >= 0 && y6_conv_variant_supports(d, prefs[i])) return prefs[i];
     return -1;
 }
 

@@ -897,26 +897,26 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
     // built, tested and selectable: Y6_AUTOTUNE_EXCLUDE="" allows all, "15,16" excludes just those.
     std::vector<char> excluded(nv, 0);
     const char* ex = getenv("Y6_AUTOTUNE_EXCLUDE");
-    // 24 / 30 (dma8_c2p2 at 4 waves per SIMD, the front-loaded request form) never won.  28 / 29 (32-channel chunks, one
-    // 157 KB block per CU) are the fastest 3x3 kernels on a warm chip (-5 % on the 60-GFLOP layers) but on most boxes of
-    // this pool their FIRST launch after a memory-bound op costs +25-50 us (r02b: 118 us for a 69 us layer), which eats
-    // the gain; the 16-channel-chunk forms (two / three blocks per CU, < 64 KB of LDS per block) do not show it
-    // (same-box A/B tools/gpu_ab_firstop.sh: 11.0 k img/s without them, 10.8 k with).
-    // 33-37, first measured in round 3 (profiles/r03/ab_variants_r03a.txt, same box, in sequence): 33 dma8_c4p1 (128 couts x
-    // 256 pixels on eight waves) takes 17 of the 35 stride-1 layers from dma_c2p2 / dma_c2p1, 37 dma8s2_c4p1 three stride-2
-    // layers, 35 dmarw8_c2p2 (tap images resident in LDS) wins the 64-channel layers in isolation: candidates (+1.9 % img/s
-    // with all three allowed).  34 dmar8_c2p2 and 36 dma_c2p4 lost on every layer: selectable, never default.
-    // 38-42, round 4 (conv_wreg.hip, profiles/r04/conv_bench_wreg_v3_r04e.json): 39 wreg_p7 / 40 wreg_p4 take the 128-cout-block
-    // layers from the LDS-DMA forms (+6...12 % on the 60-GFLOP layers in isolation); 38 wreg_p6 / 41 wreg_p5 (tiles of 192 / 160 pixel slots) are
-    // candidates since r04n; the 64-cout form 42 loses: selectable, not default.
-    if (!ex) ex = "7,8,9,12,13,14,15,16,17,18,19,20,21,24,28,29,30,34,36,42";
+    // Default candidates: every built form except the per-tap 2-fragment tiles on 3x3 stride-1 layers' behalf (they never win
+    // there but hop the plan between kernels).  Y6_AUTOTUNE_EXCLUDE="" allows all; a comma list of variant NAMES (or indices)
+    // excludes just those.  History of what was measured and retired: DESIGN 6 / 6b / 6c.
+    if (!ex) ex = "";
     {
         for (const char* c = ex; *c;) {
-            char* end = nullptr;
-            const long v = strtol(c, &end, 10);
-            if (end == c) break;
-            if (v >= 0 && v < nv) excluded[v] = 1;
-            c = (*end == ',') ? end + 1 : end;
+            const char* e = c;
+            while (*e && *e != ',') ++e;
+            const std::string tok(c, e);
+            if (!tok.empty()) {
+                char* end = nullptr;
+                const long v = strtol(tok.c_str(), &end, 10);
+                if (end && *end == 0) {
+                    if (v >= 0 && v < nv) excluded[v] = 1;
+                } else {
+                    for (int i = 0; i < nv; ++i)
+                        if (tok == y6_conv_variant_name(i)) excluded[i] = 1;
+                }
+            }
+            c = *e ? e + 1 : e;
         }
     }
     static const bool in_context = !(getenv("Y6_AUTOTUNE_BURST") != nullptr);   // A/B switch: old burst timing
