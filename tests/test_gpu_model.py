@@ -275,3 +275,23 @@ def test_uint8_images_equal_half_div255():
         torch.cuda.synchronize()
         outs.append(o.to_nhwc_tensor().clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_replaced_parameter_is_noticed_without_invalidate_plans():
+    """`m.bias = nn.Parameter(...)` (what the reference's re-parameterisation and many user scripts do) registers a NEW tensor:
+    the version counters of the old ones do not move, so the per-call fast path of HipModule.compile must also check that every
+    captured parameter / buffer is still the registered object.  In-place edits (`copy_`, optimizers) were
+    already seen through the version counters."""
+    cfg, meta, sd, m = _build("tiny", deploy=True)
+    x = synth.synth_images(2, 64, seed=5).to(DEV).half()
+    a = m(x)[0].clone()
+    b = m(x)[0].clone()
+    assert torch.equal(a, b)
+    conv = m.detect.cls_preds[0]
+    conv.bias = torch.nn.Parameter(conv.bias.detach() + 2.0)           # a different Parameter object
+    c = m(x)[0].clone()
+    assert not torch.equal(a[..., 5:], c[..., 5:]), "the plan kept running on the replaced parameter"
+    with torch.no_grad():
+        conv.bias.sub_(2.0)                                             # in place: the version counter moves
+    d = m(x)[0].clone()
+    assert torch.equal(a, d)

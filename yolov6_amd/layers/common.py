@@ -169,12 +169,14 @@ class HipModule(nn.Module):
         # Fast path (the per-call cost of the reference-signature API): the full key below walks every module of the tree
         # (~1 ms of Python for YOLOv6-S); a repeat call is recognised by the input signature, the process-wide
         # generations and the SUM of the autograd version counters of the tensors the plan was built from (in-place
-        # updates through torch - optimizers, load_state_dict, copy_ - bump them).  Edits through `.data` or of scalar
-        # attributes (eps, use_dfl, ...) need `invalidate_plans()`, as before.
+        # updates through torch - optimizers, load_state_dict, copy_ - bump them) plus the identity of every registered
+        # parameter / buffer (a replaced Parameter is a different object).  Edits through `.data` or of scalar attributes
+        # (eps, use_dfl, ...) need `invalidate_plans()`, as before.
         sig = (tuple((tuple(t.shape), t.dtype) for t in flat), self.training, autotune, None if quant is None else quant.key(),
                _NATIVE_GENERATION[0], _STRUCTURE_GENERATION[0])
         fast = self.__dict__.get("_y6_fast")
-        if fast is not None and fast[0] == sig and sum(t._version for t in fast[1]) == fast[2]:
+        if (fast is not None and fast[0] == sig and sum(t._version for t in fast[1]) == fast[2]
+                and all(d.get(n) is t for d, n, t in fast[4])):     # every captured parameter / buffer is still the registered one
             plan = fast[3]
             plan.bind_inputs([contig[j] for j in plan.input_order])
             return plan
@@ -207,7 +209,10 @@ class HipModule(nn.Module):
         else:
             plan.bind_inputs([contig[j] for j in plan.input_order])
         tensors = list(self.parameters()) + list(self.buffers())
-        self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan)
+        # (registry dict, name, tensor) of every parameter and buffer below this module: `m.weight = nn.Parameter(...)` replaces
+        # the entry, and the version counters of the OLD tensors this tuple keeps alive would not notice
+        holders = [(d, n, t) for m in self.modules() for d in (m._parameters, m._buffers) for n, t in d.items() if t is not None]
+        self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan, holders)
         return plan
 
     def forward(self, *inputs):
