@@ -489,12 +489,13 @@ typedef struct y6_bn_train_desc {
     float* shift;
     float* mean;
     float* invstd;
-    void* workspace;               /* y6_bn_stats_workspace_bytes(C) */
+    void* workspace;               /* y6_bn_stats_workspace_bytes_for(C, B*H*W) */
     size_t workspace_bytes;
     int32_t workspace_clean;       /* nonzero: the workspace is all-zero on entry (allocated zeroed, used by these calls only - they
                                       leave it zeroed); no memset launch.  0: a memset is issued first. */
 } y6_bn_train_desc;
-size_t y6_bn_stats_workspace_bytes(int C);
+size_t y6_bn_stats_workspace_bytes(int C);                 /* worst case (1024 partial blocks) */
+size_t y6_bn_stats_workspace_bytes_for(int C, long npix);   /* what a tensor of npix = B*H*W pixels needs */
 int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream);
 
 /* out = act( sum_b ( x_b * scale_b[c] + shift_b[c] ) ) [+ alpha * res]   (1..3 branches; NULL scale = 1, NULL shift = 0)
@@ -534,11 +535,12 @@ typedef struct y6_bnact_bwd_desc {
     y6_tensor dres;                /* data == NULL: none */
     int32_t dres_acc;
     float* dalpha;                 /* += ; NULL: skip */
-    void* workspace;               /* y6_bnact_bwd_workspace_bytes(C) */
+    void* workspace;               /* y6_bnact_bwd_workspace_bytes_for(C, B*H*W) */
     size_t workspace_bytes;
     int32_t workspace_clean;       /* as in y6_bn_train_desc: all-zero on entry, left all-zero */
 } y6_bnact_bwd_desc;
 size_t y6_bnact_bwd_workspace_bytes(int C);
+size_t y6_bnact_bwd_workspace_bytes_for(int C, long npix);
 int y6_bnact_backward(const y6_bnact_bwd_desc* d, void* stream);
 
 /* Pixel-run-major ("transposed") sampling of an activation for the weight-gradient GEMM:

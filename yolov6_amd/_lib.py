@@ -251,6 +251,8 @@ SIGNATURES = {
     "y6_distill_backward": (C.c_int, [C.POINTER(DistillDesc), C.c_void_p]),
     "y6_distill_cw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_bn_stats_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "y6_bn_stats_workspace_bytes_for": (C.c_size_t, [C.c_int, C.c_long]),
+    "y6_bnact_bwd_workspace_bytes_for": (C.c_size_t, [C.c_int, C.c_long]),
     "y6_bn_train_stats": (C.c_int, [C.POINTER(BnTrainDesc), C.c_void_p]),
     "y6_bnact_forward": (C.c_int, [C.POINTER(BnActDesc), C.c_void_p]),
     "y6_bnact_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),

@@ -236,9 +236,9 @@ int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
     Y6_REQUIRE(view_ok(d->x), "bn_train_stats: the view must be fp16 NHWC with 8-channel alignment");
     const int C = d->x.C, G = C / 8;
     Y6_REQUIRE(C <= 2048, "bn_train_stats: at most 2048 channels");
-    Y6_REQUIRE(d->workspace_bytes >= y6_bn_stats_workspace_bytes(C), "bn_train_stats: workspace too small");
     const long npix = (long)d->x.B * d->x.H * d->x.W;
     Y6_REQUIRE(npix > 0, "bn_train_stats: empty tensor");
+    Y6_REQUIRE(d->workspace_bytes >= y6_bn_stats_workspace_bytes_for(C, npix), "bn_train_stats: workspace too small");
     double* ws = (double*)d->workspace;
     const int R = 256 / G;
     if (!bn_use_atomics()) {
@@ -967,7 +967,7 @@ int bnact_backward_launch(const y6_bnact_bwd_desc* d, hipStream_t s) {
     const y6_tensor& ref = d->fwd.x[0];
     const int C = ref.C, n = d->fwd.n;
     Y6_REQUIRE(C <= 1024, "bnact_backward: at most 1024 channels");
-    Y6_REQUIRE(d->workspace_bytes >= y6_bnact_bwd_workspace_bytes(C), "bnact_backward: workspace too small");
+    Y6_REQUIRE(d->workspace_bytes >= y6_bnact_bwd_workspace_bytes_for(C, (long)ref.B * ref.H * ref.W), "bnact_backward: workspace too small");
     Y6_REQUIRE(view_ok(d->dout) && same_shape(d->dout, ref), "bnact_backward: bad dout view");
     a.dout = (const __half*)d->dout.data;
     a.dcs = d->dout.cstride;
@@ -1887,9 +1887,23 @@ __global__ void scaler_update_kernel(float* scale, int32_t* found_inf, int32_t* 
 // ====================================================================== C ABI
 // [2C] totals (the atomic form, Y6_BN_ATOMICS=1) followed by [kBnPartBlocks][2C] block partials
 extern "C" size_t y6_bn_stats_workspace_bytes(int C) { return (size_t)2 * C * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
+// ... sized for the tensor: the launcher uses min(kBnPartBlocks, ceil(npix / (16 pixel rows of 256 / (C / 8) pixels))) partial blocks.
+// (The worst case above is 8.4 MB per BatchNorm at C = 512 - GBs over the hundreds of BatchNorms of an M / L training graph.)
+static long bn_part_blocks(int C, long npix, int rows_per_thread) {
+    const int G = C / 8 > 0 ? C / 8 : 1;
+    const long ppb = (long)(256 / G > 0 ? 256 / G : 1) * rows_per_thread;
+    const long blocks = (npix + ppb - 1) / ppb;
+    return blocks > kBnPartBlocks ? kBnPartBlocks : (blocks < 1 ? 1 : blocks);
+}
+extern "C" size_t y6_bn_stats_workspace_bytes_for(int C, long npix) {
+    return (size_t)2 * C * sizeof(double) * (size_t)(1 + bn_part_blocks(C, npix, 16));
+}
 
 // [4C + 1] totals followed by [kBnPartBlocks][4C + 1] block partials
 extern "C" size_t y6_bnact_bwd_workspace_bytes(int C) { return ((size_t)4 * C + 1) * sizeof(double) * (size_t)(1 + kBnPartBlocks); }
+extern "C" size_t y6_bnact_bwd_workspace_bytes_for(int C, long npix) {
+    return ((size_t)4 * C + 1) * sizeof(double) * (size_t)(1 + bn_part_blocks(C, npix, 8));
+}
 
 extern "C" int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();

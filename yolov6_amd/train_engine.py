@@ -341,7 +341,7 @@ class TrainBuilder:
     def bn(self, y: TRef, bn: nn.BatchNorm2d) -> BnStats:
         Cn = y.C
         st = BnStats(bn, self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn))
-        ws = self.bytes_(int(self.lib.y6_bn_stats_workspace_bytes(Cn)))
+        ws = self.bytes_(int(self.lib.y6_bn_stats_workspace_bytes_for(Cn, y.B * y.H * y.W)))   # sized for this tensor
         d = _lib.BnTrainDesc()
         d.x = y.ct()
         d.gamma = self.arena.data_ptr(bn.weight) if bn.weight is not None else None
@@ -567,7 +567,7 @@ class TrainBuilder:
             if alpha is not None:
                 g.dalpha = self.arena.grad_ptr(alpha).value
                 finals.append(alpha)
-        ws = self.bytes_(int(self.lib.y6_bnact_bwd_workspace_bytes(out.C)))
+        ws = self.bytes_(int(self.lib.y6_bnact_bwd_workspace_bytes_for(out.C, out.B * out.H * out.W)))
         g.workspace, g.workspace_bytes = _ptr(ws), ws.numel()
         g.workspace_clean = 1
         self._b(self.lib.y6_plan_add_bnact_backward(self.bwd, C.byref(g)), "plan_add_bnact_backward", branches=list(branches),
