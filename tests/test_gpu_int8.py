@@ -211,6 +211,66 @@ def test_conv_i8_dma_variants_bit_exact(variant):
         assert torch.equal(_nchw(out), ref)
 
 
+@pytest.mark.parametrize("variant", [10, 11, 12])
+def test_conv_i8_wreg_variants_bit_exact(variant):
+    """The register-fed int8 kernels (conv_wreg.hip, I8 form; 10 / 11: stride 1 with 7 / 4 pixel fragments per wave, 12: stride 2)
+    read the producer's int8 twin in 64-channel stages.  They have the fast epilogue only (no accumulator dump), so the check is
+    on what they write: the fp16 output bit-exact against the oracle (conv + bias (+ ReLU)), within one fp16 ulp for the kept
+    post-BN affine + SiLU, and - bit for bit - the outputs and the int8 twin of the per-tap kernel (variant 2) on the same
+    inputs; twin-only calls write the same twin.  Ragged maps, several stages, several cout blocks."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(57)
+    stride = 2 if variant == 12 else 1
+    shapes = [(3, 40, 40, 64, 128, "relu", False), (2, 22, 38, 128, 256, None, False), (4, 80, 80, 64, 128, "relu", True),
+              (2, 30, 50, 192, 128, "silu", True), (33, 20, 20, 256, 256, "relu", False)]
+    if stride == 1:
+        shapes.append((2, 21, 37, 64, 128, "relu", False))   # odd map: ragged tiles in both directions
+    for (B, H, W, Cin, Cout, act, with_post) in shapes:
+        x = rand_nhwc(B, H, W, Cin, seed=23, scale=4.0)
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) * 0.2
+        b = torch.randn((Cout,), generator=g)
+        post = (torch.rand((Cout,), generator=g) + 0.5, torch.randn((Cout,), generator=g) * 0.2) if with_post else None
+        amax = 3.1
+        twin = _i8_buffer(B, H, W, Cin)
+        xt, qt = x.ct(), twin.ct()
+        _lib.check(lib.y6_quantize_i8(C.byref(xt), C.c_float(amax), C.byref(qt), None), "quantize_i8")
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        qa, qb, qc = _i8_buffer(B, Ho, Wo, Cout), _i8_buffer(B, Ho, Wo, Cout), _i8_buffer(B, Ho, Wo, Cout)
+        tag = f"variant {variant} {(B, H, W, Cin, Cout, act, with_post)}"
+        out, _ = _run_i8(x, w, b, stride, act, amax, post=post, variant=variant, q_in=twin, q_out=qa, q_out_amax=4.2, want_acc=False)
+        base, _ = _run_i8(x, w, b, stride, act, amax, post=post, variant=2, q_in=twin, q_out=qb, q_out_amax=4.2, want_acc=False)
+        assert torch.equal(out.buf, base.buf), f"fp16 output differs from the per-tap kernel's: {tag}"
+        assert torch.equal(qa.buf, qb.buf), f"int8 twin differs from the per-tap kernel's: {tag}"
+        _run_i8(x, w, b, stride, act, amax, post=post, variant=variant, q_in=twin, q_out=qc, q_out_amax=4.2, want_out=False, want_acc=False)
+        assert torch.equal(qa.buf, qc.buf), f"twin-only output differs: {tag}"
+        ref, _ = int8_conv(_Q16(), _nchw(x), w, b, stride, act, post, amax)
+        got = _nchw(out)
+        if post is None and act in (None, "relu"):
+            assert torch.equal(got, ref), f"fp16 output differs from the oracle: {tag} max {float((got - ref).abs().max()):.3e}"
+        else:
+            rel = (got - ref).abs() / ref.abs().clamp(min=1.0)
+            assert float(rel.max()) <= 2 * 2.0 ** -10 * 1.002, tag
+
+
+def test_conv_i8_wreg_refuses_what_it_cannot_do():
+    """No residual, no accumulator dump, whole 64-channel stages and 128-cout blocks: anything else is an error from the C ABI
+    (the kernel has the fast epilogue only), not a wrong result."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    x = rand_nhwc(2, 20, 20, 64, seed=5, scale=2.0)
+    twin = _i8_buffer(2, 20, 20, 64)
+    xt, qt = x.ct(), twin.ct()
+    _lib.check(lib.y6_quantize_i8(C.byref(xt), C.c_float(2.0), C.byref(qt), None), "quantize_i8")
+    w = torch.randn((128, 64, 3, 3), generator=g) * 0.2
+    with pytest.raises(RuntimeError, match="register-fed"):
+        _run_i8(x, w, None, 1, "relu", 2.0, variant=10, q_in=twin, want_acc=True)      # accumulator dump
+    with pytest.raises(RuntimeError, match="register-fed"):
+        _run_i8(x, w, None, 1, "relu", 2.0, variant=10, want_acc=False)                 # no int8 input view
+    w96 = torch.randn((96, 64, 3, 3), generator=g) * 0.2
+    with pytest.raises(RuntimeError, match="register-fed"):
+        _run_i8(x, w96, None, 1, "relu", 2.0, variant=11, q_in=twin, want_acc=False)   # 96 couts
+
+
 def test_absmax_exact_on_views():
     lib = _lib.load()
     x = rand_nhwc(3, 15, 17, 40, cstride=64, coff=16, seed=8, scale=9.0)

@@ -110,7 +110,7 @@ int y6_conv_i8_variant(const y6_conv_i8_desc* q);
 int y6_conv_dma_launch(const void* launch_record, int cf, int pf, int nw, int stages, int interleave, int chunk_channels, int stride,
                        int i8, int resident_weights, hipStream_t s);   // conv_dma.hip
 int y6_conv_dma_halo_cap(int block_pixels, int stride);
-int y6_conv_wreg_launch(const void* launch_record, int pf, int cout_waves, int pixel_waves, int stride, hipStream_t s);   // conv_wreg.hip
+int y6_conv_wreg_launch(const void* launch_record, int pf, int cout_waves, int pixel_waves, int stride, int i8, hipStream_t s);   // conv_wreg.hip
 int y6_conv_wreg_max_pieces(int waves, int stride);
 // nms.hip: where the key lists / their lengths of a y6_nms workspace live (the candidate sink of head_decode.hip writes them)
 int y6_nms_workspace_views(void* workspace, size_t bytes, int B, int A, int nc, int multi_label, unsigned long long** keys, size_t* cap, int** counts);

@@ -1092,7 +1092,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
             static const int prio = getenv("Y6_WREG_PRIO") ? atoi(getenv("Y6_WREG_PRIO")) : 0;   // A/B switch (unmeasured: off)
             k.prio_mode = prio;
         }
-        L->lds = 2 * (size_t)k.dma_nhp * 1024 + 3 * (size_t)vc.cf * 32 * 4;   // two stage images + bias / post scale / post shift of the block's couts
+        L->lds = 2 * (size_t)k.dma_nhp * 1024 + 4 * (size_t)vc.cf * 32 * 4;   // two stage images + bias / post scale / post shift / dequant of the block's couts
     } else if (vc.persist == 4) {
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
@@ -1252,11 +1252,34 @@ int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 }
 }  // namespace
 
+constexpr bool kI8WregDefault = false;
+// what conv_wreg.hip's int8 form handles (it has the fast epilogue only): 3x3 over the producer's int8 twin, whole 64-channel
+// stages and 128-cout blocks, no residual, no raw accumulators, a 16-byte aligned fp16 view and / or a 4-byte aligned int8 twin
+static bool i8_wreg_ok(const y6_conv_i8_desc* q, int stride) {
+    const y6_conv_desc* d = &q->conv;
+    const y6_tensor& o = d->out.data ? d->out : q->q_out;
+    if (d->ksize != 3 || d->stride != stride || !q->q_in.data || q->q_in.C % 64 || o.C % 128) return false;
+    if (d->res.data || q->acc_out) return false;
+    if (d->out.data && (d->out.cstride % 8 || d->out.coff % 8 || ((uintptr_t)d->out.data & 15))) return false;
+    if (q->q_out.data && ((q->q_out.cstride | q->q_out.coff) & 3)) return false;
+    if (y6_tensor_elems(o) / o.C * o.cstride * 2 >= 0xe0000000ull) return false;
+    return true;
+}
 int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     const y6_conv_desc* d = &q->conv;
-    if (d->variant >= 1 && d->variant <= 9) return d->variant;
+    if (d->variant >= 1 && d->variant <= 12) return d->variant;
     const int co = d->out.data ? d->out.C : q->q_out.C;
     static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
+    // 10 / 11 / 12: the register-fed kernels (conv_wreg.hip, int8 form) - the producer's int8 twin, whole 64-channel stages, whole
+    // 128-cout blocks; 7 pixel fragments per wave when the 200-pixel items fill the 512 resident blocks, else 4 (the fp16 rule,
+    // conv_misc.hip: default_variant); stride 2: 3 fragments.  Y6_I8_WREG=0 / 1: A/B switch (round 4: opt-in until measured)
+    static const bool wreg = getenv("Y6_I8_WREG") ? atoi(getenv("Y6_I8_WREG")) != 0 : kI8WregDefault;
+    if (wreg && !no_dma && i8_wreg_ok(q, d->stride)) {
+        const long px = (long)q->q_in.B * (q->q_in.H / d->stride) * (q->q_in.W / d->stride);
+        const long items200 = (px + 199) / 200 * (co / 128);
+        if (d->stride == 1) return items200 >= 512 ? 10 : 11;
+        if (d->stride == 2 && q->q_in.H % 2 == 0 && q->q_in.W % 2 == 0) return 12;
+    }
     // 7 / 8 / 9: the LDS-DMA kernels (conv_dma.hip) - need the producer's int8 twin and whole 32- (9: 64-) channel chunks
     if (!no_dma && d->ksize == 3 && d->stride == 1 && q->q_in.data && q->q_in.C % 32 == 0 && co >= 64) {
         const long npix = (long)q->q_in.B * q->q_in.H * q->q_in.W;
@@ -1298,13 +1321,19 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
                    "conv_i8: int8 output view");
     }
     const int variant = y6_conv_i8_variant(q);
-    const bool dma = variant >= 7;
+    const bool wreg = variant >= 10;
+    const bool dma = variant >= 7 && !wreg;
     if (dma)
         Y6_REQUIRE(d.ksize == 3 && d.stride == 1 && has_qin && q->q_in.C % 32 == 0, "conv_i8: the LDS-DMA variants need k3 s1, an int8 input view and Cin %% 32 == 0");
-    Y6_REQUIRE(dma || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
+    if (wreg)
+        Y6_REQUIRE(i8_wreg_ok(q, variant == 12 ? 2 : 1),
+                   "conv_i8: the register-fed variants need k3, an int8 input view, Cin %% 64 == 0, Cout %% 128 == 0, no residual, aligned outputs");
+    Y6_REQUIRE(dma || wreg || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
     Launch L;
-    static const int kv7 = variant_index("i8_dma8_c2p2"), kv8 = variant_index("dma_c2p2"), kv9 = variant_index("i8_dmaw8_c2p2");
-    const int kv = dma ? (variant == 7 ? kv7 : (variant == 8 ? kv8 : kv9)) : variant;   // kVariants row that sizes the tile
+    static const int kv7 = variant_index("i8_dma8_c2p2"), kv8 = variant_index("dma_c2p2"), kv9 = variant_index("i8_dmaw8_c2p2"),
+                     kv10 = variant_index("wreg_p7"), kv11 = variant_index("wreg_p4"), kv12 = variant_index("wregs2_p3");
+    const int kv = wreg ? (variant == 10 ? kv10 : (variant == 11 ? kv11 : kv12))
+                        : dma ? (variant == 7 ? kv7 : (variant == 8 ? kv8 : kv9)) : variant;   // kVariants row that sizes the tile
     if (variant == 9) Y6_REQUIRE(q->q_in.C % 64 == 0, "conv_i8: variant 9 needs Cin %% 64 == 0");
     int rc = build_launch(&d, kv, 0, 0, 0, &L);
     if (rc) return rc;
@@ -1324,6 +1353,7 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
         k.out = nullptr;
         k.epi_lds = 0;
     }
+    if (wreg) return y6_conv_wreg_launch(&L, kVariants[kv].pf, kVariants[kv].cf, kVariants[kv].nw / kVariants[kv].cf, kVariants[kv].cs, 1, s);
     if (dma) return y6_conv_dma_launch(&L, kVariants[kv].cf, kVariants[kv].pf, kVariants[kv].nw, 2, 1, kVariants[kv].hc, 1, 1, 0, s);
     switch (variant) {
         case 1: return launch_i8_cfg<1, 1>(L, d.ksize, d.stride, s);
@@ -1421,7 +1451,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 4:
             return y6_conv_dma_launch(&L, vc.cf, vc.pf, vc.nw, vc.depth, vc.st, vc.hc, vc.cs, 0, vc.wres, s);
         case 6:
-            return y6_conv_wreg_launch(&L, vc.pf, vc.cf, vc.nw / vc.cf, vc.cs, s);
+            return y6_conv_wreg_launch(&L, vc.pf, vc.cf, vc.nw / vc.cf, vc.cs, 0, s);
     }
     return Y6_EINVAL;
 }

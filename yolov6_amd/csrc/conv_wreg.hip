@@ -98,9 +98,15 @@ __device__ __forceinline__ int div_small(int n, float inv) { return (int)(((floa
 #endif
 constexpr int kWregProbe = Y6_WREG_PROBE;
 
-template <int PF, int WC, int WP, int ST>
+// I8: the int8 form (include/yolov6_hip.h: y6_conv_i8_desc).  v_mfma_i32_32x32x32_i8 takes the same 16 bytes per lane and operand
+// as the fp16 instruction, so a stage is 64 int8 channels in the SAME 64-byte pixel slots, a weight fragment is the same 1 KiB
+// (quant.hip's packing: [cout/32][cin/64][tap][k-step]) and the request / wait / barrier protocol below is shared word for word;
+// what differs is the element size of the input view, int32 accumulators and the epilogue's dequantisation (+ the int8 twin).
+template <int PF, int WC, int WP, int ST, bool I8>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
     constexpr int kMaxP = ST == 2 ? kMaxP2 : kMaxP1;   // halo requests per wave and stage
+    constexpr int ES = I8 ? 1 : 2;                     // bytes per input element
+    typedef typename std::conditional<I8, i32x16_t, f32x16_t>::type acc_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = WC * WP;
     constexpr int R = kRing;
@@ -114,12 +120,12 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     const int RP = a.dma_rp, NHP = a.dma_nhp;
     const unsigned stage_bytes = (unsigned)NHP * 1024u;
     const unsigned smem_base = lds_addr(smem);
-    const int nsc = a.Cin >> 5;
+    const int nsc = I8 ? a.Cin >> 6 : a.Cin >> 5;   // stages of 64 bytes per pixel
     const int nids = a.nids;
     const int gstride = gridDim.x;
-    const int ics = a.in_cs;
+    const int ics = I8 ? a.qin_cs : a.in_cs, ico = I8 ? a.qin_co : a.in_co;
 
-    const i32x4_t rsA = make_rsrc(a.in, (unsigned)((size_t)a.B * a.H * a.W * ics * 2));
+    const i32x4_t rsA = make_rsrc(I8 ? (const void*)a.qin : (const void*)a.in, (unsigned)((size_t)a.B * a.H * a.W * ics * ES));
     const i32x4_t rsW = make_rsrc(a.wpk, 0xfffffe00u);
 
     auto decode = [&](int id, int& tile, int& cb) {
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             // consecutive output pixels, input columns two apart - still read 16 consecutive pixel slots
             const int hx = ST == 1 ? hc : (hc <= a.TW ? 2 * hc : 2 * (hc - a.TW - 1) + 1);
             const bool v = (i < npw) && (j < 4) && (hy < a.HH) && (ST == 1 || hc <= 2 * a.TW) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
-            hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * 2) + (unsigned)(j * 16) : kOob;
+            hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * ES) + (unsigned)(j * 16) : kOob;
         }
     };
     // requests of one stage (always npw of them: the counted waits below rely on it; behind the last stage they ask for nothing)
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         iy0 = ty_i * a.TH * ST - 1;
         ix0 = tx_i * a.TW * ST - 1;
         // modulo 2^32 (tensors up to 3.5 GiB): the origin may lie one row / column outside the image
-        base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)a.in_co) * 2u;
+        base = (((unsigned)(b * a.H + iy0) * (unsigned)a.W + (unsigned)ix0) * (unsigned)ics + (unsigned)ico) * (unsigned)ES;
     };
 
     const int fq = frag_pixel(lane & 31);   // fragment pixel this lane holds
@@ -241,31 +247,48 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     unsigned woff_next = nsc > 1 ? wbase + kUnits * 1024 : wbase;         // the one after it (the next item restarts the stream)
     i32x4_t wr[R];
 
-    f32x16_t acc[PF];
+    acc_t acc[PF];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[pf][r] = 0;
 
     // ---- fast epilogue (conv + bias (+ QARepVGG post-affine) + activation, no residual, into a 16-byte aligned fp16 view - every
     //      3x3 of the deploy graphs but the BottleRep shortcut convs): per-channel vectors of the block's couts in LDS (the cout
     //      block is the same for all its items: written once, visible behind the first stage barrier), stores through a buffer
     //      descriptor with 32-bit byte offsets.  Anything else takes conv_common.hpp's general epilogue.
-    float* ldsVec = reinterpret_cast<float*>(smem + 2u * stage_bytes);   // [bias | post scale | post shift][WC * 32]
+    //      The int8 form multiplies the exact int32 sums by s_x * s_w[c] first (a rounding of its own, as every int8 kernel of
+    //      this library) and may write the int8 twin of its output for quantised consumers - with or without the fp16 view.
+    float* ldsVec = reinterpret_cast<float*>(smem + 2u * stage_bytes);   // [bias | post scale | post shift | dequant][WC * 32]
     const bool has_post = a.pscale != nullptr;
-    const bool fast = a.res == nullptr && a.up == 0 && a.out != nullptr && a.vec16_ok && (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
+    const bool has_out = a.out != nullptr, has_qout = I8 && a.qout != nullptr;
+    const bool fast = a.res == nullptr && a.up == 0 && (has_out || has_qout) && (!has_out || a.vec16_ok) &&
+                      (!has_qout || ((a.qout_cs | a.qout_co) & 3) == 0) && (!I8 || a.acc_out == nullptr) &&
+                      (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
     const bool smooth_act = a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH;
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
-    auto fast_unit = [&](const f32x16_t& accv, unsigned obyte, const float (&bias16)[16]) {
+    const __amdgpu_buffer_rsrc_t rsQ =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.qout, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * (I8 ? a.qout_cs : 0)), 0x00020000);
+    auto fast_unit = [&](const acc_t& accv, unsigned obyte, unsigned qbyte, const float (&bias16)[16]) {
         const int kh = lane >> 5;
         const float* lb = ldsVec + wc * 32;
         float v[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float x[4] = {accv[g * 4 + 0] + bias16[g * 4 + 0], accv[g * 4 + 1] + bias16[g * 4 + 1], accv[g * 4 + 2] + bias16[g * 4 + 2],
-                          accv[g * 4 + 3] + bias16[g * 4 + 3]};
+            float x[4] = {(float)accv[g * 4 + 0], (float)accv[g * 4 + 1], (float)accv[g * 4 + 2], (float)accv[g * 4 + 3]};
+            if constexpr (I8) {   // exact int32 -> fp32, * s_x * s_w[c] as a rounding of its own (no fma with the bias add)
+                const float4 qs = *reinterpret_cast<const float4*>(lb + 3 * WC * 32 + 8 * g + 4 * kh);
+                x[0] *= qs.x;
+                x[1] *= qs.y;
+                x[2] *= qs.z;
+                x[3] *= qs.w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(x[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] += bias16[g * 4 + j];
             if (has_post) {   // QARepVGG: conv -> BatchNorm are two fp16 ops (finish16 in conv_common.hpp)
                 const float4 ps = *reinterpret_cast<const float4*>(lb + WC * 32 + 8 * g + 4 * kh);
                 const float4 pt = *reinterpret_cast<const float4*>(lb + 2 * WC * 32 + 8 * g + 4 * kh);
@@ -294,6 +317,16 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
                 pk[g][h] = __builtin_bit_cast(unsigned, t);
             }
         const unsigned ocol = (unsigned)((cb * WC + wc) * 32 + 8 * kh);
+        if constexpr (I8) {
+            if (has_qout) {   // the int8 twin: the SAME fp16 values, quantised with the consumers' scale; channels cfrag + 8 g + 4 kh ..
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned q = q8_quad(pk[g][0], pk[g][1], a.qo_inv2, a.qo_lo2, a.qo_hi2);
+                    __builtin_amdgcn_raw_buffer_store_b32(q, rsQ, (int)(qbyte + ocol + (unsigned)(8 * g) - (unsigned)(4 * kh)), 0, 0);
+                }
+            }
+            if (!has_out) return;
+        }
 #pragma unroll
         for (int gp = 0; gp < 2; ++gp) {   // pair groups across the two half-waves: one 16-byte store per lane and pair
             auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
@@ -327,6 +360,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         ldsVec[tid] = a.bias != nullptr ? a.bias[c] : 0.f;
         ldsVec[WC * 32 + tid] = has_post ? a.pscale[c] : 1.f;
         ldsVec[2 * WC * 32 + tid] = has_post ? a.pshift[c] : 0.f;
+        if constexpr (I8) ldsVec[3 * WC * 32 + tid] = a.qscale[c];
     }
 
     __builtin_amdgcn_sched_barrier(0);   // the requests above leave first; the arithmetic below fills their latency
@@ -440,8 +474,12 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
                 }
             }
             wait_lds<(TOTAL - 1 - i < G - 1 ? TOTAL - 1 - i : G - 1)>(fb[i % G]);
-            if (kWregProbe != 6)
-                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[i % G]), acc[pf], 0, 0, 0);
+            if constexpr (I8) {
+                if (kWregProbe != 6) acc[pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[u % R], fb[i % G], acc[pf], 0, 0, 0);
+            } else {
+                if (kWregProbe != 6)
+                    acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[u % R]), __builtin_bit_cast(h8_t, fb[i % G]), acc[pf], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (i + G < TOTAL) {
                 frag_read(std::integral_constant<int, i + G>{});
@@ -472,10 +510,13 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) {
                     const unsigned ob = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;   // overhang: dropped by the range check
-                    if (kWregProbe != 5) fast_unit(acc[pf], ob, bias16);
+                    const unsigned qb = (I8 && opix[pf] >= 0) ? (unsigned)opix[pf] * (unsigned)a.qout_cs + (unsigned)a.qout_co : kOob;
+                    if (kWregProbe != 5) fast_unit(acc[pf], ob, qb, bias16);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[pf][r] = 0;
                 }
+            } else if constexpr (I8) {   // the host (conv_mfma.hip: y6_conv_i8_variant) sends only fast-path layers here
+                __builtin_trap();
             } else {
                 const ConvKArgs ea = reload_args();
                 int opix[PF];
@@ -517,9 +558,9 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 // a lone wave per SIMD issues MFMAs at 89 % of the pipe's rate, and every phase lasts as long as the longer of the two partners.
 // Removed; git history has it.)
 
-template <int PF, int WC, int WP, int ST>
+template <int PF, int WC, int WP, int ST, bool I8 = false>
 int launch_wreg(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST>;
+    auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8>;
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
         Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -554,8 +595,19 @@ int launch_wreg(const Launch& L, hipStream_t s) {
 int y6_conv_wreg_max_pieces(int nw, int stride) { return (stride == 2 ? kMaxP2 : kMaxP1) * nw; }
 
 // L points at conv_mfma.hip's launch record (conv_common.hpp)
-int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, hipStream_t s) {
+int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, int i8, hipStream_t s) {
     const Launch& L = *static_cast<const Launch*>(Lp);
+    if (i8) {   // conv_mfma.hip: y6_conv_i8_launch (variants 10 / 11 / 12)
+        if (stride == 1 && wc == 4 && wpx == 1) {
+            switch (pf) {
+                case 7: return launch_wreg<7, 4, 1, 1, true>(L, s);
+                case 4: return launch_wreg<4, 4, 1, 1, true>(L, s);
+            }
+        }
+        if (stride == 2 && wc == 4 && wpx == 1 && pf == 3) return launch_wreg<3, 4, 1, 2, true>(L, s);
+        y6_set_error("conv_wreg: no int8 instantiation pf %d, %d x %d waves, stride %d", pf, wc, wpx, stride);
+        return Y6_EUNSUPPORTED;
+    }
     if (stride == 2 && wc == 4 && wpx == 1) {
         switch (pf) {
             case 4: return launch_wreg<4, 4, 1, 2>(L, s);
