@@ -640,7 +640,7 @@ def main():
                                    "; the reference-signature API step is reported under dropin_api",
                        "global_batch": world * args.batch, "parallelism": f"replicas x{world} (no collective)",
                        "weights": "random (oracle/synth.py), cls bias calibrated to ~2% candidates"},
-            "roofline": {"bound": "mfma", "kernel": ("int8 convs 3x3 / 3x3 s2 / 1x1 (conv3x3_dma_kernel<int8> conv_dma.hip, conv_i8_kernel conv_mfma.hip), all launches" if args.int8 else
+            "roofline": {"bound": "mfma", "kernel": ("int8 convs 3x3 / 3x3 s2 / 1x1 (conv3x3_wreg_kernel<int8> conv_wreg.hip, conv3x3_dma_kernel<int8> conv_dma.hip, conv_i8_kernel conv_mfma.hip), all launches" if args.int8 else
                                                      "3x3 stride-1 conv+bias+act (register-fed kernels conv_wreg.hip, LDS-DMA kernels conv_dma.hip); variants chosen per layer: "
                                                      + ", ".join(f"{n} x{c}" for n, c in sorted(dom_variants.items()))),
                          "achieved": round(achieved, 2), "peak": peak, "unit": "TOP/s" if args.int8 else "TFLOP/s",

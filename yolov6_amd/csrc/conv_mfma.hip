@@ -1252,7 +1252,7 @@ int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 }
 }  // namespace
 
-constexpr bool kI8WregDefault = false;
+constexpr bool kI8WregDefault = true;   // r04ai: S-QA int8 15 155 -> 15 875 img/s (two steps in flight), 12 825 -> 14 825 one at a time
 // what conv_wreg.hip's int8 form handles (it has the fast epilogue only): 3x3 over the producer's int8 twin, whole 64-channel
 // stages and 128-cout blocks, no residual, no raw accumulators, a 16-byte aligned fp16 view and / or a 4-byte aligned int8 twin
 static bool i8_wreg_ok(const y6_conv_i8_desc* q, int stride) {
@@ -1272,7 +1272,7 @@ int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
     // 10 / 11 / 12: the register-fed kernels (conv_wreg.hip, int8 form) - the producer's int8 twin, whole 64-channel stages, whole
     // 128-cout blocks; 7 pixel fragments per wave when the 200-pixel items fill the 512 resident blocks, else 4 (the fp16 rule,
-    // conv_misc.hip: default_variant); stride 2: 3 fragments.  Y6_I8_WREG=0 / 1: A/B switch (round 4: opt-in until measured)
+    // conv_misc.hip: default_variant); stride 2: 3 fragments.  Y6_I8_WREG=0: A/B switch (the LDS-DMA / per-tap kernels of round 3)
     static const bool wreg = getenv("Y6_I8_WREG") ? atoi(getenv("Y6_I8_WREG")) != 0 : kI8WregDefault;
     if (wreg && !no_dma && i8_wreg_ok(q, d->stride)) {
         const long px = (long)q->q_in.B * (q->q_in.H / d->stride) * (q->q_in.W / d->stride);

@@ -622,11 +622,6 @@ int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, int
             case 4: return launch_wreg<4, 4, 1, 1>(L, s);
         }
     }
-    if (stride == 1 && wc == 2 && wpx == 2) {
-        switch (pf) {
-            case 7: return launch_wreg<7, 2, 2, 1>(L, s);
-        }
-    }
     y6_set_error("conv_wreg: no instantiation pf %d, %d x %d waves, stride %d", pf, wc, wpx, stride);
     return Y6_EUNSUPPORTED;
 }
