@@ -120,7 +120,10 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     const int RP = a.dma_rp, NHP = a.dma_nhp;
     const unsigned stage_bytes = (unsigned)NHP * 1024u;
     const unsigned smem_base = lds_addr(smem);
-    const int nsc = I8 ? a.Cin >> 6 : a.Cin >> 5;   // stages of 64 bytes per pixel
+    const int nsc = I8 ? (a.Cin + 63) >> 6 : a.Cin >> 5;   // stages of 64 bytes per pixel
+    // int8 with fewer than 64 input channels (the 32 -> 64 stride-2 conv behind the stem): one stage whose upper pieces are not
+    // requested (LDS-DMA writes zeros for an out-of-range piece, the packed weights hold zeros there as well)
+    const int jmax = (I8 && a.Cin < 64) ? a.Cin >> 4 : 4;
     const int nids = a.nids;
     const int gstride = gridDim.x;
     const int ics = I8 ? a.qin_cs : a.in_cs, ico = I8 ? a.qin_co : a.in_co;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             // stride 2: a halo row is stored as [even columns (TW + 1) | odd columns (TW)], so that the 16 lanes of a read group -
             // consecutive output pixels, input columns two apart - still read 16 consecutive pixel slots
             const int hx = ST == 1 ? hc : (hc <= a.TW ? 2 * hc : 2 * (hc - a.TW - 1) + 1);
-            const bool v = (i < npw) && (j < 4) && (hy < a.HH) && (ST == 1 || hc <= 2 * a.TW) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
+            const bool v = (i < npw) && (j < jmax) && (hy < a.HH) && (ST == 1 || hc <= 2 * a.TW) && ((unsigned)(iy0 + hy) < (unsigned)a.H) && ((unsigned)(ix0 + hx) < (unsigned)a.W);
             hvoff[i] = v ? base + (unsigned)(hy * a.W + hx) * (unsigned)(ics * ES) + (unsigned)(j * 16) : kOob;
         }
     };
@@ -605,6 +608,9 @@ int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, int
             }
         }
         if (stride == 2 && wc == 4 && wpx == 1 && pf == 3) return launch_wreg<3, 4, 1, 2, true>(L, s);
+        // 64-cout blocks: two cout waves x two pixel waves (the 64-channel layers of the 160x160 / 80x80 maps)
+        if (stride == 1 && wc == 2 && wpx == 2 && pf == 4) return launch_wreg<4, 2, 2, 1, true>(L, s);
+        if (stride == 2 && wc == 2 && wpx == 2 && pf == 2) return launch_wreg<2, 2, 2, 2, true>(L, s);
         y6_set_error("conv_wreg: no int8 instantiation pf %d, %d x %d waves, stride %d", pf, wc, wpx, stride);
         return Y6_EUNSUPPORTED;
     }
