@@ -124,9 +124,9 @@ int y6_dma_probe(const void* src, unsigned bytes, unsigned lds_off, unsigned lon
  *                fp16 conv's epilogue (kept post-BN affine of QARepVGG common.py:338-339, activation, residual)
  * conv.in / conv.out are fp16 NHWC views as for y6_conv2d (conv.out.data may be NULL when only q_out is wanted);
  * conv.w_packed is the y6_pack_conv_weight_i8 image; conv.variant: 0 = heuristic, 1..6 force a per-tap tile, 7 / 8 / 9 the LDS-DMA kernels (512 / 256 / 512 pixel blocks; need q_in, k3 s1, Cin % 32 == 0; 9: Cin % 64 == 0),
- * 10 / 11 / 12 the register-fed kernels (csrc/conv_wreg.hip, int8 form: 7 / 4 pixel fragments per wave at stride 1, 3 at stride 2;
- * need q_in, k3, Cin % 64 == 0, Cout % 128 == 0, no residual, no acc_out, out 16-byte / q_out 4-byte aligned views; anything else
- * is Y6_EINVAL).                                                                                                            */
+ * 10 / 11 / 12 / 13 the register-fed kernels (csrc/conv_wreg.hip, int8 form: 7 / 4 pixel fragments per wave at stride 1, 3 at
+ * stride 2, 13: stride 2 with 64-cout blocks; need q_in, k3, Cin % 64 == 0 (or Cin == 32), Cout % 128 == 0 (13: % 64), no residual,
+ * no acc_out, out 16-byte / q_out 4-byte aligned views; anything else is Y6_EINVAL).                                        */
 typedef struct y6_conv_i8_desc {
     y6_conv_desc conv;
     const float* dequant;      /* [Cout]                                                          */

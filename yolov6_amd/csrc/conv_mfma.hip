@@ -906,9 +906,9 @@ const VariantCfg kVariants[] = {
     {2, 2, 4, "i8_dma8_c2p2", 8, 1, 2, 16, 1, 0, 1}, {2, 2, 4, "i8_dmaw8_c2p2", 8, 1, 2, 32, 1, 0, 1},
     {4, 6, 6, "wreg_p6", 4}, {4, 7, 6, "wreg_p7", 4}, {4, 4, 6, "wreg_p4", 4}, {4, 5, 6, "wreg_p5", 4},
     {4, 3, 6, "wregs2_p3", 4, 1, 2, 16, 2}, {4, 4, 6, "wregs2_p4", 4, 1, 2, 16, 2},
-    // int8 only (y6_conv_i8 variants 13 / 14): 64-cout blocks of the register-fed kernel - two cout waves x two pixel waves,
-    // 256 pixel slots at stride 1, 128 at stride 2
-    {2, 4, 6, "i8_wreg2_p4", 4, 1, 2, 16, 1, 0, 1}, {2, 2, 6, "i8_wreg2s2_p2", 4, 1, 2, 16, 2, 0, 1}};
+    // int8 only (y6_conv_i8 variant 13): 64-cout blocks of the register-fed stride-2 kernel - two cout waves x two pixel waves,
+    // 128 pixel slots
+    {2, 2, 6, "i8_wreg2s2_p2", 4, 1, 2, 16, 2, 0, 1}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int variant_index(const char* name) {
     for (int i = 0; i < kNumVariants; ++i)
@@ -1255,7 +1255,7 @@ int launch_i8_cfg(const Launch& L, int ks, int st, hipStream_t s) {
 }
 }  // namespace
 
-constexpr bool kI8Wreg2Default = false;   // the 64-cout forms: opt-in until measured
+constexpr bool kI8Wreg2Default = true;    // r04ak: 64 -> 64 stride 2 @160 -> 80: 50.8 -> 36 us; S-QA int8 15 961 -> 16 262 / 16 287 img/s with it and its (deleted) stride-1 sibling
 constexpr bool kI8WregDefault = true;   // r04ai: S-QA int8 15 155 -> 15 875 img/s (two steps in flight), 12 825 -> 14 825 one at a time
 // what conv_wreg.hip's int8 form handles (it has the fast epilogue only): 3x3 over the producer's int8 twin, whole 64-channel
 // stages and 128-cout blocks, no residual, no raw accumulators, a 16-byte aligned fp16 view and / or a 4-byte aligned int8 twin
@@ -1271,7 +1271,7 @@ static bool i8_wreg_ok(const y6_conv_i8_desc* q, int stride, int cout_waves) {
 }
 int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     const y6_conv_desc* d = &q->conv;
-    if (d->variant >= 1 && d->variant <= 14) return d->variant;
+    if (d->variant >= 1 && d->variant <= 13) return d->variant;
     const int co = d->out.data ? d->out.C : q->q_out.C;
     static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
     // 10 / 11 / 12: the register-fed kernels (conv_wreg.hip, int8 form) - the producer's int8 twin, whole 64-channel stages, whole
@@ -1284,13 +1284,11 @@ int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
         if (d->stride == 1) return items200 >= 512 ? 10 : 11;
         if (d->stride == 2 && q->q_in.H % 2 == 0 && q->q_in.W % 2 == 0) return 12;
     }
-    // 13 / 14: the same kernel with 64-cout blocks (two cout waves x two pixel waves) for the layers 10-12 cannot take: Cout % 64 == 0,
-    // Cin % 64 == 0 or Cin == 32.  Y6_I8_WREG2=0 / 1: A/B switch
+    // 13: the stride-2 kernel with 64-cout blocks (two cout waves x two pixel waves) for the layers 12 cannot take: Cout % 64 == 0,
+    // Cin % 64 == 0 or Cin == 32.  Y6_I8_WREG2=0: A/B switch (the per-tap kernel).  (Its stride-1 sibling lost to the LDS-DMA
+    // kernels on the 64 -> 64 layers, r04ak, and was deleted.)
     static const bool wreg2 = getenv("Y6_I8_WREG2") ? atoi(getenv("Y6_I8_WREG2")) != 0 : kI8Wreg2Default;
-    if (wreg && wreg2 && !no_dma && i8_wreg_ok(q, d->stride, 2)) {
-        if (d->stride == 1) return 13;
-        if (d->stride == 2 && q->q_in.H % 2 == 0 && q->q_in.W % 2 == 0) return 14;
-    }
+    if (wreg && wreg2 && !no_dma && d->stride == 2 && i8_wreg_ok(q, 2, 2) && q->q_in.H % 2 == 0 && q->q_in.W % 2 == 0) return 13;
     // 7 / 8 / 9: the LDS-DMA kernels (conv_dma.hip) - need the producer's int8 twin and whole 32- (9: 64-) channel chunks
     if (!no_dma && d->ksize == 3 && d->stride == 1 && q->q_in.data && q->q_in.C % 32 == 0 && co >= 64) {
         const long npix = (long)q->q_in.B * q->q_in.H * q->q_in.W;
@@ -1337,14 +1335,14 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
     if (dma)
         Y6_REQUIRE(d.ksize == 3 && d.stride == 1 && has_qin && q->q_in.C % 32 == 0, "conv_i8: the LDS-DMA variants need k3 s1, an int8 input view and Cin %% 32 == 0");
     if (wreg)
-        Y6_REQUIRE(i8_wreg_ok(q, (variant == 12 || variant == 14) ? 2 : 1, variant >= 13 ? 2 : 4),
-                   "conv_i8: the register-fed variants need k3, an int8 input view, Cin %% 64 == 0 (or 32), Cout %% 128 == 0 (13 / 14: %% 64), no residual, aligned outputs");
+        Y6_REQUIRE(i8_wreg_ok(q, variant >= 12 ? 2 : 1, variant == 13 ? 2 : 4),
+                   "conv_i8: the register-fed variants need k3, an int8 input view, Cin %% 64 == 0 (or 32), Cout %% 128 == 0 (13: %% 64), no residual, aligned outputs");
     Y6_REQUIRE(dma || wreg || !(d.stride == 2 && kVariants[variant].pf != 1), "conv_i8: stride 2 needs a pf=1 variant");
     Launch L;
     static const int kv7 = variant_index("i8_dma8_c2p2"), kv8 = variant_index("dma_c2p2"), kv9 = variant_index("i8_dmaw8_c2p2"),
                      kv10 = variant_index("wreg_p7"), kv11 = variant_index("wreg_p4"), kv12 = variant_index("wregs2_p3"),
-                     kv13 = variant_index("i8_wreg2_p4"), kv14 = variant_index("i8_wreg2s2_p2");
-    const int kv = wreg ? (variant == 10 ? kv10 : variant == 11 ? kv11 : variant == 12 ? kv12 : variant == 13 ? kv13 : kv14)
+                     kv13 = variant_index("i8_wreg2s2_p2");
+    const int kv = wreg ? (variant == 10 ? kv10 : variant == 11 ? kv11 : variant == 12 ? kv12 : kv13)
                         : dma ? (variant == 7 ? kv7 : (variant == 8 ? kv8 : kv9)) : variant;   // kVariants row that sizes the tile
     if (variant == 9) Y6_REQUIRE(q->q_in.C % 64 == 0, "conv_i8: variant 9 needs Cin %% 64 == 0");
     int rc = build_launch(&d, kv, 0, 0, 0, &L);

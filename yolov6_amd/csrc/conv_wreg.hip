@@ -600,7 +600,7 @@ int y6_conv_wreg_max_pieces(int nw, int stride) { return (stride == 2 ? kMaxP2 :
 // L points at conv_mfma.hip's launch record (conv_common.hpp)
 int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, int i8, hipStream_t s) {
     const Launch& L = *static_cast<const Launch*>(Lp);
-    if (i8) {   // conv_mfma.hip: y6_conv_i8_launch (variants 10 / 11 / 12)
+    if (i8) {   // conv_mfma.hip: y6_conv_i8_launch (variants 10 - 13)
         if (stride == 1 && wc == 4 && wpx == 1) {
             switch (pf) {
                 case 7: return launch_wreg<7, 4, 1, 1, true>(L, s);
@@ -608,8 +608,9 @@ int y6_conv_wreg_launch(const void* Lp, int pf, int wc, int wpx, int stride, int
             }
         }
         if (stride == 2 && wc == 4 && wpx == 1 && pf == 3) return launch_wreg<3, 4, 1, 2, true>(L, s);
-        // 64-cout blocks: two cout waves x two pixel waves (the 64-channel layers of the 160x160 / 80x80 maps)
-        if (stride == 1 && wc == 2 && wpx == 2 && pf == 4) return launch_wreg<4, 2, 2, 1, true>(L, s);
+        // 64-cout blocks at stride 2: two cout waves x two pixel waves (r04ak: 64 -> 64 @160 -> 80: 36 us against 51 for the per-tap
+        // kernel.  The stride-1 form of the same shape - 256 pixel slots, 16 x 16 tiles - lost 1-4 us per layer to the LDS-DMA kernel
+        // on the 64 -> 64 layers of the 160 x 160 / 80 x 80 maps and was deleted.)
         if (stride == 2 && wc == 2 && wpx == 2 && pf == 2) return launch_wreg<2, 2, 2, 2, true>(L, s);
         y6_set_error("conv_wreg: no int8 instantiation pf %d, %d x %d waves, stride %d", pf, wc, wpx, stride);
         return Y6_EUNSUPPORTED;
