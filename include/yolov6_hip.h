@@ -137,6 +137,10 @@ typedef struct y6_conv_i8_desc {
     void* acc_out;             /* optional int32 [B*Ho*Wo][Cout]: raw accumulators (parity tests)   */
 } y6_conv_i8_desc;
 int y6_conv2d_i8(const y6_conv_i8_desc* d, void* stream);
+/* the kernel variant (1..13, see conv.variant above) y6_conv2d_i8 would run for this descriptor: host arithmetic only, nothing is
+ * launched and no pointer is dereferenced (only tested for NULL) - so that a caller planning int8 twins can see whether a conv
+ * gets the register-fed / LDS-DMA kernels (which need q_in) before it decides where twins are written */
+int y6_conv2d_i8_variant(const y6_conv_i8_desc* d);
 /* src: int8 OIHW [Cout][Cin][K][K] -> [cout/32][cin/64][tap][kstep=2][lane=64][16] (zero padded); bytes of the image: */
 size_t y6_packed_weight_i8_bytes(int Cout, int Cin, int K);
 int y6_pack_conv_weight_i8(const void* src_i8_oihw, int Cout, int Cin, int K, void* dst, void* stream);

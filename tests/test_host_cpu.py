@@ -614,6 +614,56 @@ def _device_kernel_notes(lib_path):
     return out
 
 
+def test_int8_conv_variant_heuristic_over_the_sqa_layer_shapes(hip_lib):
+    """y6_conv2d_i8_variant is host arithmetic (nothing launched): which kernel each int8 conv shape of YOLOv6-S-QA at 640 x 640,
+    batch 32 gets, and that every precondition of the register-fed kernels (conv_wreg.hip, int8 form: it has the fast epilogue
+    only) sends a conv back to the kernels that can do it.  Pointers are only tested for NULL."""
+    import ctypes as C
+
+    def desc(B, H, W, Cin, Cout, k, stride, q_in=True, out=True, q_out=True, res=False, acc=False, out_cstride=None, q_out_coff=0):
+        d = _lib.ConvI8Desc()
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        fake = 1 << 20      # 16-byte aligned, never dereferenced
+        d.conv.inp = _lib.Tensor(fake, B, H, W, Cin, Cin, 0)
+        d.conv.out = _lib.Tensor(fake if out else None, B, Ho, Wo, Cout, out_cstride or Cout, 0)
+        d.conv.res = _lib.Tensor(fake if res else None, B, Ho, Wo, Cout, Cout, 0)
+        d.conv.w_packed = fake
+        d.conv.ksize, d.conv.stride, d.conv.variant = k, stride, 0
+        d.dequant = fake
+        d.in_amax = 1.0
+        d.q_in = _lib.Tensor(fake if q_in else None, B, H, W, Cin, Cin, 0)
+        d.q_out = _lib.Tensor(fake if q_out else None, B, Ho, Wo, Cout, Cout + q_out_coff, q_out_coff)
+        d.q_out_amax = 1.0
+        d.acc_out = fake if acc else None
+        return d
+
+    v = lambda *a, **k: hip_lib.y6_conv2d_i8_variant(C.byref(desc(*a, **k)))
+    # the backbone of S-QA: (B, H, W, Cin, Cout, k, stride) -> variant
+    assert v(32, 80, 80, 128, 128, 3, 1) == 10        # 200-pixel items fill the 512 resident blocks: 7 fragments per wave
+    assert v(32, 40, 40, 256, 256, 3, 1) == 10
+    assert v(32, 20, 20, 512, 512, 3, 1) == 11        # 4 fragments per wave
+    assert v(32, 160, 160, 64, 128, 3, 2) == 12
+    assert v(32, 80, 80, 128, 256, 3, 2) == 12
+    assert v(32, 160, 160, 64, 64, 3, 2) == 13        # 64-cout blocks, stride 2
+    assert v(32, 320, 320, 32, 64, 3, 2) == 13        # 32 input channels: half a stage
+    assert v(32, 160, 160, 64, 64, 3, 1) in (8, 9)    # 64 couts at stride 1: the LDS-DMA kernels (their register-fed form lost)
+    assert v(32, 80, 80, 128, 128, 1, 1) in (1, 2, 3)  # 1x1: per-tap tiles
+    # preconditions: each one alone sends the conv elsewhere
+    base = (32, 80, 80, 128, 128, 3, 1)
+    assert v(*base, q_in=False) in (4, 5)             # quantise-on-load: per-tap
+    assert v(*base, res=True) in (8, 9)               # residual: the LDS-DMA kernels' general epilogue
+    assert v(*base, acc=True) in (8, 9)               # accumulator dump
+    assert v(*base, out_cstride=132) in (8, 9)        # fp16 view not 16-byte aligned per pixel
+    assert v(*base, q_out_coff=2) in (8, 9)           # int8 twin not 4-byte aligned
+    assert v(*base, out=False) == 10                  # twin only is fine
+    assert v(32, 81, 81, 64, 128, 3, 2) in (1, 2, 3)  # odd map at stride 2
+    assert v(32, 80, 80, 96, 128, 3, 1) in (8,)       # 96 input channels: not whole 64-channel stages
+    d = desc(*base)
+    d.conv.variant = 5
+    assert hip_lib.y6_conv2d_i8_variant(C.byref(d)) == 5   # a forced variant is returned as is
+    assert hip_lib.y6_conv2d_i8_variant(None) == 0
+
+
 def test_wreg_kernels_keep_their_asm_loaded_registers():
     """conv_wreg.hip loads weight and pixel fragments by inline asm and awaits them by hand-counted s_waitcnt: hipcc does not know
     those registers are still in flight, so a spilled one (scratch store of a value that has not landed) is a WRONG RESULT, not a

@@ -217,6 +217,7 @@ SIGNATURES = {
     "y6_pack_convt2x2_weight": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "y6_conv2d_i8": (C.c_int, [C.POINTER(ConvI8Desc), C.c_void_p]),
+    "y6_conv2d_i8_variant": (C.c_int, [C.POINTER(ConvI8Desc)]),
     "y6_packed_weight_i8_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "y6_pack_conv_weight_i8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "y6_absmax": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_void_p]),

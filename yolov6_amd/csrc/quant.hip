@@ -188,6 +188,11 @@ extern "C" int y6_conv2d_i8(const y6_conv_i8_desc* d, void* stream) {
     return y6_conv_i8_launch(d, (hipStream_t)stream);
 }
 
+extern "C" int y6_conv2d_i8_variant(const y6_conv_i8_desc* d) {
+    if (!d) return 0;
+    return y6_conv_i8_variant(d);
+}
+
 extern "C" int y6_plan_add_conv_i8(y6_plan* p, const y6_conv_i8_desc* d) {
     Y6_REQUIRE(p && d, "plan_add_conv_i8: null argument");
     return y6_plan_push(p, y6_conv_i8_launch, d, Y6_TOP_CONV_I8, i8_flops(d), i8_bytes(d));
