@@ -102,6 +102,24 @@ int y6_conv_variants(void);
 const char* y6_conv_variant_name(int i);
 /* 1 if variant i can run desc d */
 int y6_conv_variant_supports(const y6_conv_desc* d, int i);
+/* The launch geometry variant i would use for desc d: host arithmetic only (nothing is launched, no pointer is dereferenced; the
+ * CU count is the device's, or 256 without a device).  For callers that want to know a layer's tiling before they commit to a
+ * batch size, and for the property test of the tile choosers (tests/test_host_cpu.py).  Returns Y6_EUNSUPPORTED when the
+ * variant does not take the conv.                                                                                         */
+typedef struct y6_conv_geometry {
+    int32_t tile_h, tile_w;        /* output pixels of one work item                                        */
+    int32_t tiles_x, tiles_y;      /* tiles per image                                                       */
+    int32_t items;                 /* work items of the launch (tiles x cout blocks, padded to whole groups) */
+    int32_t cout_blocks;           /* cout blocks (a block of the grid computes one of them per item)       */
+    int32_t block_pixels;          /* pixel slots of a work item (tile_h * tile_w <= block_pixels)          */
+    int32_t halo_h, halo_w;        /* input rows / columns a tile reads                                     */
+    int32_t halo_pieces;           /* register-fed / LDS-DMA kernels: 1 KiB requests per halo stage, else 0 */
+    int32_t halo_pieces_max;       /* ... and what the kernel can issue per stage (0: not applicable)       */
+    int32_t row_pitch;             /* register-fed kernels: pixel slots per halo row in LDS, else 0         */
+    uint64_t lds_bytes;            /* dynamic LDS of the launch                                             */
+    uint64_t lds_limit;            /* what the kernel family may ask for                                    */
+} y6_conv_geometry;
+int y6_conv_launch_geometry(const y6_conv_desc* d, int variant, y6_conv_geometry* out);
 /* Self-test of the LDS-DMA addressing the "dma*" conv variants rely on (csrc/conv_dma.hip): one wave copies 1 KiB from
  * src into LDS at byte offset lds_off (< 160 KiB) by `buffer_load_dwordx4 ... lds` and writes it to dst; lanes whose bit
  * is set in oob_mask request a piece beyond `bytes` and must read zeros.  No reference counterpart (diagnostic).       */

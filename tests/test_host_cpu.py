@@ -664,6 +664,98 @@ def test_int8_conv_variant_heuristic_over_the_sqa_layer_shapes(hip_lib):
     assert hip_lib.y6_conv2d_i8_variant(None) == 0
 
 
+def _conv_desc_for_geometry(B, H, W, Cin, Cout, k, stride):
+    d = _lib.ConvDesc()
+    fake = 1 << 20      # 16-byte aligned, never dereferenced
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    d.inp = _lib.Tensor(fake, B, H, W, Cin, Cin, 0)
+    d.out = _lib.Tensor(fake, B, Ho, Wo, Cout, Cout, 0)
+    d.res = _lib.Tensor(None, 0, 0, 0, 0, 0, 0)
+    d.w_packed, d.w_oihw = fake, fake
+    d.ksize, d.stride, d.variant = k, stride, -1
+    return d, Ho, Wo
+
+
+def _check_geometry(hip_lib, shape):
+    """Invariants of one conv shape's launch geometry under EVERY kernel variant that claims to support it."""
+    import ctypes as C
+    B, H, W, Cin, Cout, k, stride = shape
+    d, Ho, Wo = _conv_desc_for_geometry(*shape)
+    g = _lib.ConvGeometry()
+    took = 0
+    for i in range(1, hip_lib.y6_conv_variants()):
+        if not hip_lib.y6_conv_variant_supports(C.byref(d), i):
+            assert hip_lib.y6_conv_launch_geometry(C.byref(d), i, C.byref(g)) != 0
+            continue
+        name = hip_lib.y6_conv_variant_name(i).decode()
+        tag = f"{name} on {shape}"
+        assert hip_lib.y6_conv_launch_geometry(C.byref(d), i, C.byref(g)) == 0, tag
+        took += 1
+        assert g.lds_bytes <= g.lds_limit, f"{tag}: {g.lds_bytes} bytes of LDS"
+        assert g.tile_h >= 1 and g.tile_w >= 1 and g.tile_h * g.tile_w <= g.block_pixels, tag
+        if k == 1:       # a GEMM over flattened pixels: one image of one row
+            npix = B * Ho * Wo
+            assert g.tile_h == 1 and (g.tiles_x - 1) * g.tile_w < npix <= g.tiles_x * g.tile_w and g.tiles_y == 1, tag
+            tiles = g.tiles_x
+        else:
+            assert (g.tiles_x - 1) * g.tile_w < Wo <= g.tiles_x * g.tile_w, tag
+            assert (g.tiles_y - 1) * g.tile_h < Ho <= g.tiles_y * g.tile_h, tag
+            assert g.halo_h == (g.tile_h - 1) * stride + k and g.halo_w == (g.tile_w - 1) * stride + k, tag
+            tiles = B * g.tiles_x * g.tiles_y
+        assert g.cout_blocks >= 1 and g.items >= tiles * g.cout_blocks, tag
+        if g.cout_blocks > 1:
+            assert g.items % (8 * g.cout_blocks) == 0, tag     # ids of one tile's cout blocks share id % 8 (XCD)
+        if name.startswith("wreg"):
+            assert 0 < g.halo_pieces <= g.halo_pieces_max, tag
+            assert g.row_pitch >= g.halo_w, tag                                     # a halo row fits its LDS row
+            assert g.halo_pieces * 64 >= 5 * g.halo_h * g.row_pitch, tag            # 5 16-byte slots per halo pixel
+            assert g.lds_bytes >= 2 * g.halo_pieces * 1024, tag                      # two stage images
+            assert Cin % 32 == 0 and Cout % 128 == 0, tag
+    return took
+
+
+def test_conv_launch_geometry_on_the_benchmarked_layers(hip_lib):
+    """y6_conv_launch_geometry is host arithmetic (nothing launched): every 3x3 / 1x1 layer shape of YOLOv6-S at 640 x 640 b32 and
+    YOLOv6-L6 at 1280 x 1280 b8, under every kernel variant that takes it."""
+    shapes = []
+    for B, size, chans in ((32, 640, (32, 64, 128, 256, 512)), (8, 1280, (64, 128, 256, 512, 768, 1024))):
+        for lvl, c in enumerate(chans):
+            hw = size // (2 << lvl)
+            shapes += [(B, hw, hw, c, c, 3, 1), (B, hw, hw, c, c, 1, 1)]
+            if lvl + 1 < len(chans):
+                shapes.append((B, hw, hw, c, chans[lvl + 1], 3, 2))
+    for sh in shapes:
+        assert _check_geometry(hip_lib, sh) >= 1, sh
+    # the register-fed kernels are the ones the headline runs on: whole rounds of the persistent walk on the large maps
+    import ctypes as C
+    d, _, _ = _conv_desc_for_geometry(32, 40, 40, 256, 256, 3, 1)
+    g = _lib.ConvGeometry()
+    p7 = [i for i in range(hip_lib.y6_conv_variants()) if hip_lib.y6_conv_variant_name(i) == b"wreg_p7"][0]
+    assert hip_lib.y6_conv_launch_geometry(C.byref(d), p7, C.byref(g)) == 0
+    assert g.tile_h * g.tile_w == 200 and g.items == 512      # 5 x 40 / 10 x 20 tiles: one item per resident block
+
+
+def test_conv_launch_geometry_property(hip_lib):
+    """Random conv shapes (odd maps, thin maps, one-pixel maps, ragged channel counts, large batches): whatever a variant claims to
+    support, its tile must cover the map, fit its pixel slots and its LDS, and - for the register-fed kernels - its halo must fit
+    the requests a stage can issue.  A violated invariant here is a memory fault or a refused launch on a user's shape."""
+    from hypothesis import given, settings, strategies as st
+
+    chan = st.sampled_from([8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 320, 384, 512, 768, 1024])
+    dim = st.one_of(st.integers(1, 40), st.sampled_from([64, 80, 96, 160, 320, 333, 640]))
+
+    @settings(max_examples=250, deadline=None, derandomize=True)
+    @given(B=st.sampled_from([1, 2, 3, 8, 32, 64]), H=dim, W=dim, Cin=chan, Cout=chan, k=st.sampled_from([1, 3]), stride=st.sampled_from([1, 2]))
+    def run(B, H, W, Cin, Cout, k, stride):
+        if k == 1 and stride == 2:
+            return
+        if B * H * W * max(Cin, Cout) >= 1 << 30:      # the library's tensor-size limits are tested elsewhere
+            return
+        _check_geometry(hip_lib, (B, H, W, Cin, Cout, k, stride))
+
+    run()
+
+
 def test_wreg_kernels_keep_their_asm_loaded_registers():
     """conv_wreg.hip loads weight and pixel fragments by inline asm and awaits them by hand-counted s_waitcnt: hipcc does not know
     those registers are still in flight, so a spilled one (scratch store of a value that has not landed) is a WRONG RESULT, not a

@@ -34,6 +34,12 @@ class ConvI8Desc(C.Structure):
                 ("q_out_amax", C.c_float), ("acc_out", C.c_void_p)]
 
 
+class ConvGeometry(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("tile_h", "tile_w", "tiles_x", "tiles_y", "items", "cout_blocks", "block_pixels", "halo_h",
+                                         "halo_w", "halo_pieces", "halo_pieces_max", "row_pitch")] + \
+               [("lds_bytes", C.c_uint64), ("lds_limit", C.c_uint64)]
+
+
 class ConvTDesc(C.Structure):
     _fields_ = [("inp", Tensor), ("out", Tensor), ("w_packed", C.c_void_p), ("bias", C.c_void_p)]
 
@@ -197,7 +203,7 @@ IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
 # public struct of include/yolov6_hip.h -> its ctypes mirror above (load() checks every size against y6_abi_sizeof)
 STRUCTS = {
-    "y6_tensor": Tensor, "y6_conv_desc": ConvDesc, "y6_conv_i8_desc": ConvI8Desc, "y6_convt_desc": ConvTDesc, "y6_stem_desc": StemDesc,
+    "y6_tensor": Tensor, "y6_conv_desc": ConvDesc, "y6_conv_geometry": ConvGeometry, "y6_conv_i8_desc": ConvI8Desc, "y6_convt_desc": ConvTDesc, "y6_stem_desc": StemDesc,
     "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
@@ -225,6 +231,7 @@ SIGNATURES = {
     "y6_conv_variants": (C.c_int, []),
     "y6_conv_variant_name": (C.c_char_p, [C.c_int]),
     "y6_conv_variant_supports": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "y6_conv_launch_geometry": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(ConvGeometry)]),
     "y6_dma_probe": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "y6_convt2x2": (C.c_int, [C.POINTER(ConvTDesc), C.c_void_p]),
     "y6_stem_conv": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),

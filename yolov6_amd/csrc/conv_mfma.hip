@@ -1428,6 +1428,39 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
     return 1;
 }
 
+extern "C" int y6_conv_launch_geometry(const y6_conv_desc* d, int variant, y6_conv_geometry* g) {
+    Y6_REQUIRE(d && g, "conv_launch_geometry: null argument");
+    if (variant < 1 || variant >= kNumVariants || !y6_conv_mfma_supports(d, variant)) {
+        y6_set_error("conv_launch_geometry: variant %d does not take this conv", variant);
+        return Y6_EUNSUPPORTED;
+    }
+    Launch L;
+    int rc = build_launch(d, variant, 0, 0, 0, &L);
+    if (rc) return rc;
+    const VariantCfg& vc = kVariants[variant];
+    const ConvKArgs& k = L.k;
+    memset(g, 0, sizeof(*g));
+    g->tile_h = k.TH;
+    g->tile_w = k.TW;
+    g->tiles_x = k.tiles_x;
+    g->tiles_y = k.tiles_y;
+    g->items = k.nids;
+    g->cout_blocks = k.ncb;
+    g->block_pixels = vc.persist == 6 ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
+    g->halo_h = k.HH;
+    g->halo_w = k.HWd;
+    if (vc.persist == 6) {
+        g->halo_pieces = k.dma_nhp;
+        g->halo_pieces_max = y6_conv_wreg_max_pieces(vc.nw, d->stride);
+        g->row_pitch = k.dma_rp;
+    } else if (vc.persist == 4) {
+        g->halo_pieces = k.dma_nhp;
+    }
+    g->lds_bytes = L.lds;
+    g->lds_limit = (vc.persist == 0 ? 128 : 160) * 1024;
+    return Y6_OK;
+}
+
 int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int up, int updy, int updx) {
     if (!y6_conv_mfma_supports(d, variant)) {
         y6_set_error("conv_mfma: variant %d does not support this conv (k%d s%d Cin %d Cout %d)", variant, d->ksize,

@@ -29,6 +29,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
     static const struct { const char* n; size_t s; } kTab[] = {
         {"y6_tensor", sizeof(y6_tensor)},
         {"y6_conv_desc", sizeof(y6_conv_desc)},
+        {"y6_conv_geometry", sizeof(y6_conv_geometry)},
         {"y6_conv_i8_desc", sizeof(y6_conv_i8_desc)},
         {"y6_convt_desc", sizeof(y6_convt_desc)},
         {"y6_stem_desc", sizeof(y6_stem_desc)},
