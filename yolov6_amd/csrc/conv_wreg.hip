@@ -1,4 +1,5 @@
-// conv_wreg.hip - 3x3 stride-1 fp16 convolution, weights through REGISTERS, halo through LDS in 32-channel stages.
+// conv_wreg.hip - 3x3 convolution (stride 1 and 2; fp16, and int8 since r04ai), weights through REGISTERS, halo through LDS in
+// 64-byte-per-pixel stages (32 fp16 / 64 int8 channels).
 //
 // Replaces the same aten compositions as conv_dma.hip (reference yolov6/layers/common.py:51-54 ConvModule, :247-248 RepVGGBlock
 // deploy branch, :338-339 QARepVGGBlock, :605-608 BottleRep): the fused 3x3 conv + bias (+ post-affine) + activation of the
