@@ -167,7 +167,6 @@ def test_inflight_runner_equals_one_at_a_time():
     from oracle import synth
     import copy
     from yolov6_amd.pipeline import InflightRunner
-    from yolov6_amd.utils.nms import non_max_suppression
     import bench
     cfg, sd, model, x = _bench_setup("yolov6s", 320, 8)
     batches = [synth.synth_images(8, 320, seed=40 + i).to(x.device).half() for i in range(5)]
@@ -176,8 +175,6 @@ def test_inflight_runner_equals_one_at_a_time():
     one = InflightRunner(model, batches[0].clone(), depth=1, conf_thres=bench.CONF, iou_thres=bench.IOU, multi_label=True,
                          max_det=bench.MAX_DET, autotune=False)
     want = [[t.clone() for t in one.submit(b).result()[0]] for b in batches]
-    ref0 = non_max_suppression(model(batches[0])[0], bench.CONF, bench.IOU, multi_label=True, max_det=bench.MAX_DET)
-    assert [int(t.shape[0]) for t in ref0] == [int(t.shape[0]) for t in want[0]] or True     # (model(x) may run timed variants)
     run = InflightRunner(copy.deepcopy(model), batches[0].clone(), depth=2, conf_thres=bench.CONF, iou_thres=bench.IOU, multi_label=True,
                          max_det=bench.MAX_DET, autotune=False)
     tickets = [run.submit(b) for b in batches[:2]]
@@ -188,6 +185,11 @@ def test_inflight_runner_equals_one_at_a_time():
         tickets.append(run.submit(b))
     for t in tickets:
         got.append([u.clone() for u in t.result()[0]])
+    stale = run.submit(batches[0])
+    run.submit(batches[1])
+    run.submit(batches[2])                               # reuses the slot of `stale`
+    with pytest.raises(RuntimeError, match="slot was reused"):
+        stale.result()
     assert len(got) == len(want) == 5
     for k, (g, w) in enumerate(zip(got, want)):
         assert len(g) == len(w) == 8

@@ -756,6 +756,36 @@ def test_conv_launch_geometry_property(hip_lib):
     run()
 
 
+def test_inflight_ticket_expires_when_its_slot_is_reused():
+    """pipeline.Ticket.result(): rows are independent copies by default; a ticket whose slot a later submit() took raises instead
+    of returning the later batch's rows (host logic only: a stand-in runner and event)."""
+    from yolov6_amd.pipeline import Ticket
+
+    class Ev:
+        waited = 0
+
+        def synchronize(self):
+            Ev.waited += 1
+
+    class Runner:
+        generation = [3, 7]
+        plans = [None, None]
+
+    dets = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6)
+    count = torch.tensor([2, 0], dtype=torch.int32)
+    t = Ticket(None, dets, None, count, Ev(), Runner, 1, 7)
+    rows, counts = t.result()
+    assert counts == [2, 0] and [tuple(r.shape) for r in rows] == [(2, 6), (0, 6)] and Ev.waited == 1
+    dets[0, 0, 0] = -1.0
+    assert float(rows[0][0, 0]) == 0.0                                  # a copy
+    views, _ = t.result(copy=False)
+    assert float(views[0][0, 0]) == -1.0                                # a view
+    Runner.generation[1] = 8                                            # the slot was handed to a later batch
+    with pytest.raises(RuntimeError, match="slot was reused"):
+        t.result()
+    assert Ticket(None, dets, None, count, Ev()).result()[1] == [2, 0]  # a bare ticket (no runner) has nothing to check
+
+
 def test_wreg_kernels_keep_their_asm_loaded_registers():
     """conv_wreg.hip loads weight and pixel fragments by inline asm and awaits them by hand-counted s_waitcnt: hipcc does not know
     those registers are still in flight, so a spilled one (scratch store of a value that has not landed) is a WRONG RESULT, not a

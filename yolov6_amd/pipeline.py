@@ -28,14 +28,25 @@ from .utils.nms import nms_raw
 
 
 class Ticket:
-    def __init__(self, det, dets, index, count, event):
+    def __init__(self, det, dets, index, count, event, runner=None, slot=0, generation=0):
         self.det, self.dets, self.index, self.count, self._event = det, dets, index, count, event
+        self._runner, self._slot, self._generation = runner, slot, generation
 
-    def result(self):
-        """Per-image detection lists as `non_max_suppression` returns them (one host synchronisation on this batch's event)."""
+    def result(self, copy=True):
+        """Per-image detection lists as `non_max_suppression` returns them (one host synchronisation on this batch's event).
+
+        The tensors of a slot (raw head output, NMS result) are reused by the submission `depth` later: a ticket whose slot has
+        been handed to a later batch raises instead of returning that batch's rows.  `copy=True` (default) returns independent
+        tensors, as the reference's `non_max_suppression` does; `copy=False` returns views into the slot's result buffer, valid
+        until that slot is submitted to again."""
+        r = self._runner
+        if r is not None and r.generation[self._slot] != self._generation:
+            raise RuntimeError("yolov6_amd.pipeline: this ticket's slot was reused by a later submit() before result() was called "
+                               f"(depth {len(r.plans)}): consume a ticket within `depth` submissions")
         self._event.synchronize()
         counts = self.count.tolist()
-        return [self.dets[i, :n] for i, n in enumerate(counts)], counts
+        rows = [self.dets[i, :n] for i, n in enumerate(counts)]
+        return ([t.clone() for t in rows] if copy else rows), counts
 
 
 class InflightRunner:
@@ -53,6 +64,7 @@ class InflightRunner:
         self.tokens = [p.attach_nms(conf_thres, classes, multi_label) for p in self.plans]
         self.streams = pick_streams(depth, self._trial)
         self.done = [None] * depth
+        self.generation = [0] * depth       # per slot: how many batches it has been handed (Ticket.result checks it)
         self.i = 0
 
     def _trial(self, streams):
@@ -67,21 +79,26 @@ class InflightRunner:
         return time.perf_counter() - t
 
     def submit(self, x: torch.Tensor) -> Ticket:
-        """Enqueue forward + NMS of one batch (same shape / dtype as the example).  The slot's previous batch must have been
-        consumed (`Ticket.result()`) or be older than `depth` submissions: its tensors are overwritten."""
+        """Enqueue forward + NMS of one batch (same shape / dtype as the example) and return at once.  The slot's tensors are
+        overwritten: a ticket of this slot that has not been consumed yet expires (its `result()` raises)."""
+        if x.shape != self.inputs[0].shape or x.dtype != self.inputs[0].dtype:
+            raise RuntimeError(f"yolov6_amd.pipeline: batch {tuple(x.shape)} {x.dtype} does not match the example "
+                               f"{tuple(self.inputs[0].shape)} {self.inputs[0].dtype} the plans were built for")
         j = self.i % len(self.plans)
         self.i += 1
+        self.generation[j] += 1
         st = self.streams[j]
         st.wait_stream(torch.cuda.current_stream())          # x was produced on the caller's stream
         with torch.cuda.stream(st):
             if x.data_ptr() != self.inputs[j].data_ptr():
+                x.record_stream(st)                          # the caching allocator must not recycle x while the copy is pending
                 self.inputs[j].copy_(x, non_blocking=True)
             det = self.plans[j].run()
             dets, index, count = nms_raw(det, candidates=self.tokens[j], **self.kw)
             ev = torch.cuda.Event()
             ev.record(st)
         self.done[j] = ev
-        return Ticket(det, dets, index, count, ev)
+        return Ticket(det, dets, index, count, ev, self, j, self.generation[j])
 
 
 def pick_streams(n, trial):
