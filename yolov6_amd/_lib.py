@@ -374,13 +374,6 @@ def load():
     return lib
 
 
-def candidate_enabled(token: str) -> bool:
-    """Y6_ENABLE_CANDIDATES: "1" / "all" enables every kernel or lowering that has not been on a device yet, a comma list the
-    named ones (csrc/common.hpp y6_candidate_enabled reads the same variable)."""
-    e = os.environ.get("Y6_ENABLE_CANDIDATES", "")
-    return e in ("1", "all") or token in [t.strip() for t in e.split(",") if t.strip()]
-
-
 def check(rc, what=""):
     if rc != 0:
         msg = load().y6_last_error().decode("utf-8", "replace")

@@ -12,22 +12,6 @@
 
 void y6_set_error(const char* fmt, ...);
 
-// Kernels / lowerings written after a round's last GPU visit stay unreachable until a device has run them:
-// Y6_ENABLE_CANDIDATES=1 (or "all") enables every one, a comma list ("kres,sppf,levels") the named ones.
-inline bool y6_candidate_enabled(const char* token) {
-    const char* e = getenv("Y6_ENABLE_CANDIDATES");
-    if (!e || !*e) return false;
-    if (strcmp(e, "1") == 0 || strcmp(e, "all") == 0) return true;
-    const size_t n = strlen(token);
-    for (const char* c = e; *c;) {
-        const char* end = strchr(c, ',');
-        const size_t len = end ? (size_t)(end - c) : strlen(c);
-        if (len == n && strncmp(c, token, n) == 0) return true;
-        c = end ? end + 1 : c + len;
-    }
-    return false;
-}
-
 #define Y6_HIP(expr)                                                                         \
     do {                                                                                     \
         hipError_t _e = (expr);                                                              \

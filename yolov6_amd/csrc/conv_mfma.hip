@@ -941,12 +941,11 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
         const double eff = ((double)Ho * Wo) / (tiles * bp);
         const double halo = (double)(TH * st) * (TW * st) / ((double)HH * HW);
         // a 32-lane MFMA fragment that stays on one tile row reads 32 consecutive halo pixels: with the
-        // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is 2-way.  Preferring
-        // such tiles (Y6_CONV_TW32=1) cuts the conflict cycles from 0.41 to 0.15 per access and does not move
-        // the time (tools/gpu_pmc2.sh), so it is off by default.
-        static const int tw32 = getenv("Y6_CONV_TW32") ? atoi(getenv("Y6_CONV_TW32")) : 0;
+        // 80-byte pixel pitch that is bank-conflict free; a fragment split over two rows is 2-way.  (Preferring
+        // such tiles cut the conflict cycles from 0.41 to 0.15 per access and did not move the time - round 1,
+        // profiles/r01 - so the per-tap kernels take the tile with the best fill.)
         // tw_mult (LDS-DMA kernels): widths that keep the 16-lane read groups on one halo row are conflict-free
-        const double rowfit = tw_mult ? (TW % tw_mult == 0 ? 1.0 : 0.95) : ((tw32 == 0 || TW % 32 == 0) ? 1.0 : 0.90);
+        const double rowfit = tw_mult ? (TW % tw_mult == 0 ? 1.0 : 0.95) : 1.0;
         const double score = eff * (0.85 + 0.15 * halo) * rowfit;
         if (score > best + 1e-9) {
             best = score;
@@ -961,14 +960,13 @@ void choose_tile(int Ho, int Wo, int ks, int st, int bp, int cap, int* pTH, int*
 
 // conv_wreg.hip: halo row pitch for a tile width (a read group that wraps to the next tile row must continue at a pixel index
 // that is consecutive modulo 16), 1 KiB requests per stage image, and the tile itself
-// (Y6_WREG_PITCH=conflictfree: TW + 16 for widths that are not multiples of 16 - a read group that wraps to the next tile row then
-// continues at a pixel index consecutive modulo 16 and never conflicts.  Default: the dense pitch TW + 2 - a wrapping group has two
-// 2-way conflicts, one extra LDS cycle on some reads, but the stage image is 25-40 % smaller and the halo REQUESTS are what the
-// stage top costs: 470 cycles each with ten per wave in flight, profiles/r04/v0_trace_wreg_*.txt)
+// (The dense pitch TW + 2: a read group that wraps to the next tile row has two 2-way conflicts, one extra LDS cycle on some reads.
+// The conflict-free alternative - TW + 16 for widths that are not multiples of 16 - was measured in round 4 and lost: the stage
+// image is 25-40 % larger and the halo REQUESTS are what the stage top costs, 470 cycles each with ten per wave in flight,
+// profiles/r04/v0_trace_wreg_*.txt.)
 int wreg_row_pitch(int TW, int st) {
     if (st == 2) return 2 * TW + 2;   // TW + 1 even columns, TW odd ones, one pad slot
-    static const bool conflict_free = getenv("Y6_WREG_PITCH") && strcmp(getenv("Y6_WREG_PITCH"), "conflictfree") == 0;
-    return (TW % 16 == 0 || !conflict_free) ? TW + 2 : TW + 16;
+    return TW + 2;
 }
 int wreg_pieces(int TH, int TW, int st) { return y6_cdiv(5 * ((TH - 1) * st + 3) * wreg_row_pitch(TW, st), 64); }
 // TH x TW <= bp pixel slots: fewest rounds of the persistent walk (items / resident blocks, rounded up) first - a block's time is
