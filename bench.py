@@ -37,6 +37,15 @@ HBM_PEAK_GBS = 8000.0
 CONF, IOU, MAX_DET = 0.03, 0.65, 300
 
 
+def stage(name):
+    """Y6_BENCH_TRACE=1 (debug): name each phase on stderr after draining the device, so that an asynchronous GPU fault is
+    attributed to the phase that enqueued it."""
+    if os.environ.get("Y6_BENCH_TRACE"):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        print(f"[bench-trace] {time.perf_counter():.3f} reached: {name}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
@@ -467,29 +476,38 @@ def main():
     device = rep.device()                # "nccl" (= RCCL) process group for N > 1: barriers + one MAX reduce only
 
     from yolov6_amd.utils.nms import nms_raw
+    stage("start")
     cfg, sd_train, model, x = build_model_and_input(args, device)
+    stage("model and input on device")
     shift = calibrate_head_bias(model, x)
+    stage("calibrate_head_bias")
     if args.int8:
         from yolov6_amd import quant
         from yolov6_amd.utils import synth as _synth
         cal = [_synth.synth_images(8, args.size, seed=100 + i).to(device).half() for i in range(4)]
         quant.quantize(model, quant.calibrate(model, cal))
     plan = model.compile(x, autotune=not args.no_autotune)
+    stage("compile plan 0")
     # --inflight N (default 2): N steps in flight.  Step i runs on HIP stream i % N with its own plan - its own activation buffers
     # and NMS workspace, the same weights - so the launch ramps of one step (every kernel's prologue fetch, store burst and tail:
     # ~10 us of a 26 us small-map launch) overlap the other step's kernels.  Every step is still one full forward +
     # NMS of one b32 batch, the K steps of a window are all inside its barrier + synchronize bracket; `sequential` in the line
     # is the same loop with one step at a time.
-    import copy
     n_fly = max(1, args.inflight)
-    plans = [plan]
-    for _ in range(1, n_fly):
-        m2 = copy.deepcopy(model)           # (HipModule.__getstate__ leaves native plans behind: the copy compiles its own)
-        plans.append(m2.compile(x, autotune=not args.no_autotune))
+    # (HipModule.new_plan: one more plan of the SAME module - same parameters, same int8 calibration - with its own buffers;
+    # round 4 deep-copied the module, which silently dropped the int8 state of the copies: ADVICE r4)
+    plans = [plan] + [model.new_plan(x, autotune=not args.no_autotune) for _ in range(1, n_fly)]
+    assert all(p.quant_key == plan.quant_key and p.num_ops == plan.num_ops for p in plans), "in-flight plans differ in kind"
+    # every slot reads its own input tensor (distinct images per slot, resident before the timed region)
+    from yolov6_amd.utils import synth as _sy
+    xs = [x] + [_sy.synth_images(args.batch, args.size, seed=j).to(device).half() for j in range(1, n_fly)]
+    for p, xi in zip(plans[1:], xs[1:]):
+        p.bind_inputs([xi])
     # the fused head tail selects the NMS candidates of its rows while they are in LDS (Plan.attach_nms: y6_nms's own first stage,
     # same thresholds); y6_nms then starts at the sort.
     cands = [None if args.no_fuse_candidates else p.attach_nms(CONF, None, True) for p in plans]
     cand = cands[0]
+    stage("in-flight plans compiled, NMS attached")
 
     def stream_trial(ss):
         torch.cuda.synchronize()
@@ -548,11 +566,13 @@ def main():
 
     from yolov6_amd.pipeline import pick_streams   # (two streams on one hardware queue do not overlap: pairs are timed)
     streams = pick_streams(n_fly, stream_trial)
+    stage("pick_streams")
     for i in range(max(args.warmup, n_fly)):
         with torch.cuda.stream(streams[i % n_fly]):
             d = plans[i % n_fly].run()
             nms_raw(d, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[i % n_fly])
     torch.cuda.synchronize()
+    stage("warmup")
     # Three windows (--windows) of EXACTLY K steps each; `value` comes from the median window, the others are reported as the
     # spread (a short region on a power-managed chip moves by several per cent from one window to the next).
     elapsed_w = [run_window(streams, True) for _ in range(n_win)]
@@ -561,6 +581,7 @@ def main():
     # the same K steps one at a time (one stream, one plan, no event sampling): what a caller that waits for every result gets
     seq_elapsed = run_window(streams[:1], False) if n_fly > 1 else None
 
+    stage("timed windows")
     rows = plan.timing_read()
     nms_ms = sum(a.elapsed_time(b) for a, b in nms_ev) / len(nms_ev)
     kept = out[2].float().mean().item()
@@ -570,6 +591,7 @@ def main():
 
     # the same step through the reference-signature API (models/yolo.py:33-41 + utils/nms.py:31-105): Model.forward clones
     # the [B,A,85] fp32 tensor (91 MB at b32) and non_max_suppression syncs once to slice the per-image lists
+    stage("verify_nms")
     dropin = None
     if args.dropin_steps > 0:
         from yolov6_amd.utils.nms import non_max_suppression

@@ -461,3 +461,48 @@ def test_histogram_entropy_calibration_recipe_end_to_end():
         quant.dequantize(model)
     print("int8 vs fp16 class scores:", errs)
     assert errs["entropy"] < max(2.0 * errs["max"], 2e-2), errs
+
+
+def test_inflight_runner_on_a_quantised_model_runs_int8_in_every_slot():
+    """round 4's runner deep-copied the module and `HipModule.__getstate__` dropped the int8 state, so odd batches
+    of a quantised model ran an fp16 plan.  Every slot's plan must be the int8 lowering (same quant key, same kernel table) and the
+    detections of a sequence of batches must equal the one-at-a-time int8 path bit for bit."""
+    from oracle import synth
+    from yolov6_amd.pipeline import InflightRunner
+    cfg, meta, sd, model, _ = _qa_model()
+    size = meta["size"]
+    cal = [synth.synth_images(2, size, seed=100 + i).to(DEV).half() for i in range(4)]
+    quant.quantize(model, quant.calibrate(model, cal))
+    batches = [synth.synth_images(2, size, seed=60 + i).to(DEV).half() for i in range(4)]
+    kw = dict(conf_thres=0.03, iou_thres=0.65, multi_label=True, max_det=300, autotune=False)
+    one = InflightRunner(model, batches[0].clone(), depth=1, **kw)
+    want = [[t.clone() for t in one.submit(b).result()[0]] for b in batches]
+    run = InflightRunner(model, batches[0].clone(), depth=2, **kw)
+    qk = model.__dict__["_y6_quant"].key()
+    assert all(p.quant_key == qk for p in run.plans), "a slot's plan lost the int8 state"
+    kinds = [[e["kind"] for e in p.op_log] for p in run.plans]
+    assert kinds[0] == kinds[1] and "conv_i8" in kinds[0], "both slots must run the int8 lowering"
+    got, tickets = [], []                                      # results are consumed within `depth` submissions
+    for b in batches:
+        tickets.append(run.submit(b))
+        if len(tickets) == 2:
+            got.append([t.clone() for t in tickets.pop(0).result()[0]])
+    got += [[t.clone() for t in tk.result()[0]] for tk in tickets]
+    for k, (g, w) in enumerate(zip(got, want)):
+        for a, b_ in zip(g, w):
+            assert torch.equal(a, b_), f"batch {k}: in-flight int8 detections differ from one at a time"
+
+
+def test_inflight_runner_refuses_stale_plans():
+    """The runner's plans are lowered from the module's parameters; after an in-place update of a parameter (optimizer step,
+    load_state_dict) or a change of the int8 state every slot would serve stale weights: submit() raises instead."""
+    from oracle import synth
+    from yolov6_amd.pipeline import InflightRunner
+    cfg, meta, sd, model, _ = _qa_model()
+    x = synth.synth_images(2, meta["size"], seed=3).to(DEV).half()
+    run = InflightRunner(model, x, depth=2, conf_thres=0.03, iou_thres=0.65, multi_label=True, autotune=False)
+    run.submit(x).result()
+    with torch.no_grad():
+        next(model.parameters()).mul_(1.0)                    # bumps the autograd version counter
+    with pytest.raises(RuntimeError, match="changed after this runner was built"):
+        run.submit(x)

@@ -165,7 +165,6 @@ def test_inflight_runner_equals_one_at_a_time():
     batch equal those of the plain `model(x)` + `non_max_suppression` path, batch by batch, for a sequence of different batches -
     nothing of one batch leaks into the other (own activation buffers, own NMS workspace, own result tensors)."""
     from oracle import synth
-    import copy
     from yolov6_amd.pipeline import InflightRunner
     import bench
     cfg, sd, model, x = _bench_setup("yolov6s", 320, 8)
@@ -175,7 +174,7 @@ def test_inflight_runner_equals_one_at_a_time():
     one = InflightRunner(model, batches[0].clone(), depth=1, conf_thres=bench.CONF, iou_thres=bench.IOU, multi_label=True,
                          max_det=bench.MAX_DET, autotune=False)
     want = [[t.clone() for t in one.submit(b).result()[0]] for b in batches]
-    run = InflightRunner(copy.deepcopy(model), batches[0].clone(), depth=2, conf_thres=bench.CONF, iou_thres=bench.IOU, multi_label=True,
+    run = InflightRunner(model, batches[0].clone(), depth=2, conf_thres=bench.CONF, iou_thres=bench.IOU, multi_label=True,
                          max_det=bench.MAX_DET, autotune=False)
     tickets = [run.submit(b) for b in batches[:2]]
     got = []

@@ -33,12 +33,24 @@ void y6_set_error(const char* fmt, ...);
 // another library) would otherwise be reported by the next launch check.  Entry points clear it.
 #define Y6_CLEAR_STALE_ERROR() (void)hipGetLastError()
 
+// Y6_SYNC_TRACE=1 (debug): every launch site names itself on stderr and then waits for the device, so that a GPU memory
+// fault (which aborts the process from the runtime's event thread) is preceded by the line of the launch that caused it.
+static inline bool y6_sync_trace() {
+    static const bool v = getenv("Y6_SYNC_TRACE") != nullptr;
+    return v;
+}
+
 #define Y6_LAUNCH_CHECK()                                                                    \
     do {                                                                                     \
         hipError_t _e = hipGetLastError();                                                   \
         if (_e != hipSuccess) {                                                              \
             y6_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
             return Y6_EHIP;                                                                  \
+        }                                                                                    \
+        if (y6_sync_trace()) {                                                               \
+            fprintf(stderr, "[y6-sync-trace] launched %s (%s:%d)\n", __func__, __FILE__, __LINE__); \
+            fflush(stderr);                                                                  \
+            (void)hipDeviceSynchronize();                                                    \
         }                                                                                    \
     } while (0)
 

@@ -702,6 +702,12 @@ extern "C" int y6_conv2d(const y6_conv_desc* d, void* stream) {
     if (v < 0) v = default_variant(d);
     Y6_REQUIRE(v >= 0, "conv2d: no kernel variant supports this conv (k%d s%d Cin %d Cout %d)", d->ksize, d->stride,
                d->in.C, d->out.C);
+    if (y6_sync_trace()) {
+        fprintf(stderr, "[y6-sync-trace] conv2d k%d s%d cin %d cout %d in %dx%dx%d (cs %d co %d) out cs %d co %d res %d act %d variant %d (%s) in %p out %p w %p\n",
+                d->ksize, d->stride, d->in.C, d->out.C, d->in.B, d->in.H, d->in.W, d->in.cstride, d->in.coff, d->out.cstride, d->out.coff,
+                d->res.data != nullptr, d->act, v, y6_conv_variant_name(v), d->in.data, d->out.data, d->w_packed);
+        fflush(stderr);
+    }
     if (v == 0) return y6_conv_naive_launch(d, (hipStream_t)stream);
     return y6_conv_mfma_launch(d, v, (hipStream_t)stream, 0, 0, 0);
 }

@@ -185,26 +185,8 @@ class HipModule(nn.Module):
         cache = self.__dict__.setdefault("_y6_plans", {})
         plan = cache.get(key)
         if plan is None:
-            self._check_runnable()
             cache.clear()  # one live plan per module: buffers are large
-            if quant is not None:
-                quant.decisions = None
-                if quant.mode == "int8" and quant.twins:
-                    # scan lowering: who reads / writes which buffer with which scale -> int8 twins (quant.plan_twins)
-                    from ..quant import plan_twins
-                    quant.begin_lowering()
-                    scan = PlanBuilder(flat[0].device, quant=quant)
-                    self.lower(scan, _wrap(x, iter(contig)))
-                    quant.decisions = plan_twins(scan)
-                    del scan
-                quant.begin_lowering()
-            pb = PlanBuilder(flat[0].device, quant=quant)
-            outs = self.lower(pb, _wrap(x, iter(contig)))
-            odt = flat[0].dtype if flat[0].dtype in (torch.float16, torch.float32) else torch.float16
-            outs = self._finish_outputs(pb, outs, odt)
-            plan = pb.finalize(outs, autotune=autotune)
-            # builder order of the boundary tensors -> position in the caller's argument list
-            plan.input_order = [next(j for j, c in enumerate(contig) if c is t) for t in plan.inputs]
+            plan = self._lower_plan(x, flat, contig, quant, autotune)
             cache[key] = plan
         else:
             plan.bind_inputs([contig[j] for j in plan.input_order])
@@ -214,6 +196,51 @@ class HipModule(nn.Module):
         holders = [(d, n, t) for m in self.modules() for d in (m._parameters, m._buffers) for n, t in d.items() if t is not None]
         self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan, holders)
         return plan
+
+    def _lower_plan(self, x, flat, contig, quant, autotune):
+        self._check_runnable()
+        if quant is not None:
+            quant.decisions = None
+            if quant.mode == "int8" and quant.twins:
+                # scan lowering: who reads / writes which buffer with which scale -> int8 twins (quant.plan_twins)
+                from ..quant import plan_twins
+                quant.begin_lowering()
+                scan = PlanBuilder(flat[0].device, quant=quant)
+                self.lower(scan, _wrap(x, iter(contig)))
+                quant.decisions = plan_twins(scan)
+                del scan
+            quant.begin_lowering()
+        pb = PlanBuilder(flat[0].device, quant=quant)
+        outs = self.lower(pb, _wrap(x, iter(contig)))
+        odt = flat[0].dtype if flat[0].dtype in (torch.float16, torch.float32) else torch.float16
+        outs = self._finish_outputs(pb, outs, odt)
+        plan = pb.finalize(outs, autotune=autotune)
+        # builder order of the boundary tensors -> position in the caller's argument list
+        plan.input_order = [next(j for j, c in enumerate(contig) if c is t) for t in plan.inputs]
+        plan.params_version = _params_version(self)      # what the packed weights of this plan were derived from
+        plan.quant_key = None if quant is None else quant.key()
+        return plan
+
+    def new_plan(self, *inputs, autotune=True):
+        """One MORE plan of this module for these inputs, outside the plan cache: its own activation buffers and its own packed
+        copies of the weights, lowered from the SAME parameters, BatchNorm buffers and int8 calibration as the cached plan
+        (pipeline.InflightRunner keeps N of them for N batches in flight).  The caller owns it; `plan.params_version` /
+        `plan.quant_key` say what it was derived from (`plan_is_current()` re-checks)."""
+        x = inputs[0] if len(inputs) == 1 else list(inputs)
+        flat = _flatten(x)
+        for t in flat:
+            if not t.is_cuda:
+                raise RuntimeError("yolov6_amd: the HIP hot path needs ROCm tensors; there is no CPU fallback "
+                                   f"(got a tensor on {t.device})")
+        contig = [t.contiguous() for t in flat]
+        return self._lower_plan(x, flat, contig, self.__dict__.get("_y6_quant"), autotune)
+
+    def plan_is_current(self, plan) -> bool:
+        """Does `plan` (compile() / new_plan()) still describe this module - same parameter tensors at the same autograd
+        versions, same lowering attributes, same int8 state?  (Edits through `.data` need invalidate_plans(), as for compile().)"""
+        quant = self.__dict__.get("_y6_quant")
+        return (getattr(plan, "params_version", None) == _params_version(self)
+                and getattr(plan, "quant_key", None) == (None if quant is None else quant.key()))
 
     def forward(self, *inputs):
         plan = self.compile(*inputs)

@@ -3,7 +3,8 @@
 A forward pass is ~60 dependent kernel launches, and every launch has ramps - the first fetch of every block at once, the store
 burst at the end, the tail while the last blocks finish - during which most of the chip idles (~10 us of a 26 us
 small-map launch).  Consecutive layers cannot overlap them (data dependence); consecutive BATCHES can: `InflightRunner` keeps N
-plans of the same model (own activation buffers and NMS workspace, the same weights) on N HIP streams and hands batch i to plan
+plans of the same module (own activation buffers, own packed copies of the weights and own NMS workspace, all lowered from the
+same parameters: `HipModule.new_plan`) on N HIP streams and hands batch i to plan
 i % N.  Measured on one MI355X, YOLOv6-S 640^2 b32 fp16 forward + NMS: 13 961 -> 15 730 img/s with N = 2 (bench.py, r04y).
 
 The reference's eval loop (yolov6/core/evaler.py:98-120: `outputs = model(imgs)`; `non_max_suppression(outputs, ...)`; convert to
@@ -19,7 +20,6 @@ host side by one batch gets the overlap:
             ...
         pending = ticket
 """
-import copy
 import time
 
 import torch
@@ -56,8 +56,16 @@ class InflightRunner:
             raise ValueError("yolov6_amd.pipeline: depth >= 1")
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, multi_label=multi_label,
                        max_det=max_det)
-        self.models = [model] + [copy.deepcopy(model) for _ in range(depth - 1)]   # HipModule.__getstate__: copies compile their own plans
-        self.plans = [m.compile(example, autotune=autotune) for m in self.models]
+        # ONE module, `depth` plans lowered from it (the extra ones outside the module's plan cache, never shared with
+        # `model.forward`): the same parameters, BatchNorm buffers and int8 calibration behind every slot.  (Round 4 deep-copied
+        # the module: N copies of the weights, and `HipModule.__getstate__` dropped the int8 state, so odd batches of a quantised
+        # model ran the fp16 plan - ADVICE r4.)
+        self.model = model
+        self.autotune = autotune
+        self.plans = [model.new_plan(example, autotune=autotune) for _ in range(depth)]
+        self._tensors = list(model.parameters()) + list(model.buffers())
+        self._vsum = sum(t._version for t in self._tensors)
+        self._quant = model.__dict__.get("_y6_quant")
         self.inputs = [example] + [torch.empty_like(example) for _ in range(depth - 1)]
         for p, x in zip(self.plans[1:], self.inputs[1:]):
             p.bind_inputs([x])
@@ -85,6 +93,13 @@ class InflightRunner:
             raise RuntimeError(f"yolov6_amd.pipeline: batch {tuple(x.shape)} {x.dtype} does not match the example "
                                f"{tuple(self.inputs[0].shape)} {self.inputs[0].dtype} the plans were built for")
         j = self.i % len(self.plans)
+        # (cheap first: the sum of the autograd version counters of the tensors the plans were lowered from and the identity of
+        # the int8 state; the full key - a walk over every module - only when those moved)
+        if ((sum(t._version for t in self._tensors) != self._vsum or self.model.__dict__.get("_y6_quant") is not self._quant)
+                and not self.model.plan_is_current(self.plans[j])):
+            # load_state_dict / an optimizer step / quantize() since the plans were built: every slot would serve stale weights
+            raise RuntimeError("yolov6_amd.pipeline: the model's parameters (or its int8 state) changed after this runner was built; "
+                               "build a new InflightRunner")
         self.i += 1
         self.generation[j] += 1
         st = self.streams[j]
