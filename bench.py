@@ -29,6 +29,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def supervise():
+    """The measurement runs in a CHILD process (this file again, Y6_BENCH_CHILD=1); this parent - which never touches the GPU or
+    imports torch - passes the child's single JSON line on, with a `supervisor` object added.  If the child is killed by a signal
+    (round 4's driver run died of `Memory access fault by GPU node-2`, SIGABRT from the HIP runtime, 4 s into the process; 45
+    fresh-process runs and the guard-page allocator sweeps of round 5 could not reproduce it - DESIGN 6d) the measurement is run
+    ONCE more and the line says so: `attempts`, and the exit status and stderr tail of the failed attempt.  A child that exits
+    with an ordinary error (assertion, Python exception) is not retried.  `--no-supervisor` runs the measurement in this process."""
+    import subprocess
+    env = dict(os.environ, Y6_BENCH_CHILD="1")
+    failures = []
+    for attempt in (1, 2):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
+        lines = r.stdout.splitlines()
+        js = [i for i, ln in enumerate(lines) if ln.startswith("{")]
+        if r.returncode == 0 and js:
+            d = json.loads(lines[js[-1]])
+            d["supervisor"] = {"attempts": attempt, "failed_attempts": failures,
+                               "what": "the measurement ran in a child process; a child killed by a signal is re-run once"}
+            for i, ln in enumerate(lines):
+                if i != js[-1]:
+                    print(ln)
+            print(json.dumps(d), flush=True)
+            return 0
+        sys.stdout.write(r.stdout)
+        sys.stdout.flush()
+        if r.returncode >= 0 or attempt == 2:       # an ordinary failure, or the second abnormal death: no (further) retry
+            return r.returncode if r.returncode > 0 else (128 - r.returncode if r.returncode < 0 else 1)
+        failures.append({"attempt": attempt, "signal": -r.returncode})
+        print(f"bench.py: attempt {attempt} was killed by signal {-r.returncode}; running the measurement once more", file=sys.stderr, flush=True)
+    return 1
+
+
+if (__name__ == "__main__" and os.environ.get("Y6_BENCH_CHILD") != "1" and "WORLD_SIZE" not in os.environ
+        and "--no-supervisor" not in sys.argv):
+    sys.exit(supervise())
+
 import torch  # noqa: E402
 
 INT8_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the bf16/fp16 rate (MI355X_MICROARCH.md dtype table: ubench >= 3944 TOPS)
@@ -58,6 +96,7 @@ def parse():
     ap.add_argument("--model", default="yolov6s")
     ap.add_argument("--int8", action="store_true", help="BASELINE configs[4]: int8 plan (use with --model yolov6s_qa): max-"
                     "calibration on 4 synthetic batches, backbone + neck convs on the int8 MFMA kernels, head fp16")
+    ap.add_argument("--no-supervisor", action="store_true", help="measure in this process (default: in a child that is re-run once if a signal kills it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU-baseline sample (1 warm-up + 3 timed passes of forward + NMS + TAL)")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
@@ -79,6 +118,20 @@ def parse():
     if a.mode == "train" and "--steps" not in " ".join(sys.argv):
         a.steps, a.warmup = 30, 5          # ~50 ms steps: 30 timed steps are a 1.5 s region
     return a
+
+
+def timed_window(rep, steps, enqueue, drain):
+    """The bench contract's timed region: EXACTLY `steps` steps (enqueue(i), asynchronous) bracketed by a barrier + drain() on both
+    sides, MAX over the ranks.  Nothing rank-dependent (stream selection, autotuning, calibration) may sit between a rank's
+    last collective and the first barrier here except work that ends by itself: a slow rank only makes the others wait."""
+    rep.barrier()
+    drain()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        enqueue(i)
+    drain()
+    rep.barrier()
+    return rep.max_over_ranks(time.perf_counter() - t0)
 
 
 def spawn_ranks(args):
@@ -229,6 +282,13 @@ def cpu_baseline(args, cfg, sd_train, shift):
                 sample=f"{n} images {args.size}x{args.size}: fp32 torch-CPU oracle forward + numpy NMS (value = images / median "
                        f"(forward + NMS)), numpy task-aligned assigner on {n} images; 1 warm-up + 3 timed passes",
                 torch=torch.__version__)
+
+
+def peak_memory_gb():
+    try:
+        return round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
+    except RuntimeError:          # a pluggable allocator (tests/tight_probe.py) keeps no statistics
+        return None
 
 
 def synth_targets(batch, seed=0):
@@ -387,7 +447,7 @@ def train_main(args):
                      "bits": [float(v).hex() for v in losses] + [float(last).hex()]},
             "variants": {"chosen_by": "timing (this process)" if (args.train_autotune and not args.no_autotune) else "layer shape",
                          "fwd_hash": graph.fwd_plan.variant_hash(), "bwd_hash": graph.bwd_plan.variant_hash()},
-            "memory_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            "memory_gb": peak_memory_gb(),
         }
         if args.profile_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
@@ -461,6 +521,13 @@ def train_sub_bench():
 
 def main():
     args = parse()
+    hook = os.environ.get("Y6_BENCH_TEST_ABORT")       # tests/test_host_cpu.py: the supervisor's retry path ("once:<flag file>" | "always")
+    if hook and "WORLD_SIZE" not in os.environ:
+        flag = hook.partition(":")[2]
+        if hook == "always" or not os.path.exists(flag):
+            if flag:
+                open(flag, "w").close()
+            os.abort()
     if os.environ.get("Y6_BENCH_MOCK") == "1":
         if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
             sys.exit(spawn_ranks(args))
@@ -532,13 +599,12 @@ def main():
     state = {"k": 0, "det": None, "out": None}
 
     def run_window(streams, sample):
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over the ranks."""
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over the ranks (timed_window)."""
         n = len(streams)
         done = [None] * n
-        rep.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
+        last = {}
+
+        def enqueue(i):
             j = i % n
             st = streams[j]
             timed = sample and i % ev_every == 0
@@ -559,10 +625,11 @@ def main():
                     out = nms_raw(det, CONF, IOU, multi_label=True, max_det=MAX_DET, candidates=cands[j])
                 done[j] = torch.cuda.Event()
                 done[j].record(st)
-        torch.cuda.synchronize()          # drains every stream
-        rep.barrier()
-        state["det"], state["out"] = det, out
-        return rep.max_over_ranks(time.perf_counter() - t0)
+            last["det"], last["out"] = det, out
+
+        elapsed = timed_window(rep, args.steps, enqueue, torch.cuda.synchronize)      # (synchronize drains every stream)
+        state["det"], state["out"] = last["det"], last["out"]
+        return elapsed
 
     from yolov6_amd.pipeline import pick_streams   # (two streams on one hardware queue do not overlap: pairs are timed)
     streams = pick_streams(n_fly, stream_trial)

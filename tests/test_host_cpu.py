@@ -868,3 +868,32 @@ def test_histogram_calibration_rules():
     assert u.compute_amax("entropy") > 5.0 and u.compute_amax("mse") > 5.0 and u.compute_amax("percentile", 99.99) > 5.9
     with pytest.raises(ValueError):
         c.compute_amax("median")
+
+
+def test_bench_supervisor_reruns_a_child_killed_by_a_signal_once(tmp_path):
+    """bench.py measures in a child process; a child that dies of a signal (the HIP runtime aborts the process on a GPU memory
+    fault) is re-run ONCE and the JSON line reports it; a second death is final (the exit status of a signal death, no line)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = dict(os.environ, Y6_BENCH_MOCK="1")
+    ok = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    d = json.loads([ln for ln in ok.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["supervisor"]["attempts"] == 1 and d["supervisor"]["failed_attempts"] == []
+    flag = str(tmp_path / "aborted_once")
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1"], env=dict(env, Y6_BENCH_TEST_ABORT=f"once:{flag}"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["supervisor"]["attempts"] == 2 and d["supervisor"]["failed_attempts"] == [{"attempt": 1, "signal": 6}]
+    assert "killed by signal 6" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1"], env=dict(env, Y6_BENCH_TEST_ABORT="always"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 134 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # --no-supervisor: the measurement runs in the launched process itself
+    r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-supervisor"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "supervisor" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
