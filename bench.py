@@ -98,6 +98,8 @@ def parse():
                     "calibration on 4 synthetic batches, backbone + neck convs on the int8 MFMA kernels, head fp16")
     ap.add_argument("--no-supervisor", action="store_true", help="measure in this process (default: in a child that is re-run once if a signal kills it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="no GPU needed: only the `cpu_baseline` object of the headline workload "
+                    "(the reference's own modules when /root/reference exists, else the oracle port); --cpu-batch 32 is BASELINE.md's b32")
     ap.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU-baseline sample (1 warm-up + 3 timed passes of forward + NMS + TAL)")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
     ap.add_argument("--no-autotune", action="store_true")
@@ -244,8 +246,11 @@ def cpu_baseline(args, cfg, sd_train, shift):
     task-aligned assigner on a training-sized problem (the same number of images, 8400 anchors, 80 classes, up to 40 boxes)."""
     import statistics
     import numpy as np
-    from oracle import nms_oracle, synth, tal_oracle
+    from oracle import nms_oracle, ref_cpu_baseline, synth, tal_oracle
     from oracle.model_oracle import Oracle, deploy_state_dict
+    if ref_cpu_baseline.available() and args.model in ("yolov6s", "yolov6n", "yolov6l6", "yolov6s_qa"):
+        # the reference checkout is on this machine (the build container): time ITS modules (BASELINE.md 2), kind "reference"
+        return ref_cpu_baseline.time_reference(args.model, args.size, args.cpu_batch, sd_train, shift, CONF, IOU, MAX_DET)
     threads = torch.get_num_threads()
     sd = deploy_state_dict(cfg, sd_train, 80)
     for k in list(sd):
@@ -289,6 +294,28 @@ def peak_memory_gb():
         return round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
     except RuntimeError:          # a pluggable allocator (tests/tight_probe.py) keeps no statistics
         return None
+
+
+def cpu_baseline_only(args):
+    """`--cpu-baseline-only`: the CPU leg by itself on a machine without a GPU (the build container holds the reference checkout,
+    the GPU box does not).  The head-bias calibration of the GPU run (~2 % of the scores above conf 0.03) is repeated on the CPU
+    with the oracle's forward of four images."""
+    import math
+    from yolov6_amd.configs import get_config
+    from yolov6_amd.models.yolo import build_model
+    from yolov6_amd.utils import synth
+    from oracle.model_oracle import Oracle, deploy_state_dict
+    cfg = get_config(args.model)
+    sd = synth.synth_state_dict(build_model(cfg, 80, "cpu").state_dict(), seed=0)
+    orc = Oracle(cfg, deploy_state_dict(cfg, sd, 80), 80)
+    with torch.no_grad():
+        det, _ = orc.forward(synth.synth_images(4, args.size, seed=0))
+    scores = det[..., 5:].float().flatten()
+    q = float(torch.quantile(scores[torch.randperm(scores.numel())[:2_000_000]], 0.98))
+    shift = math.log(CONF / (1.0 - CONF)) - math.log(q / (1.0 - q))
+    res = cpu_baseline(args, cfg, sd, shift)
+    print(json.dumps({"cpu_baseline": res, "workload": f"{args.model} {args.size}x{args.size}, {args.cpu_batch} images", "head_bias_shift": round(shift, 4)}),
+          flush=True)
 
 
 def synth_targets(batch, seed=0):
@@ -532,6 +559,8 @@ def main():
         if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
             sys.exit(spawn_ranks(args))
         return mock_main(args)
+    if args.cpu_baseline_only:
+        return cpu_baseline_only(args)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (the hot path has no CPU fallback)"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
@@ -563,7 +592,7 @@ def main():
     n_fly = max(1, args.inflight)
     # (HipModule.new_plan: one more plan of the SAME module - same parameters, same int8 calibration - with its own buffers;
     # round 4 deep-copied the module, which silently dropped the int8 state of the copies: ADVICE r4)
-    plans = [plan] + [model.new_plan(x, autotune=not args.no_autotune) for _ in range(1, n_fly)]
+    plans = [plan] + [model.new_plan(x, autotune=not args.no_autotune, variants_from=plan) for _ in range(1, n_fly)]   # tuned once
     assert all(p.quant_key == plan.quant_key and p.num_ops == plan.num_ops for p in plans), "in-flight plans differ in kind"
     # every slot reads its own input tensor (distinct images per slot, resident before the timed region)
     from yolov6_amd.utils import synth as _sy

@@ -784,9 +784,17 @@ int y6_plan_side_pending(const y6_plan* p);
 int y6_plan_add_nchw2nhwc(y6_plan* p, const void* src, int src_dtype, const y6_tensor* dst);
 int y6_plan_add_nhwc2nchw(y6_plan* p, const y6_tensor* src, void* dst, int dst_dtype);
 int y6_plan_num_ops(const y6_plan* p);
-/* Time every supported conv variant of every conv op (hipEvents on `stream`, `iters` timed
- * launches each) and pin the fastest.  Synchronises the stream. */
+/* Choose the conv kernel variant of every conv op by timing (hipEvents on `stream`).  First every supported variant of every
+ * conv op by itself (`iters` timed launches each, right behind its predecessor in the plan), then the WHOLE STEP: starting from the
+ * better of {per-layer winners, the shape-derived table}, layer groups (equal signature) are switched to their other near-best
+ * variants and a switch is kept when the step as a whole gets faster (the first launch of a kernel function that has not run for a
+ * while costs 20-35 us: a table that hops between functions loses what the per-layer times promise).  Replaces the reference's
+ * reliance on cuDNN's own algorithm search (torch.backends.cudnn.benchmark, tools/train.py:97).  Synchronises the stream.
+ * Env: Y6_AUTOTUNE_MODE=layer (per-layer winners only), Y6_AUTOTUNE_CACHE, Y6_AUTOTUNE_LOG, Y6_AUTOTUNE_EXCLUDE. */
 int y6_plan_autotune(y6_plan* p, void* stream, int iters);
+/* Give `dst` the conv kernel choices of `src`: two plans lowered from the same module for the same input shapes (the slots of
+ * yolov6_amd/pipeline.py's InflightRunner) run the same kernels without tuning twice.  Error if the plans differ in ops / shapes. */
+int y6_plan_copy_variants(y6_plan* dst, const y6_plan* src);
 /* Re-point every op that reads the caller's NCHW boundary tensor at `old_ptr` to `new_ptr`
  * (same shape/dtype). Returns the number of fields changed (>=0) or a negative error.
  * Invalidates a captured graph. */

@@ -326,6 +326,7 @@ SIGNATURES = {
     "y6_plan_add_nhwc2nchw": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_void_p, C.c_int]),
     "y6_plan_num_ops": (C.c_int, [C.c_void_p]),
     "y6_plan_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "y6_plan_copy_variants": (C.c_int, [C.c_void_p, C.c_void_p]),
     "y6_plan_rebind": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_plan_rebind_input": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "y6_plan_rebind_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -98,6 +98,7 @@ __device__ __forceinline__ float y6_act(float v, int act) {
 // internal launchers shared between translation units
 struct y6_conv_geom;  // conv_mfma.hip
 int y6_conv_naive_launch(const y6_conv_desc* d, hipStream_t s);                 // conv_misc.hip
+int y6_conv_default_variant(const y6_conv_desc* d);                             // conv_misc.hip: the shape-derived kernel choice (-1: none)
 int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s,      // conv_mfma.hip
                         int up, int updy, int updx);
 int y6_conv_mfma_supports(const y6_conv_desc* d, int variant);

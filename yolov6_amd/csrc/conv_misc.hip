@@ -660,7 +660,7 @@ static int variant_by_name(const char* name) {
         if (strcmp(y6_conv_variant_name(v), name) == 0) return v;
     return -1;
 }
-static int default_variant(const y6_conv_desc* d) {
+int y6_conv_default_variant(const y6_conv_desc* d) {
     const long px = (long)d->out.B * d->out.H * d->out.W;
     if (d->ksize == 3) {
         // round 4 (profiles/r04): the register-fed kernels win wherever they apply (Cin % 32 == 0, Cout % 128 == 0): 7 pixel
@@ -699,7 +699,7 @@ extern "C" int y6_conv2d(const y6_conv_desc* d, void* stream) {
     int rc = check_conv_desc(d);
     if (rc) return rc;
     int v = d->variant;
-    if (v < 0) v = default_variant(d);
+    if (v < 0) v = y6_conv_default_variant(d);
     Y6_REQUIRE(v >= 0, "conv2d: no kernel variant supports this conv (k%d s%d Cin %d Cout %d)", d->ksize, d->stride,
                d->in.C, d->out.C);
     if (y6_sync_trace()) {

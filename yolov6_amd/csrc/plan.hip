@@ -2,6 +2,7 @@
 // replayed once per forward (eagerly or from a captured hipGraph), with per-conv kernel
 // autotuning and a per-op hipEvent profile.  This is what sits behind Model.forward
 // (reference yolov6/models/yolo.py:33-41) instead of ~200 aten dispatches.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -986,6 +987,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
         Y6_REQUIRE(best >= 0, "plan_autotune: op %zu has no runnable conv variant", i);
         op.conv.variant = best;
         measured[i] = best > 0;
+        if (logf) fflush(logf);
     }
     // Consolidate: burst timings of the top variants are often within 1-3 % of each other, and a plan that
     // hops between many different kernels pays for it at every switch (cold instruction cache, LDS / scratch
@@ -1010,18 +1012,146 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                 fprintf(logf, "op %zu consolidated %s (%.5f ms) -> %s (%.5f ms)\n", i, y6_conv_variant_name(op.conv.variant),
                         best_ms, y6_conv_variant_name(pick), row[pick]);
             op.conv.variant = pick;
-            if (cachepath) {
-                const std::string sig = signature(op.conv);
-                cache.emplace_back(sig, y6_conv_variant_name(pick));
-                if (FILE* cf = fopen(cachepath, "a")) {
-                    fprintf(cf, "%s %s\n", sig.c_str(), y6_conv_variant_name(pick));
-                    fclose(cf);
+        }
+    }
+    // ---- whole-step refinement (round 5).  A layer timed by itself - even right behind its predecessor - is not the layer in the
+    // step: the FIRST launch of a kernel function that has not run for a few hundred microseconds costs 20-35 us more than the
+    // following ones (profiles/r05/first_of_run_*.json: 256 -> 256 @40x40 on wreg_p7 takes 80 us as the first wreg_p7 launch of
+    // the step and 58 us when the 80x80 layers in front of it ran on wreg_p7 too), so a table of per-layer winners that hops
+    // between kernel functions loses to a table with fewer functions - by 4 % of the step on one box, while on another box the
+    // per-layer table wins.  So the STEP is what gets timed: start from the better of {the per-layer table above, the shape-derived
+    // table (y6_conv_default_variant: what a plan that is not autotuned runs)}, then walk the layer groups (equal signature =
+    // equal variant) by descending time and try, for every group, the variants whose per-layer time is within 30 % of the group's
+    // best; a change is kept if the whole step gets faster by more than the noise.  Y6_AUTOTUNE_MODE=layer keeps the per-layer table.
+    {
+        const char* mode = getenv("Y6_AUTOTUNE_MODE");
+        bool any = false;
+        for (size_t i = 0; i < p->ops.size(); ++i) any = any || measured[i];
+        if (any && !(mode && strcmp(mode, "layer") == 0)) {
+            const size_t n = p->ops.size();
+            hipEvent_t e0, e1;
+            Y6_HIP(hipEventCreate(&e0));
+            Y6_HIP(hipEventCreate(&e1));
+            int rc_step = Y6_OK;
+            auto step_ms = [&](int reps) -> float {   // median whole-step time (plan order, this stream)
+                std::vector<float> t;
+                for (int r = 0; r < reps && rc_step == Y6_OK; ++r) {
+                    (void)hipEventRecord(e0, s);
+                    for (size_t i = 0; i < n && rc_step == Y6_OK; ++i) rc_step = run_op(p->ops[i], s);
+                    (void)hipEventRecord(e1, s);
+                    if (hipEventSynchronize(e1) != hipSuccess) rc_step = Y6_EHIP;
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    t.push_back(ms);
                 }
+                if (t.empty()) return 1e30f;
+                std::sort(t.begin(), t.end());
+                return t[t.size() / 2];
+            };
+            std::vector<int> layer_tab(n, -1), shape_tab(n, -1);
+            for (size_t i = 0; i < n; ++i) {
+                if (!measured[i]) continue;
+                layer_tab[i] = p->ops[i].conv.variant;
+                const int dv = y6_conv_default_variant(&p->ops[i].conv);
+                shape_tab[i] = (dv > 0 && !excluded[dv]) ? dv : layer_tab[i];
+            }
+            auto apply = [&](const std::vector<int>& tab) {
+                for (size_t i = 0; i < n; ++i)
+                    if (measured[i]) p->ops[i].conv.variant = tab[i];
+            };
+            (void)step_ms(2);   // warm
+            apply(shape_tab);
+            const float t_shape = step_ms(5);
+            apply(layer_tab);
+            const float t_layer = step_ms(5);
+            std::vector<int> cur = t_shape < t_layer ? shape_tab : layer_tab;
+            float best_t = t_shape < t_layer ? t_shape : t_layer;
+            apply(cur);
+            if (logf) fprintf(logf, "whole step: shape-derived table %.4f ms, per-layer table %.4f ms\n", t_shape, t_layer);
+            // groups of equal signature
+            std::vector<std::string> sigs(n);
+            std::vector<std::vector<size_t>> groups;
+            for (size_t i = 0; i < n; ++i) {
+                if (!measured[i]) continue;
+                sigs[i] = signature(p->ops[i].conv);
+                bool found = false;
+                for (auto& g : groups)
+                    if (sigs[g[0]] == sigs[i]) {
+                        g.push_back(i);
+                        found = true;
+                        break;
+                    }
+                if (!found) groups.push_back({i});
+            }
+            auto group_time = [&](const std::vector<size_t>& g) { return (double)times[g[0]][cur[g[0]]] * (double)g.size(); };
+            std::sort(groups.begin(), groups.end(), [&](const auto& a, const auto& b) { return group_time(a) > group_time(b); });
+            int trials = 0, kept = 0;
+            for (const auto& g : groups) {
+                const std::vector<float>& row = times[g[0]];
+                float iso_best = 1e30f;
+                for (int v = 1; v < nv; ++v)
+                    if (row[v] < iso_best) iso_best = row[v];
+                for (int v = 1; v < nv && rc_step == Y6_OK; ++v) {
+                    if (v == cur[g[0]] || row[v] > 1e29f || excluded[v]) continue;
+                    if (row[v] > iso_best * 1.3f && v != shape_tab[g[0]] && v != layer_tab[g[0]]) continue;
+                    const int old = cur[g[0]];
+                    for (size_t i : g) p->ops[i].conv.variant = v;
+                    const float t = step_ms(5);
+                    ++trials;
+                    if (t < best_t * 0.996f) {
+                        if (logf) fprintf(logf, "whole step: %s x%zu %s -> %s: %.4f -> %.4f ms\n", sigs[g[0]].c_str(), g.size(), y6_conv_variant_name(old), y6_conv_variant_name(v), best_t, t);
+                        best_t = t;
+                        for (size_t i : g) cur[i] = v;
+                        ++kept;
+                    } else {
+                        for (size_t i : g) p->ops[i].conv.variant = old;
+                    }
+                }
+            }
+            if (logf) fprintf(logf, "whole step: %d trials, %d kept, %.4f ms\n", trials, kept, best_t);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            if (rc_step) {
+                if (logf) fclose(logf);
+                return rc_step;
+            }
+        }
+    }
+    if (cachepath) {
+        for (size_t i = 0; i < p->ops.size(); ++i) {
+            if (!measured[i]) continue;
+            const std::string sig = signature(p->ops[i].conv);
+            bool have = false;
+            for (const auto& kv : cache) have = have || kv.first == sig;
+            if (have) continue;
+            cache.emplace_back(sig, y6_conv_variant_name(p->ops[i].conv.variant));
+            if (FILE* cf = fopen(cachepath, "a")) {
+                fprintf(cf, "%s %s\n", sig.c_str(), y6_conv_variant_name(p->ops[i].conv.variant));
+                fclose(cf);
             }
         }
     }
     if (logf) fclose(logf);
     Y6_HIP(hipStreamSynchronize(s));
+    return Y6_OK;
+}
+
+// The conv kernel choices of `src` for `dst` - two plans lowered from the same module for the same shapes (HipModule.new_plan: the
+// in-flight slots of pipeline.InflightRunner / bench.py) run the same kernels without tuning twice.
+extern "C" int y6_plan_copy_variants(y6_plan* dst, const y6_plan* src) {
+    Y6_REQUIRE(dst && src && dst->ops.size() == src->ops.size(), "plan_copy_variants: the plans differ in length");
+    for (size_t i = 0; i < dst->ops.size(); ++i) {
+        const Op& a = src->ops[i];
+        Op& b = dst->ops[i];
+        Y6_REQUIRE(a.kind == b.kind, "plan_copy_variants: op %zu differs in kind", i);
+        if (a.kind != Y6_OP_CONV) continue;
+        Y6_REQUIRE(a.conv.ksize == b.conv.ksize && a.conv.stride == b.conv.stride && a.conv.in.C == b.conv.in.C && a.conv.out.C == b.conv.out.C &&
+                       a.conv.in.B == b.conv.in.B && a.conv.in.H == b.conv.in.H && a.conv.in.W == b.conv.in.W,
+                   "plan_copy_variants: op %zu differs in shape", i);
+        if (a.conv.variant >= 0) Y6_REQUIRE(y6_conv_variant_supports(&b.conv, a.conv.variant), "plan_copy_variants: op %zu cannot run variant %d", i, a.conv.variant);
+        b.conv.variant = a.conv.variant;
+    }
+    drop_graph(dst);
     return Y6_OK;
 }
 

@@ -154,6 +154,10 @@ class Plan:
     def autotune(self, iters: int = 3):
         _lib.check(self._lib.y6_plan_autotune(self._h, _lib.current_stream_ptr(), iters), "plan_autotune")
 
+    def copy_variants_from(self, other: "Plan"):
+        """Run the conv kernels `other` runs (a plan of the same module for the same input shapes: no second tuning)."""
+        _lib.check(self._lib.y6_plan_copy_variants(self._h, other._h), "plan_copy_variants")
+
     def capture(self):
         """Capture into a hipGraph (needs a non-default stream current)."""
         _lib.check(self._lib.y6_plan_capture(self._h, _lib.current_stream_ptr()), "plan_capture")
@@ -726,12 +730,14 @@ class PlanBuilder:
         return out
 
     # ---------------------------------------------------------------- finish
-    def finalize(self, outputs, autotune=True, iters=3) -> Plan:
+    def finalize(self, outputs, autotune=True, iters=3, variants_from: Optional[Plan] = None) -> Plan:
         self._flush()
         plan = Plan(self.h, self.keep, outputs, self.inputs)
         plan.op_log = self.op_log
         self.h = None
-        if autotune and self.force_variant < 0:
+        if variants_from is not None:
+            plan.copy_variants_from(variants_from)
+        elif autotune and self.force_variant < 0:
             plan.autotune(iters)
         import os
         # two-stream schedule of run(): on since r03u (+2.0 % img/s same box, alternating runs, bit-identical results:

@@ -197,7 +197,7 @@ class HipModule(nn.Module):
         self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan, holders)
         return plan
 
-    def _lower_plan(self, x, flat, contig, quant, autotune):
+    def _lower_plan(self, x, flat, contig, quant, autotune, variants_from=None):
         self._check_runnable()
         if quant is not None:
             quant.decisions = None
@@ -214,14 +214,14 @@ class HipModule(nn.Module):
         outs = self.lower(pb, _wrap(x, iter(contig)))
         odt = flat[0].dtype if flat[0].dtype in (torch.float16, torch.float32) else torch.float16
         outs = self._finish_outputs(pb, outs, odt)
-        plan = pb.finalize(outs, autotune=autotune)
+        plan = pb.finalize(outs, autotune=autotune, variants_from=variants_from)
         # builder order of the boundary tensors -> position in the caller's argument list
         plan.input_order = [next(j for j, c in enumerate(contig) if c is t) for t in plan.inputs]
         plan.params_version = _params_version(self)      # what the packed weights of this plan were derived from
         plan.quant_key = None if quant is None else quant.key()
         return plan
 
-    def new_plan(self, *inputs, autotune=True):
+    def new_plan(self, *inputs, autotune=True, variants_from=None):
         """One MORE plan of this module for these inputs, outside the plan cache: its own activation buffers and its own packed
         copies of the weights, lowered from the SAME parameters, BatchNorm buffers and int8 calibration as the cached plan
         (pipeline.InflightRunner keeps N of them for N batches in flight).  The caller owns it; `plan.params_version` /
@@ -233,7 +233,8 @@ class HipModule(nn.Module):
                 raise RuntimeError("yolov6_amd: the HIP hot path needs ROCm tensors; there is no CPU fallback "
                                    f"(got a tensor on {t.device})")
         contig = [t.contiguous() for t in flat]
-        return self._lower_plan(x, flat, contig, self.__dict__.get("_y6_quant"), autotune)
+        # variants_from: a plan of this module for the same shapes whose (tuned) kernel choices the new plan takes over
+        return self._lower_plan(x, flat, contig, self.__dict__.get("_y6_quant"), autotune, variants_from=variants_from)
 
     def plan_is_current(self, plan) -> bool:
         """Does `plan` (compile() / new_plan()) still describe this module - same parameter tensors at the same autograd

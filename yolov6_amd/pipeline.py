@@ -62,7 +62,8 @@ class InflightRunner:
         # model ran the fp16 plan - ADVICE r4.)
         self.model = model
         self.autotune = autotune
-        self.plans = [model.new_plan(example, autotune=autotune) for _ in range(depth)]
+        self.plans = [model.new_plan(example, autotune=autotune)]
+        self.plans += [model.new_plan(example, autotune=autotune, variants_from=self.plans[0]) for _ in range(depth - 1)]   # tuned once
         self._tensors = list(model.parameters()) + list(model.buffers())
         self._vsum = sum(t._version for t in self._tensors)
         self._quant = model.__dict__.get("_y6_quant")
