@@ -492,6 +492,8 @@ def mock_main(args):
     from yolov6_amd.parallel import GradReducer, Replicas
     from yolov6_amd.train_engine import ParamArena
     rep = Replicas(backend="gloo")
+    if args.mode == "infer":
+        return mock_infer(args, rep)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
     arena = ParamArena(net, "cpu")
@@ -525,6 +527,36 @@ def mock_main(args):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "mock (Y6_BENCH_MOCK=1)",
                           "config": {"workload": "launch-path stand-in", "global_batch": rep.world * b, "parallelism": f"dp{rep.world}"},
                           "grad_abs_sum": gsum}), flush=True)
+    rep.close()
+
+
+def mock_infer(args, rep):
+    """Y6_BENCH_MOCK=1, inference mode: the N-rank control flow of the headline path on CPU ranks over gloo - per-rank set-up of
+    DIFFERENT length in front of the first barrier (on a GPU: autotuning and the stream-pair selection are timed loops whose length
+    differs per rank; they contain no collective, so a slow rank only makes the others wait in timed_window's barrier), then the
+    same `timed_window` the GPU path times its windows with (three windows + the one-at-a-time window), MAX over the ranks, one
+    JSON line from rank 0.  Replicas only: no data-path collective.  Not a benchmark: `data` says so."""
+    g = torch.Generator().manual_seed(rep.rank)
+    a = torch.randn((64, 64), generator=g)
+    time.sleep(0.05 * (1 + rep.rank))               # rank-dependent set-up time (stands for autotune + pick_streams)
+    state = {"n": 0}
+
+    def enqueue(i):
+        state["n"] += 1
+        state["y"] = a @ a
+
+    windows = [timed_window(rep, args.steps, enqueue, lambda: None) for _ in range(max(1, args.windows))]
+    seq = timed_window(rep, args.steps, enqueue, lambda: None)
+    elapsed = sorted(windows)[len(windows) // 2]
+    if rep.rank == 0:
+        print("bench.py mock launch: not a measurement", flush=True)
+        print(json.dumps({"metric": "mock steps/sec", "value": round(rep.throughput(args.batch, args.steps, elapsed), 2), "unit": "images/sec",
+                          "n_gpus": rep.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                          "sequential": {"value": round(rep.throughput(args.batch, args.steps, seq), 2)},
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "mock (Y6_BENCH_MOCK=1)",
+                          "config": {"workload": "launch-path stand-in (inference control flow)", "global_batch": rep.world * args.batch,
+                                     "parallelism": f"replicas x{rep.world} (no collective)"},
+                          "steps_enqueued_rank0": state["n"]}), flush=True)
     rep.close()
 
 

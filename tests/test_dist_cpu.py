@@ -389,3 +389,24 @@ def test_two_rank_gloo_ddp_buffer_broadcast_lands_in_the_storage_the_plans_hold(
         res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
         assert res["same_storage"] and res["follows_rank0"] and res["params_are_views"], res
         assert res["moved"] > 1e-4, res
+
+
+def test_bench_infer_two_ranks_self_spawn_on_gloo(tmp_path):
+    """`python bench.py --gpus 2` (the headline, inference mode) as the driver launches it on a multi-GPU node, minus the GPUs
+    (Y6_BENCH_MOCK=1): self-spawn under torch.distributed.run on 127.0.0.1, ranks whose set-up takes DIFFERENT time meet in the
+    timed windows' barriers (no hang), `timed_window` - the function the GPU path times with - runs EXACTLY K steps per window on every
+    rank, rank 0 prints ONE JSON line last: n_gpus 2, replicas (no collective), weak scaling, global batch doubled."""
+    env = dict(os.environ, Y6_BENCH_MOCK="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "7", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
+    assert sum(1 for l in lines if l.startswith("{")) == 1, lines
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 64 and "no collective" in d["config"]["parallelism"]
+    assert d["steps_enqueued_rank0"] == 7 * 4            # three windows + the one-at-a-time window, exactly K steps each
+    assert d["value"] > 0 and d["sequential"]["value"] > 0
+    assert d["supervisor"]["attempts"] == 1

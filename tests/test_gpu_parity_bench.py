@@ -195,3 +195,54 @@ def test_inflight_runner_equals_one_at_a_time():
         for a, b_ in zip(g, w):
             assert torch.equal(a, b_), f"batch {k}: detections differ from the one-at-a-time path"
     assert sum(int(t.shape[0]) for w in want for t in w) > 0
+
+
+def test_whole_step_tuned_plan_and_its_copy_run_the_same_kernels():
+    """y6_plan_autotune's whole-step pass leaves every conv op with a named variant the op supports; `new_plan(variants_from=...)`
+    (the in-flight slots: tuned once) takes the table over without tuning again - same variant table, same hash - and, running the
+    same kernels on the same input, produces the same BITS; the tuned plan agrees with the shape-derived plan of the same model
+    within the fp16 tolerance of a different accumulation order."""
+    cfg, sd, model, x = _bench_setup("yolov6s", 320, 8)
+    tuned = model.compile(x, autotune=True)
+    tab = tuned.variant_table()
+    assert tab and all(name not in ("", "shape-derived", "naive") for _, name in tab), tab
+    twin = model.new_plan(x, autotune=True, variants_from=tuned)
+    assert twin.variant_table() == tab and twin.variant_hash() == tuned.variant_hash()
+    a = tuned.run().clone()
+    b = twin.run().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), "two plans with the same kernel table must produce the same bits"
+    shape = model.new_plan(x, autotune=False)
+    c = shape.run().clone()
+    torch.cuda.synchronize()
+    assert float((a[..., 5:] - c[..., 5:]).abs().max()) < 2e-3
+    assert float((a[..., :4] - c[..., :4]).abs().max()) < 0.5           # pixels
+    other = model.new_plan(x[:4].contiguous(), autotune=False)
+    with pytest.raises(RuntimeError, match="differs in shape|differ in length"):
+        other.copy_variants_from(tuned)
+
+
+@pytest.mark.parametrize("mode", ["infer", "train"])
+def test_bench_under_torchrun_with_a_one_rank_rccl_group(mode):
+    """The driver's N > 1 launch form - `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` - with the one GPU
+    a test box has and the process group forced up (Y6_FORCE_DIST=1): the RCCL communicator, the barriers of timed_window, the MAX
+    all-reduce and (train) the chunked gradient all-reduce behind the backward plan all execute; rank 0 prints one JSON line."""
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    extra = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-train-sub", "--dropin-steps", "0"] if mode == "infer" else \
+        ["--mode", "train", "--steps", "3", "--warmup", "2"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
+    env = dict(os.environ, Y6_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    if mode == "infer":
+        assert d["inflight"] == 2 and d["sequential"]["value"] > 0 and d["self_check"]["nms_equals_oracle_images"] >= 2

@@ -3,6 +3,9 @@
 // dispatcher; conv_dma.hip: the LDS-DMA fed 3x3 kernels).  Everything lives in an anonymous namespace: each TU gets its
 // own copy, nothing is exported.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -460,5 +463,34 @@ struct Launch {
     int grid;
     size_t lds;
 };
+
+// Resident grid of a persistent conv kernel: CUs of the current device x blocks of `threads` threads with `lds` bytes of dynamic LDS
+// that fit a CU.  The occupancy query costs tens of microseconds of host time: its answers are kept per (device, LDS size) - one table
+// per kernel instantiation (`cache` is a function-local static of the launcher template), behind a mutex (the single-entry
+// cache it replaces was neither per-device nor thread-safe, and re-queried whenever consecutive layers differed in LDS size).
+struct OccupancyCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, int> grid;   // (device, lds) -> n_cu * blocks per CU
+    bool big_lds[64] = {};                        // per device: hipFuncAttributeMaxDynamicSharedMemorySize raised
+};
+template <class K>
+int resident_grid(OccupancyCache& cache, K kern, int threads, size_t lds, size_t lds_limit, int* grid_out) {
+    int dev = 0;
+    Y6_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(cache.mu);
+    if (lds > 64 * 1024 && dev >= 0 && dev < 64 && !cache.big_lds[dev]) {
+        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_limit));
+        cache.big_lds[dev] = true;
+    }
+    auto it = cache.grid.find({dev, lds});
+    if (it == cache.grid.end()) {
+        int bpc = 0, n_cu = 0;
+        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, threads, lds));
+        Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        it = cache.grid.emplace(std::make_pair(dev, lds), n_cu * (bpc < 1 ? 1 : bpc)).first;
+    }
+    *grid_out = it->second;
+    return Y6_OK;
+}
 
 }  // namespace

@@ -680,26 +680,13 @@ __global__ void dma_probe_kernel(const char* src, unsigned bytes, unsigned lds_o
 template <int CF, int PF, int NW, int WPS, int STG, int IL, int HC, bool I8, int ST = 1, bool WRES = false>
 int launch_dma(const Launch& L, hipStream_t s) {
     auto kern = conv3x3_dma_kernel<CF, PF, NW, WPS, STG, IL, HC, I8, ST, WRES>;
-    static bool big_lds_enabled = false;
-    if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds_enabled = true;
-    }
     Y6_REQUIRE(L.lds <= 160 * 1024, "conv_dma: tile needs %zu bytes of LDS", L.lds);
-    static size_t cached_lds = 0;
-    static int cached_bpc = 0, n_cu = 0;
-    if (cached_lds != L.lds) {
-        int bpc = 0;
-        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, L.lds));
-        if (n_cu == 0) {
-            int dev = 0;
-            Y6_HIP(hipGetDevice(&dev));
-            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        cached_bpc = bpc < 1 ? 1 : bpc;
-        cached_lds = L.lds;
+    static OccupancyCache occ;
+    int grid = 0;
+    {
+        int rc = resident_grid(occ, kern, NW * 64, L.lds, 160 * 1024, &grid);
+        if (rc) return rc;
     }
-    int grid = n_cu * cached_bpc;
     // ids of one tile's cout blocks share id % 8 (XCD): keep the stride a multiple.  Resident weights: a multiple of 8 * ncb,
     // so that (id >> 3) % ncb - the cout block - is the same for every item of a block
     const int gq = (WRES && L.k.ncb > 1) ? 8 * L.k.ncb : 8;

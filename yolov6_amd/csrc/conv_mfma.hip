@@ -1131,26 +1131,13 @@ int launch_one(const Launch& L, hipStream_t s) {
 template <int CF, int PF, int WPS, int NW = 4, int ST = 1, int DEPTH = 2>
 int launch_pipe(const Launch& L, hipStream_t s) {
     auto kern = conv_mfma_pipe_kernel<CF, PF, WPS, NW, ST, DEPTH>;
-    static bool big_lds_enabled = false;
-    if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds_enabled = true;
-    }
     Y6_REQUIRE(L.lds <= 160 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
-    static size_t cached_lds = 0;
-    static int cached_bpc = 0, n_cu = 0;
-    if (cached_lds != L.lds) {
-        int bpc = 0;
-        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, NW * 64, L.lds));
-        if (n_cu == 0) {
-            int dev = 0;
-            Y6_HIP(hipGetDevice(&dev));
-            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        cached_bpc = bpc < 1 ? 1 : bpc;
-        cached_lds = L.lds;
+    static OccupancyCache occ;
+    int grid = 0;
+    {
+        int rc = resident_grid(occ, kern, NW * 64, L.lds, 160 * 1024, &grid);
+        if (rc) return rc;
     }
-    int grid = n_cu * cached_bpc;
     grid -= grid % 8;
     if (grid < 8) grid = 8;
     if (grid > L.grid) grid = L.grid;

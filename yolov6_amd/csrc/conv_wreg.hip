@@ -565,26 +565,13 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 template <int PF, int WC, int WP, int ST, bool I8 = false>
 int launch_wreg(const Launch& L, hipStream_t s) {
     auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8>;
-    static bool big_lds_enabled = false;
-    if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        big_lds_enabled = true;
-    }
     Y6_REQUIRE(L.lds <= 160 * 1024, "conv_wreg: tile needs %zu bytes of LDS", L.lds);
-    static size_t cached_lds = 0;
-    static int cached_bpc = 0, n_cu = 0;
-    if (cached_lds != L.lds) {
-        int bpc = 0;
-        Y6_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, (const void*)kern, WC * WP * 64, L.lds));
-        if (n_cu == 0) {
-            int dev = 0;
-            Y6_HIP(hipGetDevice(&dev));
-            Y6_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
-        cached_bpc = bpc < 1 ? 1 : bpc;
-        cached_lds = L.lds;
+    static OccupancyCache occ;
+    int grid = 0;
+    {
+        int rc = resident_grid(occ, kern, WC * WP * 64, L.lds, 160 * 1024, &grid);
+        if (rc) return rc;
     }
-    int grid = n_cu * cached_bpc;
     const int gq = 8 * L.k.ncb;   // ids of one tile's cout blocks share id % 8 (XCD); (id >> 3) % ncb - the cout block - is the same for every item of a block
     grid -= grid % gq;
     if (grid < gq) grid = gq;
