@@ -66,6 +66,21 @@ class _ResultRing:
     def _refs(lst, i):
         return sys.getrefcount(lst[i])
 
+    _supported = None
+
+    @classmethod
+    def supported(cls):
+        """Start-up self check of what the ring relies on: a view keeps its base alive THROUGH THE PYTHON OBJECT, i.e. making a
+        view raises the base tensor's CPython reference count (true for torch 2.x's PyObject preservation).  On a build where it does
+        not, `boxes = det[..., :4]; del det` would leave the slot looking free - Model.forward then clones every result instead."""
+        if cls._supported is None:
+            probe = [torch.empty(4)]
+            before = sys.getrefcount(probe[0])
+            view = probe[0][:2]
+            cls._supported = sys.getrefcount(probe[0]) > before
+            del view
+        return cls._supported
+
     def next(self, held_by_plan=None):
         """The tensor the next run writes.  `held_by_plan`: the plan's current output (its own reference is not a caller's)."""
         self.pos = (self.pos + 1) % len(self.slots)
@@ -115,6 +130,8 @@ class Model(HipModule):
         if prev is not None:
             prev._fill()            # a caller still holds the previous result unread: copy it out before overwriting
         nbuf = int(self.output_buffers)
+        if nbuf >= 2 and not _ResultRing.supported():
+            nbuf = 0                      # views are not counted on this torch build: hand out clones
         if nbuf >= 2:
             ring = getattr(plan, "_det_ring", None)
             if ring is None or len(ring.slots) != nbuf:
