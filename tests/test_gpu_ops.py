@@ -557,3 +557,41 @@ def test_head_decode(use_dfl, nc, sizes):
     ref = torch.cat([box, torch.ones(B, box.shape[1], 1), c], -1)
     assert out.shape == ref.shape and out.dtype == torch.float32
     assert G.max_rel(out.cpu(), ref) < TOL
+
+
+def test_conv_wreg_relu_only_form_is_bit_identical_to_the_general_form():
+    """conv3x3_wreg_kernel<..., EPI = 1 | 2> (round 5: the bias + ReLU / bias + SiLU epilogue compiled alone, 14-25 KB of code instead
+    of 180 KB - the once-per-item epilogue no longer runs at instruction-fetch latency after a kernel switch) computes
+    the same arithmetic in the same order as the general form: same bits, for every register-fed variant, stride 1 and 2, ragged maps.  The
+    general form is selected by Y6_WREG_GENERAL_EPI=1 (read once per process): it runs in a child process.  The same for the
+    activation-specialised instantiations of the per-tap 1x1 kernel (conv_mfma_kernel<..., ACT>, Y6_CONV_GENERAL_EPI=1)."""
+    import subprocess
+    import sys
+    _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import gpu_utils as G
+from test_gpu_ops import _mk_weights
+names = G.variant_names()
+out = []
+for (cin, cout, k, s, H, W, B) in [(128, 128, 3, 1, 40, 40, 3), (64, 128, 3, 1, 37, 23, 2), (128, 256, 3, 2, 40, 40, 2), (64, 128, 3, 2, 33, 47, 2),
+                                   (128, 64, 1, 1, 40, 40, 2), (192, 64, 1, 1, 19, 23, 3), (512, 256, 1, 1, 20, 20, 2)]:
+    x = G.rand_nhwc(B, H, W, cin, seed=5)
+    w, b = _mk_weights(cout, cin, k, 7)
+    for v, name in enumerate(names):
+        if not name.startswith("wreg" if k == 3 else "mfma") or not G.supports(x, w, s, v):
+            continue
+        for act in ("relu", "silu"):
+            o, _ = G.run_conv(x, w, b, s, act, v)
+            out.append("%%s:k%%d:%%d:%%s:%%s" %% (name, k, s, act, hashlib.sha256(o.to_nhwc_tensor().contiguous().cpu().numpy().tobytes()).hexdigest()[:16]))
+print("HASHES " + " ".join(out))
+''' % (_ROOT, os.path.join(_ROOT, "tests"))
+    def run(env_extra):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][-1].split()[1:]
+    fast, general = run({}), run({"Y6_WREG_GENERAL_EPI": "1", "Y6_CONV_GENERAL_EPI": "1"})
+    assert len(fast) >= 24 and fast == general, (fast, general)

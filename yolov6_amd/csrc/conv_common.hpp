@@ -194,8 +194,16 @@ __device__ __forceinline__ void finish16(const ConvKArgs& a, const f32x16_t& acc
     }
 }
 
+// ACT >= 0: the activation is a compile-time fact of the kernel instantiation (round 5: the four-way switch below is instantiated
+// per fragment in fully unrolled epilogues - three quarters of a 100-380 KB kernel that an instruction cache of 64 KB has to
+// step over); ACT < 0: decided per launch.
+template <int ACT = -1>
 __device__ __forceinline__ void finish16_any(const ConvKArgs& a, const f32x16_t& acc, const float (&bias)[16], int cfrag,
                                              int kh, int cend, const __half* rrow, float ralpha, float (&v)[16]) {
+    if constexpr (ACT >= 0) {
+        finish16<ACT>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v);
+        return;
+    }
     switch (a.act) {   // one wave-uniform branch per fragment
         case Y6_ACT_RELU: finish16<Y6_ACT_RELU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
         case Y6_ACT_SILU: finish16<Y6_ACT_SILU>(a, acc, bias, cfrag, kh, cend, rrow, ralpha, v); break;
@@ -231,7 +239,7 @@ __device__ __forceinline__ void load_bias(const ConvKArgs& a, int cb, int upc0, 
         }
 }
 
-template <int CF, int PF>
+template <int CF, int PF, int ACT = -1>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF], const int (&opix)[PF],
                                               int cb, int upc0, int lane, const BiasRegs<CF>& bz) {
     const float ralpha = (a.res != nullptr && a.res_alpha != nullptr) ? *a.res_alpha : 1.f;
@@ -248,7 +256,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t
             const int cfrag = (cb * CF + cf) * 32 - upc0;   // first output channel of this fragment
             // 1) finish the 16 values of this lane
             float v[16];
-            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
+            finish16_any<ACT>(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
             // 2) pack to fp16 pairs: group g -> dwords pk[g][0..1]
             unsigned pk[4][2];
 #pragma unroll
@@ -299,7 +307,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& a, const f32x16_t
 // channel row: a store instruction now covers 64*16 B of (at most 64/(CF*4)) complete NHWC rows.
 // Wave-private region -> no block barrier (LDS ops of one wave complete in order; lgkmcnt(0) between
 // the phases).  Callers must have passed a block barrier after the last main-loop LDS read.
-template <int CF, int PF>
+template <int CF, int PF, int ACT = -1>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvKArgs& a, const f32x16_t (&acc)[CF][PF],
                                                   const int (&opix)[PF], int cb, int upc0, int lane, int wave,
                                                   const BiasRegs<CF>& bz, char* lds) {
@@ -323,7 +331,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvKArgs& a, const f32x
         for (int cf = 0; cf < CF; ++cf) {
             const int cfrag = cblock + cf * 32;
             float v[16];
-            finish16_any(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
+            finish16_any<ACT>(a, acc[cf][pf], bz.v[cf], cfrag, kh, cend, (pvalid ? rrow : nullptr), ralpha, v);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 typedef _Float16 h4v __attribute__((ext_vector_type(4)));

@@ -21,7 +21,9 @@
 
 namespace {
 
-template <int CF, int PF, int KS, int ST>
+// ACT: the activation as a compile-time fact (Y6_ACT_RELU / Y6_ACT_SILU instantiations exist for the 1x1 stride-1 form: the 14
+// 1x1 launches of a YOLOv6-S step), -1: decided per launch.  The same epilogue functions, the same arithmetic: bit-identical.
+template <int CF, int PF, int KS, int ST, int ACT = -1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = KS * KS;
@@ -213,9 +215,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvKArgs a) {
 
     // the last step's barrier has been passed by every wave: halo / weight LDS is dead, re-use it
     if (a.epi_lds)
-        conv_epilogue_lds<CF, PF>(a, acc, opix, cb, upc0, lane, wave, bz, smem);
+        conv_epilogue_lds<CF, PF, ACT>(a, acc, opix, cb, upc0, lane, wave, bz, smem);
     else
-        conv_epilogue<CF, PF>(a, acc, opix, cb, upc0, lane, bz);
+        conv_epilogue<CF, PF, ACT>(a, acc, opix, cb, upc0, lane, bz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1112,18 +1114,23 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     return Y6_OK;
 }
 
-template <int CF, int PF, int KS, int ST>
+template <int CF, int PF, int KS, int ST, int ACT = -1>
 int launch_one(const Launch& L, hipStream_t s) {
+    if constexpr (KS == 1 && ST == 1 && ACT < 0) {   // the activation-specialised forms of the 1x1 kernel (A/B: Y6_CONV_GENERAL_EPI=1)
+        static const bool general = getenv("Y6_CONV_GENERAL_EPI") != nullptr;
+        if (!general && L.k.act == Y6_ACT_RELU) return launch_one<CF, PF, 1, 1, Y6_ACT_RELU>(L, s);
+        if (!general && L.k.act == Y6_ACT_SILU) return launch_one<CF, PF, 1, 1, Y6_ACT_SILU>(L, s);
+    }
     // dynamic LDS above 64 KiB (stride-2 halo + a 3-slot ring of 4-fragment weight images) must be
     // opted into once per kernel; gfx950 has 160 KiB per CU
     static bool big_lds_enabled = false;
     if (L.lds > 64 * 1024 && !big_lds_enabled) {
-        Y6_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<CF, PF, KS, ST>,
+        Y6_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<CF, PF, KS, ST, ACT>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         big_lds_enabled = true;
     }
     Y6_REQUIRE(L.lds <= 128 * 1024, "conv_mfma: tile needs %zu bytes of LDS", L.lds);
-    hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, KS, ST>), dim3(L.grid), dim3(256), L.lds, s, L.k);
+    hipLaunchKernelGGL((conv_mfma_kernel<CF, PF, KS, ST, ACT>), dim3(L.grid), dim3(256), L.lds, s, L.k);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

@@ -103,8 +103,18 @@ constexpr int kWregProbe = Y6_WREG_PROBE;
 // as the fp16 instruction, so a stage is 64 int8 channels in the SAME 64-byte pixel slots, a weight fragment is the same 1 KiB
 // (quant.hip's packing: [cout/32][cin/64][tap][k-step]) and the request / wait / barrier protocol below is shared word for word;
 // what differs is the element size of the input view, int32 accumulators and the epilogue's dequantisation (+ the int8 twin).
-template <int PF, int WC, int WP, int ST, bool I8>
+// RELU_ONLY (round 5): the epilogue specialised at compile time for what 32 of the 38 register-fed launches of YOLOv6-S need - bias +
+// ReLU into a 16-byte aligned fp16 view, no post-affine, no residual.  The general form's epilogue is ~20 KB of straight-line code
+// per item (seven unrolled fast_unit copies, each carrying the post-affine / SiLU / hardswish arithmetic behind wave-uniform
+// branches) plus the out-of-line general epilogue; code that runs once per item is executed at instruction-fetch latency whenever
+// the function's lines have left the 64 KB instruction cache, i.e. after two or three other kernels (22 500 cycles
+// instead of 7 200 for the first item's epilogue).  This form's epilogue is ~3 KB and the function ~40 KB instead of 110-180 KB.
+// Same arithmetic in the same order: bit-identical outputs (tests/test_gpu_ops.py; A/B switch Y6_WREG_GENERAL_EPI=1).
+// EPI: 0 = the general form, 1 = bias + ReLU only (RELU_ONLY above), 2 = bias + SiLU only (the head's cls / reg convs,
+// effidehead.py:172-181: ConvBNSiLU - 3 launches of YOLOv6-S, one of them 108 us cold against 55 warm on the general form).
+template <int PF, int WC, int WP, int ST, bool I8, int EPI = 0>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
+    constexpr bool RELU_ONLY = EPI == 1, SILU_ONLY = EPI == 2, SPECIAL = EPI != 0;
     constexpr int kMaxP = ST == 2 ? kMaxP2 : kMaxP1;   // halo requests per wave and stage
     constexpr int ES = I8 ? 1 : 2;                     // bytes per input element
     typedef typename std::conditional<I8, i32x16_t, f32x16_t>::type acc_t;
@@ -264,13 +274,13 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     //      The int8 form multiplies the exact int32 sums by s_x * s_w[c] first (a rounding of its own, as every int8 kernel of
     //      this library) and may write the int8 twin of its output for quantised consumers - with or without the fp16 view.
     float* ldsVec = reinterpret_cast<float*>(smem + 2u * stage_bytes);   // [bias | post scale | post shift | dequant][WC * 32]
-    const bool has_post = a.pscale != nullptr;
+    const bool has_post = !SPECIAL && a.pscale != nullptr;
     const bool has_out = a.out != nullptr, has_qout = I8 && a.qout != nullptr;
     const bool fast = a.res == nullptr && a.up == 0 && (has_out || has_qout) && (!has_out || a.vec16_ok) &&
                       (!has_qout || ((a.qout_cs | a.qout_co) & 3) == 0) && (!I8 || a.acc_out == nullptr) &&
                       (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
-    const float fast_lo = a.act == Y6_ACT_RELU ? 0.f : -__builtin_inff();
-    const bool smooth_act = a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH;
+    const float fast_lo = (RELU_ONLY || a.act == Y6_ACT_RELU) ? 0.f : -__builtin_inff();
+    const bool smooth_act = SILU_ONLY || (!SPECIAL && (a.act == Y6_ACT_SILU || a.act == Y6_ACT_HARDSWISH));
     const __amdgpu_buffer_rsrc_t rsO =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsQ =
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
             }
             if (smooth_act) {   // one wave-uniform branch per group, the arithmetic of act_const<>
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[g * 4 + j] = a.act == Y6_ACT_SILU ? act_const<Y6_ACT_SILU>(x[j]) : act_const<Y6_ACT_HARDSWISH>(x[j]);
+                for (int j = 0; j < 4; ++j) v[g * 4 + j] = (SILU_ONLY || a.act == Y6_ACT_SILU) ? act_const<Y6_ACT_SILU>(x[j]) : act_const<Y6_ACT_HARDSWISH>(x[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[g * 4 + j] = fmaxf(x[j], fast_lo);
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[pf][r] = 0;
                 }
-            } else if constexpr (I8) {   // the host (conv_mfma.hip: y6_conv_i8_variant) sends only fast-path layers here
+            } else if constexpr (I8 || SPECIAL) {   // the host sends only fast-path layers here (y6_conv_i8_variant / wreg_special_epilogue)
                 __builtin_trap();
             } else {
                 const ConvKArgs ea = reload_args();
@@ -562,9 +572,25 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 // a lone wave per SIMD issues MFMAs at 89 % of the pipe's rate, and every phase lasts as long as the longer of the two partners.
 // Removed; git history has it.)
 
-template <int PF, int WC, int WP, int ST, bool I8 = false>
+// which specialised epilogue a launch can take: the kernel's fast-epilogue condition (its `fast`) without a post-affine, with ReLU
+// (1) or SiLU (2); 0: the general form
+static int wreg_special_epilogue(const ConvKArgs& k) {
+    static const bool off = getenv("Y6_WREG_GENERAL_EPI") != nullptr;   // A/B switch
+    if (off || k.pscale != nullptr || k.res != nullptr || k.up != 0 || k.out == nullptr || !k.vec16_ok ||
+        (size_t)k.B * k.Ho * k.Wo * k.out_cs * 2 >= 0xe0000000ull)
+        return 0;
+    return k.act == Y6_ACT_RELU ? 1 : (k.act == Y6_ACT_SILU ? 2 : 0);
+}
+
+template <int PF, int WC, int WP, int ST, bool I8 = false, int EPI = 0>
 int launch_wreg(const Launch& L, hipStream_t s) {
-    auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8>;
+    if constexpr (!I8 && EPI == 0) {
+        switch (wreg_special_epilogue(L.k)) {
+            case 1: return launch_wreg<PF, WC, WP, ST, false, 1>(L, s);
+            case 2: return launch_wreg<PF, WC, WP, ST, false, 2>(L, s);
+        }
+    }
+    auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8, EPI>;
     Y6_REQUIRE(L.lds <= 160 * 1024, "conv_wreg: tile needs %zu bytes of LDS", L.lds);
     static OccupancyCache occ;
     int grid = 0;
