@@ -764,8 +764,11 @@ def main():
         fwd_ms = sum(r["ms"] for r in rows)
         ms_per_step = elapsed / args.steps * 1e3
         res = {
+            # (`value` is the throughput with n_fly batches in flight, and the metric says so; the one-batch-at-a-time
+            # figure - what rounds 1-3 reported as `value` - is `sequential` in the same line)
             "metric": ("images/sec (b32, 640x640) YOLOv6-S fp16 inference (forward + NMS)" if headline else
-                       f"images/sec (b{args.batch}, {args.size}x{args.size}) {args.model} {'int8' if args.int8 else 'fp16'} inference (forward + NMS)"),
+                       f"images/sec (b{args.batch}, {args.size}x{args.size}) {args.model} {'int8' if args.int8 else 'fp16'} inference (forward + NMS)")
+                      + (f", {n_fly} batches in flight" if n_fly > 1 else ""),
             "value": round(rep.throughput(args.batch, args.steps, elapsed), 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -20,6 +20,19 @@ def pytest_configure(config):
         install(mode)
 
 
+def pytest_unconfigure(config):
+    # proof for the parent test that this process really allocated through the guard allocator (its own stderr banner is swallowed
+    # by pytest's capture): "<mode> <allocations served>" into the file named by Y6_GUARD_ALLOC_MARK
+    mode, mark = os.environ.get("Y6_GUARD_ALLOC"), os.environ.get("Y6_GUARD_ALLOC_MARK")
+    if mode and mark:
+        import ctypes
+        from tests.native import build as gb
+        lib = ctypes.CDLL(gb.LIB)              # the library torch already loaded: the same counters
+        lib.guard_total_blocks.restype = ctypes.c_long
+        with open(mark, "w") as f:
+            f.write(f"{mode} {int(lib.guard_total_blocks())}\n")
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

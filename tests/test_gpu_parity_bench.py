@@ -215,8 +215,8 @@ def test_whole_step_tuned_plan_and_its_copy_run_the_same_kernels():
     shape = model.new_plan(x, autotune=False)
     c = shape.run().clone()
     torch.cuda.synchronize()
-    assert float((a[..., 5:] - c[..., 5:]).abs().max()) < 2e-3
-    assert float((a[..., :4] - c[..., :4]).abs().max()) < 0.5           # pixels
+    assert float((a[..., 5:] - c[..., 5:]).abs().max()) < 5e-3          # (a sanity bound, not a parity claim: other kernels, other
+    assert float((a[..., :4] - c[..., :4]).abs().max()) < 1.0           #  fp32 summation orders; parity is against the oracle elsewhere)
     other = model.new_plan(x[:4].contiguous(), autotune=False)
     with pytest.raises(RuntimeError, match="differs in shape|differ in length"):
         other.copy_variants_from(tuned)

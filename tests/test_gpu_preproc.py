@@ -55,9 +55,11 @@ def test_process_image_planes_feed_the_uint8_image_conv():
     model = build_model(cfg, 80, "cpu").eval()
     model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=0))
     model = model.to(DEV).half()
-    det_u8 = model(planes[None].contiguous())[0].clone()
-    det_f16 = model(half[None].contiguous())[0].clone()
+    # (shape-derived kernel tables: two plans that are each autotuned on their own may pick different conv variants - different fp32
+    # summation orders, up to 3e-3 apart on this model, which made this test fail one run in seven in round 5; with the same
+    # kernels the two input forms differ by nothing but the stem's load path)
+    det_u8 = model.compile(planes[None].contiguous(), autotune=False).run().clone()
+    det_f16 = model.compile(half[None].contiguous(), autotune=False).run().clone()
     torch.cuda.synchronize()
-    # (two plans, each autotuned on its own: conv variants - i.e. fp32 summation orders - may differ; the image bytes are equal)
     err = ((det_u8 - det_f16).abs() / det_f16.abs().clamp(min=1.0)).max()
     assert float(err) < 2e-3, float(err)

@@ -24,7 +24,7 @@ def classify(name):
     m = re.search(r"conv_mfma_persist_kernel<\d+, \d+, (\d)>", name)
     if m:
         return "conv3x3s%s" % m.group(1)
-    m = re.search(r"conv_mfma_kernel<\d+, \d+, (\d), (\d)>", name)
+    m = re.search(r"conv_mfma_kernel<\d+, \d+, (\d), (\d)(?:, -?\d+)?>", name)   # (<CF, PF, KS, ST[, ACT]>)
     if m:
         return "conv%sx%ss%s" % (m.group(1), m.group(1), m.group(2))
     for key, cls in (("stem_", "stem"), ("head_decode", "decode"), ("nms_", "nms"), ("sppf", "sppf")):

@@ -21,7 +21,7 @@ def classify(name):
     m = re.search(r"conv_mfma_pipe_kernel<\d+, \d+, \d+, \d+, (\d)", name)
     if m:
         return "conv3x3s%s" % m.group(1)
-    m = re.search(r"conv_mfma_kernel<\d+, \d+, (\d), (\d)>", name)
+    m = re.search(r"conv_mfma_kernel<\d+, \d+, (\d), (\d)(?:, -?\d+)?>", name)   # (<CF, PF, KS, ST[, ACT]>)
     if m:
         return "conv%sx%ss%s" % (m.group(1), m.group(1), m.group(2))
     for key, cls in (("fused_pw_s2", "pw_s2"), ("fused_stem_s2", "stem_s2"), ("stem_", "stem"), ("pred_decode", "pred_decode"), ("head_decode", "decode"),

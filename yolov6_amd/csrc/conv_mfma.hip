@@ -1120,6 +1120,7 @@ int launch_one(const Launch& L, hipStream_t s) {
         static const bool general = getenv("Y6_CONV_GENERAL_EPI") != nullptr;
         if (!general && L.k.act == Y6_ACT_RELU) return launch_one<CF, PF, 1, 1, Y6_ACT_RELU>(L, s);
         if (!general && L.k.act == Y6_ACT_SILU) return launch_one<CF, PF, 1, 1, Y6_ACT_SILU>(L, s);
+        if (!general && L.k.act == Y6_ACT_NONE) return launch_one<CF, PF, 1, 1, Y6_ACT_NONE>(L, s);   // (the training-form graph's 1x1 convs)
     }
     // dynamic LDS above 64 KiB (stride-2 halo + a 3-slot ring of 4-fragment weight images) must be
     // opted into once per kernel; gfx950 has 160 KiB per CU

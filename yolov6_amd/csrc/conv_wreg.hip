@@ -111,10 +111,11 @@ constexpr int kWregProbe = Y6_WREG_PROBE;
 // instead of 7 200 for the first item's epilogue).  This form's epilogue is ~3 KB and the function ~40 KB instead of 110-180 KB.
 // Same arithmetic in the same order: bit-identical outputs (tests/test_gpu_ops.py; A/B switch Y6_WREG_GENERAL_EPI=1).
 // EPI: 0 = the general form, 1 = bias + ReLU only (RELU_ONLY above), 2 = bias + SiLU only (the head's cls / reg convs,
-// effidehead.py:172-181: ConvBNSiLU - 3 launches of YOLOv6-S, one of them 108 us cold against 55 warm on the general form).
+// effidehead.py:172-181: ConvBNSiLU - 3 launches of YOLOv6-S, one of them 108 us cold against 55 warm on the general form),
+// 3 = bias only (the convs of the training-form graph: their BatchNorm is a kernel of its own).
 template <int PF, int WC, int WP, int ST, bool I8, int EPI = 0>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
-    constexpr bool RELU_ONLY = EPI == 1, SILU_ONLY = EPI == 2, SPECIAL = EPI != 0;
+    constexpr bool RELU_ONLY = EPI == 1, SILU_ONLY = EPI == 2, SPECIAL = EPI != 0;   // EPI == 3: bias only (the training step's convs: BatchNorm follows)
     constexpr int kMaxP = ST == 2 ? kMaxP2 : kMaxP1;   // halo requests per wave and stage
     constexpr int ES = I8 ? 1 : 2;                     // bytes per input element
     typedef typename std::conditional<I8, i32x16_t, f32x16_t>::type acc_t;
@@ -579,7 +580,7 @@ static int wreg_special_epilogue(const ConvKArgs& k) {
     if (off || k.pscale != nullptr || k.res != nullptr || k.up != 0 || k.out == nullptr || !k.vec16_ok ||
         (size_t)k.B * k.Ho * k.Wo * k.out_cs * 2 >= 0xe0000000ull)
         return 0;
-    return k.act == Y6_ACT_RELU ? 1 : (k.act == Y6_ACT_SILU ? 2 : 0);
+    return k.act == Y6_ACT_RELU ? 1 : (k.act == Y6_ACT_SILU ? 2 : (k.act == Y6_ACT_NONE ? 3 : 0));
 }
 
 template <int PF, int WC, int WP, int ST, bool I8 = false, int EPI = 0>
@@ -588,6 +589,7 @@ int launch_wreg(const Launch& L, hipStream_t s) {
         switch (wreg_special_epilogue(L.k)) {
             case 1: return launch_wreg<PF, WC, WP, ST, false, 1>(L, s);
             case 2: return launch_wreg<PF, WC, WP, ST, false, 2>(L, s);
+            case 3: return launch_wreg<PF, WC, WP, ST, false, 3>(L, s);
         }
     }
     auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8, EPI>;
