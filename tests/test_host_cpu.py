@@ -803,6 +803,55 @@ def test_wreg_kernels_keep_their_asm_loaded_registers():
         assert meta.get("private_segment_fixed_size", -1) == 0, (name, meta)
 
 
+def _device_function_sizes(lib_path):
+    """(mangled kernel name -> bytes of machine code) from the symbol tables of the gfx950 code objects embedded in the library."""
+    import struct
+    import subprocess
+    import tempfile
+    blob = open(lib_path, "rb").read()
+    out = {}
+    pos = blob.find(b"\x7fELF", 1)
+    while pos >= 0:
+        e_shoff, = struct.unpack_from("<Q", blob, pos + 0x28)
+        e_shentsize, e_shnum = struct.unpack_from("<HH", blob, pos + 0x3A)
+        e_machine, = struct.unpack_from("<H", blob, pos + 0x12)
+        size = e_shoff + e_shentsize * e_shnum
+        if e_machine == 224 and size > 0:
+            with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                f.write(blob[pos:pos + size])
+                f.flush()
+                txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-s", "--wide", f.name], capture_output=True, text=True).stdout
+            for line in txt.splitlines():
+                p = line.split()
+                if len(p) >= 8 and p[3] == "FUNC":
+                    out[p[7]] = int(p[2])
+        pos = blob.find(b"\x7fELF", pos + 4)
+    return out
+
+
+def test_specialised_epilogue_kernels_stay_small():
+    """code that runs once per work item is executed at instruction-fetch latency whenever the function's lines have
+    left the 64 KB instruction cache (a conv launch lost 20-35 us to it after two or three other kernels).  The forms that compile one
+    epilogue alone - conv3x3_wreg_kernel<..., EPI = 1 | 2 | 3> and the activation-specialised per-tap 1x1 kernels - are what keeps a
+    step's kernel functions resident together: their machine code must stay a fraction of the general forms' (a change that inlines
+    a second epilogue into them shows up here, on the CPU, not as 2 % on a GPU box)."""
+    import os
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not present")
+    from yolov6_amd import _lib
+    sizes = _device_function_sizes(_lib.LIB_PATH)
+    wreg = {k: v for k, v in sizes.items() if "conv3x3_wreg_kernel" in k}
+    special = {k: v for k, v in wreg.items() if k.endswith(("Lb0ELi1EEEvNS_9ConvKArgsE", "Lb0ELi2EEEvNS_9ConvKArgsE", "Lb0ELi3EEEvNS_9ConvKArgsE"))}
+    general = {k: v for k, v in wreg.items() if k.endswith("Lb0ELi0EEEvNS_9ConvKArgsE")}
+    assert len(special) >= 18 and len(general) >= 6, (len(special), len(general), sorted(wreg)[:3])
+    assert max(special.values()) <= 32 * 1024, max(special.items(), key=lambda kv: kv[1])
+    assert min(general.values()) >= 2 * max(special.values())          # (what they replace: 89-180 KB)
+    one = {k: v for k, v in sizes.items() if "conv_mfma_kernelILi2ELi1ELi1ELi1E" in k}      # <2, 1, 1, 1, ACT>: the 1x1 c2p1 tile
+    relu = [v for k, v in one.items() if "ELi1EEEvNS" in k[len("_ZN12_GLOBAL__N_116conv_mfma_kernelILi2ELi1ELi1ELi1"):]]
+    gen = [v for k, v in one.items() if "ELin1EEEvNS" in k]
+    assert relu and gen and relu[0] * 2 < gen[0], one
+
+
 @pytest.mark.parametrize("case,flags", [("tiny", {}), ("s_qa_tiny", {}), ("s_mbla_tiny", {}), ("tiny", {"fuse_ab": True}), ("m_tiny", {})])
 def test_backward_side_stream_contract_holds_on_every_training_graph(case, flags):
     """The backward plan runs its weight-gradient work (operand transposes, weight-gradient GEMMs, bias sums) on a side stream
