@@ -12,6 +12,10 @@ max_det 300; tools/eval.py:29-30, core/evaler.py:133).  Inputs are resident in H
 the timed region.  The path shards by independent images: each rank runs its own replica on
 its own batch, no data-path collective ("scaling": "weak").
 
+The measurement runs in a child process of this file (`supervise()` below): a child that a signal kills - the HIP runtime aborts the
+process on a GPU memory fault - is re-run once, and the line reports it (`supervisor`).  `value` is the throughput with
+`--inflight` (default 2) batches in flight; `sequential` in the same line is one batch at a time.
+
 Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline      the dominant kernel (3x3 stride-1 MFMA conv, 84 % of model FLOPs): algorithmic
                 FLOPs per step / its measured time per step (hipEvents between ops, recorded
