@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$PWD
 for c in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && timeout -k 5 420 rocprofv3 --kernel-trace --output-format csv --pmc $c -d "$OUT/$c" -o t -- python "$R/bench.py" --mode train --batch $BATCH --steps 2 --warmup 1 --no-autotune > "$OUT/$c.json" 2> "$OUT/$c.err" )
+  ( cd /tmp && timeout -k 5 420 rocprofv3 --kernel-trace --output-format csv --pmc $c -d "$OUT/$c" -o t -- python "$R/bench.py" --no-supervisor --mode train --batch $BATCH --steps 2 --warmup 1 --no-autotune > "$OUT/$c.json" 2> "$OUT/$c.err" )
   echo "$c rc=$?"
   find "$OUT/$c" -name "*kernel_trace.csv" -delete
 done
