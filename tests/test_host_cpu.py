@@ -946,3 +946,16 @@ def test_bench_supervisor_reruns_a_child_killed_by_a_signal_once(tmp_path):
     # --no-supervisor: the measurement runs in the launched process itself
     r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-supervisor"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "supervisor" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_y6_autotune_env_switch_is_read_by_compile(monkeypatch):
+    """Y6_AUTOTUNE=0 turns every `compile()` - `model(x)` included - into the shape-derived (reproducible) form.  Host logic only: the
+    switch must reach the point where the plan cache key is formed (a CPU tensor stops compile() right after it)."""
+    import inspect
+    from yolov6_amd.layers.common import HipModule
+    src = inspect.getsource(HipModule.compile)
+    assert src.index('Y6_AUTOTUNE') < src.index('sig = ('), "the switch must be applied before the cache signature is formed"
+    m = HipModule()
+    monkeypatch.setenv("Y6_AUTOTUNE", "0")
+    with pytest.raises(RuntimeError, match="needs ROCm tensors"):
+        m.compile(torch.zeros(1, 3, 8, 8))

@@ -157,7 +157,15 @@ class HipModule(nn.Module):
             [self._finish_outputs(pb, o, dtype) for o in outs]
 
     def compile(self, *inputs, autotune=True):
-        """Build (or fetch) the plan for these input shapes and bind it to these tensors."""
+        """Build (or fetch) the plan for these input shapes and bind it to these tensors.
+
+        autotune=True times kernel variants in THIS process (per layer, then the whole step: include/yolov6_hip.h y6_plan_autotune) -
+        two processes may settle on different kernels, i.e. different fp32 summation orders and different low bits.  autotune=False
+        (or the environment variable Y6_AUTOTUNE=0 for every plan, `model(x)` included) takes the kernel of every layer from its
+        shape: the same bits in every process, within a few per cent of the tuned plan's speed."""
+        import os
+        if os.environ.get("Y6_AUTOTUNE", "1") == "0":
+            autotune = False
         x = inputs[0] if len(inputs) == 1 else list(inputs)
         flat = _flatten(x)
         for t in flat:
