@@ -53,6 +53,7 @@ def supervise():
             d = json.loads(lines[js[-1]])
             d["supervisor"] = {"attempts": attempt, "failed_attempts": failures,
                                "what": "the measurement ran in a child process; a child killed by a signal is re-run once"}
+            d["failed_attempts"] = failures        # top level: a retried run must not pass for a clean one (tests fail on it)
             for i, ln in enumerate(lines):
                 if i != js[-1]:
                     print(ln)
@@ -90,8 +91,9 @@ def stage(name):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
-                    help="infer: BASELINE configs[1] (the headline metric); train: configs[2], the b64/GPU training step")
+    ap.add_argument("--mode", choices=("infer", "train", "latency"), default="infer",
+                    help="infer: BASELINE configs[1] (the headline metric); train: configs[2], the b64/GPU training step; "
+                         "latency: configs[0]'s per-image call (model(x) + NMS 0.4 / 0.45 / max_det 1000, one image at a time) on the GPU path")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # 200 x ~3 ms: a timed region of >= 0.6 s (20 steps gave +-10 %)
     ap.add_argument("--warmup", type=int, default=10)
@@ -104,7 +106,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="no GPU needed: only the `cpu_baseline` object of the headline workload "
                     "(the reference's own modules when /root/reference exists, else the oracle port); --cpu-batch 32 is BASELINE.md's b32")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="images in the CPU-baseline sample (1 warm-up + 3 timed passes of forward + NMS + TAL)")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="images in the CPU-baseline sample (1 warm-up + 3 timed passes of forward + NMS + TAL)")
     ap.add_argument("--profile-out", default=None, help="write the per-op table (JSON) here")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--train-autotune", action="store_true",
@@ -115,6 +117,7 @@ def parse():
                     "signature API: model(x) + non_max_suppression(); 0 disables")
     ap.add_argument("--no-verify", action="store_true", help="skip the NMS-vs-oracle self check (outside the timed region)")
     ap.add_argument("--no-train-sub", action="store_true", help="skip the ten training steps reported under `train` next to the headline")
+    ap.add_argument("--no-config-subs", action="store_true", help="skip the `l6` / `int8` / `n_b1` sub-benches (BASELINE configs[3], [4], [0]) next to the headline")
     ap.add_argument("--windows", type=int, default=3, help="timed windows of --steps steps each; the reported value is the median window")
     ap.add_argument("--no-fuse-candidates", action="store_true",
                     help="A/B: NMS selects its candidates itself (re-reads the prediction tensor) instead of the decode launch doing it")
@@ -244,18 +247,53 @@ def classify(row):
     return row["kind"]
 
 
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def reference_container():
+    """The reference's OWN modules timed on the build container's 8 cores at b32 (the GPU box holds no reference checkout and can
+    only time the oracle port): the newest committed profiles/*/cpu_baseline_reference_b32_container.json, so that the line never
+    shows only the stand-in."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "cpu_baseline_reference_b32_container.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            c = json.load(f)["cpu_baseline"]
+        n = c["tal_s"]["images"]
+        return {"kind": "reference", "cores": c["cores"], "images": n, "forward_img_s": round(n / c["forward_s"]["median"], 2),
+                "forward_nms_img_s": c["value"], "forward_s": c["forward_s"], "nms_s": c["nms_s"], "tal_s": c["tal_s"],
+                "note": "measured in the build container (8 cores), NOT in this run; the reference's NMS calls torchvision.ops.nms, "
+                        "served there by the numpy stand-in without early stop (10 s per batch) - compare forward_img_s",
+                "source": os.path.relpath(files[-1], ROOT)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
+
+
 def cpu_baseline(args, cfg, sd_train, shift):
     """Oracle port of the same workload on the host cores (one warm-up + three timed passes, the three parts of
-    the path timed separately, min and median): deploy-form fp32 forward and numpy NMS of `--cpu-batch` images, and the numpy
-    task-aligned assigner on a training-sized problem (the same number of images, 8400 anchors, 80 classes, up to 40 boxes)."""
+    the path timed separately, min and median): deploy-form fp32 forward and numpy NMS of `--cpu-batch` images (default 32 = the
+    GPU batch), and the numpy task-aligned assigner on a training-sized problem (the same number of images, 8400 anchors, 80
+    classes, up to 40 boxes).  Threads: min(physical cores, 32) - torch's default of one thread per LOGICAL core (128 on the GPU
+    boxes) ran the forward 2.4x slower than the reference's modules on 8 cores."""
     import statistics
     import numpy as np
     from oracle import nms_oracle, ref_cpu_baseline, synth, tal_oracle
     from oracle.model_oracle import Oracle, deploy_state_dict
+    threads = max(1, min(physical_cores(), 32))
+    torch.set_num_threads(threads)
     if ref_cpu_baseline.available() and args.model in ("yolov6s", "yolov6n", "yolov6l6", "yolov6s_qa"):
         # the reference checkout is on this machine (the build container): time ITS modules (BASELINE.md 2), kind "reference"
         return ref_cpu_baseline.time_reference(args.model, args.size, args.cpu_batch, sd_train, shift, CONF, IOU, MAX_DET)
-    threads = torch.get_num_threads()
     sd = deploy_state_dict(cfg, sd_train, 80)
     for k in list(sd):
         if "cls_preds" in k and k.endswith(".bias"):
@@ -268,6 +306,7 @@ def cpu_baseline(args, cfg, sd_train, shift):
     tal_in = synth.synth_tal_inputs(n, fs, st, 80, 40, seed=9, n_valid=[int(v) for v in g.integers(1, 41, n)], img=args.size)
     tal_np = [tal_in[k].numpy() for k in ("pd_scores", "pd_bboxes", "anc_points", "gt_labels", "gt_bboxes", "mask_gt")]
     fwd, nms, tal = [], [], []
+    t_start = time.perf_counter()
     with torch.no_grad():
         for rep in range(4):                        # pass 0 warms caches / thread pools and is not counted
             t0 = time.perf_counter()
@@ -281,15 +320,20 @@ def cpu_baseline(args, cfg, sd_train, shift):
                 fwd.append(t1 - t0)
                 nms.append(t2 - t1)
                 tal.append(t3 - t2)
+            if rep >= 2 and time.perf_counter() - t_start > 45.0:     # bounded: a slow host stops after two timed passes
+                break
     step = [a + b for a, b in zip(fwd, nms)]        # the bench's step: forward + NMS
     med = statistics.median
     return dict(value=round(n / med(step), 3), unit="images/sec", cores=threads, kind="port",
                 value_best=round(n / min(step), 3),
+                forward_img_s=round(n / med(fwd), 3), forward_nms_img_s=round(n / med(step), 3),
                 forward_s={"min": round(min(fwd), 3), "median": round(med(fwd), 3)},
                 nms_s={"min": round(min(nms), 3), "median": round(med(nms), 3)},
                 tal_s={"min": round(min(tal), 3), "median": round(med(tal), 3), "images": n, "anchors": 8400, "max_boxes": 40},
                 sample=f"{n} images {args.size}x{args.size}: fp32 torch-CPU oracle forward + numpy NMS (value = images / median "
-                       f"(forward + NMS)), numpy task-aligned assigner on {n} images; 1 warm-up + 3 timed passes",
+                       f"(forward + NMS)), numpy task-aligned assigner on {n} images; 1 warm-up + {len(fwd)} timed passes, "
+                       f"{threads} threads (min(physical cores, 32))",
+                reference_container=reference_container(),
                 torch=torch.__version__)
 
 
@@ -564,21 +608,82 @@ def mock_infer(args, rep):
     rep.close()
 
 
+def _child_line(argv, timeout):
+    """Run this file again with `argv` in a child process (its own supervisor included) and return its JSON line."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError((r.stderr or r.stdout)[-400:])
+    return json.loads(line[-1])
+
+
 def train_sub_bench():
     """BASELINE configs[2] beside the headline (N = 1 only): ten timed steps of `--mode train` (YOLOv6-S 640^2 b64) in a child
     process, summarised - so that the run the driver times also carries a training-step figure.  Never fails the headline."""
-    import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--mode", "train", "--steps", "10", "--warmup", "3"],
-                           capture_output=True, text=True, timeout=420)
-        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not line:
-            return {"error": (r.stderr or r.stdout)[-400:]}
-        d = json.loads(line[-1])
+        d = _child_line(["--mode", "train", "--steps", "10", "--warmup", "3"], 420)
         return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
                 "ms_per_step": d["ms_per_step"], "mfma_frac": d["roofline"]["frac"], "hbm_frac": d["roofline_hbm"]["frac"],
-                "loss_first": d["loss"]["first"], "loss_last": d["loss"]["last"], "variants": d["variants"], "memory_gb": d["memory_gb"]}
+                "wgrad": d["roofline"].get("wgrad"),
+                "loss_first": d["loss"]["first"], "loss_last": d["loss"]["last"], "variants": d["variants"], "memory_gb": d["memory_gb"],
+                "failed_attempts": d.get("failed_attempts", [])}
     except Exception as e:      # noqa: BLE001 - a reported sub-bench, not the headline
+        return {"error": repr(e)[:400]}
+
+
+def infer_sub_bench(extra, steps=40, warmup=5):
+    """BASELINE configs[3] (YOLOv6-L6 1280^2 b8) and configs[4] (YOLOv6-S-QA int8) beside the headline, the way `train` is: a few
+    seconds of the same measurement loop in a child process, summarised with its own roofline."""
+    try:
+        d = _child_line(extra + ["--steps", str(steps), "--warmup", str(warmup), "--windows", "1", "--no-cpu-baseline", "--no-train-sub",
+                                 "--no-config-subs", "--dropin-steps", "0"], 600)
+        rf = d["roofline"]
+        return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"],
+                "ms_per_step": d["ms_per_step"], "inflight": d["inflight"], "sequential": (d.get("sequential") or {}).get("value"),
+                "dtype": d["dtype"], "workload": d["config"]["workload"][:160],
+                "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "gflop_per_step", "ms_per_step")},
+                "forward_ms": d["forward"]["ms"], "nms_ms": d["nms"]["ms"], "self_check": d["self_check"],
+                "failed_attempts": d.get("failed_attempts", [])}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:400]}
+
+
+def latency_main(args):
+    """BASELINE configs[0] on the GPU path: what `tools/infer.py` does per image (core/inferer.py:70-159) - `model(img)` of ONE
+    image, then `non_max_suppression(pred, 0.4, 0.45, classes, agnostic, max_det=1000)`, the host reading every result before the
+    next image - through the reference-signature API, one image at a time.  Latency per image (host-timed, synchronised per
+    image as the Inferer is), not a throughput figure."""
+    import statistics
+    from yolov6_amd.utils.nms import non_max_suppression
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    cfg, sd_train, model, x = build_model_and_input(args, device)
+    calibrate_head_bias(model, x)
+    lat = []
+    with torch.no_grad():
+        for i in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pred = model(x)[0]
+            det = non_max_suppression(pred, 0.4, 0.45, None, False, max_det=1000)[0]
+            n = int(det.shape[0])               # the Inferer reads the rows on the host
+            lat.append(time.perf_counter() - t0)
+    lat = sorted(lat[args.warmup:])
+    res = {"metric": f"latency per image ({args.model} {args.size}x{args.size} b{args.batch}, model(x) + non_max_suppression(0.4, 0.45, max_det=1000), "
+                     "host-synchronised per image)",
+           "value": round(statistics.median(lat) * 1e3, 4), "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "p10_ms": round(lat[len(lat) // 10] * 1e3, 4), "p90_ms": round(lat[(len(lat) * 9) // 10] * 1e3, 4),
+           "images_per_sec": round(args.batch / statistics.median(lat), 1), "kept_last": n, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": f"{args.model} {args.size}x{args.size} b{args.batch} fp16, reference-signature API, shape-derived kernels (the default of model(x))"}}
+    print(json.dumps(res), flush=True)
+
+
+def latency_sub_bench():
+    try:
+        d = _child_line(["--mode", "latency", "--model", "yolov6n", "--batch", "1", "--steps", "200", "--warmup", "20"], 300)
+        return {k: d[k] for k in ("metric", "value", "unit", "p10_ms", "p90_ms", "images_per_sec", "steps")}
+    except Exception as e:      # noqa: BLE001
         return {"error": repr(e)[:400]}
 
 
@@ -602,6 +707,8 @@ def main():
         sys.exit(spawn_ranks(args))
     if args.mode == "train":
         return train_main(args)
+    if args.mode == "latency":
+        return latency_main(args)
     from yolov6_amd.parallel import Replicas
     rep = Replicas()                     # RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment
     rank, world = rep.rank, rep.world
@@ -724,24 +831,36 @@ def main():
     # the same step through the reference-signature API (models/yolo.py:33-41 + utils/nms.py:31-105): Model.forward clones
     # the [B,A,85] fp32 tensor (91 MB at b32) and non_max_suppression syncs once to slice the per-image lists
     stage("verify_nms")
-    dropin = None
+    dropin = dropin_tuned = None
     if args.dropin_steps > 0:
         from yolov6_amd.utils.nms import non_max_suppression
-        for _ in range(3):
-            d2, _ = model(x)
-            non_max_suppression(d2, CONF, IOU, multi_label=True, max_det=MAX_DET)
-        rep.barrier()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.dropin_steps):
-            d2, _ = model(x)
-            non_max_suppression(d2, CONF, IOU, multi_label=True, max_det=MAX_DET)
-        torch.cuda.synchronize()
-        rep.barrier()
-        el2 = rep.max_over_ranks(time.perf_counter() - t1)
-        dropin = dict(api="model(x) + non_max_suppression(det, 0.03, 0.65, multi_label=True, max_det=300)", steps=args.dropin_steps,
-                      ms_per_step=round(el2 / args.dropin_steps * 1e3, 4),
-                      value=round(rep.throughput(args.batch, args.dropin_steps, el2), 2), unit="images/sec")
+
+        def dropin_run(what):
+            for _ in range(3):
+                d2, _ = model(x)
+                non_max_suppression(d2, CONF, IOU, multi_label=True, max_det=MAX_DET)
+            rep.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.dropin_steps):
+                d2, _ = model(x)
+                non_max_suppression(d2, CONF, IOU, multi_label=True, max_det=MAX_DET)
+            torch.cuda.synchronize()
+            rep.barrier()
+            el2 = rep.max_over_ranks(time.perf_counter() - t1)
+            return dict(api="model(x) + non_max_suppression(det, 0.03, 0.65, multi_label=True, max_det=300)", kernels=what,
+                        steps=args.dropin_steps, ms_per_step=round(el2 / args.dropin_steps * 1e3, 4),
+                        value=round(rep.throughput(args.batch, args.dropin_steps, el2), 2), unit="images/sec")
+
+        # the default of model(x): kernels from the layer shapes (the same bits in every process) ...
+        dropin = dropin_run("shape-derived (the default of model(x): reproducible bits)")
+        # ... and opted in to the timed table (Y6_AUTOTUNE=1: replayed from the on-disk table plan 0 just wrote - no re-timing)
+        if not args.no_autotune and os.environ.get("Y6_AUTOTUNE") is None:
+            os.environ["Y6_AUTOTUNE"] = "1"
+            try:
+                dropin_tuned = dropin_run("timed (Y6_AUTOTUNE=1, table replayed from disk)")
+            finally:
+                os.environ.pop("Y6_AUTOTUNE", None)
 
     if rank == 0:
         by_class = {}
@@ -815,6 +934,7 @@ def main():
             "nms": {"ms": round(nms_ms, 4), "mean_kept": round(kept, 1),
                     "candidates_from": "decode launch (y6_nms_sink)" if cand is not None else "nms first stage"},
             "dropin_api": dropin,
+            "dropin_api_tuned": dropin_tuned,
             "self_check": {"nms_equals_oracle_images": verified},
             # two-stream schedule of the un-instrumented steps (yolov6_amd/schedule.py; the event-sampled steps run in plan
             # order on one stream, so the per-kernel times above are kernels running alone)
@@ -827,6 +947,12 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args, cfg, sd_train, shift)
         if world == 1 and headline and not args.no_train_sub:
             res["train"] = train_sub_bench()
+        if world == 1 and headline and not args.no_config_subs and not args.int8:
+            # the other BASELINE configs, each a few seconds in a child process of its own (the headline's buffers are released first)
+            res["l6"] = infer_sub_bench(["--model", "yolov6l6", "--size", "1280", "--batch", "8"], steps=30)
+            res["int8"] = infer_sub_bench(["--model", "yolov6s_qa", "--int8"], steps=40)
+            res["int8_fp16_same_model"] = infer_sub_bench(["--model", "yolov6s_qa"], steps=40)
+            res["n_b1"] = latency_sub_bench()
         if args.profile_out:
             os.makedirs(os.path.dirname(os.path.abspath(args.profile_out)), exist_ok=True)
             with open(args.profile_out, "w") as f:

@@ -948,14 +948,78 @@ def test_bench_supervisor_reruns_a_child_killed_by_a_signal_once(tmp_path):
     assert r.returncode == 0 and "supervisor" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-def test_y6_autotune_env_switch_is_read_by_compile(monkeypatch):
-    """Y6_AUTOTUNE=0 turns every `compile()` - `model(x)` included - into the shape-derived (reproducible) form.  Host logic only: the
-    switch must reach the point where the plan cache key is formed (a CPU tensor stops compile() right after it)."""
+def test_autotune_resolution_default_is_reproducible_and_env_reaches_every_plan(monkeypatch, tmp_path):
+    """`model(x)` / compile() / new_plan() without an argument take their kernels from the layer shapes (the same bits in every
+    process); Y6_AUTOTUNE=1 opts the default in, autotune=True asks explicitly, Y6_AUTOTUNE=0 forces shape-derived
+    kernels for EVERY plan - new_plan() / InflightRunner included.  Host logic only (a CPU tensor stops compile())."""
     import inspect
-    from yolov6_amd.layers.common import HipModule
-    src = inspect.getsource(HipModule.compile)
-    assert src.index('Y6_AUTOTUNE') < src.index('sig = ('), "the switch must be applied before the cache signature is formed"
-    m = HipModule()
+    from yolov6_amd.layers import common
+    from yolov6_amd.layers.common import HipModule, resolve_autotune
+    monkeypatch.delenv("Y6_AUTOTUNE", raising=False)
+    assert resolve_autotune(None) is False and resolve_autotune(False) is False and resolve_autotune(True) is True
+    monkeypatch.setenv("Y6_AUTOTUNE", "1")
+    assert resolve_autotune(None) is True and resolve_autotune(False) is False and resolve_autotune(True) is True
     monkeypatch.setenv("Y6_AUTOTUNE", "0")
+    assert resolve_autotune(None) is False and resolve_autotune(True) is False
+    src = inspect.getsource(HipModule.compile)
+    assert src.index("resolve_autotune") < src.index("sig = ("), "the switch must be applied before the cache signature is formed"
+    # every plan is lowered by _lower_plan: compile() and new_plan() both go through the resolution there
+    assert "resolve_autotune" in inspect.getsource(HipModule._lower_plan)
+    assert inspect.signature(HipModule.compile).parameters["autotune"].default is None
+    assert inspect.signature(HipModule.new_plan).parameters["autotune"].default is None
+    m = HipModule()
     with pytest.raises(RuntimeError, match="needs ROCm tensors"):
         m.compile(torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError, match="needs ROCm tensors"):
+        m.new_plan(torch.zeros(1, 3, 8, 8))
+    # the on-disk table: a caller-chosen file wins, "" disables
+    monkeypatch.setattr(common, "_cache_path_set", [False])
+    monkeypatch.setenv("Y6_AUTOTUNE_CACHE", str(tmp_path / "t.txt"))
+    assert common.autotune_cache_path() == str(tmp_path / "t.txt")
+    monkeypatch.setattr(common, "_cache_path_set", [False])
+    monkeypatch.setenv("Y6_AUTOTUNE_CACHE", "")
+    assert common.autotune_cache_path() is None
+
+
+def test_plan_is_current_and_inflight_guard_see_native_updates():
+    """Native kernels (fused SGD, running-statistics update, EMA) bump a process-wide generation instead of `tensor._version`;
+    `plan_is_current` and InflightRunner.submit's cheap check compare it."""
+    import inspect
+    from types import SimpleNamespace
+    from yolov6_amd import pipeline
+    from yolov6_amd.layers import common
+    from yolov6_amd.layers.common import HipModule, _params_version
+    m = HipModule()
+    m.w = torch.nn.Parameter(torch.zeros(3))
+    plan = SimpleNamespace(params_version=_params_version(m), quant_key=None,
+                           generations=(common._NATIVE_GENERATION[0], common._STRUCTURE_GENERATION[0]))
+    assert m.plan_is_current(plan)
+    common.bump_native_generation()
+    assert not m.plan_is_current(plan), "a native parameter update must make the plan stale"
+    plan.generations = (common._NATIVE_GENERATION[0], common._STRUCTURE_GENERATION[0])
+    assert m.plan_is_current(plan)
+    m.invalidate_plans()
+    assert not m.plan_is_current(plan), "invalidate_plans() / _apply must make the plan stale"
+    src = inspect.getsource(pipeline.InflightRunner.submit)
+    assert "_NATIVE_GENERATION" in src and "_STRUCTURE_GENERATION" in src and "_holders" in src
+
+
+def test_result_ring_slots_count_views_in_every_grad_mode():
+    """The result ring hands out a slot again only when nobody holds it or a view of it; inference tensors do not count views, so
+    slots are allocated outside inference mode and every slot is probed itself."""
+    from yolov6_amd.models.yolo import _ResultRing
+    like = torch.empty(2, 4)
+    for ctx in (torch.enable_grad, torch.no_grad, torch.inference_mode):
+        with ctx():
+            ring = _ResultRing(like, 2)
+            assert all(not t.is_inference() and _ResultRing.counts_views(t) for t in ring.slots)
+            a = ring.next()
+            boxes = a[..., :2]
+            ida = id(a)
+            del a
+            b = ring.next()
+            c = ring.next()           # position of `a` again: still held through `boxes` -> a fresh tensor, never the old one
+            assert id(c) != ida and c.data_ptr() != boxes.data_ptr()
+            assert not c.is_inference()
+    with torch.inference_mode():
+        assert not _ResultRing.counts_views(torch.empty(3))      # what the per-slot probe exists for

@@ -1027,6 +1027,18 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
         const char* mode = getenv("Y6_AUTOTUNE_MODE");
         bool any = false;
         for (size_t i = 0; i < p->ops.size(); ++i) any = any || measured[i];
+        // The pass replays EVERY op of the plan a few hundred times: only for plans made of pure ops.  A training graph's
+        // BatchNorm statistics op moves running statistics, its weight-gradient ops accumulate: such plans keep
+        // the per-layer table unless the caller asks (Y6_AUTOTUNE_MODE=step).
+        bool stateful = false;
+        for (const Op& o : p->ops)
+            if (o.kind == Y6_OP_GENERIC) {
+                const int t = o.gtag;
+                if (!(t == Y6_TOP_CONV_I8 || t == Y6_TOP_ABSMAX || t == Y6_TOP_QUANT || t == Y6_TOP_PRED_DECODE || t == Y6_TOP_PW_S2 ||
+                      t == Y6_TOP_STEM_S2))
+                    stateful = true;
+            }
+        if (stateful && !(mode && strcmp(mode, "step") == 0)) any = false;
         if (any && !(mode && strcmp(mode, "layer") == 0)) {
             const size_t n = p->ops.size();
             hipEvent_t e0, e1;
@@ -1094,6 +1106,11 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
                 for (int v = 1; v < nv && rc_step == Y6_OK; ++v) {
                     if (v == cur[g[0]] || row[v] > 1e29f || excluded[v]) continue;
                     if (row[v] > iso_best * 1.3f && v != shape_tab[g[0]] && v != layer_tab[g[0]]) continue;
+                    // the signature leaves out the channel offset, the pointer alignment and the packed-weight flag that
+                    // y6_conv_variant_supports tests: every member of the group must be able to run the trial variant
+                    bool all_ok = true;
+                    for (size_t i : g) all_ok = all_ok && y6_conv_variant_supports(&p->ops[i].conv, v);
+                    if (!all_ok) continue;
                     const int old = cur[g[0]];
                     for (size_t i : g) p->ops[i].conv.variant = v;
                     const float t = step_ms(5);
@@ -1112,6 +1129,7 @@ extern "C" int y6_plan_autotune(y6_plan* p, void* stream, int iters) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             if (rc_step) {
+                apply(cur);        // never leave a trial variant behind
                 if (logf) fclose(logf);
                 return rc_step;
             }

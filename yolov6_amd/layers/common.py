@@ -14,6 +14,8 @@ torch parameters (checkpoints / state_dicts stay interchangeable); packed MFMA w
 derived caches inside the plan.  There is no aten fallback: CPU tensors, training-mode
 BatchNorm and grouped convs raise.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -80,6 +82,48 @@ _STRUCTURE_GENERATION = [0]
 
 def bump_native_generation():
     _NATIVE_GENERATION[0] += 1
+
+
+def resolve_autotune(autotune):
+    """How a plan gets its conv kernels.  `None` (what `model(x)` passes): from the layer shapes - the same kernels, fp32
+    summation orders and output bits in every process (the drop-in contract: same outputs on the same inputs) - unless the
+    environment says Y6_AUTOTUNE=1.  `True`: timed in this process (y6_plan_autotune), the table kept on disk per (device, library
+    build) so that later processes on the machine replay it instead of re-timing (`autotune_cache_path`).  Y6_AUTOTUNE=0 forces
+    shape-derived kernels for EVERY plan - compile(), new_plan(), InflightRunner - whatever the caller passed."""
+    env = os.environ.get("Y6_AUTOTUNE")
+    if env == "0":
+        return False
+    if autotune is None:
+        return env == "1"
+    return bool(autotune)
+
+
+_cache_path_set = [False]
+
+
+def autotune_cache_path():
+    """Point the library's persistent kernel table (env Y6_AUTOTUNE_CACHE, read by y6_plan_autotune) at a per-(device, library
+    build) file unless the caller chose one: <Y6_CACHE_DIR | $XDG_CACHE_HOME/yolov6_amd | ~/.cache/yolov6_amd>/autotune-<device>-
+    <md5 of libyolov6_hip.so>.txt.  A line is `<layer signature> <variant name>`; the shapes are part of the signature.
+    Y6_AUTOTUNE_CACHE="" disables the file."""
+    if _cache_path_set[0] or "Y6_AUTOTUNE_CACHE" in os.environ:
+        if os.environ.get("Y6_AUTOTUNE_CACHE") == "":
+            os.environ.pop("Y6_AUTOTUNE_CACHE")
+            _cache_path_set[0] = True
+        return os.environ.get("Y6_AUTOTUNE_CACHE")
+    _cache_path_set[0] = True
+    try:
+        import hashlib
+        from .. import _lib
+        with open(_lib.LIB_PATH, "rb") as f:
+            h = hashlib.md5(f.read()).hexdigest()[:12]
+        dev = torch.cuda.get_device_name(torch.cuda.current_device()).replace(" ", "_").replace("/", "_")
+        root = os.environ.get("Y6_CACHE_DIR") or os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.expanduser("~/.cache"), "yolov6_amd")
+        os.makedirs(root, exist_ok=True)
+        os.environ["Y6_AUTOTUNE_CACHE"] = os.path.join(root, f"autotune-{dev}-{h}.txt")
+    except Exception:       # noqa: BLE001 - an unwritable home directory must not stop a forward; the plan is tuned without a file
+        return None
+    return os.environ["Y6_AUTOTUNE_CACHE"]
 
 
 def _params_version(module):
@@ -156,16 +200,15 @@ class HipModule(nn.Module):
         return type(outs)(self._finish_outputs(pb, o, dtype) for o in outs) if isinstance(outs, tuple) else \
             [self._finish_outputs(pb, o, dtype) for o in outs]
 
-    def compile(self, *inputs, autotune=True):
+    def compile(self, *inputs, autotune=None):
         """Build (or fetch) the plan for these input shapes and bind it to these tensors.
 
-        autotune=True times kernel variants in THIS process (per layer, then the whole step: include/yolov6_hip.h y6_plan_autotune) -
-        two processes may settle on different kernels, i.e. different fp32 summation orders and different low bits.  autotune=False
-        (or the environment variable Y6_AUTOTUNE=0 for every plan, `model(x)` included) takes the kernel of every layer from its
-        shape: the same bits in every process, within a few per cent of the tuned plan's speed."""
-        import os
-        if os.environ.get("Y6_AUTOTUNE", "1") == "0":
-            autotune = False
+        autotune=None (the default, what `model(x)` uses) and autotune=False take the kernel of every layer from its shape: the
+        same bits in every process, within a few per cent of a tuned plan's speed.  autotune=True (or Y6_AUTOTUNE=1 in the
+        environment for the default) times kernel variants (per layer, then the whole step: include/yolov6_hip.h
+        y6_plan_autotune) and keeps the table on disk per (device, library build): the first process on a machine tunes, the
+        others replay its choices (`resolve_autotune`, `autotune_cache_path`).  Y6_AUTOTUNE=0 forces shape-derived kernels."""
+        autotune = resolve_autotune(autotune)
         x = inputs[0] if len(inputs) == 1 else list(inputs)
         flat = _flatten(x)
         for t in flat:
@@ -207,6 +250,9 @@ class HipModule(nn.Module):
 
     def _lower_plan(self, x, flat, contig, quant, autotune, variants_from=None):
         self._check_runnable()
+        autotune = resolve_autotune(autotune)        # (new_plan() arrives here too: Y6_AUTOTUNE=0 reaches every plan)
+        if autotune and variants_from is None:
+            autotune_cache_path()
         if quant is not None:
             quant.decisions = None
             if quant.mode == "int8" and quant.twins:
@@ -227,9 +273,13 @@ class HipModule(nn.Module):
         plan.input_order = [next(j for j, c in enumerate(contig) if c is t) for t in plan.inputs]
         plan.params_version = _params_version(self)      # what the packed weights of this plan were derived from
         plan.quant_key = None if quant is None else quant.key()
+        # native kernels (fused SGD, running-statistics update, EMA) and .half() / .to() / invalidate_plans() move the weights
+        # without touching autograd's version counters: the two process-wide generations are part of what a plan was built from
+        plan.generations = (_NATIVE_GENERATION[0], _STRUCTURE_GENERATION[0])
+        plan.autotuned = bool(autotune)
         return plan
 
-    def new_plan(self, *inputs, autotune=True, variants_from=None):
+    def new_plan(self, *inputs, autotune=None, variants_from=None):
         """One MORE plan of this module for these inputs, outside the plan cache: its own activation buffers and its own packed
         copies of the weights, lowered from the SAME parameters, BatchNorm buffers and int8 calibration as the cached plan
         (pipeline.InflightRunner keeps N of them for N batches in flight).  The caller owns it; `plan.params_version` /
@@ -246,9 +296,11 @@ class HipModule(nn.Module):
 
     def plan_is_current(self, plan) -> bool:
         """Does `plan` (compile() / new_plan()) still describe this module - same parameter tensors at the same autograd
-        versions, same lowering attributes, same int8 state?  (Edits through `.data` need invalidate_plans(), as for compile().)"""
+        versions, no native update (fused SGD / running statistics / EMA) and no `_apply` / invalidate_plans() anywhere since,
+        same lowering attributes, same int8 state?  (Edits through `.data` need invalidate_plans(), as for compile().)"""
         quant = self.__dict__.get("_y6_quant")
-        return (getattr(plan, "params_version", None) == _params_version(self)
+        return (getattr(plan, "generations", None) == (_NATIVE_GENERATION[0], _STRUCTURE_GENERATION[0])
+                and getattr(plan, "params_version", None) == _params_version(self)
                 and getattr(plan, "quant_key", None) == (None if quant is None else quant.key()))
 
     def forward(self, *inputs):

@@ -57,7 +57,7 @@ class _ResultRing:
     (evaler.py:128-132, inferer.py:61-63: straight into non_max_suppression, result dropped) never triggers an allocation."""
 
     def __init__(self, like, n):
-        self.slots = [torch.empty_like(like) for _ in range(n)]
+        self.slots = [self._fresh(like) for _ in range(n)]
         self.pos = 0
         probe = [torch.empty(0)]
         self._base = self._refs(probe, 0)        # references to a tensor that only its list holds, counted the same way
@@ -66,27 +66,34 @@ class _ResultRing:
     def _refs(lst, i):
         return sys.getrefcount(lst[i])
 
-    _supported = None
+    @staticmethod
+    def counts_views(t):
+        """Does making a view of THIS tensor raise its CPython reference count?  True for ordinary and no_grad tensors on torch 2.x
+        (a view keeps its base alive through the Python object), False for inference tensors (`torch.inference_mode()`: views of
+        an inference tensor do not reference the base's PyObject - `boxes = det[..., :4]; del det` would leave the slot looking
+        free).  Decided per slot on the slot's own tensor (a process-wide probe made in whatever grad mode the first
+        forward happened to run in answered for every later slot)."""
+        if t.is_inference():
+            return False
+        holder = [t]
+        before = sys.getrefcount(holder[0])
+        view = holder[0][:0]
+        ok = sys.getrefcount(holder[0]) > before
+        del view
+        return ok
 
-    @classmethod
-    def supported(cls):
-        """Start-up self check of what the ring relies on: a view keeps its base alive THROUGH THE PYTHON OBJECT, i.e. making a
-        view raises the base tensor's CPython reference count (true for torch 2.x's PyObject preservation).  On a build where it does
-        not, `boxes = det[..., :4]; del det` would leave the slot looking free - Model.forward then clones every result instead."""
-        if cls._supported is None:
-            probe = [torch.empty(4)]
-            before = sys.getrefcount(probe[0])
-            view = probe[0][:2]
-            cls._supported = sys.getrefcount(probe[0]) > before
-            del view
-        return cls._supported
+    @staticmethod
+    def _fresh(like):
+        # ring slots are ordinary tensors even when the forward runs under torch.inference_mode(): their views must count
+        with torch.inference_mode(False):
+            return torch.empty_like(like)
 
     def next(self, held_by_plan=None):
         """The tensor the next run writes.  `held_by_plan`: the plan's current output (its own reference is not a caller's)."""
         self.pos = (self.pos + 1) % len(self.slots)
         extra = 1 if held_by_plan is self.slots[self.pos] else 0
         if self._refs(self.slots, self.pos) > self._base + extra:
-            self.slots[self.pos] = torch.empty_like(self.slots[self.pos])     # the caller keeps the old one
+            self.slots[self.pos] = self._fresh(self.slots[self.pos])         # the caller keeps the old one
         return self.slots[self.pos]
 
 
@@ -130,13 +137,15 @@ class Model(HipModule):
         if prev is not None:
             prev._fill()            # a caller still holds the previous result unread: copy it out before overwriting
         nbuf = int(self.output_buffers)
-        if nbuf >= 2 and not _ResultRing.supported():
-            nbuf = 0                      # views are not counted on this torch build: hand out clones
         if nbuf >= 2:
             ring = getattr(plan, "_det_ring", None)
             if ring is None or len(ring.slots) != nbuf:
                 ring = plan._det_ring = _ResultRing(plan.outputs, nbuf)
-            plan.rebind_output(ring.next(plan.outputs))
+            slot = ring.next(plan.outputs)
+            if _ResultRing.counts_views(slot):
+                plan.rebind_output(slot)
+            else:
+                nbuf = 0                  # views of this tensor are not counted (an inference tensor): hand out a clone
         det = plan.run()
         feats = _LazyFeatmaps(self._featrefs, x.dtype)
         self.__dict__["_last_featmaps"] = weakref.ref(feats)

@@ -52,6 +52,7 @@ class Ticket:
 class InflightRunner:
     def __init__(self, model, example, depth=2, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                  max_det=300, autotune=True):
+        # (autotune=True: timed kernels, replayed from the on-disk table where one exists; Y6_AUTOTUNE=0 forces shape-derived kernels)
         if depth < 1:
             raise ValueError("yolov6_amd.pipeline: depth >= 1")
         self.kw = dict(conf_thres=conf_thres, iou_thres=iou_thres, classes=classes, agnostic=agnostic, multi_label=multi_label,
@@ -64,8 +65,16 @@ class InflightRunner:
         self.autotune = autotune
         self.plans = [model.new_plan(example, autotune=autotune)]
         self.plans += [model.new_plan(example, autotune=autotune, variants_from=self.plans[0]) for _ in range(depth - 1)]   # tuned once
+        # what the slots' packed weights were derived from (submit() re-checks, cheap things first): the autograd version counters
+        # of the tensors, WHICH tensor objects are registered where (a replaced Parameter is another object; the old one, kept alive
+        # here, would never change), the process-wide generations that native kernels (fused SGD, running-statistics update, EMA)
+        # and .half() / .to() / invalidate_plans() bump instead of `_version`, and the int8 state
+        from .layers import common as _c
+        self._gens = _c
         self._tensors = list(model.parameters()) + list(model.buffers())
+        self._holders = [(d, n, t) for m in model.modules() for d in (m._parameters, m._buffers) for n, t in d.items() if t is not None]
         self._vsum = sum(t._version for t in self._tensors)
+        self._generations = (_c._NATIVE_GENERATION[0], _c._STRUCTURE_GENERATION[0])
         self._quant = model.__dict__.get("_y6_quant")
         self.inputs = [example] + [torch.empty_like(example) for _ in range(depth - 1)]
         for p, x in zip(self.plans[1:], self.inputs[1:]):
@@ -96,9 +105,13 @@ class InflightRunner:
         j = self.i % len(self.plans)
         # (cheap first: the sum of the autograd version counters of the tensors the plans were lowered from and the identity of
         # the int8 state; the full key - a walk over every module - only when those moved)
-        if ((sum(t._version for t in self._tensors) != self._vsum or self.model.__dict__.get("_y6_quant") is not self._quant)
+        c = self._gens
+        if ((sum(t._version for t in self._tensors) != self._vsum or self.model.__dict__.get("_y6_quant") is not self._quant
+             or (c._NATIVE_GENERATION[0], c._STRUCTURE_GENERATION[0]) != self._generations
+             or not all(d.get(n) is t for d, n, t in self._holders))
                 and not self.model.plan_is_current(self.plans[j])):
-            # load_state_dict / an optimizer step / quantize() since the plans were built: every slot would serve stale weights
+            # load_state_dict / an optimizer step (torch's or the native fused SGD) / a replaced Parameter / .half() / quantize()
+            # since the plans were built: every slot would serve stale weights
             raise RuntimeError("yolov6_amd.pipeline: the model's parameters (or its int8 state) changed after this runner was built; "
                                "build a new InflightRunner")
         self.i += 1
