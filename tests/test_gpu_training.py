@@ -137,13 +137,18 @@ def _wgrad_nhwc(ksize, dyv: TRef, xv: TRef, M, N):
     return out.cpu()
 
 
+@pytest.mark.parametrize("kernel", ["flat", "ring"])
 @pytest.mark.parametrize("cin,cout,B,H,W", [(16, 24, 3, 13, 17), (64, 64, 2, 20, 20), (40, 80, 2, 9, 33), (128, 32, 1, 40, 40),
-                                            (64, 64, 3, 37, 160), (256, 128, 5, 20, 20), (32, 96, 2, 7, 80), (64, 68, 2, 11, 40)])
-def test_wgrad_nhwc_3x3_s1_and_1x1(cin, cout, B, H, W):
-    """The NHWC-fed weight gradient (LDS-DMA rows + ds_read_b64_tr_b16, csrc/wgrad.hip) against torch's conv2d_weight: ragged
-    widths (pad columns must read as zeros), several images per slice (the x row ring crosses image borders), channel counts
-    that are not multiples of the 32-channel chunk / the 64-channel block tile, and - last case - an 8-channel padded dy view
-    (68 -> 72, zero pad channels) as the prediction convs' gradients are stored."""
+                                            (64, 64, 3, 37, 160), (256, 128, 5, 20, 20), (32, 96, 2, 7, 80), (64, 68, 2, 11, 40),
+                                            (128, 256, 16, 40, 40), (72, 136, 9, 20, 20), (64, 192, 3, 80, 80)])
+def test_wgrad_nhwc_3x3_s1_and_1x1(cin, cout, B, H, W, kernel, monkeypatch):
+    """The NHWC-fed weight gradients against torch's conv2d_weight - `flat`: the flat-index block-tiled kernel (csrc/wgrad_flat.hip:
+    LDS-DMA chunks of the whole batch's padded pixel sequence + ds_read_b64_tr_b16; the 160-wide case does not fit its stages and
+    takes the row ring), `ring`: the row-ring kernel (csrc/wgrad.hip, Y6_WGRAD_FLAT=0).  Ragged widths (pad cells must read as
+    zeros), chunks and slices that cross row and image borders, channel counts that are not multiples of the 32-channel image /
+    the block tile (two cout tiles, ragged last tile), and an 8-channel padded dy view (68 -> 72, zero pad channels) as the
+    prediction convs' gradients are stored."""
+    monkeypatch.setenv("Y6_WGRAD_FLAT", "1" if kernel == "flat" else "0")
     g = torch.Generator().manual_seed(cin + cout + W)
     x = (torch.rand((B, cin, H, W), generator=g) - 0.5).half().float()
     dy = (torch.rand((B, cout, H, W), generator=g) - 0.5).half().float()

@@ -36,6 +36,7 @@ SOURCES = {
     "loss.hip": ["-ffp-contract=off"],
     "train.hip": [],
     "wgrad.hip": [],
+    "wgrad_flat.hip": [],
     "quant.hip": [],
     "plan.hip": [],
 }

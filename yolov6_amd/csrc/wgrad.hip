@@ -694,12 +694,38 @@ int wgrad_launch(const y6_wgrad_desc* d, hipStream_t s) {
 
 size_t wgrad_nhwc_lds_bytes(int ksize, int Q, int da, int dx) { return (size_t)(da + 1 + dx + (ksize == 3 ? 3 : 1)) * 2 * Q * 64; }
 
+}  // namespace
+
 bool wgrad_nhwc_view_ok(const y6_tensor& t) {
     return t.data && t.C % 8 == 0 && t.cstride % 8 == 0 && t.coff % 8 == 0 && (((uintptr_t)t.data) & 15) == 0 &&
            (size_t)t.B * t.H * t.W * t.cstride * 2 < 0xf0000000ull;
 }
 
+// wgrad_flat.hip: the flat-index block-tiled kernel (round 6)
+const char* wgrad_flat_unsupported(const y6_wgrad_nhwc_desc* d);
+int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s);
+
+namespace {
+
+// Which NHWC-fed kernel takes a conv: the flat-index kernel wherever its stages fit the LDS and the map is at most
+// Y6_WGRAD_FLAT_MAXW columns wide (default: every fitting map), the row-ring kernel otherwise.  Y6_WGRAD_FLAT=0: row ring only (A/B).
+bool use_flat(const y6_wgrad_nhwc_desc* d) {
+    const char* e = getenv("Y6_WGRAD_FLAT");            // read per call: tests and tools/wgrad_bench.py flip it inside one process
+    const char* w = getenv("Y6_WGRAD_FLAT_MAXW");
+    if (!d || (e && atoi(e) == 0) || wgrad_flat_unsupported(d) != nullptr) return false;
+    if (e && atoi(e) == 1) return true;                 // forced (tests, tools/wgrad_bench.py)
+    // measured on the YOLOv6-S b64 shapes (profiles/r06/wgrad_bench_r06b.json): the flat kernel wins on every map up to 80 wide
+    // with more than 64 couts (256 -> 256 @40: 169 against 265 us, 512 -> 512 @20: 172 against 431, 1x1s 23-58 against 46-245); the
+    // row ring keeps the 160-wide maps (the flat stage's halo is 2*Wp + 24 positions per 128) and the 64-cout layers of the 80-wide
+    // maps (a 64-cout flat block is four waves alone on a CU there: 97 against 68 us)
+    const int maxw = w ? atoi(w) : 100;
+    if (d->x.W > maxw) return false;
+    if (d->M <= 64 && d->x.W >= 64) return false;
+    return true;
+}
+
 const char* wgrad_nhwc_unsupported(const y6_wgrad_nhwc_desc* d) {
+    if (use_flat(d)) return nullptr;
     if (!d || !d->out) return "null argument";
     if (d->ksize != 1 && d->ksize != 3) return "ksize must be 1 or 3 (stride 1)";
     if (!wgrad_nhwc_view_ok(d->dy) || !wgrad_nhwc_view_ok(d->x)) return "views must be fp16 NHWC, 8-channel / 16-byte aligned, below 3.75 GiB";
@@ -711,6 +737,7 @@ const char* wgrad_nhwc_unsupported(const y6_wgrad_nhwc_desc* d) {
 }
 
 int wgrad_nhwc_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
+    if (use_flat(d)) return wgrad_flat_launch(d, s);
     const char* why = wgrad_nhwc_unsupported(d);
     Y6_REQUIRE(why == nullptr, "wgrad_nhwc: %s", why ? why : "");
     WgLArgs a;

@@ -154,8 +154,10 @@ class TrainBuilder:
         self.planes = {}                   # (view key, sy, sx, oy, ox, R, Q, C) -> transposed copy already in the backward plan
         self.share_planes = os.environ.get("Y6_NO_SHARED_PLANES") is None
         self.wgrad_nhwc = os.environ.get("Y6_WGRAD_PLANES") is None     # A/B: weight gradients of stride-1 convs from NHWC (LDS transpose reads)
-        self.wgrad_nhwc_minw3 = int(os.environ.get("Y6_WGRAD_NHWC_MINW3", "64"))   # narrower 3x3 maps keep the plane-fed kernel
-        self.wgrad_nhwc_minw1 = int(os.environ.get("Y6_WGRAD_NHWC_MINW1", "64"))
+        # round 6: every stride-1 conv reads NHWC (csrc/wgrad_flat.hip takes the narrow maps the row-ring kernel lost to the
+        # plane-fed one; the library routes per shape); a minimum width > 0 sends narrower maps back to the plane-fed kernel (A/B)
+        self.wgrad_nhwc_minw3 = int(os.environ.get("Y6_WGRAD_NHWC_MINW3", "0"))
+        self.wgrad_nhwc_minw1 = int(os.environ.get("Y6_WGRAD_NHWC_MINW1", "0"))
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
