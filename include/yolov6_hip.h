@@ -617,6 +617,10 @@ typedef struct y6_wgrad_nhwc_desc {
     int32_t M, N;
     float* out;
     int32_t sm, sn, st;
+    int32_t stride;                /* 0 / 1: stride 1 (dy and x have one spatial shape); 2: x is [B, H, W, .] and dy either
+                                      [B, (H-1)/2+1, (W-1)/2+1, .] or the zero-inserted gradient [B, H, W, .] the stride-2 data gradient
+                                      reads (values at (2y, 2x)); 3x3 pad 1 or 1x1 pad 0 - the flat-index kernel only (round 6; the
+                                      field fills the struct's former padding) */
     double flops;
     void* workspace;               /* as y6_wgrad_desc */
     size_t workspace_bytes;

@@ -161,7 +161,7 @@ class WgradDesc(C.Structure):
 
 class WgradNhwcDesc(C.Structure):
     _fields_ = [("ksize", C.c_int32), ("dy", Tensor), ("x", Tensor), ("M", C.c_int32), ("N", C.c_int32), ("out", C.c_void_p),
-                ("sm", C.c_int32), ("sn", C.c_int32), ("st", C.c_int32), ("flops", C.c_double), ("workspace", C.c_void_p),
+                ("sm", C.c_int32), ("sn", C.c_int32), ("st", C.c_int32), ("stride", C.c_int32), ("flops", C.c_double), ("workspace", C.c_void_p),
                 ("workspace_bytes", C.c_size_t)]
 
 

@@ -140,17 +140,31 @@ __global__ __launch_bounds__(256) void bn_sum_part_kernel(const __half* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
         long p = p0 + prow;
-        for (; p + 3 * (long)R < p1; p += 4 * (long)R) {
-            float v0[8], v1[8], v2[8], v3[8];
-            load8(x + p * cs + co + g * 8, v0);
-            load8(x + (p + R) * cs + co + g * 8, v1);
-            load8(x + (p + 2 * (long)R) * cs + co + g * 8, v2);
-            load8(x + (p + 3 * (long)R) * cs + co + g * 8, v3);
+        // eight independent 16-byte loads in flight per thread; the sums and the sums of squares of the eight pixels are formed in
+        // fp32 (a product of two fp16 values is exact in fp32; eight terms) before they enter the double accumulators - one
+        // conversion and one fp64 add per value and round instead of one fp64 multiply-add per element (round 6: 2.2 -> see
+        // profiles/r06 TB/s; the fp64 work, not the loads, paced the loop)
+        for (; p + 7 * (long)R < p1; p += 8 * (long)R) {
+            uint4 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (p + u * (long)R) * cs + co + g * 8);
+            float fs[8], fq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fs[j] = fq[j] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const __half* h = reinterpret_cast<const __half*>(&raw[u]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = __half2float(h[j]);
+                    fs[j] += v;
+                    fq[j] = __builtin_fmaf(v, v, fq[j]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                s[j] += (double)((v0[j] + v1[j]) + (v2[j] + v3[j]));
-                q[j] += (double)v0[j] * (double)v0[j] + (double)v1[j] * (double)v1[j] + (double)v2[j] * (double)v2[j] +
-                        (double)v3[j] * (double)v3[j];
+                s[j] += (double)fs[j];
+                q[j] += (double)fq[j];
             }
         }
         for (; p < p1; p += R) {

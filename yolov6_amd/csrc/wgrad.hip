@@ -713,6 +713,7 @@ bool use_flat(const y6_wgrad_nhwc_desc* d) {
     const char* e = getenv("Y6_WGRAD_FLAT");            // read per call: tests and tools/wgrad_bench.py flip it inside one process
     const char* w = getenv("Y6_WGRAD_FLAT_MAXW");
     if (!d || (e && atoi(e) == 0) || wgrad_flat_unsupported(d) != nullptr) return false;
+    if (d->stride == 2) return true;                    // the row ring has no stride-2 form
     if (e && atoi(e) == 1) return true;                 // forced (tests, tools/wgrad_bench.py)
     // measured on the YOLOv6-S b64 shapes (profiles/r06/wgrad_bench_r06b.json): the flat kernel wins on every map up to 80 wide
     // with more than 64 couts (256 -> 256 @40: 169 against 265 us, 512 -> 512 @20: 172 against 431, 1x1s 23-58 against 46-245); the
@@ -726,6 +727,7 @@ bool use_flat(const y6_wgrad_nhwc_desc* d) {
 
 const char* wgrad_nhwc_unsupported(const y6_wgrad_nhwc_desc* d) {
     if (use_flat(d)) return nullptr;
+    if (d && d->stride == 2) return "stride 2 needs the flat-index kernel (map too wide for its stage, or Y6_WGRAD_FLAT=0)";
     if (!d || !d->out) return "null argument";
     if (d->ksize != 1 && d->ksize != 3) return "ksize must be 1 or 3 (stride 1)";
     if (!wgrad_nhwc_view_ok(d->dy) || !wgrad_nhwc_view_ok(d->x)) return "views must be fp16 NHWC, 8-channel / 16-byte aligned, below 3.75 GiB";

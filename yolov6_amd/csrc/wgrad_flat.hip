@@ -49,9 +49,11 @@ struct WgFArgs {
     unsigned a_bytes, x_bytes;
     int a_cs, a_co, a_C;       // dy view: pixel pitch, channel offset (halves), readable channels (multiple of 8)
     int x_cs, x_co, x_C;
-    int B, H, W;
+    int B, H, W;               // x (input) extent
+    int Ho, Wo, stride;        // output grid; stride 1 or 2
+    int dyd;                   // 2: dy is stored zero-inserted at (2y, 2x) of an [B, H, W] buffer (the data gradient's operand)
     int M, N;
-    int Wp, Pp;                // padded row / plane of the flat index (1x1: W, H*W)
+    int Wp, Pp;                // padded row / plane of the flat index over the OUTPUT grid (1x1: Wo, Ho*Wo)
     float inv_Pp, inv_Wp;
     int total;                 // B * Pp
     int xpos;                  // positions of an X stage image (multiple of 16)
@@ -143,9 +145,10 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
     // ---- requests of one chunk: instruction i of the list [dy images | X images], 16 positions x 4 pieces of 8 channels each
     const int ia = KC / 16, ix = a.xpos / 16;
     const int ni = NWM * ia + 2 * ix;
-    auto issue_chunk = [&](int chunk, unsigned lds_stage) {
+    // (one request instruction; i = wave, wave + NWV, ... are this wave's)
+    auto issue_piece = [&](int chunk, unsigned lds_stage, int i) {
         const int q0 = chunk * KC;
-        for (int i = wave; i < ni; i += NWV) {
+        {
             const bool isx = i >= NWM * ia;
             const int ii = isx ? i - NWM * ia : i;
             const int per = isx ? ix : ia;
@@ -156,7 +159,17 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
                 const int ch = m2 * (NWM * 32) + img * 32 + (lane & 3) * 8;
                 const int Q = q0 + p;
                 if (KS == 1) {
-                    if (Q < a.total && ch + 8 <= a.a_C) voff = (unsigned)(((unsigned long long)Q * a.a_cs + a.a_co + ch) * 2ull);
+                    if (Q < a.total && ch + 8 <= a.a_C) {
+                        if (a.dyd == 1) {
+                            voff = (unsigned)(((unsigned long long)Q * a.a_cs + a.a_co + ch) * 2ull);
+                        } else {
+                            const int b = div_small(Q, a.Pp, a.inv_Pp);
+                            const int rem = Q - b * a.Pp;
+                            const int y = div_small(rem, a.Wp, a.inv_Wp);
+                            const int xx = rem - y * a.Wp;
+                            voff = (unsigned)(((((unsigned long long)b * a.H + 2 * y) * a.W + 2 * xx) * a.a_cs + a.a_co + ch) * 2ull);
+                        }
+                    }
                 } else if (Q < a.total && ch + 8 <= a.a_C) {
                     const int b = div_small(Q, a.Pp, a.inv_Pp);
                     const int rem = Q - b * a.Pp;
@@ -170,7 +183,17 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
                 const int ch = n2 * TN + img * 32 + (lane & 3) * 8;
                 const int P = q0 - HALO + p;
                 if (KS == 1) {
-                    if (P < a.total && ch + 8 <= a.x_C) voff = (unsigned)(((unsigned long long)P * a.x_cs + a.x_co + ch) * 2ull);
+                    if (P < a.total && ch + 8 <= a.x_C) {
+                        if (a.stride == 1) {
+                            voff = (unsigned)(((unsigned long long)P * a.x_cs + a.x_co + ch) * 2ull);
+                        } else {                                   // 1x1 stride 2: output (y, x) reads input (2y, 2x)
+                            const int b = div_small(P, a.Pp, a.inv_Pp);
+                            const int rem = P - b * a.Pp;
+                            const int y = div_small(rem, a.Wp, a.inv_Wp);
+                            const int xx = rem - y * a.Wp;
+                            voff = (unsigned)(((((unsigned long long)b * a.H + 2 * y) * a.W + 2 * xx) * a.x_cs + a.x_co + ch) * 2ull);
+                        }
+                    }
                 } else if (P >= 0 && P < a.total && ch + 8 <= a.x_C) {
                     const int b = div_small(P, a.Pp, a.inv_Pp);
                     const int rem = P - b * a.Pp;
@@ -182,6 +205,9 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
                 dma16(rsX, voff, lds_stage + (unsigned)(NWM * a_img + img * x_img + j * 1024));
             }
         }
+    };
+    auto issue_chunk = [&](int chunk, unsigned lds_stage) {
+        for (int i = wave; i < ni; i += NWV) issue_piece(chunk, lds_stage, i);
     };
 
     f32x16_t acc[NT];
@@ -200,7 +226,11 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
         const int st = (c - c0) & 1;
         // chunk c has landed for this wave ... and for every wave, and everyone has left chunk c-1 (whose stage is refilled next)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (c + 1 < c1) issue_chunk(c + 1, lds0 + (unsigned)((st ^ 1) * stage_bytes));
+        // The next chunk's requests go out ONE PER K-STEP, between the MFMAs (their address arithmetic - two divisions per piece -
+        // runs in the shadow of the matrix pipe; issued in a burst behind the barrier it kept every wave of the block off the
+        // matrix pipe for ~500 cycles per chunk); what the k-steps do not cover follows the last one.
+        const bool more = c + 1 < c1;
+        const unsigned nst = lds0 + (unsigned)((st ^ 1) * stage_bytes);
         const char* const sb = smem + st * stage_bytes;
         const char* const ab = sb + mtl * a_img + lane_off;
         if constexpr (KS == 3) {
@@ -218,6 +248,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
 #pragma unroll
             for (int kk = 0; kk < KC / 16; ++kk) {
                 const int sp = kk % 3, sc = (kk + 1) % 3, sn = (kk + 2) % 3;
+                if (more && wave + kk * NWV < ni) issue_piece(c + 1, nst, wave + kk * NWV);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) R[sn][r] = tr_run(xb[r] + (kk + 1) * 8 * 64);
                 if (kk + 1 < KC / 16) A[(kk + 1) & 1] = tr_run(ab + (kk + 1) * 8 * 64);
@@ -240,6 +271,7 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
             Bq[0] = tr_run(xb);
 #pragma unroll
             for (int kk = 0; kk < KC / 16; ++kk) {
+                if (more && wave + kk * NWV < ni) issue_piece(c + 1, nst, wave + kk * NWV);
                 if (kk + 1 < KC / 16) {
                     A[(kk + 1) & 1] = tr_run(ab + (kk + 1) * 8 * 64);
                     Bq[(kk + 1) & 1] = tr_run(xb + (kk + 1) * 8 * 64);
@@ -248,6 +280,8 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_h8(A[kk & 1]), as_h8(Bq[kk & 1]), acc[0], 0, 0, 0);
             }
         }
+        if (more)
+            for (int i = wave + (KC / 16) * NWV; i < ni; i += NWV) issue_piece(c + 1, nst, i);
     }
     // C/D layout: column n = lane & 31, row m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5).  The slice's partial tile goes to the
     // workspace with plain stores (n contiguous across lanes); wgrad_flat_reduce_kernel sums the slices in a fixed order.
@@ -262,38 +296,180 @@ __global__ __launch_bounds__(NWM * 128, 2) void wgrad_flat_kernel(const WgFArgs 
         }
 }
 
-// out[m*sm + n*sn + t*st] += sum over the slices, in slice order (deterministic).  Consecutive threads own consecutive n: the
-// reads of a slice are coalesced; the OIHW destination (sn = T) is a strided read-modify-write of a few MB at most.
+// ---- 3x3 stride 2 (pad 1): dW[m][n][ky][kx] += sum dy(b,y,x,m) * X(b, 2y+ky-1, 2x+kx-1, n) ------------------------------------
+// The input splits into four row/column parity planes X_pq(r, c) = X(2r+p, 2c+q), each laid out over the OUTPUT grid's padded
+// flat index exactly as the stride-1 X image (cell b*Pp + (r+1)*Wp + (c+1)).  Tap (ky, kx) then reads ONE plane at ONE constant
+// offset from the output position Q:   ky: 0 -> odd rows, r = y-1 (+0) | 1 -> even rows, r = y (+Wp) | 2 -> odd rows, r = y (+Wp);
+// kx likewise with +0 / +1 / +1.  No shifted runs: every tap's operand is a plain transpose-read at (position + offset).  A stage
+// holds NWM dy images and the four plane images of 32 input channels (the LDS-DMA source address samples every other pixel and
+// row); it is single-buffered and two blocks share a CU: one multiplies while the other's requests are in flight.
+template <int NWM, int KCS>
+__global__ __launch_bounds__(NWM * 64, 2) void wgrad_flat_s2_kernel(const WgFArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles = a.mt2 * a.nt2;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int ks = (bi / tiles) * 8 + xcd, slot = bi % tiles;
+    if (ks >= a.nsplit) return;
+    const int n2 = slot % a.nt2, m2 = slot / a.nt2;
+    const int c0 = ks * a.chunks_per;
+    const int c1 = c0 + a.chunks_per < a.nchunks ? c0 + a.chunks_per : a.nchunks;
+    const int a_img = KCS * 64, x_img = a.xpos * 64;
+    const i32x4_t rsA = make_rsrc(a.a, a.a_bytes), rsX = make_rsrc(a.x, a.x_bytes);
+    const int ia = KCS / 16, ix = a.xpos / 16;
+    const int ni = NWM * ia + 4 * ix;
+    const unsigned lds0 = lds_addr(smem);
+    auto issue_chunk = [&](int chunk) {
+        const int q0 = chunk * KCS;
+        for (int i = wave; i < ni; i += NWM) {
+            const bool isx = i >= NWM * ia;
+            const int ii = isx ? i - NWM * ia : i;
+            const int per = isx ? ix : ia;
+            const int img = ii / per, j = ii - img * per;
+            const int P = q0 + j * 16 + (lane >> 2);
+            unsigned voff = kOob;
+            const int chl = (lane & 3) * 8;
+            if (P < a.total) {
+                const int b = div_small(P, a.Pp, a.inv_Pp);
+                const int rem = P - b * a.Pp;
+                const int rr = div_small(rem, a.Wp, a.inv_Wp);
+                const int cc = rem - rr * a.Wp;
+                if (!isx) {
+                    const int ch = m2 * (NWM * 32) + img * 32 + chl;
+                    if (rr < a.Ho && cc < a.Wo && ch + 8 <= a.a_C)
+                        voff = a.dyd == 1 ? (unsigned)(((((unsigned long long)b * a.Ho + rr) * a.Wo + cc) * a.a_cs + a.a_co + ch) * 2ull)
+                                          : (unsigned)(((((unsigned long long)b * a.H + 2 * rr) * a.W + 2 * cc) * a.a_cs + a.a_co + ch) * 2ull);
+                } else {
+                    const int ch = n2 * 32 + chl;
+                    const int sr = 2 * (rr - 1) + (img >> 1), sc = 2 * (cc - 1) + (img & 1);
+                    if (rr >= 1 && cc >= 1 && sr < a.H && sc < a.W && ch + 8 <= a.x_C)
+                        voff = (unsigned)(((((unsigned long long)b * a.H + sr) * a.W + sc) * a.x_cs + a.x_co + ch) * 2ull);
+                }
+            }
+            if (!isx) dma16(rsA, voff, lds0 + (unsigned)(img * a_img + j * 1024));
+            else dma16(rsX, voff, lds0 + (unsigned)(NWM * a_img + img * x_img + j * 1024));
+        }
+    };
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    const int lane_off = ((lane & 15) >> 2) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2 + half * (KCS / 2) * 64;
+    const char* const ab = smem + wave * a_img + lane_off;
+    const char* xt[9];                                   // per tap: plane image + constant offset
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        const int pl = (ky == 1 ? 0 : 2) + (kx == 1 ? 0 : 1);
+        const int off = (ky == 0 ? 0 : a.Wp) + (kx == 0 ? 0 : 1);
+        xt[t] = smem + NWM * a_img + pl * x_img + lane_off + off * 64;
+    }
+    for (int c = c0; c < c1; ++c) {
+        issue_chunk(c);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");          // the chunk has landed for every wave
+#pragma unroll
+        for (int kk = 0; kk < KCS / 16; ++kk) {
+            const h8_t af = as_h8(tr_run(ab + kk * 8 * 64));
+            u32x4 Bq[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) Bq[t] = tr_run(xt[t] + kk * 8 * 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, as_h8(Bq[t]), acc[t], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // everyone has read it: the stage may be refilled
+    }
+    const int n_out = n2 * 32 + l31;
+    if (n_out >= a.N) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m_out = m2 * (NWM * 32) + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (m_out < a.M) a.ws[(((size_t)ks * 9 + t) * a.M + m_out) * a.N + n_out] = acc[t][q];
+        }
+}
+
+// out[m*sm + n*sn + t*st] += sum over the slices, in slice order (deterministic).  A thread owns four consecutive (m, n) cells of
+// one tap (the [t][m][n] partials are contiguous over (m, n): a wave reads 1 KiB of every slice, sixteen 16-byte loads in flight per
+// lane), and adds its four sums into the OIHW gradient.  What bounds this kernel is bytes in flight, not bytes: 128 slices of a
+// 128 x 128 x 9 tile are 75 MB behind only 37 k threads (first forms, round 6: one element per thread in [t][m][n] order, then one
+// cout row x 64 cin per block - 19-35 us per call, 2.1 ms of a training step).
 __global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float* __restrict__ ws, int nsplit, int T, int M, int N, float* __restrict__ out,
                                                                 int sm, int sn, int st) {
-    const size_t per = (size_t)T * M * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * per + i];
-        const int n = (int)(i % N);
-        const int m = (int)((i / N) % M);
-        const int t = (int)(i / ((size_t)N * M));
-        out[(size_t)m * sm + (size_t)n * sn + (size_t)t * st] += s;
+    const size_t quads = (size_t)T * M * N / 4;          // N % 8 == 0 (host): a quad never straddles two cout rows
+    const size_t per4 = quads;
+    const float4* p4 = reinterpret_cast<const float4*>(ws);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 16 <= nsplit; k += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p4[(size_t)(k + u) * per4 + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {               // slice order
+                s.x += v[u].x;
+                s.y += v[u].y;
+                s.z += v[u].z;
+                s.w += v[u].w;
+            }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = p4[(size_t)k * per4 + i];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        const size_t e = i * 4;
+        const int n = (int)(e % N);
+        const int m = (int)((e / N) % M);
+        const int t = (int)(e / ((size_t)N * M));
+        float* o = out + (size_t)m * sm + (size_t)n * sn + (size_t)t * st;
+        o[0] += s.x;
+        o[(size_t)sn] += s.y;
+        o[(size_t)2 * sn] += s.z;
+        o[(size_t)3 * sn] += s.w;
     }
 }
 
 struct FlatGeom {
-    int Wp, Pp, total, xpos, nwm, nchunks;
+    int Wp, Pp, total, xpos, nwm, nchunks, stride, kc, tn;
     size_t lds;
 };
 
 bool flat_geom(const y6_wgrad_nhwc_desc* d, FlatGeom* g) {
     const int KS = d->ksize;
-    const long H = d->x.H, W = d->x.W, B = d->x.B;
-    g->Wp = KS == 3 ? (int)W + 1 : (int)W;
-    g->Pp = KS == 3 ? (int)((H + 1) * (W + 1)) : (int)(H * W);
+    const int stride = d->stride == 2 ? 2 : 1;
+    const long Ho = stride == 2 ? (d->x.H - 1) / 2 + 1 : d->x.H, Wo = stride == 2 ? (d->x.W - 1) / 2 + 1 : d->x.W, B = d->x.B;
+    g->stride = stride;
+    g->Wp = KS == 3 ? (int)Wo + 1 : (int)Wo;
+    g->Pp = KS == 3 ? (int)((Ho + 1) * (Wo + 1)) : (int)(Ho * Wo);
     const long total = B * (long)g->Pp;
     if (total >= (1l << 24)) return false;             // div_small's exact range
     g->total = (int)total;
+    g->nwm = d->M > 64 ? 4 : 2;
+    if (KS == 3 && stride == 2) {
+        if (Wo > 48) return false;                     // (80-wide outputs: 216-483 us against the plane-fed kernel's 135-260, profiles/r06)
+        // single stage, two blocks per CU: <= 80 KiB each; 128-position chunks where the four plane images fit, else 64
+        g->tn = 32;
+        // (a 64-position chunk fits the 80-wide outputs too, but it is 36 MFMAs per 56 request instructions and the zero-inserted dy
+        // wastes half of every line: 696 us against the plane-fed kernel's 260 on 64 -> 128 @160 -> 80, profiles/r06 - 128 only)
+        for (int kc : {128}) {
+            g->kc = kc;
+            g->xpos = (kc + g->Wp + 1 + 15) / 16 * 16;
+            g->lds = (size_t)g->nwm * kc * 64 + 4 * (size_t)g->xpos * 64;
+            if (g->lds <= 80u * 1024) break;
+        }
+        g->nchunks = (int)((total + g->kc - 1) / g->kc);
+        return g->lds <= 80u * 1024;
+    }
+    g->tn = TN;
+    g->kc = KC;
     const int xp = KS == 3 ? KC + 2 * g->Wp + 24 : KC;
     g->xpos = (xp + 15) / 16 * 16;
-    g->nwm = d->M > 64 ? 4 : 2;
     g->lds = 2 * ((size_t)g->nwm * KC * 64 + 2 * (size_t)g->xpos * 64);
     g->nchunks = (int)((total + KC - 1) / KC);
     return g->lds <= 160u * 1024;                      // (4-wave blocks: two per CU while their stages stay below 80 KiB)
@@ -307,8 +483,16 @@ const char* wgrad_flat_unsupported(const y6_wgrad_nhwc_desc* d) {
     if (!d || !d->out) return "null argument";
     if (d->ksize != 1 && d->ksize != 3) return "ksize must be 1 or 3 (stride 1)";
     if (!wgrad_nhwc_view_ok(d->dy) || !wgrad_nhwc_view_ok(d->x)) return "views must be fp16 NHWC, 8-channel / 16-byte aligned, below 3.75 GiB";
-    if (d->dy.B != d->x.B || d->dy.H != d->x.H || d->dy.W != d->x.W || d->x.B < 1 || d->x.H < 1 || d->x.W < 1) return "dy and x must have one spatial shape";
+    if (d->stride == 2) {
+        const bool compact = d->dy.H == (d->x.H - 1) / 2 + 1 && d->dy.W == (d->x.W - 1) / 2 + 1;
+        const bool dilated = d->dy.H == d->x.H && d->dy.W == d->x.W && d->x.H > 1 && d->x.W > 1;
+        if (d->dy.B != d->x.B || !(compact || dilated) || d->x.B < 1 || d->x.H < 1 || d->x.W < 1)
+            return "stride 2: dy must be [B, (H-1)/2+1, (W-1)/2+1, .] or the zero-inserted [B, H, W, .] for x [B, H, W, .]";
+    } else if (d->dy.B != d->x.B || d->dy.H != d->x.H || d->dy.W != d->x.W || d->x.B < 1 || d->x.H < 1 || d->x.W < 1) {
+        return "dy and x must have one spatial shape";
+    }
     if (d->M < 1 || d->N < 1 || d->dy.C < d->M || d->x.C < d->N) return "views narrower than M / N";
+    if (d->N % 4 != 0 || (((uintptr_t)d->workspace) & 15) != 0) return "N must be a multiple of 4 and the workspace 16-byte aligned (the slice sum reads float4)";
     FlatGeom g;
     if (!flat_geom(d, &g)) return "map too wide (or batch too large) for the flat stages";
     return nullptr;
@@ -328,18 +512,22 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
     a.a_cs = d->dy.cstride, a.a_co = d->dy.coff, a.a_C = d->dy.C;
     a.x_cs = d->x.cstride, a.x_co = d->x.coff, a.x_C = d->x.C;
     a.B = d->x.B, a.H = d->x.H, a.W = d->x.W;
+    a.stride = g.stride;
+    a.Ho = g.stride == 2 ? (d->x.H - 1) / 2 + 1 : d->x.H, a.Wo = g.stride == 2 ? (d->x.W - 1) / 2 + 1 : d->x.W;
+    a.dyd = (g.stride == 2 && d->dy.H == d->x.H && d->dy.W == d->x.W && d->x.H > 1) ? 2 : 1;
     a.M = d->M, a.N = d->N;
     a.Wp = g.Wp, a.Pp = g.Pp, a.total = g.total, a.xpos = g.xpos, a.nchunks = g.nchunks;
     a.inv_Pp = 1.0f / (float)g.Pp, a.inv_Wp = 1.0f / (float)g.Wp;
     const int TM = g.nwm * 32;
     a.mt2 = y6_cdiv(d->M, TM);
-    a.nt2 = y6_cdiv(d->N, TN);
+    a.nt2 = y6_cdiv(d->N, g.tn);
     const int T = d->ksize * d->ksize;
     const long tiles = (long)a.mt2 * a.nt2;
     const size_t per = (size_t)T * d->M * d->N;
     Y6_REQUIRE(d->workspace && d->workspace_bytes >= per * sizeof(float), "wgrad_flat: workspace missing or too small");
     // one round of blocks over the chip (256 CUs x 1 block of 8 waves or 2 blocks of 4), a slice no shorter than 4 chunks
-    const long slots = (g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512;
+    const bool s2k3 = d->ksize == 3 && g.stride == 2;
+    const long slots = s2k3 ? 512 : ((g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512);
     long nsplit = slots / tiles;
     if (nsplit > g.nchunks / 4) nsplit = g.nchunks / 4;
     const long max_by_ws = (long)(d->workspace_bytes / (per * sizeof(float)));
@@ -355,9 +543,18 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
         Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_s2_kernel<4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_s2_kernel<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_s2_kernel<2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Y6_HIP(hipFuncSetAttribute((const void*)wgrad_flat_s2_kernel<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
-    if (d->ksize == 3) {
+    if (s2k3) {
+        if (g.nwm == 4 && g.kc == 128) hipLaunchKernelGGL((wgrad_flat_s2_kernel<4, 128>), dim3(grid), dim3(256), g.lds, s, a);
+        else if (g.nwm == 4) hipLaunchKernelGGL((wgrad_flat_s2_kernel<4, 64>), dim3(grid), dim3(256), g.lds, s, a);
+        else if (g.kc == 128) hipLaunchKernelGGL((wgrad_flat_s2_kernel<2, 128>), dim3(grid), dim3(128), g.lds, s, a);
+        else hipLaunchKernelGGL((wgrad_flat_s2_kernel<2, 64>), dim3(grid), dim3(128), g.lds, s, a);
+    } else if (d->ksize == 3) {
         if (g.nwm == 4) hipLaunchKernelGGL((wgrad_flat_kernel<3, 4>), dim3(grid), dim3(512), g.lds, s, a);
         else hipLaunchKernelGGL((wgrad_flat_kernel<3, 2>), dim3(grid), dim3(256), g.lds, s, a);
     } else {
@@ -365,8 +562,8 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
         else hipLaunchKernelGGL((wgrad_flat_kernel<1, 2>), dim3(grid), dim3(256), g.lds, s, a);
     }
     Y6_LAUNCH_CHECK();
-    unsigned rg = (unsigned)((per + 255) / 256);
-    if (rg > 4096) rg = 4096;
+    unsigned rg = (unsigned)((per / 4 + 255) / 256);
+    if (rg > 8192) rg = 8192;
     hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3(rg), dim3(256), 0, s, a.ws, a.nsplit, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
     Y6_LAUNCH_CHECK();
     return Y6_OK;

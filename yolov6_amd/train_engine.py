@@ -158,6 +158,7 @@ class TrainBuilder:
         # plane-fed one; the library routes per shape); a minimum width > 0 sends narrower maps back to the plane-fed kernel (A/B)
         self.wgrad_nhwc_minw3 = int(os.environ.get("Y6_WGRAD_NHWC_MINW3", "0"))
         self.wgrad_nhwc_minw1 = int(os.environ.get("Y6_WGRAD_NHWC_MINW1", "0"))
+        self.wgrad_flat_s2 = os.environ.get("Y6_WGRAD_FLAT_S2", "1") != "0"      # A/B: stride-2 convs back on the plane-fed kernel
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -652,10 +653,13 @@ class TrainBuilder:
         dyv = TRef(dy.buf, dy.B, dy.H, dy.W, rec.cpad or dy.C, dy.cstride, dy.coff)
         flops = 2.0 * Cout * Cin * K * K * B * Ho * Wo
         wlog = dict(weight=rec.weight, x=(xt if is_stem else xv), dy=dyv, dil=rec.dy_dil, k=K, stride=s, cout=Cout)
-        if s == 1 and not is_stem and rec.dy_dil == 1 and self.wgrad_nhwc and Wo >= (self.wgrad_nhwc_minw3 if K == 3 else self.wgrad_nhwc_minw1):
-            # stride-1 convs: the weight gradient reads x and dy as they lie (NHWC) - no transposed copies
+        nhwc_s1 = s == 1 and rec.dy_dil == 1 and Wo >= (self.wgrad_nhwc_minw3 if K == 3 else self.wgrad_nhwc_minw1)
+        nhwc_s2 = s == 2 and self.wgrad_flat_s2           # round 6: the flat-index kernel's parity-plane form (dy compact or zero-inserted)
+        if not is_stem and self.wgrad_nhwc and (nhwc_s1 or nhwc_s2):
+            # the weight gradient reads x and dy as they lie (NHWC) - no transposed copies
             w = _lib.WgradNhwcDesc()
             w.ksize, w.dy, w.x, w.M, w.N = K, dyv.ct(), xv.ct(), Cout, Cin
+            w.stride = s
             w.out = self.arena.grad_ptr(rec.weight)
             w.sm, w.sn, w.st = Cin * K * K, K * K, 1
             w.flops = flops
