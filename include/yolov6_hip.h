@@ -191,8 +191,14 @@ typedef struct y6_stem_desc {
     const float* post_scale;
     const float* post_shift;
     int32_t act;
+    /* round 6 (int8 plans): optional int8 NHWC twin of the output for a quantised consumer, q = quantise(fp16 output, q_out_amax) -
+     * the same rule and bits as y6_quantize_i8 / a y6_conv_i8_desc.q_out; `out.data` may then be NULL (twin only).  Needs the
+     * tiled kernel's shapes (y6_stem_twin_supported).  data NULL: none. */
+    y6_tensor q_out;
+    float q_out_amax;
 } y6_stem_desc;
 int y6_stem_conv(const y6_stem_desc* d, void* stream);
+int y6_stem_twin_supported(const y6_stem_desc* d);   /* 1: y6_stem_conv can write d->q_out (host-only query) */
 
 /* Producer -> 3x3 stride-2 conv pairs as ONE launch (csrc/conv_fused.hip): the producer's output tile stays in LDS, the
  * intermediate tensor is never written to HBM (pw.out / stem.out are IGNORED, their data may be NULL).

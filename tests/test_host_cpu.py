@@ -879,7 +879,8 @@ def test_backward_side_stream_contract_holds_on_every_training_graph(case, flags
     i = next(k for k, e in enumerate(log) if e["kind"] == "wgrad_transpose" and hasattr(e["src"], "buf"))
     rogue = dict(kind="tensor_add", side=False, x=log[i]["src"], out=log[i]["src"], acc=0)
     bad = S.side_conflicts(log[:i + 1] + [rogue], arena)
-    assert bad and bad[0][0] == i and bad[0][2] == "writes an input"
+    # (round 6: the NHWC-fed weight gradients read the same activation without a transposed copy, so earlier side ops may be hit too)
+    assert bad and any(b[0] == i and b[2] == "writes an input" for b in bad)
     j = next(k for k, e in enumerate(log) if e["kind"] == "wgrad")
     from yolov6_amd.engine import TRef
     g = arena.grad

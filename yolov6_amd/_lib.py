@@ -47,7 +47,8 @@ class ConvTDesc(C.Structure):
 class StemDesc(C.Structure):
     _fields_ = [("in_nchw", C.c_void_p), ("in_dtype", C.c_int32), ("B", C.c_int32), ("Cin", C.c_int32),
                 ("H", C.c_int32), ("W", C.c_int32), ("out", Tensor), ("w_oihw_f32", C.c_void_p),
-                ("bias", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int32)]
+                ("bias", C.c_void_p), ("post_scale", C.c_void_p), ("post_shift", C.c_void_p), ("act", C.c_int32),
+                ("q_out", Tensor), ("q_out_amax", C.c_float)]
 
 
 class DecodeDesc(C.Structure):
@@ -235,6 +236,7 @@ SIGNATURES = {
     "y6_dma_probe": (C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "y6_convt2x2": (C.c_int, [C.POINTER(ConvTDesc), C.c_void_p]),
     "y6_stem_conv": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
+    "y6_stem_twin_supported": (C.c_int, [C.POINTER(StemDesc)]),
     "y6_sppf_pool": (C.c_int, [C.POINTER(Tensor)] * 4 + [C.c_void_p]),
     "y6_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tensor), C.c_void_p]),
     "y6_nhwc_to_nchw": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_int, C.c_void_p]),

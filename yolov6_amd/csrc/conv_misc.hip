@@ -3,6 +3,7 @@
 // NCHW<->NHWC boundary adapters.  File:line citations are into the reference tree.
 #include "common.hpp"
 #include <cstring>
+#include "conv_common.hpp"
 #include "stem_piece.hpp"
 
 namespace {
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(256) void stem_mfma_v4_kernel(const TI* __restrict_
                                                            const float* __restrict__ pscale,
                                                            const float* __restrict__ pshift, int B, int H, int W, int Ho,
                                                            int Wo, int Cout, int out_cs, int out_co, int act, int tiles_x,
-                                                           int tiles_y) {
+                                                           int tiles_y, signed char* __restrict__ qout, int q_cs, int q_co, unsigned q_inv2,
+                                                           unsigned q_lo2, unsigned q_hi2) {
     constexpr int RS = CF * 64 + 16;   // epilogue row pitch (bytes)
     __shared__ __attribute__((aligned(16))) _Float16 s_in[3 * STEM_IH * STEM4_PITCH];
     __shared__ __attribute__((aligned(16))) char s_out[4 * 64 * RS];
@@ -474,13 +476,28 @@ __global__ __launch_bounds__(256) void stem_mfma_v4_kernel(const TI* __restrict_
         if (rows_ok) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             constexpr int PPR = CF * 4;   // 16-byte pieces per pixel row
+            if (out != nullptr) {
 #pragma unroll
-            for (int i = 0; i < PPR; ++i) {
-                const int q = lane + 64 * i;
-                const int px = q / PPR, pcq = q - px * PPR;
-                if (oy < Ho && (ox0 + px) < Wo && pcq * 8 + 8 <= Cout)
-                    *reinterpret_cast<uint4*>(out + (rowbase + ox0 + px) * out_cs + out_co + pcq * 8) =
-                        *reinterpret_cast<const uint4*>(tl + px * RS + pcq * 16);
+                for (int i = 0; i < PPR; ++i) {
+                    const int q = lane + 64 * i;
+                    const int px = q / PPR, pcq = q - px * PPR;
+                    if (oy < Ho && (ox0 + px) < Wo && pcq * 8 + 8 <= Cout)
+                        *reinterpret_cast<uint4*>(out + (rowbase + ox0 + px) * out_cs + out_co + pcq * 8) =
+                            *reinterpret_cast<const uint4*>(tl + px * RS + pcq * 16);
+                }
+            }
+            if (qout != nullptr) {   // the int8 twin: the SAME fp16 values, 16 channels per 16-byte piece (round 6)
+                constexpr int QPR = CF * 2;
+#pragma unroll
+                for (int i = 0; i < QPR; ++i) {
+                    const int q = lane + 64 * i;
+                    const int px = q / QPR, pcq = q - px * QPR;
+                    if (oy < Ho && (ox0 + px) < Wo && pcq * 16 + 16 <= Cout) {
+                        const uint4 lo = *reinterpret_cast<const uint4*>(tl + px * RS + pcq * 32);
+                        const uint4 hi = *reinterpret_cast<const uint4*>(tl + px * RS + pcq * 32 + 16);
+                        *reinterpret_cast<uint4*>(qout + (rowbase + ox0 + px) * q_cs + q_co + pcq * 16) = q8_piece(lo, hi, q_inv2, q_lo2, q_hi2);
+                    }
+                }
             }
         }
         __syncthreads();   // window reads and tile reads are over: the next iteration overwrites both
@@ -769,9 +786,37 @@ extern "C" int y6_convt2x2(const y6_convt_desc* d, void* stream) {
     return Y6_OK;
 }
 
+static unsigned stem_half2_bits(float v) {
+    const _Float16 h = (_Float16)v;
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return (unsigned)b | ((unsigned)b << 16);
+}
+
+// the tiled kernel (stem_mfma_v4_kernel) takes the call: the only one that writes the int8 twin
+static bool stem_v4_ok(const y6_stem_desc* d) {
+    const size_t esz = d->in_dtype == Y6_F16 ? 2 : (d->in_dtype == Y6_U8 ? 1 : 4);
+    const size_t palign = 8 * esz;
+    static const bool no_v4 = getenv("Y6_STEM_NO_V4") != nullptr;   // A/B switch for profiling
+    return d->Cin * 9 <= 32 && d->out.C <= 64 && d->out.cstride % 4 == 0 && d->out.coff % 4 == 0 && !no_v4 && d->Cin == 3 && d->W % 8 == 0 &&
+           ((uintptr_t)d->in_nchw % palign) == 0 && ((size_t)d->H * d->W * esz) % palign == 0 &&
+           (d->in_dtype == Y6_F16 || d->in_dtype == Y6_F32 || d->in_dtype == Y6_U8);
+}
+
+extern "C" int y6_stem_twin_supported(const y6_stem_desc* d) {
+    if (!d || !d->in_nchw) return 0;
+    const y6_tensor& q = d->q_out;
+    return stem_v4_ok(d) && d->out.C % 16 == 0 && d->out.cstride % 8 == 0 && d->out.coff % 8 == 0 && q.C == d->out.C && q.cstride % 16 == 0 &&
+                   q.coff % 16 == 0 && q.B == d->out.B && q.H == d->out.H && q.W == d->out.W
+               ? 1
+               : 0;
+}
+
 extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
-    Y6_REQUIRE(d && d->in_nchw && d->out.data && d->w_oihw_f32, "stem_conv: null argument");
+    Y6_REQUIRE(d && d->in_nchw && (d->out.data || d->q_out.data) && d->w_oihw_f32, "stem_conv: null argument");
+    Y6_REQUIRE(d->q_out.data == nullptr || (y6_stem_twin_supported(d) && (((uintptr_t)d->q_out.data) & 15) == 0 && d->q_out_amax > 0.f),
+               "stem_conv: the int8 twin needs the tiled kernel's shapes (3 input channels, W %% 8 == 0, Cout %% 16 == 0, aligned views)");
     const int Ho = (d->H + 2 - 3) / 2 + 1, Wo = (d->W + 2 - 3) / 2 + 1;
     Y6_REQUIRE(d->out.B == d->B && d->out.H == Ho && d->out.W == Wo, "stem_conv: bad output shape");
     Y6_REQUIRE(d->out.cstride % 8 == 0 && d->out.coff % 8 == 0, "stem_conv: output slice must be 8-channel aligned");
@@ -785,11 +830,7 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     hipLaunchKernelGGL((stem_mfma_kernel<TI, CF_>), g, blk, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data,      \
                        d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->Cin, d->H, d->W, Ho, Wo, CO, \
                        d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
-        const size_t esz = d->in_dtype == Y6_F16 ? 2 : (d->in_dtype == Y6_U8 ? 1 : 4);
-        static const bool no_v4 = getenv("Y6_STEM_NO_V4") != nullptr;   // A/B switch for profiling
-        const size_t palign = 8 * esz;     // one piece = 8 pixels
-        if (!no_v4 && d->Cin == 3 && d->W % 8 == 0 && ((uintptr_t)d->in_nchw % palign) == 0 && ((size_t)d->H * d->W * esz) % palign == 0 &&
-            (d->in_dtype == Y6_F16 || d->in_dtype == Y6_F32 || d->in_dtype == Y6_U8)) {
+        if (stem_v4_ok(d)) {
             static int n_cu = 0;
             if (n_cu == 0) {
                 int dev = 0;
@@ -802,7 +843,13 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
 #define Y6_STEM_V4(TI, CF_)                                                                                        \
     hipLaunchKernelGGL((stem_mfma_v4_kernel<TI, CF_>), dim3(gridp), blk, 0, s, (const TI*)d->in_nchw,                \
                        (__half*)d->out.data, d->w_oihw_f32, d->bias, d->post_scale, d->post_shift, d->B, d->H, d->W, \
-                       Ho, Wo, CO, d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y)
+                       Ho, Wo, CO, d->out.cstride, d->out.coff, d->act, tiles_x, tiles_y, (signed char*)d->q_out.data,           \
+                       d->q_out.cstride, d->q_out.coff, q_inv2, q_lo2, q_hi2)
+            unsigned q_inv2 = 0, q_lo2 = 0, q_hi2 = 0;
+            if (d->q_out.data) {   // fp16(amax) and fp16(127 / fp16(amax)): the quantiser constants of y6_conv_i8_desc
+                const float ah = (float)(_Float16)d->q_out_amax;
+                q_inv2 = stem_half2_bits(127.0f / ah), q_lo2 = stem_half2_bits(-ah), q_hi2 = stem_half2_bits(ah);
+            }
             if (d->in_dtype == Y6_F16) {
                 if (CO <= 32) Y6_STEM_V4(__half, 1); else Y6_STEM_V4(__half, 2);
             } else if (d->in_dtype == Y6_U8) {
@@ -814,6 +861,7 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
             Y6_LAUNCH_CHECK();
             return Y6_OK;
         }
+        Y6_REQUIRE(d->out.data && !d->q_out.data, "stem_conv: only the tiled kernel writes the int8 twin");
         if (d->in_dtype == Y6_F16) {
             if (CO <= 32) Y6_STEM_MFMA(__half, 1); else Y6_STEM_MFMA(__half, 2);
         } else if (d->in_dtype == Y6_F32) {
@@ -827,6 +875,7 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
         Y6_LAUNCH_CHECK();
         return Y6_OK;
     }
+    Y6_REQUIRE(d->out.data && !d->q_out.data, "stem_conv: only the tiled kernel writes the int8 twin");
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
 #define Y6_STEM_CASE(TI, CO_)                                                                                      \
     hipLaunchKernelGGL((stem_conv_kernel<TI, CO_>), grid, block, 0, s, (const TI*)d->in_nchw, (__half*)d->out.data, \

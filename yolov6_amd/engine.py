@@ -609,7 +609,24 @@ class PlanBuilder:
         d.post_scale = self._ptr(self._f32(post[0])) if post is not None else None
         d.post_shift = self._ptr(self._f32(post[1])) if post is not None else None
         d.act = ACT_BY_NAME[act]
+        d.q_out, d.q_out_amax = _null_tensor(), 0.0
         entry = dict(kind="stem", x=t, out=out, w=w32, b=bias, stride=2, act=act, post=post, res=None, alpha=None)
+        if self.quant is not None and self.quant.mode == "int8" and not self._no_quant:
+            # int8 plans (round 6): the image conv stays fp16 (its input is 8-bit pixels already) but can leave the int8 twin of
+            # its output for the quantised conv behind it - that conv then reads 1/2 of the bytes on the register-fed stride-2
+            # int8 kernel instead of quantising 210 MB of fp16 on the per-tap kernel (S-QA 640^2 b32: 205 us, 10 % of the step)
+            probe = _lib.Tensor(None, out.B, out.H, out.W, out.C, (out.cstride + 15) // 16 * 16, out.coff)
+            d.q_out = probe
+            entry["twin_ok"] = bool(self.lib.y6_stem_twin_supported(C.byref(d))) and out.cstride % 16 == 0 and out.coff % 16 == 0
+            d.q_out = _null_tensor()
+            dec = getattr(self.quant, "decisions", None)
+            do = dec.get(self.buf_id(out)) if dec else None
+            if do is not None and do["twin"] and entry["twin_ok"]:
+                q_out = self._twin(out, do["amax"])
+                d.q_out, d.q_out_amax = q_out.ct(), float(do["amax"])
+                entry.update(q_out=q_out, q_out_amax=float(do["amax"]), has_out=bool(do["fp16"]))
+                if not do["fp16"]:
+                    d.out = _lib.Tensor(None, out.B, out.H, out.W, out.C, out.cstride, out.coff)
         if (self._fuse_s2 and single_use and fresh_out and post is None and self.quant is None and self.force_variant < 0
                 and Cin == 3 and Cout == 32):
             self._pending = dict(kind="stem", desc=d, entry=entry, out=out)      # (conv() flushed before calling us)

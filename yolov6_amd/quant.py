@@ -98,7 +98,7 @@ def plan_twins(pb):
 
     A buffer gets one when every quantised conv reading it uses ONE scale (convs reading the same tensor - or a concat
     buffer as a whole - calibrate to the same amax) and every op writing it is an int8 conv (whose epilogue then emits
-    the int8 copy for free).  Its fp16 form is still written if anything else reads it: fp16 ops (transposed convs,
+    the int8 copy for free) or the fp16 image conv in its tiled form (which can, round 6).  Its fp16 form is still written if anything else reads it: fp16 ops (transposed convs,
     pools, the head, residual adds, the decode), the caller (feature maps), or an int8 conv with a different scale."""
     info = {}
 
@@ -125,7 +125,8 @@ def plan_twins(pb):
         for w in wr:
             s = slot(w)
             if s is not None:
-                s["i8_writes" if e["kind"] == "conv_i8" else "other_writes"] += 1
+                # (the fp16 image conv can write the twin too: engine.PlanBuilder._stem, round 6)
+                s["i8_writes" if (e["kind"] == "conv_i8" or (e["kind"] == "stem" and e.get("twin_ok"))) else "other_writes"] += 1
     for r in pb.fp16_reads:
         s = slot(r)
         if s is not None:
