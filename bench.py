@@ -611,7 +611,12 @@ def mock_infer(args, rep):
 def _child_line(argv, timeout):
     """Run this file again with `argv` in a child process (its own supervisor included) and return its JSON line."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout)
+    # (a sub-bench is a one-GPU job of its own: it must not inherit a launcher's rendezvous - RANK / WORLD_SIZE / MASTER_* of a
+    # one-rank torchrun launch would make it join the parent's process group)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "Y6_FORCE_DIST", "Y6_BENCH_CHILD", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout, env=env)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not line:
         raise RuntimeError((r.stderr or r.stdout)[-400:])

@@ -233,7 +233,7 @@ def test_bench_under_torchrun_with_a_one_rank_rccl_group(mode):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    extra = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-train-sub", "--dropin-steps", "0"] if mode == "infer" else \
+    extra = ["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-train-sub", "--no-config-subs", "--dropin-steps", "0"] if mode == "infer" else \
         ["--mode", "train", "--steps", "3", "--warmup", "2"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra
