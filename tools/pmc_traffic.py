@@ -10,7 +10,7 @@ out = sys.argv[1]
 def classify(name):
     if "conv1x1_stream_kernel" in name:
         return "conv1x1s1"
-    m = re.search(r"conv3x3_wreg_kernel<\d+, \d+, \d+, (\d)>", name)   # conv_wreg.hip: <PF, WC, WP, stride>
+    m = re.search(r"conv3x3_wreg_kernel<\d+, \d+, \d+, (\d)[,>]", name)   # conv_wreg.hip: <PF, WC, WP, stride>
     if m:
         return "conv3x3s%s" % m.group(1)
     if "conv3x3_dma_kernel" in name:     # conv_dma.hip: <..., I8, stride[, resident weights]> (builds before the flag end at the stride)
