@@ -633,6 +633,20 @@ typedef struct y6_wgrad_nhwc_desc {
 } y6_wgrad_nhwc_desc;
 int y6_wgrad_nhwc_supported(const y6_wgrad_nhwc_desc* d);
 int y6_wgrad_nhwc(const y6_wgrad_nhwc_desc* d, void* stream);
+/* Planning queries, host arithmetic only (they also run on a machine without a GPU; tests/test_host_cpu.py property-tests them):
+ * which kernel a descriptor gets - 0 none (keep y6_wgrad), 1 the flat-index kernel (csrc/wgrad_flat.hip), 2 the row ring - and,
+ * for the flat kernel, its geometry: the padded flat index (row pitch W+1, plane (H+1)(W+1) over the OUTPUT grid; 1x1: W, H*W),
+ * chunk size and count, block tile, stage images, LDS, slices of the flat range and the bytes of partial tiles they leave. */
+typedef struct y6_wgrad_flat_geom {
+    int32_t row_pitch, plane, flat_positions;
+    int32_t chunk, chunks;
+    int32_t tile_m, tile_n, tiles;
+    int32_t x_positions, stages;
+    int32_t slices, chunks_per_slice;
+    uint64_t lds_bytes, partial_bytes;
+} y6_wgrad_flat_geom;
+int y6_wgrad_nhwc_route(const y6_wgrad_nhwc_desc* d);
+int y6_wgrad_flat_geometry(const y6_wgrad_nhwc_desc* d, y6_wgrad_flat_geom* out);
 
 /* Per-step weight preparation: every packed fp16 MFMA weight image the step's convs read is rebuilt from the fp32
  * master parameters by ONE launch over a device job table.

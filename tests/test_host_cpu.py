@@ -1024,3 +1024,75 @@ def test_result_ring_slots_count_views_in_every_grad_mode():
             assert not c.is_inference()
     with torch.inference_mode():
         assert not _ResultRing.counts_views(torch.empty(3))      # what the per-slot probe exists for
+
+
+def test_wgrad_flat_routing_and_geometry_properties():
+    """The weight-gradient planning queries of the C ABI (host arithmetic, no GPU): which kernel a conv's weight gradient gets
+    (y6_wgrad_nhwc_route: 1 flat-index kernel, 2 row ring, 0 neither = the plane-fed kernel stays) and the flat kernel's geometry
+    (y6_wgrad_flat_geometry), over the YOLOv6 training shapes and random ones.  Invariants: the padded flat index covers the batch,
+    the chunks tile it, the slices tile the chunks, the stages fit the LDS (160 KiB double-buffered; 80 KiB single-buffered at
+    stride 2), the partial tiles fit the workspace."""
+    import ctypes as C
+    import random
+    from yolov6_amd import _lib
+    lib = _lib.load()
+
+    def desc(K, cin, cout, B, H, W, stride=1, ws=256 << 20, dilated=False):
+        d = _lib.WgradNhwcDesc()
+        Ho, Wo = ((H - 1) // 2 + 1, (W - 1) // 2 + 1) if stride == 2 else (H, W)
+        dh, dw = (H, W) if dilated else (Ho, Wo)
+        d.ksize, d.M, d.N, d.stride = K, cout, cin, stride
+        d.dy = _lib.Tensor(C.c_void_p(4096), B, dh, dw, cout, cout, 0)
+        d.x = _lib.Tensor(C.c_void_p(8192), B, H, W, cin, cin, 0)
+        d.out = 16384                       # (never dereferenced: host arithmetic only)
+        d.sm, d.sn, d.st = cin * K * K, K * K, 1
+        d.workspace, d.workspace_bytes = C.c_void_p(1 << 20), ws
+        return d, Ho, Wo
+
+    # the routing of the YOLOv6-S b64 layers (measured: profiles/r06/wgrad_bench_r06i.json)
+    want = {(3, 256, 256, 40): 1, (3, 512, 512, 20): 1, (3, 128, 128, 80): 1, (1, 256, 256, 40): 1, (3, 64, 64, 160): 2, (3, 64, 64, 80): 2,
+            (3, 128, 128, 40): 1, (1, 64, 64, 160): 2}
+    for (K, cin, cout, hw), route in want.items():
+        d, _, _ = desc(K, cin, cout, 64, hw, hw)
+        assert lib.y6_wgrad_nhwc_route(C.byref(d)) == route, (K, cin, cout, hw)
+    # stride 2: the flat kernel or nothing (the row ring has no stride-2 form); outputs wider than 48 keep the plane-fed kernel
+    d, _, _ = desc(3, 128, 256, 64, 80, 80, stride=2, dilated=True)
+    assert lib.y6_wgrad_nhwc_route(C.byref(d)) == 1
+    d, _, _ = desc(3, 64, 128, 64, 160, 160, stride=2)
+    assert lib.y6_wgrad_nhwc_route(C.byref(d)) == 0
+    d, _, _ = desc(1, 64, 128, 64, 160, 160, stride=2)
+    assert lib.y6_wgrad_nhwc_route(C.byref(d)) == 1
+
+    rnd = random.Random(7)
+    seen = 0
+    for _ in range(400):
+        K = rnd.choice((1, 3))
+        stride = rnd.choice((1, 1, 2))
+        cin, cout = 8 * rnd.randint(1, 64), 8 * rnd.randint(1, 64)
+        B, H, W = rnd.randint(1, 64), 2 * rnd.randint(1, 60), 2 * rnd.randint(1, 60)
+        ws = rnd.choice((4 << 20, 64 << 20, 256 << 20))
+        d, Ho, Wo = desc(K, cin, cout, B, H, W, stride=stride, ws=ws, dilated=rnd.random() < 0.5)
+        g = _lib.WgradFlatGeom()
+        rc = lib.y6_wgrad_flat_geometry(C.byref(d), C.byref(g))
+        if rc != 0:
+            continue
+        seen += 1
+        T = K * K
+        if K == 3:
+            assert g.row_pitch == Wo + 1 and g.plane == (Ho + 1) * (Wo + 1)
+        else:
+            assert g.row_pitch == Wo and g.plane == Ho * Wo
+        assert g.flat_positions == B * g.plane < (1 << 24)
+        assert g.chunk == 128 and (g.chunks - 1) * g.chunk < g.flat_positions <= g.chunks * g.chunk
+        assert g.tile_m in (64, 128) and g.tile_n in (32, 64) and g.tiles == -(-cout // g.tile_m) * -(-cin // g.tile_n)
+        assert 1 <= g.slices and (g.slices - 1) * g.chunks_per_slice < g.chunks <= g.slices * g.chunks_per_slice
+        assert g.slices * g.tiles <= 512 + g.tiles                      # one round of blocks over the chip
+        assert g.partial_bytes == g.slices * T * cout * cin * 4 <= ws
+        if K == 3 and stride == 2:
+            assert g.stages == 1 and g.lds_bytes <= 80 * 1024 and Wo <= 48 and g.tile_n == 32
+            assert g.x_positions >= g.chunk + g.row_pitch + 1
+        else:
+            assert g.stages == 2 and g.lds_bytes <= 160 * 1024 and g.tile_n == 64
+            assert g.x_positions >= (g.chunk + 2 * g.row_pitch + 24 if K == 3 else g.chunk)
+        assert g.x_positions % 16 == 0
+    assert seen > 100

@@ -166,6 +166,12 @@ class WgradNhwcDesc(C.Structure):
                 ("workspace_bytes", C.c_size_t)]
 
 
+class WgradFlatGeom(C.Structure):
+    _fields_ = [("row_pitch", C.c_int32), ("plane", C.c_int32), ("flat_positions", C.c_int32), ("chunk", C.c_int32), ("chunks", C.c_int32),
+                ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tiles", C.c_int32), ("x_positions", C.c_int32), ("stages", C.c_int32),
+                ("slices", C.c_int32), ("chunks_per_slice", C.c_int32), ("lds_bytes", C.c_uint64), ("partial_bytes", C.c_uint64)]
+
+
 class PackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("kind", C.c_int32), ("Cout", C.c_int32), ("Cin", C.c_int32),
                 ("K", C.c_int32), ("first", C.c_uint64)]
@@ -208,7 +214,7 @@ STRUCTS = {
     "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
-    "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc,
+    "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
     "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_head_pack_desc": HeadPackDesc,
     "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
 }
@@ -271,6 +277,8 @@ SIGNATURES = {
     "y6_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "y6_wgrad_nhwc": (C.c_int, [C.POINTER(WgradNhwcDesc), C.c_void_p]),
     "y6_wgrad_nhwc_supported": (C.c_int, [C.POINTER(WgradNhwcDesc)]),
+    "y6_wgrad_nhwc_route": (C.c_int, [C.POINTER(WgradNhwcDesc)]),
+    "y6_wgrad_flat_geometry": (C.c_int, [C.POINTER(WgradNhwcDesc), C.POINTER(WgradFlatGeom)]),
     "y6_pack_job_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "y6_pack_weights_batched": (C.c_int, [C.POINTER(PackBatchDesc), C.c_void_p]),
     "y6_sppf_pool_backward": (C.c_int, [C.POINTER(SppfBwdDesc), C.c_void_p]),

@@ -825,6 +825,12 @@ extern "C" int y6_plan_add_wgrad(y6_plan* p, const y6_wgrad_desc* d) {
 
 extern "C" int y6_wgrad_nhwc_supported(const y6_wgrad_nhwc_desc* d) { return wgrad_nhwc_unsupported(d) == nullptr ? 1 : 0; }
 
+// 0: no NHWC-fed kernel takes the descriptor (the caller keeps the plane-fed y6_wgrad), 1: the flat-index kernel, 2: the row ring
+extern "C" int y6_wgrad_nhwc_route(const y6_wgrad_nhwc_desc* d) {
+    if (wgrad_nhwc_unsupported(d) != nullptr) return 0;
+    return use_flat(d) ? 1 : 2;
+}
+
 extern "C" int y6_wgrad_nhwc(const y6_wgrad_nhwc_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
     return wgrad_nhwc_launch(d, (hipStream_t)stream);

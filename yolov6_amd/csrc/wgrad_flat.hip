@@ -475,6 +475,21 @@ bool flat_geom(const y6_wgrad_nhwc_desc* d, FlatGeom* g) {
     return g->lds <= 160u * 1024;                      // (4-wave blocks: two per CU while their stages stay below 80 KiB)
 }
 
+// slices of the flat range: one round of blocks over the chip (256 CUs x 1 block of 8 waves or 2 blocks of 4), a slice no shorter
+// than 4 chunks, as many as the workspace holds partial tile sets for
+void flat_split(const y6_wgrad_nhwc_desc* d, const FlatGeom& g, long tiles, int* nsplit_out, int* chunks_per_out) {
+    const bool s2k3 = d->ksize == 3 && g.stride == 2;
+    const size_t per = (size_t)d->ksize * d->ksize * d->M * d->N;
+    const long slots = s2k3 ? 512 : ((g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512);
+    long nsplit = slots / tiles;
+    if (nsplit > g.nchunks / 4) nsplit = g.nchunks / 4;
+    const long max_by_ws = (long)(d->workspace_bytes / (per * sizeof(float)));
+    if (nsplit > max_by_ws) nsplit = max_by_ws;
+    if (nsplit < 1) nsplit = 1;
+    *chunks_per_out = (int)((g.nchunks + nsplit - 1) / nsplit);
+    *nsplit_out = (int)((g.nchunks + *chunks_per_out - 1) / *chunks_per_out);
+}
+
 }  // namespace
 
 bool wgrad_nhwc_view_ok(const y6_tensor& t);          // wgrad.hip
@@ -493,6 +508,7 @@ const char* wgrad_flat_unsupported(const y6_wgrad_nhwc_desc* d) {
     }
     if (d->M < 1 || d->N < 1 || d->dy.C < d->M || d->x.C < d->N) return "views narrower than M / N";
     if (d->N % 4 != 0 || (((uintptr_t)d->workspace) & 15) != 0) return "N must be a multiple of 4 and the workspace 16-byte aligned (the slice sum reads float4)";
+    if (!d->workspace || d->workspace_bytes < (size_t)d->ksize * d->ksize * d->M * d->N * sizeof(float)) return "workspace missing or smaller than one partial tile set";
     FlatGeom g;
     if (!flat_geom(d, &g)) return "map too wide (or batch too large) for the flat stages";
     return nullptr;
@@ -525,16 +541,8 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
     const long tiles = (long)a.mt2 * a.nt2;
     const size_t per = (size_t)T * d->M * d->N;
     Y6_REQUIRE(d->workspace && d->workspace_bytes >= per * sizeof(float), "wgrad_flat: workspace missing or too small");
-    // one round of blocks over the chip (256 CUs x 1 block of 8 waves or 2 blocks of 4), a slice no shorter than 4 chunks
     const bool s2k3 = d->ksize == 3 && g.stride == 2;
-    const long slots = s2k3 ? 512 : ((g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512);
-    long nsplit = slots / tiles;
-    if (nsplit > g.nchunks / 4) nsplit = g.nchunks / 4;
-    const long max_by_ws = (long)(d->workspace_bytes / (per * sizeof(float)));
-    if (nsplit > max_by_ws) nsplit = max_by_ws;
-    if (nsplit < 1) nsplit = 1;
-    a.chunks_per = (int)((g.nchunks + nsplit - 1) / nsplit);
-    a.nsplit = (int)((g.nchunks + a.chunks_per - 1) / a.chunks_per);
+    flat_split(d, g, tiles, &a.nsplit, &a.chunks_per);
     a.ws = (float*)d->workspace;
     const unsigned grid = (unsigned)(8 * ((a.nsplit + 7) / 8) * tiles);
     static bool attr_set = false;
@@ -566,5 +574,28 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
     if (rg > 8192) rg = 8192;
     hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3(rg), dim3(256), 0, s, a.ws, a.nsplit, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
     Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// Host-only planning query (no launch, no pointer dereferenced): the flat kernel's geometry for a descriptor it takes.
+extern "C" int y6_wgrad_flat_geometry(const y6_wgrad_nhwc_desc* d, y6_wgrad_flat_geom* out) {
+    Y6_REQUIRE(d && out, "wgrad_flat_geometry: null argument");
+    const char* why = wgrad_flat_unsupported(d);
+    if (why) {
+        y6_set_error("wgrad_flat_geometry: %s", why);
+        return Y6_EUNSUPPORTED;
+    }
+    FlatGeom g;
+    flat_geom(d, &g);
+    memset(out, 0, sizeof(*out));
+    out->row_pitch = g.Wp, out->plane = g.Pp, out->flat_positions = g.total;
+    out->chunk = g.kc, out->chunks = g.nchunks;
+    out->tile_m = g.nwm * 32, out->tile_n = g.tn;
+    out->tiles = y6_cdiv(d->M, g.nwm * 32) * y6_cdiv(d->N, g.tn);
+    out->x_positions = g.xpos;
+    out->stages = (d->ksize == 3 && g.stride == 2) ? 1 : 2;
+    out->lds_bytes = g.lds;
+    flat_split(d, g, out->tiles, &out->slices, &out->chunks_per_slice);
+    out->partial_bytes = (uint64_t)out->slices * d->ksize * d->ksize * d->M * d->N * sizeof(float);
     return Y6_OK;
 }
