@@ -47,3 +47,51 @@ def test_reference_checkpoint_runs_on_hip_path():
         for k in [k for k in sys.modules if k == "yolov6" or k.startswith("yolov6.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+@pytest.mark.gpu
+def test_torch_library_ops_equal_the_module_mirrors_and_trace_under_torch_compile():
+    """`torch.ops.yolov6_hip.*` (yolov6_amd/torch_ops.py) call the same kernels as the module mirrors: bit-equal results; a function
+    that calls them is traceable by torch.compile (the op stays an opaque call; backend aot_eager: no code generation involved)."""
+    import numpy as np
+    import torch.nn.functional as F
+    import yolov6_amd.torch_ops  # noqa: F401
+    from oracle import synth
+    from yolov6_amd.assigners import ATSSAssigner, TaskAlignedAssigner, generate_anchors
+    from yolov6_amd.utils.nms import nms_raw
+    from yolov6_amd.utils.synth import synth_predictions
+    dev = "cuda:0"
+    ns = torch.ops.yolov6_hip
+    pred = synth_predictions(3, 2100, 80, seed=3).to(dev)
+    want = nms_raw(pred, 0.03, 0.65, None, False, True, 300)
+    got = ns.nms_batched(pred, 0.03, 0.65, None, False, True, 300)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+    def f(p):
+        d, i, c = ns.nms_batched(p * 1.0, 0.03, 0.65, None, False, True, 300)
+        return d.sum(-1), c
+    cf = torch.compile(f, backend="aot_eager", fullgraph=True)
+    a, b = cf(pred), f(pred)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+    fs, st = [(20, 20), (10, 10), (5, 5)], [8, 16, 32]
+    inp = synth.synth_tal_inputs(2, fs, st, 80, 9, seed=5, n_valid=[9, 4], img=160)
+    keys = ("pd_scores", "pd_bboxes", "anc_points", "gt_labels", "gt_bboxes", "mask_gt")
+    want = TaskAlignedAssigner(13, 80, 1.0, 6.0)(*(inp[k].to(dev) for k in keys))
+    got = ns.tal_assign(*(inp[k].to(dev) for k in keys), 13, 1.0, 6.0, 1e-9)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    anchors, _, n_list, _ = generate_anchors([torch.zeros(1, 1, h, w) for h, w in fs], st, 5.0, 0.5, device="cpu", is_eval=False)
+    args = (anchors.to(dev), n_list, inp["gt_labels"].to(dev), inp["gt_bboxes"].to(dev), inp["mask_gt"].to(dev), inp["pd_bboxes"].to(dev))
+    want = ATSSAssigner(9, 80)(*args)
+    got = ns.atss_assign(*args, 9, 80)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand((2, 32, 24, 40), generator=g) - 0.5).half()
+    w = (torch.rand((64, 32, 3, 3), generator=g) - 0.5) * 0.2
+    bias = torch.rand((64,), generator=g) - 0.5
+    y = ns.conv2d_bias_act(x.to(dev), w.to(dev), bias.to(dev), "relu", 1)
+    ref = F.relu(F.conv2d(x.float(), w.half().float(), bias.half().float(), padding=1))
+    err = float((y.float().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert y.shape == ref.shape and err <= 2e-3, err

@@ -1096,3 +1096,26 @@ def test_wgrad_flat_routing_and_geometry_properties():
             assert g.x_positions >= (g.chunk + 2 * g.row_pitch + 24 if K == 3 else g.chunk)
         assert g.x_positions % 16 == 0
     assert seen > 100
+
+
+def test_torch_library_seam_registers_the_stateless_operators():
+    """yolov6_amd/torch_ops.py (`TORCH_LIBRARY(yolov6_hip, m)`): the stateless operators are dispatcher-visible custom
+    ops with schemas and fake kernels (shape inference without a GPU); there is no CPU kernel - a CPU tensor raises a RuntimeError
+    (NotImplementedError is one), never a fallback."""
+    import yolov6_amd.torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ns = torch.ops.yolov6_hip
+    for name in ("nms_batched", "tal_assign", "atss_assign", "conv2d_bias_act"):
+        assert hasattr(ns, name), name
+    assert "(Tensor, Tensor, Tensor)" in str(ns.nms_batched.default._schema)
+    with FakeTensorMode():
+        d, i, c = ns.nms_batched(torch.empty(2, 100, 85, device="cuda"), 0.03, 0.65, None, False, True, 300)
+        assert d.shape == (2, 300, 6) and i.dtype == torch.int32 and c.shape == (2,)
+        lab, box, sc, fg = ns.tal_assign(torch.empty(2, 50, 80, device="cuda"), torch.empty(2, 50, 4, device="cuda"), torch.empty(50, 2, device="cuda"),
+                                         torch.empty(2, 7, 1, device="cuda"), torch.empty(2, 7, 4, device="cuda"), torch.empty(2, 7, 1, device="cuda"),
+                                         13, 1.0, 6.0, 1e-9)
+        assert lab.shape == (2, 50) and lab.dtype == torch.int64 and sc.shape == (2, 50, 80) and fg.dtype == torch.bool
+        y = ns.conv2d_bias_act(torch.empty(2, 16, 20, 24, device="cuda", dtype=torch.float16), torch.empty(32, 16, 3, 3), None, "relu", 2)
+        assert y.shape == (2, 32, 10, 12) and y.dtype == torch.float16
+    with pytest.raises(RuntimeError):
+        ns.nms_batched(torch.zeros(1, 10, 85), 0.03, 0.65, None, False, True, 300)
