@@ -27,6 +27,7 @@ SOURCES = {
     "conv_mfma.hip": [],
     "conv_dma.hip": [],
     "conv_wreg.hip": [],
+    "conv_pw.hip": [],
     "conv_misc.hip": [],
     "conv_fused.hip": [],
     "preproc.hip": ["-ffp-contract=off"],

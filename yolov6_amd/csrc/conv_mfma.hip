@@ -893,6 +893,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(const ConvKArgs 
 //                              LDS-DMA fed 3x3 kernels (conv_dma.hip); depth = LDS stages, hc = channels per chunk, cs = stride
 //   wreg_p{4,5,6,7}, wregs2_p{3,4}   weights through registers, halo in 32-channel LDS stages (conv_wreg.hip), stride 1 / 2:
 //                              cf = waves along the couts (32 each), pf = pixel fragments per wave, two 4-wave blocks per CU
+//   pw_c4p2 / pw_c2p2          1x1 stride 1 with the whole reduction in LDS (conv_pw.hip)
 const VariantCfg kVariants[] = {
     {0, 0, 0, "naive"},     {1, 1, 0, "mfma_c1p1"}, {2, 1, 0, "mfma_c2p1"}, {4, 1, 0, "mfma_c4p1"},
     {1, 2, 0, "mfma_c1p2"}, {2, 2, 0, "mfma_c2p2"}, {4, 2, 0, "mfma_c4p2"},
@@ -910,7 +911,10 @@ const VariantCfg kVariants[] = {
     {4, 3, 6, "wregs2_p3", 4, 1, 2, 16, 2}, {4, 4, 6, "wregs2_p4", 4, 1, 2, 16, 2},
     // int8 only (y6_conv_i8 variant 13): 64-cout blocks of the register-fed stride-2 kernel - two cout waves x two pixel waves,
     // 128 pixel slots
-    {2, 2, 6, "i8_wreg2s2_p2", 4, 1, 2, 16, 2, 0, 1}};
+    {2, 2, 6, "i8_wreg2s2_p2", 4, 1, 2, 16, 2, 0, 1},
+    // conv_pw.hip (round 6): 1x1 stride 1, the whole reduction of a 64- / 128-pixel tile requested at once; cf = cout waves, pf = pixel
+    // fragments per wave: 128 couts x 64 pixels / 64 couts x 128 pixels per block
+    {4, 2, 7, "pw_c4p2", 4}, {2, 2, 7, "pw_c2p2", 4}};
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 static int variant_index(const char* name) {
     for (int i = 0; i < kNumVariants; ++i)
@@ -1047,7 +1051,7 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
     k.upH = d->in.H;
     k.upW = d->in.W;
     k.upC = up == 2 ? d->out.C / 4 : d->out.C;
-    const int bp = vc.persist == 6 ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
+    const int bp = (vc.persist == 6 || vc.persist == 7) ? 32 * vc.pf * (vc.nw / vc.cf) : 32 * vc.nw * vc.pf;
     if (ks == 1) {
         // a 1x1 conv is a GEMM over flattened pixels: one "image" of one row
         const long npix = (long)d->in.B * d->in.H * d->in.W;
@@ -1391,6 +1395,14 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         if (y6_tensor_elems(d->in) >= (size_t)1 << 31 || y6_tensor_elems(d->out) >= (size_t)1 << 31) return 0;
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
+    if (vc.persist == 7) {   // conv_pw.hip: whole 64-channel stages, whole cout blocks, plain bias + activation into a 16-byte aligned view
+        if (ks != 1 || st != 1 || d->w_packed == nullptr || d->res.data != nullptr || d->post_scale != nullptr) return 0;
+        if (!y6_conv_pw_cin_ok(d->in.C, 32 * vc.pf * (vc.nw / vc.cf)) || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
+        if (d->out.cstride % 8 || d->out.coff % 8 || ((uintptr_t)d->out.data & 15)) return 0;
+        if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
+        if (y6_tensor_elems(d->in) * 2 >= 0xe0000000ull || y6_tensor_elems(d->out) * 2 >= 0xe0000000ull) return 0;
+        return 1;
+    }
     if (vc.persist && ks != 3) return 0;
     if (vc.persist == 6) {   // weights through registers: whole 32-channel stages, whole cout blocks, 16-byte pieces straight from the tensor
         if (st != vc.cs || d->w_packed == nullptr) return 0;
@@ -1488,6 +1500,8 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
             return y6_conv_dma_launch(&L, vc.cf, vc.pf, vc.nw, vc.depth, vc.st, vc.hc, vc.cs, 0, vc.wres, s);
         case 6:
             return y6_conv_wreg_launch(&L, vc.pf, vc.cf, vc.nw / vc.cf, vc.cs, 0, s);
+        case 7:
+            return y6_conv_pw_launch(&L, vc.cf, vc.pf, s);
     }
     return Y6_EINVAL;
 }

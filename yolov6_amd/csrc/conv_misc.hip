@@ -688,6 +688,14 @@ int y6_conv_default_variant(const y6_conv_desc* d) {
         if (first > 0 && y6_conv_variant_supports(d, first)) return first;
         if (d->stride == 1 && p4 > 0 && y6_conv_variant_supports(d, p4)) return p4;
     }
+    if (d->ksize == 1 && d->stride == 1) {
+        // round 6: the whole-reduction 1x1 kernel (conv_pw.hip) wherever it applies - 128-cout blocks, else 64-cout blocks.
+        // Y6_CONV_PW=0: A/B switch (the per-tap kernel of round 1)
+        static const bool pw_on = getenv("Y6_CONV_PW") ? atoi(getenv("Y6_CONV_PW")) != 0 : true;
+        static const int pw4 = variant_by_name("pw_c4p2"), pw2 = variant_by_name("pw_c2p2");
+        if (pw_on && pw4 > 0 && y6_conv_variant_supports(d, pw4)) return pw4;
+        if (pw_on && pw2 > 0 && y6_conv_variant_supports(d, pw2)) return pw2;
+    }
     // then (profiles/r02 autotune logs) the LDS-DMA kernels on 3x3 stride 1 - 256-pixel blocks when there are at least two of
     // them per CU slot, else 128-pixel blocks - then round 1's pipelined kernel; elsewhere high-occupancy small tiles win
     const long items256 = (px + 255) / 256 * ((d->out.C + 63) / 64);

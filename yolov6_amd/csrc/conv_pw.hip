@@ -1,0 +1,314 @@
+// conv_pw.hip - 1x1 convolution (stride 1) as a latency-lean GEMM: the WHOLE reduction of a block's pixel tile is requested at
+// once (LDS-DMA in full 128-byte lines), the weights stream global -> VGPR, one block barrier in front of the matrix loop.
+//
+// Replaces the same aten composition as conv_mfma.hip's per-tap kernel for ksize 1 (reference yolov6/layers/common.py:51-54
+// ConvModule.forward_fuse behind ConvBNReLU / ConvBNSiLU: the CSP-SPPF convs common.py:140-176, the neck's reduce / BiFusion convs
+// reppan.py:215-237, the head stems effidehead.py:166-170) - 14 launches of a YOLOv6-S step.
+//
+// Why another kernel (round 6).  The per-tap kernel walks the reduction in 32-channel chunks: a chunk is four MFMAs per wave between
+// two block barriers, its pixel piece prefetched ONE chunk ahead through registers - every chunk pays a full global-memory round
+// trip, sixteen in a row for Cin = 512 (profiles/r06/ops_driver_r06ev.json: 512 -> 256 @20x20 b32, 3.4 GFLOP / 20 MB, 21.7 us; the
+// bytes are 4 us of HBM time and the FLOPs 3 us of the matrix pipe).  The 1x1 launches are latency, not throughput.  Here
+//   * a block owns TP = 64 / 128 pixels x TC = 128 / 64 couts and asks for its whole [TP][Cin] pixel image in the prologue - Cin / 64
+//     stages of [pixel][128 B], each request 8 pixel rows x 128 B = eight whole cache lines (the per-tap kernel's pieces and the
+//     streaming kernel's fragment-shaped loads touch 32-byte quarters of 32 lines) - so the memory round trip is paid ONCE;
+//   * LDS image of a stage: [pixel][eight 16-byte slots], slot = piece ^ ((pixel >> 1) & 7), the swizzle applied on the SOURCE side
+//     of the request (a lane may ask for any 16 bytes): the sixteen lanes ds_read_b128 serves per cycle (16 consecutive pixels, one
+//     k-half) land on sixteen different bank groups; no pad bytes, so a request writes 1 KiB of contiguous LDS;
+//   * a wave owns one 32-cout fragment x PF pixel fragments; its weight fragments (1 KiB per k-step, contiguous in the packed
+//     weights) go global -> VGPR through a ring of up to sixteen loads (a k-step is only PF MFMAs: the ring has to cover the L2
+//     latency by depth) and never touch LDS;
+//   * ONE wait + barrier (everything this wave asked for has landed), then Cin / 16 k-steps without any block-wide
+//     synchronisation; the reduction is fully unrolled (Cin / 64 is a template parameter: 1, 2, 3, 4, 6, 8, 16);
+//   * epilogue: bias + activation in conv_common.hpp's arithmetic, the fp16 tile staged through the (dead) pixel
+//     image and written as whole NHWC rows - 16 lanes x 16 B per pixel row of 128 couts.
+// Vector-memory ordering follows conv_wreg.hip's rule: requests and VGPR loads are awaited TOGETHER (vmcnt(0)) where both are in
+// flight; counted waits appear only where nothing but weight loads is outstanding.
+#include "common.hpp"
+#include "conv_common.hpp"
+#include <type_traits>
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void pw_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pw_static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void pw_load_frag(i32x4_t& dst, const i32x4_t& rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pw_wait_frag(i32x4_t& frag) {
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void pw_lds_read16(i32x4_t& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(IMM) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void pw_wait_lds(i32x4_t& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
+}
+
+// NK: Cin / 64 (stages of 128 bytes per pixel).  WC x WP = 4 waves: WC along the couts (32 each), WP along the pixels (PF fragments
+// of 32 each).  ConvKArgs as conv_mfma.hip's build_launch fills it for a 1x1 conv: W = flattened pixel count, TW = TP, ntiles, ncb, nids.
+template <int NK, int WC, int WP, int PF>
+__global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
+    constexpr int TP = WP * PF * 32, TC = WC * 32;
+    constexpr int NKS = NK * 4;                       // k-steps of 16 channels
+    constexpr int R = NKS < 16 ? NKS : 16;            // weight fragments in flight per wave
+    constexpr int LA = 2;                             // k-steps of pixel fragments requested ahead of the MFMAs
+    constexpr int NREQ = NK * (TP / 8);               // 1 KiB requests of the block's pixel image
+    constexpr int NREQW = NREQ / 4;                   // per wave
+    constexpr int OP = TC * 2 + 16;                   // row pitch of the staged output tile
+    static_assert(WC * WP == 4 && NREQ % 4 == 0 && (TP / 8) % 4 == 0, "four waves share the requests; a wave's pixel groups have one parity");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave % WC, wp = wave / WC;
+
+    // ---- block -> (pixel tile, cout block); the cout blocks of one tile share an XCD (id % 8)
+    int tile, cb;
+    {
+        const int id = blockIdx.x;
+        if (a.ncb == 1) {
+            tile = id;
+            cb = 0;
+        } else {
+            const int lo = id & 7, r = id >> 3;
+            cb = r % a.ncb;
+            tile = (r / a.ncb) * 8 + lo;
+        }
+    }
+    if (tile >= a.ntiles) return;
+    const int npix = a.W;
+    const int pix0 = tile * TP;
+    const unsigned smem_base = lds_addr(smem);
+    const unsigned rowB = (unsigned)a.in_cs * 2u;
+
+    const i32x4_t rsA = make_rsrc(a.in, (unsigned)((size_t)npix * a.in_cs * 2));
+    const i32x4_t rsW = make_rsrc(a.wpk, 0xfffffe00u);
+
+    // ---- the pixel image.  Request q = wave + 4 i covers stage s = q / (TP / 8), pixel group g = q % (TP / 8): lane l asks for
+    //      piece (l & 7) ^ swz of pixel 8 g + (l >> 3), swz = ((8 g + (l >> 3)) >> 1) & 7 = ((l >> 4) + 4 g) & 7; g has the wave's parity.
+    {
+        const unsigned pl = (unsigned)(lane >> 3);
+        const unsigned piece = ((unsigned)(lane & 7) ^ (((unsigned)(lane >> 4) + 4u * (unsigned)(wave & 1)) & 7u));
+        const unsigned vlane = ((unsigned)pix0 + pl) * rowB + piece * 16u;   // (the tile's origin in the VECTOR offset: kOob + scalar offset must not wrap)
+        const unsigned sbase = (unsigned)a.in_co * 2u;
+#pragma unroll
+        for (int i = 0; i < NREQW; ++i) {
+            const int q = wave + 4 * i;
+            const int s = q / (TP / 8), g = q % (TP / 8);
+            const bool v = pix0 + 8 * g + (int)pl < npix;
+            const unsigned voff = v ? vlane + (unsigned)(8 * g) * rowB : kOob;
+            dma16(rsA, voff, sbase + (unsigned)s * 128u, smem_base + (unsigned)(s * TP + 8 * g) * 128u);
+        }
+    }
+    // ---- the first R weight fragments of this wave's cout fragment
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)((cb * WC + wc) * NKS) * 1024u;
+    i32x4_t wr[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) pw_load_frag(wr[u], rsW, lane16, wbase + (unsigned)(u * 1024));
+
+    // the bias of this lane's sixteen couts (8 g + 4 (lane >> 5) .. + 3 of the wave's fragment), behind the same wait; a null bias is a
+    // descriptor of zero records: the loads return zeros
+    i32x4_t bzr[4];
+    {
+        const i32x4_t rsB = make_rsrc(a.bias, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
+        const unsigned bo = (unsigned)((cb * WC + wc) * 32 + 4 * (lane >> 5)) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pw_load_frag(bzr[g], rsB, bo + (unsigned)(g * 32), 0u);
+    }
+
+    // this lane's pixels: LDS address of k-step (kk & 3) of stage 0
+    const int fq = frag_pixel(lane & 31);
+    unsigned baddr[PF][4];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const unsigned p = (unsigned)(wp * (PF * 32) + pf * 32 + fq);
+        const unsigned swz = (p >> 1) & 7u;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) baddr[pf][k4] = smem_base + p * 128u + ((((unsigned)(k4 * 2) + (unsigned)(lane >> 5)) ^ swz) * 16u);
+    }
+
+    f32x16_t acc[PF];
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+
+    // everything this wave asked for (its share of the image, its first R weight fragments, the bias) has landed; then everybody's
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // ---- the reduction: NKS k-steps x PF fragment products, pixel fragments LA k-steps ahead, weight fragments R k-steps ahead
+    constexpr int NB = LA + 1;
+    i32x4_t fb[NB][PF];
+    auto frag_read = [&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        constexpr int s = kk >> 2, k4 = kk & 3;
+        constexpr int off = s * TP * 128;
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) pw_lds_read16<(off & 0xffff)>(fb[kk % NB][pf], baddr[pf][k4] + (unsigned)(off & ~0xffff));
+    };
+    pw_static_for<0, (LA < NKS ? LA : NKS)>(frag_read);
+    pw_static_for<0, NKS>([&](auto kc) {
+        constexpr int kk = decltype(kc)::value;
+        if constexpr (kk + LA < NKS) frag_read(std::integral_constant<int, kk + LA>{});
+        // weight fragment kk: the younger weight loads in flight are those of k-steps kk + 1 .. min(kk + R, NKS) - 1
+        if constexpr (kk < R) {
+            asm volatile("" : "+v"(wr[kk % R]));   // landed in front of the barrier
+        } else {
+            pw_wait_frag<(NKS - 1 - kk < R - 1 ? NKS - 1 - kk : R - 1)>(wr[kk % R]);
+        }
+        constexpr int ahead = (NKS - 1 - kk < LA ? NKS - 1 - kk : LA);   // k-steps of pixel fragments requested behind this one
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            switch (PF - 1 - pf + PF * ahead) {   // (compile-time after unrolling)
+                case 0: pw_wait_lds<0>(fb[kk % NB][pf]); break;
+                case 1: pw_wait_lds<1>(fb[kk % NB][pf]); break;
+                case 2: pw_wait_lds<2>(fb[kk % NB][pf]); break;
+                case 3: pw_wait_lds<3>(fb[kk % NB][pf]); break;
+                case 4: pw_wait_lds<4>(fb[kk % NB][pf]); break;
+                case 5: pw_wait_lds<5>(fb[kk % NB][pf]); break;
+                case 6: pw_wait_lds<6>(fb[kk % NB][pf]); break;
+                case 7: pw_wait_lds<7>(fb[kk % NB][pf]); break;
+                case 8: pw_wait_lds<8>(fb[kk % NB][pf]); break;
+                default: pw_wait_lds<9>(fb[kk % NB][pf]); break;
+            }
+            acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[kk % R]), __builtin_bit_cast(h8_t, fb[kk % NB][pf]), acc[pf], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kk + R < NKS) {   // the slot this k-step released
+            pw_load_frag(wr[kk % R], rsW, lane16, wbase + (unsigned)((kk + R) * 1024));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+
+    // ---- epilogue: the block's [TP][TC] fp16 tile through LDS (the pixel image is dead once everybody has left the loop)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        const int kh = lane >> 5;
+        float bias16[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bits = bzr[g][j];   // (a copy: __builtin_bit_cast of the vector-element lvalue itself reads element 0 whatever j is)
+                bias16[g * 4 + j] = __builtin_bit_cast(float, bits);
+            }
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) {
+            float v[16];
+            switch (a.act) {   // one wave-uniform branch per fragment; conv_common.hpp's arithmetic (finish16 without post-affine / residual)
+                case Y6_ACT_RELU:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_RELU>(acc[pf][r] + bias16[r]);
+                    break;
+                case Y6_ACT_SILU:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_SILU>(acc[pf][r] + bias16[r]);
+                    break;
+                case Y6_ACT_HARDSWISH:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_HARDSWISH>(acc[pf][r] + bias16[r]);
+                    break;
+                default:
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[pf][r] + bias16[r];
+                    break;
+            }
+            const int row = wp * (PF * 32) + pf * 32 + fq;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)v[g * 4 + j];
+                *reinterpret_cast<h4_t*>(smem + row * OP + wc * 64 + g * 16 + kh * 8) = o;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const __amdgpu_buffer_rsrc_t rsO =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)npix * a.out_cs * 2), 0x00020000);
+        constexpr int PPR = TC / 8;                  // 16-byte pieces per row
+        constexpr int NPC = TP * PPR / 256;          // pieces per thread
+        const unsigned obase = ((unsigned)pix0 * (unsigned)a.out_cs + (unsigned)a.out_co + (unsigned)(cb * TC)) * 2u;
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int q = tid + 256 * i;
+            const int row = q / PPR, pc = q % PPR;
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * OP + pc * 16);
+            const unsigned ob = pix0 + row < npix ? obase + (unsigned)row * (unsigned)a.out_cs * 2u + (unsigned)pc * 16u : kOob;   // overhang: dropped by the range check
+            __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)ob, 0, 0);
+        }
+    }
+}
+
+template <int NK, int WC, int WP, int PF>
+int launch_pw_nk(const Launch& L, hipStream_t s) {
+    constexpr int TP = WP * PF * 32, TC = WC * 32;
+    auto kern = conv_pw_kernel<NK, WC, WP, PF>;
+    size_t lds = (size_t)TP * NK * 128;
+    const size_t epi = (size_t)TP * (TC * 2 + 16);
+    if (epi > lds) lds = epi;
+    Y6_REQUIRE(lds <= 160 * 1024, "conv_pw: tile needs %zu bytes of LDS", lds);
+    if (lds > 64 * 1024) {
+        static std::mutex mu;
+        static bool big[64] = {};
+        int dev = 0;
+        Y6_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && !big[dev]) {
+            Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            big[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(L.grid), dim3(256), lds, s, L.k);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+template <int WC, int WP, int PF>
+int launch_pw(const Launch& L, hipStream_t s) {
+    switch (L.k.Cin / 64) {
+        case 1: return launch_pw_nk<1, WC, WP, PF>(L, s);
+        case 2: return launch_pw_nk<2, WC, WP, PF>(L, s);
+        case 3: return launch_pw_nk<3, WC, WP, PF>(L, s);
+        case 4: return launch_pw_nk<4, WC, WP, PF>(L, s);
+        case 6: return launch_pw_nk<6, WC, WP, PF>(L, s);
+        case 8: return launch_pw_nk<8, WC, WP, PF>(L, s);
+        case 16: return launch_pw_nk<16, WC, WP, PF>(L, s);
+    }
+    y6_set_error("conv_pw: no instantiation for Cin %d", L.k.Cin);
+    return Y6_EUNSUPPORTED;
+}
+
+}  // namespace
+
+// Cin the kernel is built for (whole 64-channel stages; the reduction is unrolled per instantiation), and the block's whole pixel
+// image [block_pixels][Cin] must fit the CU's LDS
+int y6_conv_pw_cin_ok(int cin, int block_pixels) {
+    if (cin % 64 || (size_t)block_pixels * cin * 2 > 160 * 1024) return 0;
+    switch (cin / 64) {
+        case 1: case 2: case 3: case 4: case 6: case 8: case 16: return 1;
+    }
+    return 0;
+}
+
+// L points at conv_mfma.hip's launch record (conv_common.hpp)
+int y6_conv_pw_launch(const void* Lp, int wc, int pf, hipStream_t s) {
+    const Launch& L = *static_cast<const Launch*>(Lp);
+    if (wc == 4 && pf == 2) return launch_pw<4, 1, 2>(L, s);
+    if (wc == 2 && pf == 2) return launch_pw<2, 2, 2>(L, s);
+    y6_set_error("conv_pw: no instantiation %d cout waves, %d pixel fragments", wc, pf);
+    return Y6_EUNSUPPORTED;
+}
