@@ -311,8 +311,47 @@ def test_conv_epilogue_variants(act):
         assert torch.equal(outbuf.buf[..., :64], before[..., :64]) and torch.equal(outbuf.buf[..., 128:], before[..., 128:])
 
 
-def test_convt2x2():
-    B, H, W, Cin, Cout = 2, 10, 12, 64, 64
+@pytest.mark.parametrize("act", [None, "relu", "silu"])
+@pytest.mark.parametrize("shape", [(128, 128, 23, 19, 2), (192, 64, 40, 40, 3), (512, 256, 20, 20, 2), (1024, 256, 10, 10, 3)])
+def test_conv_pw_epilogues(shape, act):
+    """The whole-reduction 1x1 kernel (csrc/conv_pw.hip): plain, with the residual add (BottleRep / the accumulating data-gradient
+    convs, res == out included) and through channel-slice views; ragged last tile, several cout blocks."""
+    Cin, Cout, H, W, B = shape
+    names = G.variant_names()
+    pw = [v for v, n in enumerate(names) if n.startswith("pw_")]
+    assert len(pw) == 2
+    xin = G.rand_nhwc(B, H, W, Cin, cstride=Cin + 64, coff=32, seed=41)
+    w, b = _mk_weights(Cout, Cin, 1, 42)
+    res = G.rand_nhwc(B, H, W, Cout, cstride=Cout + 32, coff=16, seed=43)
+    alpha = torch.tensor([0.75])
+    outbuf = G.rand_nhwc(B, H, W, Cout + 128, seed=44)
+    before = outbuf.buf.clone()
+    out = outbuf.slice(64, Cout)
+    xn = G.nhwc_to_nchw_f32(xin)
+    ran = 0
+    for v in pw:
+        if not G.supports(xin, w, 1, v):
+            continue
+        ran += 1
+        outbuf.buf.copy_(before)
+        o, _ = G.run_conv(xin, w, b, 1, act, v, out=out)
+        assert G.max_rel(G.nhwc_to_nchw_f32(o), G.conv_reference(xn, w, b, 1, act)) < G.op_tolerance(act), names[v]
+        assert torch.equal(outbuf.buf[..., :64], before[..., :64]) and torch.equal(outbuf.buf[..., 64 + Cout:], before[..., 64 + Cout:])
+        o, _ = G.run_conv(xin, w, b, 1, act, v, out=out, res=res, alpha=alpha)
+        ref = G.conv_reference(xn, w, b, 1, act, None, G.nhwc_to_nchw_f32(res), alpha)
+        assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < G.op_tolerance(act, with_res=True), names[v]
+        # accumulate in place: out += conv (res == out, alpha 1)
+        prev = G.nhwc_to_nchw_f32(out)
+        o, _ = G.run_conv(xin, w, b, 1, act, v, out=out, res=out)
+        ref = G.conv_reference(xn, w, b, 1, act, None, prev, None)
+        assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < G.op_tolerance(act, with_res=True), names[v]
+        assert torch.equal(outbuf.buf[..., :64], before[..., :64]) and torch.equal(outbuf.buf[..., 64 + Cout:], before[..., 64 + Cout:])
+    assert ran >= 1
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 128), (64, 32)])
+def test_convt2x2(cin, cout):
+    B, H, W, Cin, Cout = 2, 10, 12, cin, cout
     x = G.rand_nhwc(B, H, W, Cin, seed=11)
     g = torch.Generator().manual_seed(12)
     w = torch.randn((Cin, Cout, 2, 2), generator=g) / 8

@@ -1396,7 +1396,8 @@ int y6_conv_mfma_supports(const y6_conv_desc* d, int variant) {
         return vc.cf <= y6_cdiv(d->out.C, 32);
     }
     if (vc.persist == 7) {   // conv_pw.hip: whole 64-channel stages, whole cout blocks, plain bias + activation into a 16-byte aligned view
-        if (ks != 1 || st != 1 || d->w_packed == nullptr || d->res.data != nullptr || d->post_scale != nullptr) return 0;
+        if (ks != 1 || st != 1 || d->w_packed == nullptr || d->post_scale != nullptr) return 0;
+        if (d->res.data != nullptr && (d->res.cstride % 8 || d->res.coff % 8 || ((uintptr_t)d->res.data & 15) || y6_tensor_elems(d->res) * 2 >= 0xe0000000ull)) return 0;
         if (!y6_conv_pw_cin_ok(d->in.C, 32 * vc.pf * (vc.nw / vc.cf)) || d->out.C % (32 * vc.cf) || d->in.cstride % 8 || d->in.coff % 8) return 0;
         if (d->out.cstride % 8 || d->out.coff % 8 || ((uintptr_t)d->out.data & 15)) return 0;
         if (((uintptr_t)d->in.data & 15) || ((uintptr_t)d->w_packed & 15)) return 0;
@@ -1472,7 +1473,12 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
                      d->stride, d->in.C, d->out.C);
         return Y6_EUNSUPPORTED;
     }
-    if (kVariants[variant].persist && up) {
+    if (kVariants[variant].persist == 7 && up) {   // conv_pw.hip scatters whole cout blocks of the fused [4 Cout x Cin] form
+        if (up != 2 || d->res.data != nullptr || (d->out.C / 4) % (32 * kVariants[variant].cf) != 0 || y6_tensor_elems(d->out) * 8 >= 0xe0000000ull) {
+            y6_set_error("conv_pw: the convT scatter needs the fused form with whole cout blocks per sub-kernel");
+            return Y6_EUNSUPPORTED;
+        }
+    } else if (kVariants[variant].persist && up) {
         y6_set_error("conv_mfma: persistent variants do not implement the convT scatter");
         return Y6_EUNSUPPORTED;
     }

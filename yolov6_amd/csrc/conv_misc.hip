@@ -750,6 +750,12 @@ double y6_conv_bytes(const y6_conv_desc* d) {
 // variant for a convT (sub-)GEMM: small pixel tiles win (autotune table, profiles/r01); the cout block
 // must not straddle two (dy,dx) sub-kernels in the fused form
 static int convt_variant(const y6_conv_desc* c, int upC, int fused) {
+    if (fused) {   // round 6: the whole-reduction 1x1 kernel scatters whole cout blocks (conv_pw.hip); Y6_CONV_PW=0: A/B switch
+        static const bool pw_on = getenv("Y6_CONV_PW") ? atoi(getenv("Y6_CONV_PW")) != 0 : true;
+        static const int pw4 = variant_by_name("pw_c4p2"), pw2 = variant_by_name("pw_c2p2");
+        if (pw_on && pw4 > 0 && upC % 128 == 0 && y6_conv_mfma_supports(c, pw4) && y6_tensor_elems(c->out) * 8 < 0xe0000000ull) return pw4;
+        if (pw_on && pw2 > 0 && upC % 64 == 0 && y6_conv_mfma_supports(c, pw2) && y6_tensor_elems(c->out) * 8 < 0xe0000000ull) return pw2;
+    }
     const int prefs[] = {2, 1, 5, 4, 3, 6};
     const int cfs[] = {0, 1, 2, 4, 1, 2, 4};
     for (int i = 0; i < 6; ++i) {

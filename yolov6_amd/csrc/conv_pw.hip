@@ -21,7 +21,8 @@
 //   * ONE wait + barrier (everything this wave asked for has landed), then Cin / 16 k-steps without any block-wide
 //     synchronisation; the reduction is fully unrolled (Cin / 64 is a template parameter: 1, 2, 3, 4, 6, 8, 16);
 //   * epilogue: bias + activation in conv_common.hpp's arithmetic, the fp16 tile staged through the (dead) pixel
-//     image and written as whole NHWC rows - 16 lanes x 16 B per pixel row of 128 couts.
+//     image and written as whole NHWC rows - 16 lanes x 16 B per pixel row of 128 couts; the residual add (BottleRep, the
+//     accumulating data-gradient convs of the training step) and the ConvTranspose2d(k2, s2) scatter happen on those rows.
 // Vector-memory ordering follows conv_wreg.hip's rule: requests and VGPR loads are awaited TOGETHER (vmcnt(0)) where both are in
 // flight; counted waits appear only where nothing but weight loads is outstanding.
 #include "common.hpp"
@@ -121,8 +122,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
     // descriptor of zero records: the loads return zeros
     i32x4_t bzr[4];
     {
-        const i32x4_t rsB = make_rsrc(a.bias, a.bias != nullptr ? (unsigned)a.Cout * 4u : 0u);
-        const unsigned bo = (unsigned)((cb * WC + wc) * 32 + 4 * (lane >> 5)) * 4u;
+        // ConvTranspose2d(k2, s2) as one [4 Cout x Cin] GEMM (a.up == 2): the block's couts belong to ONE (dy, dx) sub-kernel
+        // (host: upC % TC == 0) and the bias is indexed by the real channel
+        const int cend = a.up == 2 ? a.upC : a.Cout;
+        const int upc0 = a.up == 2 ? ((cb * TC) / a.upC) * a.upC : 0;
+        const i32x4_t rsB = make_rsrc(a.bias, a.bias != nullptr ? (unsigned)cend * 4u : 0u);
+        const unsigned bo = (unsigned)((cb * WC + wc) * 32 - upc0 + 4 * (lane >> 5)) * 4u;
 #pragma unroll
         for (int g = 0; g < 4; ++g) pw_load_frag(bzr[g], rsB, bo + (unsigned)(g * 32), 0u);
     }
@@ -236,16 +241,63 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
     }
     __syncthreads();
     {
-        const __amdgpu_buffer_rsrc_t rsO =
-            __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)npix * a.out_cs * 2), 0x00020000);
         constexpr int PPR = TC / 8;                  // 16-byte pieces per row
         constexpr int NPC = TP * PPR / 256;          // pieces per thread
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        if (a.up == 2) {   // scatter: input pixel (b, y, x) -> output pixel (b, 2 y + dy, 2 x + dx), channels of the block's sub-kernel
+            const int sub = (cb * TC) / a.upC;
+            const int dy = sub >> 1, dx = sub & 1;
+            const unsigned ccol = (unsigned)(a.out_co + cb * TC - sub * a.upC) * 2u;
+            const __amdgpu_buffer_rsrc_t rsO =
+                __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)npix * 4 * a.out_cs * 2), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int q = tid + 256 * i;
+                const int row = q / PPR, pc = q % PPR;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * OP + pc * 16);
+                const int ip = pix0 + row;
+                const int x = ip % a.upW, t = ip / a.upW;
+                const int y = t % a.upH, bb = t / a.upH;
+                const unsigned op = (unsigned)((bb * 2 * a.upH + 2 * y + dy) * (2 * a.upW) + 2 * x + dx);
+                const unsigned ob = ip < npix ? op * (unsigned)a.out_cs * 2u + ccol + (unsigned)pc * 16u : kOob;
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)ob, 0, 0);
+            }
+            return;
+        }
+        const __amdgpu_buffer_rsrc_t rsO =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)npix * a.out_cs * 2), 0x00020000);
         const unsigned obase = ((unsigned)pix0 * (unsigned)a.out_cs + (unsigned)a.out_co + (unsigned)(cb * TC)) * 2u;
+        if (a.res != nullptr) {   // out = fp16(x) + fp16(alpha * res) (conv_common.hpp finish16: BottleRep, the accumulating data-gradient convs)
+            const float ralpha = a.res_alpha != nullptr ? *a.res_alpha : 1.f;
+            const __amdgpu_buffer_rsrc_t rsR =
+                __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)(unsigned)((size_t)npix * a.res_cs * 2), 0x00020000);
+            const unsigned rbase = ((unsigned)pix0 * (unsigned)a.res_cs + (unsigned)a.res_co + (unsigned)(cb * TC)) * 2u;
+            u32x4_t rr[NPC];
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int q = tid + 256 * i;
+                const int row = q / PPR, pc = q % PPR;
+                const unsigned rb = pix0 + row < npix ? rbase + (unsigned)row * (unsigned)a.res_cs * 2u + (unsigned)pc * 16u : kOob;
+                rr[i] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)rb, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int q = tid + 256 * i;
+                const int row = q / PPR, pc = q % PPR;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * OP + pc * 16);
+                const h8_t xo = __builtin_bit_cast(h8_t, o), xr = __builtin_bit_cast(h8_t, rr[i]);
+                h8_t y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)xo[e] + y6_round_f16(ralpha * (float)xr[e]));
+                const unsigned ob = pix0 + row < npix ? obase + (unsigned)row * (unsigned)a.out_cs * 2u + (unsigned)pc * 16u : kOob;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, y), rsO, (int)ob, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NPC; ++i) {
             const int q = tid + 256 * i;
             const int row = q / PPR, pc = q % PPR;
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
             const u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * OP + pc * 16);
             const unsigned ob = pix0 + row < npix ? obase + (unsigned)row * (unsigned)a.out_cs * 2u + (unsigned)pc * 16u : kOob;   // overhang: dropped by the range check
             __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)ob, 0, 0);
