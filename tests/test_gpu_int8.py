@@ -257,6 +257,48 @@ def test_conv_i8_wreg_variants_bit_exact(variant):
             assert float(rel.max()) <= 2 * 2.0 ** -10 * 1.002, tag
 
 
+@pytest.mark.parametrize("variant", [14, 15])
+def test_conv_i8_pw_variants_bit_exact(variant):
+    """The whole-reduction 1x1 kernel (conv_pw.hip, int8 form; 14: 128-cout blocks, 15: 64-cout blocks) over the producer's int8 twin:
+    the fp16 output bit-exact against the oracle (conv + bias (+ ReLU)), within two fp16 ulps with SiLU, and - bit for bit - the
+    outputs and the int8 twin of the per-tap kernel (variant 2) on the same inputs; twin-only calls write the same twin.  Partial
+    last stages (Cin 64 / 192), ragged last tiles, several cout blocks, the deepest reduction (1024)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(58)
+    shapes = [(3, 40, 40, 64, 128, "relu"), (2, 22, 38, 128, 256, None), (2, 30, 50, 192, 128, "silu"), (5, 20, 20, 512, 256, "relu"),
+              (3, 10, 10, 1024, 256, "relu"), (2, 21, 37, 384, 128, "relu"), (9, 20, 20, 256, 512, "silu")]
+    if variant == 15:
+        shapes = [(B, H, W, Cin, Cout // 2 if Cout > 128 else 64, act) for (B, H, W, Cin, Cout, act) in shapes if Cin < 1024]
+    for (B, H, W, Cin, Cout, act) in shapes:
+        x = rand_nhwc(B, H, W, Cin, seed=24, scale=4.0)
+        w = torch.randn((Cout, Cin, 1, 1), generator=g) * 0.2
+        b = torch.randn((Cout,), generator=g)
+        amax = 3.1
+        twin = _i8_buffer(B, H, W, Cin)
+        xt, qt = x.ct(), twin.ct()
+        _lib.check(lib.y6_quantize_i8(C.byref(xt), C.c_float(amax), C.byref(qt), None), "quantize_i8")
+        qa, qb, qc = _i8_buffer(B, H, W, Cout), _i8_buffer(B, H, W, Cout), _i8_buffer(B, H, W, Cout)
+        tag = f"variant {variant} {(B, H, W, Cin, Cout, act)}"
+        out, _ = _run_i8(x, w, b, 1, act, amax, variant=variant, q_in=twin, q_out=qa, q_out_amax=4.2, want_acc=False)
+        base, _ = _run_i8(x, w, b, 1, act, amax, variant=2, q_in=twin, q_out=qb, q_out_amax=4.2, want_acc=False)
+        assert torch.equal(out.buf, base.buf), f"fp16 output differs from the per-tap kernel's: {tag}"
+        assert torch.equal(qa.buf, qb.buf), f"int8 twin differs from the per-tap kernel's: {tag}"
+        _run_i8(x, w, b, 1, act, amax, variant=variant, q_in=twin, q_out=qc, q_out_amax=4.2, want_out=False, want_acc=False)
+        assert torch.equal(qa.buf, qc.buf), f"twin-only output differs: {tag}"
+        ref, _ = int8_conv(_Q16(), _nchw(x), w, b, 1, act, None, amax)
+        got = _nchw(out)
+        if act in (None, "relu"):
+            assert torch.equal(got, ref), f"fp16 output differs from the oracle: {tag} max {float((got - ref).abs().max()):.3e}"
+        else:
+            rel = (got - ref).abs() / ref.abs().clamp(min=1.0)
+            assert float(rel.max()) <= 2 * 2.0 ** -10 * 1.002, tag
+    # what it cannot do is an error, not a wrong result
+    with pytest.raises(RuntimeError, match="whole-reduction"):
+        _run_i8(x, w, b, 1, act, amax, variant=variant, q_in=twin, want_acc=True)       # accumulator dump
+    with pytest.raises(RuntimeError, match="whole-reduction"):
+        _run_i8(x, w, b, 1, act, amax, variant=variant, want_acc=False)                  # no int8 input view
+
+
 def test_conv_i8_wreg_refuses_what_it_cannot_do():
     """No residual, no accumulator dump, whole 64-channel stages and 128-cout blocks: anything else is an error from the C ABI
     (the kernel has the fast epilogue only), not a wrong result."""

@@ -395,6 +395,7 @@ def test_fused_pw_s2_equals_two_convs(chans, hw, batch, acts):
     for fuse in (True, False):
         pb = PlanBuilder(G.DEV)
         pb._fuse_s2 = fuse
+        pb._fuse_pw_widths = (64, 128)                          # (the builder's default fuses the 64-channel pair only since round 6)
         pb.hint_single_use()                                    # what BiFusion.lower says about cv2's output
         t = pb.conv(x, w1, b1, stride=1, act=acts[0])
         Ho, Wo = (hw[0] + 1) // 2, (hw[1] + 1) // 2
@@ -491,8 +492,9 @@ def test_stem_conv_persistent_many_tiles():
     assert G.max_rel(G.nhwc_to_nchw_f32(o), ref) < TOL
 
 
-def test_sppf_pool_exact():
-    B, H, W, C_ = 2, 20, 20, 64
+@pytest.mark.parametrize("shape", [(2, 20, 20, 64), (11, 20, 20, 256), (3, 13, 17, 24), (2, 40, 40, 48), (9, 10, 10, 80)])
+def test_sppf_pool_exact(shape):
+    B, H, W, C_ = shape        # four / one / one / two 16-byte pieces per pixel and block; batches that do not fill the last group of eight
     cat = G.rand_nhwc(B, H, W, 4 * C_, seed=15)
     s = [cat.slice(i * C_, C_) for i in range(4)]
     pb = PlanBuilder(G.DEV)

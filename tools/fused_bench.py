@@ -32,14 +32,14 @@ B = 32
 for fuse in (True, False):
     tag = "fused" if fuse else "two_ops"
     # stem (3 -> 32) + 3x3 s2 (32 -> 64) on 640x640
-    pb = PlanBuilder(dev); pb._fuse_s2 = fuse
+    pb = PlanBuilder(dev); pb._fuse_s2 = fuse; pb._fuse_pw_widths = (64, 128)
     img = torch.rand((B, 3, 640, 640), generator=g).half().to(dev)
     pb.hint_single_use()
     t = pb.conv(NCHWInput(img), *w(32, 3, 3), stride=2, act="relu")
     o = pb.conv(t, *w(64, 32, 3), stride=2, act="relu")
     res[f"stem_s2_{tag}_us"] = round(timed(pb.finalize(o, autotune=False)), 1)
     for C_, H in ((64, 160), (128, 80)):
-        pb = PlanBuilder(dev); pb._fuse_s2 = fuse
+        pb = PlanBuilder(dev); pb._fuse_s2 = fuse; pb._fuse_pw_widths = (64, 128)
         x = TRef(torch.randn((B, H, H, C_), generator=g).half().to(dev), B, H, H, C_, C_, 0)
         pb.hint_single_use()
         t = pb.conv(x, *w(C_, C_, 1), stride=1, act="relu")

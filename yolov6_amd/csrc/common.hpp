@@ -109,7 +109,8 @@ int y6_conv_dma_launch(const void* launch_record, int cf, int pf, int nw, int st
 int y6_conv_dma_halo_cap(int block_pixels, int stride);
 int y6_conv_wreg_launch(const void* launch_record, int pf, int cout_waves, int pixel_waves, int stride, int i8, hipStream_t s);   // conv_wreg.hip
 int y6_conv_wreg_max_pieces(int waves, int stride);
-int y6_conv_pw_launch(const void* launch_record, int cout_waves, int pixel_frags, hipStream_t s);   // conv_pw.hip (1x1 stride 1)
+int y6_conv_pw_launch(const void* launch_record, int cout_waves, int pixel_frags, int i8, hipStream_t s);   // conv_pw.hip (1x1 stride 1)
+int y6_conv_pw_i8_cin_ok(int cin, int block_pixels);
 int y6_conv_pw_cin_ok(int cin, int block_pixels);
 // nms.hip: where the key lists / their lengths of a y6_nms workspace live (the candidate sink of head_decode.hip writes them)
 int y6_nms_workspace_views(void* workspace, size_t bytes, int B, int A, int nc, int multi_label, unsigned long long** keys, size_t* cap, int** counts);

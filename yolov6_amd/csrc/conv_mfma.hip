@@ -1266,11 +1266,28 @@ static bool i8_wreg_ok(const y6_conv_i8_desc* q, int stride, int cout_waves) {
     if (y6_tensor_elems(o) / o.C * o.cstride * 2 >= 0xe0000000ull) return false;
     return true;
 }
+// what conv_pw.hip's int8 form handles: 1x1 stride 1 over the producer's int8 twin, whole cout blocks, no residual / post-affine / raw
+// accumulators, a 16-byte aligned fp16 view and / or a 4-byte aligned int8 twin
+static bool i8_pw_ok(const y6_conv_i8_desc* q, int cout_waves) {
+    const y6_conv_desc* d = &q->conv;
+    const y6_tensor& o = d->out.data ? d->out : q->q_out;
+    const int tp = 32 * 2 * (4 / cout_waves);
+    if (d->ksize != 1 || d->stride != 1 || !q->q_in.data || !y6_conv_pw_i8_cin_ok(q->q_in.C, tp) || o.C % (32 * cout_waves)) return false;
+    if (d->res.data || d->post_scale || q->acc_out) return false;
+    if (d->out.data && (d->out.cstride % 8 || d->out.coff % 8 || ((uintptr_t)d->out.data & 15))) return false;
+    if (q->q_out.data && ((q->q_out.cstride | q->q_out.coff) & 3)) return false;
+    if (y6_tensor_elems(o) / o.C * o.cstride * 2 >= 0xe0000000ull) return false;
+    return true;
+}
 int y6_conv_i8_variant(const y6_conv_i8_desc* q) {
     const y6_conv_desc* d = &q->conv;
-    if (d->variant >= 1 && d->variant <= 13) return d->variant;
+    if (d->variant >= 1 && d->variant <= 15) return d->variant;
     const int co = d->out.data ? d->out.C : q->q_out.C;
     static const bool no_dma = getenv("Y6_I8_NO_DMA") != nullptr;   // A/B switch
+    // 14 / 15 (round 6): the whole-reduction 1x1 kernel (conv_pw.hip, int8 form): 128- / 64-cout blocks.  Y6_I8_PW=0: A/B switch
+    static const bool pw_on = getenv("Y6_I8_PW") ? atoi(getenv("Y6_I8_PW")) != 0 : true;
+    if (pw_on && i8_pw_ok(q, 4)) return 14;
+    if (pw_on && i8_pw_ok(q, 2)) return 15;
     // 10 / 11 / 12: the register-fed kernels (conv_wreg.hip, int8 form) - the producer's int8 twin, whole 64-channel stages, whole
     // 128-cout blocks; 7 pixel fragments per wave when the 200-pixel items fill the 512 resident blocks, else 4 (the fp16 rule,
     // conv_misc.hip: default_variant); stride 2: 3 fragments.  Y6_I8_WREG=0: A/B switch (the LDS-DMA / per-tap kernels of round 3)
@@ -1327,6 +1344,25 @@ int y6_conv_i8_launch(const y6_conv_i8_desc* q, hipStream_t s) {
                    "conv_i8: int8 output view");
     }
     const int variant = y6_conv_i8_variant(q);
+    if (variant >= 14) {   // conv_pw.hip
+        Y6_REQUIRE(variant <= 15 && i8_pw_ok(q, variant == 14 ? 4 : 2),
+                   "conv_i8: the whole-reduction 1x1 variants need k1 s1, an int8 input view with Cin in {64 .. 1024}, whole cout blocks, no residual / post-affine, aligned outputs");
+        static const int kv14 = variant_index("pw_c4p2"), kv15 = variant_index("pw_c2p2");
+        Launch L;
+        int rc = build_launch(&d, variant == 14 ? kv14 : kv15, 0, 0, 0, &L);
+        if (rc) return rc;
+        ConvKArgs& k = L.k;
+        k.qscale = q->dequant;
+        k.qin = (const signed char*)q->q_in.data;
+        k.qin_cs = q->q_in.cstride;
+        k.qin_co = q->q_in.coff;
+        k.qout = (signed char*)q->q_out.data;
+        k.qout_cs = q->q_out.cstride;
+        k.qout_co = q->q_out.coff;
+        if (has_qout) quantiser_consts(q->q_out_amax, &k.qo_inv2, &k.qo_lo2, &k.qo_hi2);
+        if (!has_out) k.out = nullptr;
+        return y6_conv_pw_launch(&L, variant == 14 ? 4 : 2, 2, 1, s);
+    }
     const bool wreg = variant >= 10;
     const bool dma = variant >= 7 && !wreg;
     if (dma)
@@ -1507,7 +1543,7 @@ int y6_conv_mfma_launch(const y6_conv_desc* d, int variant, hipStream_t s, int u
         case 6:
             return y6_conv_wreg_launch(&L, vc.pf, vc.cf, vc.nw / vc.cf, vc.cs, 0, s);
         case 7:
-            return y6_conv_pw_launch(&L, vc.cf, vc.pf, s);
+            return y6_conv_pw_launch(&L, vc.cf, vc.pf, 0, s);
     }
     return Y6_EINVAL;
 }

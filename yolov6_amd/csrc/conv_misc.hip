@@ -516,46 +516,57 @@ __device__ __forceinline__ h8_t hmax8(const h8_t& v, const h8_t& m) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void sppf_pool_kernel(const __half* __restrict__ x, int x_cs, int x_co,
+// CG: 16-byte pieces (8 channels) of a pixel a block owns.  Round 6: CG = 4 - a block reads and writes 64 contiguous bytes per pixel
+// instead of 16 (one piece per block touched every 128-byte line of the 20x20x256 map from eight different blocks: 32 us for 26 MB), and
+// the blocks of one image share an XCD (id % 8), so the pieces of a line meet in one L2.
+template <int CG>
+__global__ __launch_bounds__(1024) void sppf_pool_kernel(const __half* __restrict__ x, int x_cs, int x_co,
                                                         __half* __restrict__ y1, int y1_cs, int y1_co,
                                                         __half* __restrict__ y2, int y2_cs, int y2_co,
                                                         __half* __restrict__ y3, int y3_cs, int y3_co, int H, int W,
-                                                        int C8) {
+                                                        int ncg, int B) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h8_t* cur = reinterpret_cast<h8_t*>(smem);
-    h8_t* tmp = cur + H * W;
-    const int b = blockIdx.x / C8, cg = blockIdx.x % C8;
-    const int HW = H * W;
+    h8_t* tmp = cur + H * W * CG;
+    // id -> (image, channel group): groups of one image on one XCD
+    const int id = blockIdx.x, lo = id & 7, r = id >> 3;
+    const int cg = r % ncg, b = (r / ncg) * 8 + lo;
+    if (b >= B) return;
+    const int HW = H * W, N = HW * CG;
     const size_t pbase = (size_t)b * HW;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x)
-        cur[p] = *reinterpret_cast<const h8_t*>(x + (pbase + p) * x_cs + x_co + cg * 8);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const int p = i / CG, j = i - p * CG;
+        cur[i] = *reinterpret_cast<const h8_t*>(x + (pbase + p) * x_cs + x_co + (cg * CG + j) * 8);
+    }
     __syncthreads();
     __half* outs[3] = {y1, y2, y3};
     const int ocs[3] = {y1_cs, y2_cs, y3_cs};
     const int oco[3] = {y1_co, y2_co, y3_co};
     for (int pass = 0; pass < 3; ++pass) {
-        for (int p = threadIdx.x; p < HW; p += blockDim.x) {  // row max
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {  // row max
+            const int p = i / CG, j = i - p * CG;
             const int yy = p / W, xx = p - yy * W;
-            h8_t m = cur[p];
+            h8_t m = cur[i];
             for (int d = -2; d <= 2; ++d) {
                 const int x2 = xx + d;
                 if (d == 0 || x2 < 0 || x2 >= W) continue;
-                m = hmax8(cur[yy * W + x2], m);
+                m = hmax8(cur[(yy * W + x2) * CG + j], m);
             }
-            tmp[p] = m;
+            tmp[i] = m;
         }
         __syncthreads();
-        for (int p = threadIdx.x; p < HW; p += blockDim.x) {  // column max
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {  // column max
+            const int p = i / CG, j = i - p * CG;
             const int yy = p / W, xx = p - yy * W;
-            h8_t m = tmp[p];
+            h8_t m = tmp[i];
             for (int d = -2; d <= 2; ++d) {
                 const int y2i = yy + d;
                 if (d == 0 || y2i < 0 || y2i >= H) continue;
-                m = hmax8(tmp[y2i * W + xx], m);
+                m = hmax8(tmp[(y2i * W + xx) * CG + j], m);
             }
-            *reinterpret_cast<h8_t*>(outs[pass] + (pbase + p) * ocs[pass] + oco[pass] + cg * 8) = m;
-            // safe to overwrite cur[p]: the column pass reads tmp only
-            cur[p] = m;
+            *reinterpret_cast<h8_t*>(outs[pass] + (pbase + p) * ocs[pass] + oco[pass] + (cg * CG + j) * 8) = m;
+            // safe to overwrite cur[i]: the column pass reads tmp only
+            cur[i] = m;
         }
         __syncthreads();
     }
@@ -940,15 +951,25 @@ extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_te
         Y6_REQUIRE(ys[i]->B == x->B && ys[i]->H == x->H && ys[i]->W == x->W && ys[i]->C == x->C &&
                        ys[i]->coff % 8 == 0 && ys[i]->cstride % 8 == 0,
                    "sppf_pool: output %d shape/alignment mismatch", i);
-    const size_t lds = (size_t)x->H * x->W * 16 * 2;
-    Y6_REQUIRE(lds <= 160 * 1024, "sppf_pool: plane %dx%d too large for LDS", x->H, x->W);
-    auto kern = sppf_pool_kernel;
-    if (lds > 64 * 1024)
-        Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int C8 = x->C / 8;
-    hipLaunchKernelGGL(kern, dim3(x->B * C8), dim3(256), lds, (hipStream_t)stream, (const __half*)x->data,
-                       x->cstride, x->coff, (__half*)y1->data, y1->cstride, y1->coff, (__half*)y2->data, y2->cstride,
-                       y2->coff, (__half*)y3->data, y3->cstride, y3->coff, x->H, x->W, C8);
+    // pieces per pixel and block: four (64 bytes) when the two planes fit 64 KiB of LDS and the channels divide, else two, else one
+    int cgp = 4;
+    while (cgp > 1 && (C8 % cgp || (size_t)x->H * x->W * 16 * 2 * cgp > 64 * 1024)) cgp >>= 1;
+    const size_t lds = (size_t)x->H * x->W * 16 * 2 * cgp;
+    Y6_REQUIRE(lds <= 160 * 1024, "sppf_pool: plane %dx%d too large for LDS", x->H, x->W);
+    const int ncg = C8 / cgp;
+    const int grid = y6_cdiv(x->B, 8) * 8 * ncg;
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // one thread per (pixel, piece) where the plane allows: the six passes are LDS round trips, not bytes
+        const int threads = x->H * x->W * cgp >= 1024 ? 1024 : (x->H * x->W * cgp >= 512 ? 512 : 256);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, (hipStream_t)stream, (const __half*)x->data,
+                           x->cstride, x->coff, (__half*)y1->data, y1->cstride, y1->coff, (__half*)y2->data, y2->cstride,
+                           y2->coff, (__half*)y3->data, y3->cstride, y3->coff, x->H, x->W, ncg, x->B);
+        return Y6_OK;
+    };
+    int rc = cgp == 4 ? launch(sppf_pool_kernel<4>) : (cgp == 2 ? launch(sppf_pool_kernel<2>) : launch(sppf_pool_kernel<1>));
+    if (rc) return rc;
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }

@@ -19,7 +19,7 @@
 //     weights) go global -> VGPR through a ring of up to sixteen loads (a k-step is only PF MFMAs: the ring has to cover the L2
 //     latency by depth) and never touch LDS;
 //   * ONE wait + barrier (everything this wave asked for has landed), then Cin / 16 k-steps without any block-wide
-//     synchronisation; the reduction is fully unrolled (Cin / 64 is a template parameter: 1, 2, 3, 4, 6, 8, 16);
+//     synchronisation; the reduction is fully unrolled (Cin / 64 is a template parameter: 1 ... 6, 8, 10, 12, 16);
 //   * epilogue: bias + activation in conv_common.hpp's arithmetic, the fp16 tile staged through the (dead) pixel
 //     image and written as whole NHWC rows - 16 lanes x 16 B per pixel row of 128 couts; the residual add (BottleRep, the
 //     accumulating data-gradient convs of the training step) and the ConvTranspose2d(k2, s2) scatter happen on those rows.
@@ -54,12 +54,19 @@ __device__ __forceinline__ void pw_wait_lds(i32x4_t& frag) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N) : "memory");
 }
 
-// NK: Cin / 64 (stages of 128 bytes per pixel).  WC x WP = 4 waves: WC along the couts (32 each), WP along the pixels (PF fragments
-// of 32 each).  ConvKArgs as conv_mfma.hip's build_launch fills it for a 1x1 conv: W = flattened pixel count, TW = TP, ntiles, ncb, nids.
-template <int NK, int WC, int WP, int PF>
+// NKS: k-steps of the reduction - a k-step is 32 BYTES per pixel (16 fp16 / 32 int8 channels), a stage four of them (128 bytes per
+// pixel); the last stage may be partial (int8: Cin = 64, 192).  WC x WP = 4 waves: WC along the couts (32 each), WP along the pixels
+// (PF fragments of 32 each).  ConvKArgs as conv_mfma.hip's build_launch fills it for a 1x1 conv: W = flattened pixel count, TW = TP,
+// ntiles, ncb, nids.
+// I8: the int8 form (include/yolov6_hip.h y6_conv_i8_desc; BASELINE configs[4]) - the producer's int8 twin as input, v_mfma_i32_32x32x32_i8
+// (the same 16 bytes per lane and operand: requests, LDS image, weight stream and waits are shared word for word), exact int32 sums
+// times s_x * s_w[c] as a rounding of its own, then the fp16 epilogue; optionally the int8 twin of the output rows.
+template <int NKS, int WC, int WP, int PF, bool I8>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
     constexpr int TP = WP * PF * 32, TC = WC * 32;
-    constexpr int NKS = NK * 4;                       // k-steps of 16 channels
+    constexpr int NK = (NKS + 3) / 4;                 // stages
+    constexpr int ES = I8 ? 1 : 2;                    // bytes per input element
+    typedef typename std::conditional<I8, i32x16_t, f32x16_t>::type acc_t;
     constexpr int R = NKS < 16 ? NKS : 16;            // weight fragments in flight per wave
     constexpr int LA = 2;                             // k-steps of pixel fragments requested ahead of the MFMAs
     constexpr int NREQ = NK * (TP / 8);               // 1 KiB requests of the block's pixel image
@@ -90,9 +97,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
     const int npix = a.W;
     const int pix0 = tile * TP;
     const unsigned smem_base = lds_addr(smem);
-    const unsigned rowB = (unsigned)a.in_cs * 2u;
+    const int ics = I8 ? a.qin_cs : a.in_cs, ico = I8 ? a.qin_co : a.in_co;
+    const unsigned rowB = (unsigned)ics * (unsigned)ES;
 
-    const i32x4_t rsA = make_rsrc(a.in, (unsigned)((size_t)npix * a.in_cs * 2));
+    const i32x4_t rsA = make_rsrc(I8 ? (const void*)a.qin : (const void*)a.in, (unsigned)((size_t)npix * ics * ES));
     const i32x4_t rsW = make_rsrc(a.wpk, 0xfffffe00u);
 
     // ---- the pixel image.  Request q = wave + 4 i covers stage s = q / (TP / 8), pixel group g = q % (TP / 8): lane l asks for
@@ -101,12 +109,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
         const unsigned pl = (unsigned)(lane >> 3);
         const unsigned piece = ((unsigned)(lane & 7) ^ (((unsigned)(lane >> 4) + 4u * (unsigned)(wave & 1)) & 7u));
         const unsigned vlane = ((unsigned)pix0 + pl) * rowB + piece * 16u;   // (the tile's origin in the VECTOR offset: kOob + scalar offset must not wrap)
-        const unsigned sbase = (unsigned)a.in_co * 2u;
+        const unsigned sbase = (unsigned)ico * (unsigned)ES;
 #pragma unroll
         for (int i = 0; i < NREQW; ++i) {
             const int q = wave + 4 * i;
             const int s = q / (TP / 8), g = q % (TP / 8);
-            const bool v = pix0 + 8 * g + (int)pl < npix;
+            const int vp = (NKS - 4 * s) * 2 < 8 ? (NKS - 4 * s) * 2 : 8;   // pieces of this stage that exist (a partial last stage: zeros behind them, never read)
+            const bool v = pix0 + 8 * g + (int)pl < npix && (int)piece < vp;
             const unsigned voff = v ? vlane + (unsigned)(8 * g) * rowB : kOob;
             dma16(rsA, voff, sbase + (unsigned)s * 128u, smem_base + (unsigned)(s * TP + 8 * g) * 128u);
         }
@@ -131,6 +140,13 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) pw_load_frag(bzr[g], rsB, bo + (unsigned)(g * 32), 0u);
     }
+    i32x4_t qzr[I8 ? 4 : 1];   // int8: s_x * s_w[c] of the same couts
+    if constexpr (I8) {
+        const i32x4_t rsQ = make_rsrc(a.qscale, (unsigned)a.Cout * 4u);
+        const unsigned qo = (unsigned)((cb * WC + wc) * 32 + 4 * (lane >> 5)) * 4u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pw_load_frag(qzr[g], rsQ, qo + (unsigned)(g * 32), 0u);
+    }
 
     // this lane's pixels: LDS address of k-step (kk & 3) of stage 0
     const int fq = frag_pixel(lane & 31);
@@ -143,11 +159,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
         for (int k4 = 0; k4 < 4; ++k4) baddr[pf][k4] = smem_base + p * 128u + ((((unsigned)(k4 * 2) + (unsigned)(lane >> 5)) ^ swz) * 16u);
     }
 
-    f32x16_t acc[PF];
+    acc_t acc[PF];
 #pragma unroll
     for (int pf = 0; pf < PF; ++pf)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pf][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[pf][r] = 0;
 
     // everything this wave asked for (its share of the image, its first R weight fragments, the bias) has landed; then everybody's
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -187,7 +203,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
                 case 8: pw_wait_lds<8>(fb[kk % NB][pf]); break;
                 default: pw_wait_lds<9>(fb[kk % NB][pf]); break;
             }
-            acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[kk % R]), __builtin_bit_cast(h8_t, fb[kk % NB][pf]), acc[pf], 0, 0, 0);
+            if constexpr (I8)
+                acc[pf] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wr[kk % R], fb[kk % NB][pf], acc[pf], 0, 0, 0);
+            else
+                acc[pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8_t, wr[kk % R]), __builtin_bit_cast(h8_t, fb[kk % NB][pf]), acc[pf], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (kk + R < NKS) {   // the slot this k-step released
@@ -208,25 +227,45 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
                 const int bits = bzr[g][j];   // (a copy: __builtin_bit_cast of the vector-element lvalue itself reads element 0 whatever j is)
                 bias16[g * 4 + j] = __builtin_bit_cast(float, bits);
             }
+        float qs16[16];
+        if constexpr (I8) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int bits = qzr[g][j];
+                    qs16[g * 4 + j] = __builtin_bit_cast(float, bits);
+                }
+        }
 #pragma unroll
         for (int pf = 0; pf < PF; ++pf) {
-            float v[16];
+            float x[16], v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (I8) {   // exact int32 -> fp32, * s_x * s_w[c] as a rounding of its own (no fma with the bias add): conv_i8_epilogue
+                    float t = (float)acc[pf][r] * qs16[r];
+                    asm volatile("" : "+v"(t));
+                    x[r] = t + bias16[r];
+                } else {
+                    x[r] = acc[pf][r] + bias16[r];
+                }
+            }
             switch (a.act) {   // one wave-uniform branch per fragment; conv_common.hpp's arithmetic (finish16 without post-affine / residual)
                 case Y6_ACT_RELU:
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_RELU>(acc[pf][r] + bias16[r]);
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_RELU>(x[r]);
                     break;
                 case Y6_ACT_SILU:
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_SILU>(acc[pf][r] + bias16[r]);
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_SILU>(x[r]);
                     break;
                 case Y6_ACT_HARDSWISH:
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_HARDSWISH>(acc[pf][r] + bias16[r]);
+                    for (int r = 0; r < 16; ++r) v[r] = act_const<Y6_ACT_HARDSWISH>(x[r]);
                     break;
                 default:
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[pf][r] + bias16[r];
+                    for (int r = 0; r < 16; ++r) v[r] = x[r];
                     break;
             }
             const int row = wp * (PF * 32) + pf * 32 + fq;
@@ -244,6 +283,29 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
         constexpr int PPR = TC / 8;                  // 16-byte pieces per row
         constexpr int NPC = TP * PPR / 256;          // pieces per thread
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        if constexpr (I8) {   // (host: no residual, no scatter) the fp16 rows and / or their int8 twin for quantised consumers
+            const bool has_out = a.out != nullptr, has_q = a.qout != nullptr;
+            const __amdgpu_buffer_rsrc_t rsO =
+                __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, has_out ? (int)(unsigned)((size_t)npix * a.out_cs * 2) : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsQo =
+                __builtin_amdgcn_make_buffer_rsrc((void*)a.qout, 0, has_q ? (int)(unsigned)((size_t)npix * a.qout_cs) : 0, 0x00020000);
+            const unsigned obase = ((unsigned)pix0 * (unsigned)a.out_cs + (unsigned)a.out_co + (unsigned)(cb * TC)) * 2u;
+            const unsigned qbase = (unsigned)pix0 * (unsigned)a.qout_cs + (unsigned)a.qout_co + (unsigned)(cb * TC);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) {
+                const int q = tid + 256 * i;
+                const int row = q / PPR, pc = q % PPR;
+                const u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + row * OP + pc * 16);
+                const bool inr = pix0 + row < npix;
+                if (has_out) __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(inr ? obase + (unsigned)row * (unsigned)a.out_cs * 2u + (unsigned)pc * 16u : kOob), 0, 0);
+                if (has_q) {   // the SAME fp16 values, quantised with the consumers' scale (conv_common.hpp q8_quad)
+                    const unsigned qb = inr ? qbase + (unsigned)row * (unsigned)a.qout_cs + (unsigned)pc * 8u : kOob;
+                    __builtin_amdgcn_raw_buffer_store_b32(q8_quad(o[0], o[1], a.qo_inv2, a.qo_lo2, a.qo_hi2), rsQo, (int)qb, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(q8_quad(o[2], o[3], a.qo_inv2, a.qo_lo2, a.qo_hi2), rsQo, (int)(inr ? qb + 4u : kOob), 0, 0);
+                }
+            }
+            return;
+        }
         if (a.up == 2) {   // scatter: input pixel (b, y, x) -> output pixel (b, 2 y + dy, 2 x + dx), channels of the block's sub-kernel
             const int sub = (cb * TC) / a.upC;
             const int dy = sub >> 1, dx = sub & 1;
@@ -305,11 +367,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvKArgs a) {
     }
 }
 
-template <int NK, int WC, int WP, int PF>
+template <int NKS, int WC, int WP, int PF, bool I8>
 int launch_pw_nk(const Launch& L, hipStream_t s) {
     constexpr int TP = WP * PF * 32, TC = WC * 32;
-    auto kern = conv_pw_kernel<NK, WC, WP, PF>;
-    size_t lds = (size_t)TP * NK * 128;
+    auto kern = conv_pw_kernel<NKS, WC, WP, PF, I8>;
+    size_t lds = (size_t)TP * ((NKS + 3) / 4) * 128;
     const size_t epi = (size_t)TP * (TC * 2 + 16);
     if (epi > lds) lds = epi;
     Y6_REQUIRE(lds <= 160 * 1024, "conv_pw: tile needs %zu bytes of LDS", lds);
@@ -332,15 +394,32 @@ int launch_pw_nk(const Launch& L, hipStream_t s) {
 template <int WC, int WP, int PF>
 int launch_pw(const Launch& L, hipStream_t s) {
     switch (L.k.Cin / 64) {
-        case 1: return launch_pw_nk<1, WC, WP, PF>(L, s);
-        case 2: return launch_pw_nk<2, WC, WP, PF>(L, s);
-        case 3: return launch_pw_nk<3, WC, WP, PF>(L, s);
-        case 4: return launch_pw_nk<4, WC, WP, PF>(L, s);
-        case 6: return launch_pw_nk<6, WC, WP, PF>(L, s);
-        case 8: return launch_pw_nk<8, WC, WP, PF>(L, s);
-        case 16: return launch_pw_nk<16, WC, WP, PF>(L, s);
+        case 1: return launch_pw_nk<4, WC, WP, PF, false>(L, s);
+        case 2: return launch_pw_nk<8, WC, WP, PF, false>(L, s);
+        case 3: return launch_pw_nk<12, WC, WP, PF, false>(L, s);
+        case 4: return launch_pw_nk<16, WC, WP, PF, false>(L, s);
+        case 5: return launch_pw_nk<20, WC, WP, PF, false>(L, s);
+        case 6: return launch_pw_nk<24, WC, WP, PF, false>(L, s);
+        case 8: return launch_pw_nk<32, WC, WP, PF, false>(L, s);
+        case 10: return launch_pw_nk<40, WC, WP, PF, false>(L, s);
+        case 12: return launch_pw_nk<48, WC, WP, PF, false>(L, s);
+        case 16: return launch_pw_nk<64, WC, WP, PF, false>(L, s);
     }
     y6_set_error("conv_pw: no instantiation for Cin %d", L.k.Cin);
+    return Y6_EUNSUPPORTED;
+}
+template <int WC, int WP, int PF>
+int launch_pw_i8(const Launch& L, hipStream_t s) {
+    switch (L.k.Cin / 32) {
+        case 2: return launch_pw_nk<2, WC, WP, PF, true>(L, s);
+        case 4: return launch_pw_nk<4, WC, WP, PF, true>(L, s);
+        case 6: return launch_pw_nk<6, WC, WP, PF, true>(L, s);
+        case 8: return launch_pw_nk<8, WC, WP, PF, true>(L, s);
+        case 12: return launch_pw_nk<12, WC, WP, PF, true>(L, s);
+        case 16: return launch_pw_nk<16, WC, WP, PF, true>(L, s);
+        case 32: return launch_pw_nk<32, WC, WP, PF, true>(L, s);
+    }
+    y6_set_error("conv_pw: no int8 instantiation for Cin %d", L.k.Cin);
     return Y6_EUNSUPPORTED;
 }
 
@@ -351,16 +430,30 @@ int launch_pw(const Launch& L, hipStream_t s) {
 int y6_conv_pw_cin_ok(int cin, int block_pixels) {
     if (cin % 64 || (size_t)block_pixels * cin * 2 > 160 * 1024) return 0;
     switch (cin / 64) {
-        case 1: case 2: case 3: case 4: case 6: case 8: case 16: return 1;
+        case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: return 1;
+    }
+    return 0;
+}
+
+// the int8 form: Cin in {64, 128, 192, 256, 384, 512, 1024}
+int y6_conv_pw_i8_cin_ok(int cin, int block_pixels) {
+    if (cin % 32 || (size_t)block_pixels * ((cin + 127) / 128) * 128 > 160 * 1024) return 0;
+    switch (cin / 32) {
+        case 2: case 4: case 6: case 8: case 12: case 16: case 32: return 1;
     }
     return 0;
 }
 
 // L points at conv_mfma.hip's launch record (conv_common.hpp)
-int y6_conv_pw_launch(const void* Lp, int wc, int pf, hipStream_t s) {
+int y6_conv_pw_launch(const void* Lp, int wc, int pf, int i8, hipStream_t s) {
     const Launch& L = *static_cast<const Launch*>(Lp);
-    if (wc == 4 && pf == 2) return launch_pw<4, 1, 2>(L, s);
-    if (wc == 2 && pf == 2) return launch_pw<2, 2, 2>(L, s);
+    if (i8) {
+        if (wc == 4 && pf == 2) return launch_pw_i8<4, 1, 2>(L, s);
+        if (wc == 2 && pf == 2) return launch_pw_i8<2, 2, 2>(L, s);
+    } else {
+        if (wc == 4 && pf == 2) return launch_pw<4, 1, 2>(L, s);
+        if (wc == 2 && pf == 2) return launch_pw<2, 2, 2>(L, s);
+    }
     y6_set_error("conv_pw: no instantiation %d cout waves, %d pixel fragments", wc, pf);
     return Y6_EUNSUPPORTED;
 }

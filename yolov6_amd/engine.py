@@ -317,6 +317,10 @@ class PlanBuilder:
         self._elided = set()     # data_ptr of buffers whose producer was fused away
         import os
         self._fuse_s2 = not os.environ.get("Y6_NO_FUSE_S2")
+        # widths at which `1x1 -> 3x3 stride 2` runs as the fused kernel.  Round 6: with the whole-reduction 1x1 kernel (csrc/conv_pw.hip)
+        # the 128-channel pair is faster as two launches (80x80 b32: 50 us against 66 fused, tools/fused_bench.py); the 64-channel pair
+        # stays fused (60 against 90).  Y6_FUSE_PW_S2_128=1: A/B switch
+        self._fuse_pw_widths = (64, 128) if os.environ.get("Y6_FUSE_PW_S2_128") else (64,)
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -503,7 +507,7 @@ class PlanBuilder:
         self._flush()                                # (a held-back producer whose consumer the fused kernel did not take)
         # a 1x1 conv into a tensor of its own may turn out to be the producer of a 3x3 stride-2 conv: hold it back one call
         if (self._fuse_s2 and single_use and K == 1 and stride == 1 and fresh_out and post is None and res is None and self.quant is None
-                and self.force_variant < 0 and Cin == Cout and Cout in (64, 128)):
+                and self.force_variant < 0 and Cin == Cout and Cout in self._fuse_pw_widths):
             self._pending = dict(kind="pw", desc=d, entry=entry, out=out)
             return out
         _lib.check(self.lib.y6_plan_add_conv(self.h, C.byref(d)), "plan_add_conv")
