@@ -248,6 +248,19 @@ int y6_letterbox(const y6_letterbox_desc* d, void* stream);
  * x,y1,y2,y3 are usually the four channel slices of one 4*C buffer (no torch.cat).        */
 int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3, void* stream);
 
+/* The same three pools, also leaving the int8 twins of y1,y2,y3 for quantised consumers (int8 plans, BASELINE configs[4]: the
+ * 1x1 conv behind the SPPF concat - common.py:112 / :158 `cv2` / `cv5` - then reads one int8 image instead of quantising
+ * 4*C fp16 channels on its way in).  q = clamp(rne(y * 127 / amax)) of the fp16 values written to y (the quantiser of
+ * y6_conv_i8_desc.q_out); max-pooling commutes with it, so the twin equals quantise-on-load bit for bit.
+ * q1,q2,q3: int8 NHWC views (data may be NULL: no twin), channel offsets / strides multiples of 8.                      */
+typedef struct y6_sppf_q_desc {
+    y6_tensor x, y1, y2, y3;
+    y6_tensor q1, q2, q3;
+    float q_amax;
+    int32_t pad[3];
+} y6_sppf_q_desc;
+int y6_sppf_pool_q(const y6_sppf_q_desc* d, void* stream);
+
 /* Layout adapters at the module boundary (reference tensors are NCHW). */
 int y6_nchw_to_nhwc(const void* src_nchw, int src_dtype, const y6_tensor* dst, void* stream);
 int y6_nhwc_to_nchw(const y6_tensor* src, void* dst_nchw, int dst_dtype, void* stream);
@@ -502,7 +515,7 @@ enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_W
        Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16,
        /* fused inference ops (generic plan ops as well) */
        Y6_TOP_PRED_DECODE = 17, Y6_TOP_PW_S2 = 18, Y6_TOP_STEM_S2 = 19,
-       Y6_TOP_AVGPOOL3 = 20 };
+       Y6_TOP_AVGPOOL3 = 20, Y6_TOP_SPPF_Q = 21 };
 
 /* Batch statistics of a conv output + everything derived from them, on device:
  *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
@@ -796,6 +809,7 @@ int y6_plan_add_stem(y6_plan* p, const y6_stem_desc* d);
 int y6_plan_add_sppf(y6_plan* p, const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3);
 int y6_plan_add_decode(y6_plan* p, const y6_decode_desc* d);
 int y6_plan_add_pw_s2(y6_plan* p, const y6_pw_s2_desc* d);       /* generic op, tag Y6_TOP_PW_S2 */
+int y6_plan_add_sppf_q(y6_plan* p, const y6_sppf_q_desc* d);     /* generic op, tag Y6_TOP_SPPF_Q */
 int y6_plan_add_stem_s2(y6_plan* p, const y6_stem_s2_desc* d);   /* generic op, tag Y6_TOP_STEM_S2; its image pointer is a rebindable input */
 int y6_plan_add_pred_decode(y6_plan* p, const y6_pred_decode_desc* d);   /* generic op, tag Y6_TOP_PRED_DECODE; its `out` is rebindable */
 /* Attach (sink->workspace set) or detach (NULL workspace) the candidate sink of the plan's fused head-tail op(s).  Returns the

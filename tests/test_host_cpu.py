@@ -647,7 +647,15 @@ def test_int8_conv_variant_heuristic_over_the_sqa_layer_shapes(hip_lib):
     assert v(32, 160, 160, 64, 64, 3, 2) == 13        # 64-cout blocks, stride 2
     assert v(32, 320, 320, 32, 64, 3, 2) == 13        # 32 input channels: half a stage
     assert v(32, 160, 160, 64, 64, 3, 1) in (8, 9)    # 64 couts at stride 1: the LDS-DMA kernels (their register-fed form lost)
-    assert v(32, 80, 80, 128, 128, 1, 1) in (1, 2, 3)  # 1x1: per-tap tiles
+    assert v(32, 80, 80, 128, 128, 1, 1) == 14         # 1x1 over the twin: the whole-reduction kernel (conv_pw.hip, round 6), 128-cout blocks
+    assert v(32, 80, 80, 192, 64, 1, 1) == 15          # ... 64-cout blocks
+    assert v(32, 20, 20, 1024, 256, 1, 1) == 14        # the SPPF concat
+    assert v(32, 80, 80, 128, 128, 1, 1, q_in=False) in (1, 2, 3)   # quantise-on-load: per-tap tiles
+    assert v(32, 80, 80, 128, 128, 1, 1, res=True) in (1, 2, 3)     # residual
+    assert v(32, 80, 80, 128, 128, 1, 1, acc=True) in (1, 2, 3)     # accumulator dump
+    assert v(32, 80, 80, 96, 128, 1, 1) in (1, 2, 3)                # 96 input channels
+    assert v(32, 80, 80, 128, 96, 1, 1) in (1, 2, 3)                # 96 couts: not whole 64-cout blocks
+    assert v(32, 80, 80, 128, 128, 1, 1, out_cstride=132) in (1, 2, 3)
     # preconditions: each one alone sends the conv elsewhere
     base = (32, 80, 80, 128, 128, 3, 1)
     assert v(*base, q_in=False) in (4, 5)             # quantise-on-load: per-tap

@@ -186,6 +186,11 @@ class SppfBwdDesc(C.Structure):
                 ("dx", Tensor), ("dx_acc", C.c_int32)]
 
 
+class SppfQDesc(C.Structure):
+    _fields_ = [("x", Tensor), ("y1", Tensor), ("y2", Tensor), ("y3", Tensor), ("q1", Tensor), ("q2", Tensor), ("q3", Tensor),
+                ("q_amax", C.c_float), ("pad", C.c_int32 * 3)]
+
+
 class HeadPackDesc(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("cls", Tensor * 4), ("reg", Tensor * 4), ("scores", C.c_void_p),
                 ("distri", C.c_void_p), ("dscores", C.c_void_p), ("ddistri", C.c_void_p), ("nc", C.c_int32), ("nreg", C.c_int32)]
@@ -204,7 +209,7 @@ class LossGradDesc(C.Structure):
 WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
 TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
              8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize",
-             17: "pred_decode", 18: "pw_s2", 19: "stem_s2", 20: "avgpool3"}
+             17: "pred_decode", 18: "pw_s2", 19: "stem_s2", 20: "avgpool3", 21: "sppf"}
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
@@ -215,7 +220,7 @@ STRUCTS = {
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
     "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
-    "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_head_pack_desc": HeadPackDesc,
+    "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_sppf_q_desc": SppfQDesc, "y6_head_pack_desc": HeadPackDesc,
     "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
 }
 
@@ -244,6 +249,7 @@ SIGNATURES = {
     "y6_stem_conv": (C.c_int, [C.POINTER(StemDesc), C.c_void_p]),
     "y6_stem_twin_supported": (C.c_int, [C.POINTER(StemDesc)]),
     "y6_sppf_pool": (C.c_int, [C.POINTER(Tensor)] * 4 + [C.c_void_p]),
+    "y6_sppf_pool_q": (C.c_int, [C.POINTER(SppfQDesc), C.c_void_p]),
     "y6_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Tensor), C.c_void_p]),
     "y6_nhwc_to_nchw": (C.c_int, [C.POINTER(Tensor), C.c_void_p, C.c_int, C.c_void_p]),
     "y6_head_decode": (C.c_int, [C.POINTER(DecodeDesc), C.c_void_p]),
@@ -326,6 +332,7 @@ SIGNATURES = {
     "y6_plan_add_convt": (C.c_int, [C.c_void_p, C.POINTER(ConvTDesc)]),
     "y6_plan_add_stem": (C.c_int, [C.c_void_p, C.POINTER(StemDesc)]),
     "y6_plan_add_sppf": (C.c_int, [C.c_void_p] + [C.POINTER(Tensor)] * 4),
+    "y6_plan_add_sppf_q": (C.c_int, [C.c_void_p, C.POINTER(SppfQDesc)]),
     "y6_plan_add_decode": (C.c_int, [C.c_void_p, C.POINTER(DecodeDesc)]),
     "y6_plan_add_pred_decode": (C.c_int, [C.c_void_p, C.POINTER(PredDecodeDesc)]),
     "y6_plan_set_nms_sink": (C.c_int, [C.c_void_p, C.POINTER(NmsSink)]),

@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include <cstring>
 #include "conv_common.hpp"
+#include "plan_internal.hpp"
 #include "stem_piece.hpp"
 
 namespace {
@@ -516,6 +517,13 @@ __device__ __forceinline__ h8_t hmax8(const h8_t& v, const h8_t& m) {
     return r;
 }
 
+// int8 twins of the three pooled slices (y6_sppf_pool_q): q[i] == nullptr: none
+struct SppfTwins {
+    signed char* q[3];
+    int cs[3], co[3];
+    unsigned inv2, lo2, hi2;   // half2 constants of the quantiser (conv_common.hpp q8_quad)
+};
+
 // CG: 16-byte pieces (8 channels) of a pixel a block owns.  Round 6: CG = 4 - a block reads and writes 64 contiguous bytes per pixel
 // instead of 16 (one piece per block touched every 128-byte line of the 20x20x256 map from eight different blocks: 32 us for 26 MB), and
 // the blocks of one image share an XCD (id % 8), so the pieces of a line meet in one L2.
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(1024) void sppf_pool_kernel(const __half* __restric
                                                         __half* __restrict__ y1, int y1_cs, int y1_co,
                                                         __half* __restrict__ y2, int y2_cs, int y2_co,
                                                         __half* __restrict__ y3, int y3_cs, int y3_co, int H, int W,
-                                                        int ncg, int B) {
+                                                        int ncg, int B, SppfTwins tw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h8_t* cur = reinterpret_cast<h8_t*>(smem);
     h8_t* tmp = cur + H * W * CG;
@@ -565,6 +573,11 @@ __global__ __launch_bounds__(1024) void sppf_pool_kernel(const __half* __restric
                 m = hmax8(tmp[(y2i * W + xx) * CG + j], m);
             }
             *reinterpret_cast<h8_t*>(outs[pass] + (pbase + p) * ocs[pass] + oco[pass] + (cg * CG + j) * 8) = m;
+            if (tw.q[pass] != nullptr) {   // the same eight values as int8 codes
+                const uint4 mb = __builtin_bit_cast(uint4, m);
+                *reinterpret_cast<uint2*>(tw.q[pass] + (pbase + p) * tw.cs[pass] + tw.co[pass] + (cg * CG + j) * 8) =
+                    make_uint2(q8_quad(mb.x, mb.y, tw.inv2, tw.lo2, tw.hi2), q8_quad(mb.z, mb.w, tw.inv2, tw.lo2, tw.hi2));
+            }
             // safe to overwrite cur[i]: the column pass reads tmp only
             cur[i] = m;
         }
@@ -941,16 +954,41 @@ extern "C" int y6_stem_conv(const y6_stem_desc* d, void* stream) {
     return Y6_OK;
 }
 
-extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3,
-                            void* stream) {
-    Y6_CLEAR_STALE_ERROR();
-    Y6_REQUIRE(x && y1 && y2 && y3 && x->data && y1->data && y2->data && y3->data, "sppf_pool: null tensor");
+static unsigned sppf_half2_bits(float v) {
+    const _Float16 h = (_Float16)v;
+    unsigned short b;
+    memcpy(&b, &h, 2);
+    return (unsigned)b | ((unsigned)b << 16);
+}
+
+static int sppf_launch(const y6_sppf_q_desc* d, hipStream_t stream) {
+    Y6_REQUIRE(d, "sppf_pool: null descriptor");
+    const y6_tensor *x = &d->x, *y1 = &d->y1, *y2 = &d->y2, *y3 = &d->y3;
+    Y6_REQUIRE(x->data && y1->data && y2->data && y3->data, "sppf_pool: null tensor");
     Y6_REQUIRE(x->C % 8 == 0 && x->coff % 8 == 0 && x->cstride % 8 == 0, "sppf_pool: channels must be 8-aligned");
     const y6_tensor* ys[3] = {y1, y2, y3};
-    for (int i = 0; i < 3; ++i)
+    const y6_tensor* qs[3] = {&d->q1, &d->q2, &d->q3};
+    SppfTwins tw;
+    memset(&tw, 0, sizeof(tw));
+    for (int i = 0; i < 3; ++i) {
         Y6_REQUIRE(ys[i]->B == x->B && ys[i]->H == x->H && ys[i]->W == x->W && ys[i]->C == x->C &&
                        ys[i]->coff % 8 == 0 && ys[i]->cstride % 8 == 0,
                    "sppf_pool: output %d shape/alignment mismatch", i);
+        if (qs[i]->data) {
+            Y6_REQUIRE(qs[i]->B == x->B && qs[i]->H == x->H && qs[i]->W == x->W && qs[i]->C == x->C && qs[i]->coff % 8 == 0 &&
+                           qs[i]->cstride % 8 == 0 && (((uintptr_t)qs[i]->data) & 7) == 0 && d->q_amax > 0.f,
+                       "sppf_pool: int8 twin %d shape/alignment mismatch (or q_amax <= 0)", i);
+            tw.q[i] = (signed char*)qs[i]->data;
+            tw.cs[i] = qs[i]->cstride;
+            tw.co[i] = qs[i]->coff;
+        }
+    }
+    if (d->q_amax > 0.f) {   // fp16(amax) and fp16(127 / fp16(amax)): the quantiser constants of y6_conv_i8_desc
+        const float ah = (float)(_Float16)d->q_amax;
+        tw.inv2 = sppf_half2_bits(127.0f / ah);
+        tw.lo2 = sppf_half2_bits(-ah);
+        tw.hi2 = sppf_half2_bits(ah);
+    }
     const int C8 = x->C / 8;
     // pieces per pixel and block: four (64 bytes) when the two planes fit 64 KiB of LDS and the channels divide, else two, else one
     int cgp = 4;
@@ -963,15 +1001,38 @@ extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_te
         if (lds > 64 * 1024) Y6_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // one thread per (pixel, piece) where the plane allows: the six passes are LDS round trips, not bytes
         const int threads = x->H * x->W * cgp >= 1024 ? 1024 : (x->H * x->W * cgp >= 512 ? 512 : 256);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, (hipStream_t)stream, (const __half*)x->data,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, (const __half*)x->data,
                            x->cstride, x->coff, (__half*)y1->data, y1->cstride, y1->coff, (__half*)y2->data, y2->cstride,
-                           y2->coff, (__half*)y3->data, y3->cstride, y3->coff, x->H, x->W, ncg, x->B);
+                           y2->coff, (__half*)y3->data, y3->cstride, y3->coff, x->H, x->W, ncg, x->B, tw);
         return Y6_OK;
     };
     int rc = cgp == 4 ? launch(sppf_pool_kernel<4>) : (cgp == 2 ? launch(sppf_pool_kernel<2>) : launch(sppf_pool_kernel<1>));
     if (rc) return rc;
     Y6_LAUNCH_CHECK();
     return Y6_OK;
+}
+
+extern "C" int y6_sppf_pool_q(const y6_sppf_q_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return sppf_launch(d, (hipStream_t)stream);
+}
+extern "C" int y6_sppf_pool(const y6_tensor* x, const y6_tensor* y1, const y6_tensor* y2, const y6_tensor* y3,
+                            void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    Y6_REQUIRE(x && y1 && y2 && y3, "sppf_pool: null tensor");
+    y6_sppf_q_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x = *x;
+    d.y1 = *y1;
+    d.y2 = *y2;
+    d.y3 = *y3;
+    return sppf_launch(&d, (hipStream_t)stream);
+}
+extern "C" int y6_plan_add_sppf_q(y6_plan* p, const y6_sppf_q_desc* d) {
+    Y6_REQUIRE(p && d, "plan_add_sppf_q: null argument");
+    const double px = (double)d->x.B * d->x.H * d->x.W * d->x.C;
+    const int nq = (d->q1.data != nullptr) + (d->q2.data != nullptr) + (d->q3.data != nullptr);
+    return y6_plan_push(p, sppf_launch, d, Y6_TOP_SPPF_Q, 0.0, px * (2.0 * 4 + nq));
 }
 
 extern "C" int y6_nchw_to_nhwc(const void* src, int src_dtype, const y6_tensor* dst, void* stream) {

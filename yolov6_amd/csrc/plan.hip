@@ -55,6 +55,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
         {"y6_pack_job", sizeof(y6_pack_job)},
         {"y6_pack_batch_desc", sizeof(y6_pack_batch_desc)},
         {"y6_sppf_bwd_desc", sizeof(y6_sppf_bwd_desc)},
+        {"y6_sppf_q_desc", sizeof(y6_sppf_q_desc)},
         {"y6_head_pack_desc", sizeof(y6_head_pack_desc)},
         {"y6_head_ab_desc", sizeof(y6_head_ab_desc)},
         {"y6_loss_grad_desc", sizeof(y6_loss_grad_desc)}};

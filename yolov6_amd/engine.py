@@ -665,9 +665,24 @@ class PlanBuilder:
     def sppf_pool(self, x: TRef, y1: TRef, y2: TRef, y3: TRef):
         self._flush()
         self._live(x)
-        cts = [t.ct() for t in (x, y1, y2, y3)]
-        _lib.check(self.lib.y6_plan_add_sppf(self.h, *[C.byref(c) for c in cts]), "plan_add_sppf")
-        self.op_log.append(dict(kind="sppf", x=x, outs=[y1, y2, y3]))
+        # int8 plans (round 6): when the concat buffer the pools write has an int8 twin (quant.plan_twins: every other writer is an int8
+        # conv, one consumer scale), the pools leave the twins of their slices too - max-pooling commutes with the quantiser
+        dec = getattr(self.quant, "decisions", None) if self.quant is not None else None
+        do = dec.get(self.buf_id(y1)) if dec else None
+        twin_ok = all(t.cstride % 8 == 0 and t.coff % 8 == 0 for t in (y1, y2, y3))
+        q_outs, amax = None, 0.0
+        if do is not None and do["twin"] and twin_ok and all(self.buf_id(t) == self.buf_id(y1) for t in (y2, y3)):
+            amax = float(do["amax"])
+            q_outs = [self._twin(t, amax) for t in (y1, y2, y3)]
+            d = _lib.SppfQDesc()
+            d.x, d.y1, d.y2, d.y3 = x.ct(), y1.ct(), y2.ct(), y3.ct()
+            d.q1, d.q2, d.q3 = (q.ct() for q in q_outs)
+            d.q_amax = amax
+            _lib.check(self.lib.y6_plan_add_sppf_q(self.h, C.byref(d)), "plan_add_sppf_q")
+        else:
+            cts = [t.ct() for t in (x, y1, y2, y3)]
+            _lib.check(self.lib.y6_plan_add_sppf(self.h, *[C.byref(c) for c in cts]), "plan_add_sppf")
+        self.op_log.append(dict(kind="sppf", x=x, outs=[y1, y2, y3], q_outs=q_outs, q_amax=amax, twin_ok=twin_ok))
 
     def head_decode(self, cls: List[TRef], reg: List[TRef], strides, use_dfl, reg_max, proj, nc,
                     grid_cell_offset=0.5) -> torch.Tensor:

@@ -126,7 +126,9 @@ def plan_twins(pb):
             s = slot(w)
             if s is not None:
                 # (the fp16 image conv can write the twin too: engine.PlanBuilder._stem, round 6)
-                s["i8_writes" if (e["kind"] == "conv_i8" or (e["kind"] == "stem" and e.get("twin_ok"))) else "other_writes"] += 1
+                # ... and so can the SPPF pools (round 6: y6_sppf_pool_q; max-pooling commutes with the quantiser)
+                can = e["kind"] == "conv_i8" or (e["kind"] == "stem" and e.get("twin_ok")) or (e["kind"] == "sppf" and e.get("twin_ok"))
+                s["i8_writes" if can else "other_writes"] += 1
     for r in pb.fp16_reads:
         s = slot(r)
         if s is not None:

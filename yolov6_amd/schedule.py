@@ -55,6 +55,8 @@ def op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
     elif k == "sppf":
         rd.append(entry["x"])
         wr += list(entry["outs"])
+        if entry.get("q_outs"):                            # int8 plans: the pools leave the int8 twins of their slices too
+            wr += list(entry["q_outs"])
     elif k == "decode":
         rd += list(entry["cls"]) + list(entry["reg"])
         wr.append(entry["out"])
@@ -97,6 +99,8 @@ def train_op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
     elif k == "sppf":
         rd.append(entry["x"])
         wr += list(entry["outs"])
+        if entry.get("q_outs"):                            # int8 plans: the pools leave the int8 twins of their slices too
+            wr += list(entry["q_outs"])
     elif k in ("head_pack", "head_ab_pack"):
         rd += list(entry["cls"]) + list(entry["reg"])
         wr += [t for t in (entry.get("scores"), entry.get("distri")) if t is not None]
