@@ -8,7 +8,7 @@ out = sys.argv[1]
 
 
 def classify(name):
-    if "conv1x1_stream_kernel" in name:
+    if "conv1x1_stream_kernel" in name or "conv_pw_kernel" in name:
         return "conv1x1s1"
     m = re.search(r"conv3x3_wreg_kernel<\d+, \d+, \d+, (\d)[,>]", name)   # conv_wreg.hip: <PF, WC, WP, stride>
     if m:

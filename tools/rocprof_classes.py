@@ -10,7 +10,7 @@ d, steps = sys.argv[1], float(sys.argv[2])
 
 def classify(name):
     import re
-    if "conv1x1_stream_kernel" in name:
+    if "conv1x1_stream_kernel" in name or "conv_pw_kernel" in name:   # (conv_pw_kernel also runs the two ConvTranspose2d layers: two launches of the class per step)
         return "conv1x1s1"
     m = re.search(r"conv3x3_wreg_kernel<\d+, \d+, \d+, (\d)", name)
     if m:
