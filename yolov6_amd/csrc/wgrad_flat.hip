@@ -435,6 +435,56 @@ __global__ __launch_bounds__(256) void wgrad_flat_reduce_kernel(const float* __r
     }
 }
 
+// The same sum for the nine-tap layers whose gradient is OIHW-contiguous (sn == 9, st == 1): a block owns one cout row x 256 cins x
+// all nine taps - wave t sums tap t, a lane four consecutive cins (the same coalesced 1 KiB per slice and wave as above) - and the
+// 2 304 sums meet in LDS in the gradient's own [cin][tap] order, so the read-modify-write of the gradient is 576 contiguous 16-byte
+// pieces instead of four 4-byte cells 36 bytes apart per thread (every 128-byte line of the gradient was touched by nine different
+// waves).  The additions are the ones of the kernel above, in the same order: the same bits.
+__global__ __launch_bounds__(576) void wgrad_flat_reduce9_kernel(const float* __restrict__ ws, int nsplit, int M, int N, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_t[256 * 9];
+    const int t = threadIdx.x >> 6, j = threadIdx.x & 63;
+    const int nb = (N + 255) >> 8;
+    const int m = blockIdx.x / nb, n0 = (blockIdx.x - m * nb) * 256;
+    const int n = n0 + 4 * j;
+    const size_t per4 = (size_t)9 * M * N / 4;
+    if (n < N) {
+        const float4* p4 = reinterpret_cast<const float4*>(ws) + (((size_t)t * M + m) * N + n) / 4;
+        float4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 16 <= nsplit; k += 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = p4[(size_t)(k + u) * per4];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {               // slice order
+                s.x += v[u].x;
+                s.y += v[u].y;
+                s.z += v[u].z;
+                s.w += v[u].w;
+            }
+        }
+        for (; k < nsplit; ++k) {
+            const float4 v = p4[(size_t)k * per4];
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+        }
+        s_t[(4 * j + 0) * 9 + t] = s.x;
+        s_t[(4 * j + 1) * 9 + t] = s.y;
+        s_t[(4 * j + 2) * 9 + t] = s.z;
+        s_t[(4 * j + 3) * 9 + t] = s.w;
+    }
+    __syncthreads();
+    const int nn = N - n0 < 256 ? N - n0 : 256;            // cins of this block: nn * 9 floats, nn % 4 == 0 -> whole 16-byte pieces
+    const int q = threadIdx.x;
+    if (q * 4 < nn * 9) {
+        float4* o = reinterpret_cast<float4*>(out + ((size_t)m * N + n0) * 9) + q;
+        const float4 a = *o, b = *reinterpret_cast<const float4*>(s_t + 4 * q);
+        *o = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
 struct FlatGeom {
     int Wp, Pp, total, xpos, nwm, nchunks, stride, kc, tn;
     size_t lds;
@@ -570,6 +620,12 @@ int wgrad_flat_launch(const y6_wgrad_nhwc_desc* d, hipStream_t s) {
         else hipLaunchKernelGGL((wgrad_flat_kernel<1, 2>), dim3(grid), dim3(256), g.lds, s, a);
     }
     Y6_LAUNCH_CHECK();
+    static const bool reduce9 = getenv("Y6_WGRAD_REDUCE9") ? atoi(getenv("Y6_WGRAD_REDUCE9")) != 0 : true;   // A/B switch
+    if (reduce9 && T == 9 && d->sn == 9 && d->st == 1 && d->sm == (long)d->N * 9 && d->N % 4 == 0 && (((uintptr_t)d->out) & 15) == 0) {
+        hipLaunchKernelGGL(wgrad_flat_reduce9_kernel, dim3((unsigned)(d->M * ((d->N + 255) / 256))), dim3(576), 0, s, a.ws, a.nsplit, d->M, d->N, d->out);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
     unsigned rg = (unsigned)((per / 4 + 255) / 256);
     if (rg > 8192) rg = 8192;
     hipLaunchKernelGGL(wgrad_flat_reduce_kernel, dim3(rg), dim3(256), 0, s, a.ws, a.nsplit, T, d->M, d->N, d->out, d->sm, d->sn, d->st);
