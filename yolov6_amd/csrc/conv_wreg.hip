@@ -112,10 +112,13 @@ constexpr int kWregProbe = Y6_WREG_PROBE;
 // Same arithmetic in the same order: bit-identical outputs (tests/test_gpu_ops.py; A/B switch Y6_WREG_GENERAL_EPI=1).
 // EPI: 0 = the general form, 1 = bias + ReLU only (RELU_ONLY above), 2 = bias + SiLU only (the head's cls / reg convs,
 // effidehead.py:172-181: ConvBNSiLU - 3 launches of YOLOv6-S, one of them 108 us cold against 55 warm on the general form),
-// 3 = bias only (the convs of the training-form graph: their BatchNorm is a kernel of its own).
+// 3 = bias only (the convs of the training-form graph: their BatchNorm is a kernel of its own), 4 (round 6) = bias only, ADDED to what the
+// output view holds (res == out: the accumulating data-gradient convs of the training step - 24 launches per step that ran the
+// general epilogue, a residual round trip per fragment: 132 us a launch against 82 for the same layers forward); the sixteen-byte
+// pieces a lane will store are loaded for ALL its fragments before the first one is finished.
 template <int PF, int WC, int WP, int ST, bool I8, int EPI = 0>
 __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const ConvKArgs a) {
-    constexpr bool RELU_ONLY = EPI == 1, SILU_ONLY = EPI == 2, SPECIAL = EPI != 0;   // EPI == 3: bias only (the training step's convs: BatchNorm follows)
+    constexpr bool RELU_ONLY = EPI == 1, SILU_ONLY = EPI == 2, SPECIAL = EPI != 0, ACCUM = EPI == 4;   // EPI == 3: bias only (the training step's convs: BatchNorm follows)
     constexpr int kMaxP = ST == 2 ? kMaxP2 : kMaxP1;   // halo requests per wave and stage
     constexpr int ES = I8 ? 1 : 2;                     // bytes per input element
     typedef typename std::conditional<I8, i32x16_t, f32x16_t>::type acc_t;
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
     float* ldsVec = reinterpret_cast<float*>(smem + 2u * stage_bytes);   // [bias | post scale | post shift | dequant][WC * 32]
     const bool has_post = !SPECIAL && a.pscale != nullptr;
     const bool has_out = a.out != nullptr, has_qout = I8 && a.qout != nullptr;
-    const bool fast = a.res == nullptr && a.up == 0 && (has_out || has_qout) && (!has_out || a.vec16_ok) &&
+    const bool fast = (ACCUM || a.res == nullptr) && a.up == 0 && (has_out || has_qout) && (!has_out || a.vec16_ok) &&
                       (!has_qout || ((a.qout_cs | a.qout_co) & 3) == 0) && (!I8 || a.acc_out == nullptr) &&
                       (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
     const float fast_lo = (RELU_ONLY || a.act == Y6_ACT_RELU) ? 0.f : -__builtin_inff();
@@ -286,7 +289,8 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * a.out_cs * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsQ =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.qout, 0, (int)(unsigned)((size_t)a.B * a.Ho * a.Wo * (I8 ? a.qout_cs : 0)), 0x00020000);
-    auto fast_unit = [&](const acc_t& accv, unsigned obyte, unsigned qbyte, const float (&bias16)[16]) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto fast_unit = [&](const acc_t& accv, unsigned obyte, unsigned qbyte, const float (&bias16)[16], const u32x4_t* prev) {
         const int kh = lane >> 5;
         const float* lb = ldsVec + wc * 32;
         float v[16];
@@ -346,8 +350,14 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
         for (int gp = 0; gp < 2; ++gp) {   // pair groups across the two half-waves: one 16-byte store per lane and pair
             auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
             auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+            u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+            if constexpr (ACCUM) {   // fp16(x) + what the view held (conv_common.hpp finish16 with res == out, alpha 1: the same two roundings)
+                const h8_t xo = __builtin_bit_cast(h8_t, o), xr = __builtin_bit_cast(h8_t, prev[gp]);
+                h8_t y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)xo[e] + (float)xr[e]);
+                o = __builtin_bit_cast(u32x4_t, y);
+            }
             __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyte + (ocol + (unsigned)(16 * gp)) * 2u), 0, 0);
         }
         // (r04n: the same stores as 64-byte runs - each fragment transposed through a per-wave LDS scratch so that four adjacent
@@ -522,11 +532,21 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
                     bias16[g * 4 + 3] = bz.w;
                 }
                 DT(20);
+                u32x4_t prev[ACCUM ? PF : 1][2];
+                if constexpr (ACCUM) {   // every piece this lane is going to add to, requested before the first fragment is finished
+                    const unsigned ocol2 = (unsigned)((cb * WC + wc) * 32 + 8 * (lane >> 5)) * 2u;
+#pragma unroll
+                    for (int pf = 0; pf < PF; ++pf) {
+                        const unsigned ob = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) prev[pf][gp] = __builtin_amdgcn_raw_buffer_load_b128(rsO, (int)(ob + ocol2 + (unsigned)(32 * gp)), 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) {
                     const unsigned ob = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;   // overhang: dropped by the range check
                     const unsigned qb = (I8 && opix[pf] >= 0) ? (unsigned)opix[pf] * (unsigned)a.qout_cs + (unsigned)a.qout_co : kOob;
-                    if (kWregProbe != 5) fast_unit(acc[pf], ob, qb, bias16);
+                    if (kWregProbe != 5) fast_unit(acc[pf], ob, qb, bias16, prev[ACCUM ? pf : 0]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[pf][r] = 0;
                 }
@@ -577,9 +597,11 @@ __global__ __launch_bounds__(WC * WP * 64, 2) void conv3x3_wreg_kernel(const Con
 // (1) or SiLU (2); 0: the general form
 static int wreg_special_epilogue(const ConvKArgs& k) {
     static const bool off = getenv("Y6_WREG_GENERAL_EPI") != nullptr;   // A/B switch
-    if (off || k.pscale != nullptr || k.res != nullptr || k.up != 0 || k.out == nullptr || !k.vec16_ok ||
-        (size_t)k.B * k.Ho * k.Wo * k.out_cs * 2 >= 0xe0000000ull)
+    static const bool acc_on = getenv("Y6_WREG_ACC") ? atoi(getenv("Y6_WREG_ACC")) != 0 : true;   // A/B switch (4)
+    if (off || k.pscale != nullptr || k.up != 0 || k.out == nullptr || !k.vec16_ok || (size_t)k.B * k.Ho * k.Wo * k.out_cs * 2 >= 0xe0000000ull)
         return 0;
+    if (k.res != nullptr)   // accumulate into the output view itself, no scaling, no activation
+        return (acc_on && k.res == k.out && k.res_cs == k.out_cs && k.res_co == k.out_co && k.res_alpha == nullptr && k.act == Y6_ACT_NONE) ? 4 : 0;
     return k.act == Y6_ACT_RELU ? 1 : (k.act == Y6_ACT_SILU ? 2 : (k.act == Y6_ACT_NONE ? 3 : 0));
 }
 
@@ -590,6 +612,9 @@ int launch_wreg(const Launch& L, hipStream_t s) {
             case 1: return launch_wreg<PF, WC, WP, ST, false, 1>(L, s);
             case 2: return launch_wreg<PF, WC, WP, ST, false, 2>(L, s);
             case 3: return launch_wreg<PF, WC, WP, ST, false, 3>(L, s);
+            case 4:
+                if constexpr (ST == 1) return launch_wreg<PF, WC, WP, ST, false, 4>(L, s);   // (data-gradient convs are stride-1 convs)
+                break;
         }
     }
     auto kern = conv3x3_wreg_kernel<PF, WC, WP, ST, I8, EPI>;
