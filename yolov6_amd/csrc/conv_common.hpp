@@ -55,6 +55,7 @@ struct ConvKArgs {
     // conv_wreg.hip only: 1.0f / halo row pitch, 1.0f / tile width (div_small)
     float inv_rp, inv_tw;
     int prio_mode;   // conv_wreg.hip: bit 0 = matrix-phase priority falls from stage to stage, bit 1 = non-matrix phases at priority 3
+    int accum_fast;  // conv_dma.hip: 1 = accumulating convs (res == out) take the end-of-item fast epilogue (A/B switch Y6_DMA_ACC=0)
 };
 
 // LDS-DMA of 16 B per lane (1 KiB per wave) issued from inline asm: hipcc does not see it, so it

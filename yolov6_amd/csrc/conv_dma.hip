@@ -423,7 +423,15 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
     unsigned ocolP = 0;    // + channel offset of its cout block and of this lane's piece (in channels)
     const float* lbP = ldsBias;
     bool haveP = false;
-    auto fast_unit = [&](const acc_t (&accP)[CF][PF], int u) {
+    // (round 6) the accumulating data-gradient convs of the training step: the same bias-only arithmetic ADDED to what the output view
+    // holds (res == out, no scaling, no activation) - at the end of the item, not deferred (a load behind the next item's requests
+    // could only be awaited by draining them), with the pieces of all units requested before the first one is finished.  The
+    // general epilogue paid a residual round trip per unit: 270 us against 159 forward for 64 -> 64 @160 b64.
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const bool accum = !I8 && a.res != nullptr && a.res == a.out && a.res_cs == a.out_cs && a.res_co == a.out_co && a.res_alpha == nullptr &&
+                       a.act == Y6_ACT_NONE && !has_post && (a.Cout % (CF * 32)) == 0 && a.up == 0 && has_out && a.vec16_ok && a.accum_fast &&
+                       (size_t)a.B * a.Ho * a.Wo * a.out_cs * 2 < 0xe0000000ull;
+    auto fast_unit = [&](const acc_t (&accP)[CF][PF], int u, const u32x4_t* prev = nullptr) {
         const int cf = u / PF, pf = u - cf * PF;
         const int kh = lane >> 5;
         float v[16];
@@ -488,8 +496,14 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             for (int gp = 0; gp < 2; ++gp) {
                 auto s0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
                 auto s1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+                u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+                if (prev != nullptr) {   // fp16(x) + what the view held: conv_common.hpp finish16 with res == out, alpha 1 (the same two roundings)
+                    const h8_t xo = __builtin_bit_cast(h8_t, o), xr = __builtin_bit_cast(h8_t, prev[gp]);
+                    h8_t y;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (_Float16)((float)xo[e] + (float)xr[e]);
+                    o = __builtin_bit_cast(u32x4_t, y);
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(o, rsO, (int)(obyteP[pf] + (ocolP + (unsigned)(cf * 32 + 16 * gp)) * 2), 0, 0);
             }
         }
@@ -618,6 +632,25 @@ __global__ __launch_bounds__(NW * 64, WPS) void conv3x3_dma_kernel(const ConvKAr
             ocolP = (unsigned)(cb * CF * 32 + 8 * (lane >> 5));
             lbP = lbias;
             haveP = true;
+        } else if (accum) {
+            int opix[PF];
+            out_pix(a, id, opix);
+#pragma unroll
+            for (int pf = 0; pf < PF; ++pf) {
+                obyteP[pf] = opix[pf] >= 0 ? ((unsigned)opix[pf] * (unsigned)a.out_cs + (unsigned)a.out_co) * 2u : kOob;
+                qbyteP[pf] = kOob;
+            }
+            ocolP = (unsigned)(cb * CF * 32 + 8 * (lane >> 5));
+            lbP = lbias;
+            u32x4_t prev[NUNIT][2];
+#pragma unroll
+            for (int u = 0; u < NUNIT; ++u)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+                    prev[u][gp] = __builtin_amdgcn_raw_buffer_load_b128(rsO, (int)(obyteP[u % PF] + (ocolP + (unsigned)((u / PF) * 32 + 16 * gp)) * 2), 0, 0);
+            DT(21);
+#pragma unroll
+            for (int u = 0; u < NUNIT; ++u) fast_unit(acc, u, prev[u]);
         } else {
             const ConvKArgs ea = reload_args();
             int opix[PF];

@@ -1101,6 +1101,10 @@ int build_launch(const y6_conv_desc* d, int variant, int up, int updy, int updx,
         }
         L->lds = 2 * (size_t)k.dma_nhp * 1024 + 4 * (size_t)vc.cf * 32 * 4;   // two stage images + bias / post scale / post shift / dequant of the block's couts
     } else if (vc.persist == 4) {
+        {
+            static const int acc_on = getenv("Y6_DMA_ACC") ? atoi(getenv("Y6_DMA_ACC")) : 1;   // A/B switch
+            k.accum_fast = acc_on;
+        }
         k.dma_rp = k.HWd;
         k.dma_pls = k.HH * k.HWd;
         k.dma_nhp = y6_cdiv((vc.hc / 8) * k.dma_pls, 64);
