@@ -541,6 +541,15 @@ typedef struct y6_bn_train_desc {
 size_t y6_bn_stats_workspace_bytes(int C);                 /* worst case (1024 partial blocks) */
 size_t y6_bn_stats_workspace_bytes_for(int C, long npix);   /* what a tensor of npix = B*H*W pixels needs */
 int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream);
+/* The statistics of up to three tensors in one pair of launches: the raw outputs of a RepVGG block's 3x3 / 1x1 branches and its
+ * identity input (yolov6/layers/common.py:250-255 normalises all three before the sum).  Entries of one shape share the launches
+ * (same blocks and addition order as y6_bn_train_stats: same bits); otherwise the entries run one after the other.  The entries
+ * must not share outputs, workspaces or running statistics. */
+typedef struct y6_bn_train_multi_desc {
+    int32_t n;                     /* 1..3 */
+    y6_bn_train_desc d[3];
+} y6_bn_train_multi_desc;
+int y6_bn_train_stats_multi(const y6_bn_train_multi_desc* d, void* stream);
 
 /* out = act( sum_b ( x_b * scale_b[c] + shift_b[c] ) ) [+ alpha * res]   (1..3 branches; NULL scale = 1, NULL shift = 0)
  * - the RepVGG train-form sum (common.py:250-255), ConvModule's BN + act (:45-49), QARepVGG's raw branches (:341-347),
@@ -773,6 +782,7 @@ int y6_scaler_update(float* scale, int32_t* found_inf, int32_t* growth_tracker, 
 
 /* plan builders for the ops above */
 int y6_plan_add_bn_train_stats(y6_plan* p, const y6_bn_train_desc* d);
+int y6_plan_add_bn_train_stats_multi(y6_plan* p, const y6_bn_train_multi_desc* d);
 int y6_plan_add_bnact_forward(y6_plan* p, const y6_bnact_desc* d);
 int y6_plan_add_bnact_backward(y6_plan* p, const y6_bnact_bwd_desc* d);
 int y6_plan_add_wgrad_transpose(y6_plan* p, const y6_wgrad_t_desc* d);

@@ -284,6 +284,56 @@ def _bn_stats(ref: TRef, gamma, beta, rm, rv, eps=1e-3, mom=0.03):
     return outs, nb
 
 
+@pytest.mark.parametrize("shape,n", [((4, 64, 40, 40), 3), ((2, 128, 33, 20), 2), ((3, 24, 6, 10), 3), ((2, 256, 20, 20), 1)])
+def test_bn_stats_multi_equals_the_single_launches_bit_for_bit(shape, n):
+    """y6_bn_train_stats_multi (the statistics of a RepVGG block's branch tensors in one launch pair, common.py:250-255) leaves
+    the bits of n calls of y6_bn_train_stats - scale / shift / mean / invstd, running statistics, num_batches_tracked - and both
+    agree with torch's batch statistics."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    B, Cn, H, W = shape
+    ys = [(torch.randn((B, Cn, H, W), generator=g) * s + m).half().float() for s, m in ((1.0, 0.0), (0.5, 0.3), (2.0, -1.0))][:n]
+    gam = [(torch.rand(Cn, generator=g) + 0.5).to(DEV) for _ in range(n)]
+    bet = [(torch.randn(Cn, generator=g) * 0.1).to(DEV) for _ in range(n)]
+    refs = [_nhwc(y) for y in ys]
+    single = []
+    for y, r, ga, be in zip(ys, refs, gam, bet):
+        rm, rv = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV)
+        outs, nb = _bn_stats(r, ga, be, rm, rv)
+        single.append(outs + [rm, rv, nb])
+    md = _lib.BnTrainMultiDesc()
+    md.n = n
+    keep, multi = [], []
+    for t, (r, ga, be) in enumerate(zip(refs, gam, bet)):
+        outs = [torch.empty(Cn, dtype=torch.float32, device=DEV) for _ in range(4)]
+        ws = torch.zeros(int(lib.y6_bn_stats_workspace_bytes(Cn)), dtype=torch.uint8, device=DEV)
+        rm, rv, nb = torch.zeros(Cn, device=DEV), torch.ones(Cn, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+        d = md.d[t]
+        d.x = r.ct()
+        d.gamma, d.beta = ga.data_ptr(), be.data_ptr()
+        d.running_mean, d.running_var, d.num_batches_tracked = rm.data_ptr(), rv.data_ptr(), nb.data_ptr()
+        d.momentum, d.eps = 0.03, 1e-3
+        d.scale, d.shift, d.mean, d.invstd = (o.data_ptr() for o in outs)
+        d.workspace, d.workspace_bytes, d.workspace_clean = ws.data_ptr(), ws.numel(), 1
+        keep.append(ws)
+        multi.append(outs + [rm, rv, nb])
+    _lib.check(lib.y6_bn_train_stats_multi(C.byref(md), _stream()), "bn_train_stats_multi")
+    torch.cuda.synchronize()
+    for t in range(n):
+        for i, (a, b) in enumerate(zip(single[t], multi[t])):
+            assert torch.equal(a, b), f"tensor {t}, output {i}: the shared launch changed bits"
+        assert int(multi[t][6]) == 1
+        mean = ys[t].double().mean((0, 2, 3))
+        var = ys[t].double().var((0, 2, 3), unbiased=False)
+        assert float((multi[t][2].cpu().double() - mean).abs().max()) <= 1e-5 * max(1.0, float(mean.abs().max()))
+        assert float((multi[t][3].cpu().double() * torch.sqrt(var + 1e-3) - 1.0).abs().max()) <= 1e-5
+    # entries that share a BatchNorm's outputs are refused, not raced
+    if n >= 2:
+        md.d[1].scale = md.d[0].scale
+        rc = lib.y6_bn_train_stats_multi(C.byref(md), _stream())
+        assert rc != 0
+
+
 @pytest.mark.parametrize("act,with_res,dil", [("relu", False, 1), ("silu", False, 1), ("relu", True, 1), ("relu", False, 2), (None, False, 1)])
 def test_bnact_forward_backward_vs_autograd(act, with_res, dil):
     """ReLU(bn(y3) + bn(y1) + bn_id(x)) [+ alpha*res] with batch statistics, and every gradient of it."""

@@ -112,31 +112,40 @@ class TrainChain:
                 y = F.conv2d(x, w, b, stride=e["stride"], padding=e["k"] // 2)
                 outs.append((e["out"], y))
                 desc = f"conv {w.shape[1]}->{w.shape[0]} k{e['k']} s{e['stride']} out {y.shape[2]}x{y.shape[3]}"
-            elif k == "bn_train_stats":
-                x = self.get(e["x"]).double()
-                bn, st = e["bn"], e["stats"]
-                n = x.numel() / x.shape[1]
-                mean = x.mean((0, 2, 3))
-                var = x.var((0, 2, 3), unbiased=False)
-                invstd = 1.0 / torch.sqrt(var + bn.eps)
-                gamma = bn.weight.detach().double().cpu() if bn.weight is not None else torch.ones_like(mean)
-                beta = bn.bias.detach().double().cpu() if bn.bias is not None else torch.zeros_like(mean)
-                scale = gamma * invstd
-                shift = beta - mean * scale
-                ref = dict(scale=scale.float(), shift=shift.float(), mean=mean.float(), invstd=invstd.float())
-                self.stats[id(st)] = ref
-                self.stats[id(bn)] = ref           # channel slices of these statistics (BnStats.slice: MBLABlock's cv1) look them up by module
-                rm0, rv0 = bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()
+            elif k in ("bn_train_stats", "bn_train_stats_multi"):
+                # one op = the statistics of one tensor, or of the up-to-three branch tensors of a RepVGG block (one launch pair)
+                items = e["items"] if k == "bn_train_stats_multi" else [(e["x"], e["bn"], e["stats"])]
+                todo = []
+                for xv_, bn, st in items:
+                    x = self.get(xv_).double()
+                    n = x.numel() / x.shape[1]
+                    mean = x.mean((0, 2, 3))
+                    var = x.var((0, 2, 3), unbiased=False)
+                    invstd = 1.0 / torch.sqrt(var + bn.eps)
+                    gamma = bn.weight.detach().double().cpu() if bn.weight is not None else torch.ones_like(mean)
+                    beta = bn.bias.detach().double().cpu() if bn.bias is not None else torch.zeros_like(mean)
+                    scale = gamma * invstd
+                    shift = beta - mean * scale
+                    ref = dict(scale=scale.float(), shift=shift.float(), mean=mean.float(), invstd=invstd.float())
+                    self.stats[id(st)] = ref
+                    self.stats[id(bn)] = ref           # channel slices of these statistics (BnStats.slice: MBLABlock's cv1) look them up by module
+                    rm0, rv0 = bn.running_mean.detach().cpu().clone(), bn.running_var.detach().cpu().clone()
+                    todo.append((x, bn, st, n, mean, var, ref, rm0, rv0))
                 plan.run_range(i, i + 1)
                 torch.cuda.synchronize()
-                C = x.shape[1]
-                pairs = [(nm, getattr(st, nm)[:C].cpu(), ref[nm]) for nm in ("scale", "shift", "mean", "invstd")]
-                m = bn.momentum
-                pairs.append(("running_mean", bn.running_mean.detach().cpu(), ((1 - m) * rm0.double() + m * mean).float()))
-                pairs.append(("running_var", bn.running_var.detach().cpu(), ((1 - m) * rv0.double() + m * var * (n / max(n - 1, 1))).float()))
-                self._cmp("fwd", i, e, f"bn_stats C={C} n={int(n)}", pairs, 1e-4)
-                for nm in ("scale", "shift", "mean", "invstd"):
-                    getattr(st, nm)[:C].copy_(ref[nm].to(st.scale.device))
+                pairs = []
+                for t_, (x, bn, st, n, mean, var, ref, rm0, rv0) in enumerate(todo):
+                    C = x.shape[1]
+                    tag = f"[{t_}]" if len(todo) > 1 else ""
+                    pairs += [(nm + tag, getattr(st, nm)[:C].cpu(), ref[nm]) for nm in ("scale", "shift", "mean", "invstd")]
+                    m = bn.momentum
+                    pairs.append(("running_mean" + tag, bn.running_mean.detach().cpu(), ((1 - m) * rm0.double() + m * mean).float()))
+                    pairs.append(("running_var" + tag, bn.running_var.detach().cpu(), ((1 - m) * rv0.double() + m * var * (n / max(n - 1, 1))).float()))
+                self._cmp("fwd", i, e, f"bn_stats x{len(todo)} C={C} n={int(n)}", pairs, 1e-4)
+                for (x, bn, st, n, mean, var, ref, rm0, rv0) in todo:
+                    C = x.shape[1]
+                    for nm in ("scale", "shift", "mean", "invstd"):
+                        getattr(st, nm)[:C].copy_(ref[nm].to(st.scale.device))
                 continue
             elif k == "bnact_forward":
                 z = 0.0

@@ -135,6 +135,10 @@ class BnTrainDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("workspace_clean", C.c_int32)]
 
 
+class BnTrainMultiDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("d", BnTrainDesc * 3)]
+
+
 class BnActDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("x", Tensor * 3), ("scale", C.c_void_p * 3), ("shift", C.c_void_p * 3), ("res", Tensor),
                 ("res_alpha", C.c_void_p), ("out", Tensor), ("act", C.c_int32)]
@@ -218,7 +222,7 @@ STRUCTS = {
     "y6_tensor": Tensor, "y6_conv_desc": ConvDesc, "y6_conv_geometry": ConvGeometry, "y6_conv_i8_desc": ConvI8Desc, "y6_convt_desc": ConvTDesc, "y6_stem_desc": StemDesc,
     "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
-    "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bnact_desc": BnActDesc,
+    "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bn_train_multi_desc": BnTrainMultiDesc, "y6_bnact_desc": BnActDesc,
     "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
     "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_sppf_q_desc": SppfQDesc, "y6_head_pack_desc": HeadPackDesc,
     "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
@@ -276,6 +280,7 @@ SIGNATURES = {
     "y6_bn_stats_workspace_bytes_for": (C.c_size_t, [C.c_int, C.c_long]),
     "y6_bnact_bwd_workspace_bytes_for": (C.c_size_t, [C.c_int, C.c_long]),
     "y6_bn_train_stats": (C.c_int, [C.POINTER(BnTrainDesc), C.c_void_p]),
+    "y6_bn_train_stats_multi": (C.c_int, [C.POINTER(BnTrainMultiDesc), C.c_void_p]),
     "y6_bnact_forward": (C.c_int, [C.POINTER(BnActDesc), C.c_void_p]),
     "y6_bnact_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "y6_bnact_backward": (C.c_int, [C.POINTER(BnActBwdDesc), C.c_void_p]),
@@ -310,6 +315,7 @@ SIGNATURES = {
                                       C.c_float, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "y6_scaler_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "y6_plan_add_bn_train_stats": (C.c_int, [C.c_void_p, C.POINTER(BnTrainDesc)]),
+    "y6_plan_add_bn_train_stats_multi": (C.c_int, [C.c_void_p, C.POINTER(BnTrainMultiDesc)]),
     "y6_plan_add_bnact_forward": (C.c_int, [C.c_void_p, C.POINTER(BnActDesc)]),
     "y6_plan_add_bnact_backward": (C.c_int, [C.c_void_p, C.POINTER(BnActBwdDesc)]),
     "y6_plan_add_wgrad_transpose": (C.c_int, [C.c_void_p, C.POINTER(WgradTDesc)]),

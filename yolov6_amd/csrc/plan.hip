@@ -46,6 +46,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
         {"y6_loss_desc", sizeof(y6_loss_desc)},
         {"y6_distill_desc", sizeof(y6_distill_desc)},
         {"y6_bn_train_desc", sizeof(y6_bn_train_desc)},
+        {"y6_bn_train_multi_desc", sizeof(y6_bn_train_multi_desc)},
         {"y6_bnact_desc", sizeof(y6_bnact_desc)},
         {"y6_bnact_bwd_desc", sizeof(y6_bnact_bwd_desc)},
         {"y6_wgrad_t_desc", sizeof(y6_wgrad_t_desc)},
@@ -235,7 +236,18 @@ static int run_ops(y6_plan* p, hipStream_t s, size_t first, size_t last) {
         }
         return Y6_OK;
     }
-    if (!p->side_stream) Y6_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+    if (!p->side_stream) {
+        // A/B switch Y6_SIDE_PRIO: "high" / "low" = the side stream's queue at the device's highest / lowest priority (its
+        // kernels are dispatched before / after the main stream's whenever both have workgroups waiting)
+        static const char* prio = getenv("Y6_SIDE_PRIO");
+        if (prio && (prio[0] == 'h' || prio[0] == 'l')) {
+            int lo = 0, hi = 0;
+            Y6_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = numerically greatest = least priority
+            Y6_HIP(hipStreamCreateWithPriority(&p->side_stream, hipStreamNonBlocking, prio[0] == 'h' ? hi : lo));
+        } else {
+            Y6_HIP(hipStreamCreateWithFlags(&p->side_stream, hipStreamNonBlocking));
+        }
+    }
     bool main_ahead = true, side_used = false;   // main_ahead: the main stream holds work the side stream has not been ordered behind
     for (size_t i = first; i < last; ++i) {
         const bool on_side = i < p->side.size() && p->side[i];

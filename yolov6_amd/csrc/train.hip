@@ -198,6 +198,22 @@ __global__ __launch_bounds__(256) void bn_sum_part_kernel(const __half* __restri
 __device__ __forceinline__ double part_subsum(const double* __restrict__ p, size_t stride, int nblocks, int prt) {
     double s = 0.0;
     int b = prt;
+    // (round 6, last session) four of the rounds below requested at once - 64 loads in flight, added in the order of the four rounds
+    // (same bits): with 800-1024 partials the kernel was four dependent round trips to memory the partials were just written to
+    for (; b + 3 * 256 + 240 < nblocks; b += 1024) {
+        double v[64];
+#pragma unroll
+        for (int u = 0; u < 64; ++u) v[u] = p[(size_t)(b + 16 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 64; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+    }
+    for (; b + 256 + 240 < nblocks; b += 512) {   // two rounds at once (400-1000 partials)
+        double v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = p[(size_t)(b + 16 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 32; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+    }
     for (; b + 240 < nblocks; b += 256) {   // sixteen independent loads in flight (round 6: the loop is a chain of global round trips -
         double v[16];                       // 17.7 us per backward BatchNorm with four in flight, 63 of them per training step)
 #pragma unroll
@@ -218,6 +234,100 @@ __device__ __forceinline__ double part_subsum(const double* __restrict__ p, size
 __global__ __launch_bounds__(512) void bn_train_finalize_part_kernel(const double* __restrict__ part, int nblocks, int C, double n,
                                                                     const y6_bn_train_desc d) {
     __shared__ double red[16][33];
+    const int t = threadIdx.x, vi = t & 31, prt = t >> 5;
+    const int k = vi >> 4, c = blockIdx.x * 16 + (vi & 15);
+    red[prt][vi] = c < C ? part_subsum(part + (size_t)k * C + c, (size_t)2 * C, nblocks, prt) : 0.0;
+    __syncthreads();
+    if (t < 32) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][t];
+        red[0][t] = tot;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && t == 0 && d.num_batches_tracked) *d.num_batches_tracked += 1;
+    if (t < 16 && blockIdx.x * 16 + t < C) bn_finalize_channel(blockIdx.x * 16 + t, red[0][t], red[0][16 + t], n, d);
+}
+
+// ---- (round 6) the statistics of up to three tensors of one shape in ONE pair of launches (a RepVGG block's 3x3 / 1x1 / identity
+// branches, yolov6/layers/common.py:250-255): blockIdx.y picks the tensor.  Each tensor's block walks the same pixels and adds in the
+// same order as in a launch of its own, so the statistics have the same bits; what goes is four of the six launches (a statistics
+// pass over a 13-52 MB map cost 12-22 us, most of it the two launches' ramps).
+struct BnMultiArgs {
+    const __half* x[3];
+    int cs[3], co[3];
+    double* part[3];
+    y6_bn_train_desc d[3];
+};
+
+__global__ __launch_bounds__(256) void bn_sum_part_multi_kernel(const BnMultiArgs m, long npix, int G, long pix_per_block, int C) {
+    extern __shared__ double s_rows[];   // as in bn_sum_part_kernel
+    const int t = blockIdx.y;
+    const __half* __restrict__ x = m.x[t];
+    const int cs = m.cs[t], co = m.co[t];
+    const int tid = threadIdx.x;
+    const int R = 256 / G;
+    if (tid < R * G) {
+        const int g = tid % G, prow = tid / G;
+        const long p0 = (long)blockIdx.x * pix_per_block;
+        const long p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+        double s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.0;
+        long p = p0 + prow;
+        for (; p + 7 * (long)R < p1; p += 8 * (long)R) {
+            uint4 raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const uint4*>(x + (p + u * (long)R) * cs + co + g * 8);
+            float fs[8], fq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fs[j] = fq[j] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const __half* h = reinterpret_cast<const __half*>(&raw[u]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = __half2float(h[j]);
+                    fs[j] += v;
+                    fq[j] = __builtin_fmaf(v, v, fq[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)fs[j];
+                q[j] += (double)fq[j];
+            }
+        }
+        for (; p < p1; p += R) {
+            float v[8];
+            load8(x + p * cs + co + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += (double)v[j];
+                q[j] += (double)v[j] * (double)v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s_rows[((prow * 2 + 0) * 8 + j) * G + g] = s[j];
+            s_rows[((prow * 2 + 1) * 8 + j) * G + g] = q[j];
+        }
+    }
+    __syncthreads();
+    double* dst = m.part[t] + (size_t)blockIdx.x * (size_t)(2 * C);
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int g = i % G, kj = i / G;
+        double tot = 0.0;
+        for (int r = 0; r < R; ++r) tot += s_rows[(size_t)r * 2 * C + i];
+        dst[(kj >> 3) * C + g * 8 + (kj & 7)] = tot;
+    }
+}
+
+__global__ __launch_bounds__(512) void bn_train_finalize_part_multi_kernel(const BnMultiArgs m, int nblocks, int C, double n) {
+    __shared__ double red[16][33];
+    const int tn = blockIdx.y;
+    const double* __restrict__ part = m.part[tn];
+    const y6_bn_train_desc& d = m.d[tn];
     const int t = threadIdx.x, vi = t & 31, prt = t >> 5;
     const int k = vi >> 4, c = blockIdx.x * 16 + (vi & 15);
     red[prt][vi] = c < C ? part_subsum(part + (size_t)k * C + c, (size_t)2 * C, nblocks, prt) : 0.0;
@@ -292,6 +402,62 @@ int bn_train_stats_launch(const y6_bn_train_desc* d, hipStream_t s) {
                        (const __half*)d->x.data, d->x.cstride, d->x.coff, npix, G, ppb, ws, C);
     Y6_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, ws, C, (double)npix, *d);
+    Y6_LAUNCH_CHECK();
+    return Y6_OK;
+}
+
+// up to three statistics ops of one shape; anything else (different shapes, the atomic A/B form, one tensor) runs them one by one
+int bn_train_stats_multi_launch(const y6_bn_train_multi_desc* md, hipStream_t s) {
+    Y6_REQUIRE(md && md->n >= 1 && md->n <= 3, "bn_train_stats_multi: 1..3 tensors");
+    const int n = md->n;
+    bool same = n > 1 && !bn_use_atomics();
+    for (int t = 0; t < n; ++t) {
+        const y6_bn_train_desc* d = &md->d[t];
+        Y6_REQUIRE(d->scale && d->shift && d->mean && d->invstd && d->workspace, "bn_train_stats_multi: null argument");
+        Y6_REQUIRE(view_ok(d->x), "bn_train_stats_multi: the views must be fp16 NHWC with 8-channel alignment");
+        same = same && same_shape(d->x, md->d[0].x);
+        for (int u = 0; u < t; ++u)    // two ops of one launch must not share a BatchNorm (the running statistics would race)
+            Y6_REQUIRE(d->scale != md->d[u].scale && d->workspace != md->d[u].workspace &&
+                           (d->running_mean == nullptr || d->running_mean != md->d[u].running_mean),
+                       "bn_train_stats_multi: two entries share outputs");
+    }
+    static const bool off = getenv("Y6_BN_MULTI") != nullptr && atoi(getenv("Y6_BN_MULTI")) == 0;   // A/B switch
+    if (!same || off) {
+        for (int t = 0; t < n; ++t) {
+            int rc = bn_train_stats_launch(&md->d[t], s);
+            if (rc) return rc;
+        }
+        return Y6_OK;
+    }
+    const y6_tensor& x0 = md->d[0].x;
+    const int C = x0.C, G = C / 8;
+    Y6_REQUIRE(C <= 2048, "bn_train_stats: at most 2048 channels");
+    const long npix = (long)x0.B * x0.H * x0.W;
+    Y6_REQUIRE(npix > 0, "bn_train_stats: empty tensor");
+    const int R = 256 / G;
+    long ppb = (long)R * 16;                         // the geometry of bn_train_stats_launch: same blocks, same additions
+    long blocks = (npix + ppb - 1) / ppb;
+    if (blocks > kBnPartBlocks) {
+        blocks = kBnPartBlocks;
+        ppb = (npix + blocks - 1) / blocks;
+        blocks = (npix + ppb - 1) / ppb;
+    }
+    BnMultiArgs m;
+    memset(&m, 0, sizeof(m));
+    for (int t = 0; t < n; ++t) {
+        const y6_bn_train_desc* d = &md->d[t];
+        Y6_REQUIRE(d->workspace_bytes >= y6_bn_stats_workspace_bytes_for(C, npix), "bn_train_stats_multi: workspace too small");
+        m.x[t] = (const __half*)d->x.data;
+        m.cs[t] = d->x.cstride;
+        m.co[t] = d->x.coff;
+        m.part[t] = (double*)d->workspace + (size_t)2 * C;
+        m.d[t] = *d;
+    }
+    hipLaunchKernelGGL(bn_sum_part_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), (size_t)R * 2 * C * sizeof(double), s, m,
+                       npix, G, ppb, C);
+    Y6_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_train_finalize_part_multi_kernel, dim3((unsigned)((C + 15) / 16), (unsigned)n), dim3(512), 0, s, m, (int)blocks, C,
+                       (double)npix);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -1930,6 +2096,10 @@ extern "C" int y6_bn_train_stats(const y6_bn_train_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
     return bn_train_stats_launch(d, (hipStream_t)stream);
 }
+extern "C" int y6_bn_train_stats_multi(const y6_bn_train_multi_desc* d, void* stream) {
+    Y6_CLEAR_STALE_ERROR();
+    return bn_train_stats_multi_launch(d, (hipStream_t)stream);
+}
 extern "C" int y6_bnact_forward(const y6_bnact_desc* d, void* stream) {
     Y6_CLEAR_STALE_ERROR();
     return bnact_forward_launch(d, (hipStream_t)stream);
@@ -2057,6 +2227,12 @@ static double nhwc_bytes(const y6_tensor& t) { return 2.0 * t.B * t.H * t.W * t.
 extern "C" int y6_plan_add_bn_train_stats(y6_plan* p, const y6_bn_train_desc* d) {
     Y6_REQUIRE(p && d, "plan_add: null argument");
     return y6_plan_push(p, bn_train_stats_launch, d, Y6_TOP_BN_STATS, 0.0, nhwc_bytes(d->x));
+}
+extern "C" int y6_plan_add_bn_train_stats_multi(y6_plan* p, const y6_bn_train_multi_desc* d) {
+    Y6_REQUIRE(p && d && d->n >= 1 && d->n <= 3, "plan_add: null argument");
+    double bytes = 0.0;
+    for (int t = 0; t < d->n; ++t) bytes += nhwc_bytes(d->d[t].x);
+    return y6_plan_push(p, bn_train_stats_multi_launch, d, Y6_TOP_BN_STATS, 0.0, bytes);
 }
 extern "C" int y6_plan_add_bnact_forward(y6_plan* p, const y6_bnact_desc* d) {
     Y6_REQUIRE(p && d, "plan_add: null argument");

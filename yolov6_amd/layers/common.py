@@ -604,10 +604,11 @@ class RepVGGBlock(HipModule):
         s = self.rbr_dense.conv.stride[0]
         y3 = pb.conv(x, self.rbr_dense.conv.weight, s)
         y1 = pb.conv(x, self.rbr_1x1.conv.weight, s)
-        branches = [(y3, pb.bn(y3, self.rbr_dense.bn)), (y1, pb.bn(y1, self.rbr_1x1.bn))]
+        pairs = [(y3, self.rbr_dense.bn), (y1, self.rbr_1x1.bn)]
         if self.rbr_identity is not None:
-            xr = pb.as_nhwc(x)
-            branches.append((xr, pb.bn(xr, self.rbr_identity)))
+            pairs.append((pb.as_nhwc(x), self.rbr_identity))
+        stats = pb.bn_multi(pairs) if hasattr(pb, "bn_multi") else [pb.bn(t, bn) for t, bn in pairs]   # one statistics op for the block
+        branches = [(t, st) for (t, _), st in zip(pairs, stats)]
         return pb.bnact(branches, "relu", out=out, res=res, alpha=res_alpha)
 
     def lower(self, pb, x, out=None, res=None, res_alpha=None):

@@ -82,12 +82,13 @@ def train_op_access(entry: dict) -> Optional[Tuple[List[Span], List[Span]]]:
             return None                                    # an accumulating conv reads a tensor the log does not name
         rd.append(entry["x"])
         wr.append(entry["out"])
-    elif k == "bn_train_stats":
-        st, bn = entry["stats"], entry["bn"]
-        rd.append(entry["x"])
-        wr += [st.scale, st.shift, st.mean, st.invstd]
-        if getattr(bn, "track_running_stats", False) and getattr(bn, "running_mean", None) is not None:
-            wr += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+    elif k in ("bn_train_stats", "bn_train_stats_multi"):
+        items = entry["items"] if k == "bn_train_stats_multi" else [(entry["x"], entry["bn"], entry["stats"])]
+        for x, bn, st in items:
+            rd.append(x)
+            wr += [st.scale, st.shift, st.mean, st.invstd]
+            if getattr(bn, "track_running_stats", False) and getattr(bn, "running_mean", None) is not None:
+                wr += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
     elif k == "bnact_forward":
         for t, st in entry["branches"]:
             rd.append(t)

@@ -341,11 +341,10 @@ class TrainBuilder:
         self.tape.append(lambda: self._conv_backward(rec))
         return y
 
-    def bn(self, y: TRef, bn: nn.BatchNorm2d) -> BnStats:
+    def _bn_desc(self, d, y: TRef, bn: nn.BatchNorm2d) -> BnStats:
         Cn = y.C
         st = BnStats(bn, self.f32(Cn), self.f32(Cn), self.f32(Cn), self.f32(Cn))
         ws = self.bytes_(int(self.lib.y6_bn_stats_workspace_bytes_for(Cn, y.B * y.H * y.W)))   # sized for this tensor
-        d = _lib.BnTrainDesc()
         d.x = y.ct()
         d.gamma = self.arena.data_ptr(bn.weight) if bn.weight is not None else None
         d.beta = self.arena.data_ptr(bn.bias) if bn.bias is not None else None
@@ -358,8 +357,30 @@ class TrainBuilder:
         d.scale, d.shift, d.mean, d.invstd = (_ptr(t) for t in (st.scale, st.shift, st.mean, st.invstd))
         d.workspace, d.workspace_bytes = _ptr(ws), ws.numel()
         d.workspace_clean = 1          # bytes_() hands out zeroed memory and nothing else touches it: one launch per BatchNorm
+        return st
+
+    def bn(self, y: TRef, bn: nn.BatchNorm2d) -> BnStats:
+        d = _lib.BnTrainDesc()
+        st = self._bn_desc(d, y, bn)
         self._f(self.lib.y6_plan_add_bn_train_stats(self.fwd, C.byref(d)), "plan_add_bn_train_stats", x=y, bn=bn, stats=st)
         return st
+
+    def bn_multi(self, pairs) -> List[BnStats]:
+        """The statistics of up to three (tensor, BatchNorm) pairs of ONE shape as one plan op (one pair of launches instead of one
+        per tensor; same bits - include/yolov6_hip.h y6_bn_train_stats_multi): the branches of a RepVGG block.  Falls back to one op
+        per tensor for a single pair, for mixed shapes, with Y6_BN_MULTI=0 (A/B) and under the opt-in two-stream forward schedule
+        (whose point is to run the 1x1 / identity statistics beside the 3x3 conv)."""
+        pairs = list(pairs)
+        shape = {(y.B, y.H, y.W, y.C) for y, _ in pairs}
+        if (len(pairs) < 2 or len(pairs) > 3 or len(shape) != 1 or os.environ.get("Y6_BN_MULTI", "1") == "0"
+                or os.environ.get("Y6_TRAIN_FWD_STREAMS", "1") == "2"):
+            return [self.bn(y, bn) for y, bn in pairs]
+        md = _lib.BnTrainMultiDesc()
+        md.n = len(pairs)
+        sts = [self._bn_desc(md.d[i], y, bn) for i, (y, bn) in enumerate(pairs)]
+        self._f(self.lib.y6_plan_add_bn_train_stats_multi(self.fwd, C.byref(md)), "plan_add_bn_train_stats_multi",
+                items=[(y, bn, st) for (y, bn), st in zip(pairs, sts)])
+        return sts
 
     def bnact(self, branches, act, out: Optional[TRef] = None, res: Optional[TRef] = None,
               alpha: Optional[nn.Parameter] = None) -> TRef:
