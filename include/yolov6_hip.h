@@ -670,6 +670,30 @@ typedef struct y6_wgrad_flat_geom {
 int y6_wgrad_nhwc_route(const y6_wgrad_nhwc_desc* d);
 int y6_wgrad_flat_geometry(const y6_wgrad_nhwc_desc* d, y6_wgrad_flat_geom* out);
 
+/* The weight gradients of the convs that read the caller's NCHW image - the stem block of EfficientRep / CSPBepBackbone in train form
+ * (yolov6/models/efficientrep.py:28-41: RepVGGBlock(3 -> C, k3 s2), forward yolov6/layers/common.py:250-255) - in one pass over the
+ * image and the two gradients (csrc/wgrad_stem.hip):
+ *   out3[m][c][ky][kx] += sum_{b,y,x} dy3(b,y,x,m) * x(b, c, 2y+ky-1, 2x+kx-1)     3x3 stride 2 pad 1
+ *   out1[m][c]         += sum_{b,y,x} dy1(b,y,x,m) * x(b, c, 2y, 2x)               1x1 stride 2 (dy1.data == NULL: none)
+ * x: contiguous fp16 NCHW [B][Cin <= 3][H][W], H and W even; dy3 / dy1: compact NHWC views [B, H/2, W/2, >= Cout]; out3 / out1:
+ * contiguous fp32 OIHW, accumulated into.  Deterministic (block partials added in a fixed order).
+ * y6_wgrad_stem_supported: 1 when the descriptor fits (otherwise the plane-fed route of y6_wgrad serves). */
+typedef struct y6_wgrad_stem_desc {
+    const void* x;
+    int32_t in_dtype;              /* Y6_F16 */
+    int32_t B, Cin, H, W;
+    int32_t Cout;
+    y6_tensor dy3;
+    y6_tensor dy1;
+    float* out3;
+    float* out1;
+    void* workspace;               /* y6_wgrad_stem_workspace_bytes(Cout) */
+    size_t workspace_bytes;
+} y6_wgrad_stem_desc;
+size_t y6_wgrad_stem_workspace_bytes(int Cout);
+int y6_wgrad_stem_supported(const y6_wgrad_stem_desc* d);
+int y6_wgrad_stem(const y6_wgrad_stem_desc* d, void* stream);
+
 /* Per-step weight preparation: every packed fp16 MFMA weight image the step's convs read is rebuilt from the fp32
  * master parameters by ONE launch over a device job table.
  *   kind 0: forward conv    dst = pack(W[Cout][Cin][K][K])
@@ -788,6 +812,7 @@ int y6_plan_add_bnact_backward(y6_plan* p, const y6_bnact_bwd_desc* d);
 int y6_plan_add_wgrad_transpose(y6_plan* p, const y6_wgrad_t_desc* d);
 int y6_plan_add_wgrad(y6_plan* p, const y6_wgrad_desc* d);
 int y6_plan_add_wgrad_nhwc(y6_plan* p, const y6_wgrad_nhwc_desc* d);
+int y6_plan_add_wgrad_stem(y6_plan* p, const y6_wgrad_stem_desc* d);
 int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d);
 int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
 int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);

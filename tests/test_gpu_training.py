@@ -267,6 +267,54 @@ def test_wgrad_convt():
     assert float((got - w.grad).abs().max()) <= 1e-3 * float(w.grad.abs().max())
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,with_1x1", [(2, 3, 64, 64, 32, True), (1, 3, 96, 160, 16, True), (1, 3, 32, 704, 64, True),
+                                                      (2, 3, 64, 96, 48, False), (1, 1, 64, 64, 32, True), (3, 3, 70, 74, 32, True)])
+def test_wgrad_stem_one_pass_vs_autograd(B, Cin, H, W, Cout, with_1x1):
+    """csrc/wgrad_stem.hip: the 3x3 s2 and 1x1 s2 weight gradients of the stem block (efficientrep.py:28-41, train form
+    common.py:250-255) from the NCHW image and the compact NHWC gradients in one pass; accumulates; two runs agree bit for bit."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(13)
+    x = (torch.rand((B, Cin, H, W), generator=g) - 0.3).half()
+    Ho, Wo = H // 2, W // 2
+    dy3 = (torch.randn((B, Cout, Ho, Wo), generator=g) * 0.5).half().float()
+    dy1 = (torch.randn((B, Cout, Ho, Wo), generator=g) * 0.5).half().float()
+    w3 = torch.zeros((Cout, Cin, 3, 3), requires_grad=True)
+    w1 = torch.zeros((Cout, Cin, 1, 1), requires_grad=True)
+    F.conv2d(x.float(), w3, None, stride=2, padding=1).backward(dy3)
+    F.conv2d(x.float(), w1, None, stride=2).backward(dy1)
+    xd = x.to(DEV).contiguous()
+    r3, r1 = _nhwc(dy3), _nhwc(dy1)
+    ws = torch.empty(int(lib.y6_wgrad_stem_workspace_bytes(Cout)), dtype=torch.uint8, device=DEV)
+    outs = []
+    for _ in range(2):
+        o3 = torch.full((Cout, Cin, 3, 3), 1.0, dtype=torch.float32, device=DEV)       # the op accumulates
+        o1 = torch.full((Cout, Cin), -2.0, dtype=torch.float32, device=DEV)
+        d = _lib.WgradStemDesc()
+        d.x, d.in_dtype = xd.data_ptr(), _lib.Y6_F16
+        d.B, d.Cin, d.H, d.W, d.Cout = B, Cin, H, W, Cout
+        d.dy3 = r3.ct()
+        d.out3 = o3.data_ptr()
+        if with_1x1:
+            d.dy1 = r1.ct()
+            d.out1 = o1.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        if H % 2 or W % 2:
+            assert lib.y6_wgrad_stem_supported(C.byref(d)) == 0
+            return
+        assert lib.y6_wgrad_stem_supported(C.byref(d)) == 1
+        _lib.check(lib.y6_wgrad_stem(C.byref(d), _stream()), "wgrad_stem")
+        torch.cuda.synchronize()
+        outs.append((o3.cpu(), o1.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "two runs differ"
+    g3 = outs[0][0] - 1.0
+    assert float((g3 - w3.grad).abs().max()) <= 1e-3 * float(w3.grad.abs().max()) + 1e-4
+    if with_1x1:
+        g1 = outs[0][1] + 2.0
+        assert float((g1 - w1.grad.view(Cout, Cin)).abs().max()) <= 1e-3 * float(w1.grad.abs().max()) + 1e-4
+    else:
+        assert torch.equal(outs[0][1], torch.full((Cout, Cin), -2.0))
+
+
 def _bn_stats(ref: TRef, gamma, beta, rm, rv, eps=1e-3, mom=0.03):
     lib = _lib.load()
     Cn = ref.C

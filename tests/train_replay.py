@@ -254,6 +254,9 @@ class TrainChain:
             if k == "wgrad":
                 self._wgrad(i, e)
                 continue
+            if k == "wgrad_stem":
+                self._wgrad_stem(i, e)
+                continue
             if k == "channel_sum":
                 p = e["param"]
                 ref = self.get(e["x"]).double().sum((0, 2, 3)).float()
@@ -424,6 +427,23 @@ class TrainChain:
         plan.run_range(i, i + 1)
         torch.cuda.synchronize()
         self._check_param("bwd", i, e, desc, [("dW", p, ref)], 1e-3)
+
+    def _wgrad_stem(self, i, e):
+        """Both weight gradients of the stem block from the NCHW image (csrc/wgrad_stem.hip): 3x3 s2 and, if present, 1x1 s2."""
+        plan = self.g.bwd_plan
+        x = q16(e["x"].float().cpu())
+        items = []
+        for p, dyv, k in zip(e["weights"], e["dys"], (3, 1)):
+            if p is None:
+                continue
+            dy = self.get(dyv)[:, :e["cout"]]
+            w = p.detach().float().cpu().clone().requires_grad_(True)
+            (ref,) = torch.autograd.grad(F.conv2d(x, w, None, stride=2, padding=k // 2), [w], dy)
+            items.append((f"dW{k}", p, ref))
+            self._grad_view(p).zero_()
+        plan.run_range(i, i + 1)
+        torch.cuda.synchronize()
+        self._check_param("bwd", i, e, f"wgrad stem {x.shape[1]}->{e['cout']} k3+k1 s2 image {x.shape[2]}x{x.shape[3]}", items, 1e-3)
 
     def _dgrad(self, i, e):
         plan = self.g.bwd_plan

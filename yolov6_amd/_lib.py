@@ -170,6 +170,12 @@ class WgradNhwcDesc(C.Structure):
                 ("workspace_bytes", C.c_size_t)]
 
 
+class WgradStemDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("in_dtype", C.c_int32), ("B", C.c_int32), ("Cin", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Cout", C.c_int32), ("dy3", Tensor), ("dy1", Tensor), ("out3", C.c_void_p), ("out1", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
 class WgradFlatGeom(C.Structure):
     _fields_ = [("row_pitch", C.c_int32), ("plane", C.c_int32), ("flat_positions", C.c_int32), ("chunk", C.c_int32), ("chunks", C.c_int32),
                 ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tiles", C.c_int32), ("x_positions", C.c_int32), ("stages", C.c_int32),
@@ -223,7 +229,7 @@ STRUCTS = {
     "y6_pw_s2_desc": PwS2Desc, "y6_stem_s2_desc": StemS2Desc, "y6_letterbox_desc": LetterboxDesc, "y6_decode_desc": DecodeDesc,
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bn_train_multi_desc": BnTrainMultiDesc, "y6_bnact_desc": BnActDesc,
-    "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
+    "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_stem_desc": WgradStemDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
     "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_sppf_q_desc": SppfQDesc, "y6_head_pack_desc": HeadPackDesc,
     "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
 }
@@ -289,6 +295,9 @@ SIGNATURES = {
     "y6_wgrad_nhwc": (C.c_int, [C.POINTER(WgradNhwcDesc), C.c_void_p]),
     "y6_wgrad_nhwc_supported": (C.c_int, [C.POINTER(WgradNhwcDesc)]),
     "y6_wgrad_nhwc_route": (C.c_int, [C.POINTER(WgradNhwcDesc)]),
+    "y6_wgrad_stem": (C.c_int, [C.POINTER(WgradStemDesc), C.c_void_p]),
+    "y6_wgrad_stem_supported": (C.c_int, [C.POINTER(WgradStemDesc)]),
+    "y6_wgrad_stem_workspace_bytes": (C.c_size_t, [C.c_int]),
     "y6_wgrad_flat_geometry": (C.c_int, [C.POINTER(WgradNhwcDesc), C.POINTER(WgradFlatGeom)]),
     "y6_pack_job_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "y6_pack_weights_batched": (C.c_int, [C.POINTER(PackBatchDesc), C.c_void_p]),
@@ -321,6 +330,7 @@ SIGNATURES = {
     "y6_plan_add_wgrad_transpose": (C.c_int, [C.c_void_p, C.POINTER(WgradTDesc)]),
     "y6_plan_add_wgrad": (C.c_int, [C.c_void_p, C.POINTER(WgradDesc)]),
     "y6_plan_add_wgrad_nhwc": (C.c_int, [C.c_void_p, C.POINTER(WgradNhwcDesc)]),
+    "y6_plan_add_wgrad_stem": (C.c_int, [C.c_void_p, C.POINTER(WgradStemDesc)]),
     "y6_plan_add_pack_batch": (C.c_int, [C.c_void_p, C.POINTER(PackBatchDesc)]),
     "y6_plan_add_sppf_backward": (C.c_int, [C.c_void_p, C.POINTER(SppfBwdDesc)]),
     "y6_plan_add_head_pack": (C.c_int, [C.c_void_p, C.POINTER(HeadPackDesc)]),

@@ -38,6 +38,7 @@ SOURCES = {
     "train.hip": [],
     "wgrad.hip": [],
     "wgrad_flat.hip": [],
+    "wgrad_stem.hip": [],
     "quant.hip": [],
     "plan.hip": [],
 }

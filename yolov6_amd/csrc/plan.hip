@@ -52,6 +52,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
         {"y6_wgrad_t_desc", sizeof(y6_wgrad_t_desc)},
         {"y6_wgrad_desc", sizeof(y6_wgrad_desc)},
         {"y6_wgrad_nhwc_desc", sizeof(y6_wgrad_nhwc_desc)},
+        {"y6_wgrad_stem_desc", sizeof(y6_wgrad_stem_desc)},
         {"y6_wgrad_flat_geom", sizeof(y6_wgrad_flat_geom)},
         {"y6_pack_job", sizeof(y6_pack_job)},
         {"y6_pack_batch_desc", sizeof(y6_pack_batch_desc)},

@@ -137,6 +137,10 @@ def train_bwd_access(entry: dict, arena) -> Optional[Tuple[List[Span], List[Span
             rd += [_span(entry["a"])] + [_span(t) for t in entry["planes"]]
         wr.append(_grad_span(arena, entry["weight"]))
         wr.append(_span(entry["ws"]))
+    elif k == "wgrad_stem":                           # both stem convs' weight gradients from the NCHW image and the compact dy views
+        rd += [_span(entry["x"])] + [_span(t) for t in entry["dys"] if t is not None]
+        wr += [_grad_span(arena, w) for w in entry["weights"] if w is not None]
+        wr.append(_span(entry["ws"]))
     elif k == "channel_sum":
         rd.append(_span(entry["x"]))
         wr += [_grad_span(arena, entry["param"]), _span(entry["ws"])]

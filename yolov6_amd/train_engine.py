@@ -159,6 +159,9 @@ class TrainBuilder:
         self.wgrad_nhwc_minw3 = int(os.environ.get("Y6_WGRAD_NHWC_MINW3", "0"))
         self.wgrad_nhwc_minw1 = int(os.environ.get("Y6_WGRAD_NHWC_MINW1", "0"))
         self.wgrad_flat_s2 = os.environ.get("Y6_WGRAD_FLAT_S2", "1") != "0"      # A/B: stride-2 convs back on the plane-fed kernel
+        # round 6: the stem block's weight gradients (3x3 s2 + 1x1 s2 over the NCHW image) as one pass of csrc/wgrad_stem.hip
+        self.wgrad_stem = os.environ.get("Y6_WGRAD_STEM", "1") != "0"            # A/B: back on the plane-fed kernel + its transposes
+        self.stem_recs: List[ConvRec] = []
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -231,7 +234,7 @@ class TrainBuilder:
     # (include/yolov6_hip.h y6_plan_mark_side).  Their inputs are complete when they are emitted (grad_ready asserts it for
     # gradients; activations and operand planes do not change during the backward), every buffer of the graph is its own
     # allocation, and the workspaces they share (wgrad_ws) are shared among side ops only.
-    _SIDE_OPS = ("plan_add_wgrad_transpose", "plan_add_wgrad", "plan_add_channel_sum")
+    _SIDE_OPS = ("plan_add_wgrad_transpose", "plan_add_wgrad", "plan_add_wgrad_stem", "plan_add_channel_sum")
 
     def _b(self, rc, what, **log):
         _lib.check(rc, what)
@@ -338,6 +341,7 @@ class TrainBuilder:
         self.fwd_flops += 2.0 * B * Ho * Wo * Cout * Cin * K * K
         rec = ConvRec(x, y, weight, None, K, 2)
         y._conv = rec
+        self.stem_recs.append(rec)
         self.tape.append(lambda: self._conv_backward(rec))
         return y
 
@@ -691,6 +695,9 @@ class TrainBuilder:
                 self.bwd_flops += flops
                 self._conv_backward_rest(rec, dyv, is_stem)
                 return
+        if is_stem and self._stem_wgrad(rec, dyv):
+            self._conv_backward_rest(rec, dyv, is_stem)
+            return
         a = self._transpose(dyv, rec.dy_dil, rec.dy_dil, 0, 0, Ho, Q, dyv.C, B)
         if s == 1 and K == 3:
             mode = _lib.WG_3X3S1
@@ -716,6 +723,47 @@ class TrainBuilder:
             planes = [(self._transpose(xv, 2, 2, 0, 0, Ho, Q, Cin, B, xt), Ho, 0)]
         self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight), flops, a_ch=dyv.C, b_ch=Cin, log=wlog)
         self._conv_backward_rest(rec, dyv, is_stem)
+
+    def _stem_wgrad(self, rec: ConvRec, dyv: TRef) -> bool:
+        """The weight gradient(s) of the convs that read the NCHW image `rec.x.t` (the stem block: RepVGGBlock(3 -> C, k3 s2) in train
+        form, efficientrep.py:28-41 / common.py:250-255) as ONE op of csrc/wgrad_stem.hip: the 3x3 conv and - when the block has one and
+        its gradient is at hand - the 1x1 conv of the same image in the same pass.  Returns False when the plane-fed route must serve
+        (A/B switch, fp32 / uint8 images, odd sizes, a lone 1x1 conv)."""
+        if getattr(rec, "_stem_done", False):
+            return True                      # written by its partner's op
+        if not self.wgrad_stem or rec.stride != 2 or rec.dy_dil != 1:
+            return False
+        xt = rec.x.t
+        mates = [r for r in self.stem_recs if r is not rec and r.x.t is xt and r.stride == 2 and r.k != rec.k and r.dy is not None
+                 and r.dy_dil == 1 and not getattr(r, "_stem_done", False) and r.weight.shape[0] == rec.weight.shape[0]]
+        r3 = rec if rec.k == 3 else (mates[0] if mates else None)
+        r1 = rec if rec.k == 1 else (mates[0] if mates else None)
+        if r3 is None or r3.k != 3 or (r1 is not None and r1.k != 1):
+            return False
+
+        def view(r):
+            return TRef(r.dy.buf, r.dy.B, r.dy.H, r.dy.W, r.cpad or r.dy.C, r.dy.cstride, r.dy.coff)
+        B, Cin, H, W = xt.shape
+        Cout = r3.weight.shape[0]
+        d = _lib.WgradStemDesc()
+        d.x, d.in_dtype = xt.data_ptr(), _dtype_tag(xt)
+        d.B, d.Cin, d.H, d.W, d.Cout = B, Cin, H, W, Cout
+        v3 = view(r3)
+        v1 = view(r1) if r1 is not None else None
+        d.dy3 = v3.ct()
+        d.dy1 = v1.ct() if v1 is not None else _null_tensor()
+        d.out3 = self.arena.grad_ptr(r3.weight)
+        d.out1 = self.arena.grad_ptr(r1.weight) if r1 is not None else None
+        d.workspace, d.workspace_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel()
+        if not xt.is_contiguous() or not self.lib.y6_wgrad_stem_supported(C.byref(d)):
+            return False
+        self._b(self.lib.y6_plan_add_wgrad_stem(self.bwd, C.byref(d)), "plan_add_wgrad_stem", x=xt, dys=[v3, v1],
+                weights=[r3.weight, r1.weight if r1 is not None else None], ws=self.wgrad_ws, cout=Cout)
+        self.bwd_flops += 2.0 * Cout * Cin * (9 + (1 if r1 is not None else 0)) * B * v3.H * v3.W
+        for r in (r3, r1):
+            if r is not None and r is not rec:
+                r._stem_done = True
+        return True
 
     def _conv_backward_rest(self, rec: ConvRec, dyv: TRef, is_stem: bool):
         """Bias gradient and data gradient of one conv (after its weight gradient)."""
