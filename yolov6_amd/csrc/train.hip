@@ -1351,8 +1351,8 @@ int wgrad_transpose_launch(const y6_wgrad_t_desc* d, hipStream_t s) {
 
 // ------------------------------------------------------------------ batched weight packing
 // packed layout as y6_pack_conv_weight: dst[cfr][chunk][tap][ks][lane][j] = W'[o = cfr*32 + (lane&31)][i = chunk*32 + ks*16 + (lane>>5)*8 + j][tap]
-__global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t total) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_one_element(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t i) {
+    {
         int lo = 0, hi = njobs - 1;                 // last job with first <= i
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
         if (jb.kind == 4) {       // fp32 [Cout][Cin][3][3] with the 1x1 kernel at the centre tap (the stem's 1x1 stride-2 branch)
             const uint64_t oi = e / 9;
             reinterpret_cast<float*>(jb.dst)[e] = (e - oi * 9 == 4) ? jb.src[oi] : 0.f;
-            continue;
+            return;
         }
         const int K = jb.K, NT = K * K;
         if (jb.kind == 2 && (jb.Cout % 32) != 0) {    // un-fused ConvTranspose2d image: four separately padded 1x1 weights
@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
             float v2 = 0.f;
             if (co < jb.Cout && ci < jb.Cin) v2 = jb.src[((size_t)ci * jb.Cout + co) * 4 + sub];
             reinterpret_cast<__half*>(jb.dst)[e] = __float2half(v2);
-            continue;
+            return;
         }
         // logical output-channel / input-channel counts of the packed matrix
         int O = jb.Cout, I = jb.Cin;
@@ -1413,9 +1413,71 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
     }
 }
 
+
+// (round 6, last session) one thread per EIGHT packed elements: the eight consecutive input channels of one (cout, tap) that form a
+// 16-byte run of the packed image - one job search, one index decode and one 16-byte store instead of eight (the per-element form
+// was 37 M threads-iterations with a binary search each: 0.32 ms per training step at 0.8 TB/s).  Groups that are not a whole run of
+// a conv / convT job (the fp32 centre-tap image of kind 4, the un-fused ConvTranspose2d image, a job boundary) take the
+// per-element code.
+__global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t total) {
+    const uint64_t groups = (total + 7) >> 3;
+    for (uint64_t g8 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g8 < groups; g8 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = g8 << 3;
+        int lo = 0, hi = njobs - 1;                 // last job with first <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first <= i) lo = mid; else hi = mid - 1;
+        }
+        const y6_pack_job jb = jobs[lo];
+        const uint64_t e = i - jb.first;
+        const uint64_t end = lo + 1 < njobs ? jobs[lo + 1].first : total;
+        const bool fused_t = jb.kind != 2 || (jb.Cout % 32) == 0;
+        if (jb.kind == 4 || !fused_t || (e & 7) != 0 || i + 8 > end) {
+            for (uint64_t k = i; k < i + 8 && k < total; ++k) pack_one_element(jobs, njobs, k);
+            continue;
+        }
+        const int K = jb.K, NT = K * K;
+        int O = jb.Cout, I = jb.Cin;
+        if (jb.kind == 1) { O = jb.Cin; I = jb.Cout; }
+        if (jb.kind == 2) { O = 4 * jb.Cout; I = jb.Cin; }
+        if (jb.kind == 3) { O = jb.Cin; I = 4 * jb.Cout; }
+        const int nchunk = (I + 31) / 32;
+        const int nt = (jb.kind >= 2) ? 1 : NT;
+        const int lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+        uint64_t r = e >> 10;
+        const int tap = (int)(r % nt);
+        r /= nt;
+        const int chunk = (int)(r % nchunk);
+        const int cfr = (int)(r / nchunk);
+        const int o = cfr * 32 + (lane & 31);
+        const int ic0 = chunk * 32 + ks * 16 + (lane >> 5) * 8;
+        h8_t out;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ic = ic0 + j;
+            float v = 0.f;
+            if (o < O && ic < I) {
+                if (jb.kind == 0) {
+                    v = jb.src[((size_t)o * jb.Cin + ic) * NT + tap];
+                } else if (jb.kind == 1) {
+                    v = jb.src[((size_t)ic * jb.Cin + o) * NT + (NT - 1 - tap)];
+                } else if (jb.kind == 2) {
+                    const int sub = o / jb.Cout, co = o - sub * jb.Cout;
+                    v = jb.src[((size_t)ic * jb.Cout + co) * 4 + sub];
+                } else {
+                    const int sub = ic / jb.Cout, co = ic - sub * jb.Cout;
+                    v = jb.src[((size_t)o * jb.Cout + co) * 4 + sub];
+                }
+            }
+            out[j] = (_Float16)v;
+        }
+        *reinterpret_cast<h8_t*>(reinterpret_cast<__half*>(jb.dst) + e) = out;
+    }
+}
+
 int pack_batch_launch(const y6_pack_batch_desc* d, hipStream_t s) {
     Y6_REQUIRE(d && d->jobs && d->njobs > 0 && d->total > 0, "pack_weights_batched: bad arguments");
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(grid_for((size_t)d->total, 256, 256 * 64)), dim3(256), 0, s, d->jobs, d->njobs, d->total);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(grid_for(((size_t)d->total + 7) / 8, 256, 256 * 64)), dim3(256), 0, s, d->jobs, d->njobs, d->total);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -1599,6 +1661,77 @@ __global__ __launch_bounds__(256) void head_unpack_kernel(const HeadArgs a) {
     }
 }
 
+// (round 6, last session) four channels per thread - an 8-byte fp16 access and a 16-byte fp32 access, one index decode per four
+// elements (the per-element kernels ran at 1.1 / 2.7 TB/s: 64-bit divisions and 2-byte accesses per element); the same arithmetic
+// per element, so the same bits.  Taken when every channel count / pitch / offset is a multiple of four.
+__global__ __launch_bounds__(256) void head_pack4_kernel(const HeadArgs a) {
+    const unsigned gc = (unsigned)a.nc >> 2, per = gc + ((unsigned)a.nreg >> 2);
+    const unsigned total = (unsigned)a.B * (unsigned)a.A * per;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ba = i / per, g = i - ba * per;
+        const unsigned b = ba / (unsigned)a.A, an = ba - b * (unsigned)a.A;
+        int l = 0;
+        while (l + 1 < a.n_levels && (int)an >= a.a0[l + 1]) ++l;
+        const size_t pix = (size_t)b * a.hw[l] + (an - a.a0[l]);
+        if (g < gc) {
+            float z[4];
+            load4(a.cls[l] + pix * a.ccs[l] + a.cco[l] + 4 * g, z);
+            float4 o;
+            o.x = 1.f / (1.f + expf(-z[0]));
+            o.y = 1.f / (1.f + expf(-z[1]));
+            o.z = 1.f / (1.f + expf(-z[2]));
+            o.w = 1.f / (1.f + expf(-z[3]));
+            *reinterpret_cast<float4*>(a.scores + (size_t)ba * a.nc + 4 * g) = o;
+        } else {
+            const unsigned r = 4 * (g - gc);
+            float v[4];
+            load4(a.reg[l] + pix * a.rcs[l] + a.rco[l] + r, v);
+            *reinterpret_cast<float4*>(a.distri + (size_t)ba * a.nreg + r) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void head_unpack4_kernel(const HeadArgs a) {
+    const unsigned gc = (unsigned)a.nc >> 2, per = gc + ((unsigned)a.nreg >> 2);
+    const unsigned total = (unsigned)a.B * (unsigned)a.A * per;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ba = i / per, g = i - ba * per;
+        const unsigned b = ba / (unsigned)a.A, an = ba - b * (unsigned)a.A;
+        int l = 0;
+        while (l + 1 < a.n_levels && (int)an >= a.a0[l + 1]) ++l;
+        const size_t pix = (size_t)b * a.hw[l] + (an - a.a0[l]);
+        float o[4];
+        if (g < gc) {
+            const float4 p = *reinterpret_cast<const float4*>(a.scores + (size_t)ba * a.nc + 4 * g);
+            const float4 d = *reinterpret_cast<const float4*>(a.dscores + (size_t)ba * a.nc + 4 * g);
+            o[0] = d.x * p.x * (1.f - p.x);
+            o[1] = d.y * p.y * (1.f - p.y);
+            o[2] = d.z * p.z * (1.f - p.z);
+            o[3] = d.w * p.w * (1.f - p.w);
+            store4(a.dcls[l] + pix * a.ccs[l] + a.cco[l] + 4 * g, o);
+        } else {
+            const unsigned r = 4 * (g - gc);
+            const float4 d = *reinterpret_cast<const float4*>(a.ddistri + (size_t)ba * a.nreg + r);
+            o[0] = d.x, o[1] = d.y, o[2] = d.z, o[3] = d.w;
+            store4(a.dreg[l] + pix * a.rcs[l] + a.rco[l] + r, o);
+        }
+    }
+}
+
+// every access of the four-channel kernels is aligned
+bool head_vec4_ok(const HeadArgs& a, bool backward) {
+    static const bool off = getenv("Y6_HEAD_VEC4") != nullptr && atoi(getenv("Y6_HEAD_VEC4")) == 0;   // A/B switch
+    if (off || a.nc % 4 || a.nreg % 4 || a.nreg == 0) return false;
+    if ((double)a.B * a.A * ((a.nc + a.nreg) / 4) >= 4.0e9) return false;
+    auto al = [](const void* p, size_t n) { return (((uintptr_t)p) & (n - 1)) == 0; };
+    for (int l = 0; l < a.n_levels; ++l) {
+        if (a.rcs[l] % 4 || a.rco[l] % 4 || !al(a.reg[l], 8)) return false;
+        if (a.nc && (a.ccs[l] % 4 || a.cco[l] % 4 || !al(a.cls[l], 8))) return false;
+    }
+    if (a.nc && (!al(a.scores, 16) || (backward && !al(a.dscores, 16)))) return false;
+    return backward ? al(a.ddistri, 16) : al(a.distri, 16);
+}
+
 int fill_head_args(const y6_head_pack_desc* d, HeadArgs* a, bool backward) {
     // nc == 0: a regression-only pack (the plain-distance output of the distillation head, effidehead_distill_ns.py:95-101)
     Y6_REQUIRE(d && d->n_levels >= 1 && d->n_levels <= 4 && (d->scores || d->nc == 0), "head_pack: bad descriptor");
@@ -1638,7 +1771,10 @@ int head_pack_launch(const y6_head_pack_desc* d, hipStream_t s) {
     HeadArgs a;
     int rc = fill_head_args(d, &a, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_pack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
+    if (head_vec4_ok(a, false))
+        hipLaunchKernelGGL(head_pack4_kernel, dim3(grid_for((size_t)a.B * a.A * ((a.nc + a.nreg) / 4), 256, 256 * 32)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(head_pack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
@@ -1646,7 +1782,10 @@ int head_unpack_launch(const y6_head_pack_desc* d, hipStream_t s) {
     HeadArgs a;
     int rc = fill_head_args(d, &a, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_unpack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
+    if (head_vec4_ok(a, true))
+        hipLaunchKernelGGL(head_unpack4_kernel, dim3(grid_for((size_t)a.B * a.A * ((a.nc + a.nreg) / 4), 256, 256 * 32)), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(head_unpack_kernel, dim3(grid_for((size_t)a.B * a.A * (a.nc + a.nreg), 256, 256 * 32)), dim3(256), 0, s, a);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
