@@ -515,7 +515,7 @@ enum { Y6_TOP_BN_STATS = 1, Y6_TOP_BNACT_FWD = 2, Y6_TOP_BNACT_BWD = 3, Y6_TOP_W
        Y6_TOP_CONV_I8 = 14, Y6_TOP_ABSMAX = 15, Y6_TOP_QUANT = 16,
        /* fused inference ops (generic plan ops as well) */
        Y6_TOP_PRED_DECODE = 17, Y6_TOP_PW_S2 = 18, Y6_TOP_STEM_S2 = 19,
-       Y6_TOP_AVGPOOL3 = 20, Y6_TOP_SPPF_Q = 21 };
+       Y6_TOP_AVGPOOL3 = 20, Y6_TOP_SPPF_Q = 21, Y6_TOP_DGRAD_S2 = 22 };
 
 /* Batch statistics of a conv output + everything derived from them, on device:
  *   mean, biased var over B*H*W -> invstd = 1/sqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale;
@@ -725,6 +725,23 @@ typedef struct y6_sppf_bwd_desc {
 } y6_sppf_bwd_desc;
 int y6_sppf_pool_backward(const y6_sppf_bwd_desc* d, void* stream);
 
+/* Data gradient of a 3x3 stride-2 conv - and of the 1x1 stride-2 conv that reads the same input (RepVGGBlock(k3 s2) in train
+ * form, common.py:250-255; ConvBNReLU / ConvBNSiLU(k3 s2), common.py:26-94) - from the COMPACT output gradients: the input half of
+ * autograd's conv backward under scaler.scale(loss).backward() (core/engine.py:173).  Four parity classes of dx, nine (ten) tap
+ * GEMMs over dy (csrc/dgrad_s2.hip); every element of dx is written once, or added to what dx holds (`accumulate`, the two
+ * roundings of the accumulating convs).  M = dy3.C and N = dx.C multiples of 32, dx = [B, 2*Ho, 2*Wo, N], 16-byte aligned views.
+ *   w3_packed / w1_packed: the data-gradient images of the 3x3 / 1x1 weight (y6_pack_job kind 1 with K = 3 / 1). */
+typedef struct y6_dgrad_s2_desc {
+    y6_tensor dy3;                 /* [B, Ho, Wo, M] gradient of the 3x3 conv's output */
+    y6_tensor dy1;                 /* gradient of the 1x1 conv's output, same shape (data == NULL: no 1x1 branch) */
+    y6_tensor dx;                  /* [B, 2*Ho, 2*Wo, N] */
+    const void* w3_packed;
+    const void* w1_packed;         /* NULL without dy1 */
+    int32_t accumulate;            /* 1: dx += ... */
+} y6_dgrad_s2_desc;
+int y6_dgrad_s2_supported(const y6_dgrad_s2_desc* d);
+int y6_dgrad_s2(const y6_dgrad_s2_desc* d, void* stream);
+
 /* Detect training branch (effidehead.py:72-92): per-level NHWC prediction maps -> cls_scores [B,A,nc] = sigmoid(logits),
  * reg_distri [B,A,nreg], both fp32 (the loss computes in fp32, loss.py:208); and its backward
  * dlogit = dscore * p * (1-p), dreg passes through, written as NHWC fp16 per level. */
@@ -815,6 +832,7 @@ int y6_plan_add_wgrad_nhwc(y6_plan* p, const y6_wgrad_nhwc_desc* d);
 int y6_plan_add_wgrad_stem(y6_plan* p, const y6_wgrad_stem_desc* d);
 int y6_plan_add_pack_batch(y6_plan* p, const y6_pack_batch_desc* d);
 int y6_plan_add_sppf_backward(y6_plan* p, const y6_sppf_bwd_desc* d);
+int y6_plan_add_dgrad_s2(y6_plan* p, const y6_dgrad_s2_desc* d);         /* generic op, tag Y6_TOP_DGRAD_S2 */
 int y6_plan_add_head_pack(y6_plan* p, const y6_head_pack_desc* d);
 int y6_plan_add_head_unpack_backward(y6_plan* p, const y6_head_pack_desc* d);
 int y6_plan_add_head_ab_pack(y6_plan* p, const y6_head_ab_desc* d);

@@ -268,6 +268,9 @@ class TrainChain:
             if k == "conv":
                 self._dgrad(i, e)
                 continue
+            if k == "dgrad_s2":
+                self._dgrad_s2(i, e)
+                continue
             if k == "avgpool3":            # backward of the branch: the same (self-adjoint) op on the gradient, maybe accumulating
                 gv = self.get(e["x"])
                 d = F.avg_pool2d(gv, 3, 1, 1) + (gv if e["with_identity"] else 0.0)
@@ -472,5 +475,28 @@ class TrainChain:
         plan.run_range(i, i + 1)
         torch.cuda.synchronize()
         v16 = self.put(out, dx, acc=bool(e["acc"]))
+        self._cmp("bwd", i, e, desc, [("dx", self.download(out), v16)], 3e-3)
+        self.upload(out, v16)
+
+    def _dgrad_s2(self, i, e):
+        """csrc/dgrad_s2.hip: dx of a stride-2 3x3 conv and, when present, of the 1x1 stride-2 conv of the same input, from the
+        compact gradients, one launch."""
+        plan = self.g.bwd_plan
+        out = e["out"]
+        dx = None
+        names = []
+        for dyv, p, k in zip(e["dys"], e["weights"], (3, 1)):
+            if dyv is None:
+                continue
+            dy = self.get(dyv)[:, :p.shape[0]]
+            t = F.conv_transpose2d(dy, self._w16(p), None, stride=2, padding=k // 2, output_padding=1)
+            dx = t if dx is None else dx + t
+            names.append(f"k{k}")
+        p3 = e["weights"][0]
+        assert dx.shape[2:] == (out.H, out.W), (dx.shape, out.H, out.W)
+        plan.run_range(i, i + 1)
+        torch.cuda.synchronize()
+        v16 = self.put(out, dx, acc=bool(e["acc"]))
+        desc = f"dgrad_s2 {p3.shape[0]}->{p3.shape[1]} {'+'.join(names)} out {out.H}x{out.W}{' acc' if e['acc'] else ''}"
         self._cmp("bwd", i, e, desc, [("dx", self.download(out), v16)], 3e-3)
         self.upload(out, v16)

@@ -196,6 +196,11 @@ class SppfBwdDesc(C.Structure):
                 ("dx", Tensor), ("dx_acc", C.c_int32)]
 
 
+class DgradS2Desc(C.Structure):
+    _fields_ = [("dy3", Tensor), ("dy1", Tensor), ("dx", Tensor), ("w3_packed", C.c_void_p), ("w1_packed", C.c_void_p),
+                ("accumulate", C.c_int32)]
+
+
 class SppfQDesc(C.Structure):
     _fields_ = [("x", Tensor), ("y1", Tensor), ("y2", Tensor), ("y3", Tensor), ("q1", Tensor), ("q2", Tensor), ("q3", Tensor),
                 ("q_amax", C.c_float), ("pad", C.c_int32 * 3)]
@@ -219,7 +224,7 @@ class LossGradDesc(C.Structure):
 WG_3X3S1, WG_1X1, WG_3X3S2, WG_CONVT = 0, 1, 2, 3
 TOP_NAMES = {1: "bn_stats", 2: "bnact_fwd", 3: "bnact_bwd", 4: "wgrad_transpose", 5: "wgrad", 6: "pack", 7: "pool_bwd",
              8: "head_pack", 9: "head_unpack", 10: "s2d", 11: "bias_grad", 12: "fill", 13: "add", 14: "conv_i8", 15: "absmax", 16: "quantize",
-             17: "pred_decode", 18: "pw_s2", 19: "stem_s2", 20: "avgpool3", 21: "sppf"}
+             17: "pred_decode", 18: "pw_s2", 19: "stem_s2", 20: "avgpool3", 21: "sppf", 22: "conv_dgrad_s2"}
 
 IOU_TYPES = {"giou": 0, "diou": 1, "ciou": 2, "siou": 3}
 
@@ -230,7 +235,7 @@ STRUCTS = {
     "y6_pred_decode_desc": PredDecodeDesc, "y6_nms_sink": NmsSink, "y6_nms_desc": NmsDesc, "y6_tal_desc": TalDesc, "y6_atss_desc": AtssDesc,
     "y6_loss_desc": LossDesc, "y6_distill_desc": DistillDesc, "y6_bn_train_desc": BnTrainDesc, "y6_bn_train_multi_desc": BnTrainMultiDesc, "y6_bnact_desc": BnActDesc,
     "y6_bnact_bwd_desc": BnActBwdDesc, "y6_wgrad_t_desc": WgradTDesc, "y6_wgrad_desc": WgradDesc, "y6_wgrad_nhwc_desc": WgradNhwcDesc, "y6_wgrad_stem_desc": WgradStemDesc, "y6_wgrad_flat_geom": WgradFlatGeom,
-    "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_sppf_q_desc": SppfQDesc, "y6_head_pack_desc": HeadPackDesc,
+    "y6_pack_job": PackJob, "y6_pack_batch_desc": PackBatchDesc, "y6_sppf_bwd_desc": SppfBwdDesc, "y6_dgrad_s2_desc": DgradS2Desc, "y6_sppf_q_desc": SppfQDesc, "y6_head_pack_desc": HeadPackDesc,
     "y6_head_ab_desc": HeadAbDesc, "y6_loss_grad_desc": LossGradDesc,
 }
 
@@ -310,6 +315,9 @@ SIGNATURES = {
     "y6_plan_add_head_ab_unpack_backward": (C.c_int, [C.c_void_p, C.POINTER(HeadAbDesc)]),
     "y6_space_to_depth2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
     "y6_subsample2": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_void_p]),
+    "y6_dgrad_s2_supported": (C.c_int, [C.POINTER(DgradS2Desc)]),
+    "y6_dgrad_s2": (C.c_int, [C.POINTER(DgradS2Desc), C.c_void_p]),
+    "y6_plan_add_dgrad_s2": (C.c_int, [C.c_void_p, C.POINTER(DgradS2Desc)]),
     "y6_plan_add_subsample2": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor)]),
     "y6_avgpool3": (C.c_int, [C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_int, C.c_void_p]),
     "y6_plan_add_avgpool3": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.POINTER(Tensor), C.c_int, C.c_int]),

@@ -39,6 +39,7 @@ SOURCES = {
     "wgrad.hip": [],
     "wgrad_flat.hip": [],
     "wgrad_stem.hip": [],
+    "dgrad_s2.hip": [],
     "quant.hip": [],
     "plan.hip": [],
 }

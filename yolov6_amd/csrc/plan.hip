@@ -57,6 +57,7 @@ extern "C" size_t y6_abi_sizeof(const char* name) {
         {"y6_pack_job", sizeof(y6_pack_job)},
         {"y6_pack_batch_desc", sizeof(y6_pack_batch_desc)},
         {"y6_sppf_bwd_desc", sizeof(y6_sppf_bwd_desc)},
+        {"y6_dgrad_s2_desc", sizeof(y6_dgrad_s2_desc)},
         {"y6_sppf_q_desc", sizeof(y6_sppf_q_desc)},
         {"y6_head_pack_desc", sizeof(y6_head_pack_desc)},
         {"y6_head_ab_desc", sizeof(y6_head_ab_desc)},

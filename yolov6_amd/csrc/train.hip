@@ -1577,6 +1577,148 @@ __global__ __launch_bounds__(256) void sppf_bwd_kernel(const SppfBwdArgs a) {
     }
 }
 
+// Second form (round 6): the argmax of every window is found ONCE, separably - the leftmost maximum of each 5-wide row piece, then
+// the first row that holds the window's maximum: torch's first maximum in row-major order - and kept as a 16-bit pixel index; then
+// every INPUT pixel gathers from the <= 25 outputs whose window holds it, in row-major order of the outputs.  No rounds (the
+// scatter form above walks 25 rounds x 3 stages with half of the block idle and 25 dependent LDS reads per output: 0.41 ms for
+// the 13 MB tensors of a YOLOv6-S step), no atomics, the same additions in the same order on every run.
+// block = (image, 8-channel group), 256 threads, a thread item = (pixel, channel pair): consecutive lanes touch consecutive words.
+struct SppfLds {
+    _Float16* vin;            // [HW][8] forward plane of the stage's input
+    _Float16* rmv;            // [HW][8] maximum of the row piece x-2 .. x+2
+    unsigned short* rmi;      // [HW][8] ... and the x of its leftmost occurrence
+    unsigned short* arg;      // [HW][8] pixel index of the window's first maximum
+    float *gA, *gB;           // [HW][8] gradients
+};
+
+__device__ __forceinline__ void pool_gather(const SppfLds& L, const float* __restrict__ gout, float* __restrict__ gin, int H, int W,
+                                            int tid) {
+    // branch-free on purpose: every LDS read of an item is unconditional (clamped index, the result masked), so the 5 / 5 / 50 reads
+    // of the three passes go out back to back instead of one round trip per neighbour
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int n = H * W * 4;
+    for (int i = tid; i < n; i += 256) {                     // row maxima (strict >: the leftmost one; values are finite)
+        const int cp = i & 3, p = i >> 2;
+        const int y = p / W, x = p - y * W;
+        float b0 = -INFINITY, b1 = -INFINITY;
+        int i0 = x, i1 = x;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            const bool ok = (unsigned)xx < (unsigned)W;
+            const int xc = ok ? xx : x;
+            const h2 v = *reinterpret_cast<const h2*>(L.vin + (y * W + xc) * 8 + cp * 2);
+            const float v0 = (float)v[0], v1 = (float)v[1];
+            const bool t0 = ok && v0 > b0, t1 = ok && v1 > b1;
+            b0 = t0 ? v0 : b0;
+            i0 = t0 ? xx : i0;
+            b1 = t1 ? v1 : b1;
+            i1 = t1 ? xx : i1;
+        }
+        h2 o;
+        o[0] = (_Float16)b0;
+        o[1] = (_Float16)b1;
+        *reinterpret_cast<h2*>(L.rmv + p * 8 + cp * 2) = o;
+        *reinterpret_cast<unsigned*>(L.rmi + p * 8 + cp * 2) = (unsigned)i0 | ((unsigned)i1 << 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {                     // first row holding the window maximum -> argmax pixel
+        const int cp = i & 3, p = i >> 2;
+        const int y = p / W, x = p - y * W;
+        float b0 = -INFINITY, b1 = -INFINITY;
+        unsigned a0 = p, a1 = p;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            const bool ok = (unsigned)yy < (unsigned)H;
+            const int yc = ok ? yy : y;
+            const h2 v = *reinterpret_cast<const h2*>(L.rmv + (yc * W + x) * 8 + cp * 2);
+            const unsigned xi = *reinterpret_cast<const unsigned*>(L.rmi + (yc * W + x) * 8 + cp * 2);
+            const float v0 = (float)v[0], v1 = (float)v[1];
+            const bool t0 = ok && v0 > b0, t1 = ok && v1 > b1;
+            b0 = t0 ? v0 : b0;
+            a0 = t0 ? (unsigned)yc * W + (xi & 0xffffu) : a0;
+            b1 = t1 ? v1 : b1;
+            a1 = t1 ? (unsigned)yc * W + (xi >> 16) : a1;
+        }
+        *reinterpret_cast<unsigned*>(L.arg + p * 8 + cp * 2) = a0 | (a1 << 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {                     // gin[q] += the gradients of the outputs whose argmax is q, row-major
+        const int cp = i & 3, q = i >> 2;
+        const int y = q / W, x = q - y * W;
+        float a0 = gin[q * 8 + cp * 2], a1 = gin[q * 8 + cp * 2 + 1];
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy) {
+            const int yy = y + dy;
+            const bool oky = (unsigned)yy < (unsigned)H;
+            const int yc = oky ? yy : y;
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int xx = x + dx;
+                const bool ok = oky && (unsigned)xx < (unsigned)W;
+                const int pc = yc * W + (((unsigned)xx < (unsigned)W) ? xx : x);
+                const unsigned ar = *reinterpret_cast<const unsigned*>(L.arg + pc * 8 + cp * 2);
+                const float2 gv = *reinterpret_cast<const float2*>(gout + pc * 8 + cp * 2);
+                a0 += (ok && (int)(ar & 0xffffu) == q) ? gv.x : 0.f;
+                a1 += (ok && (int)(ar >> 16) == q) ? gv.y : 0.f;
+            }
+        }
+        *reinterpret_cast<float2*>(gin + q * 8 + cp * 2) = make_float2(a0, a1);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void sppf_bwd2_kernel(const SppfBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm2[];
+    const int HW = a.H * a.W, G = a.C >> 3;
+    const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+    SppfLds L;
+    L.gA = reinterpret_cast<float*>(sm2);
+    L.gB = L.gA + HW * 8;
+    L.vin = reinterpret_cast<_Float16*>(L.gB + HW * 8);
+    L.rmv = L.vin + HW * 8;
+    L.rmi = reinterpret_cast<unsigned short*>(L.rmv + HW * 8);
+    L.arg = L.rmi + HW * 8;
+    const int tid = threadIdx.x;
+    auto load_f = [&](const __half* base, int cs, int co, float* dst, bool add) {
+        for (int p = tid; p < HW; p += 256) {
+            float v[8];
+            load8(base + ((size_t)b * HW + p) * cs + co + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[p * 8 + j] = add ? dst[p * 8 + j] + v[j] : v[j];
+        }
+    };
+    auto load_h = [&](const __half* base, int cs, int co) {
+        for (int p = tid; p < HW; p += 256)
+            *reinterpret_cast<uint4*>(L.vin + p * 8) = *reinterpret_cast<const uint4*>(base + ((size_t)b * HW + p) * cs + co + g * 8);
+    };
+    // stage 3: y2 -> y3
+    load_h(a.y2, a.cs[2], a.co[2]);
+    load_f(a.dy3, a.cs[5], a.co[5], L.gA, false);
+    load_f(a.dy2, a.cs[4], a.co[4], L.gB, false);        // gradient that reached y2 directly
+    __syncthreads();
+    pool_gather(L, L.gA, L.gB, a.H, a.W, tid);
+    // stage 2: y1 -> y2 ; gB holds d y2
+    load_h(a.y1, a.cs[1], a.co[1]);
+    load_f(a.dy1, a.cs[3], a.co[3], L.gA, false);
+    __syncthreads();
+    pool_gather(L, L.gB, L.gA, a.H, a.W, tid);           // gA now holds d y1
+    // stage 1: x -> y1 ; result into gB
+    load_h(a.x, a.cs[0], a.co[0]);
+    if (a.acc) load_f(a.dx, a.cs[6], a.co[6], L.gB, false);
+    else
+        for (int i = tid; i < HW * 8; i += 256) L.gB[i] = 0.f;
+    __syncthreads();
+    pool_gather(L, L.gA, L.gB, a.H, a.W, tid);
+    for (int p = tid; p < HW; p += 256) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = L.gB[p * 8 + j];
+        store8(a.dx + ((size_t)b * HW + p) * a.cs[6] + a.co[6] + g * 8, v);
+    }
+}
+
 int sppf_backward_launch(const y6_sppf_bwd_desc* d, hipStream_t s) {
     Y6_REQUIRE(d, "sppf_pool_backward: null argument");
     const y6_tensor* t[7] = {&d->x, &d->y1, &d->y2, &d->dy1, &d->dy2, &d->dy3, &d->dx};
@@ -1598,6 +1740,19 @@ int sppf_backward_launch(const y6_sppf_bwd_desc* d, hipStream_t s) {
     a.W = d->x.W;
     a.C = d->x.C;
     a.acc = d->dx_acc;
+    // the gather form (round 6) where its six planes fit the LDS and the 16-bit pixel indices reach (Y6_SPPF_BWD=0: A/B)
+    static const bool gather_form = !(getenv("Y6_SPPF_BWD") && atoi(getenv("Y6_SPPF_BWD")) == 0);
+    const size_t lds2 = (size_t)a.H * a.W * 8 * (2 * sizeof(float) + 4 * sizeof(unsigned short));
+    if (gather_form && lds2 <= 160 * 1024 - 1024 && a.H * a.W < 65536) {
+        static bool big2 = false;
+        if (lds2 > 64 * 1024 && !big2) {
+            Y6_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_bwd2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            big2 = true;
+        }
+        hipLaunchKernelGGL(sppf_bwd2_kernel, dim3((unsigned)(d->x.B * (a.C / 8))), dim3(256), lds2, s, a);
+        Y6_LAUNCH_CHECK();
+        return Y6_OK;
+    }
     const size_t lds = (size_t)3 * a.H * a.W * 8 * sizeof(float);
     Y6_REQUIRE(lds <= 160 * 1024 - 1024, "sppf_pool_backward: %dx%d plane does not fit the LDS", a.H, a.W);
     if (lds > 64 * 1024)

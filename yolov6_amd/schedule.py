@@ -127,6 +127,11 @@ def train_bwd_access(entry: dict, arena) -> Optional[Tuple[List[Span], List[Span
         wr.append(_span(entry["out"]))
         if entry.get("acc"):
             rd.append(_span(entry["out"]))
+    elif k == "dgrad_s2":                             # both branches of a stride-2 block: compact dy views in, dx out
+        rd += [_span(t) for t in entry["dys"] if t is not None]
+        wr.append(_span(entry["out"]))
+        if entry.get("acc"):
+            rd.append(_span(entry["out"]))
     elif k == "wgrad_transpose":
         rd.append(_span(entry["src"]))
         wr.append(_span(entry["dst"]))

@@ -162,6 +162,9 @@ class TrainBuilder:
         # round 6: the stem block's weight gradients (3x3 s2 + 1x1 s2 over the NCHW image) as one pass of csrc/wgrad_stem.hip
         self.wgrad_stem = os.environ.get("Y6_WGRAD_STEM", "1") != "0"            # A/B: back on the plane-fed kernel + its transposes
         self.stem_recs: List[ConvRec] = []
+        # round 6: the data gradient of the stride-2 convs from the COMPACT gradient (csrc/dgrad_s2.hip: four parity classes, the
+        # 1x1 branch of a RepVGG block in the same launch) instead of the stride-1 conv over a zero-inserted one
+        self.dgrad_s2 = os.environ.get("Y6_DGRAD_S2", "1") != "0"              # A/B: zero-inserted dy + the stride-1 kernels
 
     # ------------------------------------------------------------------ memory
     def new_buffer(self, B, H, W, C_, zero=False) -> TRef:
@@ -565,7 +568,8 @@ class TrainBuilder:
                     finals.append(bn.bias)
             rec = getattr(t, "_conv", None)
             if rec is not None:                      # a conv output: its gradient lives in a private buffer
-                if rec.stride == 2 and not isinstance(rec.x, NCHWInput):     # (the stem has no data gradient: compact dy)
+                if rec.stride == 2 and not isinstance(rec.x, NCHWInput) and not self._dgrad_s2_route(rec):
+                    # (the stem has no data gradient, csrc/dgrad_s2.hip reads the compact one: compact dy for both)
                     xin = rec.x
                     Hd, Wd = (xin.shape[2], xin.shape[3]) if isinstance(xin, NCHWInput) else (xin.H, xin.W)
                     if Hd % 2 or Wd % 2:
@@ -724,6 +728,52 @@ class TrainBuilder:
         self._wgrad(mode, a, planes, Cout, Cin, B, Q, Ho, K * K, self.arena.grad_ptr(rec.weight), flops, a_ch=dyv.C, b_ch=Cin, log=wlog)
         self._conv_backward_rest(rec, dyv, is_stem)
 
+    def _s2_mate(self, rec: ConvRec, k: int) -> Optional[ConvRec]:
+        """The stride-2 conv with kernel size k that reads exactly rec.x (the other branch of a RepVGG stride-2 block)."""
+        x = rec.x
+        key = (x.buf.data_ptr(), x.B, x.H, x.W, x.C, x.cstride, x.coff)
+        for o in self.convs:
+            if o is rec or o.k != k or o.stride != 2 or isinstance(o.x, NCHWInput) or o.bias is not None:
+                continue
+            ox = o.x
+            if (ox.buf.data_ptr(), ox.B, ox.H, ox.W, ox.C, ox.cstride, ox.coff) == key:
+                return o
+        return None
+
+    def _dgrad_s2_route(self, rec: ConvRec) -> bool:
+        """Does csrc/dgrad_s2.hip compute this stride-2 conv's data gradient (then its dy stays compact)?  A 3x3 conv whose
+        channel counts are multiples of 32 over an even-sized map; a 1x1 conv only as the partner of such a 3x3 conv over the same
+        input with the same output width (its gradient is a tenth tap of the partner's launch)."""
+        if not self.dgrad_s2 or rec.stride != 2 or isinstance(rec.x, NCHWInput) or rec.bias is not None:
+            return False
+        x, y = rec.x, rec.y
+        if x.H % 2 or x.W % 2 or x.C % 32 or y.C % 32 or x.cstride % 8 or x.coff % 8 or rec.weight.shape[0] != y.C:
+            return False
+        if rec.k == 3:
+            return True
+        m = self._s2_mate(rec, 3) if rec.k == 1 else None
+        return m is not None and m.y.C == y.C and self._dgrad_s2_route(m)
+
+    def _dgrad_s2_op(self, r3: ConvRec, r1: Optional[ConvRec]):
+        """dx of a stride-2 3x3 conv (+ its 1x1 partner) as one op of csrc/dgrad_s2.hip."""
+        def view(r):
+            return TRef(r.dy.buf, r.dy.B, r.dy.H, r.dy.W, r.cpad or r.dy.C, r.dy.cstride, r.dy.coff)
+        Cout, Cin = r3.weight.shape[0], r3.weight.shape[1]
+        gx = self.grad(r3.x)
+        acc = self.grad_mode(gx)
+        d = _lib.DgradS2Desc()
+        v3 = view(r3)
+        v1 = view(r1) if r1 is not None else None
+        d.dy3 = v3.ct()
+        d.dy1 = v1.ct() if v1 is not None else _null_tensor()
+        d.dx = gx.ct()
+        d.w3_packed = _ptr(self._add_pack(self.arena.data_ptr(r3.weight), 1, Cout, Cin, 3))
+        d.w1_packed = _ptr(self._add_pack(self.arena.data_ptr(r1.weight), 1, Cout, Cin, 1)) if r1 is not None else None
+        d.accumulate = int(acc)
+        self._b(self.lib.y6_plan_add_dgrad_s2(self.bwd, C.byref(d)), "plan_add_dgrad_s2", dys=[v3, v1], out=gx, acc=acc,
+                weights=[r3.weight, r1.weight if r1 is not None else None])
+        self.bwd_flops += 2.0 * Cout * Cin * (9 + (1 if r1 is not None else 0)) * v3.B * v3.H * v3.W
+
     def _stem_wgrad(self, rec: ConvRec, dyv: TRef) -> bool:
         """The weight gradient(s) of the convs that read the NCHW image `rec.x.t` (the stem block: RepVGGBlock(3 -> C, k3 s2) in train
         form, efficientrep.py:28-41 / common.py:250-255) as ONE op of csrc/wgrad_stem.hip: the 3x3 conv and - when the block has one and
@@ -776,8 +826,18 @@ class TrainBuilder:
             self._b(self.lib.y6_plan_add_channel_sum(self.bwd, C.byref(ct), self.arena.grad_ptr(rec.bias), _ptr(ws), ws.numel()),
                     "plan_add_channel_sum", x=TRef(dy.buf, dy.B, dy.H, dy.W, y.C, dy.cstride, dy.coff), param=rec.bias, ws=ws)
             finals.append(rec.bias)
-        # data gradient: the forward conv kernel on the flipped / transposed weights, stride 1 over the (dilated) dy
-        if not is_stem:
+        # data gradient: the forward conv kernel on the flipped / transposed weights, stride 1 over the (dilated) dy -
+        # or, for the stride-2 convs csrc/dgrad_s2.hip takes, one launch per block over the compact dy: emitted by whichever of
+        # the two branches runs its backward LAST (both gradients are at hand then)
+        if not is_stem and rec.dy_dil == 1 and self._dgrad_s2_route(rec):
+            mate = self._s2_mate(rec, 1 if K == 3 else 3)
+            if mate is not None and not self._dgrad_s2_route(mate):
+                mate = None
+            rec._s2_wgrad_done = True
+            if mate is None or getattr(mate, "_s2_wgrad_done", False):
+                r3, r1 = (rec, mate) if K == 3 else (mate, rec)
+                self._dgrad_s2_op(r3, r1)
+        elif not is_stem:
             gx = self.grad(x)
             acc = self.grad_mode(gx)
             # padded prediction-conv gradients (68 -> 72 channels): the packed image is zero beyond Cout and the
