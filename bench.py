@@ -854,6 +854,9 @@ def main():
             rep.barrier()
             el2 = rep.max_over_ranks(time.perf_counter() - t1)
             return dict(api="model(x) + non_max_suppression(det, 0.03, 0.65, multi_label=True, max_det=300)", kernels=what,
+                        nms_candidates=("selected by the forward's head tail once a first call has told the plan the thresholds "
+                                        "(utils/nms.py speculation)" if os.environ.get("Y6_DROPIN_SINK", "1") != "0"
+                                        else "nms first stage (Y6_DROPIN_SINK=0)"),
                         steps=args.dropin_steps, ms_per_step=round(el2 / args.dropin_steps * 1e3, 4),
                         value=round(rep.throughput(args.batch, args.dropin_steps, el2), 2), unit="images/sec")
 

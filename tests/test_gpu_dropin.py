@@ -95,3 +95,69 @@ def test_torch_library_ops_equal_the_module_mirrors_and_trace_under_torch_compil
     ref = F.relu(F.conv2d(x.float(), w.half().float(), bias.half().float(), padding=1))
     err = float((y.float().cpu() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
     assert y.shape == ref.shape and err <= 2e-3, err
+
+
+def test_nms_takes_the_forwards_candidates_only_when_they_are_this_results():
+    """The drop-in `non_max_suppression(model(x)[0], ...)` (evaler.py:128-132) arms the plan's fused head tail with the thresholds of
+    the first call and takes the candidates later forwards select (utils/nms.py `_speculated_candidates`) - but only for the very
+    tensor the LAST forward returned, unmodified, with the same thresholds.  Every other case must take the full path, and both
+    paths return the same detections bit for bit."""
+    from tests.test_gpu_model import _build
+    from yolov6_amd.utils import nms as N
+    cfg, meta, sd, m = _build("tiny", deploy=True)
+    with torch.no_grad():
+        m.detect.cls_preds[0].bias.add_(3.0)           # enough candidates above the threshold to make the comparison mean something
+    m = m.eval()
+    x1 = synth.synth_images(meta["batch"], meta["size"], seed=1).to("cuda:0").half()
+    x2 = synth.synth_images(meta["batch"], meta["size"], seed=2).to("cuda:0").half()
+    kw = dict(conf_thres=0.03, iou_thres=0.65, multi_label=True, max_det=300)
+
+    def full(det, **k):      # the full path: a clone is not the tensor the forward returned
+        return N.non_max_suppression(det.clone(), **(k or kw))
+
+    def same(a, b):
+        return len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b))
+
+    taken = []
+    orig = N._speculated_candidates
+
+    def spy(*a, **k):
+        t = orig(*a, **k)
+        taken.append(t is not None)
+        return t
+    N._speculated_candidates = spy
+    try:
+        d = m(x1)[0]
+        first = N.non_max_suppression(d, **kw)                       # first call: full path, arms the plan
+        assert taken[-1] is False and sum(len(t) for t in first) > 0
+        d = m(x1)[0]
+        fast = N.non_max_suppression(d, **kw)                        # now the forward selected the candidates
+        assert taken[-1] is True and same(fast, first) and same(fast, full(d))
+        again = N.non_max_suppression(d, **kw)                       # the workspace was consumed: a second call re-reads the tensor
+        assert taken[-1] is False and same(again, first)
+        # an older result: the plan's workspace holds the candidates of the LATER run
+        d1 = m(x1)[0]
+        d2 = m(x2)[0]
+        r1 = N.non_max_suppression(d1, **kw)
+        assert taken[-1] is False and same(r1, first)
+        r2 = N.non_max_suppression(d2, **kw)
+        assert taken[-1] is True and same(r2, full(d2)) and not same(r2, first)
+        # written in place after the forward
+        d = m(x1)[0]
+        d[..., 5:] *= 0.5
+        r = N.non_max_suppression(d, **kw)
+        assert taken[-1] is False and same(r, full(d))
+        # other thresholds: full path (and the plan is re-armed with them)
+        d = m(x1)[0]
+        k2 = dict(conf_thres=0.25, iou_thres=0.45, multi_label=False, max_det=100)
+        r = N.non_max_suppression(d, **k2)
+        assert taken[-1] is False and same(r, full(d, **k2))
+        d = m(x2)[0]
+        r = N.non_max_suppression(d, **k2)
+        assert taken[-1] is True and same(r, full(d, **k2))
+        # a view / a clone is never matched
+        d = m(x1)[0]
+        r = N.non_max_suppression(d[:], **k2)
+        assert taken[-1] is False and same(r, full(d, **k2))
+    finally:
+        N._speculated_candidates = orig

@@ -530,7 +530,14 @@ bool flat_geom(const y6_wgrad_nhwc_desc* d, FlatGeom* g) {
 void flat_split(const y6_wgrad_nhwc_desc* d, const FlatGeom& g, long tiles, int* nsplit_out, int* chunks_per_out) {
     const bool s2k3 = d->ksize == 3 && g.stride == 2;
     const size_t per = (size_t)d->ksize * d->ksize * d->M * d->N;
-    const long slots = s2k3 ? 512 : ((g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512);
+    // Y6_WGRAD_SLOTS_PCT=p (A/B; default 100): p % of a round of blocks - that share of the partial volume the slice sum moves, and the
+    // rest of the chip left to the main stream's kernels while the GEMM runs longer on the side stream.  Measured on the YOLOv6-S
+    // b64 step [GPU r06zc / r06zd, two visits, alternating runs]: 100 % 30.85 / 31.2 ms (weight gradients 7.9 ms by themselves),
+    // 75 % 31.0 (8.6), 50 % 30.50 / 30.9 (9.95), 38 % 31.6 (11.7), 25 % 33.2 (14.8): 0.2-0.3 ms for 50 %, inside the run-to-run
+    // spread of the second visit - the default stays a full round (and the GEMM's own rate the one the tables quote).
+    static const int slots_pct = getenv("Y6_WGRAD_SLOTS_PCT") ? (atoi(getenv("Y6_WGRAD_SLOTS_PCT")) > 0 ? atoi(getenv("Y6_WGRAD_SLOTS_PCT")) : 100) : 100;
+    long slots = (long)(s2k3 ? 512 : ((g.nwm == 4 || g.lds > 80u * 1024) ? 256 : 512)) * slots_pct / 100;
+    if (slots < tiles) slots = tiles;
     long nsplit = slots / tiles;
     if (nsplit > g.nchunks / 4) nsplit = g.nchunks / 4;
     const long max_by_ws = (long)(d->workspace_bytes / (per * sizeof(float)));

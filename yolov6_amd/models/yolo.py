@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.common import HipModule, get_block
+from ..utils import nms as _nms
 from ..utils.torch_utils import initialize_weights
 from . import efficientrep, reppan
 from .effidehead import Detect, build_effidehead_layer
@@ -149,7 +150,11 @@ class Model(HipModule):
         det = plan.run()
         feats = _LazyFeatmaps(self._featrefs, x.dtype)
         self.__dict__["_last_featmaps"] = weakref.ref(feats)
-        return [det if nbuf >= 2 else det.clone(), feats]
+        if nbuf < 2:
+            det = det.clone()
+        elif isinstance(det, torch.Tensor):
+            _nms.note_model_output(det, plan)      # non_max_suppression(det, ...) may take the candidates this run selected
+        return [det, feats]
 
     def _apply(self, fn):
         self = super()._apply(fn)
