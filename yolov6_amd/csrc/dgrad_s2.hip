@@ -20,9 +20,9 @@
 // staged per 32-channel chunk in LDS (80-byte pixel pitch, as conv_mfma.hip), the chunk's ten weight images arrive by LDS-DMA from the
 // data-gradient pack the plan already keeps (y6_pack_job kind 1: W'[ci][co][2-ky][2-kx]); a wave holds four accumulator sets (one
 // per output parity) of CF x PF fragments and issues 9 (10) x CF x PF x 2 MFMAs per chunk between two barriers; each of the four
-// shifted pixel fragments of a chunk is read once and serves every tap of its shift.  Epilogue = conv_common.hpp's (16-byte NHWC stores, optional
-// accumulate with the same two roundings as the accumulating convs).  HBM-bound for the wide early layers (the 32->64 block: 0.21 GB in,
-// 0.42 GB out), MFMA-bound for the 256->512 one.
+// shifted pixel fragments of a chunk is read once and serves every tap of its shift.  Epilogue: the output rows of one parity staged
+// in LDS and written (or read, added and written: the two roundings of the accumulating convs) as contiguous 16-byte pieces.
+// HBM-bound for the wide early layers (the 32->64 block: 0.21 GB in, 0.42 GB out), MFMA-leaning for the 256->512 one.
 #include "conv_common.hpp"
 #include "plan_internal.hpp"
 
@@ -41,18 +41,21 @@ struct DgS2Args {
     int ldsA_bytes, ldsB_bytes;
 };
 
-template <int PF>
+template <int BP>                  // halo pixels of a block of BP pixel slots: (TH + 1) x (TW + 1) over the tiles choose_tile() may pick
 struct S2HaloCap {
-    static constexpr int value = PF == 1 ? 176 : 304;
+    static constexpr int value = BP == 128 ? 176 : 304;
 };
 
-template <int CF, int PF>
-__global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
+// NW waves per block: 4 (two blocks per CU; the default) or 8 (one block: twice the pixels behind one set of weight images)
+template <int CF, int PF, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void dgrad_s2_kernel(const DgS2Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WCF = 10 * 2048;                       // bytes of one cout fragment's ten tap images (2 k-steps x 1 KiB each)
-    constexpr int MAXHP = S2HaloCap<PF>::value;
-    constexpr int NP = (MAXHP * 4 + 255) / 256;          // 16-byte halo pieces per thread
-    constexpr int NPB = PF * 2;                          // ... of the 1x1 branch's tile (PF*128 pixels x 4 pieces / 256 threads)
+    constexpr int NT = NW * 64;                          // threads
+    constexpr int BP = NW * PF * 32;                     // pixel slots of the block
+    constexpr int MAXHP = S2HaloCap<BP>::value;
+    constexpr int NP = (MAXHP * 4 + NT - 1) / NT;        // 16-byte halo pieces per thread
+    constexpr int NPB = BP * 4 / NT;                     // ... of the 1x1 branch's tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
     int goff[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         int o = -2;
         if (idx < npieces) {
             const int hp = idx >> 2, q = idx & 3;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
     int boff[NPB];
 #pragma unroll
     for (int i = 0; i < NPB; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         int o = -2;
         if (has1 && idx < npx * 4) {
             const int p = idx >> 2, q = idx & 3;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
     // the ten tap images of a chunk: nine contiguous KiB pairs per cout fragment of the 3x3 pack, one pair of the 1x1 pack
     auto issue_w = [&](int chunk) {
 #pragma unroll
-        for (int j = 0; j < (CF * 18 + 3) / 4; ++j) {
-            const int p = wave + 4 * j;
+        for (int j = 0; j < (CF * 18 + NW - 1) / NW; ++j) {
+            const int p = wave + NW * j;
             if (p < CF * 18) {
                 const int cf = p / 18, r = p - cf * 18;
                 const __half* src = g.w3 + ((size_t)(cb * CF + cf) * g.nchunk + chunk) * (9 * 1024) + r * 512 + lane * 8;
@@ -176,12 +179,12 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
     auto store_A = [&](const uint4 (&ra)[NP], const uint4 (&rb)[NPB]) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             if (goff[i] != -2) *reinterpret_cast<uint4*>(ldsA + (idx >> 2) * PIXB + (idx & 3) * 16) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < NPB; ++i) {
-            const int idx = tid + i * 256;
+            const int idx = tid + i * NT;
             if (boff[i] != -2) *reinterpret_cast<uint4*>(ldsB + (idx >> 2) * PIXB + (idx & 3) * 16) = rb[i];
         }
     };
@@ -196,35 +199,45 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
     for (int chunk = 0; chunk < g.nchunk; ++chunk) {
         const bool more = (chunk + 1) < g.nchunk;
         if (more) load_A(chunk + 1, areg, breg);      // register prefetch of the next chunk's pixels, in flight under the MFMAs
-        // the four shifted pixel fragments of this chunk, each read once and used by every tap of its shift
-        // (shift index = 2 * (row shift) + (column shift); image of the data-gradient pack = 8 - (ky*3 + kx))
-        h8_t bfr[PF][2];
-#define Y6_S2_SHIFT(D)                                                                                                      \
+        // The four shifted pixel fragments of this chunk are each read once and used by every tap of their shift.
+        // Weight fragments are requested one tap AHEAD of the MFMAs that use them (nxt), the pixel fragments of a shift when the
+        // last tap of the previous shift goes out: the matrix pipe does not wait a full LDS round trip in front of every tap.
+        h8_t bfr[PF][2], bnx[PF][2];
+        h8_t cur[CF][2], nxt[CF][2];
+#define Y6_S2_LOADW(DST, TAU)                                                                                               \
+    _Pragma("unroll") for (int cf = 0; cf < CF; ++cf) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
+        DST[cf][ks] = *reinterpret_cast<const h8_t*>(wb + cf * WCF + ((TAU) * 2 + ks) * 1024);                              \
+    __builtin_amdgcn_sched_barrier(0);     /* the scheduler would sink the reads back in front of their use */
+#define Y6_S2_LOADB(DST, D)                                                                                                 \
     _Pragma("unroll") for (int pf = 0; pf < PF; ++pf) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
-        bfr[pf][ks] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + (((D) >> 1) * g.HWd + ((D) & 1)) * PIXB + ks * 32);
-#define Y6_S2_TAP(CLS, TAU)                                                                                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                      \
-        _Pragma("unroll") for (int cf = 0; cf < CF; ++cf) {                                                                 \
-            const h8_t af = *reinterpret_cast<const h8_t*>(wb + cf * WCF + ((TAU) * 2 + ks) * 1024);                        \
-            _Pragma("unroll") for (int pf = 0; pf < PF; ++pf)                                                               \
-                acc[CLS][cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfr[pf][ks], acc[CLS][cf][pf], 0, 0, 0);      \
-        }                                                                                                                   \
-    }
-        Y6_S2_SHIFT(0)         // dy[I][J]
-        Y6_S2_TAP(0, 4)        //   (0,0): W[1][1]
-        Y6_S2_TAP(1, 3)        //   (0,1): W[1][2]
-        Y6_S2_TAP(2, 1)        //   (1,0): W[2][1]
-        Y6_S2_TAP(3, 0)        //   (1,1): W[2][2]
-        Y6_S2_SHIFT(1)         // dy[I][J+1]
-        Y6_S2_TAP(1, 5)        //   (0,1): W[1][0]
-        Y6_S2_TAP(3, 2)        //   (1,1): W[2][0]
-        Y6_S2_SHIFT(2)         // dy[I+1][J]
-        Y6_S2_TAP(2, 7)        //   (1,0): W[0][1]
-        Y6_S2_TAP(3, 6)        //   (1,1): W[0][2]
-        Y6_S2_SHIFT(3)         // dy[I+1][J+1]
-        Y6_S2_TAP(3, 8)        //   (1,1): W[0][0]
-#undef Y6_S2_SHIFT
-#undef Y6_S2_TAP
+        DST[pf][ks] = *reinterpret_cast<const h8_t*>(ldsA + pixoff[pf] + (((D) >> 1) * g.HWd + ((D) & 1)) * PIXB + ks * 32); \
+    __builtin_amdgcn_sched_barrier(0);
+#define Y6_S2_MFMA(CLS)                                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int cf = 0; cf < CF; ++cf)                      \
+        _Pragma("unroll") for (int pf = 0; pf < PF; ++pf)                                                                   \
+            acc[CLS][cf][pf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur[cf][ks], bfr[pf][ks], acc[CLS][cf][pf], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#define Y6_S2_ROLL()                                                                                                        \
+    _Pragma("unroll") for (int cf = 0; cf < CF; ++cf) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) cur[cf][ks] = nxt[cf][ks];
+#define Y6_S2_ROLLB()                                                                                                       \
+    _Pragma("unroll") for (int pf = 0; pf < PF; ++pf) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) bfr[pf][ks] = bnx[pf][ks];
+        // (shift index = 2 * (row shift) + (column shift); image of the data-gradient pack = 8 - (ky*3 + kx))
+        Y6_S2_LOADB(bfr, 0)                       // dy[I][J]
+        Y6_S2_LOADW(cur, 4)
+        Y6_S2_LOADW(nxt, 3)  Y6_S2_MFMA(0)  Y6_S2_ROLL()             //   (0,0): W[1][1]
+        Y6_S2_LOADW(nxt, 1)  Y6_S2_MFMA(1)  Y6_S2_ROLL()             //   (0,1): W[1][2]
+        Y6_S2_LOADW(nxt, 0)  Y6_S2_MFMA(2)  Y6_S2_ROLL()             //   (1,0): W[2][1]
+        Y6_S2_LOADW(nxt, 5)  Y6_S2_LOADB(bnx, 1)  Y6_S2_MFMA(3)  Y6_S2_ROLL()  Y6_S2_ROLLB()   //   (1,1): W[2][2]; next: dy[I][J+1]
+        Y6_S2_LOADW(nxt, 2)  Y6_S2_MFMA(1)  Y6_S2_ROLL()             //   (0,1): W[1][0]
+        Y6_S2_LOADW(nxt, 7)  Y6_S2_LOADB(bnx, 2)  Y6_S2_MFMA(3)  Y6_S2_ROLL()  Y6_S2_ROLLB()   //   (1,1): W[2][0]; next: dy[I+1][J]
+        Y6_S2_LOADW(nxt, 6)  Y6_S2_MFMA(2)  Y6_S2_ROLL()             //   (1,0): W[0][1]
+        Y6_S2_LOADW(nxt, 8)  Y6_S2_LOADB(bnx, 3)  Y6_S2_MFMA(3)  Y6_S2_ROLL()  Y6_S2_ROLLB()   //   (1,1): W[0][2]; next: dy[I+1][J+1]
+        Y6_S2_MFMA(3)                                                //   (1,1): W[0][0]
+#undef Y6_S2_LOADW
+#undef Y6_S2_LOADB
+#undef Y6_S2_MFMA
+#undef Y6_S2_ROLL
+#undef Y6_S2_ROLLB
         if (has1) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -249,17 +262,56 @@ __global__ __launch_bounds__(256, 2) void dgrad_s2_kernel(const DgS2Args g) {
         }
     }
 
-    BiasRegs<CF> bz;
+    // Epilogue: the block's output is a dense (2 TH) x (2 TW) patch of dx, but a lane's accumulators are single pixels two apart -
+    // stored as they lie they were 16-byte pieces scattered over as many cache lines (the first form of this kernel spent 2/3 of
+    // its time here: 440 us with, 133 us without the epilogue on the 32-channel layer).  So the two classes of one output-row
+    // parity are rounded to fp16 into an LDS image of their TH output rows ([row][2 TW pixels][CF*32 channels], the main loop's
+    // LDS is dead behind its last barrier), and the block writes - or reads, adds and writes - those rows as contiguous 16-byte
+    // pieces, consecutive lanes on consecutive addresses.  Same arithmetic as the accumulating convs: fp16(acc), + old, fp16.
+    {
+        constexpr int CFC = CF * 32;                   // channels of the block
+        constexpr int RSB = CFC * 2 + 16;              // bytes per staged pixel (16 B of pad: bank spread)
+        constexpr int PPX = CF * 4;                    // 16-byte pieces per pixel
+        const int W2 = 2 * g.TW;
+        const int npiece = g.TH * W2 * PPX;
 #pragma unroll
-    for (int cf = 0; cf < CF; ++cf)
+        for (int a = 0; a < 2; ++a) {
+            if (a) __syncthreads();                    // the rows of parity 0 have left the stage
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bz.v[cf][r] = 0.f;
+            for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        int opix[PF];
+                for (int pf = 0; pf < PF; ++pf) {
+                    const int m = wave * (PF * 32) + pf * 32 + (lane & 31);
+                    if (m < npx) {
+                        const int ty = m / g.TW, tx = m - ty * g.TW;
+                        char* dst = smem + (ty * W2 + 2 * tx + bb) * RSB + (lane >> 5) * 8;
 #pragma unroll
-        for (int pf = 0; pf < PF; ++pf) opix[pf] = obase[pf] >= 0 ? obase[pf] + (c >> 1) * (2 * g.Wo) + (c & 1) : -1;
-        conv_epilogue<CF, PF, Y6_ACT_NONE>(g.k, acc[c], opix, cb, 0, lane, bz);
+                        for (int cf = 0; cf < CF; ++cf)
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                h4_t o;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) o[j] = (_Float16)acc[a * 2 + bb][cf][pf][gq * 4 + j];
+                                *reinterpret_cast<h4_t*>(dst + cf * 64 + gq * 16) = o;
+                            }
+                    }
+                }
+            __syncthreads();
+            for (int q = tid; q < npiece; q += NT) {
+                const int pix = q / PPX, pc = q - pix * PPX;
+                const int ty = pix / W2, ox = pix - ty * W2;
+                const int y = 2 * (oy0 + ty) + a, x = 2 * ox0 + ox;
+                if (oy0 + ty >= g.Ho || x >= 2 * g.Wo) continue;
+                h8_t v = *reinterpret_cast<const h8_t*>(smem + pix * RSB + pc * 16);
+                __half* gp = g.k.out + ((size_t)(b * 2 * g.Ho + y) * (2 * g.Wo) + x) * g.k.out_cs + g.k.out_co + cb * CFC + pc * 8;
+                if (g.k.res != nullptr) {
+                    const h8_t old = *reinterpret_cast<const h8_t*>(gp);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (_Float16)((float)v[j] + (float)old[j]);
+                }
+                *reinterpret_cast<h8_t*>(gp) = v;
+            }
+        }
     }
 }
 
@@ -306,7 +358,7 @@ int check(const y6_dgrad_s2_desc* d) {
     return Y6_OK;
 }
 
-template <int CF, int PF>
+template <int CF, int PF, int NW>
 int launch_cfg(const y6_dgrad_s2_desc* d, hipStream_t s) {
     DgS2Args g;
     memset(&g, 0, sizeof(g));
@@ -337,7 +389,7 @@ int launch_cfg(const y6_dgrad_s2_desc* d, hipStream_t s) {
     }
     g.Ho = d->dy3.H;
     g.Wo = d->dy3.W;
-    choose_tile(g.Ho, g.Wo, PF * 128, S2HaloCap<PF>::value, &g.TH, &g.TW);
+    choose_tile(g.Ho, g.Wo, NW * PF * 32, S2HaloCap<NW * PF * 32>::value, &g.TH, &g.TW);
     g.tiles_x = y6_cdiv(g.Wo, g.TW);
     g.tiles_y = y6_cdiv(g.Ho, g.TH);
     g.ntiles = g.tiles_x * g.tiles_y * d->dy3.B;
@@ -347,23 +399,28 @@ int launch_cfg(const y6_dgrad_s2_desc* d, hipStream_t s) {
     g.HWd = g.TW + 1;
     g.ldsA_bytes = (g.HH * g.HWd * PIXB + 15) & ~15;
     g.ldsB_bytes = g.dy1 ? ((g.TH * g.TW * PIXB + 15) & ~15) : 0;
-    const size_t lds = (size_t)g.ldsA_bytes + g.ldsB_bytes + (size_t)CF * 10 * 2048;
+    size_t lds = (size_t)g.ldsA_bytes + g.ldsB_bytes + (size_t)CF * 10 * 2048;
+    const size_t stage = (size_t)g.TH * 2 * g.TW * (CF * 64 + 16);     // the epilogue's image of one row parity
+    if (lds < stage) lds = stage;
     static bool big = false;            // one attribute call per instantiation (benign if two threads race: same value)
     if (lds > 64 * 1024 && !big) {
-        Y6_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_s2_kernel<CF, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        Y6_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_s2_kernel<CF, PF, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         big = true;
     }
     Y6_REQUIRE(lds <= 96 * 1024, "dgrad_s2: %zu bytes of LDS", lds);
     const int grid = g.ncb == 1 ? g.ntiles : y6_cdiv(g.ntiles, 8) * 8 * g.ncb;
-    hipLaunchKernelGGL((dgrad_s2_kernel<CF, PF>), dim3((unsigned)grid), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((dgrad_s2_kernel<CF, PF, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, s, g);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
 
 int dgrad_s2_launch(const y6_dgrad_s2_desc* d, hipStream_t s) {
     if (int rc = check(d)) return rc;
-    if (d->dx.C % 64 == 0) return launch_cfg<2, 1>(d, s);
-    return launch_cfg<1, 2>(d, s);
+    // Y6_DGRAD_S2_WAVES=8 (A/B): 256-pixel blocks of eight waves - half the weight traffic per pixel, measured no faster
+    // (0.94 against 0.905 ms for the eight launches of a YOLOv6-S step [GPU r06zh]): the launch is its phases in a row, not L2-bound
+    static const int waves = getenv("Y6_DGRAD_S2_WAVES") ? atoi(getenv("Y6_DGRAD_S2_WAVES")) : 4;
+    if (d->dx.C % 64 == 0) return waves == 8 ? launch_cfg<2, 1, 8>(d, s) : launch_cfg<2, 1, 4>(d, s);
+    return launch_cfg<1, 2, 4>(d, s);
 }
 
 }  // namespace
