@@ -704,12 +704,18 @@ static int variant_by_name(const char* name) {
 int y6_conv_default_variant(const y6_conv_desc* d) {
     const long px = (long)d->out.B * d->out.H * d->out.W;
     if (d->ksize == 3) {
-        // round 4 (profiles/r04): the register-fed kernels win wherever they apply (Cin % 32 == 0, Cout % 128 == 0): 7 pixel
-        // fragments per wave when the 200-pixel items fill the 512 resident blocks, else 4; stride 2: 3 / 4 fragments
-        static const int p7 = variant_by_name("wreg_p7"), p4 = variant_by_name("wreg_p4"), s2p3 = variant_by_name("wregs2_p3");
-        const long items200 = (px + 199) / 200 * ((d->out.C + 127) / 128);
-        const int first = d->stride == 1 ? (items200 >= 512 ? p7 : p4) : s2p3;
+        // round 4 (profiles/r04): the register-fed kernels win wherever they apply (Cin % 32 == 0, Cout % 128 == 0); stride 2: 3
+        // fragments.  Fragments per wave from the item count of the 224-pixel form (round 6, the timed tables of the b32 inference and
+        // the b64 training plans agree - profiles/r06/autotune_train_r06zj.log): 5 fragments (160-pixel items) when even the large
+        // items make several rounds over the 512 block slots, 7 (224 pixels: the most MFMAs per weight fragment) while they still
+        // reach most CUs, 4 (128 pixels) for the small maps.  E.g. 256->256 @40x40: b64 916 items -> p5 (98 us against 106 p7),
+        // b32 458 -> p7; 128->128 @40x40 b32 229 -> p7; 256->256 @20x20 b32 116 -> p4.
+        static const int p7 = variant_by_name("wreg_p7"), p5 = variant_by_name("wreg_p5"), p4 = variant_by_name("wreg_p4"),
+                         s2p3 = variant_by_name("wregs2_p3");
+        const long items224 = (px + 223) / 224 * ((d->out.C + 127) / 128);
+        const int first = d->stride == 1 ? (items224 >= 900 ? p5 : (items224 >= 200 ? p7 : p4)) : s2p3;
         if (first > 0 && y6_conv_variant_supports(d, first)) return first;
+        if (d->stride == 1 && first == p5 && p7 > 0 && y6_conv_variant_supports(d, p7)) return p7;
         if (d->stride == 1 && p4 > 0 && y6_conv_variant_supports(d, p4)) return p4;
     }
     if (d->ksize == 1 && d->stride == 1) {
@@ -727,11 +733,14 @@ int y6_conv_default_variant(const y6_conv_desc* d) {
                      pipe21 = variant_by_name("pipe_c2p1"), pipe12 = variant_by_name("pipe_c1p2"), c2p1 = variant_by_name("mfma_c2p1"), c1p1 = variant_by_name("mfma_c1p1"),
                      c2p2 = variant_by_name("mfma_c2p2"), c1p2 = variant_by_name("mfma_c1p2"), c4p1 = variant_by_name("mfma_c4p1"),
                      c4p2 = variant_by_name("mfma_c4p2");
-    const int dma_a = items256 >= 512 ? dma22 : dma21, dma_b = items256 >= 512 ? dma21 : dma22;
+    // (round 6: 256-pixel blocks only for the very large maps - 64->64 @160x160 b64: 149 against 156 us; @80x80 b64 and @160x160 b32
+    // the 128-pixel blocks win by 3-5 us)
+    const int dma_a = items256 >= 4096 ? dma22 : dma21, dma_b = items256 >= 4096 ? dma21 : dma22;
     const int prefs_s1[] = {dma_a, dma_b, pipe22, pipe21, pipe12, c2p1, c1p1, c2p2, c1p2, c4p1, c4p2, 0};
-    const int prefs_s2[] = {c2p1, c1p1, c4p1, 0};
+    static const int dma8s2 = variant_by_name("dma8s2_c2p1");     // round 6: the LDS-DMA stride-2 form first (32->64 @320x320 b64: 182 against 213 us)
+    const int prefs_s2[] = {dma8s2, c2p1, c1p1, c4p1, 0};
     const int* prefs = d->stride == 1 ? prefs_s1 : prefs_s2;
-    const int n = d->stride == 1 ? 12 : 4;
+    const int n = d->stride == 1 ? 12 : 5;
     for (int i = 0; i < n; ++i)
         if (prefs[i] >= 0 && y6_conv_variant_supports(d, prefs[i])) return prefs[i];
     return -1;
