@@ -7,7 +7,8 @@ import csv, glob, json, os, re, sys
 
 out = sys.argv[1]
 MFMA = ("conv3x3_dma_kernel", "conv_mfma_pipe_kernel", "conv_mfma_kernel", "conv_mfma_persist_kernel", "conv1x1_stream_kernel",
-        "stem_", "wgrad_kernel", "conv3x3_wreg_kernel", "wgrad_lds_kernel", "wgrad_flat_kernel", "wgrad_flat_s2_kernel")
+        "stem_", "wgrad_kernel", "conv3x3_wreg_kernel", "wgrad_lds_kernel", "wgrad_flat_kernel", "wgrad_flat_s2_kernel", "conv_pw_kernel",
+        "wgrad_stem_kernel", "dgrad_s2_kernel")
 
 
 def base(name):
