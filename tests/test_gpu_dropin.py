@@ -155,6 +155,12 @@ def test_nms_takes_the_forwards_candidates_only_when_they_are_this_results():
         d = m(x2)[0]
         r = N.non_max_suppression(d, **k2)
         assert taken[-1] is True and same(r, full(d, **k2))
+        # the plan launched again behind the forward's back (the plan API on the same plan): its workspace is no longer this result's
+        d = m(x2)[0]
+        m.compile(x2).run()
+        torch.cuda.synchronize()
+        r = N.non_max_suppression(d, **k2)
+        assert taken[-1] is False and same(r, full(d, **k2))
         # a view / a clone is never matched
         d = m(x1)[0]
         r = N.non_max_suppression(d[:], **k2)

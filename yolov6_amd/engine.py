@@ -107,6 +107,8 @@ class Plan:
         self.captured = False
 
     def run(self):
+        # every launch of the plan counts: utils/nms.py takes the head tail's candidates only for the plan's LATEST run
+        self._run_seq = getattr(self, "_run_seq", 0) + 1
         _lib.check(self._lib.y6_plan_run(self._h, _lib.current_stream_ptr()), "plan_run")
         return self.outputs
 
@@ -149,6 +151,7 @@ class Plan:
 
     def run_range(self, first: int, last: int):
         """Eager launch of ops [first, last) only (per-layer parity tests)."""
+        self._run_seq = getattr(self, "_run_seq", 0) + 1
         _lib.check(self._lib.y6_plan_run_range(self._h, _lib.current_stream_ptr(), first, last), "plan_run_range")
 
     def autotune(self, iters: int = 3):

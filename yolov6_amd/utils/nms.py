@@ -34,13 +34,14 @@ def note_model_output(det, plan):
     """Called by models.yolo.Model.forward with the tensor it is about to return."""
     if not _SINK_ON:
         return
-    plan._run_seq = getattr(plan, "_run_seq", 0) + 1
+    # (engine.Plan.run / run_range count the plan's launches in plan._run_seq: a launch made behind Model.forward's back - the
+    # plan API on the same plan - also invalidates this entry)
     if len(_PRODUCED) > 32:
         for k in [k for k, v in _PRODUCED.items() if v[0]() is None or v[1]() is None]:
             del _PRODUCED[k]
         if len(_PRODUCED) > 32:
             _PRODUCED.clear()
-    _PRODUCED[id(det)] = (weakref.ref(det), weakref.ref(plan), plan._run_seq, det._version,
+    _PRODUCED[id(det)] = (weakref.ref(det), weakref.ref(plan), getattr(plan, "_run_seq", 0), det._version,
                           torch.cuda.current_stream(det.device).cuda_stream)
 
 
