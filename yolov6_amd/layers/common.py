@@ -16,6 +16,8 @@ BatchNorm and grouped convs raise.
 """
 import os
 
+import operator
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -149,6 +151,9 @@ def _params_version(module):
     return hash(tuple(items))
 
 
+_VERSION_OF = operator.attrgetter("_version")
+
+
 class HipModule(nn.Module):
     """nn.Module whose forward is a cached native plan of HIP kernels."""
 
@@ -226,8 +231,10 @@ class HipModule(nn.Module):
         sig = (tuple((tuple(t.shape), t.dtype) for t in flat), self.training, autotune, None if quant is None else quant.key(),
                _NATIVE_GENERATION[0], _STRUCTURE_GENERATION[0])
         fast = self.__dict__.get("_y6_fast")
-        if (fast is not None and fast[0] == sig and sum(t._version for t in fast[1]) == fast[2]
-                and all(d.get(n) is t for d, n, t in fast[4])):     # every captured parameter / buffer is still the registered one
+        # (both scans run in C: map() over operator callables - as generator expressions they were 35 of the ~60 us this check costs
+        # per call, and the GPU idles from the NMS sync until the next forward's first launch, tools/dropin_profile.py)
+        if (fast is not None and fast[0] == sig and sum(map(_VERSION_OF, fast[1])) == fast[2]
+                and all(map(operator.is_, map(dict.get, fast[4][0], fast[4][1]), fast[4][2]))):   # every captured parameter / buffer is still the registered one
             plan = fast[3]
             plan.bind_inputs([contig[j] for j in plan.input_order])
             return plan
@@ -245,6 +252,7 @@ class HipModule(nn.Module):
         # (registry dict, name, tensor) of every parameter and buffer below this module: `m.weight = nn.Parameter(...)` replaces
         # the entry, and the version counters of the OLD tensors this tuple keeps alive would not notice
         holders = [(d, n, t) for m in self.modules() for d in (m._parameters, m._buffers) for n, t in d.items() if t is not None]
+        holders = tuple(list(col) for col in zip(*holders)) if holders else ([], [], [])      # (dicts, names, tensors): parallel lists
         self.__dict__["_y6_fast"] = (sig, tensors, sum(t._version for t in tensors), plan, holders)
         return plan
 
