@@ -111,3 +111,45 @@ def test_dgrad_s2_refuses_what_it_cannot_do():
     dx = _nhwc(torch.zeros(1, 32, 8, 9))
     d.dy3, d.dx = dy.ct(), dx.ct()
     assert lib.y6_dgrad_s2_supported(C.byref(d)) == 0            # dx is not [2*Ho, 2*Wo]
+
+
+@pytest.mark.parametrize("M,N,Ho", [(64, 32, 160), (128, 64, 80), (256, 128, 40), (512, 256, 20)])
+def test_dgrad_s2_is_the_adjoint_of_the_forward_convs_at_the_training_batch(M, N, Ho):
+    """BASELINE configs[2] sizes (YOLOv6-S b64, the four stride-2 RepVGG blocks of the backbone), where an element-wise CPU reference
+    of dx would take minutes: the size-independent property instead.  dx = conv3^T(dy3) + conv1^T(dy1) is the adjoint of the block's
+    two convs, so for any x:  <dx, x> = <dy3, conv3x3_s2(x)> + <dy1, conv1x1_s2(x)>  (fp64 inner products; the right side from
+    torch-CPU fp32 convs of the same fp16-rounded operands).  dx is stored in fp16: independent roundings of 26-105 M elements
+    leave the inner product well inside 1e-3 of its scale."""
+    lib = _lib.load()
+    B = 64
+    g = torch.Generator().manual_seed(M + Ho)
+    dy3 = torch.randn((B, M, Ho, Ho), generator=g).half()
+    dy1 = torch.randn((B, M, Ho, Ho), generator=g).half()
+    x = torch.randn((B, N, 2 * Ho, 2 * Ho), generator=g).half()
+    w3 = (torch.randn((M, N, 3, 3), generator=g) * (1.0 / (9 * M) ** 0.5)).half().float()
+    w1 = (torch.randn((M, N, 1, 1), generator=g) * (1.0 / M ** 0.5)).half().float()
+    with torch.no_grad():
+        y3 = F.conv2d(x.float(), w3, None, stride=2, padding=1)
+        y1 = F.conv2d(x.float(), w1, None, stride=2, padding=0)
+    rhs = float((dy3.double() * y3.double()).sum() + (dy1.double() * y1.double()).sum())
+    scale = float((dy3.double().pow(2).sum() * y3.double().pow(2).sum()).sqrt() + (dy1.double().pow(2).sum() * y1.double().pow(2).sum()).sqrt())
+    del y3, y1
+    t3 = TRef(dy3.permute(0, 2, 3, 1).contiguous().to(DEV), B, Ho, Ho, M, M, 0)
+    t1 = TRef(dy1.permute(0, 2, 3, 1).contiguous().to(DEV), B, Ho, Ho, M, M, 0)
+    dxb = torch.empty((B, 2 * Ho, 2 * Ho, N), dtype=torch.float16, device=DEV)
+    tx = TRef(dxb, B, 2 * Ho, 2 * Ho, N, N, 0)
+    p3, k3 = _pack_dgrad(w3)
+    p1, k1 = _pack_dgrad(w1)
+    d = _lib.DgradS2Desc()
+    d.dy3, d.dy1, d.dx = t3.ct(), t1.ct(), tx.ct()
+    d.w3_packed, d.w1_packed, d.accumulate = p3.data_ptr(), p1.data_ptr(), 0
+    _lib.check(lib.y6_dgrad_s2(C.byref(d), _lib.current_stream_ptr()), "dgrad_s2")
+    torch.cuda.synchronize()
+    lhs = float((dxb.double() * x.permute(0, 2, 3, 1).contiguous().to(DEV).double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * scale, (lhs, rhs, scale)
+    # and the accumulating form adds exactly one more copy (a second launch over what the first left: dx + dx, rounded once more)
+    d.accumulate = 1
+    first = dxb.clone()
+    _lib.check(lib.y6_dgrad_s2(C.byref(d), _lib.current_stream_ptr()), "dgrad_s2")
+    torch.cuda.synchronize()
+    assert torch.equal(dxb, (first.float() + first.float()).half())
