@@ -63,7 +63,7 @@ struct TalArgs {
     unsigned char* fg_mask;
 };
 
-__global__ __launch_bounds__(256) void tal_topk_kernel(const TalArgs a) {
+__global__ __launch_bounds__(256) void tal_topk_lds_kernel(const TalArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vals = reinterpret_cast<float*>(smem);  // [A]
     __shared__ float s_v[4];
@@ -76,10 +76,18 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(const TalArgs a) {
     const int label = gt_label(a.gt_labels, bg);
     const float* sc = a.pd_scores + (size_t)b * a.A * a.C + label;
     const float4* pb = a.pd_bboxes + (size_t)b * a.A;
+    // metrics * mask_in_gts (:116).  Only the anchors inside the box (2-3 % of them for a typical COCO box) have a metric that can
+    // survive the mask, so only they pay for it: the class score of an anchor is one float out of every C = 80 (a cache line per
+    // anchor: 1 MB of lines per box, 1 751 boxes per b64 step - the kernel was 280 us of line traffic), the anchor points are 67 KB
+    // of coalesced reads.  For finite metrics 0 is what `0 * m` gave (a NaN metric outside the box no longer stays a NaN here: such
+    // an anchor could never be kept anyway - mask_pos needs in_gt below).
     for (int an = tid; an < a.A; an += 256) {
-        const float iou = iou_gt_pd(g, pb[an], 1e-9f);
-        const float m = align_metric(sc[(size_t)an * a.C], iou, a.alpha, a.beta);
-        vals[an] = in_gt(a.anc[an], g, 1e-9f) ? m : 0.f * m;  // metrics * mask_in_gts (:116)
+        float v = 0.f;
+        if (in_gt(a.anc[an], g, 1e-9f)) {
+            const float iou = iou_gt_pd(g, pb[an], 1e-9f);
+            v = align_metric(sc[(size_t)an * a.C], iou, a.alpha, a.beta);
+        }
+        vals[an] = v;
     }
     __syncthreads();
     const int k = a.topk < a.A ? a.topk : a.A;
@@ -122,6 +130,85 @@ __global__ __launch_bounds__(256) void tal_topk_kernel(const TalArgs a) {
             }
         }
         __syncthreads();
+    }
+}
+
+// The same selection with the metric row in REGISTERS (A <= 256 * NV: the 8 400 anchors of a 640 x 640 image are 33 per thread): the
+// topk rounds compare registers instead of re-reading the whole row from LDS thirteen times (tal_topk_lds_kernel above serves the
+// larger maps).  Same comparisons in the same order - per thread ascending, first maximum; across lanes and waves the larger value,
+// the lower index on a tie - so the same anchors (bit-exact goldens: tests/test_gpu_nms_tal.py, test_gpu_b64_parity.py).
+template <int NV>
+__global__ __launch_bounds__(256) void tal_topk_reg_kernel(const TalArgs a) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ int s_pick;
+    const int bg = blockIdx.x;
+    const int b = bg / a.G;
+    if (!(a.mask_gt[bg] != 0.f)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float4 g = a.gt_bboxes[bg];
+    const int label = gt_label(a.gt_labels, bg);
+    const float* sc = a.pd_scores + (size_t)b * a.A * a.C + label;
+    const float4* pb = a.pd_bboxes + (size_t)b * a.A;
+    float v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int an = tid + j * 256;
+        float m = -INFINITY;                   // beyond A: never the maximum (bi stays >= A only if nothing is left)
+        if (an < a.A) {
+            m = 0.f;
+            if (in_gt(a.anc[an], g, 1e-9f)) {
+                const float iou = iou_gt_pd(g, pb[an], 1e-9f);
+                m = align_metric(sc[(size_t)an * a.C], iou, a.alpha, a.beta);
+            }
+        }
+        v[j] = m;
+    }
+    const int k = a.topk < a.A ? a.topk : a.A;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int an = tid + j * 256;
+            if (an < a.A && v[j] > bv) {
+                bv = v[j];
+                bi = an;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_i[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (s_v[w] > bv || (s_v[w] == bv && s_i[w] < bi)) {
+                    bv = s_v[w];
+                    bi = s_i[w];
+                }
+            s_pick = bi;
+            if (bi < a.A && in_gt(a.anc[bi], g, 1e-9f)) {
+                atomicAdd(&a.fg_cnt[(size_t)b * a.A + bi], 1);
+                atomicMin(&a.first_g[(size_t)b * a.A + bi], bg - b * a.G);
+            }
+        }
+        __syncthreads();
+        const int pick = s_pick;
+        if (pick < a.A && (pick & 255) == tid) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+                if (j == (pick >> 8)) v[j] = -INFINITY;     // taken
+        }
     }
 }
 
@@ -438,10 +525,15 @@ extern "C" int y6_tal_assign(const y6_tal_desc* d, void* stream) {
     Y6_HIP(hipMemsetAsync(a.fg_cnt, 0, nba * 4, s));
     Y6_HIP(hipMemsetAsync(a.first_g, 0x7f, nba * 4, s));
     Y6_HIP(hipMemsetAsync(a.pos_am, 0, 2 * bgn, s));
-    const size_t lds = (size_t)d->A * 4;
-    if (lds > 64 * 1024)
-        Y6_HIP(hipFuncSetAttribute((const void*)tal_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(tal_topk_kernel, dim3(d->B * d->G), dim3(256), lds, s, a);
+    static const bool reg_rows = !(getenv("Y6_TAL_TOPK_REG") && atoi(getenv("Y6_TAL_TOPK_REG")) == 0);   // A/B switch
+    if (reg_rows && d->A <= 256 * 34) {
+        hipLaunchKernelGGL(tal_topk_reg_kernel<34>, dim3(d->B * d->G), dim3(256), 0, s, a);
+    } else {
+        const size_t lds = (size_t)d->A * 4;
+        if (lds > 64 * 1024)
+            Y6_HIP(hipFuncSetAttribute((const void*)tal_topk_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(tal_topk_lds_kernel, dim3(d->B * d->G), dim3(256), lds, s, a);
+    }
     Y6_LAUNCH_CHECK();
     const unsigned nb = (unsigned)((nba + 255) / 256);
     hipLaunchKernelGGL(tal_resolve_kernel, dim3(nb), dim3(256), 0, s, a);
