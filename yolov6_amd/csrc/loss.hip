@@ -87,6 +87,39 @@ __global__ __launch_bounds__(256) void loss_cls_kernel(const float* __restrict__
     }
 }
 
+// Four classes per thread (C % 4 == 0, fewer than 2^32 scores, 16-byte aligned tensors): one 16-byte load per tensor, one 32-bit
+// division per four elements (the per-element form divides a 64-bit index by C 43 M times per b64 step), and log(p) only where
+// the target score is not zero - `q * lp` is an exact (signed) zero for q == 0 because lp is clamped to [-100, 0], so every term
+// has the value the per-element kernel gives it.
+__global__ __launch_bounds__(256) void loss_cls4_kernel(const float4* __restrict__ pred, const float4* __restrict__ tscore,
+                                                        const int64_t* __restrict__ tlabel, const uint8_t* __restrict__ fg,
+                                                        unsigned total4, unsigned C, double* __restrict__ acc) {
+    __shared__ double sh[4];
+    double s_cls = 0.0, s_ts = 0.0;
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < total4; v += gridDim.x * blockDim.x) {
+        const float4 p4 = pred[v], q4 = tscore[v];
+        const unsigned i0 = v * 4u, ba = i0 / C, c0 = i0 - ba * C;
+        const int lab = fg[ba] ? (int)tlabel[ba] : -1;
+        const float pp[4] = {p4.x, p4.y, p4.z, p4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p = pp[j], q = qq[j];
+            const float y = (lab == (int)(c0 + j)) ? 1.f : 0.f;
+            const float weight = 0.75f * (p * p) * (1.f - y) + q * y;
+            const float lp = q != 0.f ? fmaxf(logf(p), -100.f) : -1.f, l1p = fmaxf(logf(1.f - p), -100.f);
+            const float bce = -(q * lp + (1.f - q) * l1p);
+            s_cls += (double)(bce * weight);
+            s_ts += (double)q;
+        }
+    }
+    const double a = block_sum(s_cls, sh);
+    const double b = block_sum(s_ts, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[0], a);
+        atomicAdd(&acc[1], b);
+    }
+}
+
 __device__ __forceinline__ float iou_loss_xyxy(const float4 b1, const float4 b2, int type) {
     const float e = 1e-10f;
     const float iw = fmaxf(fminf(b1.z, b2.z) - fmaxf(b1.x, b2.x), 0.f);
@@ -328,6 +361,34 @@ __global__ __launch_bounds__(256) void loss_cls_bwd_kernel(const float* __restri
     }
 }
 
+// (four classes per thread: see loss_cls4_kernel)
+__global__ __launch_bounds__(256) void loss_cls_bwd4_kernel(const float4* __restrict__ pred, const float4* __restrict__ tscore,
+                                                            const int64_t* __restrict__ tlabel, const uint8_t* __restrict__ fg,
+                                                            unsigned total4, unsigned C, const double* __restrict__ fin, float w_class,
+                                                            const float* __restrict__ grad_scale, float4* __restrict__ dpred, int norm_mode) {
+    const double ts = fin[4];
+    const float coef = w_class * (grad_scale ? *grad_scale : 1.f) * (norm_cls(ts, norm_mode) ? (float)(1.0 / ts) : 1.f);
+    for (unsigned v = blockIdx.x * blockDim.x + threadIdx.x; v < total4; v += gridDim.x * blockDim.x) {
+        const float4 p4 = pred[v], q4 = tscore[v];
+        const unsigned i0 = v * 4u, ba = i0 / C, c0 = i0 - ba * C;
+        const int lab = fg[ba] ? (int)tlabel[ba] : -1;
+        const float pp[4] = {p4.x, p4.y, p4.z, p4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float p = pp[j], q = qq[j];
+            const float y = (lab == (int)(c0 + j)) ? 1.f : 0.f;
+            const float weight = 0.75f * (p * p) * (1.f - y) + q * y;
+            const float dweight = 0.75f * 2.f * p * (1.f - y);
+            const float lp = q != 0.f ? fmaxf(logf(p), -100.f) : -1.f, l1p = fmaxf(logf(1.f - p), -100.f);
+            const float bce = -(q * lp + (1.f - q) * l1p);
+            const float dbce = (p - q) / fmaxf((1.f - p) * p, 1e-12f);
+            o[j] = coef * (bce * dweight + weight * dbce);
+        }
+        dpred[v] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // d loss / d pred_distri through IoU loss (dual numbers) -> dist2bbox -> DFL projection, plus the DFL cross entropies
 __global__ __launch_bounds__(256) void loss_box_bwd_kernel(const float* __restrict__ pred_distri, const float* __restrict__ pred_bboxes,
                                                            const float* __restrict__ pts, const float* __restrict__ stride,
@@ -563,6 +624,15 @@ extern "C" int y6_loss_forward(const y6_loss_desc* d, void* stream) {
     const size_t n_ba = (size_t)d->B * d->A;
     size_t g = (n_ba * d->C + 255) / 256;
     if (g > 4096) g = 4096;
+    static const bool vec4 = !(getenv("Y6_LOSS_VEC4") && atoi(getenv("Y6_LOSS_VEC4")) == 0);     // A/B switch
+    const bool cls4 = vec4 && d->C % 4 == 0 && n_ba * d->C < (1ull << 32) &&
+                      (((uintptr_t)d->pred_scores | (uintptr_t)d->target_scores) & 15) == 0;
+    if (cls4) {
+        size_t g4 = (n_ba * d->C / 4 + 255) / 256;
+        if (g4 > 1024) g4 = 1024;     // (two double atomics per block on the SAME two addresses: 8 192 of them in a row were most of the launch)
+        hipLaunchKernelGGL(loss_cls4_kernel, dim3((unsigned)g4), dim3(256), 0, s, (const float4*)d->pred_scores, (const float4*)d->target_scores,
+                           d->target_labels, d->fg_mask, (unsigned)(n_ba * d->C / 4), (unsigned)d->C, acc);
+    } else
     hipLaunchKernelGGL(loss_cls_kernel, dim3((unsigned)g), dim3(256), 0, s, d->pred_scores, d->target_scores, d->target_labels,
                        d->fg_mask, n_ba, d->C, acc);
     Y6_LAUNCH_CHECK();
@@ -590,6 +660,16 @@ extern "C" int y6_loss_backward(const y6_loss_grad_desc* g, void* stream) {
     const size_t n_ba = (size_t)d->B * d->A;
     size_t gr = (n_ba * d->C + 255) / 256;
     if (gr > 8192) gr = 8192;
+    static const bool vec4 = !(getenv("Y6_LOSS_VEC4") && atoi(getenv("Y6_LOSS_VEC4")) == 0);
+    const bool cls4 = vec4 && d->C % 4 == 0 && n_ba * d->C < (1ull << 32) &&
+                      (((uintptr_t)d->pred_scores | (uintptr_t)d->target_scores | (uintptr_t)g->dpred_scores) & 15) == 0;
+    if (cls4) {
+        size_t g4 = (n_ba * d->C / 4 + 255) / 256;
+        if (g4 > 8192) g4 = 8192;
+        hipLaunchKernelGGL(loss_cls_bwd4_kernel, dim3((unsigned)g4), dim3(256), 0, s, (const float4*)d->pred_scores,
+                           (const float4*)d->target_scores, d->target_labels, d->fg_mask, (unsigned)(n_ba * d->C / 4), (unsigned)d->C,
+                           d->out, d->w_class, g->grad_scale, (float4*)g->dpred_scores, d->norm_mode);
+    } else
     hipLaunchKernelGGL(loss_cls_bwd_kernel, dim3((unsigned)gr), dim3(256), 0, s, d->pred_scores, d->target_scores, d->target_labels,
                        d->fg_mask, n_ba, d->C, d->out, d->w_class, g->grad_scale, g->dpred_scores, d->norm_mode);
     Y6_LAUNCH_CHECK();
