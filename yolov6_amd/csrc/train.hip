@@ -1419,7 +1419,7 @@ __device__ __forceinline__ void pack_one_element(const y6_pack_job* __restrict__
 // was 37 M threads-iterations with a binary search each: 0.32 ms per training step at 0.8 TB/s).  Groups that are not a whole run of
 // a conv / convT job (the fp32 centre-tap image of kind 4, the un-fused ConvTranspose2d image, a job boundary) take the
 // per-element code.
-__global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t total) {
+__global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __restrict__ jobs, int njobs, uint64_t total, int pack_tap_fastest) {
     const uint64_t groups = (total + 7) >> 3;
     for (uint64_t g8 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g8 < groups; g8 += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i = g8 << 3;
@@ -1443,10 +1443,27 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
         if (jb.kind == 3) { O = jb.Cin; I = 4 * jb.Cout; }
         const int nchunk = (I + 31) / 32;
         const int nt = (jb.kind >= 2) ? 1 : NT;
-        const int lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
-        uint64_t r = e >> 10;
-        const int tap = (int)(r % nt);
-        r /= nt;
+        // Which 16-byte run of the packed image this thread makes.  For the nine-tap jobs the tap runs FASTEST over the threads
+        // (a permutation of the job's runs): the nine taps of a (cout, cin) pair are 36 consecutive bytes of the OIHW source, so
+        // neighbouring threads now read the same cache lines - in packed order (tap above lane and k-step) every line of the
+        // source went through nine different waves (0.155 ms per training step for 150 MB of algorithmic traffic).
+        int lane, ks, tap;
+        uint64_t r, edst = e;
+        if (nt == 9 && jb.kind <= 1 && pack_tap_fastest) {
+            uint64_t q = e >> 3;
+            tap = (int)(q % 9);
+            q /= 9;
+            lane = (int)(q & 63);
+            ks = (int)((q >> 6) & 1);
+            r = q >> 7;
+            edst = (((r * 9 + (uint64_t)tap) * 2 + (uint64_t)ks) * 64 + (uint64_t)lane) * 8;
+        } else {
+            lane = (int)((e >> 3) & 63);
+            ks = (int)((e >> 9) & 1);
+            r = e >> 10;
+            tap = (int)(r % nt);
+            r /= nt;
+        }
         const int chunk = (int)(r % nchunk);
         const int cfr = (int)(r / nchunk);
         const int o = cfr * 32 + (lane & 31);
@@ -1471,13 +1488,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const y6_pack_job* __re
             }
             out[j] = (_Float16)v;
         }
-        *reinterpret_cast<h8_t*>(reinterpret_cast<__half*>(jb.dst) + e) = out;
+        *reinterpret_cast<h8_t*>(reinterpret_cast<__half*>(jb.dst) + edst) = out;
     }
 }
 
 int pack_batch_launch(const y6_pack_batch_desc* d, hipStream_t s) {
     Y6_REQUIRE(d && d->jobs && d->njobs > 0 && d->total > 0, "pack_weights_batched: bad arguments");
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(grid_for(((size_t)d->total + 7) / 8, 256, 256 * 64)), dim3(256), 0, s, d->jobs, d->njobs, d->total);
+    static const bool tap_fastest = !(getenv("Y6_PACK_TAPFAST") && atoi(getenv("Y6_PACK_TAPFAST")) == 0);     // A/B switch
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(grid_for(((size_t)d->total + 7) / 8, 256, 256 * 64)), dim3(256), 0, s, d->jobs, d->njobs, d->total, (int)tap_fastest);
     Y6_LAUNCH_CHECK();
     return Y6_OK;
 }
